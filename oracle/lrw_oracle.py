@@ -1,0 +1,247 @@
+"""ORACLE — CPU restatement (plain torch fp32) of the SyncVSR LRW training hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``syncvsr_amd/`` may import this module; only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg use it, and only as the checker /
+the timed CPU baseline ("port"), never as the product path.
+
+Parity status: PINNED.  ``tests/golden/make_golden_lrw.py`` imports the reference itself
+(``/root/reference/LRW/video/src/lightning.py`` with import stubs) in the build
+container, loads the same seeded weights, and records outputs/gradients in ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks this restatement against those vectors to ~1e-5.
+
+Third-party arithmetic that is not in the reference tree:
+  * timm ``resnet18`` (unpinned, ``LRW/video/setup.sh:35``)  -> restated from the topology-identical
+    in-tree classes ``LRW/video/src/tcn/models/resnet.py:28-72`` (relu) — the golden generator
+    instantiates exactly that class in place of timm.
+  * HF ``transformers.BertModel`` (unpinned; 5.15.0 in the build container) -> restated below from
+    its published post-LN algorithm; the golden generator runs the real ``BertModel``.
+  * x-transformers 1.9.2 ``Encoder`` is NOT covered (not importable; parity unpinned).
+
+Every function cites the reference lines it follows.  All maths is fp32 on CPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = dict[str, Tensor]
+
+BN_EPS = 1e-5       # torch default, never overridden by the reference (lightning.py:51)
+BN_MOMENTUM = 0.1
+
+
+# --------------------------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------------------------
+def batch_norm(x: Tensor, sd: SD, prefix: str, training: bool, stats_out: dict | None = None) -> Tensor:
+    """BatchNorm{2d,3d} over all non-channel dims (channel = dim 1).  SURVEY App. A.1.
+
+    training: biased batch variance for normalisation; running stats updated with momentum 0.1 and the
+    *unbiased* variance.  eval: running statistics.
+    """
+    w, b = sd[f"{prefix}.weight"], sd[f"{prefix}.bias"]
+    dims = [d for d in range(x.dim()) if d != 1]
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    if training:
+        mean = x.mean(dims)
+        var = x.var(dims, unbiased=False)
+        if stats_out is not None:
+            n = x.numel() // x.size(1)
+            rm, rv = sd[f"{prefix}.running_mean"], sd[f"{prefix}.running_var"]
+            stats_out[f"{prefix}.running_mean"] = ((1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean).detach()
+            stats_out[f"{prefix}.running_var"] = ((1 - BN_MOMENTUM) * rv + BN_MOMENTUM * var * n / max(n - 1, 1)).detach()
+            stats_out[f"{prefix}.num_batches_tracked"] = sd[f"{prefix}.num_batches_tracked"] + 1
+    else:
+        mean, var = sd[f"{prefix}.running_mean"], sd[f"{prefix}.running_var"]
+    xhat = (x - mean.view(shape)) * torch.rsqrt(var.view(shape) + BN_EPS)
+    return xhat * w.view(shape) + b.view(shape)
+
+
+def gelu_erf(x: Tensor) -> Tensor:
+    """nn.GELU() exact form (lightning.py:52)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+# --------------------------------------------------------------------------------------------
+# visual front-end  (lightning.py:49-55, 112-119)
+# --------------------------------------------------------------------------------------------
+def stem3d(videos: Tensor, sd: SD, training: bool, stats_out: dict | None = None, keep: dict | None = None) -> Tensor:
+    """Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) -> BatchNorm3d -> GELU -> MaxPool3d((1,3,3),(1,2,2),(0,1,1))."""
+    x = F.conv3d(videos, sd["stem3d.0.weight"], None, stride=(1, 2, 2), padding=(2, 3, 3))
+    if keep is not None:
+        keep["stem_conv"] = x
+    x = batch_norm(x, sd, "stem3d.1", training, stats_out)
+    x = gelu_erf(x)
+    x = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    return x
+
+
+def basic_block(x: Tensor, sd: SD, prefix: str, stride: int, training: bool, stats_out: dict | None = None) -> Tensor:
+    """tcn/models/resnet.py:59-72 with relu_type='relu' (== timm BasicBlock)."""
+    out = F.conv2d(x, sd[f"{prefix}.conv1.weight"], None, stride=stride, padding=1)
+    out = torch.relu(batch_norm(out, sd, f"{prefix}.bn1", training, stats_out))
+    out = F.conv2d(out, sd[f"{prefix}.conv2.weight"], None, stride=1, padding=1)
+    out = batch_norm(out, sd, f"{prefix}.bn2", training, stats_out)
+    if f"{prefix}.downsample.0.weight" in sd:
+        res = F.conv2d(x, sd[f"{prefix}.downsample.0.weight"], None, stride=stride)
+        res = batch_norm(res, sd, f"{prefix}.downsample.1", training, stats_out)
+    else:
+        res = x
+    return torch.relu(out + res)
+
+
+def forward_videos(videos: Tensor, sd: SD, training: bool, stats_out: dict | None = None, keep: dict | None = None) -> Tensor:
+    """lightning.py:112-119: stem -> (B*T) frames -> layer1..4 -> spatial mean -> [B,T,512]."""
+    B = videos.size(0)
+    h = stem3d(videos, sd, training, stats_out, keep).transpose(1, 2).flatten(0, 1)
+    if keep is not None:
+        keep["stem_out"] = h
+    for li in range(1, 5):
+        for bi in range(2):
+            stride = 2 if (bi == 0 and li > 1) else 1
+            h = basic_block(h, sd, f"resnet.layer{li}.{bi}", stride, training, stats_out)
+        if keep is not None:
+            keep[f"layer{li}"] = h
+    return h.mean((2, 3)).unflatten(0, (B, -1))
+
+
+# --------------------------------------------------------------------------------------------
+# BERT-style encoder  (lightning.py:92,152-156; HF BertModel(inputs_embeds=...))
+# --------------------------------------------------------------------------------------------
+def bert_embeddings(x: Tensor, sd: SD, eps: float) -> Tensor:
+    S = x.size(1)
+    e = x + sd["encoder.embeddings.position_embeddings.weight"][:S] + sd["encoder.embeddings.token_type_embeddings.weight"][0]
+    return layer_norm(e, sd["encoder.embeddings.LayerNorm.weight"], sd["encoder.embeddings.LayerNorm.bias"], eps)
+
+
+def bert_layer(x: Tensor, sd: SD, p: str, heads: int, eps: float, keep: dict | None = None) -> Tensor:
+    B, S, D = x.shape
+    dh = D // heads
+
+    def lin(t: Tensor, name: str) -> Tensor:
+        return F.linear(t, sd[f"{p}.{name}.weight"], sd[f"{p}.{name}.bias"])
+
+    q = lin(x, "attention.self.query").view(B, S, heads, dh).transpose(1, 2)
+    k = lin(x, "attention.self.key").view(B, S, heads, dh).transpose(1, 2)
+    v = lin(x, "attention.self.value").view(B, S, heads, dh).transpose(1, 2)
+    scores = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    probs = torch.softmax(scores, dim=-1)
+    ctx = (probs @ v).transpose(1, 2).reshape(B, S, D)
+    if keep is not None:
+        keep[f"{p}.ctx"] = ctx
+    x = layer_norm(lin(ctx, "attention.output.dense") + x, sd[f"{p}.attention.output.LayerNorm.weight"],
+                   sd[f"{p}.attention.output.LayerNorm.bias"], eps)
+    h = gelu_erf(lin(x, "intermediate.dense"))
+    x = layer_norm(lin(h, "output.dense") + x, sd[f"{p}.output.LayerNorm.weight"], sd[f"{p}.output.LayerNorm.bias"], eps)
+    return x
+
+
+def bert_encoder(x: Tensor, sd: SD, cfg: Any, keep: dict | None = None) -> Tensor:
+    bert = cfg.model.bert
+    eps = float(bert.get("layer_norm_eps", 1e-12))
+    x = bert_embeddings(x, sd, eps)
+    if keep is not None:
+        keep["emb"] = x
+    for i in range(int(bert.num_hidden_layers)):
+        x = bert_layer(x, sd, f"encoder.encoder.layer.{i}", int(bert.num_attention_heads), eps, keep)
+    return x
+
+
+# --------------------------------------------------------------------------------------------
+# heads + losses (lightning.py:161-191)
+# --------------------------------------------------------------------------------------------
+def cross_entropy(logits: Tensor, target: Tensor, label_smoothing: float = 0.0) -> Tensor:
+    """F.cross_entropy restated: class-index or probability targets, mean reduction."""
+    logp = torch.log_softmax(logits.float(), dim=-1)
+    C = logits.size(-1)
+    if target.dtype in (torch.long, torch.int32, torch.int64):
+        nll = -logp.gather(-1, target.long().unsqueeze(-1)).squeeze(-1)
+        smooth = -logp.mean(-1)
+        return ((1.0 - label_smoothing) * nll + label_smoothing * smooth).mean()
+    t = target.float() * (1.0 - label_smoothing) + label_smoothing / C
+    return (-(t * logp).sum(-1)).mean()
+
+
+def audio_dims(cfg: Any) -> tuple[int, int, int]:
+    path = cfg.model.wav2vec.path
+    if "vq" in path:
+        return 4, 2, 320
+    return 2, 2, 640
+
+
+def forward(sd: SD, cfg: Any, videos: Tensor, audio_tokens: Tensor, labels: Tensor, word_mask: Tensor,
+            training: bool = True, use_cutmix_metric: bool = False, keep: dict | None = None,
+            stats_out: dict | None = None) -> dict[str, Tensor]:
+    """TransformerLightningModule.forward (lightning.py:133-191) with dropout p = 0."""
+    A, G, V = audio_dims(cfg)
+    feats = forward_videos(videos, sd, training, stats_out, keep)                      # :136
+    if keep is not None:
+        keep["feats"] = feats
+    if cfg.data.use_word_boundary:                                                       # :145
+        feats = torch.cat((feats, word_mask.unsqueeze(-1).to(feats.dtype)), dim=-1)
+    B, T, D = feats.shape
+    audio_tokens = audio_tokens[:, : T * A]                                              # :148
+    x = torch.cat((sd["cls_token"].expand(B, -1, -1), feats), dim=1)                     # :149-150
+    h = bert_encoder(x, sd, cfg, keep)                                                   # :152-156
+    logits_category = F.linear(h[:, 0], sd["category_classifier.weight"], sd["category_classifier.bias"]).float()
+    loss_category = cross_entropy(logits_category, labels, float(cfg.train.label_smoothing))     # :161-165
+    logits_audio = F.linear(h[:, 1:], sd["audio_projection.weight"], sd["audio_projection.bias"]).float()
+    logits_audio = logits_audio.reshape(B, T, A * G, V)                                  # :168-170
+    loss_audio = cross_entropy(logits_audio.reshape(-1, V), audio_tokens.flatten())      # :171
+    loss_total = loss_category + loss_audio * float(cfg.optim.lambda_audio)              # :174
+    hard = labels.argmax(-1) if (labels.dim() == 2 and (use_cutmix_metric or labels.dtype.is_floating_point)) else labels
+    corrects = logits_category.topk(5, dim=1)[1] == hard.unsqueeze(1)                    # :177-181
+    if keep is not None:
+        keep["hidden"] = h
+        keep["logits_category"] = logits_category
+        keep["logits_audio"] = logits_audio
+    return {
+        "loss_total": loss_total,
+        "loss_category": loss_category,
+        "loss_audio": loss_audio,
+        "accuracy_top1": corrects[:, 0].float().mean(),
+        "accuracy_top5": corrects.float().amax(1).mean(),
+    }
+
+
+# --------------------------------------------------------------------------------------------
+# optimiser step restated (lightning.py:216-223) — used by the CPU baseline leg
+# --------------------------------------------------------------------------------------------
+def clip_grad_norm(grads: list[Tensor], max_norm: float) -> Tensor:
+    total = torch.sqrt(sum((g.float() ** 2).sum() for g in grads))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return total
+
+
+def adamw_step(params: list[Tensor], grads: list[Tensor], m: list[Tensor], v: list[Tensor], step: int, lr: float,
+               betas: tuple[float, float], eps: float, weight_decay: float) -> None:
+    """torch.optim.AdamW semantics; weight decay only on ndim>=2 params (lightning.py:217-219)."""
+    b1, b2 = betas
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    for p, g, mi, vi in zip(params, grads, m, v):
+        wd = weight_decay if p.dim() >= 2 else 0.0
+        p.mul_(1 - lr * wd)
+        mi.mul_(b1).add_(g, alpha=1 - b1)
+        vi.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (vi.sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(mi, denom, value=-lr / bc1)
+
+
+def cosine_lr(step: int, base_lr: float, warmup: int, total: int) -> float:
+    """HF get_scheduler('cosine') multiplier (train config :38-41)."""
+    if step < warmup:
+        return base_lr * step / max(1, warmup)
+    prog = (step - warmup) / max(1, total - warmup)
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))

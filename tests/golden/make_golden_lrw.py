@@ -1,0 +1,159 @@
+"""Golden-vector generator for the LRW hot path.  RUNS ONLY IN THE BUILD CONTAINER.
+
+Imports the reference implementation itself (``/root/reference/LRW/video/src/lightning.py``) with the
+import stubs of SURVEY.md Appendix C (pytorch_lightning / omegaconf / x_transformers / timm are not
+installed; ``timm.create_model`` is mapped to the reference's own in-tree ResNet18,
+``tcn/models/resnet.py``), loads weights produced by ``syncvsr_amd.init.init_state_dict`` and records
+outputs and gradients as small ``.npz`` fixtures next to this file.  Weights are never stored: the tests
+re-create them from the seed.  Nothing of the reference's source is copied — only numbers it computes.
+
+    python tests/golden/make_golden_lrw.py
+"""
+from __future__ import annotations
+
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import transformers  # noqa: F401  (must be imported before the stubs, SURVEY App. C pitfall 1)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/LRW/video/src"
+
+from syncvsr_amd.config import default_lrw_config  # noqa: E402
+from syncvsr_amd.init import init_state_dict, param_specs, synthetic_batch  # noqa: E402
+
+
+def _stub(name: str, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    from tcn.models.resnet import BasicBlock, ResNet  # the reference's in-tree ResNet18
+
+    _stub("timm", create_model=lambda name, **k: ResNet(BasicBlock, [2, 2, 2, 2], relu_type="relu"))
+    _stub("timm.optim", create_optimizer_v2=None)
+
+    class _LM(nn.Module):
+        def log_dict(self, *a, **k):
+            pass
+
+    _stub("pytorch_lightning", LightningModule=_LM)
+    _stub("omegaconf", DictConfig=dict)
+    _stub("x_transformers", Encoder=None)
+    import lightning as ref  # /root/reference/LRW/video/src/lightning.py
+
+    return ref
+
+
+CASES = {
+    # name: (config overrides, batch kwargs, weight seed, data seed, perturb_norm, training)
+    "lrw_full_b2": (dict(), dict(batch=2, frames=29, size=88), 0, 1234, False, True),
+    "lrw_tiny": (dict(model__bert__num_hidden_layers=2), dict(batch=2, frames=5, size=24), 1, 77, True, True),
+    "lrw_tiny_soft_ls": (dict(model__bert__num_hidden_layers=2, train__label_smoothing=0.1, train__use_cutmix=True),
+                         dict(batch=3, frames=4, size=24, soft_labels=True), 2, 78, True, True),
+    "lrw_tiny_hard_ls": (dict(model__bert__num_hidden_layers=1, train__label_smoothing=0.1),
+                         dict(batch=2, frames=3, size=16), 3, 79, True, True),
+    # NOTE: use_word_boundary=True cannot be combined with the `type: huggingface` encoder in the reference
+    # (BertConfig.hidden_size stays 512 while the features become 513-wide, lightning.py:92,145), so there is
+    # no word-boundary golden for this encoder branch.
+    "lrw_tiny_eval": (dict(model__bert__num_hidden_layers=2), dict(batch=2, frames=5, size=24), 1, 77, True, False),
+}
+
+
+def run_case(ref, name: str) -> dict[str, np.ndarray]:
+    over, bkw, wseed, dseed, perturb, training = CASES[name]
+    cfg = default_lrw_config(**over)
+    sd = init_state_dict(cfg, seed=wseed, perturb_norm=perturb)
+    if not training:  # non-trivial running statistics for the eval case
+        g = torch.Generator().manual_seed(5)
+        for k in list(sd):
+            if k.endswith("running_mean"):
+                sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+            elif k.endswith("running_var"):
+                sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+    batch = synthetic_batch(cfg, seed=dseed, **bkw)
+
+    torch.manual_seed(0)
+    model = ref.TransformerLightningModule(cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("word_embeddings" in k or "pooler" in k) for k in missing), missing
+    model.train(training)
+
+    keep: dict[str, torch.Tensor] = {}
+
+    def hook(key):
+        def f(_m, _i, o):
+            keep[key] = (o.last_hidden_state if hasattr(o, "last_hidden_state") else o).detach()
+        return f
+
+    model.stem3d.register_forward_hook(hook("stem_out"))
+    model.stem3d[0].register_forward_hook(hook("stem_conv"))
+    for li in range(1, 5):
+        getattr(model.resnet, f"layer{li}").register_forward_hook(hook(f"layer{li}"))
+    model.encoder.register_forward_hook(hook("hidden"))
+    model.encoder.embeddings.register_forward_hook(hook("emb"))
+    model.category_classifier.register_forward_hook(hook("logits_category"))
+    model.audio_projection.register_forward_hook(hook("logits_audio"))
+
+    out = model(*batch)
+    model.zero_grad()
+    if training:
+        out["loss_total"].backward()
+
+    res: dict[str, np.ndarray] = {k: np.float64(v.item()) for k, v in out.items()}
+    small = name != "lrw_full_b2"
+    for k, v in keep.items():
+        v = v.float()
+        res[f"sum.{k}"] = np.float64(v.double().sum().item())
+        res[f"abssum.{k}"] = np.float64(v.double().abs().sum().item())
+        flat = v.flatten()
+        idx = torch.linspace(0, flat.numel() - 1, 16).long()
+        res[f"sample.{k}"] = flat[idx].numpy()
+        if small and v.numel() <= 40000:
+            res[f"full.{k}"] = v.numpy()
+    if training:
+        names = [n for n, _, _ in param_specs(cfg)]
+        params = dict(model.named_parameters())
+        res["grad_names"] = np.array(names)
+        res["grad_norms"] = np.array([params[n].grad.double().norm().item() for n in names])
+        res["grad_heads"] = np.stack([
+            np.pad(params[n].grad.flatten()[:32].numpy(), (0, max(0, 32 - params[n].numel()))) for n in names])
+        if small:
+            for n in ("stem3d.0.weight", "stem3d.1.weight", "stem3d.1.bias", "cls_token", "category_classifier.bias",
+                      "resnet.layer1.0.bn1.weight", "resnet.layer4.1.bn2.bias",
+                      "encoder.encoder.layer.0.attention.self.query.bias",
+                      "encoder.embeddings.LayerNorm.weight"):
+                res[f"grad.{n}"] = params[n].grad.numpy()
+        for n in ("stem3d.1", "resnet.layer1.0.bn1", "resnet.layer2.0.downsample.1", "resnet.layer4.1.bn2"):
+            mod = model.get_submodule(n)
+            res[f"buf.{n}.running_mean"] = mod.running_mean.numpy().copy()
+            res[f"buf.{n}.running_var"] = mod.running_var.numpy().copy()
+            res[f"buf.{n}.num_batches_tracked"] = np.int64(mod.num_batches_tracked.item())
+    return res
+
+
+def main() -> None:
+    ref = import_reference()
+    torch.set_num_threads(8)
+    for name in CASES:
+        res = run_case(ref, name)
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **res)
+        print(f"{name}: loss_total={float(res['loss_total']):.6f} loss_category={float(res['loss_category']):.6f} "
+              f"loss_audio={float(res['loss_audio']):.6f}  -> {path} ({os.path.getsize(path)/1024:.0f} KB)")
+
+
+if __name__ == "__main__":
+    main()
