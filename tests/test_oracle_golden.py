@@ -9,9 +9,11 @@ from oracle import lrw_oracle as O
 SCALARS = ("loss_total", "loss_category", "loss_audio", "accuracy_top1", "accuracy_top5")
 
 
-def _run_oracle(name):
+def _run_oracle(name, dtype=torch.float64):
     cfg, sd, batch, training, gold = build_case(name)
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    batch = tuple(t.to(dtype) if t.is_floating_point() else t for t in batch)
     keep, stats = {}, {}
     out = O.forward(sd, cfg, *batch, training=training, keep=keep, stats_out=stats,
                     use_cutmix_metric=bool(cfg.train.use_cutmix) and training)
@@ -25,7 +27,7 @@ def test_oracle_matches_reference(name):
     torch.set_num_threads(8)
     cfg, sd, out, keep, stats, gold, training = _run_oracle(name)
     for k in SCALARS:
-        assert abs(out[k].item() - float(gold[k])) <= 2e-5 * max(1.0, abs(float(gold[k]))), k
+        assert abs(out[k].item() - float(gold[k])) <= 1e-6 * max(1.0, abs(float(gold[k]))), k
     for key in ("stem_conv", "stem_out", "layer1", "layer4", "emb", "hidden", "logits_category", "logits_audio"):
         v = keep[key].detach().float()
         if key == "stem_out":  # golden hooks the nn.Sequential output [B,64,T,h,w]; oracle keeps the frame-major view
@@ -34,24 +36,33 @@ def test_oracle_matches_reference(name):
         if key == "logits_audio":
             v = v.reshape(v.shape[0], v.shape[1], -1)
         ref_sum, ref_abs = float(gold[f"sum.{key}"]), float(gold[f"abssum.{key}"])
-        assert abs(v.double().abs().sum().item() - ref_abs) <= 2e-5 * ref_abs + 1e-6, key
-        assert abs(v.double().sum().item() - ref_sum) <= 2e-5 * ref_abs + 1e-6, key
+        assert abs(v.double().abs().sum().item() - ref_abs) <= 1e-6 * ref_abs + 1e-7, key
+        assert abs(v.double().sum().item() - ref_sum) <= 1e-6 * ref_abs + 1e-7, key
         flat = v.flatten()
         idx = torch.linspace(0, flat.numel() - 1, 16).long()
-        np.testing.assert_allclose(flat[idx].numpy(), gold[f"sample.{key}"], rtol=2e-4, atol=2e-5, err_msg=key)
+        np.testing.assert_allclose(flat[idx].double().numpy(), gold[f"sample.{key}"], rtol=1e-5, atol=1e-6, err_msg=key)
         if f"full.{key}" in gold:
-            np.testing.assert_allclose(v.numpy(), gold[f"full.{key}"], rtol=2e-4, atol=3e-5, err_msg=key)
+            np.testing.assert_allclose(v.numpy(), gold[f"full.{key}"], rtol=1e-5, atol=1e-6, err_msg=key)
     if training:
         names = [str(n) for n in gold["grad_names"]]
         norms = np.array([sd[n].grad.double().norm().item() for n in names])
-        np.testing.assert_allclose(norms, gold["grad_norms"], rtol=2e-3, atol=1e-7)  # fp32 BN-backward reassociation noise
+        np.testing.assert_allclose(norms, gold["grad_norms"], rtol=1e-5, atol=1e-9)
         heads = np.stack([np.pad(sd[n].grad.flatten()[:32].numpy(), (0, max(0, 32 - sd[n].numel()))) for n in names])
         scale = gold["grad_norms"][:, None] / np.sqrt(np.array([sd[n].numel() for n in names]))[:, None]
-        assert np.all(np.abs(heads - gold["grad_heads"]) <= 6e-2 * scale + 1e-7)  # key.bias grads are analytically 0
+        assert np.all(np.abs(heads - gold["grad_heads"]) <= 1e-4 * scale + 1e-9)  # key.bias grads are analytically 0
         for k in gold.files:
             if k.startswith("grad.") and k not in ("grad_names", "grad_norms", "grad_heads"):
                 g = sd[k[5:]].grad.numpy()
-                np.testing.assert_allclose(g, gold[k], rtol=1e-3, atol=1e-5 * max(1e-3, float(np.abs(gold[k]).max())), err_msg=k)
+                np.testing.assert_allclose(g, gold[k], rtol=1e-4, atol=1e-6 * max(1e-3, float(np.abs(gold[k]).max())), err_msg=k)
             if k.startswith("buf."):
                 got = stats[k[4:]]
                 np.testing.assert_allclose(np.asarray(got, dtype=np.float64), np.asarray(gold[k], dtype=np.float64), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["lrw_full_b2", "lrw_tiny"])
+def test_oracle_fp32_losses(name):
+    """The fp32 oracle (what the CPU baseline leg times and what GPU parity is judged against) agrees with
+    the fp64 reference goldens on every returned scalar to 2e-5 relative."""
+    cfg, sd, out, keep, stats, gold, training = _run_oracle(name, torch.float32)
+    for k in SCALARS:
+        assert abs(out[k].item() - float(gold[k])) <= 2e-5 * max(1.0, abs(float(gold[k]))), k
