@@ -1,0 +1,129 @@
+/* libsyncvsr_hip.so — C ABI of the MI355X (gfx950) SyncVSR training hot path.
+ *
+ * The reference (KAIST-AILab/SyncVSR) has no native/FFI layer: its hot path is reached through torch.nn modules
+ * (SURVEY.md §8b).  Each entry point below therefore names the reference *module call* it replaces.
+ *
+ * Conventions (all entry points):
+ *   - arguments are raw device pointers + explicit sizes; `void*` activations are bf16 unless stated; parameters,
+ *     statistics and gradients are fp32.  The caller owns every buffer, including workspaces.
+ *   - asynchronous: work is enqueued on `stream`; the call returns 0, SVSR_ERR_ARG (1001) for an unsupported
+ *     shape/argument, or a hipError_t value if the launch failed.  Nothing throws; no global mutable state.
+ *   - activations are NHWC ("pixels x channels"); a frame index is just the leading pixel index.
+ *
+ * The declarations are kept one per statement in a regular form because syncvsr_amd/_lib.py derives its ctypes
+ * signatures from this file.
+ */
+#ifndef SYNCVSR_HIP_H
+#define SYNCVSR_HIP_H
+
+#include <stdint.h>
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef void* hipStream_t;
+#else
+#include <hip/hip_runtime_api.h>
+#endif
+
+#define SVSR_OK 0
+#define SVSR_ERR_ARG 1001
+#define SVSR_STAT_SLOTS 64
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- implicit-GEMM contractions (igemm.hip) ------------------------------------------------------------------
+ * Iteration space: M = Nimg*Ha*Wa positions (n,a,b); source pixel (a*S+dy[t], b*S+dx[t]) of `in` [Nimg][Hi][Wi]
+ * (pitch in_pitch, Ci channels per tap, zero outside the grid); target pixel (a*OS+oy0, b*OS+ox0) of `out`
+ * [Nimg][Ho][Wo] (pitch out_pitch, Co channels).  wt: bf16 [Co][wt_taps][Ci]; tap t uses weight tap tw[t].
+ * dy/dx/tw are HOST arrays of ntaps ints.
+ *
+ * svsr_igemm_fwd replaces: nn.Conv2d forward of resnet.layer{1..4} (reference LRW/video/src/tcn/models/resnet.py:8-16,
+ *   59-72 / timm resnet18 via lightning.py:55,114-117), their input-gradient (autograd), and every nn.Linear forward /
+ *   input-gradient of the BERT encoder and heads (lightning.py:92,107,82,161,168).  Optional epilogues: +bias, +addend
+ *   (bf16 pixels laid out like `out`: residual-gradient merge; may alias `out`), exact
+ *   GELU (with the pre-activation saved to out_pre), fp32 output, per-channel BatchNorm partial sums into
+ *   stats[SVSR_STAT_SLOTS][2][Co] (accumulated with atomics; zeroed by svsr_bn_finalize). */
+int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int gelu, int out_f32, hipStream_t stream);
+
+/* svsr_igemm_wgrad replaces: the weight-gradient of the same Conv2d / Linear layers (torch autograd).
+ * dw fp32 [Co][wt_taps][Ci] is ACCUMULATED (atomics).  x = forward input pixels, dyp = output-gradient pixels. */
+int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int use_tr, hipStream_t stream);
+
+/* ---- 3-D stem (stem.hip) --------------------------------------------------------------------------------------
+ * svsr_stem_conv_fwd replaces stem3d[0] = nn.Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3),bias=False) (lightning.py:50).
+ * vid fp32 [B][1][T][H][W]; w fp32 [64][1][5][7][7]; out bf16 [B*T][H/2][W/2][64]; stats as above (64 channels). */
+int svsr_stem_conv_fwd(const float* vid, const float* w, void* out, float* stats, int B, int T, int H, int W, hipStream_t stream);
+
+/* weight gradient of the stem conv (autograd of lightning.py:50); dw fp32 [64][245] accumulated. */
+int svsr_stem_conv_wgrad(const float* vid, const void* dy, float* dw, int B, int T, int H, int W, int use_tr, hipStream_t stream);
+
+/* ---- BatchNorm / activation / pooling passes (norm_act.hip) ---------------------------------------------------
+ * svsr_bn_finalize: train-mode statistics of nn.BatchNorm2d/3d (lightning.py:51; resnet.py:37,54,14): reduces the
+ * slots, writes mean/rstd, updates running_mean/var (momentum, unbiased var) and num_batches_tracked, zeroes slots. */
+int svsr_bn_finalize(float* slots, int C, float count, float eps, float momentum, float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, hipStream_t stream);
+
+/* eval-mode statistics: mean = running_mean, rstd = rsqrt(running_var + eps). */
+int svsr_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd, hipStream_t stream);
+
+/* y = act(gamma*(x-mean)*rstd + beta [+ res]); act 0 none, 1 ReLU.  Replaces bn1/relu1, bn2/+residual/relu2 and the
+ * downsample BatchNorm of BasicBlock.forward (resnet.py:59-72). */
+int svsr_bn_act_fwd(const void* x, const void* res, void* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int64_t npix, int C, int act, hipStream_t stream);
+
+/* backward of the above: dgamma/dbeta accumulated; dx (grad of the conv output) and optional dres (= masked dy).
+ * slots [SVSR_STAT_SLOTS][2][C] zeroed workspace (left zeroed); coef [3][C] scratch. */
+int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, float* slots, float* coef, float* dgamma, float* dbeta, void* dx, void* dres, int64_t npix, int C, int act, hipStream_t stream);
+
+/* stem3d[1..3]: BatchNorm3d -> nn.GELU() (exact) -> MaxPool3d((1,3,3),(1,2,2),(0,1,1)) fused (lightning.py:51-53).
+ * x [N][Hc][Wc][C] -> y [N][Hp][Wp][C], amax uint8 [N][Hp][Wp][C] = window-local argmax (first max wins). */
+int svsr_stem_bn_gelu_pool_fwd(const void* x, void* y, void* amax, const float* mean, const float* rstd, const float* gamma, const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, hipStream_t stream);
+
+/* backward of the fused stem pass: dx = gradient of the stem conv output. */
+int svsr_stem_bn_gelu_pool_bwd(const void* dpool, const void* amax, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* slots, float* coef, float* dgamma, float* dbeta, void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, hipStream_t stream);
+
+/* hidden.mean((2,3)) (lightning.py:118) and its backward: [N][HW][C] <-> [N][C]. */
+int svsr_avgpool_fwd(const void* x, void* y, int64_t N, int HW, int C, hipStream_t stream);
+int svsr_avgpool_bwd(const void* dy, void* dx, int64_t N, int HW, int C, hipStream_t stream);
+
+/* ---- transformer encoder passes (bert.hip) --------------------------------------------------------------------
+ * y = LayerNorm(a + r) (BertSelfOutput / BertOutput, reached from lightning.py:152-156); r may be null. */
+int svsr_add_ln_fwd(const void* a, const void* r, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int R, int D, float eps, hipStream_t stream);
+int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd, void* ds, float* dgamma, float* dbeta, int R, int D, hipStream_t stream);
+
+/* BertEmbeddings on inputs_embeds = cat(cls_token, feats) (lightning.py:149-156): y = LN(e + pos[s] + type[0]).
+ * feats bf16 [B][S-1][D]; sum_out bf16 [B*S][D] keeps the pre-norm sum for the backward. */
+int svsr_embed_ln_fwd(const void* feats, const float* cls, const float* pos, const float* type0, const float* gamma, const float* beta, void* sum_out, void* y, float* mean, float* rstd, int B, int S, int D, float eps, hipStream_t stream);
+int svsr_embed_bwd_scatter(const void* ds, void* dfeats, float* dcls, float* dpos, float* dtype0, int B, int S, int D, hipStream_t stream);
+
+/* BertSelfAttention core for S <= 64, head dim 64: qkv bf16 [B*S][3*H*64] (q|k|v), ctx bf16 [B*S][H*64],
+ * probs bf16 [B*H][S][S] (saved softmax). */
+int svsr_attn_fwd(const void* qkv, void* ctx, void* probs, int B, int S, int H, int dh, float scale, hipStream_t stream);
+int svsr_attn_bwd(const void* dctx, const void* qkv, const void* probs, void* dqkv, int B, int S, int H, int dh, float scale, hipStream_t stream);
+
+/* dz = dy * gelu'(z) when z != null (BertIntermediate), db[n] += column sums (bias gradient of any nn.Linear). */
+int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, hipStream_t stream);
+
+/* ---- losses / metric / optimiser (loss_optim.hip) --------------------------------------------------------------
+ * F.cross_entropy(logits.float(), target, label_smoothing) mean over R rows (lightning.py:163-165,171): exactly one of
+ * target_idx (int64 [R]) / target_prob (fp32 [R][V], pitch ldt) is non-null.  loss_sum += mean loss (zero it first). */
+int svsr_ce_fwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt, int R, int V, float smoothing, float* loss_sum, float* lse, hipStream_t stream);
+int svsr_ce_bwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt, int R, int V, float smoothing, const float* lse, const float* gout, void* dlogits, int ldo, hipStream_t stream);
+
+/* top-1 / top-5 accuracy (lightning.py:177-183); out2 += {top1, top5} (zero it first). */
+int svsr_topk_acc(const float* logits, const int64_t* labels, const float* soft_labels, int B, int C, float* out2, hipStream_t stream);
+
+/* clip_grad_norm_ + AdamW + HF cosine-with-warm-up (lightning.py:216-223; Lightning gradient_clip_val).
+ * opt_state: 16-byte device struct {int step; float sumsq; float lr_last; float gnorm_last}, zero-initialised. */
+int svsr_grad_sumsq(const float* g, int64_t n, void* opt_state, hipStream_t stream);
+int svsr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, int64_t decay_end, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, int warmup, int total_steps, void* opt_state, hipStream_t stream);
+
+/* bf16 shadows of fp32 parameters: plain cast, and a table-driven [A][T][B] -> [B][T][Apad] transpose-cast.
+ * table: device array of {int64 src_off, dst_off; int32 A, T, Bd, Apad} (elements). */
+int svsr_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
+int svsr_transpose_cast_multi(const float* src, void* dst, const void* table, int n_entries, hipStream_t stream);
+int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYNCVSR_HIP_H */

@@ -1,0 +1,290 @@
+// Cross-entropy heads, accuracy metric, and the optimiser-side passes (gfx950).
+//   * row cross-entropy with class-index or probability targets and label smoothing — the word loss and the
+//     SyncVSR audio-token loss over (B*T*A*G) rows x V classes (reference LRW/video/src/lightning.py:161-171,
+//     README.md:47-53)
+//   * top-1 / top-5 accuracy (lightning.py:177-183)
+//   * global-norm clip + AdamW + cosine schedule + bf16 shadow refresh (lightning.py:216-223)
+//   * fp32 -> bf16 shadow casts / transposes of the weights the MFMA kernels consume
+#include "common.h"
+
+// one wave per row; logits may be bf16 or f32; V <= 64*CE_MAXPER
+#define CE_MAXPER 16
+
+struct CeArgs {
+    const void* logits; int logits_f32; int ld;   // row pitch in elements
+    const long* target_idx;                        // hard targets [R] or null
+    const float* target_prob; int ldt;             // soft targets [R][V] or null
+    int R, V;
+    float smoothing;
+    float* loss_sum;       // += sum_rows loss_r / R
+    float* lse;            // [R] saved for the backward
+};
+
+__device__ __forceinline__ float ce_load(const CeArgs& a, long off) {
+    return a.logits_f32 ? reinterpret_cast<const float*>(a.logits)[off] : bf2f(reinterpret_cast<const bf16_t*>(a.logits)[off]);
+}
+
+__global__ __launch_bounds__(256) void k_ce_fwd(const CeArgs a) {
+    __shared__ float spart[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float block_loss = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < a.R; row += gridDim.x * 4) {
+        float z[CE_MAXPER];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < CE_MAXPER; ++i) {
+            const int v = i * 64 + lane;
+            z[i] = v < a.V ? ce_load(a, (long)row * a.ld + v) : -INFINITY;
+            m = fmaxf(m, z[i]);
+        }
+        m = wave_max(m);
+        float se = 0.f, sz = 0.f;
+#pragma unroll
+        for (int i = 0; i < CE_MAXPER; ++i) {
+            const int v = i * 64 + lane;
+            if (v < a.V) { se += expf(z[i] - m); sz += z[i]; }
+        }
+        se = wave_sum(se);
+        const float lse = m + logf(se);
+        float loss;
+        if (a.target_idx != nullptr) {
+            sz = wave_sum(sz);
+            const long t = a.target_idx[row];
+            const float zt = ce_load(a, (long)row * a.ld + t);
+            loss = (1.f - a.smoothing) * (lse - zt) + a.smoothing * (lse - sz / (float)a.V);
+        } else {
+            float st = 0.f, stz = 0.f;
+#pragma unroll
+            for (int i = 0; i < CE_MAXPER; ++i) {
+                const int v = i * 64 + lane;
+                if (v < a.V) {
+                    const float t = a.target_prob[(long)row * a.ldt + v] * (1.f - a.smoothing) + a.smoothing / (float)a.V;
+                    st += t; stz += t * z[i];
+                }
+            }
+            st = wave_sum(st); stz = wave_sum(stz);
+            loss = lse * st - stz;
+        }
+        if (lane == 0) { a.lse[row] = lse; block_loss += loss; }
+    }
+    if (lane == 0) spart[wave] = block_loss;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(a.loss_sum, (spart[0] + spart[1] + spart[2] + spart[3]) / (float)a.R);
+}
+
+// dlogits = gout * (softmax * sum(t') - t') / R      (bf16 out, pitch ldo)
+__global__ __launch_bounds__(256) void k_ce_bwd(const CeArgs a, const float* gout, bf16_t* dlogits, int ldo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float g = gout[0] / (float)a.R;
+    for (int row = blockIdx.x * 4 + wave; row < a.R; row += gridDim.x * 4) {
+        const float lse = a.lse[row];
+        if (a.target_idx != nullptr) {
+            const long t = a.target_idx[row];
+            for (int v = lane; v < a.V; v += 64) {
+                const float p = expf(ce_load(a, (long)row * a.ld + v) - lse);
+                const float tt = (v == t ? 1.f - a.smoothing : 0.f) + a.smoothing / (float)a.V;
+                dlogits[(long)row * ldo + v] = f2bf(g * (p - tt));
+            }
+        } else {
+            float st = 0.f;
+            for (int v = lane; v < a.V; v += 64)
+                st += a.target_prob[(long)row * a.ldt + v] * (1.f - a.smoothing) + a.smoothing / (float)a.V;
+            st = wave_sum(st);
+            for (int v = lane; v < a.V; v += 64) {
+                const float p = expf(ce_load(a, (long)row * a.ld + v) - lse);
+                const float tt = a.target_prob[(long)row * a.ldt + v] * (1.f - a.smoothing) + a.smoothing / (float)a.V;
+                dlogits[(long)row * ldo + v] = f2bf(g * (p * st - tt));
+            }
+        }
+    }
+}
+
+// top-1 / top-5 accuracy of f32 logits [B][C]; labels are class indices, or (soft) the argmax of [B][C] probabilities
+__global__ __launch_bounds__(256) void k_topk_acc(const float* __restrict__ logits, const long* __restrict__ labels,
+                                                  const float* __restrict__ soft, int B, int C, float* out2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float t1 = 0.f, t5 = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < B; row += gridDim.x * 4) {
+        long lab;
+        if (labels != nullptr) lab = labels[row];
+        else {
+            float best = -INFINITY; int bi = 0;
+            for (int v = lane; v < C; v += 64) { const float p = soft[(long)row * C + v]; if (p > best) { best = p; bi = v; } }
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            lab = bi;
+        }
+        const float zl = logits[(long)row * C + lab];
+        float cnt = 0.f;
+        for (int v = lane; v < C; v += 64) {
+            const float z = logits[(long)row * C + v];
+            if (z > zl || (z == zl && v < lab)) cnt += 1.f;
+        }
+        cnt = wave_sum(cnt);
+        t1 += cnt < 0.5f ? 1.f : 0.f;
+        t5 += cnt < 4.5f ? 1.f : 0.f;
+    }
+    if (lane == 0) { atomicAdd(out2 + 0, t1 / (float)B); atomicAdd(out2 + 1, t5 / (float)B); }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// optimiser
+// ---------------------------------------------------------------------------------------------------------
+struct OptState { int step; float sumsq; float lr_last; float gnorm_last; };   // device-resident, 16 bytes
+
+__global__ __launch_bounds__(256) void k_grad_sumsq(const float* __restrict__ g, long n, OptState* st) {
+    __shared__ float spart[4];
+    float acc = 0.f;
+    const long nv = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0)
+        for (long i = (nv << 2) + threadIdx.x; i < n; i += 256) acc += g[i] * g[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) spart[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&st->sumsq, spart[0] + spart[1] + spart[2] + spart[3]);
+}
+
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; bf16_t* shadow;
+    long n, decay_end;       // elements [0, decay_end) get weight decay (ndim >= 2 parameters)
+    float lr, beta1, beta2, eps, weight_decay, max_norm;
+    int warmup, total_steps;  // cosine schedule with linear warm-up; total_steps <= 0 -> constant lr
+    OptState* st;
+};
+
+__device__ __forceinline__ float sched_lr(const AdamArgs& a, int step /* 0-based optimiser step index */) {
+    if (a.total_steps <= 0) return a.lr;
+    if (step < a.warmup) return a.lr * (float)step / (float)max(1, a.warmup);
+    const float prog = (float)(step - a.warmup) / (float)max(1, a.total_steps - a.warmup);
+    return a.lr * fmaxf(0.f, 0.5f * (1.f + cosf(3.14159265358979323846f * prog)));
+}
+
+__global__ __launch_bounds__(256) void k_adamw(const AdamArgs a) {
+    const int step = a.st->step;             // steps already taken
+    const float gnorm = sqrtf(a.st->sumsq);
+    const float clip = a.max_norm > 0.f ? fminf(1.f, a.max_norm / (gnorm + 1e-6f)) : 1.f;
+    const float lr = sched_lr(a, step);
+    const float t = (float)(step + 1);
+    const float bc1 = 1.f - powf(a.beta1, t), bc2 = 1.f - powf(a.beta2, t);
+    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long)gridDim.x * 256) {
+        const float g = a.g[i] * clip;
+        float p = a.p[i];
+        if (i < a.decay_end) p *= 1.f - lr * a.weight_decay;
+        const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+        p -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + a.eps);
+        a.m[i] = m; a.v[i] = v; a.p[i] = p;
+        if (a.shadow != nullptr) a.shadow[i] = f2bf(p);
+    }
+}
+
+__global__ void k_opt_advance(OptState* st, float lr_base, int warmup, int total_steps) {
+    AdamArgs a; a.lr = lr_base; a.warmup = warmup; a.total_steps = total_steps;
+    st->lr_last = sched_lr(a, st->step);
+    st->gnorm_last = sqrtf(st->sumsq);
+    st->step += 1;
+    st->sumsq = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shadow casts
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = f2bf(src[i]);
+}
+
+// table entry: src fp32 [A][T][Bd] at src_off  ->  dst bf16 [Bd][T][Apad] at dst_off   (T taps kept in the middle)
+struct TransEntry { long src_off, dst_off; int A, T, Bd, Apad; };
+
+__global__ __launch_bounds__(256) void k_transpose_cast_multi(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                              const TransEntry* __restrict__ table) {
+    const TransEntry e = table[blockIdx.y];
+    const long n = (long)e.A * e.T * e.Bd;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        // i enumerates the destination [Bd][T][A]; rows are Apad long (pad columns stay zero)
+        const int a = (int)(i % e.A);
+        const long r = i / e.A;
+        const int t = (int)(r % e.T);
+        const int bd = (int)(r / e.T);
+        dst[e.dst_off + r * e.Apad + a] = f2bf(src[e.src_off + ((long)a * e.T + t) * e.Bd + bd]);
+    }
+}
+
+__global__ void k_fill_f32(float* p, long n, float v) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_video_cast(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = f2bf(src[i]);
+}
+
+static inline int grid_for(long n) { long b = (n + 255) / 256; if (b > 4096) b = 4096; if (b < 1) b = 1; return (int)b; }
+
+extern "C" {
+
+int svsr_ce_fwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt,
+                int R, int V, float smoothing, float* loss_sum, float* lse, hipStream_t stream) {
+    if (V > 64 * CE_MAXPER || V < 1 || (target_idx == nullptr) == (target_prob == nullptr)) return SVSR_ERR_ARG;
+    CeArgs a{logits, logits_f32, ld, (const long*)target_idx, target_prob, ldt, R, V, smoothing, loss_sum, lse};
+    int grid = (R + 3) / 4; if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_ce_fwd, dim3(grid), dim3(256), 0, stream, a);
+    return svsr_check_launch();
+}
+
+int svsr_ce_bwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt,
+                int R, int V, float smoothing, const float* lse, const float* gout, void* dlogits, int ldo, hipStream_t stream) {
+    if (V < 1 || (target_idx == nullptr) == (target_prob == nullptr)) return SVSR_ERR_ARG;
+    CeArgs a{logits, logits_f32, ld, (const long*)target_idx, target_prob, ldt, R, V, smoothing, nullptr, const_cast<float*>(lse)};
+    int grid = (R + 3) / 4; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_ce_bwd, dim3(grid), dim3(256), 0, stream, a, gout, (bf16_t*)dlogits, ldo);
+    return svsr_check_launch();
+}
+
+int svsr_topk_acc(const float* logits, const int64_t* labels, const float* soft_labels, int B, int C, float* out2, hipStream_t stream) {
+    if ((labels == nullptr) == (soft_labels == nullptr)) return SVSR_ERR_ARG;
+    int grid = (B + 3) / 4; if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(k_topk_acc, dim3(grid), dim3(256), 0, stream, logits, (const long*)labels, soft_labels, B, C, out2);
+    return svsr_check_launch();
+}
+
+int svsr_grad_sumsq(const float* g, int64_t n, void* opt_state, hipStream_t stream) {
+    if (((uintptr_t)g & 15) != 0) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_grad_sumsq, dim3(grid_for(n / 4)), dim3(256), 0, stream, g, (long)n, (OptState*)opt_state);
+    return svsr_check_launch();
+}
+
+int svsr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, int64_t decay_end, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, float max_norm, int warmup, int total_steps,
+                    void* opt_state, hipStream_t stream) {
+    AdamArgs a{p, g, m, v, (bf16_t*)shadow, (long)n, (long)decay_end, lr, beta1, beta2, eps, weight_decay, max_norm, warmup,
+               total_steps, (OptState*)opt_state};
+    hipLaunchKernelGGL(k_adamw, dim3(grid_for(n)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_opt_advance, dim3(1), dim3(1), 0, stream, (OptState*)opt_state, lr, warmup, total_steps);
+    return svsr_check_launch();
+}
+
+int svsr_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_cast_bf16, dim3(grid_for(n)), dim3(256), 0, stream, src, (bf16_t*)dst, (long)n);
+    return svsr_check_launch();
+}
+
+// table: device array of n_entries {int64 src_off, int64 dst_off, int32 A, T, Bd, Apad}
+int svsr_transpose_cast_multi(const float* src, void* dst, const void* table, int n_entries, hipStream_t stream) {
+    if (n_entries < 1) return SVSR_OK;
+    hipLaunchKernelGGL(k_transpose_cast_multi, dim3(64, n_entries), dim3(256), 0, stream, src, (bf16_t*)dst, (const TransEntry*)table);
+    return svsr_check_launch();
+}
+
+int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(n)), dim3(256), 0, stream, p, (long)n, v);
+    return svsr_check_launch();
+}
+
+}  // extern "C"

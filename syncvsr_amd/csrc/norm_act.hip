@@ -1,0 +1,455 @@
+// HBM-bound passes of the visual front-end on NHWC bf16 tensors (gfx950):
+//   train-mode BatchNorm statistics -> normalise + affine + (residual) + ReLU, and its backward;
+//   the stem's BatchNorm3d + exact GELU + MaxPool3d((1,3,3),(1,2,2),(0,1,1)) fused pass and its backward;
+//   the global spatial mean.
+// Replaces nn.BatchNorm3d/2d, nn.GELU, nn.ReLU, nn.MaxPool3d, the residual add and hidden.mean((2,3))
+// (reference LRW/video/src/lightning.py:49-54,118; tcn/models/resnet.py:59-72).
+// Every thread owns 8 consecutive channels (one 16-byte vector) of a pixel; per-channel parameters stay in registers.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// statistics finalisation.  slots: [SVSR_STAT_SLOTS][2][C] (sum, sum of squares) accumulated by the producing
+// conv's epilogue.  Writes mean / rstd, updates the running statistics exactly as torch does
+// (momentum 0.1, unbiased variance for the running estimate) and re-zeroes the slots for the next step.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_bn_finalize(float* slots, int C, float count, float eps, float momentum, float* mean, float* rstd,
+                              float* running_mean, float* running_var, long* num_batches_tracked) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < SVSR_STAT_SLOTS; ++k) {
+            s += (double)slots[(k * 2 + 0) * C + c];
+            q += (double)slots[(k * 2 + 1) * C + c];
+            slots[(k * 2 + 0) * C + c] = 0.f;
+            slots[(k * 2 + 1) * C + c] = 0.f;
+        }
+        const double m = s / (double)count;
+        double var = q / (double)count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean != nullptr) {
+            const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+    if (num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+}
+
+// eval mode: mean = running_mean, rstd = 1/sqrt(running_var + eps)
+__global__ void k_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { mean[c] = running_mean[c]; rstd[c] = rsqrtf(running_var[c] + eps); }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// y = act(gamma * (x - mean) * rstd + beta [+ res])         act: 0 none, 1 relu
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bn_act_fwd(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                    bf16_t* __restrict__ y, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, long nvec, int C, int act) {
+    const int cv = C >> 3;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    if (idx >= nvec) return;
+    const int c0 = (int)(idx % cv) * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = gamma[c0 + k] * rstd[c0 + k];
+        sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k];
+    }
+    for (; idx < nvec; idx += stride) {
+        float f[8];
+        unpack8(reinterpret_cast<const u32x4*>(x)[idx], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = f[k] * sc[k] + sh[k];
+        if (res != nullptr) {
+            float r[8];
+            unpack8(reinterpret_cast<const u32x4*>(res)[idx], r);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] += r[k];
+        }
+        if (act == 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k], 0.f);
+        }
+        reinterpret_cast<u32x4*>(y)[idx] = pack8(f);
+    }
+}
+
+// block-level reduction of per-thread 8-channel partials into the atomic slots
+__device__ __forceinline__ void reduce_to_slots(float* sred, const float* s1, const float* s2, int cv, int c0, int C,
+                                                float* slots) {
+    // sred: [256][16]
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sred[tid * 16 + k] = s1[k]; sred[tid * 16 + 8 + k] = s2[k]; }
+    __syncthreads();
+    // threads sharing a channel group are tid = g, g + cv, g + 2cv, ...  (256 % cv == 0)
+    for (int o = tid; o < cv * 16; o += 256) {
+        const int g = o >> 4, k = o & 15;
+        float acc = 0.f;
+        for (int t = g; t < 256; t += cv) acc += sred[t * 16 + k];
+        const int slot = blockIdx.x & (SVSR_STAT_SLOTS - 1);
+        const int which = k >> 3, c = g * 8 + (k & 7);
+        atomicAdd(slots + ((long)slot * 2 + which) * C + c, acc);
+    }
+    (void)c0;
+}
+
+// pass 1 of the backward: slots += (sum g, sum g * xhat) with g = dy * act'(.)   (relu mask from saved y)
+__global__ __launch_bounds__(256) void k_bn_act_bwd_reduce(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+                                                           const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, long nvec, int C, int act,
+                                                           float* slots) {
+    __shared__ float sred[256 * 16];
+    const int cv = C >> 3;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    const int c0 = (int)(idx % cv) * 8;
+    float mu[8], rs[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k]; s1[k] = 0.f; s2[k] = 0.f; }
+    for (; idx < nvec; idx += stride) {
+        float g[8], xv[8];
+        unpack8(reinterpret_cast<const u32x4*>(dy)[idx], g);
+        unpack8(reinterpret_cast<const u32x4*>(x)[idx], xv);
+        if (act == 1) {
+            float yv[8];
+            unpack8(reinterpret_cast<const u32x4*>(y)[idx], yv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * (xv[k] - mu[k]) * rs[k]; }
+    }
+    reduce_to_slots(sred, s1, s2, cv, c0, C, slots);
+}
+
+// finalise the backward statistics: dbeta += sum g, dgamma += sum g*xhat, coef = {gamma*rstd, sum g / n, sum g*xhat / n}
+__global__ void k_bn_bwd_finalize(float* slots, int C, float count, const float* gamma, const float* rstd,
+                                  float* dgamma, float* dbeta, float* coef) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < SVSR_STAT_SLOTS; ++k) {
+            s += (double)slots[(k * 2 + 0) * C + c];
+            q += (double)slots[(k * 2 + 1) * C + c];
+            slots[(k * 2 + 0) * C + c] = 0.f;
+            slots[(k * 2 + 1) * C + c] = 0.f;
+        }
+        dbeta[c] += (float)s;
+        dgamma[c] += (float)q;
+        coef[c] = gamma[c] * rstd[c];
+        coef[C + c] = (float)(s / (double)count);
+        coef[2 * C + c] = (float)(q / (double)count);
+    }
+}
+
+// pass 2: dx = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat));  dres = g (optional)
+__global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+                                                          const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ coef,
+                                                          bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, long nvec,
+                                                          int C, int act) {
+    const int cv = C >> 3;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    if (idx >= nvec) return;
+    const int c0 = (int)(idx % cv) * 8;
+    float mu[8], rs[8], k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k];
+        k0[k] = coef[c0 + k]; k1[k] = coef[C + c0 + k]; k2[k] = coef[2 * C + c0 + k];
+    }
+    for (; idx < nvec; idx += stride) {
+        float g[8], xv[8], o[8];
+        unpack8(reinterpret_cast<const u32x4*>(dy)[idx], g);
+        unpack8(reinterpret_cast<const u32x4*>(x)[idx], xv);
+        if (act == 1) {
+            float yv[8];
+            unpack8(reinterpret_cast<const u32x4*>(y)[idx], yv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = k0[k] * (g[k] - k1[k] - (xv[k] - mu[k]) * rs[k] * k2[k]);
+        reinterpret_cast<u32x4*>(dx)[idx] = pack8(o);
+        if (dres != nullptr) reinterpret_cast<u32x4*>(dres)[idx] = pack8(g);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// stem: y[n,ph,pw,:] = max_{3x3 window, stride 2, pad 1 (-inf)} gelu(bn(x[n,2ph-1+i,2pw-1+j,:])); argmax index i*3+j
+// first maximum in row-major window order wins (torch CPU max_pool semantics: strictly-greater update).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stem_bn_gelu_pool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                               unsigned char* __restrict__ amax,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               int N, int Hc, int Wc, int Hp, int Wp, int C) {
+    const int cv = C >> 3;
+    const long nvec = (long)N * Hp * Wp * cv;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    if (idx >= nvec) return;
+    const int c0 = (int)(idx % cv) * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = gamma[c0 + k] * rstd[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k]; }
+    for (; idx < nvec; idx += stride) {
+        long pix = idx / cv;
+        const int pw = (int)(pix % Wp); pix /= Wp;
+        const int ph = (int)(pix % Hp);
+        const int n = (int)(pix / Hp);
+        float best[8];
+        int bi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+        bool first = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int h = 2 * ph - 1 + i;
+            if (h < 0 || h >= Hc) continue;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int w = 2 * pw - 1 + j;
+                if (w < 0 || w >= Wc) continue;
+                float f[8];
+                unpack8(*reinterpret_cast<const u32x4*>(x + (((long)n * Hc + h) * Wc + w) * C + c0), f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float v = gelu_erf(f[k] * sc[k] + sh[k]);
+                    if (first || v > best[k]) { best[k] = v; bi[k] = i * 3 + j; }
+                }
+                first = false;
+            }
+        }
+        reinterpret_cast<u32x4*>(y)[idx] = pack8(best);
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lo |= (unsigned)bi[k] << (8 * k); hi |= (unsigned)bi[k + 4] << (8 * k); }
+        reinterpret_cast<uint2*>(amax)[idx] = make_uint2(lo, hi);
+    }
+}
+
+// gradient reaching the stem conv output element (n,h,w,c..c+7) through pool -> gelu:  g = (sum of dpool over the
+// windows whose argmax is this element) * gelu'(bn(x)).
+__device__ __forceinline__ void stem_gather_g(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ amax,
+                                              int n, int h, int w, int c0, int Hp, int Wp, int C, const float* z, float* g) {
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    const int ph_lo = h >> 1, ph_hi = (h & 1) ? (h >> 1) + 1 : (h >> 1);
+    const int pw_lo = w >> 1, pw_hi = (w & 1) ? (w >> 1) + 1 : (w >> 1);
+    for (int ph = ph_lo; ph <= ph_hi; ++ph) {
+        if (ph >= Hp) continue;
+        const int i = h - (2 * ph - 1);
+        for (int pw = pw_lo; pw <= pw_hi; ++pw) {
+            if (pw >= Wp) continue;
+            const int j = w - (2 * pw - 1);
+            const long o = (((long)n * Hp + ph) * Wp + pw) * C + c0;
+            const uint2 am = *reinterpret_cast<const uint2*>(amax + o);
+            float d[8];
+            unpack8(*reinterpret_cast<const u32x4*>(dpool + o), d);
+            const unsigned want = (unsigned)(i * 3 + j);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (((am.x >> (8 * k)) & 0xffu) == want) acc[k] += d[k];
+                if (((am.y >> (8 * k)) & 0xffu) == want) acc[k + 4] += d[k + 4];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = acc[k] * gelu_erf_grad(z[k]);
+}
+
+__global__ __launch_bounds__(256) void k_stem_pool_bwd_reduce(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ amax,
+                                                              const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int N, int Hc, int Wc, int Hp, int Wp,
+                                                              int C, float* slots) {
+    __shared__ float sred[256 * 16];
+    const int cv = C >> 3;
+    const long nvec = (long)N * Hc * Wc * cv;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    const int c0 = (int)(idx % cv) * 8;
+    float mu[8], rs[8], ga[8], be[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k]; ga[k] = gamma[c0 + k]; be[k] = beta[c0 + k]; s1[k] = 0.f; s2[k] = 0.f; }
+    for (; idx < nvec; idx += stride) {
+        long pix = idx / cv;
+        const int w = (int)(pix % Wc); pix /= Wc;
+        const int h = (int)(pix % Hc);
+        const int n = (int)(pix / Hc);
+        float xv[8], xh[8], z[8], g[8];
+        unpack8(reinterpret_cast<const u32x4*>(x)[idx], xv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { xh[k] = (xv[k] - mu[k]) * rs[k]; z[k] = ga[k] * xh[k] + be[k]; }
+        stem_gather_g(dpool, amax, n, h, w, c0, Hp, Wp, C, z, g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * xh[k]; }
+    }
+    reduce_to_slots(sred, s1, s2, cv, c0, C, slots);
+}
+
+__global__ __launch_bounds__(256) void k_stem_pool_bwd_apply(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ amax,
+                                                             const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ coef,
+                                                             bf16_t* __restrict__ dx, int N, int Hc, int Wc, int Hp, int Wp, int C) {
+    const int cv = C >> 3;
+    const long nvec = (long)N * Hc * Wc * cv;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    if (idx >= nvec) return;
+    const int c0 = (int)(idx % cv) * 8;
+    float mu[8], rs[8], ga[8], be[8], k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k]; ga[k] = gamma[c0 + k]; be[k] = beta[c0 + k];
+        k0[k] = coef[c0 + k]; k1[k] = coef[C + c0 + k]; k2[k] = coef[2 * C + c0 + k];
+    }
+    for (; idx < nvec; idx += stride) {
+        long pix = idx / cv;
+        const int w = (int)(pix % Wc); pix /= Wc;
+        const int h = (int)(pix % Hc);
+        const int n = (int)(pix / Hc);
+        float xv[8], xh[8], z[8], g[8], o[8];
+        unpack8(reinterpret_cast<const u32x4*>(x)[idx], xv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { xh[k] = (xv[k] - mu[k]) * rs[k]; z[k] = ga[k] * xh[k] + be[k]; }
+        stem_gather_g(dpool, amax, n, h, w, c0, Hp, Wp, C, z, g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = k0[k] * (g[k] - k1[k] - xh[k] * k2[k]);
+        reinterpret_cast<u32x4*>(dx)[idx] = pack8(o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// global spatial mean  [N][HW][C] -> [N][C]  and its backward
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_avgpool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long N, int HW, int C) {
+    const int cv = C >> 3;
+    const long nvec = N * cv;
+    const float inv = 1.f / (float)HW;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long)gridDim.x * 256) {
+        const long n = idx / cv;
+        const int c0 = (int)(idx % cv) * 8;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int p = 0; p < HW; ++p) {
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4*>(x + ((long)n * HW + p) * C + c0), f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += f[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] *= inv;
+        reinterpret_cast<u32x4*>(y)[idx] = pack8(acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_avgpool_bwd(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, long N, int HW, int C) {
+    const int cv = C >> 3;
+    const long nvec = N * HW * cv;
+    const float inv = 1.f / (float)HW;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long)gridDim.x * 256) {
+        const long n = idx / ((long)HW * cv);
+        const int c8 = (int)(idx % cv);
+        float f[8];
+        unpack8(reinterpret_cast<const u32x4*>(dy)[n * cv + c8], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] *= inv;
+        reinterpret_cast<u32x4*>(dx)[idx] = pack8(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static inline int ew_grid(long nvec) {
+    long b = (nvec + 255) / 256;
+    if (b > 2048) b = 2048;     // 8 blocks x 256 CUs, grid-stride beyond that
+    if (b < 1) b = 1;
+    return (int)b;
+}
+static inline bool chan_ok(int C) { return C >= 8 && C <= 2048 && (2048 % C) == 0; }
+
+extern "C" {
+
+int svsr_bn_finalize(float* slots, int C, float count, float eps, float momentum, float* mean, float* rstd,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked, hipStream_t stream) {
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 127) / 128), dim3(128), 0, stream, slots, C, count, eps, momentum, mean, rstd,
+                       running_mean, running_var, (long*)num_batches_tracked);
+    return svsr_check_launch();
+}
+
+int svsr_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(k_bn_eval_prepare, dim3((C + 127) / 128), dim3(128), 0, stream, running_mean, running_var, C, eps, mean, rstd);
+    return svsr_check_launch();
+}
+
+int svsr_bn_act_fwd(const void* x, const void* res, void* y, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, int64_t npix, int C, int act, hipStream_t stream) {
+    if (!chan_ok(C)) return SVSR_ERR_ARG;
+    const long nvec = npix * (C / 8);
+    hipLaunchKernelGGL(k_bn_act_fwd, dim3(ew_grid(nvec)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y,
+                       mean, rstd, gamma, beta, nvec, C, act);
+    return svsr_check_launch();
+}
+
+int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma,
+                    float* slots, float* coef, float* dgamma, float* dbeta, void* dx, void* dres, int64_t npix, int C, int act,
+                    hipStream_t stream) {
+    if (!chan_ok(C)) return SVSR_ERR_ARG;
+    const long nvec = npix * (C / 8);
+    const int grid = ew_grid(nvec);
+    hipLaunchKernelGGL(k_bn_act_bwd_reduce, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x,
+                       mean, rstd, nvec, C, act, slots);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 127) / 128), dim3(128), 0, stream, slots, C, (float)npix, gamma, rstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(k_bn_act_bwd_apply, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x,
+                       mean, rstd, coef, (bf16_t*)dx, (bf16_t*)dres, nvec, C, act);
+    return svsr_check_launch();
+}
+
+int svsr_stem_bn_gelu_pool_fwd(const void* x, void* y, void* amax, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, hipStream_t stream) {
+    if (!chan_ok(C)) return SVSR_ERR_ARG;
+    const long nvec = (long)N * Hp * Wp * (C / 8);
+    hipLaunchKernelGGL(k_stem_bn_gelu_pool_fwd, dim3(ew_grid(nvec)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y,
+                       (unsigned char*)amax, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C);
+    return svsr_check_launch();
+}
+
+int svsr_stem_bn_gelu_pool_bwd(const void* dpool, const void* amax, const void* x, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, float* slots, float* coef, float* dgamma, float* dbeta,
+                               void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, hipStream_t stream) {
+    if (!chan_ok(C)) return SVSR_ERR_ARG;
+    const long nvec = (long)N * Hc * Wc * (C / 8);
+    const int grid = ew_grid(nvec);
+    hipLaunchKernelGGL(k_stem_pool_bwd_reduce, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
+                       (const bf16_t*)x, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, slots);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 127) / 128), dim3(128), 0, stream, slots, C, (float)((long)N * Hc * Wc), gamma, rstd,
+                       dgamma, dbeta, coef);
+    hipLaunchKernelGGL(k_stem_pool_bwd_apply, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
+                       (const bf16_t*)x, mean, rstd, gamma, beta, coef, (bf16_t*)dx, N, Hc, Wc, Hp, Wp, C);
+    return svsr_check_launch();
+}
+
+int svsr_avgpool_fwd(const void* x, void* y, int64_t N, int HW, int C, hipStream_t stream) {
+    if (C % 8) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_avgpool_fwd, dim3(ew_grid(N * (C / 8))), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (long)N, HW, C);
+    return svsr_check_launch();
+}
+
+int svsr_avgpool_bwd(const void* dy, void* dx, int64_t N, int HW, int C, hipStream_t stream) {
+    if (C % 8) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_avgpool_bwd, dim3(ew_grid(N * HW * (C / 8))), dim3(256), 0, stream, (const bf16_t*)dy, (bf16_t*)dx, (long)N, HW, C);
+    return svsr_check_launch();
+}
+
+}  // extern "C"

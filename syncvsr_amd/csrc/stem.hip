@@ -1,0 +1,319 @@
+// 3-D stem convolution Conv3d(1, 64, (5,7,7), stride (1,2,2), pad (2,3,3), bias=False) on MFMA (gfx950).
+// Replaces the ATen/MIOpen conv3d reached by `stem3d[0]` (reference LRW/video/src/lightning.py:50; LRS twin
+// conv3d_extractor.py:32-34) and its weight gradient.  C_in = 1, so the contraction is a
+// 245-tap stencil: the taps are laid out as K = 36 rows (kt,kh; 35 real) x 8 columns (kw; 7 real) = 288 and the
+// im2col operand is never materialised — A fragments are read straight out of an LDS copy of the input rows
+// (5 frames x a few rows, bf16), where 8 consecutive kw of one (kt,kh) row are 8 consecutive pixels.
+#include "common.h"
+
+#define STEM_C 64
+#define STEM_KROWS 36          // 35 (kt,kh) rows + 1 zero row
+#define STEM_WPITCH 296        // 288 + 8 pad: 592-byte rows -> conflict-free ds_read_b128 of B fragments
+
+struct StemFwdArgs {
+    const float* vid;   // [B][T][H][W] fp32 (C = 1)
+    const float* w;     // [64][5][7][7] fp32
+    bf16_t* out;        // [B*T][Ho][Wo][64] bf16
+    float* stats;       // optional BatchNorm slots [SVSR_STAT_SLOTS][2][64]
+    int B, T, H, W, Ho, Wo;
+    int tiles_per_frame, total_tiles;
+    int rows_in_max, WP;   // LDS input tile: [5][rows_in_max][WP]
+};
+
+__global__ __launch_bounds__(256) void k_stem_conv_fwd(const StemFwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);                 // [64][STEM_WPITCH]
+    bf16_t* sIn = sW + STEM_C * STEM_WPITCH;                          // [5][rows_in_max][WP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HoWo = p.Ho * p.Wo;
+
+    // weights -> LDS, padded K layout k = (kt*7+kh)*8 + kw
+    for (int e = tid; e < STEM_C * STEM_KROWS * 8; e += 256) {
+        const int c = e / (STEM_KROWS * 8), rem = e - c * (STEM_KROWS * 8);
+        const int r = rem >> 3, kw = rem & 7;
+        float v = 0.f;
+        if (r < 35 && kw < 7) v = p.w[c * 245 + r * 7 + kw];
+        sW[c * STEM_WPITCH + r * 8 + kw] = f2bf(v);
+    }
+
+    float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+        const int f = tile / p.tiles_per_frame, tp = tile - f * p.tiles_per_frame;
+        const int b = f / p.T, t = f - b * p.T;
+        const int p0 = tp * 128;
+        int plast = p0 + 127;
+        if (plast > HoWo - 1) plast = HoWo - 1;
+        const int y0 = p0 / p.Wo, y1 = plast / p.Wo;
+        const int nrows = 2 * (y1 - y0) + 7;
+        const int row_base = 2 * y0 - 3;
+
+        __syncthreads();   // previous tile's reads of sIn are complete (also orders the weight fill)
+        // fill the input tile: one 32-lane group per (kt, row)
+        for (int rr = tid >> 5; rr < 5 * nrows; rr += 8) {
+            const int kt = rr / nrows, r = rr - kt * nrows;
+            const int tt = t + kt - 2, iy = row_base + r;
+            const bool row_ok = tt >= 0 && tt < p.T && iy >= 0 && iy < p.H;
+            const float* src = p.vid + (((long)b * p.T + tt) * p.H + iy) * p.W;
+            bf16_t* dst = sIn + ((long)kt * p.rows_in_max + r) * p.WP;
+            for (int c = tid & 31; c < p.WP; c += 32) {
+                const int ix = c - 3;
+                float v = 0.f;
+                if (row_ok && ix >= 0 && ix < p.W) v = src[ix];
+                dst[c] = f2bf(v);
+            }
+        }
+        __syncthreads();
+
+        int pp = p0 + wave * 32 + (lane & 31);
+        if (pp > HoWo - 1) pp = HoWo - 1;          // clamp: rows beyond the frame are masked at the store
+        const int y = pp / p.Wo, x = pp - y * p.Wo;
+        const int abase = (2 * (y - y0)) * p.WP + 2 * x;
+        const int kg = lane >> 5;
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+
+#pragma unroll
+        for (int ks = 0; ks < STEM_KROWS / 2; ++ks) {
+            const int re = 2 * ks, ro = (2 * ks + 1 < 35) ? 2 * ks + 1 : 34;   // the zero row reads row 34's (finite) pixels
+            const int kte = re / 7, khe = re % 7, kto = ro / 7, kho = ro % 7;
+            const int kt = kg ? kto : kte, kh = kg ? kho : khe;
+            const unsigned* src = reinterpret_cast<const unsigned*>(sIn + (kt * p.rows_in_max + kh) * p.WP + abase);
+            union { bf16x8 v; unsigned u[4]; } fa;
+            fa.u[0] = src[0]; fa.u[1] = src[1]; fa.u[2] = src[2]; fa.u[3] = src[3];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + (jt * 32 + (lane & 31)) * STEM_WPITCH + ks * 16 + kg * 8);
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb, acc[jt], 0, 0, 0);
+            }
+        }
+
+        bf16_t* obase = p.out + (long)f * HoWo * STEM_C;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int c = jt * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int po = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (po < HoWo) {
+                    const float v = acc[jt][r];
+                    obase[(long)po * STEM_C + c] = f2bf(v);
+                    st_s[jt] += v;
+                    st_q[jt] += v * v;
+                }
+            }
+        }
+    }
+    if (p.stats != nullptr) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            float s = st_s[jt] + __shfl_xor(st_s[jt], 32, 64);
+            float q = st_q[jt] + __shfl_xor(st_q[jt], 32, 64);
+            if (lane < 32) {
+                const int slot = blockIdx.x & (SVSR_STAT_SLOTS - 1);
+                atomicAdd(p.stats + (slot * 2 + 0) * STEM_C + jt * 32 + lane, s);
+                atomicAdd(p.stats + (slot * 2 + 1) * STEM_C + jt * 32 + lane, q);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// weight gradient  dW[c][kt][kh][kw] += sum_{b,t,y,x} dY[b,t,y,x,c] * in[b, t+kt-2, 2y+kh-3, 2x+kw-3]
+// MFMA view: D[c][k] += sum_m dY^T[c][m] * P[m][k] with m running along x inside one output row.  A fragments
+// (8 consecutive positions of one channel) come from the position-major dY tile via ds_read_b64_tr_b16; B fragments
+// (8 consecutive x for one tap) are stride-2 pixels, made contiguous by storing the input rows de-interleaved into
+// even/odd column planes.
+// ------------------------------------------------------------------------------------------------------------
+#define SW_RB 4            // output rows per tile
+#define SW_DPITCH 80       // dY tile row pitch (bf16): 64 + 16 pad
+
+struct StemWgradArgs {
+    const float* vid;
+    const bf16_t* dy;   // [B*T][Ho][Wo][64]
+    float* dw;          // [64][245] fp32, accumulated
+    int B, T, H, W, Ho, Wo;
+    int WoP;            // Wo rounded up to 16
+    int PW;             // plane row width (elements, even): WoP + 8
+    int groups_per_frame, total_tiles;
+    int use_tr;
+};
+
+template <bool USE_TR>
+__device__ __forceinline__ bf16x8 stem_frag_T(const bf16_t* tile, int ch0, int pos0, int lane) {
+    bf16x8 f;
+    if (USE_TR) {
+        const int gq = lane >> 4, s = lane & 15;
+        const bf16_t* base = tile + (pos0 + (gq >> 1) * 8 + (s >> 2)) * SW_DPITCH + ch0 + (gq & 1) * 16 + (s & 3) * 4;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(base));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(base + 4 * SW_DPITCH));
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    } else {
+        const bf16_t* base = tile + (pos0 + (lane >> 5) * 8) * SW_DPITCH + ch0 + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = (short)base[k * SW_DPITCH];
+    }
+    return f;
+}
+
+template <bool USE_TR>
+__global__ __launch_bounds__(256) void k_stem_conv_wgrad(const StemWgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sDY = reinterpret_cast<bf16_t*>(smem_raw);                 // [SW_RB*WoP][SW_DPITCH]
+    bf16_t* sIn = sDY + SW_RB * p.WoP * SW_DPITCH;                     // [5][2*SW_RB+5][2][PW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrows = 2 * SW_RB + 5;
+    const int kg = lane >> 5;
+
+    // this lane's two taps (B-fragment columns): k = (wave*2 + q)*32 + (lane&31)
+    int kbase[2];
+    bool kvalid[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = (wave * 2 + q) * 32 + (lane & 31);
+        kvalid[q] = k < 245;
+        const int kk = kvalid[q] ? k : 0;
+        const int kt = kk / 49, kh = (kk % 49) / 7, kw = kk % 7;
+        const int plane = (kw + 1) & 1, off = (kw + 1) >> 1;      // padded column 2x+kw+1 -> plane, index x + off
+        kbase[q] = ((kt * nrows + kh) * 2 + plane) * p.PW + off + kg * 8;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+        const int f = tile / p.groups_per_frame, gi = tile - f * p.groups_per_frame;
+        const int b = f / p.T, t = f - b * p.T;
+        const int y0 = gi * SW_RB;
+        int rb = p.Ho - y0;
+        if (rb > SW_RB) rb = SW_RB;
+        const int row_base = 2 * y0 - 3;
+
+        __syncthreads();
+        // dY tile: [rb][WoP] positions x 8 chunks of 16 B; pad positions are zero
+        for (int e = tid; e < SW_RB * p.WoP * 8; e += 256) {
+            const int pos = e >> 3, ch = e & 7;
+            const int yl = pos / p.WoP, x = pos - yl * p.WoP;
+            u32x4 v = zero4;
+            if (yl < rb && x < p.Wo)
+                v = *reinterpret_cast<const u32x4*>(p.dy + (((long)f * p.Ho + y0 + yl) * p.Wo + x) * STEM_C + ch * 8);
+            *reinterpret_cast<u32x4*>(sDY + pos * SW_DPITCH + ch * 8) = v;
+        }
+        // input rows, de-interleaved: padded column cp = col + 4 -> plane cp&1, index cp>>1
+        for (int rr = tid >> 5; rr < 5 * nrows; rr += 8) {
+            const int kt = rr / nrows, r = rr - kt * nrows;
+            const int tt = t + kt - 2, iy = row_base + r;
+            const bool row_ok = tt >= 0 && tt < p.T && iy >= 0 && iy < p.H;
+            const float* src = p.vid + (((long)b * p.T + tt) * p.H + iy) * p.W;
+            bf16_t* dst = sIn + (long)rr * 2 * p.PW;
+            for (int cp = tid & 31; cp < 2 * p.PW; cp += 32) {
+                const int ix = cp - 4;
+                float v = 0.f;
+                if (row_ok && ix >= 0 && ix < p.W) v = src[ix];
+                dst[(cp & 1) * p.PW + (cp >> 1)] = f2bf(v);
+            }
+        }
+        __syncthreads();
+
+        for (int yl = 0; yl < rb; ++yl) {
+            for (int xs = 0; xs < p.WoP; xs += 16) {
+                const int pos0 = yl * p.WoP + xs;
+                bf16x8 fa[2], fb[2];
+                fa[0] = stem_frag_T<USE_TR>(sDY, 0, pos0, lane);
+                fa[1] = stem_frag_T<USE_TR>(sDY, 32, pos0, lane);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int a = kbase[q] + (2 * yl) * 2 * p.PW + xs;      // element address of x = xs + kg*8 for this tap
+                    const unsigned* src = reinterpret_cast<const unsigned*>(sIn + (a & ~1));
+                    const unsigned sh = (a & 1) * 16;
+                    const unsigned d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3], d4 = src[4];
+                    union { bf16x8 v; unsigned u[4]; } fr;
+                    fr.u[0] = __builtin_amdgcn_alignbit(d1, d0, sh);
+                    fr.u[1] = __builtin_amdgcn_alignbit(d2, d1, sh);
+                    fr.u[2] = __builtin_amdgcn_alignbit(d3, d2, sh);
+                    fr.u[3] = __builtin_amdgcn_alignbit(d4, d3, sh);
+                    if (!kvalid[q]) { fr.u[0] = 0; fr.u[1] = 0; fr.u[2] = 0; fr.u[3] = 0; }
+                    fb[q] = fr.v;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[q], acc[i][q], 0, 0, 0);
+            }
+        }
+    }
+    // D[row = channel][col = tap]
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = (wave * 2 + q) * 32 + (lane & 31);
+        if (k >= 245) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                atomicAdd(p.dw + c * 245 + k, acc[i][q][r]);
+            }
+    }
+}
+
+extern "C" {
+
+int svsr_stem_conv_fwd(const float* vid, const float* w, void* out, float* stats, int B, int T, int H, int W, hipStream_t stream) {
+    if ((H & 1) || (W & 1) || H < 8 || W < 8) return SVSR_ERR_ARG;
+    StemFwdArgs a;
+    a.vid = vid; a.w = w; a.out = (bf16_t*)out; a.stats = stats;
+    a.B = B; a.T = T; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2;
+    const int HoWo = a.Ho * a.Wo;
+    a.tiles_per_frame = (HoWo + 127) / 128;
+    a.total_tiles = a.tiles_per_frame * B * T;
+    const int span = 127 / a.Wo + 2;                 // output rows a 128-position tile can touch
+    a.rows_in_max = 2 * (span - 1) + 7;
+    a.WP = W + 6;
+    const size_t lds = (size_t)STEM_C * STEM_WPITCH * 2 + (size_t)5 * a.rows_in_max * a.WP * 2;
+    if (lds > 160 * 1024) return SVSR_ERR_ARG;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem_conv_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
+    int grid = a.total_tiles < 768 ? a.total_tiles : 768;     // persistent blocks (3 per CU), weights staged once each
+    hipLaunchKernelGGL(k_stem_conv_fwd, dim3(grid), dim3(256), lds, stream, a);
+    return svsr_check_launch();
+}
+
+int svsr_stem_conv_wgrad(const float* vid, const void* dy, float* dw, int B, int T, int H, int W, int use_tr, hipStream_t stream) {
+    if ((H & 1) || (W & 1) || H < 8 || W < 8) return SVSR_ERR_ARG;
+    StemWgradArgs a;
+    a.vid = vid; a.dy = (const bf16_t*)dy; a.dw = dw;
+    a.B = B; a.T = T; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2;
+    a.WoP = (a.Wo + 15) / 16 * 16;
+    a.PW = a.WoP + 8;
+    a.groups_per_frame = (a.Ho + SW_RB - 1) / SW_RB;
+    a.total_tiles = a.groups_per_frame * B * T;
+    a.use_tr = use_tr;
+    const size_t lds = (size_t)SW_RB * a.WoP * SW_DPITCH * 2 + (size_t)5 * (2 * SW_RB + 5) * 2 * a.PW * 2;
+    if (lds > 160 * 1024) return SVSR_ERR_ARG;
+    static size_t lds_set[2] = {0, 0};
+    const void* fn = use_tr ? reinterpret_cast<const void*>(k_stem_conv_wgrad<true>) : reinterpret_cast<const void*>(k_stem_conv_wgrad<false>);
+    if (lds > lds_set[use_tr ? 1 : 0]) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set[use_tr ? 1 : 0] = lds;
+    }
+    int grid = a.total_tiles < 512 ? a.total_tiles : 512;
+    if (use_tr) hipLaunchKernelGGL(k_stem_conv_wgrad<true>, dim3(grid), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(k_stem_conv_wgrad<false>, dim3(grid), dim3(256), lds, stream, a);
+    return svsr_check_launch();
+}
+
+}  // extern "C"

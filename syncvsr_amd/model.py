@@ -1,0 +1,523 @@
+"""Drop-in module for the reference's ``TransformerLightningModule`` (LRW/video/src/lightning.py:36-223), HIP-native.
+
+Same constructor (``Model(config)``), same ``forward(videos, audio_tokens, labels, word_mask) -> dict`` with the five
+scalar keys, same ``forward_videos`` / ``training_step`` / ``configure_optimizers`` helpers and the same state-dict key
+names (``stem3d.0.weight`` … ``encoder.encoder.layer.N.attention.self.query.weight`` … ``audio_projection.weight``).
+Everything between the inputs and the two losses runs in libsyncvsr_hip.so; this file is orchestration only:
+it owns the parameters (one flat fp32 buffer + flat fp32 gradient buffer + bf16 shadows for the MFMA kernels),
+records the forward "tape" and replays it backwards by hand — a single autograd node stands for the whole model,
+so ``loss_total.backward()`` works as in the reference loops while no per-op autograd graph is built.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import Config, audio_codec_dims
+from .init import buffer_specs, hidden_dim, init_state_dict, param_specs, resnet_block_specs
+
+BF16 = torch.bfloat16
+
+
+class _Holder(nn.Module):
+    """Name-space node: exists only so parameters get the reference's state-dict keys."""
+
+
+def _attach(root: nn.Module, name: str, tensor: torch.Tensor, is_param: bool) -> None:
+    parts = name.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Holder())
+        mod = mod._modules[p]
+    if is_param:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor))
+    else:
+        mod.register_buffer(parts[-1], tensor)
+
+
+def _get(root: nn.Module, name: str) -> torch.Tensor:
+    obj: Any = root
+    for p in name.split("."):
+        obj = obj._modules[p] if p in getattr(obj, "_modules", {}) else getattr(obj, p)
+    return obj
+
+
+class TransformerLightningModule(nn.Module):
+    """HIP-native twin of the reference LightningModule (word-level LRW model with the SyncVSR audio head)."""
+
+    def __init__(self, config: Config, seed: Optional[int] = None):
+        super().__init__()
+        if not isinstance(config, Config):
+            config = Config(config)
+        self.config = config
+        bert = config.model.bert
+        if bert.type != "huggingface":
+            raise NotImplementedError(
+                "only `model.bert.type: huggingface` is implemented natively; the x-transformers encoder of the shipped "
+                "yaml is a third-party dependency whose arithmetic cannot be pinned offline (SURVEY.md §8c)")
+        if config.data.use_word_boundary:
+            raise NotImplementedError(
+                "use_word_boundary needs a 513-wide encoder, which the reference's huggingface branch cannot build either "
+                "(BertConfig.hidden_size stays 512, lightning.py:92,145)")
+        self.is_train = False
+        self.word_labels = int(bert.num_labels)
+        self.lambda_audio = float(config.optim.lambda_audio)
+        self.label_smoothing = float(config.train.label_smoothing)
+        self.use_wb = False
+        self.codec, self.audio_alignment, self.vq_groups, self.audio_vocab_size = audio_codec_dims(config.model.wav2vec.path)
+        self.dim = hidden_dim(config)
+        self.heads = int(bert.num_attention_heads)
+        self.layers = int(bert.num_hidden_layers)
+        self.inter = int(bert.intermediate_size)
+        self.ln_eps = float(bert.get("layer_norm_eps", 1e-12))
+        if float(bert.get("emb_dropout", 0.0)) or float(bert.get("hidden_dropout_prob", 0.0)) or float(bert.get("attention_probs_dropout_prob", 0.0)):
+            raise NotImplementedError("dropout > 0 is not implemented in the HIP path yet (BASELINE configs use p = 0)")
+        if self.dim % 512 or self.dim // self.heads != 64:
+            raise NotImplementedError("encoder width must be a multiple of 512 with 64-wide heads")
+
+        self._specs = param_specs(config)
+        self._bspecs = buffer_specs(config)
+        sd = init_state_dict(config, seed=0 if seed is None else seed)
+        for name, shape, kind in self._specs:
+            t = sd[name]
+            if kind == "conv" and len(shape) == 4:
+                t = t.contiguous(memory_format=torch.channels_last)      # physical [Co][kh][kw][Ci]
+            _attach(self, name, t, True)
+        for name, shape, kind in self._bspecs:
+            _attach(self, name, sd[name], False)
+        self._store: Optional[_ParamStore] = None
+        self.use_tr = True           # ds_read_b64_tr_b16 fragments in the weight-gradient kernels
+        self.grad_ready_hook = None  # called as hook(lo, hi) when flat gradient range [lo, hi) is final (DDP buckets)
+
+    # ------------------------------------------------------------------------------------------------
+    # reference-compatible helpers
+    # ------------------------------------------------------------------------------------------------
+    def configure_optimizers(self):
+        """lightning.py:216-223 — returns the two parameter groups; the fused HIP optimiser lives in engine.TrainStep."""
+        do_decay = [p for p in self.parameters() if p.requires_grad and p.ndim >= 2]
+        no_decay = [p for p in self.parameters() if p.requires_grad and p.ndim < 2]
+        return [{"params": do_decay}, {"params": no_decay, "weight_decay": 0.0}]
+
+    def training_step(self, batch, idx: int = 0) -> torch.Tensor:
+        self.is_train = True
+        if self.config.train.use_cutmix:
+            raise NotImplementedError("CutMix is host-side augmentation outside the hot path (SURVEY §8f-3); apply it before calling")
+        return self(*batch)["loss_total"]
+
+    def store(self) -> "_ParamStore":
+        dev = self.cls_token.device
+        if self._store is None or self._store.device != dev or not self._store.owns(self):
+            self._store = _ParamStore(self, dev)
+        return self._store
+
+    # ------------------------------------------------------------------------------------------------
+    def forward_videos(self, videos: torch.Tensor) -> torch.Tensor:
+        """lightning.py:112-119: [B,1,T,H,W] -> fp32 [B,T,512] (no autograd; use forward() for training)."""
+        st = self.store()
+        st.refresh_shadows()
+        tape: dict[str, Any] = {}
+        with torch.no_grad():
+            feats = _frontend_forward(self, st, tape, videos.float().contiguous(), self.training)
+        return feats.float().view(videos.size(0), -1, 512)
+
+    def forward(self, videos: torch.Tensor, audio_tokens: torch.Tensor, labels: torch.Tensor, word_mask: torch.Tensor) -> dict[str, torch.Tensor]:
+        if videos.device.type != "cuda":
+            raise RuntimeError("syncvsr_amd runs on an MI355X HIP device only; there is no CPU fallback (use oracle/ for checking)")
+        st = self.store()
+        T = videos.size(2)
+        A = self.audio_alignment
+        audio_tokens = audio_tokens[:, : T * A].contiguous()
+        if audio_tokens.size(1) != T * A:
+            raise ValueError(f"audio_tokens has {audio_tokens.size(1)} steps, need >= {T * A}")
+        outs = _LrwFunction.apply(self.cls_token, self, st, videos.float().contiguous(), audio_tokens, labels.contiguous(),
+                                   torch.is_grad_enabled())
+        loss_category, loss_audio, acc = outs
+        loss_total = loss_category + loss_audio * self.lambda_audio
+        return {
+            "loss_total": loss_total,
+            "loss_category": loss_category,
+            "loss_audio": loss_audio,
+            "accuracy_top1": acc[0],
+            "accuracy_top5": acc[1],
+        }
+
+
+Model = TransformerLightningModule
+
+
+# ----------------------------------------------------------------------------------------------------
+# parameter store: flat fp32 master / gradient buffers + bf16 shadows
+# ----------------------------------------------------------------------------------------------------
+class _ParamStore:
+    def __init__(self, model: TransformerLightningModule, device: torch.device):
+        self.device = device
+        specs = model._specs
+        L = model.layers
+        # flat order: [decayed (ndim >= 2)] then [not decayed]; q/k/v of a layer adjacent so one GEMM covers them
+        # decayed tensors are laid out in FORWARD order (stem, trunk, embeddings, encoder layers, heads) so the backward
+        # pass finalises the buffer from its end towards its start — contiguous all-reduce buckets (engine.DataParallel).
+        def fwd_rank(name: str) -> int:
+            if name.startswith("stem3d"):
+                return 0
+            if name.startswith("resnet"):
+                return 1
+            if name == "cls_token" or name.startswith("encoder.embeddings"):
+                return 2
+            if name.startswith("encoder.encoder"):
+                return 3
+            return 4
+        decay = sorted([(n, s) for n, s, k in specs if len(s) >= 2], key=lambda e: fwd_rank(e[0]))   # stable
+        nodecay = [(n, s) for n, s, k in specs if len(s) < 2]
+        self.offsets: dict[str, tuple[int, int, tuple[int, ...]]] = {}
+        off = 0
+        for n, s in decay + nodecay:
+            numel = math.prod(s)
+            off = (off + 3) // 4 * 4                    # 16-byte alignment of every tensor
+            self.offsets[n] = (off, numel, tuple(s))
+            off += numel
+            if (n, s) == decay[-1]:
+                off = (off + 3) // 4 * 4
+                self.decay_end = off
+        self.numel = (off + 3) // 4 * 4
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.w16 = torch.zeros(self.numel, dtype=BF16, device=device)
+        self._params: dict[str, nn.Parameter] = {}
+        for n, s, kind in specs:
+            p = _get(model, n)
+            o, numel, shape = self.offsets[n]
+            view = self._view(self.flat, n)
+            view.copy_(p.data.to(device))
+            p.data = view
+            p.grad = self._view(self.grad, n)
+            self._params[n] = p
+        self.buffers = {n: _get(model, n) for n, _, _ in model._bspecs}
+        for n, b in self.buffers.items():
+            if b.device != device:
+                raise RuntimeError("move the module to the GPU before the first forward (model.to('cuda'))")
+        # transposed shadows for the data-gradient contractions
+        entries = []
+        toff = 0
+        self.t_offsets: dict[str, tuple[int, tuple[int, int, int]]] = {}
+
+        def add_t(key: str, src_off: int, A: int, T: int, Bd: int):
+            nonlocal toff
+            Apad = (A + 63) // 64 * 64
+            self.t_offsets[key] = (toff, (Bd, T, Apad))
+            entries.append((src_off, toff, A, T, Bd, Apad))
+            toff += Bd * T * Apad
+
+        for n, s, kind in specs:
+            if kind == "conv" and len(s) == 4:
+                add_t(n, self.offsets[n][0], s[0], s[2] * s[3], s[1])
+        D = model.dim
+        for i in range(L):
+            p = f"encoder.encoder.layer.{i}"
+            add_t(f"{p}.qkv", self.offsets[f"{p}.attention.self.query.weight"][0], 3 * D, 1, D)
+            add_t(f"{p}.attention.output.dense.weight", self.offsets[f"{p}.attention.output.dense.weight"][0], D, 1, D)
+            add_t(f"{p}.intermediate.dense.weight", self.offsets[f"{p}.intermediate.dense.weight"][0], model.inter, 1, D)
+            add_t(f"{p}.output.dense.weight", self.offsets[f"{p}.output.dense.weight"][0], D, 1, model.inter)
+            q, k, v = (self.offsets[f"{p}.attention.self.{x}.weight"][0] for x in ("query", "key", "value"))
+            assert k == q + D * D and v == k + D * D, "q/k/v weights must be adjacent in the flat buffer"
+            qb, kb, vb = (self.offsets[f"{p}.attention.self.{x}.bias"][0] for x in ("query", "key", "value"))
+            assert kb == qb + D and vb == kb + D
+        for n in ("audio_projection.weight", "category_classifier.weight"):
+            s = self.offsets[n][2]
+            add_t(n, self.offsets[n][0], s[0], 1, s[1])
+        self.w16t = torch.zeros(max(toff, 1), dtype=BF16, device=device)
+        import numpy as np
+
+        tab = np.zeros(len(entries), dtype=np.dtype([("src", "<i8"), ("dst", "<i8"), ("A", "<i4"), ("T", "<i4"), ("Bd", "<i4"), ("Apad", "<i4")]))
+        for i, e in enumerate(entries):
+            tab[i] = e
+        self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
+        self.n_entries = len(entries)
+        # per-BatchNorm workspaces
+        self.bn: dict[str, dict[str, torch.Tensor]] = {}
+        for n, s, kind in specs:
+            if kind == "norm_w" and (n + "").replace(".weight", ".running_mean") in self.buffers:
+                C = s[0]
+                base = n[: -len(".weight")]
+                self.bn[base] = dict(
+                    slots=torch.zeros(ops.STAT_SLOTS * 2 * C, dtype=torch.float32, device=device),
+                    coef=torch.empty(3 * C, dtype=torch.float32, device=device),
+                    mean=torch.empty(C, dtype=torch.float32, device=device),
+                    rstd=torch.empty(C, dtype=torch.float32, device=device),
+                )
+        self.shadow_version = -1
+
+    def owns(self, model: TransformerLightningModule) -> bool:
+        lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * 4
+        return all(lo <= p.data_ptr() < hi for p in self._params.values()) and model.cls_token is self._params["cls_token"]
+
+    def _view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        o, numel, shape = self.offsets[name]
+        seg = flat[o : o + numel]
+        if len(shape) == 4:   # conv weights are stored [Co][kh][kw][Ci]; the tensor keeps the logical [Co,Ci,kh,kw] shape
+            return seg.view(shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2)
+        return seg.view(shape)
+
+    # -- accessors used by the engine -------------------------------------------------------------
+    def p32(self, name: str) -> torch.Tensor:
+        o, n, _ = self.offsets[name]
+        return self.flat[o : o + n]
+
+    def g32(self, name: str) -> torch.Tensor:
+        o, n, _ = self.offsets[name]
+        return self.grad[o : o + n]
+
+    def s16(self, name: str, numel: Optional[int] = None) -> torch.Tensor:
+        o, n, _ = self.offsets[name]
+        return self.w16[o : o + (numel or n)]
+
+    def t16(self, key: str) -> torch.Tensor:
+        o, (Bd, T, Apad) = self.t_offsets[key]
+        return self.w16t[o : o + Bd * T * Apad].view(Bd, T, Apad)
+
+    def span(self, name: str, numel: Optional[int] = None) -> tuple[int, int]:
+        o, n, _ = self.offsets[name]
+        return o, o + (numel or n)
+
+    def refresh_shadows(self) -> None:
+        ops.cast_bf16(self.flat, self.w16)
+        ops.transpose_cast_multi(self.flat, self.w16t, self.table, self.n_entries)
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+
+    def rebind_grads(self) -> None:
+        for n, p in self._params.items():
+            g = p.grad
+            if g is None or g.data_ptr() != self.grad.data_ptr() + self.offsets[n][0] * 4:
+                p.grad = self._view(self.grad, n)
+
+
+# ----------------------------------------------------------------------------------------------------
+# forward / backward tape
+# ----------------------------------------------------------------------------------------------------
+def _bn_stats(st: _ParamStore, base: str, training: bool, count: int):
+    ws = st.bn[base]
+    if training:
+        ops.bn_finalize(ws["slots"], ws["mean"].numel(), count, ws["mean"], ws["rstd"], st.buffers[f"{base}.running_mean"],
+                        st.buffers[f"{base}.running_var"], st.buffers[f"{base}.num_batches_tracked"])
+    else:
+        ops.bn_eval_prepare(st.buffers[f"{base}.running_mean"], st.buffers[f"{base}.running_var"], ws["mean"], ws["rstd"])
+    return ws["mean"], ws["rstd"]      # per-layer buffers: valid until this layer's next forward
+
+
+def _conv_bn(st: _ParamStore, tape: dict, x: torch.Tensor, conv: str, bn: str, k: int, stride: int, pad: int, training: bool,
+             res: Optional[torch.Tensor], act: int) -> torch.Tensor:
+    o, n, shape = st.offsets[f"{conv}.weight"]
+    w16 = st.w16[o : o + n].view(shape[0], k, k, shape[1])
+    c = ops.conv2d_fwd(x, w16, k, stride, pad, stats=st.bn[bn]["slots"] if training else None)
+    mean, rstd = _bn_stats(st, bn, training, c.numel() // c.shape[-1])
+    y = ops.bn_act_fwd(c, res, mean, rstd, st.p32(f"{bn}.weight"), st.p32(f"{bn}.bias"), act)
+    tape[conv] = dict(x=x, c=c, y=y, mean=mean, rstd=rstd, k=k, stride=stride, pad=pad, act=act, bn=bn)
+    return y
+
+
+def _frontend_forward(model: TransformerLightningModule, st: _ParamStore, tape: dict, videos: torch.Tensor, training: bool) -> torch.Tensor:
+    B, _, T, H, W = videos.shape
+    N = B * T
+    c = ops.stem_conv_fwd(videos, st.p32("stem3d.0.weight"), st.bn["stem3d.1"]["slots"] if training else None)
+    mean, rstd = _bn_stats(st, "stem3d.1", training, c.numel() // 64)
+    x, amax = ops.stem_bn_gelu_pool_fwd(c, mean, rstd, st.p32("stem3d.1.weight"), st.p32("stem3d.1.bias"))
+    tape["stem"] = dict(videos=videos, c=c, amax=amax, mean=mean, rstd=rstd, pooled_shape=tuple(x.shape))
+    for prefix, inp, planes, stride, down in resnet_block_specs():
+        xin = x
+        o1 = _conv_bn(st, tape, xin, f"{prefix}.conv1", f"{prefix}.bn1", 3, stride, 1, training, None, 1)
+        if down:
+            idt = _conv_bn(st, tape, xin, f"{prefix}.downsample.0", f"{prefix}.downsample.1", 1, stride, 0, training, None, 0)
+        else:
+            idt = xin
+        x = _conv_bn(st, tape, o1, f"{prefix}.conv2", f"{prefix}.bn2", 3, 1, 1, training, idt, 1)
+    tape["trunk_out_shape"] = tuple(x.shape)
+    return ops.avgpool_fwd(x)            # [N, 512] bf16
+
+
+def _frontend_backward(model: TransformerLightningModule, st: _ParamStore, tape: dict, dfeats: torch.Tensor) -> None:
+    use_tr = model.use_tr
+    dx = ops.avgpool_bwd(dfeats, tape["trunk_out_shape"])
+    for prefix, inp, planes, stride, down in reversed(list(resnet_block_specs())):
+        t2 = tape[f"{prefix}.conv2"]
+        ws2 = st.bn[t2["bn"]]
+        dc2, dres = ops.bn_act_bwd(dx, t2["y"], t2["c"], t2["mean"], t2["rstd"], st.p32(f"{t2['bn']}.weight"), ws2["slots"], ws2["coef"],
+                                   st.g32(f"{t2['bn']}.weight"), st.g32(f"{t2['bn']}.bias"), 1, True)
+        _conv_wgrad(st, f"{prefix}.conv2", t2, dc2, use_tr)
+        do1 = ops.conv2d_dgrad(dc2, st.t16(f"{prefix}.conv2.weight").view(planes, 3, 3, planes), 3, 1, 1, t2["x"].shape[1:3])
+        t1 = tape[f"{prefix}.conv1"]
+        ws1 = st.bn[t1["bn"]]
+        dc1, _ = ops.bn_act_bwd(do1, t1["y"], t1["c"], t1["mean"], t1["rstd"], st.p32(f"{t1['bn']}.weight"), ws1["slots"], ws1["coef"],
+                                st.g32(f"{t1['bn']}.weight"), st.g32(f"{t1['bn']}.bias"), 1, False)
+        _conv_wgrad(st, f"{prefix}.conv1", t1, dc1, use_tr)
+        in_hw = t1["x"].shape[1:3]
+        w1t = st.t16(f"{prefix}.conv1.weight").view(inp, 3, 3, planes)
+        if down:
+            td = tape[f"{prefix}.downsample.0"]
+            wsd = st.bn[td["bn"]]
+            dcd, _ = ops.bn_act_bwd(dres, None, td["c"], td["mean"], td["rstd"], st.p32(f"{td['bn']}.weight"), wsd["slots"], wsd["coef"],
+                                    st.g32(f"{td['bn']}.weight"), st.g32(f"{td['bn']}.bias"), 0, False)
+            _conv_wgrad(st, f"{prefix}.downsample.0", td, dcd, use_tr)
+            dxa = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw)
+            dx = ops.conv2d_dgrad(dcd, st.t16(f"{prefix}.downsample.0.weight").view(inp, 1, 1, planes), 1, stride, 0, in_hw, addend=dxa)
+        else:
+            dx = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw, addend=dres)
+        _ready(model, st, f"{prefix}.conv1.weight")
+    ts = tape["stem"]
+    ws = st.bn["stem3d.1"]
+    dconv = ops.stem_bn_gelu_pool_bwd(dx, ts["amax"], ts["c"], ts["mean"], ts["rstd"], st.p32("stem3d.1.weight"), st.p32("stem3d.1.bias"),
+                                      ws["slots"], ws["coef"], st.g32("stem3d.1.weight"), st.g32("stem3d.1.bias"))
+    ops.stem_conv_wgrad(ts["videos"], dconv, st.g32("stem3d.0.weight"), use_tr)
+    _ready(model, st, None)
+
+
+def _conv_wgrad(st: _ParamStore, conv: str, t: dict, dc: torch.Tensor, use_tr: bool) -> None:
+    ops.conv2d_wgrad(t["x"], dc, st.g32(f"{conv}.weight"), t["k"], t["stride"], t["pad"], use_tr)
+
+
+def _ready(model: TransformerLightningModule, st: _ParamStore, name: Optional[str]) -> None:
+    """Gradient-ready notification for bucketed all-reduce: everything at or above `name`'s offset in the decayed
+    region is final (backward walks the flat buffer from its end to its start); None = all gradients final."""
+    if model.grad_ready_hook is not None:
+        model.grad_ready_hook(0 if name is None else st.offsets[name][0])
+
+
+def _encoder_forward(model: TransformerLightningModule, st: _ParamStore, tape: dict, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    D, S, H = model.dim, T + 1, model.heads
+    R = B * S
+    pos = st.p32("encoder.embeddings.position_embeddings.weight")
+    type0 = st.p32("encoder.embeddings.token_type_embeddings.weight")
+    s0, x, mean0, rstd0 = ops.embed_ln_fwd(feats, st.p32("cls_token"), pos, type0, st.p32("encoder.embeddings.LayerNorm.weight"),
+                                           st.p32("encoder.embeddings.LayerNorm.bias"), B, S, D, model.ln_eps)
+    tape["emb"] = dict(sum=s0, mean=mean0, rstd=rstd0)
+    for i in range(model.layers):
+        p = f"encoder.encoder.layer.{i}"
+        wqkv = st.s16(f"{p}.attention.self.query.weight", 3 * D * D)
+        bqkv = st.flat[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
+        qkv, _ = ops.linear_fwd(x, wqkv, bqkv, rows=R, K=D, N=3 * D, x_pitch=D)
+        ctx, probs = ops.attn_fwd(qkv, B, S, H, D // H)
+        ao, _ = ops.linear_fwd(ctx, st.s16(f"{p}.attention.output.dense.weight"), st.p32(f"{p}.attention.output.dense.bias"),
+                               rows=R, K=D, N=D, x_pitch=D)
+        x1, m1, r1 = ops.add_ln_fwd(ao, x, st.p32(f"{p}.attention.output.LayerNorm.weight"), st.p32(f"{p}.attention.output.LayerNorm.bias"), model.ln_eps)
+        hg, z = ops.linear_fwd(x1, st.s16(f"{p}.intermediate.dense.weight"), st.p32(f"{p}.intermediate.dense.bias"),
+                               rows=R, K=D, N=model.inter, x_pitch=D, gelu=True)
+        f, _ = ops.linear_fwd(hg, st.s16(f"{p}.output.dense.weight"), st.p32(f"{p}.output.dense.bias"), rows=R, K=model.inter, N=D,
+                              x_pitch=model.inter)
+        x2, m2, r2 = ops.add_ln_fwd(f, x1, st.p32(f"{p}.output.LayerNorm.weight"), st.p32(f"{p}.output.LayerNorm.bias"), model.ln_eps)
+        tape[p] = dict(x=x, qkv=qkv, ctx=ctx, probs=probs, ao=ao, x1=x1, m1=m1, r1=r1, z=z, hg=hg, f=f, m2=m2, r2=r2)
+        x = x2
+    return x
+
+
+def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: dict, dh: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    D, S, H, I = model.dim, T + 1, model.heads, model.inter
+    R = B * S
+    use_tr = model.use_tr
+    dx = dh
+    for i in reversed(range(model.layers)):
+        p = f"encoder.encoder.layer.{i}"
+        t = tape[p]
+        ds2 = ops.add_ln_bwd(dx, t["f"], t["x1"], st.p32(f"{p}.output.LayerNorm.weight"), t["m2"], t["r2"],
+                             st.g32(f"{p}.output.LayerNorm.weight"), st.g32(f"{p}.output.LayerNorm.bias"))
+        ops.linear_wgrad(t["hg"], ds2, st.g32(f"{p}.output.dense.weight"), rows=R, K=I, N=D, x_pitch=I, dy_pitch=D, use_tr=use_tr)
+        ops.bias_act_bwd(ds2, None, st.g32(f"{p}.output.dense.bias"), R=R, N=D, n_valid=D, ld=D)
+        dhg = ops.linear_dgrad(ds2, st.t16(f"{p}.output.dense.weight"), rows=R, N=D, K=I, dy_pitch=D)
+        dz = ops.bias_act_bwd(dhg, t["z"], st.g32(f"{p}.intermediate.dense.bias"), R=R, N=I, n_valid=I, ld=I)
+        ops.linear_wgrad(t["x1"], dz, st.g32(f"{p}.intermediate.dense.weight"), rows=R, K=D, N=I, x_pitch=D, dy_pitch=I, use_tr=use_tr)
+        dx1 = ops.linear_dgrad(dz, st.t16(f"{p}.intermediate.dense.weight"), rows=R, N=I, K=D, dy_pitch=I, addend=ds2, out=ds2)
+        ds1 = ops.add_ln_bwd(dx1, t["ao"], t["x"], st.p32(f"{p}.attention.output.LayerNorm.weight"), t["m1"], t["r1"],
+                             st.g32(f"{p}.attention.output.LayerNorm.weight"), st.g32(f"{p}.attention.output.LayerNorm.bias"))
+        ops.linear_wgrad(t["ctx"], ds1, st.g32(f"{p}.attention.output.dense.weight"), rows=R, K=D, N=D, x_pitch=D, dy_pitch=D, use_tr=use_tr)
+        ops.bias_act_bwd(ds1, None, st.g32(f"{p}.attention.output.dense.bias"), R=R, N=D, n_valid=D, ld=D)
+        dctx = ops.linear_dgrad(ds1, st.t16(f"{p}.attention.output.dense.weight"), rows=R, N=D, K=D, dy_pitch=D)
+        dqkv = ops.attn_bwd(dctx, t["qkv"], t["probs"], B, S, H, D // H)
+        gq = st.grad[st.offsets[f"{p}.attention.self.query.weight"][0] :][: 3 * D * D]
+        gqb = st.grad[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
+        ops.linear_wgrad(t["x"], dqkv, gq, rows=R, K=D, N=3 * D, x_pitch=D, dy_pitch=3 * D, use_tr=use_tr)
+        ops.bias_act_bwd(dqkv, None, gqb, R=R, N=3 * D, n_valid=3 * D, ld=3 * D)
+        dx = ops.linear_dgrad(dqkv, st.t16(f"{p}.qkv"), rows=R, N=3 * D, K=D, dy_pitch=3 * D, addend=ds1, out=ds1)
+        _ready(model, st, f"{p}.attention.self.query.weight")
+    te = tape["emb"]
+    ds0 = ops.add_ln_bwd(dx, te["sum"], None, st.p32("encoder.embeddings.LayerNorm.weight"), te["mean"], te["rstd"],
+                         st.g32("encoder.embeddings.LayerNorm.weight"), st.g32("encoder.embeddings.LayerNorm.bias"))
+    dfeats = ops.embed_bwd_scatter(ds0, st.g32("cls_token"), st.g32("encoder.embeddings.position_embeddings.weight"),
+                                   st.g32("encoder.embeddings.token_type_embeddings.weight"), B, S, D)
+    _ready(model, st, "cls_token")
+    return dfeats
+
+
+class _LrwFunction(torch.autograd.Function):
+    """One autograd node for the whole model: forward records a tape, backward replays it by hand and writes the
+    parameter gradients straight into the flat gradient buffer (the returned input gradients are all None)."""
+
+    @staticmethod
+    def forward(ctx, _anchor, model: TransformerLightningModule, st: _ParamStore, videos, audio_tokens, labels, need_grad: bool):
+        training = model.training
+        B, _, T, H, W = videos.shape
+        D, S = model.dim, T + 1
+        A, G, V = model.audio_alignment, model.vq_groups, model.audio_vocab_size
+        st.refresh_shadows()
+        tape: dict[str, Any] = {}
+        feats = _frontend_forward(model, st, tape, videos, training)
+        h = _encoder_forward(model, st, tape, feats, B, T)              # [B*S, D] bf16
+        # word head: rows s = 0
+        C = model.word_labels
+        logits_c, _ = ops.linear_fwd(h, st.s16("category_classifier.weight"), st.p32("category_classifier.bias"), rows=B, K=D, N=C,
+                                     x_pitch=D, out_f32=True, seq=(S, 0, 1))
+        hard = labels.dtype in (torch.int64, torch.int32)
+        lab_idx = labels.long() if hard else None
+        lab_prob = None if hard else labels.float().contiguous()
+        loss_c, lse_c = ops.ce_fwd(logits_c, C, lab_idx, lab_prob, B, C, model.label_smoothing)
+        # audio head: rows s = 1..T, logits [B*T, A*G*V] == [B*T*A*G, V]
+        NA = A * G * V
+        logits_a, _ = ops.linear_fwd(h, st.s16("audio_projection.weight"), st.p32("audio_projection.bias"), rows=B * T, K=D, N=NA,
+                                     x_pitch=D, seq=(S, 1, T))
+        tok = audio_tokens.reshape(-1)
+        loss_a, lse_a = ops.ce_fwd(logits_a, V, tok, None, B * T * A * G, V, 0.0)
+        acc = ops.topk_acc(logits_c, lab_idx, lab_prob)
+        model._last = dict(logits_category=logits_c, logits_audio=logits_a, feats=feats, hidden=h)
+        if need_grad:
+            tape["head"] = dict(h=h, logits_c=logits_c, lse_c=lse_c, lab_idx=lab_idx, lab_prob=lab_prob, logits_a=logits_a, lse_a=lse_a,
+                                tok=tok, dims=(B, T, D, S, A, G, V, C))
+            ctx.tape = tape
+            ctx.model = model
+            ctx.st = st
+        ctx.mark_non_differentiable(acc)
+        return loss_c, loss_a, acc
+
+    @staticmethod
+    def backward(ctx, g_cat, g_audio, _g_acc):
+        model, st, tape = ctx.model, ctx.st, ctx.tape
+        th = tape["head"]
+        B, T, D, S, A, G, V, C = th["dims"]
+        dev = th["h"].device
+        use_tr = model.use_tr
+        if not getattr(model, "accumulate_grads", False):
+            st.zero_grad()
+        st.rebind_grads()
+        g_cat = (g_cat if g_cat is not None else torch.zeros((), device=dev)).float().contiguous()
+        g_audio = (g_audio if g_audio is not None else torch.zeros((), device=dev)).float().contiguous()
+        NA = A * G * V
+        Cp = (C + 63) // 64 * 64
+        dla = torch.empty((B * T, NA), dtype=BF16, device=dev)
+        ops.ce_bwd(th["logits_a"], V, th["tok"], None, B * T * A * G, V, 0.0, th["lse_a"], g_audio, dla, V)
+        dlc = torch.zeros((B, Cp), dtype=BF16, device=dev)
+        ops.ce_bwd(th["logits_c"], C, th["lab_idx"], th["lab_prob"], B, C, model.label_smoothing, th["lse_c"], g_cat, dlc, Cp)
+        h = th["h"]
+        ops.linear_wgrad(h, dla, st.g32("audio_projection.weight"), rows=B * T, K=D, N=NA, x_pitch=D, dy_pitch=NA, seq=(S, 1, T), use_tr=use_tr)
+        ops.bias_act_bwd(dla, None, st.g32("audio_projection.bias"), R=B * T, N=NA, n_valid=NA, ld=NA)
+        ops.linear_wgrad(h, dlc, st.g32("category_classifier.weight"), rows=B, K=D, N=C, x_pitch=D, dy_pitch=Cp, seq=(S, 0, 1), use_tr=use_tr)
+        ops.bias_act_bwd(dlc, None, st.g32("category_classifier.bias"), R=B, N=Cp, n_valid=C, ld=Cp)
+        dh = torch.empty((B * S, D), dtype=BF16, device=dev)
+        ops.linear_dgrad(dla, st.t16("audio_projection.weight"), rows=B * T, N=NA, K=D, dy_pitch=NA, out=dh, seq=(S, 1, T))
+        ops.linear_dgrad(dlc, st.t16("category_classifier.weight"), rows=B, N=C, K=D, dy_pitch=Cp, out=dh, seq=(S, 0, 1))
+        _ready(model, st, "audio_projection.weight")
+        dfeats = _encoder_backward(model, st, tape, dh, B, T)
+        _frontend_backward(model, st, tape, dfeats)
+        ctx.tape = None
+        return None, None, None, None, None, None, None

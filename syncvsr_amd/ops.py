@@ -1,0 +1,347 @@
+"""Thin host-side wrappers over the C ABI (include/syncvsr_hip.h): tensors in, launches out.
+
+PyTorch is used here only as the owner of device memory and streams; every computation is a call into
+libsyncvsr_hip.so on the current HIP stream.  Tensors are NHWC bf16 activations unless stated.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+STAT_SLOTS = 64
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _ints(v: Sequence[int]):
+    return (ctypes.c_int * len(v))(*v)
+
+
+def _call(name: str, *args) -> None:
+    rc = getattr(_lib.load(), name)(*args)
+    if rc != 0:
+        _lib.check(rc, name)
+
+
+# --------------------------------------------------------------------------------------------------
+# implicit GEMM
+# --------------------------------------------------------------------------------------------------
+def igemm_fwd(inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
+              Co: int, Ho: int, Wo: int, out_pitch: int, Ha: int, Wa: int, S: int = 1, OS: int = 1, oy0: int = 0, ox0: int = 0,
+              taps: Sequence[tuple[int, int, int]] = ((0, 0, 0),), wt_taps: int = 1, bias: Optional[torch.Tensor] = None,
+              addend: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, gelu: bool = False,
+              out_pre: Optional[torch.Tensor] = None, out_f32: bool = False) -> None:
+    dy, dx, tw = zip(*taps)
+    _call("svsr_igemm_fwd", _p(inp), _p(wt), _p(out), _p(out_pre), _p(bias), _p(addend), _p(stats), Nimg, Hi, Wi, Ci, in_pitch,
+          Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw),
+          int(gelu), int(out_f32), _stream())
+
+
+def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
+                Co: int, Ho: int, Wo: int, out_pitch: int, Ha: int, Wa: int, S: int = 1, OS: int = 1, oy0: int = 0, ox0: int = 0,
+                taps: Sequence[tuple[int, int, int]] = ((0, 0, 0),), wt_taps: int = 1, use_tr: bool = True) -> None:
+    dy, dx, tw = zip(*taps)
+    _call("svsr_igemm_wgrad", _p(x), _p(dyp), _p(dw), Nimg, Hi, Wi, Ci, in_pitch, Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0,
+          len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw), int(use_tr), _stream())
+
+
+def conv_out_size(n: int, k: int, stride: int, pad: int) -> int:
+    return (n + 2 * pad - k) // stride + 1
+
+
+def conv2d_fwd(x: torch.Tensor, w16: torch.Tensor, k: int, stride: int, pad: int, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [N,H,W,Ci] bf16, w16 bf16 [Co][k][k][Ci] -> [N,Ho,Wo,Co] bf16 (+ BatchNorm partial sums into `stats`)."""
+    N, H, W, Ci = x.shape
+    Co = w16.shape[0]
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    out = torch.empty((N, Ho, Wo, Co), dtype=BF16, device=x.device)
+    taps = [(kh - pad, kw - pad, kh * k + kw) for kh in range(k) for kw in range(k)]
+    igemm_fwd(x, w16, out, Nimg=N, Hi=H, Wi=W, Ci=Ci, in_pitch=Ci, Co=Co, Ho=Ho, Wo=Wo, out_pitch=Co, Ha=Ho, Wa=Wo,
+              S=stride, taps=taps, wt_taps=k * k, stats=stats)
+    return out
+
+
+def conv2d_dgrad(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad: int, in_hw: tuple[int, int],
+                 addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dy [N,Ho,Wo,Co], w16t bf16 [Ci][k][k][Co] (transposed shadow) -> dx [N,H,W,Ci] (+ addend).
+
+    Stride 1 is one launch; stride 2 is one launch per input-parity class with that class's taps
+    (the transposed convolution never multiplies by the inserted zeros)."""
+    N, Ho, Wo, Co = dy.shape
+    Ci = w16t.shape[0]
+    H, W = in_hw
+    dx = None
+    classes = [(py, px) for py in range(stride) for px in range(stride)]
+    plans = []
+    for py, px in classes:
+        taps = []
+        for kh in range(k):
+            if (py + pad - kh) % stride:
+                continue
+            for kw in range(k):
+                if (px + pad - kw) % stride:
+                    continue
+                taps.append(((py + pad - kh) // stride, (px + pad - kw) // stride, kh * k + kw))
+        plans.append((py, px, taps))
+    full = all(len(t) > 0 for _, _, t in plans)
+    if full or addend is not None:
+        dx = torch.empty((N, H, W, Ci), dtype=BF16, device=dy.device) if addend is None else addend
+    else:
+        dx = torch.zeros((N, H, W, Ci), dtype=BF16, device=dy.device)
+    if addend is not None and not full:
+        pass  # classes without taps keep the addend's values (dx aliases addend)
+    for py, px, taps in plans:
+        if not taps:
+            continue
+        Ha, Wa = (H - py + stride - 1) // stride, (W - px + stride - 1) // stride
+        if Ha <= 0 or Wa <= 0:
+            continue
+        igemm_fwd(dy, w16t, dx, Nimg=N, Hi=Ho, Wi=Wo, Ci=Co, in_pitch=Co, Co=Ci, Ho=H, Wo=W, out_pitch=Ci, Ha=Ha, Wa=Wa,
+                  S=1, OS=stride, oy0=py, ox0=px, taps=taps, wt_taps=k * k, addend=addend)
+    return dx
+
+
+def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: int, stride: int, pad: int, use_tr: bool = True) -> None:
+    """dw fp32 [Co][k][k][Ci] += sum dy[n,y,x,co] * x[n, y*s+kh-pad, x*s+kw-pad, ci]."""
+    N, H, W, Ci = x.shape
+    _, Ho, Wo, Co = dy.shape
+    taps = [(kh - pad, kw - pad, kh * k + kw) for kh in range(k) for kw in range(k)]
+    igemm_wgrad(x, dy, dw, Nimg=N, Hi=H, Wi=W, Ci=Ci, in_pitch=Ci, Co=Co, Ho=Ho, Wo=Wo, out_pitch=Co, Ha=Ho, Wa=Wo, S=stride,
+                taps=taps, wt_taps=k * k, use_tr=use_tr)
+
+
+def linear_fwd(x: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor], *, rows: int, K: int, N: int, x_pitch: int,
+               out: Optional[torch.Tensor] = None, out_pitch: Optional[int] = None, gelu: bool = False,
+               out_f32: bool = False, addend: Optional[torch.Tensor] = None,
+               seq: Optional[tuple[int, int, int]] = None) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """out[rows, N] = x[rows, K] @ w16[N, K]^T (+bias)(+addend)(gelu).  `seq=(S, s0, n)` selects rows s0..s0+n-1 of every
+    length-S sequence of x (x is [B*S, K]) as the source and writes a dense [B*n, N] result."""
+    out_pitch = out_pitch or N
+    if out is None:
+        out = torch.empty((rows, out_pitch), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    pre = torch.empty_like(out) if gelu else None
+    if seq is None:
+        geo = dict(Nimg=rows, Hi=1, Wi=1, Ha=1, Wa=1, Ho=1, Wo=1, taps=((0, 0, 0),))
+    else:
+        S, s0, n = seq
+        geo = dict(Nimg=rows // n, Hi=1, Wi=S, Ha=1, Wa=n, Ho=1, Wo=n, taps=((0, s0, 0),))
+    igemm_fwd(x, w16, out, Ci=K, in_pitch=x_pitch, Co=N, out_pitch=out_pitch, bias=bias, addend=addend, gelu=gelu, out_pre=pre,
+              out_f32=out_f32, **geo)
+    return out, pre
+
+
+def linear_dgrad(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, K: int, dy_pitch: int, out: Optional[torch.Tensor] = None,
+                 addend: Optional[torch.Tensor] = None, seq: Optional[tuple[int, int, int]] = None) -> torch.Tensor:
+    """dx[rows, K] = dy[rows, N] @ w16t[K, Npad]^T-of-transpose, i.e. dy @ W.  With `seq=(S, s0, n)` the dense dy rows
+    [B*n] are scattered to rows s0.. of every length-S sequence of dx [B*S, K]."""
+    Np = w16t.shape[-1]
+    if seq is None:
+        if out is None:
+            out = torch.empty((rows, K), dtype=BF16, device=dy.device)
+        geo = dict(Nimg=rows, Hi=1, Wi=1, Ha=1, Wa=1, Ho=1, Wo=1, ox0=0)
+    else:
+        S, s0, n = seq
+        assert out is not None
+        geo = dict(Nimg=rows // n, Hi=1, Wi=n, Ha=1, Wa=n, Ho=1, Wo=S, ox0=s0)
+    igemm_fwd(dy, w16t, out, Ci=Np, in_pitch=dy_pitch, Co=K, out_pitch=K, addend=addend, **geo)
+    return out
+
+
+def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, rows: int, K: int, N: int, x_pitch: int, dy_pitch: int,
+                 seq: Optional[tuple[int, int, int]] = None, use_tr: bool = True) -> None:
+    """dw fp32 [N][K] += dy[rows, N]^T @ x[rows, K]."""
+    if seq is None:
+        geo = dict(Nimg=rows, Hi=1, Wi=1, Ha=1, Wa=1, Ho=1, Wo=1, taps=((0, 0, 0),))
+    else:
+        S, s0, n = seq
+        geo = dict(Nimg=rows // n, Hi=1, Wi=S, Ha=1, Wa=n, Ho=1, Wo=n, taps=((0, s0, 0),))
+    igemm_wgrad(x, dy, dw, Ci=K, in_pitch=x_pitch, Co=N, out_pitch=dy_pitch, use_tr=use_tr, **geo)
+
+
+# --------------------------------------------------------------------------------------------------
+# stem
+# --------------------------------------------------------------------------------------------------
+def stem_conv_fwd(videos: torch.Tensor, w: torch.Tensor, stats: Optional[torch.Tensor]) -> torch.Tensor:
+    B, C, T, H, W = videos.shape
+    assert C == 1 and videos.dtype == torch.float32 and videos.is_contiguous()
+    out = torch.empty((B * T, H // 2, W // 2, 64), dtype=BF16, device=videos.device)
+    _call("svsr_stem_conv_fwd", _p(videos), _p(w), _p(out), _p(stats), B, T, H, W, _stream())
+    return out
+
+
+def stem_conv_wgrad(videos: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, use_tr: bool = True) -> None:
+    B, _, T, H, W = videos.shape
+    _call("svsr_stem_conv_wgrad", _p(videos), _p(dy), _p(dw), B, T, H, W, int(use_tr), _stream())
+
+
+def stem_bn_gelu_pool_fwd(x: torch.Tensor, mean, rstd, gamma, beta) -> tuple[torch.Tensor, torch.Tensor]:
+    N, Hc, Wc, C = x.shape
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    y = torch.empty((N, Hp, Wp, C), dtype=BF16, device=x.device)
+    amax = torch.empty((N, Hp, Wp, C), dtype=torch.uint8, device=x.device)
+    _call("svsr_stem_bn_gelu_pool_fwd", _p(x), _p(y), _p(amax), _p(mean), _p(rstd), _p(gamma), _p(beta), N, Hc, Wc, Hp, Wp, C, _stream())
+    return y, amax
+
+
+def stem_bn_gelu_pool_bwd(dpool, amax, x, mean, rstd, gamma, beta, slots, coef, dgamma, dbeta) -> torch.Tensor:
+    N, Hc, Wc, C = x.shape
+    _, Hp, Wp, _ = dpool.shape
+    dx = torch.empty_like(x)
+    _call("svsr_stem_bn_gelu_pool_bwd", _p(dpool), _p(amax), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slots), _p(coef),
+          _p(dgamma), _p(dbeta), _p(dx), N, Hc, Wc, Hp, Wp, C, _stream())
+    return dx
+
+
+# --------------------------------------------------------------------------------------------------
+# BatchNorm / activation / pooling
+# --------------------------------------------------------------------------------------------------
+def bn_finalize(slots, C: int, count: int, mean, rstd, running_mean=None, running_var=None, nbt=None) -> None:
+    _call("svsr_bn_finalize", _p(slots), C, float(count), BN_EPS, BN_MOMENTUM, _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+          _p(nbt), _stream())
+
+
+def bn_eval_prepare(running_mean, running_var, mean, rstd) -> None:
+    _call("svsr_bn_eval_prepare", _p(running_mean), _p(running_var), running_mean.numel(), BN_EPS, _p(mean), _p(rstd), _stream())
+
+
+def bn_act_fwd(x, res, mean, rstd, gamma, beta, act: int) -> torch.Tensor:
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    _call("svsr_bn_act_fwd", _p(x), _p(res), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), x.numel() // C, C, act, _stream())
+    return y
+
+
+def bn_act_bwd(dy, y, x, mean, rstd, gamma, slots, coef, dgamma, dbeta, act: int, want_dres: bool):
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    _call("svsr_bn_act_bwd", _p(dy), _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(slots), _p(coef), _p(dgamma), _p(dbeta), _p(dx),
+          _p(dres), x.numel() // C, C, act, _stream())
+    return dx, dres
+
+
+def avgpool_fwd(x: torch.Tensor) -> torch.Tensor:
+    N, H, W, C = x.shape
+    y = torch.empty((N, C), dtype=BF16, device=x.device)
+    _call("svsr_avgpool_fwd", _p(x), _p(y), N, H * W, C, _stream())
+    return y
+
+
+def avgpool_bwd(dy: torch.Tensor, shape) -> torch.Tensor:
+    N, H, W, C = shape
+    dx = torch.empty(shape, dtype=BF16, device=dy.device)
+    _call("svsr_avgpool_bwd", _p(dy), _p(dx), N, H * W, C, _stream())
+    return dx
+
+
+# --------------------------------------------------------------------------------------------------
+# transformer passes
+# --------------------------------------------------------------------------------------------------
+def add_ln_fwd(a, r, gamma, beta, eps: float):
+    R, D = a.shape
+    y = torch.empty_like(a)
+    mean = torch.empty(R, dtype=torch.float32, device=a.device)
+    rstd = torch.empty(R, dtype=torch.float32, device=a.device)
+    _call("svsr_add_ln_fwd", _p(a), _p(r), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), R, D, eps, _stream())
+    return y, mean, rstd
+
+
+def add_ln_bwd(dy, a, r, gamma, mean, rstd, dgamma, dbeta) -> torch.Tensor:
+    R, D = a.shape
+    ds = torch.empty_like(a)
+    _call("svsr_add_ln_bwd", _p(dy), _p(a), _p(r), _p(gamma), _p(mean), _p(rstd), _p(ds), _p(dgamma), _p(dbeta), R, D, _stream())
+    return ds
+
+
+def embed_ln_fwd(feats, cls, pos, type0, gamma, beta, B: int, S: int, D: int, eps: float):
+    dev = feats.device
+    s = torch.empty((B * S, D), dtype=BF16, device=dev)
+    y = torch.empty((B * S, D), dtype=BF16, device=dev)
+    mean = torch.empty(B * S, dtype=torch.float32, device=dev)
+    rstd = torch.empty(B * S, dtype=torch.float32, device=dev)
+    _call("svsr_embed_ln_fwd", _p(feats), _p(cls), _p(pos), _p(type0), _p(gamma), _p(beta), _p(s), _p(y), _p(mean), _p(rstd), B, S, D,
+          eps, _stream())
+    return s, y, mean, rstd
+
+
+def embed_bwd_scatter(ds, dcls, dpos, dtype0, B: int, S: int, D: int) -> torch.Tensor:
+    dfeats = torch.empty((B * (S - 1), D), dtype=BF16, device=ds.device)
+    _call("svsr_embed_bwd_scatter", _p(ds), _p(dfeats), _p(dcls), _p(dpos), _p(dtype0), B, S, D, _stream())
+    return dfeats
+
+
+def attn_fwd(qkv, B: int, S: int, H: int, dh: int):
+    ctx = torch.empty((B * S, H * dh), dtype=BF16, device=qkv.device)
+    probs = torch.empty((B * H, S, S), dtype=BF16, device=qkv.device)
+    _call("svsr_attn_fwd", _p(qkv), _p(ctx), _p(probs), B, S, H, dh, 1.0 / (dh ** 0.5), _stream())
+    return ctx, probs
+
+
+def attn_bwd(dctx, qkv, probs, B: int, S: int, H: int, dh: int) -> torch.Tensor:
+    dqkv = torch.empty_like(qkv)
+    _call("svsr_attn_bwd", _p(dctx), _p(qkv), _p(probs), _p(dqkv), B, S, H, dh, 1.0 / (dh ** 0.5), _stream())
+    return dqkv
+
+
+def bias_act_bwd(dy, z, db, *, R: int, N: int, n_valid: int, ld: int) -> torch.Tensor:
+    """db[:n_valid] += column sums of dz, where dz = dy * gelu'(z) if z is given (returned) else dy."""
+    dz = torch.empty_like(dy) if z is not None else None
+    _call("svsr_bias_act_bwd", _p(dy), _p(z), _p(dz), _p(db), R, N, n_valid, ld, _stream())
+    return dz if z is not None else dy
+
+
+# --------------------------------------------------------------------------------------------------
+# losses / metric / optimiser
+# --------------------------------------------------------------------------------------------------
+def ce_fwd(logits, ld: int, target_idx, target_prob, R: int, V: int, smoothing: float):
+    dev = logits.device
+    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    lse = torch.empty(R, dtype=torch.float32, device=dev)
+    ldt = 0 if target_prob is None else target_prob.shape[-1]
+    _call("svsr_ce_fwd", _p(logits), int(logits.dtype == torch.float32), ld, _p(target_idx), _p(target_prob), ldt, R, V,
+          float(smoothing), _p(loss), _p(lse), _stream())
+    return loss, lse
+
+
+def ce_bwd(logits, ld: int, target_idx, target_prob, R: int, V: int, smoothing: float, lse, gout, dlogits, ldo: int) -> None:
+    ldt = 0 if target_prob is None else target_prob.shape[-1]
+    _call("svsr_ce_bwd", _p(logits), int(logits.dtype == torch.float32), ld, _p(target_idx), _p(target_prob), ldt, R, V,
+          float(smoothing), _p(lse), _p(gout), _p(dlogits), ldo, _stream())
+
+
+def topk_acc(logits_f32, labels, soft_labels) -> torch.Tensor:
+    B, C = logits_f32.shape
+    out = torch.zeros(2, dtype=torch.float32, device=logits_f32.device)
+    _call("svsr_topk_acc", _p(logits_f32), _p(labels), _p(soft_labels), B, C, _p(out), _stream())
+    return out
+
+
+def grad_sumsq(g: torch.Tensor, opt_state: torch.Tensor) -> None:
+    _call("svsr_grad_sumsq", _p(g), g.numel(), _p(opt_state), _stream())
+
+
+def adamw_step(p, g, m, v, shadow, decay_end: int, lr: float, betas, eps: float, weight_decay: float, max_norm: float, warmup: int,
+               total_steps: int, opt_state) -> None:
+    _call("svsr_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), decay_end, lr, betas[0], betas[1], eps, weight_decay,
+          max_norm, warmup, total_steps, _p(opt_state), _stream())
+
+
+def cast_bf16(src: torch.Tensor, dst: torch.Tensor) -> None:
+    _call("svsr_cast_bf16", _p(src), _p(dst), src.numel(), _stream())
+
+
+def transpose_cast_multi(src, dst, table: torch.Tensor, n_entries: int) -> None:
+    _call("svsr_transpose_cast_multi", _p(src), _p(dst), _p(table), n_entries, _stream())

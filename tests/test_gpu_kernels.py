@@ -1,0 +1,405 @@
+"""Kernel-level parity (-m gpu): every C-ABI entry point against a plain torch-fp32 CPU restatement of the same op,
+fed the same bf16-rounded inputs.  Tolerances are stated per class of tensor:
+  * bf16 activations / activation-gradients: max-abs error <= 1.5e-2 * max|ref| and relative L2 error <= 6e-3
+    (one bf16 rounding of the output = 2^-9 relative, plus fp32 accumulation-order noise)
+  * fp32 outputs (weight gradients, statistics, losses): relative L2 error <= 2e-3 (inputs are bf16-exact, products are
+    accumulated in fp32 on both sides).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from syncvsr_amd import _lib
+
+    _lib.load()      # fail loudly if the extension is missing
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(BF)
+
+
+def check(got, ref, name, max_tol=1.5e-2, l2_tol=6e-3):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite values"
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    l2 = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+    assert err <= max_tol * scale and l2 <= l2_tol, f"{name}: max err {err:.3e} (scale {scale:.3e}), rel L2 {l2:.3e}"
+
+
+def nhwc(t):  # [N,C,H,W] fp32 -> [N,H,W,C]
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # N, H, W, Ci, Co, k, stride, pad
+    (3, 11, 11, 64, 64, 3, 1, 1),
+    (2, 12, 12, 64, 128, 3, 2, 1),
+    (2, 11, 11, 64, 128, 3, 2, 1),
+    (3, 6, 6, 128, 256, 1, 2, 0),
+    (5, 3, 3, 256, 512, 3, 1, 1),
+    (40, 22, 22, 64, 64, 3, 1, 1),      # M = 19360 -> 128x64 tiles
+    (70, 11, 11, 128, 128, 3, 1, 1),    # M = 8470  -> 128x128 tiles
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_stats(dev, case):
+    from syncvsr_amd import ops
+
+    N, H, W, Ci, Co, k, s, p = case
+    x = rnd((N, H, W, Ci), 1)
+    w = rnd((Co, k, k, Ci), 2, 1.0 / math.sqrt(k * k * Ci))
+    slots = torch.zeros(ops.STAT_SLOTS * 2 * Co, device=dev)
+    out = ops.conv2d_fwd(x.to(dev), w.to(dev), k, s, p, stats=slots)
+    ref = F.conv2d(nchw(x.float()), w.float().permute(0, 3, 1, 2), stride=s, padding=p)
+    check(out, nhwc(ref), "conv_fwd")
+    st = slots.view(ops.STAT_SLOTS, 2, Co).sum(0).cpu()
+    count = ref.numel() // Co
+    sum_err = (st[0] - ref.sum((0, 2, 3))).abs()
+    assert bool((sum_err <= 2e-3 * torch.sqrt(count * (ref * ref).sum((0, 2, 3)))).all()), "stats.sum"
+    check(st[1], (ref * ref).sum((0, 2, 3)), "stats.sumsq", 3e-3, 2e-3)
+
+
+@pytest.mark.parametrize("case", CONV_CASES[:6])
+def test_conv_dgrad(dev, case):
+    from syncvsr_amd import ops
+
+    N, H, W, Ci, Co, k, s, p = case
+    Ho, Wo = ops.conv_out_size(H, k, s, p), ops.conv_out_size(W, k, s, p)
+    dy = rnd((N, Ho, Wo, Co), 3)
+    w = rnd((Co, k, k, Ci), 4, 1.0 / math.sqrt(k * k * Co))
+    wt = w.permute(3, 1, 2, 0).contiguous()                # [Ci][k][k][Co]
+    xs = torch.zeros(N, Ci, H, W, requires_grad=True)
+    F.conv2d(xs, w.float().permute(0, 3, 1, 2), stride=s, padding=p).backward(nchw(dy.float()))
+    dx = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), k, s, p, (H, W))
+    check(dx, nhwc(xs.grad), "conv_dgrad")
+    add = rnd((N, H, W, Ci), 5)
+    dx2 = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), k, s, p, (H, W), addend=add.to(dev).clone())
+    check(dx2, nhwc(xs.grad) + add.float(), "conv_dgrad+addend")
+
+
+@pytest.mark.parametrize("use_tr", [False, True])
+@pytest.mark.parametrize("case", CONV_CASES[:6])
+def test_conv_wgrad(dev, case, use_tr):
+    from syncvsr_amd import ops
+
+    N, H, W, Ci, Co, k, s, p = case
+    Ho, Wo = ops.conv_out_size(H, k, s, p), ops.conv_out_size(W, k, s, p)
+    x = rnd((N, H, W, Ci), 6)
+    dy = rnd((N, Ho, Wo, Co), 7)
+    ws = torch.zeros(Co, Ci, k, k, requires_grad=True)
+    F.conv2d(nchw(x.float()), ws, stride=s, padding=p).backward(nchw(dy.float()))
+    dw = torch.zeros(Co, k, k, Ci, device=dev)
+    ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw, k, s, p, use_tr=use_tr)
+    check(dw, ws.grad.permute(0, 2, 3, 1), f"conv_wgrad tr={use_tr}", 3e-3, 2e-3)
+
+
+def test_linear_variants(dev):
+    from syncvsr_amd import ops
+
+    B, S, K, N = 3, 7, 512, 192
+    x = rnd((B * S, K), 8)
+    w = rnd((N, K), 9, 1 / math.sqrt(K))
+    b = torch.randn(N, generator=torch.Generator().manual_seed(10))
+    ref = F.linear(x.float(), w.float(), b)
+    out, _ = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), rows=B * S, K=K, N=N, x_pitch=K)
+    check(out, ref, "linear")
+    out, pre = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), rows=B * S, K=K, N=N, x_pitch=K, gelu=True)
+    check(pre, ref, "linear.pre")
+    check(out, F.gelu(ref), "linear.gelu")
+    out, _ = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), rows=B * (S - 1), K=K, N=N, x_pitch=K, seq=(S, 1, S - 1), out_f32=True)
+    check(out, ref.view(B, S, N)[:, 1:].reshape(-1, N), "linear.seq f32", 2e-3, 1e-3)
+    # odd N (classifier-like) with fp32 output, rows s = 0
+    N2 = 100
+    w2 = rnd((N2, K), 11, 1 / math.sqrt(K))
+    out, _ = ops.linear_fwd(x.to(dev), w2.to(dev), None, rows=B, K=K, N=N2, x_pitch=K, seq=(S, 0, 1), out_f32=True)
+    check(out, F.linear(x.float(), w2.float()).view(B, S, N2)[:, 0], "linear.cls", 2e-3, 1e-3)
+    # dgrad with scatter + addend, wgrad with gather
+    dy = rnd((B * (S - 1), N), 12)
+    wt = torch.zeros(K, 1, N, dtype=BF)
+    wt[:, 0, :] = w.t()
+    dx = torch.zeros(B * S, K, dtype=BF, device=dev)
+    ops.linear_dgrad(dy.to(dev), wt.to(dev), rows=B * (S - 1), N=N, K=K, dy_pitch=N, out=dx, seq=(S, 1, S - 1))
+    ref_dx = torch.zeros(B, S, K)
+    ref_dx[:, 1:] = (dy.float() @ w.float()).view(B, S - 1, K)
+    check(dx, ref_dx.view(-1, K), "linear.dgrad.scatter")
+    for use_tr in (False, True):
+        dw = torch.zeros(N, K, device=dev)
+        ops.linear_wgrad(x.to(dev), dy.to(dev), dw, rows=B * (S - 1), K=K, N=N, x_pitch=K, dy_pitch=N, seq=(S, 1, S - 1), use_tr=use_tr)
+        ref_dw = dy.float().t() @ x.float().view(B, S, K)[:, 1:].reshape(-1, K)
+        check(dw, ref_dw, f"linear.wgrad tr={use_tr}", 3e-3, 2e-3)
+    db = torch.zeros(N, device=dev)
+    z = rnd((B * (S - 1), N), 13)
+    dz = ops.bias_act_bwd(dy.to(dev), z.to(dev), db, R=B * (S - 1), N=N, n_valid=N - 3, ld=N)
+    zz = z.float().requires_grad_(True)
+    F.gelu(zz).backward(dy.float())
+    check(dz, zz.grad, "gelu_bwd")
+    ref_db = zz.grad.to(BF).float().sum(0)
+    ref_db[N - 3:] = 0
+    check(db, ref_db, "bias_grad", 1e-2, 6e-3)
+
+
+STEM_CASES = [(2, 5, 24, 24), (1, 3, 88, 88), (2, 2, 16, 40)]
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_stem_conv(dev, case):
+    from syncvsr_amd import ops
+
+    B, T, H, W = case
+    g = torch.Generator().manual_seed(20)
+    vid = torch.randn(B, 1, T, H, W, generator=g)
+    w = (torch.rand(64, 1, 5, 7, 7, generator=g) - 0.5) * 0.2
+    slots = torch.zeros(ops.STAT_SLOTS * 2 * 64, device=dev)
+    out = ops.stem_conv_fwd(vid.to(dev), w.to(dev).reshape(-1), slots)
+    ref = F.conv3d(vid.to(BF).float(), w.to(BF).float(), stride=(1, 2, 2), padding=(2, 3, 3))      # [B,64,T,Ho,Wo]
+    ref_nhwc = ref.permute(0, 2, 3, 4, 1).reshape(B * T, H // 2, W // 2, 64)
+    check(out, ref_nhwc, "stem_conv_fwd")
+    st = slots.view(ops.STAT_SLOTS, 2, 64).sum(0).cpu()
+    check(st[1], (ref * ref).sum((0, 2, 3, 4)), "stem.stats.sumsq", 3e-3, 2e-3)
+    dy = rnd((B * T, H // 2, W // 2, 64), 21)
+    ws = w.to(BF).float().clone().requires_grad_(True)
+    F.conv3d(vid.to(BF).float(), ws, stride=(1, 2, 2), padding=(2, 3, 3)).backward(
+        dy.float().view(B, T, H // 2, W // 2, 64).permute(0, 4, 1, 2, 3))
+    for use_tr in (False, True):
+        dw = torch.zeros(64 * 245, device=dev)
+        ops.stem_conv_wgrad(vid.to(dev), dy.to(dev), dw, use_tr=use_tr)
+        check(dw.view(64, 1, 5, 7, 7), ws.grad, f"stem_conv_wgrad tr={use_tr}", 4e-3, 3e-3)
+
+
+def _bn_ref(x, gamma, beta, res, act):
+    dims = (0, 1, 2)
+    mean = x.mean(dims)
+    var = x.var(dims, unbiased=False)
+    y = (x - mean) * torch.rsqrt(var + 1e-5) * gamma + beta
+    if res is not None:
+        y = y + res
+    if act:
+        y = torch.relu(y)
+    return y, mean, var
+
+
+@pytest.mark.parametrize("C,act,use_res", [(64, 1, False), (128, 1, True), (512, 0, False), (256, 1, True)])
+def test_bn_act(dev, C, act, use_res):
+    from syncvsr_amd import ops
+
+    N, H, W = 5, 7, 6
+    x = rnd((N, H, W, C), 30, 2.0) + 0.3
+    res = rnd((N, H, W, C), 31) if use_res else None
+    g = torch.Generator().manual_seed(32)
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    dy = rnd((N, H, W, C), 33)
+    xf = x.float().requires_grad_(True)
+    rf = res.float().requires_grad_(True) if use_res else None
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yref, mean, var = _bn_ref(xf, gm, bt, rf, act)
+    yref.backward(dy.float())
+    # statistics through the slot protocol
+    slots = torch.zeros(ops.STAT_SLOTS, 2, C)
+    slots[3, 0] = x.float().sum((0, 1, 2))
+    slots[5, 1] = (x.float() ** 2).sum((0, 1, 2))
+    slots = slots.reshape(-1).to(dev)
+    m = torch.empty(C, device=dev); r = torch.empty(C, device=dev)
+    rm = torch.zeros(C, device=dev); rv = torch.ones(C, device=dev); nbt = torch.zeros((), dtype=torch.long, device=dev)
+    count = N * H * W
+    ops.bn_finalize(slots, C, count, m, r, rm, rv, nbt)
+    check(m, mean, "bn.mean", 1e-3, 1e-3)
+    check(r, torch.rsqrt(var + 1e-5), "bn.rstd", 1e-3, 1e-3)
+    check(rm, 0.1 * mean, "bn.running_mean", 1e-3, 1e-3)
+    check(rv, 0.9 + 0.1 * var * count / (count - 1), "bn.running_var", 1e-3, 1e-3)
+    assert int(nbt.item()) == 1 and float(slots.abs().max()) == 0.0
+    y = ops.bn_act_fwd(x.to(dev), None if res is None else res.to(dev), m, r, gamma.to(dev), beta.to(dev), act)
+    check(y, yref, "bn_act_fwd")
+    coef = torch.empty(3 * C, device=dev)
+    dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+    dx, dres = ops.bn_act_bwd(dy.to(dev), y if act else None, x.to(dev), m, r, gamma.to(dev), slots, coef, dg, db, act, use_res)
+    check(dx, xf.grad, "bn_act_bwd.dx", 2e-2, 8e-3)
+    check(dg, gm.grad, "bn.dgamma", 1e-2, 6e-3)
+    check(db, bt.grad, "bn.dbeta", 1e-2, 6e-3)
+    if use_res:
+        check(dres, rf.grad, "bn.dres")
+    assert float(slots.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Hc,Wc", [(12, 12), (11, 9), (44, 44)])
+def test_stem_bn_gelu_pool(dev, Hc, Wc):
+    from syncvsr_amd import ops
+
+    N, C = 3, 64
+    x = rnd((N, Hc, Wc, C), 40, 1.5)
+    g = torch.Generator().manual_seed(41)
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    xf = nchw(x.float()).requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    mean = xf.mean((0, 2, 3)); var = xf.var((0, 2, 3), unbiased=False)
+    z = (xf - mean.view(1, -1, 1, 1)) * torch.rsqrt(var.view(1, -1, 1, 1) + 1e-5) * gm.view(1, -1, 1, 1) + bt.view(1, -1, 1, 1)
+    yref = F.max_pool2d(F.gelu(z), 3, 2, 1)
+    dpool = rnd(tuple(nhwc(yref).shape), 42)
+    yref.backward(nchw(dpool.float()))
+    m = mean.detach().to(dev); r = torch.rsqrt(var.detach() + 1e-5).to(dev)
+    y, amax = ops.stem_bn_gelu_pool_fwd(x.to(dev), m, r, gamma.to(dev), beta.to(dev))
+    check(y, nhwc(yref), "stem_pool_fwd")
+    slots = torch.zeros(ops.STAT_SLOTS * 2 * C, device=dev); coef = torch.empty(3 * C, device=dev)
+    dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+    dx = ops.stem_bn_gelu_pool_bwd(dpool.to(dev), amax, x.to(dev), m, r, gamma.to(dev), beta.to(dev), slots, coef, dg, db)
+    check(dx, nhwc(xf.grad), "stem_pool_bwd.dx", 2e-2, 8e-3)
+    check(dg, gm.grad, "stem.dgamma", 1e-2, 6e-3)
+    check(db, bt.grad, "stem.dbeta", 1e-2, 6e-3)
+
+
+def test_avgpool(dev):
+    from syncvsr_amd import ops
+
+    x = rnd((7, 3, 3, 512), 50)
+    y = ops.avgpool_fwd(x.to(dev))
+    check(y, x.float().mean((1, 2)), "avgpool_fwd")
+    dy = rnd((7, 512), 51)
+    dx = ops.avgpool_bwd(dy.to(dev), (7, 3, 3, 512))
+    check(dx, (dy.float() / 9).view(7, 1, 1, 512).expand(7, 3, 3, 512), "avgpool_bwd")
+
+
+def test_add_ln_and_embed(dev):
+    from syncvsr_amd import ops
+
+    B, S, D = 3, 6, 512
+    R = B * S
+    a, r = rnd((R, D), 60), rnd((R, D), 61)
+    g = torch.Generator().manual_seed(62)
+    gamma = 1 + 0.2 * torch.randn(D, generator=g); beta = 0.2 * torch.randn(D, generator=g)
+    dy = rnd((R, D), 63)
+    af, rf = a.float().requires_grad_(True), r.float().requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yref = F.layer_norm(af + rf, (D,), gm, bt, 1e-12)
+    yref.backward(dy.float())
+    y, mean, rstd = ops.add_ln_fwd(a.to(dev), r.to(dev), gamma.to(dev), beta.to(dev), 1e-12)
+    check(y, yref, "add_ln_fwd")
+    dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev)
+    ds = ops.add_ln_bwd(dy.to(dev), a.to(dev), r.to(dev), gamma.to(dev), mean, rstd, dg, db)
+    check(ds, af.grad, "add_ln_bwd.ds", 2e-2, 8e-3)
+    check(dg, gm.grad, "ln.dgamma", 1e-2, 6e-3)
+    check(db, bt.grad, "ln.dbeta", 1e-2, 6e-3)
+    # embeddings
+    feats = rnd((B * (S - 1), D), 64)
+    cls = torch.randn(D, generator=g); pos = 0.02 * torch.randn(16, D, generator=g); typ = 0.02 * torch.randn(2, D, generator=g)
+    e = torch.cat((cls.to(BF).float().view(1, 1, D).expand(B, 1, D), feats.float().view(B, S - 1, D)), 1) + pos[:S] + typ[0]
+    yref = F.layer_norm(e, (D,), gamma, beta, 1e-12)
+    s0, y0, m0, r0 = ops.embed_ln_fwd(feats.to(dev), cls.to(dev), pos.to(dev).reshape(-1), typ.to(dev).reshape(-1), gamma.to(dev), beta.to(dev), B, S, D, 1e-12)
+    check(s0, e.view(R, D), "embed.sum")
+    check(y0, yref.view(R, D), "embed.ln", 2e-2, 8e-3)
+    ds0 = rnd((R, D), 65)
+    dcls = torch.zeros(D, device=dev); dpos = torch.zeros(16 * D, device=dev); dtyp = torch.zeros(2 * D, device=dev)
+    dfe = ops.embed_bwd_scatter(ds0.to(dev), dcls, dpos, dtyp, B, S, D)
+    d3 = ds0.float().view(B, S, D)
+    check(dfe, d3[:, 1:].reshape(-1, D), "embed.dfeats", 1e-6, 1e-6)
+    check(dcls, d3[:, 0].sum(0), "embed.dcls", 1e-3, 1e-3)
+    check(dpos.view(16, D)[:S], d3.sum(0), "embed.dpos", 1e-3, 1e-3)
+    check(dtyp.view(2, D)[0], d3.sum((0, 1)), "embed.dtype", 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("S", [30, 6, 64])
+def test_attention(dev, S):
+    from syncvsr_amd import ops
+
+    B, H, dh = 2, 8, 64
+    D = H * dh
+    qkv = rnd((B * S, 3 * D), 70)
+    dctx = rnd((B * S, D), 71)
+    q = qkv.float().requires_grad_(True)
+    qq, kk, vv = (t.reshape(B, S, H, dh).transpose(1, 2) for t in q.view(B * S, 3, D).unbind(1))
+    pr = torch.softmax(qq @ kk.transpose(-1, -2) / math.sqrt(dh), -1)
+    ctx_ref = (pr @ vv).transpose(1, 2).reshape(B * S, D)
+    ctx_ref.backward(dctx.float())
+    ctx, probs = ops.attn_fwd(qkv.to(dev), B, S, H, dh)
+    check(ctx, ctx_ref, "attn_fwd")
+    check(probs.view(B, H, S, S), pr, "attn_probs")
+    dqkv = ops.attn_bwd(dctx.to(dev), qkv.to(dev), probs, B, S, H, dh)
+    check(dqkv, q.grad, "attn_bwd", 2e-2, 1e-2)
+
+
+def test_cross_entropy_and_topk(dev):
+    from syncvsr_amd import ops
+
+    g = torch.Generator().manual_seed(80)
+    R, V = 50, 320
+    logits = (torch.randn(R, V, generator=g) * 2).to(BF)
+    tgt = torch.randint(0, V, (R,), generator=g)
+    lf = logits.float().requires_grad_(True)
+    ref = F.cross_entropy(lf, tgt)
+    (ref * 3.0).backward()
+    loss, lse = ops.ce_fwd(logits.to(dev), V, tgt.to(dev), None, R, V, 0.0)
+    check(loss, ref, "ce.hard", 1e-5, 1e-5)
+    dl = torch.empty(R, V, dtype=BF, device=dev)
+    ops.ce_bwd(logits.to(dev), V, tgt.to(dev), None, R, V, 0.0, lse, torch.tensor(3.0, device=dev), dl, V)
+    check(dl, lf.grad, "ce.hard.bwd")
+    # fp32 logits, odd class count, label smoothing, hard + soft targets
+    B, C = 9, 500
+    lg = torch.randn(B, C, generator=g) * 3
+    hard = torch.randint(0, C, (B,), generator=g)
+    soft = torch.zeros(B, C); soft[torch.arange(B), hard] = 0.7; soft[torch.arange(B), (hard + 5) % C] += 0.3
+    for tgt_i, tgt_p in ((hard, None), (None, soft)):
+        lf = lg.clone().requires_grad_(True)
+        ref = F.cross_entropy(lf, tgt_i if tgt_i is not None else tgt_p, label_smoothing=0.1)
+        ref.backward()
+        loss, lse = ops.ce_fwd(lg.to(dev), C, None if tgt_i is None else tgt_i.to(dev), None if tgt_p is None else tgt_p.to(dev), B, C, 0.1)
+        check(loss, ref, "ce.ls", 1e-5, 1e-5)
+        dl = torch.zeros(B, 512, dtype=BF, device=dev)
+        ops.ce_bwd(lg.to(dev), C, None if tgt_i is None else tgt_i.to(dev), None if tgt_p is None else tgt_p.to(dev), B, C, 0.1, lse,
+                   torch.tensor(1.0, device=dev), dl, 512)
+        check(dl[:, :C], lf.grad, "ce.ls.bwd")
+        assert float(dl[:, C:].abs().max()) == 0.0
+        acc = ops.topk_acc(lg.to(dev), None if tgt_i is None else tgt_i.to(dev), None if tgt_p is None else tgt_p.to(dev)).cpu()
+        corr = lg.topk(5, dim=1)[1] == hard.unsqueeze(1)
+        assert abs(acc[0].item() - corr[:, 0].float().mean().item()) < 1e-6
+        assert abs(acc[1].item() - corr.float().amax(1).mean().item()) < 1e-6
+
+
+def test_adamw_clip_schedule(dev):
+    from oracle import lrw_oracle as O
+    from syncvsr_amd import ops
+
+    g = torch.Generator().manual_seed(90)
+    n, decay_end = 10007, 6000
+    p = torch.randn(n, generator=g); grads = [torch.randn(n, generator=g) * s for s in (3.0, 0.01, 1.0)]
+    m = torch.zeros(n); v = torch.zeros(n)
+    pd, md, vd = p.to(dev), m.to(dev), v.to(dev)
+    shadow = torch.zeros(n, dtype=BF, device=dev)
+    state = torch.zeros(4, dtype=torch.int32, device=dev)
+    lr, betas, eps, wd, max_norm, warm, total = 1e-2, (0.9, 0.999), 1e-6, 0.01, 1.0, 2, 10
+    # oracle: two "parameters" (decayed 2-D, undecayed 1-D)
+    pa, pb = p[:decay_end].clone().view(-1, 1), p[decay_end:].clone()
+    ma, mb, va, vb = torch.zeros_like(pa), torch.zeros_like(pb), torch.zeros_like(pa), torch.zeros_like(pb)
+    for step, gr in enumerate(grads):
+        gd = gr.to(dev)
+        ops.grad_sumsq(gd, state)
+        ops.adamw_step(pd, gd, md, vd, shadow, decay_end, lr, betas, eps, wd, max_norm, warm, total, state)
+        ga, gb = gr[:decay_end].clone().view(-1, 1), gr[decay_end:].clone()
+        O.clip_grad_norm([ga, gb], max_norm)
+        O.adamw_step([pa, pb], [ga, gb], [ma, mb], [va, vb], step + 1, O.cosine_lr(step, lr, warm, total), betas, eps, wd)
+    ref = torch.cat((pa.view(-1), pb))
+    check(pd, ref, "adamw.p", 1e-5, 1e-5)
+    check(shadow, ref, "adamw.shadow", 8e-3, 4e-3)
+    st = state.cpu()
+    assert int(st[0]) == 3
