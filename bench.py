@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Headline benchmark: SyncVSR LRW training throughput (lip-clips/s) on MI355X, BASELINE.json configs[1]/[2].
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = forward + backward + (RCCL gradient all-reduce) + global-norm clip + AdamW on a synthetic batch of 32
+clips of 29x88x88 per GPU, replayed as one HIP graph.  Rank 0 prints ONE JSON line.  Besides the
+contract fields it carries:
+  roofline      — dominant kernel of the step (by summed HIP-event time over profiled eager steps), its algorithmic
+                  FLOPs / time against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md), plus the per-kernel table
+  cpu_baseline  — oracle/lrw_oracle.py (torch fp32 port of the reference path) timed on this box's host cores, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TRAIN_FLOP_PER_CLIP = 56.9e9        # fwd + dgrad + wgrad, 29x88x88 clip, 6L-512d encoder
+MFMA_PEAK_BF16 = 2.5e15             # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(cfg, batch_size: int, budget_s: float = 20.0) -> dict:
+    """Times the CPU port (oracle) of the same training step — forward, backward, clip, AdamW — on the host cores."""
+    from oracle import lrw_oracle as O
+    from syncvsr_amd.init import init_state_dict, synthetic_batch
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = init_state_dict(cfg, seed=0)
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    params = [sd[k] for k in names]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    batch = synthetic_batch(cfg, batch_size, seed=1234)
+    opt = cfg.optim.optimizer
+    times = []
+    t_start = time.perf_counter()
+    step = 0
+    while True:
+        t0 = time.perf_counter()
+        for p in params:
+            p.grad = None
+        out = O.forward(sd, cfg, *batch, training=True)
+        out["loss_total"].backward()
+        with torch.no_grad():
+            grads = [p.grad for p in params]
+            O.clip_grad_norm(grads, float(cfg.train.gradient_clip_val))
+            O.adamw_step(params, grads, m, v, step + 1, O.cosine_lr(step, float(opt.lr), 15000, 270000), tuple(opt.betas),
+                         float(opt.eps), float(opt.weight_decay))
+        times.append(time.perf_counter() - t0)
+        step += 1
+        if (time.perf_counter() - t_start > budget_s and step >= 3) or step >= 50:
+            break
+    steady = sorted(times[1:] or times)
+    med = steady[len(steady) // 2]
+    return {"value": batch_size / med, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"{step} training steps (fwd+bwd+clip+AdamW, fp32) of oracle/lrw_oracle.py at batch {batch_size} x 29x88x88, "
+                      f"median step {med * 1e3:.0f} ms, {cores} torch threads"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--profile-steps", type=int, default=2, help="eager steps with per-launch HIP events for the roofline leg")
+    ap.add_argument("--force-collective", action="store_true", help="run the RCCL path even with one rank")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or args.force_collective
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from syncvsr_amd import ops
+    from syncvsr_amd.config import default_lrw_config
+    from syncvsr_amd.engine import TrainStep
+    from syncvsr_amd.init import synthetic_batch
+    from syncvsr_amd.model import Model
+
+    cfg = default_lrw_config()
+    cfg.train.batch_size = args.batch
+    model = Model(cfg, seed=0).to(dev).train()
+    batch = [t.to(dev) for t in synthetic_batch(cfg, args.batch, seed=1234 + rank)]
+    trainer = TrainStep(model, cfg, use_graph=not args.no_graph, always_reduce=args.force_collective)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        out = trainer.step(*batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(*batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist and world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(out["loss_total"].item())
+    clips_per_s = args.batch * world * args.steps / elapsed
+
+    result = {
+        "metric": "lip-clips/sec training (29x88x88)",
+        "value": round(clips_per_s, 2),
+        "unit": "clips/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": "LRW training step (fwd+bwd+allreduce+clip+AdamW), ResNet18 + 6-layer 512-d encoder + vq audio-token CE "
+                               "head, random-init weights, N(0,1) clips 29x88x88, uniform tokens/labels",
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                   "hip_graph": not args.no_graph},
+        "step_mfma_frac": round(clips_per_s / world * TRAIN_FLOP_PER_CLIP / MFMA_PEAK_BF16, 5),
+        "final_loss": round(loss, 4),
+    }
+
+    if rank == 0:
+        # ---- roofline leg: eager steps with HIP events around every contraction launch -----------------------------
+        prof = TrainStep(model, cfg, use_graph=False, always_reduce=False)
+        prof.dp = None
+        model.grad_ready_hook = None
+        if True:
+            prof._step_impl(*batch)
+            ops.start_event_timing()
+            for _ in range(max(1, args.profile_steps)):
+                prof._step_impl(*batch)
+            table = ops.stop_event_timing()
+            rows = {k: v for k, v in table.items() if v["flops"] > 0}
+            dom = max(rows, key=lambda k: rows[k]["ms"])
+            d = rows[dom]
+            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            result["roofline"] = {
+                "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                "frac": round(achieved * 1e12 / MFMA_PEAK_BF16, 5), "traffic": None,
+                "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches"] // max(1, args.profile_steps),
+                "per_kernel": {k: {"ms_per_step": round(v["ms"] / max(1, args.profile_steps), 4),
+                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
+                                   "launches": v["launches"] // max(1, args.profile_steps)} for k, v in sorted(rows.items())},
+            }
+            if not args.no_cpu_baseline and world == 1:
+                result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch)
+        print(json.dumps(result), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

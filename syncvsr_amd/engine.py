@@ -1,0 +1,172 @@
+"""Training-step runtime around the HIP model: what Lightning's Trainer does for the reference (DDP gradient all-reduce,
+global-norm clip, AdamW, cosine schedule — LRW/video/src/train.py:23-40, lightning.py:216-223) restated
+for one process per GPU:
+
+  * gradients live in ONE flat fp32 buffer laid out in forward order; the hand-written backward (model.py) finalises it from
+    its end to its start and reports progress, so contiguous buckets are all-reduced (RCCL, average) on a side HIP stream
+    while the rest of the backward still runs;
+  * clip + AdamW + schedule + bf16 shadow refresh are two kernels over the flat buffers, with the step counter, the gradient
+    norm and the learning rate kept on the device — nothing in a step depends on host values, so
+  * the whole step (forward, backward, collectives, optimiser) is captured once into a HIP graph and replayed.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .config import Config
+from .model import TransformerLightningModule
+
+
+class TrainStep:
+    """forward + backward + (all-reduce) + clip + AdamW for the LRW model; optionally one HIP graph per step."""
+
+    def __init__(self, model: TransformerLightningModule, config: Optional[Config] = None, process_group=None,
+                 use_graph: bool = True, bucket_mb: float = 32.0, always_reduce: bool = False):
+        self.model = model
+        cfg = config or model.config
+        opt = cfg.optim.optimizer
+        sch = cfg.optim.get("scheduler", {}) or {}
+        self.lr = float(opt.lr)
+        self.betas = (float(opt.betas[0]), float(opt.betas[1]))
+        self.eps = float(opt.eps)
+        self.weight_decay = float(opt.weight_decay)
+        self.max_norm = float(cfg.train.get("gradient_clip_val", 0.0) or 0.0)
+        self.warmup = int(sch.get("num_warmup_steps", 0) or 0)
+        self.total_steps = int(sch.get("num_training_steps", 0) or 0)
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # always_reduce: run the collective path even for a 1-rank group (exercises RCCL + graph capture on one GPU)
+        self.dp = GradReducer(model, process_group, bucket_mb, always_reduce) if (self.world > 1 or always_reduce) else None
+        self.use_graph = use_graph
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._static: Optional[list[torch.Tensor]] = None
+        self._out: Optional[dict[str, torch.Tensor]] = None
+        st = model.store()
+        dev = st.flat.device
+        self.m = torch.zeros_like(st.flat)
+        self.v = torch.zeros_like(st.flat)
+        self.opt_state = torch.zeros(4, dtype=torch.int32, device=dev)     # {step, sumsq, lr_last, gnorm_last}
+
+    # -- one eager step -----------------------------------------------------------------------------
+    def _step_impl(self, videos, audio_tokens, labels, word_mask) -> dict[str, torch.Tensor]:
+        model = self.model
+        st = model.store()
+        if self.dp is not None:
+            self.dp.begin_step()
+        out = model(videos, audio_tokens, labels, word_mask)
+        out["loss_total"].backward()
+        if self.dp is not None:
+            self.dp.finish()
+        ops.grad_sumsq(st.grad, self.opt_state)
+        ops.adamw_step(st.flat, st.grad, self.m, self.v, st.w16, st.decay_end, self.lr, self.betas, self.eps, self.weight_decay,
+                       self.max_norm, self.warmup, self.total_steps, self.opt_state)
+        ops.transpose_cast_multi(st.flat, st.w16t, st.table, st.n_entries)
+        st.shadow_fresh = True
+        return {k: v.detach() for k, v in out.items()}
+
+    def step(self, videos, audio_tokens, labels, word_mask) -> dict[str, torch.Tensor]:
+        if not self.use_graph:
+            return self._step_impl(videos, audio_tokens, labels, word_mask)
+        if self._graph is None:
+            self._capture(videos, audio_tokens, labels, word_mask)
+        else:
+            for dst, src in zip(self._static, (videos, audio_tokens, labels, word_mask)):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        return self._out
+
+    def _capture(self, videos, audio_tokens, labels, word_mask) -> None:
+        self._static = [t.clone() for t in (videos, audio_tokens, labels, word_mask)]
+        # warm-up on a side stream (allocator pools, hipFuncSetAttribute, lazy module loads), state restored afterwards
+        st = self.model.store()
+        snap = (st.flat.clone(), self.m.clone(), self.v.clone(), self.opt_state.clone(),
+                {k: b.clone() for k, b in st.buffers.items()})
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._step_impl(*self._static)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        st.flat.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2]); self.opt_state.copy_(snap[3])
+        for k, b in st.buffers.items():
+            b.copy_(snap[4][k])
+        st.refresh_shadows()          # shadows follow the restored weights; inside the graph the optimiser keeps them fresh
+        st.shadow_fresh = True
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._out = self._step_impl(*self._static)
+
+    # -- introspection ------------------------------------------------------------------------------
+    def state(self) -> dict[str, float]:
+        raw = self.opt_state.cpu()
+        f = raw.view(torch.float32)
+        return {"step": int(raw[0]), "lr": float(f[2]), "grad_norm": float(f[3])}
+
+
+class GradReducer:
+    """Bucketed gradient all-reduce over the flat gradient buffer, overlapped with the backward pass.
+
+    The flat buffer is [decayed tensors in forward order | 1-D tensors].  The backward calls `on_ready(lo)` meaning
+    "decayed offsets >= lo are final"; whole buckets are peeled off the top of the decayed region as soon as they are
+    complete and reduced on a side stream.  `on_ready(0)` (end of backward) flushes the rest plus the 1-D tail.
+    """
+
+    def __init__(self, model: TransformerLightningModule, process_group=None, bucket_mb: float = 32.0, always: bool = False):
+        self.model = model
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.always = always and dist.is_initialized()
+        self.bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.comm_stream: Optional[torch.cuda.Stream] = None
+        self.top = 0
+        self.launched: list[tuple[int, int]] = []
+        model.grad_ready_hook = self.on_ready
+
+    def begin_step(self) -> None:
+        st = self.model.store()
+        self.top = st.decay_end
+        self.launched = []
+        if self.comm_stream is None and st.flat.is_cuda:
+            self.comm_stream = torch.cuda.Stream(device=st.flat.device)
+
+    def _reduce(self, lo: int, hi: int) -> None:
+        if hi <= lo:
+            return
+        self.launched.append((lo, hi))
+        st = self.model.store()
+        seg = st.grad[lo:hi]
+        if self.world == 1 and not self.always:
+            return
+        backend = dist.get_backend(self.group)
+        if seg.is_cuda:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())     # the segment's producers are enqueued there
+            with torch.cuda.stream(self.comm_stream):
+                if backend == "nccl":
+                    dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group)
+                else:
+                    dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
+                    seg.div_(self.world)
+        else:
+            dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
+            seg.div_(self.world)
+
+    def on_ready(self, lo: int) -> None:
+        st = self.model.store()
+        if lo == 0:
+            self._reduce(0, self.top)
+            self.top = 0
+            self._reduce(st.decay_end, st.numel)
+            return
+        while self.top - lo >= self.bucket_elems:
+            self._reduce(self.top - self.bucket_elems, self.top)
+            self.top -= self.bucket_elems
+
+    def finish(self) -> None:
+        if (self.world > 1 or self.always) and self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)

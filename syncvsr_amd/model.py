@@ -91,7 +91,8 @@ class TransformerLightningModule(nn.Module):
         for name, shape, kind in self._bspecs:
             _attach(self, name, sd[name], False)
         self._store: Optional[_ParamStore] = None
-        self.use_tr = True           # ds_read_b64_tr_b16 fragments in the weight-gradient kernels
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_params_dirty())
+        self.use_tr = True          # ds_read_b64_tr_b16 fragments in the weight-gradient kernels
         self.grad_ready_hook = None  # called as hook(lo, hi) when flat gradient range [lo, hi) is final (DDP buckets)
 
     # ------------------------------------------------------------------------------------------------
@@ -108,6 +109,11 @@ class TransformerLightningModule(nn.Module):
         if self.config.train.use_cutmix:
             raise NotImplementedError("CutMix is host-side augmentation outside the hot path (SURVEY §8f-3); apply it before calling")
         return self(*batch)["loss_total"]
+
+    def mark_params_dirty(self) -> None:
+        """Call after changing parameters outside engine.TrainStep (load_state_dict does it): the bf16 shadows are re-cast."""
+        if self._store is not None:
+            self._store.shadow_fresh = False
 
     def store(self) -> "_ParamStore":
         dev = self.cls_token.device
@@ -249,7 +255,7 @@ class _ParamStore:
                     mean=torch.empty(C, dtype=torch.float32, device=device),
                     rstd=torch.empty(C, dtype=torch.float32, device=device),
                 )
-        self.shadow_version = -1
+        self.shadow_fresh = False     # True only while an optimiser that writes the shadows itself owns the step loop
 
     def owns(self, model: TransformerLightningModule) -> bool:
         lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * 4
@@ -461,7 +467,8 @@ class _LrwFunction(torch.autograd.Function):
         B, _, T, H, W = videos.shape
         D, S = model.dim, T + 1
         A, G, V = model.audio_alignment, model.vq_groups, model.audio_vocab_size
-        st.refresh_shadows()
+        if not st.shadow_fresh:          # engine.TrainStep keeps the bf16 shadows current from its optimiser kernel
+            st.refresh_shadows()
         tape: dict[str, Any] = {}
         feats = _frontend_forward(model, st, tape, videos, training)
         h = _encoder_forward(model, st, tape, feats, B, T)              # [B*S, D] bf16

@@ -30,10 +30,44 @@ def _ints(v: Sequence[int]):
     return (ctypes.c_int * len(v))(*v)
 
 
-def _call(name: str, *args) -> None:
+# Optional per-launch timing with HIP events (bench.py's roofline leg): {kernel label: [(start, end, flops, bytes)]}.
+_TIMING: Optional[dict[str, list]] = None
+
+
+def start_event_timing() -> None:
+    global _TIMING
+    _TIMING = {}
+
+
+def stop_event_timing() -> dict[str, dict[str, float]]:
+    """-> {label: {launches, ms (sum), flops (sum), bytes (sum)}}; synchronises the device."""
+    global _TIMING
+    rec, _TIMING = _TIMING or {}, None
+    torch.cuda.synchronize()
+    out = {}
+    for label, evs in rec.items():
+        out[label] = dict(launches=len(evs), ms=sum(s.elapsed_time(e) for s, e, _, _ in evs),
+                          flops=float(sum(f for _, _, f, _ in evs)), bytes=float(sum(b for _, _, _, b in evs)))
+    return out
+
+
+def _call(name: str, *args, label: Optional[str] = None, flops: float = 0.0, nbytes: float = 0.0) -> None:
+    timing = _TIMING
+    if timing is not None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
     rc = getattr(_lib.load(), name)(*args)
+    if timing is not None:
+        e.record()
+        timing.setdefault(label or name, []).append((s, e, flops, nbytes))
     if rc != 0:
         _lib.check(rc, name)
+
+
+def igemm_fwd_tile(M: int, Co: int) -> tuple[int, int]:
+    """Mirror of igemm.hip::igemm_fwd_tile_m — only used to label launches with the kernel instantiation."""
+    bm = (128 if M >= 16384 else 64) if Co <= 64 else (128 if M >= 8192 else 64)
+    return (bm, 64 if (bm == 64 or Co <= 64) else 128)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -45,9 +79,11 @@ def igemm_fwd(inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: i
               addend: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, gelu: bool = False,
               out_pre: Optional[torch.Tensor] = None, out_f32: bool = False) -> None:
     dy, dx, tw = zip(*taps)
+    M = Nimg * Ha * Wa
+    bm, bn = igemm_fwd_tile(M, Co)
     _call("svsr_igemm_fwd", _p(inp), _p(wt), _p(out), _p(out_pre), _p(bias), _p(addend), _p(stats), Nimg, Hi, Wi, Ci, in_pitch,
           Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw),
-          int(gelu), int(out_f32), _stream())
+          int(gelu), int(out_f32), _stream(), label=f"k_igemm_fwd<{bm},{bn}>", flops=2.0 * M * Co * Ci * len(taps))
 
 
 def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
@@ -55,7 +91,8 @@ def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: i
                 taps: Sequence[tuple[int, int, int]] = ((0, 0, 0),), wt_taps: int = 1, use_tr: bool = True) -> None:
     dy, dx, tw = zip(*taps)
     _call("svsr_igemm_wgrad", _p(x), _p(dyp), _p(dw), Nimg, Hi, Wi, Ci, in_pitch, Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0,
-          len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw), int(use_tr), _stream())
+          len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw), int(use_tr), _stream(),
+          label=f"k_igemm_wgrad<{'true' if use_tr else 'false'}>", flops=2.0 * Nimg * Ha * Wa * Co * Ci * len(taps))
 
 
 def conv_out_size(n: int, k: int, stride: int, pad: int) -> int:
@@ -178,13 +215,15 @@ def stem_conv_fwd(videos: torch.Tensor, w: torch.Tensor, stats: Optional[torch.T
     B, C, T, H, W = videos.shape
     assert C == 1 and videos.dtype == torch.float32 and videos.is_contiguous()
     out = torch.empty((B * T, H // 2, W // 2, 64), dtype=BF16, device=videos.device)
-    _call("svsr_stem_conv_fwd", _p(videos), _p(w), _p(out), _p(stats), B, T, H, W, _stream())
+    _call("svsr_stem_conv_fwd", _p(videos), _p(w), _p(out), _p(stats), B, T, H, W, _stream(),
+          label="k_stem_conv_fwd", flops=2.0 * B * T * (H // 2) * (W // 2) * 64 * 245)
     return out
 
 
 def stem_conv_wgrad(videos: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, use_tr: bool = True) -> None:
     B, _, T, H, W = videos.shape
-    _call("svsr_stem_conv_wgrad", _p(videos), _p(dy), _p(dw), B, T, H, W, int(use_tr), _stream())
+    _call("svsr_stem_conv_wgrad", _p(videos), _p(dy), _p(dw), B, T, H, W, int(use_tr), _stream(),
+          label=f"k_stem_conv_wgrad<{'true' if use_tr else 'false'}>", flops=2.0 * B * T * (H // 2) * (W // 2) * 64 * 245)
 
 
 def stem_bn_gelu_pool_fwd(x: torch.Tensor, mean, rstd, gamma, beta) -> tuple[torch.Tensor, torch.Tensor]:
