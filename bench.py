@@ -34,7 +34,13 @@ def cpu_baseline(cfg, batch_size: int, budget_s: float = 20.0) -> dict:
     from oracle import lrw_oracle as O
     from syncvsr_amd.init import init_state_dict, synthetic_batch
 
-    cores = os.cpu_count() or 1
+    # cores this process may actually run on (the box reports 256 logical CPUs; oversubscribing them with one torch thread
+    # each made a step take minutes), capped at 32 threads where the fp32 convolutions stop scaling
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    cores = max(1, min(32, allowed))
     torch.set_num_threads(cores)
     sd = init_state_dict(cfg, seed=0)
     names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
@@ -61,7 +67,7 @@ def cpu_baseline(cfg, batch_size: int, budget_s: float = 20.0) -> dict:
                          float(opt.eps), float(opt.weight_decay))
         times.append(time.perf_counter() - t0)
         step += 1
-        if (time.perf_counter() - t_start > budget_s and step >= 3) or step >= 50:
+        if (time.perf_counter() - t_start > budget_s and step >= 2) or step >= 50 or time.perf_counter() - t_start > 4 * budget_s:
             break
     steady = sorted(times[1:] or times)
     med = steady[len(steady) // 2]

@@ -1,0 +1,184 @@
+// Weight-gradient contraction on MFMA (gfx950):
+//     dW[co][tw[t]][ci] += sum_m dY[target(m)][co] * X[source(m, t)][ci]            (fp32, accumulated with atomics)
+// for every nn.Conv2d / nn.Linear of the path (autograd of reference LRW/video/src/tcn/models/resnet.py:8-16,59-72 and
+// lightning.py:82,92,107).  The reduction index m (positions) is the slow index of both operands, so
+// the MFMA fragments (8 consecutive positions for one channel per lane) are produced from position-major LDS tiles by
+// the gfx950 transpose read ds_read_b64_tr_b16; rows are padded by 16 elements so its 4 x 32-byte accesses per
+// 16-lane group fall on disjoint banks.
+//
+// Grid: x = split of the position range (64-position chunks), y = (co tile, ci tile, tap).  Block = 4 waves (2x2), tile
+// BC x BC channels of one tap; the next chunk's global loads are issued before the MFMA block of the current one.
+#include "igemm_common.h"
+
+struct IgemmWgradArgs {
+    IgemmGeom g;
+    const bf16_t* x;       // source pixels (pitch in_pitch)
+    const bf16_t* dy;      // target pixels (pitch out_pitch)
+    float* dw;             // [Co][wt_taps][Ci] fp32, accumulated
+    int chunks_per_block;  // 64-position chunks each block reduces
+};
+
+__device__ __forceinline__ bf16x4 lds_tr_read(const bf16_t* addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(addr));
+}
+
+// fragment for MFMA 32x32x16: lane l supplies matrix row (l&31) = channel, k = (l>>5)*8 .. +7 = positions.
+template <bool USE_TR, int PITCH>
+__device__ __forceinline__ bf16x8 load_frag_T(const bf16_t* tile, int ch0, int pos0, int lane) {
+    bf16x8 f;
+    if (USE_TR) {
+        // 16-lane group gq: channels ch0 + (gq&1)*16 .., positions pos0 + (gq>>1)*8 ..; lane s of the group addresses
+        // row (s>>2) of a [4 pos][16 ch] block at channel sub-block (s&3)*4 and receives channel column s.
+        const int gq = lane >> 4, s = lane & 15;
+        const bf16_t* base = tile + (pos0 + (gq >> 1) * 8 + (s >> 2)) * PITCH + ch0 + (gq & 1) * 16 + (s & 3) * 4;
+        const bf16x4 lo = lds_tr_read(base);
+        const bf16x4 hi = lds_tr_read(base + 4 * PITCH);
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    } else {
+        const bf16_t* base = tile + (pos0 + (lane >> 5) * 8) * PITCH + ch0 + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = (short)base[k * PITCH];
+    }
+    return f;
+}
+
+template <bool USE_TR, int BC>
+__global__ __launch_bounds__(256) void k_igemm_wgrad(const IgemmWgradArgs p) {
+    constexpr int PITCH = BC + 16;          // bf16 elements per LDS row
+    constexpr int CPR = BC / 8;             // 16-byte chunks per row
+    constexpr int NL = CPR / 8;             // loads per (operand, row) per thread: thread covers chunks c, c+8, ...
+    constexpr int WT = BC / 2, TT = WT / 32;  // wave tile edge, 32x32 MFMA tiles per edge
+    __shared__ __attribute__((aligned(16))) bf16_t sm[2 * 64 * PITCH];
+    bf16_t* sY = sm;
+    bf16_t* sX = sm + 64 * PITCH;
+    const IgemmGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co_tiles = (g.Co + BC - 1) / BC, ci_tiles = (g.Ci + BC - 1) / BC;
+    int rest = blockIdx.y;
+    const int cot = rest % co_tiles; rest /= co_tiles;
+    const int cit = rest % ci_tiles; rest /= ci_tiles;
+    const int t = rest;
+    const int co0 = cot * BC, ci0 = cit * BC;
+    const int wco = (wave >> 1) * WT, wci = (wave & 1) * WT;
+    int dyt = 0, dxt = 0, tw = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)          // compile-time indices only (see igemm_common.h)
+        if (i == t) { dyt = g.dy[i]; dxt = g.dx[i]; tw = g.tw[i]; }
+    const int chunk = tid & 7, r0 = tid >> 3;
+
+    f32x16 acc[TT][TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int c_begin = blockIdx.x * p.chunks_per_block;
+    int c_end = c_begin + p.chunks_per_block;
+    const int total_chunks = (g.M + 63) / 64;
+    if (c_end > total_chunks) c_end = total_chunks;
+
+    u32x4 vy[2][NL], vx[2][NL];
+    unsigned ld_ok = 0;        // bits: (row i, load l) of dY at i*NL+l, of X at 8 + i*NL+l
+    auto load_chunk = [&](int c) {
+        ld_ok = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = c * 64 + r0 + 32 * i;
+            const bool ok_m = m < g.M;
+            int n, a, b;
+            decode_pos(g, ok_m ? m : 0, n, a, b);
+            const long opix = ((long)n * g.Ho + (a * g.OS + g.oy0)) * g.Wo + (b * g.OS + g.ox0);
+            const int iy = a * g.S + dyt, ix = b * g.S + dxt;
+            const bool okp = ok_m && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+            const long ipix = okp ? ((long)n * g.Hi + iy) * g.Wi + ix : 0;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const int cy = co0 + (chunk + 8 * l) * 8, cx = ci0 + (chunk + 8 * l) * 8;
+                const bool oky = ok_m && cy < g.Co, okx = okp && cx < g.Ci;
+                vy[i][l] = *reinterpret_cast<const u32x4*>(p.dy + (oky ? opix * g.out_pitch + cy : 0));
+                vx[i][l] = *reinterpret_cast<const u32x4*>(p.x + (okx ? ipix * g.in_pitch + cx : 0));
+                ld_ok |= (oky ? 1u : 0u) << (i * NL + l);
+                ld_ok |= (okx ? 1u : 0u) << (8 + i * NL + l);
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const bool oky = (ld_ok >> (i * NL + l)) & 1u, okx = (ld_ok >> (8 + i * NL + l)) & 1u;
+                u32x4 y = vy[i][l], x = vx[i][l];
+                y.x = oky ? y.x : 0u; y.y = oky ? y.y : 0u; y.z = oky ? y.z : 0u; y.w = oky ? y.w : 0u;
+                x.x = okx ? x.x : 0u; x.y = okx ? x.y : 0u; x.z = okx ? x.z : 0u; x.w = okx ? x.w : 0u;
+                *reinterpret_cast<u32x4*>(sY + (r0 + 32 * i) * PITCH + (chunk + 8 * l) * 8) = y;
+                *reinterpret_cast<u32x4*>(sX + (r0 + 32 * i) * PITCH + (chunk + 8 * l) * 8) = x;
+            }
+    };
+
+    if (c_begin < c_end) load_chunk(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        __syncthreads();                           // previous chunk's fragment reads are done
+        store_chunk();
+        __syncthreads();
+        if (c + 1 < c_end) load_chunk(c + 1);      // in flight while this chunk is contracted
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fa[TT], fb[TT];
+#pragma unroll
+            for (int i = 0; i < TT; ++i) fa[i] = load_frag_T<USE_TR, PITCH>(sY, wco + i * 32, ks * 16, lane);
+#pragma unroll
+            for (int j = 0; j < TT; ++j) fb[j] = load_frag_T<USE_TR, PITCH>(sX, wci + j * 32, ks * 16, lane);
+#pragma unroll
+            for (int i = 0; i < TT; ++i)
+#pragma unroll
+                for (int j = 0; j < TT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D[row = co][col = ci]
+#pragma unroll
+    for (int j = 0; j < TT; ++j) {
+        const int ci = ci0 + wci + j * 32 + (lane & 31);
+        if (ci >= g.Ci) continue;
+#pragma unroll
+        for (int i = 0; i < TT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < g.Co) atomicAdd(p.dw + ((long)co * g.wt_taps + tw) * g.Ci + ci, acc[i][j][r]);
+            }
+    }
+}
+
+template <bool USE_TR, int BC>
+static int launch_wgrad(IgemmWgradArgs& a, hipStream_t stream) {
+    const IgemmGeom& g = a.g;
+    const int tasks = ((g.Co + BC - 1) / BC) * ((g.Ci + BC - 1) / BC) * g.ntaps;
+    const int total_chunks = (g.M + 63) / 64;
+    int splits = (1024 + tasks - 1) / tasks;            // aim for ~1024 blocks; every block ends with BC*BC atomics
+    if (splits > total_chunks) splits = total_chunks;
+    if (splits < 1) splits = 1;
+    a.chunks_per_block = (total_chunks + splits - 1) / splits;
+    if (a.chunks_per_block < 4 && total_chunks >= 4) a.chunks_per_block = 4;      // keep the atomic epilogue amortised
+    splits = (total_chunks + a.chunks_per_block - 1) / a.chunks_per_block;
+    hipLaunchKernelGGL((k_igemm_wgrad<USE_TR, BC>), dim3(splits, tasks), dim3(256), 0, stream, a);
+    return svsr_check_launch();
+}
+
+extern "C" int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co,
+                                int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps,
+                                const int* dy, const int* dx, const int* tw, int use_tr, hipStream_t stream) {
+    IgemmWgradArgs a;
+    int rc = fill_geom(a.g, Nimg, Hi, Wi, Ci, in_pitch, Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, ntaps, wt_taps, dy, dx, tw);
+    if (rc != SVSR_OK) return rc;
+    if (out_pitch % 8 != 0) return SVSR_ERR_ARG;
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dyp; a.dw = dw;
+    const int tasks128 = ((Co + 127) / 128) * ((Ci + 127) / 128) * ntaps;
+    const bool big = Co >= 128 && Ci >= 128 && tasks128 >= 36;
+    if (use_tr) return big ? launch_wgrad<true, 128>(a, stream) : launch_wgrad<true, 64>(a, stream);
+    return big ? launch_wgrad<false, 128>(a, stream) : launch_wgrad<false, 64>(a, stream);
+}

@@ -70,6 +70,12 @@ def igemm_fwd_tile(M: int, Co: int) -> tuple[int, int]:
     return (bm, 64 if (bm == 64 or Co <= 64) else 128)
 
 
+def wgrad_tile(Co: int, Ci: int, ntaps: int) -> int:
+    """Mirror of igemm_wgrad.hip's tile choice (label only)."""
+    tasks128 = ((Co + 127) // 128) * ((Ci + 127) // 128) * ntaps
+    return 128 if (Co >= 128 and Ci >= 128 and tasks128 >= 36) else 64
+
+
 # --------------------------------------------------------------------------------------------------
 # implicit GEMM
 # --------------------------------------------------------------------------------------------------
@@ -92,7 +98,8 @@ def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: i
     dy, dx, tw = zip(*taps)
     _call("svsr_igemm_wgrad", _p(x), _p(dyp), _p(dw), Nimg, Hi, Wi, Ci, in_pitch, Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0,
           len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw), int(use_tr), _stream(),
-          label=f"k_igemm_wgrad<{'true' if use_tr else 'false'}>", flops=2.0 * Nimg * Ha * Wa * Co * Ci * len(taps))
+          label=f"k_igemm_wgrad<{'true' if use_tr else 'false'},{wgrad_tile(Co, Ci, len(taps))}>",
+          flops=2.0 * Nimg * Ha * Wa * Co * Ci * len(taps))
 
 
 def conv_out_size(n: int, k: int, stride: int, pad: int) -> int:
