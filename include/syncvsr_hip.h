@@ -26,7 +26,7 @@ typedef void* hipStream_t;
 
 #define SVSR_OK 0
 #define SVSR_ERR_ARG 1001
-#define SVSR_STAT_SLOTS 64
+#define SVSR_STAT_SLOTS 16
 
 #ifdef __cplusplus
 extern "C" {

@@ -322,32 +322,44 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const bf16_t* __restrict__ dct
 __global__ __launch_bounds__(256) void k_bias_act_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z,
                                                       bf16_t* __restrict__ dz, float* __restrict__ db, int R, int N, int n_valid,
                                                       int ld, int rows_per_block) {
+    // block = 8 row lanes x 32 column vectors: a wave reads 2 rows x 512 contiguous bytes per step
+    __shared__ float sred[8][32][8];
     const int cv = N >> 3;
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= cv) return;
+    const int cvi = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int v = blockIdx.x * 32 + cvi;
     const int r0 = blockIdx.y * rows_per_block;
     int r1 = r0 + rows_per_block;
     if (r1 > R) r1 = R;
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        float g[8];
-        unpack8(*reinterpret_cast<const u32x4*>(dy + (long)r * ld + v * 8), g);
-        if (z != nullptr) {
-            float zz[8];
-            unpack8(*reinterpret_cast<const u32x4*>(z + (long)r * ld + v * 8), zz);
+    if (v < cv) {
+        for (int r = r0 + rl; r < r1; r += 8) {
+            float g[8];
+            unpack8(*reinterpret_cast<const u32x4*>(dy + (long)r * ld + v * 8), g);
+            if (z != nullptr) {
+                float zz[8];
+                unpack8(*reinterpret_cast<const u32x4*>(z + (long)r * ld + v * 8), zz);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) g[k] *= gelu_erf_grad(zz[k]);
-            *reinterpret_cast<u32x4*>(dz + (long)r * ld + v * 8) = pack8(g);
+                for (int k = 0; k < 8; ++k) g[k] *= gelu_erf_grad(zz[k]);
+                *reinterpret_cast<u32x4*>(dz + (long)r * ld + v * 8) = pack8(g);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += g[k];
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += g[k];
     }
-    if (db != nullptr)
+    if (db == nullptr) return;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (v * 8 + k < n_valid) atomicAdd(db + v * 8 + k, acc[k]);
+    for (int k = 0; k < 8; ++k) sred[rl][cvi][k] = acc[k];
+    __syncthreads();
+    // 256 threads = 32 vectors x 8 columns: each sums the 8 row lanes of one column
+    const int c = threadIdx.x;
+    const int vv = c >> 3, kk = c & 7;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += sred[i][vv][kk];
+    const int col = (blockIdx.x * 32 + vv) * 8 + kk;
+    if (col < n_valid) atomicAdd(db + col, s);
 }
 
 extern "C" {
@@ -412,10 +424,12 @@ int svsr_attn_bwd(const void* dctx, const void* qkv, const void* probs, void* dq
 int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, hipStream_t stream) {
     if (N % 8 != 0 || ld % 8 != 0) return SVSR_ERR_ARG;
     const int cv = N / 8;
-    int splits = R / 32; if (splits < 1) splits = 1; if (splits > 64) splits = 64;
+    const int col_blocks = (cv + 31) / 32;
+    int splits = (R + 63) / 64;                                  // ~64 rows (8 per thread) per block ...
+    while (splits > 1 && col_blocks * splits > 2048) splits = (splits + 1) / 2;
     const int rpb = (R + splits - 1) / splits;
     splits = (R + rpb - 1) / rpb;
-    hipLaunchKernelGGL(k_bias_act_bwd, dim3((cv + 255) / 256, splits), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)z,
+    hipLaunchKernelGGL(k_bias_act_bwd, dim3(col_blocks, splits), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)z,
                        (bf16_t*)dz, db, R, N, n_valid, ld, rpb);
     return svsr_check_launch();
 }

@@ -12,7 +12,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define SVSR_OK 0
 #define SVSR_ERR_ARG 1001      // unsupported shape / argument
 #define SVSR_ERR_LAUNCH 1002
-#define SVSR_STAT_SLOTS 64   // BatchNorm partial-sum slots: blocks accumulate atomically into slot (blockIdx & 63)
+#define SVSR_STAT_SLOTS 16   // BatchNorm partial-sum slots: blocks accumulate atomically into slot (blockIdx & 15)
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((unsigned)u) << 16); }
 

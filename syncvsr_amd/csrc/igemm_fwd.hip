@@ -7,10 +7,14 @@
 // and their input-gradients.
 //
 // Block = 256 threads = 4 waves (2x2), tile BM positions x BN output channels, K step 64 channels of one tap.
-// A (gathered activation rows) and B (weight rows) are staged global -> registers -> LDS (XOR-swizzled 16-byte
-// chunks, conflict-free ds_read_b128 fragments), double-buffered with one barrier per K step; the next tile's global
-// loads are issued before the MFMA block and written to LDS after it.  Epilogue: accumulators -> LDS (fp32) ->
-// +bias +addend, exact GELU, 16-byte stores; optional per-channel BatchNorm partial sums.
+// Main kernel (k_igemm_fwd_glds): A (gathered activation rows) and B (weight rows) go global -> LDS by direct DMA
+// (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave instruction) into a 3-deep ring, two tiles in flight behind a
+// counted s_waitcnt vmcnt(N) + one s_barrier per K step; the XOR swizzle that makes the ds_read_b128 fragment reads
+// conflict-free is applied on the per-lane SOURCE address (the LDS image of a DMA is lane-linear), rows outside the grid
+// read a zero page.  k_igemm_fwd (register-staged, double-buffered) is kept as the reference variant (SVSR_IGEMM_GLDS=0).
+// Epilogue (shared): accumulators -> LDS fp32 -> +bias +addend, exact GELU, 16-byte stores; optional BatchNorm partial sums.
+#include <stdlib.h>
+
 #include "igemm_common.h"
 
 struct IgemmFwdArgs {
@@ -25,146 +29,20 @@ struct IgemmFwdArgs {
     int gelu, out_f32;
 };
 
+__device__ unsigned g_zero_page[64];     // 256 zero bytes: DMA source for rows outside the grid
+
 #define LDS_SWZ(row, chunk) ((row) * 64 + ((((chunk) ^ (((row) >> 1) & 7))) << 3))
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_igemm_fwd(const IgemmFwdArgs p) {
-    constexpr int BK = 64;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;
-    constexpr int AR = BM / 32, BR = BN / 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);
-    bf16_t* sB = sA + 2 * A_ELEMS;
-    long* sRow = reinterpret_cast<long*>(sB + 2 * B_ELEMS);   // [BM] target pixel offsets (elements), -1 = no row
-    int* sTap = reinterpret_cast<int*>(sRow + BM);            // [27] dy | dx | tw
-
+// ---------------------------------------------------------------------------------------------------------------------
+// shared epilogue
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&acc)[TM][TN], unsigned char* smem_raw, const long* sRow,
+                                               int wm0, int wn0, int n0) {
+    constexpr int WN = BN / 2;
     const IgemmGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int chunk = tid & 7, r0 = tid >> 3;
-
-    long a_base[AR];
-    int a_y[AR], a_x[AR];
-    unsigned row_ok = 0;          // bit i: A row i exists; bit 8+i: B row i exists
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int m = m0 + r0 + 32 * i;
-        const bool ok = m < g.M;
-        int n, a, b;
-        decode_pos(g, ok ? m : 0, n, a, b);
-        a_base[i] = (long)n * g.Hi * g.Wi;
-        a_y[i] = a * g.S;
-        a_x[i] = b * g.S;
-        row_ok |= (ok ? 1u : 0u) << i;
-    }
-    for (int r = tid; r < BM; r += 256) {
-        const int m = m0 + r;
-        long off = -1;
-        if (m < g.M) {
-            int n, a, b;
-            decode_pos(g, m, n, a, b);
-            off = (((long)n * g.Ho + (a * g.OS + g.oy0)) * g.Wo + (b * g.OS + g.ox0)) * g.out_pitch;
-        }
-        sRow[r] = off;
-    }
-    if (tid == 0) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { sTap[i] = g.dy[i]; sTap[9 + i] = g.dx[i]; sTap[18 + i] = g.tw[i]; }
-    }
-    const bf16_t* b_ptr[BR];
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-        const int n = n0 + r0 + 32 * i;
-        const bool ok = n < g.Co;
-        b_ptr[i] = p.wt + (long)(ok ? n : 0) * g.wt_taps * g.Ci + chunk * 8;
-        row_ok |= (ok ? 1u : 0u) << (8 + i);
-    }
-    __syncthreads();
-
-    const int KT = g.ntaps * (g.Ci / BK);
-    u32x4 ra[AR], rb[BR];
-    unsigned ld_ok = 0;              // validity of the rows currently held in ra/rb (applied when they are written to LDS)
-    int t_next = 0, c_next = 0;      // (tap, channel offset) of the tile the next load_tiles() fetches
-
-    auto load_tiles = [&]() {
-        const int dy = sTap[t_next], dx = sTap[9 + t_next], tw = sTap[18 + t_next];
-        const int c0 = c_next;
-        ld_ok = row_ok & 0xff00u;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int iy = a_y[i] + dy, ix = a_x[i] + dx;
-            const bool ok = ((row_ok >> i) & 1u) && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-            const long pix = ok ? a_base[i] + (long)iy * g.Wi + ix : 0;
-            ra[i] = *reinterpret_cast<const u32x4*>(p.in + pix * g.in_pitch + c0 + chunk * 8);
-            ld_ok |= (ok ? 1u : 0u) << i;
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (long)tw * g.Ci + c0);
-        c_next += BK;
-        if (c_next >= g.Ci) { c_next = 0; ++t_next; }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int r = r0 + 32 * i;
-            const bool ok = (ld_ok >> i) & 1u;
-            u32x4 v = ra[i];
-            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-            *reinterpret_cast<u32x4*>(sA + buf * A_ELEMS + LDS_SWZ(r, chunk)) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const int r = r0 + 32 * i;
-            const bool ok = (ld_ok >> (8 + i)) & 1u;
-            u32x4 v = rb[i];
-            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-            *reinterpret_cast<u32x4*>(sB + buf * B_ELEMS + LDS_SWZ(r, chunk)) = v;
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    load_tiles();
-    store_tiles(0);
-    __syncthreads();
-    for (int it = 0; it < KT; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < KT) load_tiles();
-        const bf16_t* cA = sA + cur * A_ELEMS;
-        const bf16_t* cB = sB + cur * B_ELEMS;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const int ch = ks * 2 + (lane >> 5);
-            bf16x8 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm0 + i * 32 + (lane & 31);
-                fa[i] = *reinterpret_cast<const bf16x8*>(cA + LDS_SWZ(row, ch));
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn0 + j * 32 + (lane & 31);
-                fb[j] = *reinterpret_cast<const bf16x8*>(cB + LDS_SWZ(row, ch));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        if (it + 1 < KT) store_tiles(cur ^ 1);
-        __syncthreads();
-    }
-
-    // ---- per-channel statistics from the fp32 accumulators (rows outside M carry exact zeros) ----------------------
+    // per-channel statistics from the fp32 accumulators (rows outside M carry exact zeros)
     float st_s[TN], st_q[TN];
     if (p.stats != nullptr) {
 #pragma unroll
@@ -178,8 +56,7 @@ __global__ __launch_bounds__(256) void k_igemm_fwd(const IgemmFwdArgs p) {
             st_q[j] = q + __shfl_xor(q, 32, 64);
         }
     }
-
-    // ---- epilogue: accumulators -> LDS fp32 [BM][BN] (tile buffers are dead after the last barrier) -----------------
+    // accumulators -> LDS fp32 [BM][BN] (the tile buffers are dead: the caller has passed a barrier after its last read)
     float* sOut = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -264,22 +141,281 @@ __global__ __launch_bounds__(256) void k_igemm_fwd(const IgemmFwdArgs p) {
     }
 }
 
+// fills sRow (target pixel offsets) and sTap; every thread calls it, followed by a barrier in the caller
+template <int BM>
+__device__ __forceinline__ void igemm_fill_tables(const IgemmGeom& g, long* sRow, int* sTap, int m0) {
+    const int tid = threadIdx.x;
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        long off = -1;
+        if (m < g.M) {
+            int n, a, b;
+            decode_pos(g, m, n, a, b);
+            off = (((long)n * g.Ho + (a * g.OS + g.oy0)) * g.Wo + (b * g.OS + g.ox0)) * g.out_pitch;
+        }
+        sRow[r] = off;
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { sTap[i] = g.dy[i]; sTap[9 + i] = g.dx[i]; sTap[18 + i] = g.tw[i]; }
+    }
+}
+
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void igemm_mma_tile(const bf16_t* cA, const bf16_t* cB, f32x16 (&acc)[TM][TN], int wm0, int wn0, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int ch = ks * 2 + (lane >> 5);
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm0 + i * 32 + (lane & 31);
+            fa[i] = *reinterpret_cast<const bf16x8*>(cA + LDS_SWZ(row, ch));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wn0 + j * 32 + (lane & 31);
+            fb[j] = *reinterpret_cast<const bf16x8*>(cB + LDS_SWZ(row, ch));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA pipeline (default)
+// ---------------------------------------------------------------------------------------------------------------------
 template <int BM, int BN>
-static int launch_fwd(const IgemmFwdArgs& a, hipStream_t stream) {
+__global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
+    constexpr int BK = 64;
+    constexpr int NS = (BM + BN) > 192 ? 2 : 3;      // ring depth: keep >= 2 workgroups per CU (64 KiB vs 72/48 KiB)
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, S_ELEMS = A_ELEMS + B_ELEMS;
+    constexpr int AR = BM / 32, BR = BN / 32, LPT = AR + BR;     // DMA instructions per thread per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sStage = reinterpret_cast<bf16_t*>(smem_raw);                 // [NS][A | B]
+    long* sRow = reinterpret_cast<long*>(sStage + NS * S_ELEMS);
+    int* sTap = reinterpret_cast<int*>(sRow + BM);
+
+    const IgemmGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int slot = tid & 7, r0 = tid >> 3;                 // lane writes LDS chunk `slot` of row r0 + 32*i ...
+    const int csw = slot ^ ((r0 >> 1) & 7);                  // ... which must hold global chunk csw (swizzle on the source)
+    const int wrow = __builtin_amdgcn_readfirstlane(wave) * 8;   // first row of this wave's 8-row group
+
+    long a_base[AR];
+    int a_y[AR], a_x[AR];
+    unsigned row_ok = 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const bool ok = m < g.M;
+        int n, a, b;
+        decode_pos(g, ok ? m : 0, n, a, b);
+        a_base[i] = (long)n * g.Hi * g.Wi;
+        a_y[i] = a * g.S;
+        a_x[i] = b * g.S;
+        row_ok |= (ok ? 1u : 0u) << i;
+    }
+    const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_page) + slot * 8;
+    const bf16_t* b_ptr[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        b_ptr[i] = n < g.Co ? p.wt + (long)n * g.wt_taps * g.Ci + csw * 8 : nullptr;
+    }
+    igemm_fill_tables<BM>(g, sRow, sTap, m0);
+    __syncthreads();
+
+    const int KT = g.ntaps * (g.Ci / BK);
+    int t_next = 0, c_next = 0;
+    auto stage = [&](int buf) {
+        const int dy = sTap[t_next], dx = sTap[9 + t_next], tw = sTap[18 + t_next];
+        const int c0 = c_next;
+        bf16_t* dstA = sStage + buf * S_ELEMS + wrow * 64;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int iy = a_y[i] + dy, ix = a_x[i] + dx;
+            const bool ok = ((row_ok >> i) & 1u) && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+            const bf16_t* src = ok ? p.in + (a_base[i] + (long)iy * g.Wi + ix) * g.in_pitch + c0 + csw * 8 : zero_src;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dstA + i * 32 * 64), 16, 0, 0);
+        }
+        bf16_t* dstB = sStage + buf * S_ELEMS + A_ELEMS + wrow * 64;
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const bf16_t* src = b_ptr[i] != nullptr ? b_ptr[i] + (long)tw * g.Ci + c0 : zero_src;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dstB + i * 32 * 64), 16, 0, 0);
+        }
+        c_next += BK;
+        if (c_next >= g.Ci) { c_next = 0; ++t_next; }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage(0);
+    if (NS == 3 && KT > 1) stage(1);
+    int buf = 0;
+    for (int it = 0; it < KT; ++it) {
+        // tile `it` has landed once at most one later tile's DMAs are still outstanding; the barrier makes every wave's
+        // part visible and proves everybody is done reading the buffer the next stage() overwrites.
+        if (NS == 3 && it + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (it + NS - 1 < KT) stage(buf >= 1 ? buf - 1 : NS - 1);   // == (it + NS - 1) % NS
+        const bf16_t* cA = sStage + buf * S_ELEMS;
+        igemm_mma_tile<BM, BN, TM, TN>(cA, cA + A_ELEMS, acc, wm0, wn0, lane);
+        buf = buf + 1 == NS ? 0 : buf + 1;
+    }
+    __syncthreads();
+    igemm_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, sRow, wm0, wn0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// register-staged, double-buffered reference variant
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_igemm_fwd(const IgemmFwdArgs p) {
+    constexpr int BK = 64;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;
+    constexpr int AR = BM / 32, BR = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* sB = sA + 2 * A_ELEMS;
+    long* sRow = reinterpret_cast<long*>(sB + 2 * B_ELEMS);
+    int* sTap = reinterpret_cast<int*>(sRow + BM);
+
+    const IgemmGeom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int chunk = tid & 7, r0 = tid >> 3;
+
+    long a_base[AR];
+    int a_y[AR], a_x[AR];
+    unsigned row_ok = 0;          // bit i: A row i exists; bit 8+i: B row i exists
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const bool ok = m < g.M;
+        int n, a, b;
+        decode_pos(g, ok ? m : 0, n, a, b);
+        a_base[i] = (long)n * g.Hi * g.Wi;
+        a_y[i] = a * g.S;
+        a_x[i] = b * g.S;
+        row_ok |= (ok ? 1u : 0u) << i;
+    }
+    const bf16_t* b_ptr[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        const bool ok = n < g.Co;
+        b_ptr[i] = p.wt + (long)(ok ? n : 0) * g.wt_taps * g.Ci + chunk * 8;
+        row_ok |= (ok ? 1u : 0u) << (8 + i);
+    }
+    igemm_fill_tables<BM>(g, sRow, sTap, m0);
+    __syncthreads();
+
+    const int KT = g.ntaps * (g.Ci / BK);
+    u32x4 ra[AR], rb[BR];
+    unsigned ld_ok = 0;              // validity of the rows held in ra/rb (applied when they are written to LDS)
+    int t_next = 0, c_next = 0;
+
+    auto load_tiles = [&]() {
+        const int dy = sTap[t_next], dx = sTap[9 + t_next], tw = sTap[18 + t_next];
+        const int c0 = c_next;
+        ld_ok = row_ok & 0xff00u;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int iy = a_y[i] + dy, ix = a_x[i] + dx;
+            const bool ok = ((row_ok >> i) & 1u) && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+            const long pix = ok ? a_base[i] + (long)iy * g.Wi + ix : 0;
+            ra[i] = *reinterpret_cast<const u32x4*>(p.in + pix * g.in_pitch + c0 + chunk * 8);
+            ld_ok |= (ok ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (long)tw * g.Ci + c0);
+        c_next += BK;
+        if (c_next >= g.Ci) { c_next = 0; ++t_next; }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int r = r0 + 32 * i;
+            const bool ok = (ld_ok >> i) & 1u;
+            u32x4 v = ra[i];
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+            *reinterpret_cast<u32x4*>(sA + buf * A_ELEMS + LDS_SWZ(r, chunk)) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int r = r0 + 32 * i;
+            const bool ok = (ld_ok >> (8 + i)) & 1u;
+            u32x4 v = rb[i];
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+            *reinterpret_cast<u32x4*>(sB + buf * B_ELEMS + LDS_SWZ(r, chunk)) = v;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tiles();
+    store_tiles(0);
+    __syncthreads();
+    for (int it = 0; it < KT; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < KT) load_tiles();
+        igemm_mma_tile<BM, BN, TM, TN>(sA + cur * A_ELEMS, sB + cur * B_ELEMS, acc, wm0, wn0, lane);
+        if (it + 1 < KT) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+    igemm_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, sRow, wm0, wn0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+static int launch_fwd(const IgemmFwdArgs& a, bool glds, hipStream_t stream) {
     const int gx = (a.g.M + BM - 1) / BM, gy = (a.g.Co + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t) + (size_t)BM * sizeof(long) + 128;
+    const size_t tail = (size_t)BM * sizeof(long) + 128;
     static bool attr_set = false;
+    const size_t lds_glds = (size_t)((BM + BN) > 192 ? 2 : 3) * (BM + BN) * 64 * sizeof(bf16_t) + tail;
+    const size_t lds_reg = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t) + tail;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_fwd<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_fwd_glds<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_glds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_fwd<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_igemm_fwd<BM, BN>), dim3(gx, gy), dim3(256), lds, stream, a);
+    if (glds) hipLaunchKernelGGL((k_igemm_fwd_glds<BM, BN>), dim3(gx, gy), dim3(256), lds_glds, stream, a);
+    else hipLaunchKernelGGL((k_igemm_fwd<BM, BN>), dim3(gx, gy), dim3(256), lds_reg, stream, a);
     return svsr_check_launch();
 }
 
 static int igemm_fwd_tile_m(int M, int Co) {
     if (Co <= 64) return M >= 16384 ? 128 : 64;
     return M >= 8192 ? 128 : 64;
+}
+
+static bool use_glds() {
+    static const bool v = [] { const char* e = getenv("SVSR_IGEMM_GLDS"); return !(e != nullptr && e[0] == '0'); }();
+    return v;
 }
 
 extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend,
@@ -292,6 +428,7 @@ extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* o
     a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = out; a.out_pre = (bf16_t*)out_pre;
     a.bias = bias; a.addend = (const bf16_t*)addend; a.stats = stats; a.gelu = gelu; a.out_f32 = out_f32;
     const int bm = igemm_fwd_tile_m(a.g.M, Co);
-    if (bm == 128) return Co <= 64 ? launch_fwd<128, 64>(a, stream) : launch_fwd<128, 128>(a, stream);
-    return launch_fwd<64, 64>(a, stream);
+    const bool glds = use_glds();
+    if (bm == 128) return Co <= 64 ? launch_fwd<128, 64>(a, glds, stream) : launch_fwd<128, 128>(a, glds, stream);
+    return launch_fwd<64, 64>(a, glds, stream);
 }

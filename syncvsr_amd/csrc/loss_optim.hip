@@ -205,15 +205,28 @@ struct TransEntry { long src_off, dst_off; int A, T, Bd, Apad; };
 
 __global__ __launch_bounds__(256) void k_transpose_cast_multi(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                                               const TransEntry* __restrict__ table) {
+    // 32x32 tiles through LDS: reads are contiguous along Bd, writes contiguous along A (pad columns stay zero)
+    __shared__ float tile[32][33];
     const TransEntry e = table[blockIdx.y];
-    const long n = (long)e.A * e.T * e.Bd;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        // i enumerates the destination [Bd][T][A]; rows are Apad long (pad columns stay zero)
-        const int a = (int)(i % e.A);
-        const long r = i / e.A;
-        const int t = (int)(r % e.T);
-        const int bd = (int)(r / e.T);
-        dst[e.dst_off + r * e.Apad + a] = f2bf(src[e.src_off + ((long)a * e.T + t) * e.Bd + bd]);
+    const int ta = (e.A + 31) / 32, tb = (e.Bd + 31) / 32;
+    const int ntiles = e.T * ta * tb;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+        const int t = tile_id / (ta * tb);
+        const int rem = tile_id - t * (ta * tb);
+        const int a0 = (rem / tb) * 32, b0 = (rem % tb) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a = a0 + ty + 8 * i, bd = b0 + tx;
+            tile[ty + 8 * i][tx] = (a < e.A && bd < e.Bd) ? src[e.src_off + ((long)a * e.T + t) * e.Bd + bd] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int bd = b0 + ty + 8 * i, a = a0 + tx;
+            if (a < e.A && bd < e.Bd) dst[e.dst_off + ((long)bd * e.T + t) * e.Apad + a] = f2bf(tile[tx][ty + 8 * i]);
+        }
+        __syncthreads();
     }
 }
 
@@ -278,7 +291,7 @@ int svsr_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {
 // table: device array of n_entries {int64 src_off, int64 dst_off, int32 A, T, Bd, Apad}
 int svsr_transpose_cast_multi(const float* src, void* dst, const void* table, int n_entries, hipStream_t stream) {
     if (n_entries < 1) return SVSR_OK;
-    hipLaunchKernelGGL(k_transpose_cast_multi, dim3(64, n_entries), dim3(256), 0, stream, src, (bf16_t*)dst, (const TransEntry*)table);
+    hipLaunchKernelGGL(k_transpose_cast_multi, dim3(128, n_entries), dim3(256), 0, stream, src, (bf16_t*)dst, (const TransEntry*)table);
     return svsr_check_launch();
 }
 

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 BF16 = torch.bfloat16
-STAT_SLOTS = 64
+STAT_SLOTS = 16
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 

@@ -1,0 +1,56 @@
+"""-m gpu: shadow cast / table-driven transpose-cast, bias-gradient tiling at encoder sizes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def test_transpose_cast_multi(dev):
+    from syncvsr_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 9, 64), (128, 9, 64), (500, 1, 512), (1536, 1, 512), (40, 3, 72)]     # (A, T, Bd)
+    src_parts, entries, soff, doff = [], [], 0, 0
+    for A, T, Bd in shapes:
+        src_parts.append(torch.randn(A * T * Bd, generator=g))
+        Apad = (A + 63) // 64 * 64
+        entries.append((soff, doff, A, T, Bd, Apad))
+        soff += A * T * Bd
+        doff += Bd * T * Apad
+    src = torch.cat(src_parts).to(dev)
+    dst = torch.zeros(doff, dtype=BF, device=dev)
+    tab = np.zeros(len(entries), dtype=np.dtype([("src", "<i8"), ("dst", "<i8"), ("A", "<i4"), ("T", "<i4"), ("Bd", "<i4"), ("Apad", "<i4")]))
+    for i, e in enumerate(entries):
+        tab[i] = e
+    table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+    ops.transpose_cast_multi(src, dst, table, len(entries))
+    shadow = torch.empty(soff, dtype=BF, device=dev)
+    ops.cast_bf16(src, shadow)
+    assert torch.equal(shadow.cpu(), src.cpu().to(BF))
+    for (so, do, A, T, Bd, Apad), part in zip(entries, src_parts):
+        ref = torch.zeros(Bd, T, Apad, dtype=BF)
+        ref[:, :, :A] = part.view(A, T, Bd).permute(2, 1, 0).to(BF)
+        got = dst[do : do + Bd * T * Apad].view(Bd, T, Apad).cpu()
+        assert torch.equal(got, ref), (A, T, Bd)
+
+
+@pytest.mark.parametrize("R,N", [(960, 512), (960, 2048), (928, 2560), (32, 512), (60, 1536)])
+def test_bias_grad_sizes(dev, R, N):
+    from syncvsr_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(R, N, generator=g).to(BF)
+    db = torch.zeros(N, device=dev)
+    ops.bias_act_bwd(dy.to(dev), None, db, R=R, N=N, n_valid=N, ld=N)
+    ref = dy.float().sum(0)
+    err = (db.cpu() - ref).abs().max().item()
+    assert err <= 1e-3 * ref.abs().max().item() + 1e-3, err
