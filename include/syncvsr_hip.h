@@ -50,6 +50,11 @@ int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, con
  * dw fp32 [Co][wt_taps][Ci] is ACCUMULATED (atomics).  x = forward input pixels, dyp = output-gradient pixels. */
 int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int use_tr, hipStream_t stream);
 
+/* svsr_conv3x3_wgrad: weight gradient of a 3x3 / stride-1 / pad-1 Conv2d (resnet.py:8-10) with all nine taps sharing one
+ * pass over x [Nimg][H][W][Ci] and dy [Nimg][H][W][Co] (zero-padded coordinates, wgrad3x3.hip).  dw fp32 [Co][9][Ci] is
+ * ACCUMULATED.  Requires Ci, Co multiples of 64 and W <= 29; other shapes go through svsr_igemm_wgrad. */
+int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Ci, int Co, hipStream_t stream);
+
 /* ---- 3-D stem (stem.hip) --------------------------------------------------------------------------------------
  * svsr_stem_conv_fwd replaces stem3d[0] = nn.Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3),bias=False) (lightning.py:50).
  * vid fp32 [B][1][T][H][W]; w fp32 [64][1][5][7][7]; out bf16 [B*T][H/2][W/2][64]; stats as above (64 channels). */

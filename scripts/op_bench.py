@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""Per-op micro-benchmark at the BASELINE shapes (B=32 -> 928 frames): times the C-ABI entry points with HIP events.
+
+    python scripts/op_bench.py [wgrad] [fwd] [dgrad] [stem] [ew]      (default: all)
+"""
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from syncvsr_amd import ops  # noqa: E402
+
+BF = torch.bfloat16
+dev = torch.device("cuda:0")
+N = 928
+LAYERS = [("L1", 22, 64, 64), ("L2", 11, 128, 128), ("L3", 6, 256, 256), ("L4", 3, 512, 512)]
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3     # us
+
+
+def main():
+    which = set(sys.argv[1:]) or {"wgrad", "fwd", "dgrad", "stem", "ew"}
+    tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("SVSR_"))
+    print(f"== op_bench {tag}")
+    for name, hw, ci, co in LAYERS:
+        x = torch.randn(N, hw, hw, ci, device=dev).to(BF)
+        dy = torch.randn(N, hw, hw, co, device=dev).to(BF)
+        w = (torch.randn(co, 3, 3, ci, device=dev) / math.sqrt(9 * ci)).to(BF)
+        wt = w.permute(3, 1, 2, 0).contiguous()
+        flops = 2.0 * N * hw * hw * ci * co * 9
+        if "fwd" in which:
+            slots = torch.zeros(ops.STAT_SLOTS * 2 * co, device=dev)
+            us = timeit(lambda: ops.conv2d_fwd(x, w, 3, 1, 1, stats=slots))
+            print(f"{name} conv3x3 fwd   {us:8.1f} us  {flops / us / 1e6:7.1f} TF")
+        if "dgrad" in which:
+            us = timeit(lambda: ops.conv2d_dgrad(dy, wt, 3, 1, 1, (hw, hw)))
+            print(f"{name} conv3x3 dgrad {us:8.1f} us  {flops / us / 1e6:7.1f} TF")
+        if "wgrad" in which:
+            dw = torch.zeros(co, 3, 3, ci, device=dev)
+            us = timeit(lambda: ops.conv2d_wgrad(x, dy, dw, 3, 1, 1))
+            print(f"{name} conv3x3 wgrad {us:8.1f} us  {flops / us / 1e6:7.1f} TF")
+            ops.HALO_WGRAD = False
+            us = timeit(lambda: ops.conv2d_wgrad(x, dy, dw, 3, 1, 1))
+            print(f"{name} conv3x3 wgrad(generic) {us:8.1f} us  {flops / us / 1e6:7.1f} TF")
+            ops.HALO_WGRAD = True
+    if "stem" in which:
+        vid = torch.randn(32, 1, 29, 88, 88, device=dev)
+        w = torch.randn(64 * 245, device=dev) * 0.05
+        slots = torch.zeros(ops.STAT_SLOTS * 2 * 64, device=dev)
+        flops = 2.0 * N * 44 * 44 * 64 * 245
+        us = timeit(lambda: ops.stem_conv_fwd(vid, w, slots))
+        print(f"stem conv fwd   {us:8.1f} us  {flops / us / 1e6:7.1f} TF")
+        dy = torch.randn(N, 44, 44, 64, device=dev).to(BF)
+        dw = torch.zeros(64 * 245, device=dev)
+        us = timeit(lambda: ops.stem_conv_wgrad(vid, dy, dw))
+        print(f"stem conv wgrad {us:8.1f} us  {flops / us / 1e6:7.1f} TF")
+        c = torch.randn(N, 44, 44, 64, device=dev).to(BF)
+        mean = torch.zeros(64, device=dev); rstd = torch.ones(64, device=dev); g = torch.ones(64, device=dev); b = torch.zeros(64, device=dev)
+        us = timeit(lambda: ops.stem_bn_gelu_pool_fwd(c, mean, rstd, g, b))
+        print(f"stem bn+gelu+pool fwd {us:8.1f} us  {c.numel() * 2 * 1.25 / us / 1e6:6.2f} TB/s (algorithmic)")
+        y, amax = ops.stem_bn_gelu_pool_fwd(c, mean, rstd, g, b)
+        dp = torch.randn_like(y)
+        coef = torch.empty(192, device=dev); dg = torch.zeros(64, device=dev); db = torch.zeros(64, device=dev)
+        us = timeit(lambda: ops.stem_bn_gelu_pool_bwd(dp, amax, c, mean, rstd, g, b, slots, coef, dg, db))
+        print(f"stem bn+gelu+pool bwd {us:8.1f} us")
+    if "ew" in which:
+        for name, hw, ci, co in LAYERS:
+            x = torch.randn(N, hw, hw, co, device=dev).to(BF)
+            res = torch.randn_like(x)
+            mean = torch.zeros(co, device=dev); rstd = torch.ones(co, device=dev); g = torch.ones(co, device=dev); b = torch.zeros(co, device=dev)
+            us = timeit(lambda: ops.bn_act_fwd(x, res, mean, rstd, g, b, 1))
+            print(f"{name} bn_act_fwd(+res) {us:7.1f} us  {x.numel() * 2 * 3 / us / 1e6:5.2f} TB/s")
+            y = ops.bn_act_fwd(x, res, mean, rstd, g, b, 1)
+            slots = torch.zeros(ops.STAT_SLOTS * 2 * co, device=dev); coef = torch.empty(3 * co, device=dev)
+            dg = torch.zeros(co, device=dev); db = torch.zeros(co, device=dev)
+            us = timeit(lambda: ops.bn_act_bwd(res, y, x, mean, rstd, g, slots, coef, dg, db, 1, True))
+            print(f"{name} bn_act_bwd(+res) {us:7.1f} us  {x.numel() * 2 * 8 / us / 1e6:5.2f} TB/s")
+
+
+if __name__ == "__main__":
+    main()

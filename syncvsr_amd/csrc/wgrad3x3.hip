@@ -1,0 +1,171 @@
+// Weight gradient of a 3x3 / stride-1 / pad-1 NHWC convolution with the nine taps sharing one pass over the
+// activations (gfx950):     dW[co][kh][kw][ci] += sum_{n,y,x} dY[n,y,x,co] * X[n,y+kh-1,x+kw-1,ci]
+// (autograd of the stride-1 conv3x3 of the ResNet18 trunk, reference LRW/video/src/tcn/models/resnet.py:8-10,59-72;
+// SURVEY.md §8 a16).
+//
+// The generic kernel (igemm_wgrad.hip) runs one tap per workgroup, so every activation and every output gradient is
+// re-read nine times; at layer1 sizes that is ~1 GB of L2->LDS traffic per convolution and bounds it at ~7 TB/s.  Here the
+// reduction runs over ZERO-PADDED pixel coordinates q = (n, y', x') of a (H+2) x (W+2) grid flattened over the batch:
+// in that space tap (kh,kw) is the constant row shift kh*(W+2)+kw, pad pixels carry dY = 0, and a contiguous chunk of 128
+// positions needs one dY tile [128][64 co] and ONE X tile [128 + 2(W+3)][64 ci] for all nine taps.  Per 16-position
+// step a wave reads one dY^T fragment and nine shifted X^T fragments (ds_read_b64_tr_b16) and issues nine MFMAs into
+// nine 32x32 accumulators.  The next chunk's rows are fetched into registers while the current one is contracted.
+#include <stdlib.h>
+
+#include "common.h"
+
+#define W3_CH 128         // padded positions per chunk
+#define W3_PITCH 80        // bf16 elements per LDS row (64 channels + 16 pad: conflict-free 4 x 32-byte tr-reads)
+#define W3_MAXXR 192       // max X-tile rows: 128 + 2*(WP+1), i.e. W <= 29
+
+struct Wgrad3Args {
+    const bf16_t* x;       // [Nimg][H][W][Ci]
+    const bf16_t* dy;      // [Nimg][H][W][Co]
+    float* dw;             // [Co][9][Ci] fp32, accumulated
+    int Nimg, H, W, Ci, Co;
+    int WP, Q, Qtot, XR;   // padded row length, padded pixels per image, total, X-tile rows
+    float inv_q, inv_wp;
+    int chunks_per_block, total_chunks;
+};
+
+__device__ __forceinline__ bf16x8 w3_frag_T(const bf16_t* tile, int ch0, int pos0, int lane) {
+    // MFMA 32x32x16 fragment: lane l <- channel ch0 + (l&31), positions pos0 + (l>>5)*8 .. +7, via two transpose reads
+    const int gq = lane >> 4, s = lane & 15;
+    const bf16_t* base = tile + (pos0 + (gq >> 1) * 8 + (s >> 2)) * W3_PITCH + ch0 + (gq & 1) * 16 + (s & 3) * 4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(base));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(base + 4 * W3_PITCH));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+// padded index q -> pixel index n*H*W + (y'-1)*W + (x'-1), or -1 for pad pixels / outside the batch
+__device__ __forceinline__ long w3_pixel(const Wgrad3Args& p, int q) {
+    if (q < 0 || q >= p.Qtot) return -1;
+    int n = (int)((float)q * p.inv_q);
+    int rem = q - n * p.Q;
+    if (rem < 0) { n--; rem += p.Q; } else if (rem >= p.Q) { n++; rem -= p.Q; }
+    int yp = (int)((float)rem * p.inv_wp);
+    int xp = rem - yp * p.WP;
+    if (xp < 0) { yp--; xp += p.WP; } else if (xp >= p.WP) { yp++; xp -= p.WP; }
+    if (yp < 1 || yp > p.H || xp < 1 || xp > p.W) return -1;
+    return ((long)n * p.H + (yp - 1)) * p.W + (xp - 1);
+}
+
+__global__ __launch_bounds__(256) void k_wgrad3x3_halo(const Wgrad3Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sY = reinterpret_cast<bf16_t*>(smem_raw);            // [128][PITCH]
+    bf16_t* sX = sY + W3_CH * W3_PITCH;                          // [XR][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci_tiles = p.Ci >> 6;
+    const int cot = blockIdx.y / ci_tiles, cit = blockIdx.y - cot * ci_tiles;
+    const int co0 = cot * 64, ci0 = cit * 64;
+    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+    const int chunk = tid & 7, r0 = tid >> 3;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int c_begin = blockIdx.x * p.chunks_per_block;
+    int c_end = c_begin + p.chunks_per_block;
+    if (c_end > p.total_chunks) c_end = p.total_chunks;
+
+    u32x4 vy[4], vx[6];
+    unsigned ld_ok = 0;
+    auto load_chunk = [&](int c) {
+        const int q0 = c * W3_CH;
+        ld_ok = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long pix = w3_pixel(p, q0 + r0 + 32 * i);
+            const bool ok = pix >= 0;
+            vy[i] = *reinterpret_cast<const u32x4*>(p.dy + (ok ? pix * p.Co + co0 + chunk * 8 : 0));
+            ld_ok |= (ok ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int rr = r0 + 32 * i;
+            const long pix = rr < p.XR ? w3_pixel(p, q0 - (p.WP + 1) + rr) : -1;
+            const bool ok = pix >= 0;
+            vx[i] = *reinterpret_cast<const u32x4*>(p.x + (ok ? pix * p.Ci + ci0 + chunk * 8 : 0));
+            ld_ok |= (ok ? 1u : 0u) << (8 + i);
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = (ld_ok >> i) & 1u;
+            u32x4 v = vy[i];
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+            *reinterpret_cast<u32x4*>(sY + (r0 + 32 * i) * W3_PITCH + chunk * 8) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int rr = r0 + 32 * i;
+            const bool ok = (ld_ok >> (8 + i)) & 1u;
+            u32x4 v = vx[i];
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+            if (rr < p.XR) *reinterpret_cast<u32x4*>(sX + rr * W3_PITCH + chunk * 8) = v;
+        }
+    };
+
+    if (c_begin < c_end) load_chunk(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        __syncthreads();                           // previous chunk's fragment reads are done
+        store_chunk();
+        __syncthreads();
+        if (c + 1 < c_end) load_chunk(c + 1);      // in flight while this chunk is contracted
+#pragma unroll 2
+        for (int ks = 0; ks < W3_CH / 16; ++ks) {
+            const bf16x8 fa = w3_frag_T(sY, wco, ks * 16, lane);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const bf16x8 fb = w3_frag_T(sX, wci, ks * 16 + kh * p.WP + kw, lane);
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[kh * 3 + kw], 0, 0, 0);
+                }
+        }
+    }
+    // D[row = co][col = ci]
+    const int ci = ci0 + wci + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            atomicAdd(p.dw + ((long)co * 9 + t) * p.Ci + ci, acc[t][r]);
+        }
+}
+
+extern "C" int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Ci, int Co, hipStream_t stream) {
+    if (Ci % 64 || Co % 64 || W + 2 > (W3_MAXXR - W3_CH) / 2 - 1 || H < 1 || W < 1) return SVSR_ERR_ARG;
+    Wgrad3Args a;
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw;
+    a.Nimg = Nimg; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+    a.WP = W + 2; a.Q = (H + 2) * (W + 2);
+    const long qtot = (long)Nimg * a.Q;
+    if (qtot >= (1L << 24)) return SVSR_ERR_ARG;
+    a.Qtot = (int)qtot;
+    a.XR = W3_CH + 2 * (a.WP + 1);
+    a.inv_q = 1.0f / (float)a.Q; a.inv_wp = 1.0f / (float)a.WP;
+    a.total_chunks = (a.Qtot + W3_CH - 1) / W3_CH;
+    const int tasks = (Co / 64) * (Ci / 64);
+    static const int target_blocks = [] { const char* e = getenv("SVSR_W3_BLOCKS"); return e ? atoi(e) : 512; }();
+    int splits = (target_blocks + tasks - 1) / tasks;         // every workgroup ends with 9*64*64 atomics
+    if (splits > a.total_chunks) splits = a.total_chunks;
+    a.chunks_per_block = (a.total_chunks + splits - 1) / splits;
+    splits = (a.total_chunks + a.chunks_per_block - 1) / a.chunks_per_block;
+    const size_t lds = (size_t)(W3_CH + a.XR) * W3_PITCH * sizeof(bf16_t);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3x3_halo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_wgrad3x3_halo, dim3(splits, tasks), dim3(256), lds, stream, a);
+    return svsr_check_launch();
+}

@@ -16,6 +16,7 @@ BF16 = torch.bfloat16
 STAT_SLOTS = 16
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+HALO_WGRAD = True      # nine-taps-per-pass weight gradient for stride-1 3x3 convs (False: generic per-tap kernel)
 
 
 def _stream() -> int:
@@ -162,6 +163,11 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: int, st
     """dw fp32 [Co][k][k][Ci] += sum dy[n,y,x,co] * x[n, y*s+kh-pad, x*s+kw-pad, ci]."""
     N, H, W, Ci = x.shape
     _, Ho, Wo, Co = dy.shape
+    if HALO_WGRAD and use_tr and k == 3 and stride == 1 and pad == 1 and W <= 29 and H * W >= 36 and Ci % 64 == 0 and Co % 64 == 0:
+        # all nine taps in one pass over zero-padded coordinates (wgrad3x3.hip)
+        _call("svsr_conv3x3_wgrad", _p(x), _p(dy), _p(dw), N, H, W, Ci, Co, _stream(), label="k_wgrad3x3_halo",
+              flops=2.0 * N * H * W * Co * Ci * 9)
+        return
     taps = [(kh - pad, kw - pad, kh * k + kw) for kh in range(k) for kw in range(k)]
     igemm_wgrad(x, dy, dw, Nimg=N, Hi=H, Wi=W, Ci=Ci, in_pitch=Ci, Co=Co, Ho=Ho, Wo=Wo, out_pitch=Co, Ha=Ho, Wa=Wo, S=stride,
                 taps=taps, wt_taps=k * k, use_tr=use_tr)

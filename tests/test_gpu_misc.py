@@ -54,3 +54,28 @@ def test_bias_grad_sizes(dev, R, N):
     ref = dy.float().sum(0)
     err = (db.cpu() - ref).abs().max().item()
     assert err <= 1e-3 * ref.abs().max().item() + 1e-3, err
+
+
+@pytest.mark.parametrize("case", [(2, 6, 6, 128, 256), (3, 11, 11, 128, 64), (1, 22, 22, 64, 64), (2, 7, 9, 64, 128), (33, 6, 6, 64, 64)])
+def test_wgrad3x3_halo(dev, case):
+    """Nine-taps-per-pass weight gradient (zero-padded coordinates) against torch's conv2d weight gradient."""
+    import torch.nn.functional as F
+
+    from syncvsr_amd import ops
+
+    N, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, H, W, Ci, generator=g).to(BF)
+    dy = torch.randn(N, H, W, Co, generator=g).to(BF)
+    ws = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), ws, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    ref = ws.grad.permute(0, 2, 3, 1)
+    assert ops.HALO_WGRAD
+    dw = torch.zeros(Co, 3, 3, Ci, device=dev)
+    ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw, 3, 1, 1, use_tr=True)
+    l2 = ((dw.cpu() - ref).norm() / ref.norm()).item()
+    assert l2 <= 2e-3, l2
+    # accumulation semantics: a second call adds
+    ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw, 3, 1, 1, use_tr=True)
+    l2 = ((dw.cpu() - 2 * ref).norm() / (2 * ref).norm()).item()
+    assert l2 <= 2e-3, l2
