@@ -50,6 +50,12 @@ int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, con
  * dw fp32 [Co][wt_taps][Ci] is ACCUMULATED (atomics).  x = forward input pixels, dyp = output-gradient pixels. */
 int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int use_tr, hipStream_t stream);
 
+/* svsr_conv3x3_c64: conv3x3(64, 64), stride 1, pad 1 (layer1 of the trunk, resnet.py:8-10,36,53) forward and, with the
+ * transposed weights and mirrored taps, its input-gradient; persistent workgroups, weights resident in LDS
+ * (conv3x3_c64.hip).  in/out/addend bf16 [Nimg][H][W][64]; wt bf16 [64][9][64]; tap t reads pixel (y+dy[t], x+dx[t]) with
+ * weight tap tw[t] (HOST arrays of 9 ints); out = conv (+ addend); stats as in svsr_igemm_fwd.  Requires W <= 29. */
+int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, const int* dy, const int* dx, const int* tw, hipStream_t stream);
+
 /* svsr_conv3x3_wgrad: weight gradient of a 3x3 / stride-1 / pad-1 Conv2d (resnet.py:8-10) with all nine taps sharing one
  * pass over x [Nimg][H][W][Ci] and dy [Nimg][H][W][Co] (zero-padded coordinates, wgrad3x3.hip).  dw fp32 [Co][9][Ci] is
  * ACCUMULATED.  Requires Ci, Co multiples of 64 and W <= 29; other shapes go through svsr_igemm_wgrad. */

@@ -8,6 +8,8 @@
 //
 // Grid: x = split of the position range (64-position chunks), y = (co tile, ci tile, tap).  Block = 4 waves (2x2), tile
 // BC x BC channels of one tap; the next chunk's global loads are issued before the MFMA block of the current one.
+#include <stdlib.h>
+
 #include "igemm_common.h"
 
 struct IgemmWgradArgs {
@@ -159,7 +161,9 @@ static int launch_wgrad(IgemmWgradArgs& a, hipStream_t stream) {
     const IgemmGeom& g = a.g;
     const int tasks = ((g.Co + BC - 1) / BC) * ((g.Ci + BC - 1) / BC) * g.ntaps;
     const int total_chunks = (g.M + 63) / 64;
-    int splits = (1024 + tasks - 1) / tasks;            // aim for ~1024 blocks; every block ends with BC*BC atomics
+    static const int target_env = [] { const char* e = getenv("SVSR_WG_BLOCKS"); return e ? atoi(e) : 0; }();
+    const int target_blocks = target_env > 0 ? target_env : (BC == 128 ? 512 : 1024);    // measured optimum per tile size
+    int splits = (target_blocks + tasks - 1) / tasks;   // every block ends with BC*BC fp32 atomics (~2.5 ns each chip-wide)
     if (splits > total_chunks) splits = total_chunks;
     if (splits < 1) splits = 1;
     a.chunks_per_block = (total_chunks + splits - 1) / splits;

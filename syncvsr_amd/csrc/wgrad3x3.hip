@@ -53,7 +53,7 @@ __device__ __forceinline__ long w3_pixel(const Wgrad3Args& p, int q) {
     return ((long)n * p.H + (yp - 1)) * p.W + (xp - 1);
 }
 
-__global__ __launch_bounds__(256) void k_wgrad3x3_halo(const Wgrad3Args p) {
+__global__ __launch_bounds__(256, 2) void k_wgrad3x3_halo(const Wgrad3Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sY = reinterpret_cast<bf16_t*>(smem_raw);            // [128][PITCH]
     bf16_t* sX = sY + W3_CH * W3_PITCH;                          // [XR][PITCH]

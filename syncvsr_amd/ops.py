@@ -114,9 +114,27 @@ def conv2d_fwd(x: torch.Tensor, w16: torch.Tensor, k: int, stride: int, pad: int
     Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
     out = torch.empty((N, Ho, Wo, Co), dtype=BF16, device=x.device)
     taps = [(kh - pad, kw - pad, kh * k + kw) for kh in range(k) for kw in range(k)]
+    if _c64_ok(Ci, Co, k, stride, pad, W):
+        conv3x3_c64(x, w16, out, None, stats, taps)
+        return out
     igemm_fwd(x, w16, out, Nimg=N, Hi=H, Wi=W, Ci=Ci, in_pitch=Ci, Co=Co, Ho=Ho, Wo=Wo, out_pitch=Co, Ha=Ho, Wa=Wo,
               S=stride, taps=taps, wt_taps=k * k, stats=stats)
     return out
+
+
+C64_CONV = True        # persistent weights-in-LDS kernel for conv3x3(64, 64) stride 1 (False: generic implicit GEMM)
+
+
+def _c64_ok(Ci: int, Co: int, k: int, stride: int, pad: int, W: int) -> bool:
+    return C64_CONV and Ci == 64 and Co == 64 and k == 3 and stride == 1 and pad == 1 and W <= 29
+
+
+def conv3x3_c64(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, addend: Optional[torch.Tensor], stats: Optional[torch.Tensor],
+                taps: Sequence[tuple[int, int, int]]) -> None:
+    N, H, W, _ = x.shape
+    dy, dx, tw = zip(*taps)
+    _call("svsr_conv3x3_c64", _p(x), _p(wt), _p(out), _p(addend), _p(stats), N, H, W, _ints(dy), _ints(dx), _ints(tw), _stream(),
+          label="k_conv3x3_c64", flops=2.0 * N * H * W * 64 * 64 * 9)
 
 
 def conv2d_dgrad(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad: int, in_hw: tuple[int, int],
@@ -148,10 +166,13 @@ def conv2d_dgrad(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad:
         dx = torch.zeros((N, H, W, Ci), dtype=BF16, device=dy.device)
     if addend is not None and not full:
         pass  # classes without taps keep the addend's values (dx aliases addend)
+    if stride == 1 and _c64_ok(Ci, Co, k, stride, pad, W):
+        conv3x3_c64(dy, w16t, dx, addend, None, plans[0][2])
+        return dx
     for py, px, taps in plans:
         if not taps:
             continue
-        Ha, Wa = (H - py + stride - 1) // stride, (W - px + stride - 1) // stride
+        Ha, Wa =(H - py + stride - 1) // stride, (W - px + stride - 1) // stride
         if Ha <= 0 or Wa <= 0:
             continue
         igemm_fwd(dy, w16t, dx, Nimg=N, Hi=Ho, Wi=Wo, Ci=Co, in_pitch=Co, Co=Ci, Ho=H, Wo=W, out_pitch=Ci, Ha=Ha, Wa=Wa,
@@ -163,7 +184,7 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: int, st
     """dw fp32 [Co][k][k][Ci] += sum dy[n,y,x,co] * x[n, y*s+kh-pad, x*s+kw-pad, ci]."""
     N, H, W, Ci = x.shape
     _, Ho, Wo, Co = dy.shape
-    if HALO_WGRAD and use_tr and k == 3 and stride == 1 and pad == 1 and W <= 29 and H * W >= 36 and Ci % 64 == 0 and Co % 64 == 0:
+    if HALO_WGRAD and use_tr and k == 3 and stride == 1 and pad == 1 and W <= 29 and H * W >= 100 and Ci % 64 == 0 and Co % 64 == 0:
         # all nine taps in one pass over zero-padded coordinates (wgrad3x3.hip)
         _call("svsr_conv3x3_wgrad", _p(x), _p(dy), _p(dw), N, H, W, Ci, Co, _stream(), label="k_wgrad3x3_halo",
               flops=2.0 * N * H * W * Co * Ci * 9)

@@ -56,6 +56,49 @@ def test_bias_grad_sizes(dev, R, N):
     assert err <= 1e-3 * ref.abs().max().item() + 1e-3, err
 
 
+@pytest.mark.parametrize("case", [(2, 7, 9), (1, 22, 22), (300, 22, 22), (5, 3, 3), (3, 29, 13)])
+def test_conv3x3_c64_persistent(dev, case):
+    """Weights-in-LDS persistent conv3x3(64,64): forward (+BN partial sums) and data-gradient (+addend) vs torch."""
+    import math
+
+    import torch.nn.functional as F
+
+    from syncvsr_amd import ops
+
+    N, H, W = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, H, W, 64, generator=g).to(BF)
+    w = (torch.randn(64, 3, 3, 64, generator=g) / math.sqrt(576)).to(BF)
+    assert ops.C64_CONV
+    slots = torch.zeros(ops.STAT_SLOTS * 2 * 64, device=dev)
+    out = ops.conv2d_fwd(x.to(dev), w.to(dev), 3, 1, 1, stats=slots)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=1)
+    refn = ref.permute(0, 2, 3, 1)
+    err = (out.float().cpu() - refn).abs().max().item()
+    assert err <= 1.5e-2 * refn.abs().max().item(), err
+    st = slots.view(ops.STAT_SLOTS, 2, 64).sum(0).cpu()
+    q_ref = (ref * ref).sum((0, 2, 3))
+    assert ((st[1] - q_ref).abs() <= 3e-3 * q_ref).all()
+    assert ((st[0] - ref.sum((0, 2, 3))).abs() <= 2e-3 * torch.sqrt(ref[0].numel() / 64 * N * q_ref)).all()
+    # data gradient with residual-gradient addend (in place)
+    dy = torch.randn(N, H, W, 64, generator=g).to(BF)
+    add = torch.randn(N, H, W, 64, generator=g).to(BF)
+    xs = torch.zeros(N, 64, H, W, requires_grad=True)
+    F.conv2d(xs, w.float().permute(0, 3, 1, 2), padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    dx = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), 3, 1, 1, (H, W), addend=add.to(dev).clone())
+    ref_dx = xs.grad.permute(0, 2, 3, 1) + add.float()
+    err = (dx.float().cpu() - ref_dx).abs().max().item()
+    assert err <= 1.5e-2 * ref_dx.abs().max().item(), err
+    # and the generic implicit-GEMM kernel agrees
+    ops.C64_CONV = False
+    try:
+        out2 = ops.conv2d_fwd(x.to(dev), w.to(dev), 3, 1, 1)
+    finally:
+        ops.C64_CONV = True
+    assert (out2.float() - out.float()).abs().max().item() <= 1e-2 * refn.abs().max().item()
+
+
 @pytest.mark.parametrize("case", [(2, 6, 6, 128, 256), (3, 11, 11, 128, 64), (1, 22, 22, 64, 64), (2, 7, 9, 64, 128), (33, 6, 6, 64, 64)])
 def test_wgrad3x3_halo(dev, case):
     """Nine-taps-per-pass weight gradient (zero-padded coordinates) against torch's conv2d weight gradient."""
