@@ -90,7 +90,7 @@ def igemm_fwd(inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: i
     bm, bn = igemm_fwd_tile(M, Co)
     _call("svsr_igemm_fwd", _p(inp), _p(wt), _p(out), _p(out_pre), _p(bias), _p(addend), _p(stats), Nimg, Hi, Wi, Ci, in_pitch,
           Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw),
-          int(gelu), int(out_f32), _stream(), label=f"k_igemm_fwd<{bm},{bn}>", flops=2.0 * M * Co * Ci * len(taps))
+          int(gelu), int(out_f32), _stream(), label=f"k_igemm_fwd_glds<{bm},{bn}>", flops=2.0 * M * Co * Ci * len(taps))
 
 
 def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
