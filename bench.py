@@ -76,6 +76,23 @@ def cpu_baseline(cfg, batch_size: int, budget_s: float = 20.0) -> dict:
                       f"median step {med * 1e3:.0f} ms, {cores} torch threads"}
 
 
+def pmc_traffic(kernel_label: str):
+    """HBM bytes per launch of `kernel_label` from the committed rocprofv3 PMC passes (profiles/round1_pmc_per_kernel.json:
+    FETCH_SIZE and WRITE_SIZE in KiB, separate --pmc runs).  gfx950 correction per MI355X_MICROARCH.md §HBM: FETCH_SIZE
+    reports half of the bytes of wide coalesced reads, so it is doubled.  None when no PMC record exists for the kernel."""
+    path = os.path.join(ROOT, "profiles", "round1_pmc_per_kernel.json")
+    try:
+        rec = json.load(open(path))
+    except OSError:
+        return None
+    key = kernel_label.replace(",", ", ")
+    for name, v in rec.items():
+        if name.replace("void ", "") == key and "FETCH_SIZE_avg_per_dispatch" in v and "WRITE_SIZE_avg_per_dispatch" in v:
+            return {"bytes_per_launch": round((2.0 * v["FETCH_SIZE_avg_per_dispatch"] + v["WRITE_SIZE_avg_per_dispatch"]) * 1024.0),
+                    "source": "profiles/round1_pmc_per_kernel.json (rocprofv3 --pmc, FETCH_SIZE doubled for gfx950)"}
+    return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +100,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per step")
+    ap.add_argument("--graph", action="store_true", help="force HIP-graph replay also for N > 1 (default there: eager; the step is "
+                                                         "GPU-bound either way, eager keeps RCCL out of stream capture)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--profile-steps", type=int, default=2, help="eager steps with per-launch HIP events for the roofline leg")
@@ -113,7 +132,8 @@ def main() -> None:
     cfg.train.batch_size = args.batch
     model = Model(cfg, seed=0).to(dev).train()
     batch = [t.to(dev) for t in synthetic_batch(cfg, args.batch, seed=1234 + rank)]
-    trainer = TrainStep(model, cfg, use_graph=not args.no_graph, always_reduce=args.force_collective)
+    use_graph = (not args.no_graph) and (world == 1 or args.graph or args.force_collective)
+    trainer = TrainStep(model, cfg, use_graph=use_graph, always_reduce=args.force_collective, bucket_mb=16.0)
 
     def barrier():
         if use_dist:
@@ -151,7 +171,7 @@ def main() -> None:
         "config": {"workload": "LRW training step (fwd+bwd+allreduce+clip+AdamW), ResNet18 + 6-layer 512-d encoder + vq audio-token CE "
                                "head, random-init weights, N(0,1) clips 29x88x88, uniform tokens/labels",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                   "hip_graph": not args.no_graph},
+                   "hip_graph": use_graph},
         "step_mfma_frac": round(clips_per_s / world * TRAIN_FLOP_PER_CLIP / MFMA_PEAK_BF16, 5),
         "final_loss": round(loss, 4),
     }
@@ -173,7 +193,7 @@ def main() -> None:
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             result["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                "frac": round(achieved * 1e12 / MFMA_PEAK_BF16, 5), "traffic": None,
+                "frac": round(achieved * 1e12 / MFMA_PEAK_BF16, 5), "traffic": pmc_traffic(dom),
                 "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches"] // max(1, args.profile_steps),
                 "per_kernel": {k: {"ms_per_step": round(v["ms"] / max(1, args.profile_steps), 4),
                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
