@@ -56,11 +56,23 @@ __global__ __launch_bounds__(256) void k_stem_conv_fwd(const StemFwdArgs p) {
             const bool row_ok = tt >= 0 && tt < p.T && iy >= 0 && iy < p.H;
             const float* src = p.vid + (((long)b * p.T + tt) * p.H + iy) * p.W;
             bf16_t* dst = sIn + ((long)kt * p.rows_in_max + r) * p.WP;
-            for (int c = tid & 31; c < p.WP; c += 32) {
-                const int ix = c - 3;
-                float v = 0.f;
-                if (row_ok && ix >= 0 && ix < p.W) v = src[ix];
-                dst[c] = f2bf(v);
+            if ((p.W & 3) == 0) {
+                // 16-byte global loads; column ix lands at dst[ix + 3]; the 3 + 3 pad columns are zeroed by lanes 0..5
+                const int l32 = tid & 31;
+                if (l32 < 6) dst[l32 < 3 ? l32 : p.W + l32] = 0;
+                for (int v4 = l32; v4 < (p.W >> 2); v4 += 32) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row_ok) v = *reinterpret_cast<const float4*>(src + 4 * v4);
+                    bf16_t* d = dst + 4 * v4 + 3;
+                    d[0] = f2bf(v.x); d[1] = f2bf(v.y); d[2] = f2bf(v.z); d[3] = f2bf(v.w);
+                }
+            } else {
+                for (int c = tid & 31; c < p.WP; c += 32) {
+                    const int ix = c - 3;
+                    float v = 0.f;
+                    if (row_ok && ix >= 0 && ix < p.W) v = src[ix];
+                    dst[c] = f2bf(v);
+                }
             }
         }
         __syncthreads();
@@ -215,11 +227,29 @@ __global__ __launch_bounds__(256) void k_stem_conv_wgrad(const StemWgradArgs p) 
             const bool row_ok = tt >= 0 && tt < p.T && iy >= 0 && iy < p.H;
             const float* src = p.vid + (((long)b * p.T + tt) * p.H + iy) * p.W;
             bf16_t* dst = sIn + (long)rr * 2 * p.PW;
-            for (int cp = tid & 31; cp < 2 * p.PW; cp += 32) {
-                const int ix = cp - 4;
-                float v = 0.f;
-                if (row_ok && ix >= 0 && ix < p.W) v = src[ix];
-                dst[(cp & 1) * p.PW + (cp >> 1)] = f2bf(v);
+            if ((p.W & 3) == 0) {
+                // 16-byte global loads: pixels 4v..4v+3 -> even plane [2v+2, 2v+3] = (x0, x2), odd plane [2v+2, 2v+3] = (x1, x3)
+                const int l32 = tid & 31;
+                unsigned* even = reinterpret_cast<unsigned*>(dst);
+                unsigned* odd = reinterpret_cast<unsigned*>(dst + p.PW);
+                const int nd = p.PW >> 1, first = 1, last = (p.W >> 2) + 1;      // dwords per plane; data dwords [first, last)
+                for (int d = l32; d < nd; d += 32) {
+                    unsigned e = 0u, o = 0u;
+                    if (row_ok && d >= first && d < last) {
+                        const float4 v = *reinterpret_cast<const float4*>(src + 4 * (d - 1));
+                        e = pack2bf(v.x, v.z);
+                        o = pack2bf(v.y, v.w);
+                    }
+                    even[d] = e;
+                    odd[d] = o;
+                }
+            } else {
+                for (int cp = tid & 31; cp < 2 * p.PW; cp += 32) {
+                    const int ix = cp - 4;
+                    float v = 0.f;
+                    if (row_ok && ix >= 0 && ix < p.W) v = src[ix];
+                    dst[(cp & 1) * p.PW + (cp >> 1)] = f2bf(v);
+                }
             }
         }
         __syncthreads();
