@@ -92,7 +92,7 @@ __device__ __forceinline__ void reduce_to_slots(float* sred, const float* s1, co
         const int g = o >> 4, k = o & 15;
         float acc = 0.f;
         for (int t = g; t < 256; t += cv) acc += sred[t * 16 + k];
-        const int slot = blockIdx.x & (SVSR_STAT_SLOTS - 1);
+        const int slot = (blockIdx.x + blockIdx.y) & (SVSR_STAT_SLOTS - 1);
         const int which = k >> 3, c = g * 8 + (k & 7);
         atomicAdd(slots + ((long)slot * 2 + which) * C + c, acc);
     }
@@ -185,25 +185,38 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const bf16_t* __restri
 // stem: y[n,ph,pw,:] = max_{3x3 window, stride 2, pad 1 (-inf)} gelu(bn(x[n,2ph-1+i,2pw-1+j,:])); argmax index i*3+j
 // first maximum in row-major window order wins (torch CPU max_pool semantics: strictly-greater update).
 // ---------------------------------------------------------------------------------------------------------
+// Index decode shared by the stem passes: a block owns `rpb` consecutive rows of one frame (blockIdx.y = frame) and walks
+// its (row, column, 8-channel group) items with 32-bit arithmetic and a float-reciprocal division — the first version's
+// 64-bit divisions by run-time values cost more than the GELU.
+struct StemRowIter {
+    int W, cv, cshift, rpb;
+    float inv_wcv;
+    __device__ __forceinline__ void decode(int e, int& rl, int& w, int& c8) const {
+        const int wcv = W << cshift;
+        rl = (int)((float)e * inv_wcv);
+        int rem = e - rl * wcv;
+        if (rem < 0) { rl--; rem += wcv; } else if (rem >= wcv) { rl++; rem -= wcv; }
+        w = rem >> cshift;
+        c8 = rem & (cv - 1);
+    }
+};
+
 __global__ __launch_bounds__(256) void k_stem_bn_gelu_pool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                                unsigned char* __restrict__ amax,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               int N, int Hc, int Wc, int Hp, int Wp, int C) {
-    const int cv = C >> 3;
-    const long nvec = (long)N * Hp * Wp * cv;
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long stride = (long)gridDim.x * 256;
-    if (idx >= nvec) return;
-    const int c0 = (int)(idx % cv) * 8;
+                                                               int N, int Hc, int Wc, int Hp, int Wp, int C, StemRowIter it) {
+    const int n = blockIdx.y, row0 = blockIdx.x * it.rpb;
+    const int c0 = (threadIdx.x & (it.cv - 1)) * 8;            // 256 % cv == 0: a thread keeps its channel group
     float sc[8], sh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sc[k] = gamma[c0 + k] * rstd[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k]; }
-    for (; idx < nvec; idx += stride) {
-        long pix = idx / cv;
-        const int pw = (int)(pix % Wp); pix /= Wp;
-        const int ph = (int)(pix % Hp);
-        const int n = (int)(pix / Hp);
+    int rows = Hp - row0; if (rows > it.rpb) rows = it.rpb;
+    const int items = rows * (Wp << it.cshift);
+    for (int e = threadIdx.x; e < items; e += 256) {
+        int rl, pw, c8;
+        it.decode(e, rl, pw, c8);
+        const int ph = row0 + rl;
         float best[8];
         int bi[8];
 #pragma unroll
@@ -227,11 +240,12 @@ __global__ __launch_bounds__(256) void k_stem_bn_gelu_pool_fwd(const bf16_t* __r
                 first = false;
             }
         }
-        reinterpret_cast<u32x4*>(y)[idx] = pack8(best);
+        const long o = (((long)n * Hp + ph) * Wp + pw) * C + c0;
+        *reinterpret_cast<u32x4*>(y + o) = pack8(best);
         unsigned lo = 0, hi = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { lo |= (unsigned)bi[k] << (8 * k); hi |= (unsigned)bi[k + 4] << (8 * k); }
-        reinterpret_cast<uint2*>(amax)[idx] = make_uint2(lo, hi);
+        *reinterpret_cast<uint2*>(amax + o) = make_uint2(lo, hi);
     }
 }
 
@@ -270,62 +284,59 @@ __global__ __launch_bounds__(256) void k_stem_pool_bwd_reduce(const bf16_t* __re
                                                               const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int N, int Hc, int Wc, int Hp, int Wp,
-                                                              int C, float* slots) {
+                                                              int C, float* slots, StemRowIter it) {
     __shared__ float sred[256 * 16];
-    const int cv = C >> 3;
-    const long nvec = (long)N * Hc * Wc * cv;
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long stride = (long)gridDim.x * 256;
-    const int c0 = (int)(idx % cv) * 8;
+    const int n = blockIdx.y, row0 = blockIdx.x * it.rpb;
+    const int c0 = (threadIdx.x & (it.cv - 1)) * 8;
     float mu[8], rs[8], ga[8], be[8], s1[8], s2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k]; ga[k] = gamma[c0 + k]; be[k] = beta[c0 + k]; s1[k] = 0.f; s2[k] = 0.f; }
-    for (; idx < nvec; idx += stride) {
-        long pix = idx / cv;
-        const int w = (int)(pix % Wc); pix /= Wc;
-        const int h = (int)(pix % Hc);
-        const int n = (int)(pix / Hc);
+    int rows = Hc - row0; if (rows > it.rpb) rows = it.rpb;
+    const int items = rows * (Wc << it.cshift);
+    for (int e = threadIdx.x; e < items; e += 256) {
+        int rl, w, c8;
+        it.decode(e, rl, w, c8);
+        const int h = row0 + rl;
         float xv[8], xh[8], z[8], g[8];
-        unpack8(reinterpret_cast<const u32x4*>(x)[idx], xv);
+        unpack8(*reinterpret_cast<const u32x4*>(x + (((long)n * Hc + h) * Wc + w) * C + c0), xv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { xh[k] = (xv[k] - mu[k]) * rs[k]; z[k] = ga[k] * xh[k] + be[k]; }
         stem_gather_g(dpool, amax, n, h, w, c0, Hp, Wp, C, z, g);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * xh[k]; }
     }
-    reduce_to_slots(sred, s1, s2, cv, c0, C, slots);
+    reduce_to_slots(sred, s1, s2, it.cv, c0, C, slots);
 }
 
 __global__ __launch_bounds__(256) void k_stem_pool_bwd_apply(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ amax,
                                                              const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ coef,
-                                                             bf16_t* __restrict__ dx, int N, int Hc, int Wc, int Hp, int Wp, int C) {
-    const int cv = C >> 3;
-    const long nvec = (long)N * Hc * Wc * cv;
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long stride = (long)gridDim.x * 256;
-    if (idx >= nvec) return;
-    const int c0 = (int)(idx % cv) * 8;
+                                                             bf16_t* __restrict__ dx, int N, int Hc, int Wc, int Hp, int Wp, int C,
+                                                             StemRowIter it) {
+    const int n = blockIdx.y, row0 = blockIdx.x * it.rpb;
+    const int c0 = (threadIdx.x & (it.cv - 1)) * 8;
     float mu[8], rs[8], ga[8], be[8], k0[8], k1[8], k2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k]; ga[k] = gamma[c0 + k]; be[k] = beta[c0 + k];
         k0[k] = coef[c0 + k]; k1[k] = coef[C + c0 + k]; k2[k] = coef[2 * C + c0 + k];
     }
-    for (; idx < nvec; idx += stride) {
-        long pix = idx / cv;
-        const int w = (int)(pix % Wc); pix /= Wc;
-        const int h = (int)(pix % Hc);
-        const int n = (int)(pix / Hc);
-        float xv[8], xh[8], z[8], g[8], o[8];
-        unpack8(reinterpret_cast<const u32x4*>(x)[idx], xv);
+    int rows = Hc - row0; if (rows > it.rpb) rows = it.rpb;
+    const int items = rows * (Wc << it.cshift);
+    for (int e = threadIdx.x; e < items; e += 256) {
+        int rl, w, c8;
+        it.decode(e, rl, w, c8);
+        const int h = row0 + rl;
+        const long o = (((long)n * Hc + h) * Wc + w) * C + c0;
+        float xv[8], xh[8], z[8], g[8], ov[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + o), xv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { xh[k] = (xv[k] - mu[k]) * rs[k]; z[k] = ga[k] * xh[k] + be[k]; }
         stem_gather_g(dpool, amax, n, h, w, c0, Hp, Wp, C, z, g);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = k0[k] * (g[k] - k1[k] - xh[k] * k2[k]);
-        reinterpret_cast<u32x4*>(dx)[idx] = pack8(o);
+        for (int k = 0; k < 8; ++k) ov[k] = k0[k] * (g[k] - k1[k] - xh[k] * k2[k]);
+        *reinterpret_cast<u32x4*>(dx + o) = pack8(ov);
     }
 }
 
@@ -378,6 +389,20 @@ static inline int ew_grid(long nvec) {
 }
 static inline bool chan_ok(int C) { return C >= 8 && C <= 2048 && (2048 % C) == 0; }
 
+// rows-per-block iteration for the stem passes: needs C/8 a power of two <= 256; ~1024 items per block
+static inline bool stem_iter(StemRowIter& it, int C, int W, int H) {
+    const int cv = C / 8;
+    if (C % 8 || cv < 1 || cv > 256 || (cv & (cv - 1))) return false;
+    it.W = W; it.cv = cv; it.cshift = 0;
+    while ((1 << it.cshift) < cv) ++it.cshift;
+    int rpb = 1024 / (W * cv);
+    if (rpb < 1) rpb = 1;
+    if (rpb > H) rpb = H;
+    it.rpb = rpb;
+    it.inv_wcv = 1.0f / (float)(W * cv);
+    return true;
+}
+
 extern "C" {
 
 int svsr_bn_finalize(float* slots, int C, float count, float eps, float momentum, float* mean, float* rstd,
@@ -419,9 +444,10 @@ int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* m
 int svsr_stem_bn_gelu_pool_fwd(const void* x, void* y, void* amax, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, hipStream_t stream) {
     if (!chan_ok(C)) return SVSR_ERR_ARG;
-    const long nvec = (long)N * Hp * Wp * (C / 8);
-    hipLaunchKernelGGL(k_stem_bn_gelu_pool_fwd, dim3(ew_grid(nvec)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y,
-                       (unsigned char*)amax, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C);
+    StemRowIter it;
+    if (!stem_iter(it, C, Wp, Hp)) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_stem_bn_gelu_pool_fwd, dim3((Hp + it.rpb - 1) / it.rpb, N), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y,
+                       (unsigned char*)amax, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, it);
     return svsr_check_launch();
 }
 
@@ -429,14 +455,15 @@ int svsr_stem_bn_gelu_pool_bwd(const void* dpool, const void* amax, const void* 
                                const float* gamma, const float* beta, float* slots, float* coef, float* dgamma, float* dbeta,
                                void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, hipStream_t stream) {
     if (!chan_ok(C)) return SVSR_ERR_ARG;
-    const long nvec = (long)N * Hc * Wc * (C / 8);
-    const int grid = ew_grid(nvec);
-    hipLaunchKernelGGL(k_stem_pool_bwd_reduce, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
-                       (const bf16_t*)x, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, slots);
+    StemRowIter it;
+    if (!stem_iter(it, C, Wc, Hc)) return SVSR_ERR_ARG;
+    const dim3 grid((Hc + it.rpb - 1) / it.rpb, N);
+    hipLaunchKernelGGL(k_stem_pool_bwd_reduce, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
+                       (const bf16_t*)x, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, slots, it);
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 127) / 128), dim3(128), 0, stream, slots, C, (float)((long)N * Hc * Wc), gamma, rstd,
                        dgamma, dbeta, coef);
-    hipLaunchKernelGGL(k_stem_pool_bwd_apply, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
-                       (const bf16_t*)x, mean, rstd, gamma, beta, coef, (bf16_t*)dx, N, Hc, Wc, Hp, Wp, C);
+    hipLaunchKernelGGL(k_stem_pool_bwd_apply, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
+                       (const bf16_t*)x, mean, rstd, gamma, beta, coef, (bf16_t*)dx, N, Hc, Wc, Hp, Wp, C, it);
     return svsr_check_launch();
 }
 
