@@ -1,0 +1,82 @@
+"""Sequential-frame CutMix of the reference (LRW/video/src/augment.py:11-118) with a host-side plan and one device gather.
+
+The reference loops over the batch in Python and splices frames IN PLACE, so a later sample can copy frames that an
+earlier iteration already replaced.  Here the same random decisions are drawn on the host in the same order from torch's
+CPU generator (so a seeded run reproduces the reference bit for bit), the in-place chain is resolved on the host into a
+[B, T] source map (which original sample each frame finally comes from), and the clip / token / mask tensors are produced
+by a single gather on the device — no per-sample launches, no device->host sync.
+
+Quirks kept on purpose: the audio tokens are spliced with the FRAME indices (not frame*alignment) exactly as
+augment.py:104-109 does; labels become [B, num_labels] probabilities and word masks become float.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+
+class CutMixPlan:
+    def __init__(self, frame_src: torch.Tensor, token_src: torch.Tensor, target_ids: torch.Tensor, mix: torch.Tensor):
+        self.frame_src = frame_src      # int64 [B, T]   original sample whose frame t ends up in sample b
+        self.token_src = token_src      # int64 [B, Ta]  same for the audio-token axis
+        self.target_ids = target_ids    # int64 [B]
+        self.mix = mix                  # float32 [B]    effective mix rate (0 where no cut happened)
+
+
+def make_plan(batch_size: int, frames: int, token_steps: int, generator: Optional[torch.Generator] = None) -> CutMixPlan:
+    """Draws exactly the random numbers CutMix.forward / mask_video draw, in the same order (augment.py:34-36,86,97-99)."""
+    target_ids = torch.randint(0, batch_size, (batch_size,), generator=generator)
+    target_rates = torch.rand(batch_size, generator=generator)
+    frame_src = torch.arange(batch_size).unsqueeze(1).repeat(1, frames)
+    token_src = torch.arange(batch_size).unsqueeze(1).repeat(1, token_steps)
+    mix = torch.zeros(batch_size)
+    for i in range(batch_size):
+        rate = target_rates[i].item()
+        cut_out_flag = torch.randint(0, 2, (1,), generator=generator)[0].item()
+        if cut_out_flag != 1:
+            continue
+        cut = int(frames * rate)
+        if cut <= 0:
+            continue
+        start = torch.randint(0, frames - cut, (1,), generator=generator).item()
+        t = int(target_ids[i])
+        # in-place semantics: the target's CURRENT frames (already spliced if t < i, or i itself) are copied
+        frame_src[i, start : start + cut] = frame_src[t, start : start + cut].clone()
+        hi = min(start + cut, token_steps)
+        if start < token_steps:
+            token_src[i, start:hi] = token_src[t, start:hi].clone()
+        mix[i] = rate
+    return CutMixPlan(frame_src, token_src, target_ids, mix)
+
+
+class CutMix(torch.nn.Module):
+    """Drop-in for the reference's ``CutMix(num_labels, wav2vec=None)`` on pre-tokenised audio."""
+
+    def __init__(self, num_labels: int, wav2vec=None) -> None:
+        super().__init__()
+        if wav2vec is not None:
+            raise NotImplementedError("on-the-fly wav2vec tokenisation is outside the hot path; pass audio tokens")
+        self.num_labels = num_labels
+        self.generator: Optional[torch.Generator] = None     # None = torch's global CPU generator, as the reference uses
+
+    def forward(self, videos: torch.Tensor, audios: torch.Tensor, labels: torch.Tensor, word_mask: torch.Tensor):
+        B, _, T = videos.shape[:3]
+        plan = make_plan(B, T, audios.shape[1], self.generator)
+        dev = videos.device
+        fsrc = plan.frame_src.to(dev, non_blocking=True)
+        tsrc = plan.token_src.to(dev, non_blocking=True)
+        tidx = torch.arange(T, device=dev).unsqueeze(0).expand(B, T)
+        mixed_videos = videos[fsrc, :, tidx].permute(0, 2, 1, 3, 4).contiguous()          # [B, 1, T, H, W]
+        aidx = torch.arange(audios.shape[1], device=dev).unsqueeze(0).expand(B, -1)
+        mixed_audios = audios[tsrc, aidx].contiguous()
+        mix = plan.mix.to(dev)
+        tgt = plan.target_ids.to(dev)
+        one_hot = F.one_hot(labels, self.num_labels)
+        # integer one-hots promoted by the float mix rate, as in augment.py:111-113; untouched samples stay integer there,
+        # the concatenation makes the batch float — here everything is float32 from the start
+        mixed_labels = (1.0 - mix).unsqueeze(1) * one_hot.float() + mix.unsqueeze(1) * one_hot[tgt].float()
+        wm = word_mask.float()
+        mixed_word_mask = (1.0 - mix).view(B, *([1] * (wm.dim() - 1))) * wm + mix.view(B, *([1] * (wm.dim() - 1))) * wm[tgt]
+        return mixed_videos, mixed_audios, mixed_labels, mixed_word_mask

@@ -90,6 +90,9 @@ class TransformerLightningModule(nn.Module):
             _attach(self, name, t, True)
         for name, shape, kind in self._bspecs:
             _attach(self, name, sd[name], False)
+        from .augment import CutMix
+
+        self.cutmix = CutMix(self.word_labels).eval()          # lightning.py:85-88
         self._store: Optional[_ParamStore] = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_params_dirty())
         self.use_tr = True          # ds_read_b64_tr_b16 fragments in the weight-gradient kernels
@@ -105,9 +108,10 @@ class TransformerLightningModule(nn.Module):
         return [{"params": do_decay}, {"params": no_decay, "weight_decay": 0.0}]
 
     def training_step(self, batch, idx: int = 0) -> torch.Tensor:
+        """lightning.py:194-202: (CutMix) -> forward -> loss_total."""
         self.is_train = True
         if self.config.train.use_cutmix:
-            raise NotImplementedError("CutMix is host-side augmentation outside the hot path (SURVEY §8f-3); apply it before calling")
+            batch = self.cutmix(*batch)
         return self(*batch)["loss_total"]
 
     def mark_params_dirty(self) -> None:

@@ -1,0 +1,28 @@
+"""CPU: syncvsr_amd.augment.CutMix reproduces the reference's sequential in-place CutMix exactly under the same torch seed
+(golden produced by tests/golden/make_golden_cutmix.py from the imported reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cutmix.npz")
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_cutmix_matches_reference(seed):
+    from syncvsr_amd.augment import CutMix
+
+    gold = np.load(GOLD)
+    B, T, A, G, C = 6, 9, 4, 2, 11
+    videos = (torch.arange(B).view(B, 1, 1, 1, 1) * 100 + torch.arange(T).view(1, 1, T, 1, 1)).float().expand(B, 1, T, 2, 3).clone()
+    audios = (torch.arange(B).view(B, 1, 1) * 1000 + torch.arange(T * A).view(1, T * A, 1) * 2 + torch.arange(G).view(1, 1, G)).clone()
+    labels = torch.arange(B) % C
+    word_mask = (torch.arange(T).view(1, T) >= torch.arange(B).view(B, 1)).long()
+    torch.manual_seed(seed)
+    v, a, l, w = CutMix(C)(videos, audios, labels, word_mask)
+    assert np.array_equal(v.numpy(), gold[f"videos_{seed}"])
+    assert np.array_equal(a.numpy(), gold[f"audios_{seed}"])
+    np.testing.assert_allclose(l.numpy(), gold[f"labels_{seed}"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(w.numpy(), gold[f"word_mask_{seed}"], rtol=0, atol=1e-7)
+    assert any((gold[f"videos_{s}"][:, 0, :, 0, 0] // 100 != np.arange(B)[:, None]).any() for s in (7, 8, 9)), "goldens must exercise a splice"

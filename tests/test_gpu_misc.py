@@ -56,6 +56,34 @@ def test_bias_grad_sizes(dev, R, N):
     assert err <= 1e-3 * ref.abs().max().item() + 1e-3, err
 
 
+def test_training_step_with_cutmix(dev):
+    """training_step with `use_cutmix: true` (the shipped LRW recipe): device CutMix -> soft-label CE -> loss vs the oracle on the
+    same mixed batch."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_cases import build_case
+    from oracle import lrw_oracle as O
+    from syncvsr_amd.model import Model
+
+    cfg, sd, batch, training, gold = build_case("lrw_tiny")
+    cfg.train.use_cutmix = True
+    hard_batch = [batch[0], batch[1], batch[2], batch[3]]
+    model = Model(cfg)
+    model.load_state_dict(sd)
+    model.to(dev).train()
+    torch.manual_seed(123)
+    mixed = model.cutmix(*[t.to(dev) for t in hard_batch])
+    assert mixed[2].shape == (batch[0].shape[0], 500) and mixed[2].dtype == torch.float32
+    out = model(*mixed)
+    out["loss_total"].backward()
+    ref = O.forward({k: v.clone() for k, v in sd.items()}, cfg, *[t.cpu() for t in mixed], training=True, use_cutmix_metric=True)
+    for k in ("loss_total", "loss_category", "loss_audio"):
+        assert abs(out[k].item() - ref[k].item()) <= 2e-2 * abs(ref[k].item()), (k, out[k].item(), ref[k].item())
+    torch.manual_seed(123)
+    loss = model.training_step([t.to(dev) for t in hard_batch])
+    assert torch.isfinite(loss) and abs(loss.item() - out["loss_total"].item()) <= 1e-3 * abs(loss.item())
+
+
 @pytest.mark.parametrize("case", [(2, 7, 9), (1, 22, 22), (300, 22, 22), (5, 3, 3), (3, 29, 13)])
 def test_conv3x3_c64_persistent(dev, case):
     """Weights-in-LDS persistent conv3x3(64,64): forward (+BN partial sums) and data-gradient (+addend) vs torch."""
