@@ -23,6 +23,20 @@ def timeit(fn, iters=10, warm=2):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    if os.environ.get("OPB_GRAPH", "1") == "1":
+        # replay a captured graph so small kernels are not host-launch bound
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / iters * 1e3
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
@@ -57,6 +71,20 @@ def main():
             us = timeit(lambda: ops.conv2d_wgrad(x, dy, dw, 3, 1, 1))
             print(f"{name} conv3x3 wgrad(generic) {us:8.1f} us  {flops / us / 1e6:7.1f} TF")
             ops.HALO_WGRAD = True
+    if "linear" in which:
+        R = 960
+        for nm, K, Nn in (("qkv", 512, 1536), ("attn_out", 512, 512), ("ffn1", 512, 2048), ("ffn2", 2048, 512), ("audio", 512, 2560)):
+            x = torch.randn(R, K, device=dev).to(BF); w = (torch.randn(Nn, K, device=dev) / math.sqrt(K)).to(BF)
+            b = torch.zeros(Nn, device=dev); dy = torch.randn(R, Nn, device=dev).to(BF)
+            wt = w.t().contiguous().view(K, 1, Nn)
+            fl = 2.0 * R * K * Nn
+            us = timeit(lambda: ops.linear_fwd(x, w, b, rows=R, K=K, N=Nn, x_pitch=K), iters=20)
+            print(f"linear {nm:9s} fwd   {us:7.1f} us {fl / us / 1e6:7.1f} TF")
+            us = timeit(lambda: ops.linear_dgrad(dy, wt, rows=R, N=Nn, K=K, dy_pitch=Nn), iters=20)
+            print(f"linear {nm:9s} dgrad {us:7.1f} us {fl / us / 1e6:7.1f} TF")
+            dw = torch.zeros(Nn, K, device=dev)
+            us = timeit(lambda: ops.linear_wgrad(x, dy, dw, rows=R, K=K, N=Nn, x_pitch=K, dy_pitch=Nn), iters=20)
+            print(f"linear {nm:9s} wgrad {us:7.1f} us {fl / us / 1e6:7.1f} TF")
     if "stem" in which:
         vid = torch.randn(32, 1, 29, 88, 88, device=dev)
         w = torch.randn(64 * 245, device=dev) * 0.05

@@ -27,6 +27,7 @@ struct IgemmFwdArgs {
     const bf16_t* addend;  // optional bf16 pixels with the geometry of `out`, added before the activation
     float* stats;          // optional BatchNorm partials: atomically accumulated slots [SVSR_STAT_SLOTS][2][Co]
     int gelu, out_f32;
+    int dbg;               // tuning aid (SVSR_IGEMM_DBG): bit0 skip the K loop, bit1 skip the epilogue stores
 };
 
 __device__ unsigned g_zero_page[64];     // 256 zero bytes: DMA source for rows outside the grid
@@ -188,10 +189,21 @@ __device__ __forceinline__ void igemm_mma_tile(const bf16_t* cA, const bf16_t* c
 // ---------------------------------------------------------------------------------------------------------------------
 // LDS-DMA pipeline (default)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+// s_waitcnt vmcnt(LPT * later) + s_barrier with a compile-time immediate for every possible `later` in [0, MAXL]
+template <int LPT, int MAXL>
+__device__ __forceinline__ void wait_tiles_barrier(int later) {
+    if constexpr (MAXL > 0) {
+        if (later == MAXL) { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPT * MAXL) : "memory"); return; }
+        wait_tiles_barrier<LPT, MAXL - 1>(later);
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+template <int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
     constexpr int BK = 64;
-    constexpr int NS = (BM + BN) > 192 ? 2 : 3;      // ring depth: keep >= 2 workgroups per CU (64 KiB vs 72/48 KiB)
+    static_assert(NS >= 2 && (BM / 32 + BN / 32) * (NS - 2) <= 63, "vmcnt immediate is 6 bits");
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, S_ELEMS = A_ELEMS + B_ELEMS;
     constexpr int AR = BM / 32, BR = BN / 32, LPT = AR + BR;     // DMA instructions per thread per tile
@@ -208,19 +220,26 @@ __global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
     const int csw = slot ^ ((r0 >> 1) & 7);                  // ... which must hold global chunk csw (swizzle on the source)
     const int wrow = __builtin_amdgcn_readfirstlane(wave) * 8;   // first row of this wave's 8-row group
 
-    long a_base[AR];
-    int a_y[AR], a_x[AR];
-    unsigned row_ok = 0;
+    // Everything that depends on the row is hoisted out of the K loop: a pointer to the row's centre pixel and one validity
+    // bit per tap.  A K step then costs one 64-bit add + one select per DMA (the first version redid the bounds checks and a
+    // 64-bit multiply per DMA per step, which left the MFMA pipe idle behind ~200 VALU instructions per step).
+    const bf16_t* a_ptr[AR];
+    unsigned a_mask[AR];           // bit t: tap t of this row reads inside the grid
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + r0 + 32 * i;
         const bool ok = m < g.M;
         int n, a, b;
         decode_pos(g, ok ? m : 0, n, a, b);
-        a_base[i] = (long)n * g.Hi * g.Wi;
-        a_y[i] = a * g.S;
-        a_x[i] = b * g.S;
-        row_ok |= (ok ? 1u : 0u) << i;
+        const int y = a * g.S, x = b * g.S;
+        a_ptr[i] = p.in + (((long)n * g.Hi + y) * g.Wi + x) * g.in_pitch + csw * 8;
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = y + g.dy[t], ix = x + g.dx[t];
+            mk |= ((ok && t < g.ntaps && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) ? 1u : 0u) << t;
+        }
+        a_mask[i] = mk;
     }
     const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_page) + slot * 8;
     const bf16_t* b_ptr[BR];
@@ -232,17 +251,16 @@ __global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
     igemm_fill_tables<BM>(g, sRow, sTap, m0);
     __syncthreads();
 
-    const int KT = g.ntaps * (g.Ci / BK);
+    const int KT = (p.dbg & 1) ? 0 : g.ntaps * (g.Ci / BK);
     int t_next = 0, c_next = 0;
     auto stage = [&](int buf) {
-        const int dy = sTap[t_next], dx = sTap[9 + t_next], tw = sTap[18 + t_next];
+        const int t = t_next, tw = sTap[18 + t_next];
         const int c0 = c_next;
+        const long a_off = (long)(sTap[t] * g.Wi + sTap[9 + t]) * g.in_pitch + c0;     // wave-uniform
         bf16_t* dstA = sStage + buf * S_ELEMS + wrow * 64;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int iy = a_y[i] + dy, ix = a_x[i] + dx;
-            const bool ok = ((row_ok >> i) & 1u) && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-            const bf16_t* src = ok ? p.in + (a_base[i] + (long)iy * g.Wi + ix) * g.in_pitch + c0 + csw * 8 : zero_src;
+            const bf16_t* src = ((a_mask[i] >> t) & 1u) ? a_ptr[i] + a_off : zero_src;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dstA + i * 32 * 64), 16, 0, 0);
         }
@@ -265,20 +283,24 @@ __global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    stage(0);
-    if (NS == 3 && KT > 1) stage(1);
+    // prologue: NS-1 tiles in flight (the LDS-DMA round trip is ~1 us: the loop is bound by latency / tiles in flight)
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < KT) stage(s);
     int buf = 0;
     for (int it = 0; it < KT; ++it) {
-        // tile `it` has landed once at most one later tile's DMAs are still outstanding; the barrier makes every wave's
-        // part visible and proves everybody is done reading the buffer the next stage() overwrites.
-        if (NS == 3 && it + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // tile `it` has landed once at most min(NS-2, tiles left) later tiles' DMAs are still outstanding (vmcnt retires in
+        // order); the barrier makes every wave's part visible and proves everybody is done reading the buffer the next
+        // stage() overwrites.
+        const int later = KT - 1 - it < NS - 2 ? KT - 1 - it : NS - 2;
+        wait_tiles_barrier<LPT, NS - 2>(later);
         if (it + NS - 1 < KT) stage(buf >= 1 ? buf - 1 : NS - 1);   // == (it + NS - 1) % NS
         const bf16_t* cA = sStage + buf * S_ELEMS;
         igemm_mma_tile<BM, BN, TM, TN>(cA, cA + A_ELEMS, acc, wm0, wn0, lane);
         buf = buf + 1 == NS ? 0 : buf + 1;
     }
     __syncthreads();
+    if (p.dbg & 2) return;
     igemm_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, sRow, wm0, wn0, n0);
 }
 
@@ -391,26 +413,52 @@ __global__ __launch_bounds__(256) void k_igemm_fwd(const IgemmFwdArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN>
-static int launch_fwd(const IgemmFwdArgs& a, bool glds, hipStream_t stream) {
-    const int gx = (a.g.M + BM - 1) / BM, gy = (a.g.Co + BN - 1) / BN;
-    const size_t tail = (size_t)BM * sizeof(long) + 128;
+template <int BM, int BN, int NS>
+static int launch_glds(const IgemmFwdArgs& a, int gx, int gy, hipStream_t stream) {
+    const size_t lds = (size_t)NS * (BM + BN) * 64 * sizeof(bf16_t) + (size_t)BM * sizeof(long) + 128;
     static bool attr_set = false;
-    const size_t lds_glds = (size_t)((BM + BN) > 192 ? 2 : 3) * (BM + BN) * 64 * sizeof(bf16_t) + tail;
-    const size_t lds_reg = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t) + tail;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_fwd_glds<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_glds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_fwd<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_fwd_glds<BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    if (glds) hipLaunchKernelGGL((k_igemm_fwd_glds<BM, BN>), dim3(gx, gy), dim3(256), lds_glds, stream, a);
-    else hipLaunchKernelGGL((k_igemm_fwd<BM, BN>), dim3(gx, gy), dim3(256), lds_reg, stream, a);
+    hipLaunchKernelGGL((k_igemm_fwd_glds<BM, BN, NS>), dim3(gx, gy), dim3(256), lds, stream, a);
     return svsr_check_launch();
 }
 
+// Ring depth per launch.  One K step of a block costs max(MFMA time, LDS-DMA round trip / tiles in flight) and the round
+// trip is ~1.1 us, so what matters is the number of tiles in flight PER CU: with at least ~2 blocks per CU a shallow ring
+// and several co-resident blocks is best; with about one block per CU (small M*N, long K) the whole 160 KiB goes to one
+// deep ring.  SHALLOW / DEEP stage counts: 128x128 -> 2 / 4, 128x64 -> 3 / 5, 64x64 -> 4 (3 if many blocks) / 8.
+template <int BM, int BN>
+static int launch_fwd(const IgemmFwdArgs& a, bool glds, hipStream_t stream) {
+    const int gx = (a.g.M + BM - 1) / BM, gy = (a.g.Co + BN - 1) / BN;
+    if (!glds) {
+        const size_t lds_reg = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t) + (size_t)BM * sizeof(long) + 128;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_fwd<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_igemm_fwd<BM, BN>), dim3(gx, gy), dim3(256), lds_reg, stream, a);
+        return svsr_check_launch();
+    }
+    static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+    static const int deep_env = [] { const char* e = getenv("SVSR_IGEMM_DEEP"); return e ? atoi(e) : -1; }();   // tuning: 0 never, 1 always
+    const long blocks = (long)gx * gy;
+    const bool deep = deep_env == 1;      // measured: deep rings do not help (the K step was VALU-bound on address generation, not DMA-latency-bound)
+    constexpr int TILE = BM + BN;
+    if (TILE > 192) return deep ? launch_glds<BM, BN, 4>(a, gx, gy, stream) : launch_glds<BM, BN, 2>(a, gx, gy, stream);
+    if (TILE > 128) return deep ? launch_glds<BM, BN, 5>(a, gx, gy, stream) : launch_glds<BM, BN, 3>(a, gx, gy, stream);
+    if (deep) return launch_glds<BM, BN, 8>(a, gx, gy, stream);
+    return blocks <= (long)cus * 5 / 2 ? launch_glds<BM, BN, 4>(a, gx, gy, stream) : launch_glds<BM, BN, 3>(a, gx, gy, stream);
+}
+
 static int igemm_fwd_tile_m(int M, int Co) {
+    static const int forced = [] { const char* e = getenv("SVSR_IGEMM_TILE"); return e ? atoi(e) : 0; }();   // tuning knob
+    static const int thr = [] { const char* e = getenv("SVSR_IGEMM_M128"); return e ? atoi(e) : 8192; }();
+    if (forced == 64 || forced == 128) return forced;
     if (Co <= 64) return M >= 16384 ? 128 : 64;
-    return M >= 8192 ? 128 : 64;
+    return M >= thr ? 128 : 64;
 }
 
 static bool use_glds() {
@@ -427,6 +475,8 @@ extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* o
     if (rc != SVSR_OK) return rc;
     a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = out; a.out_pre = (bf16_t*)out_pre;
     a.bias = bias; a.addend = (const bf16_t*)addend; a.stats = stats; a.gelu = gelu; a.out_f32 = out_f32;
+    static const int dbg = [] { const char* e = getenv("SVSR_IGEMM_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
     const int bm = igemm_fwd_tile_m(a.g.M, Co);
     const bool glds = use_glds();
     if (bm == 128) return Co <= 64 ? launch_fwd<128, 64>(a, glds, stream) : launch_fwd<128, 128>(a, glds, stream);

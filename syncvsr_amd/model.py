@@ -23,6 +23,33 @@ from .init import buffer_specs, hidden_dim, init_state_dict, param_specs, resnet
 BF16 = torch.bfloat16
 
 
+class _SideStream:
+    """Weight-gradient launches go to a second HIP stream: they only feed the flat gradient buffer, so they can fill the
+    tails of the data-gradient / BatchNorm kernels of the main stream (every kernel here ends with a partially filled
+    last round of workgroups).  Tensors handed to the side stream are kept alive until join()."""
+
+    def __init__(self) -> None:
+        self.stream: Optional[torch.cuda.Stream] = None
+        self.keep: list = []
+        self.enabled = False     # measured: concurrent trunk kernels contend for LDS/CU slots, 8.28 -> 8.52 ms; kept as an option
+
+    def run(self, fn, *keep) -> None:
+        if not self.enabled:
+            fn()
+            return
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            fn()
+        self.keep.extend(keep)
+
+    def join(self) -> None:
+        if self.stream is not None and self.enabled:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep.clear()
+
+
 class _Holder(nn.Module):
     """Name-space node: exists only so parameters get the reference's state-dict keys."""
 
@@ -96,6 +123,7 @@ class TransformerLightningModule(nn.Module):
         self._store: Optional[_ParamStore] = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_params_dirty())
         self.use_tr = True          # ds_read_b64_tr_b16 fragments in the weight-gradient kernels
+        self._side = _SideStream()  # second stream for the trunk's weight-gradient launches (._side.enabled = False serialises)
         self.grad_ready_hook = None  # called as hook(lo, hi) when flat gradient range [lo, hi) is final (DDP buckets)
 
     # ------------------------------------------------------------------------------------------------
@@ -358,13 +386,13 @@ def _frontend_backward(model: TransformerLightningModule, st: _ParamStore, tape:
         ws2 = st.bn[t2["bn"]]
         dc2, dres = ops.bn_act_bwd(dx, t2["y"], t2["c"], t2["mean"], t2["rstd"], st.p32(f"{t2['bn']}.weight"), ws2["slots"], ws2["coef"],
                                    st.g32(f"{t2['bn']}.weight"), st.g32(f"{t2['bn']}.bias"), 1, True)
-        _conv_wgrad(st, f"{prefix}.conv2", t2, dc2, use_tr)
+        _conv_wgrad(model, st, f"{prefix}.conv2", t2, dc2, use_tr)
         do1 = ops.conv2d_dgrad(dc2, st.t16(f"{prefix}.conv2.weight").view(planes, 3, 3, planes), 3, 1, 1, t2["x"].shape[1:3])
         t1 = tape[f"{prefix}.conv1"]
         ws1 = st.bn[t1["bn"]]
         dc1, _ = ops.bn_act_bwd(do1, t1["y"], t1["c"], t1["mean"], t1["rstd"], st.p32(f"{t1['bn']}.weight"), ws1["slots"], ws1["coef"],
                                 st.g32(f"{t1['bn']}.weight"), st.g32(f"{t1['bn']}.bias"), 1, False)
-        _conv_wgrad(st, f"{prefix}.conv1", t1, dc1, use_tr)
+        _conv_wgrad(model, st, f"{prefix}.conv1", t1, dc1, use_tr)
         in_hw = t1["x"].shape[1:3]
         w1t = st.t16(f"{prefix}.conv1.weight").view(inp, 3, 3, planes)
         if down:
@@ -372,7 +400,7 @@ def _frontend_backward(model: TransformerLightningModule, st: _ParamStore, tape:
             wsd = st.bn[td["bn"]]
             dcd, _ = ops.bn_act_bwd(dres, None, td["c"], td["mean"], td["rstd"], st.p32(f"{td['bn']}.weight"), wsd["slots"], wsd["coef"],
                                     st.g32(f"{td['bn']}.weight"), st.g32(f"{td['bn']}.bias"), 0, False)
-            _conv_wgrad(st, f"{prefix}.downsample.0", td, dcd, use_tr)
+            _conv_wgrad(model, st, f"{prefix}.downsample.0", td, dcd, use_tr)
             dxa = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw)
             dx = ops.conv2d_dgrad(dcd, st.t16(f"{prefix}.downsample.0.weight").view(inp, 1, 1, planes), 1, stride, 0, in_hw, addend=dxa)
         else:
@@ -383,17 +411,19 @@ def _frontend_backward(model: TransformerLightningModule, st: _ParamStore, tape:
     dconv = ops.stem_bn_gelu_pool_bwd(dx, ts["amax"], ts["c"], ts["mean"], ts["rstd"], st.p32("stem3d.1.weight"), st.p32("stem3d.1.bias"),
                                       ws["slots"], ws["coef"], st.g32("stem3d.1.weight"), st.g32("stem3d.1.bias"))
     ops.stem_conv_wgrad(ts["videos"], dconv, st.g32("stem3d.0.weight"), use_tr)
+    model._side.join()
     _ready(model, st, None)
 
 
-def _conv_wgrad(st: _ParamStore, conv: str, t: dict, dc: torch.Tensor, use_tr: bool) -> None:
-    ops.conv2d_wgrad(t["x"], dc, st.g32(f"{conv}.weight"), t["k"], t["stride"], t["pad"], use_tr)
+def _conv_wgrad(model: TransformerLightningModule, st: _ParamStore, conv: str, t: dict, dc: torch.Tensor, use_tr: bool) -> None:
+    model._side.run(lambda: ops.conv2d_wgrad(t["x"], dc, st.g32(f"{conv}.weight"), t["k"], t["stride"], t["pad"], use_tr), dc)
 
 
 def _ready(model: TransformerLightningModule, st: _ParamStore, name: Optional[str]) -> None:
     """Gradient-ready notification for bucketed all-reduce: everything at or above `name`'s offset in the decayed
     region is final (backward walks the flat buffer from its end to its start); None = all gradients final."""
     if model.grad_ready_hook is not None:
+        model._side.join()            # the bucket's weight gradients were produced on the side stream
         model.grad_ready_hook(0 if name is None else st.offsets[name][0])
 
 
