@@ -65,10 +65,19 @@ def _call(name: str, *args, label: Optional[str] = None, flops: float = 0.0, nby
         _lib.check(rc, name)
 
 
-def igemm_fwd_tile(M: int, Co: int) -> tuple[int, int]:
-    """Mirror of igemm.hip::igemm_fwd_tile_m — only used to label launches with the kernel instantiation."""
+_CUS: Optional[int] = None
+
+
+def igemm_fwd_tile(M: int, Co: int) -> tuple[int, int, int]:
+    """Mirror of igemm_fwd.hip's tile / ring-depth choice — only used to label launches with the kernel instantiation."""
+    global _CUS
+    if _CUS is None:
+        _CUS = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     bm = (128 if M >= 16384 else 64) if Co <= 64 else (128 if M >= 8192 else 64)
-    return (bm, 64 if (bm == 64 or Co <= 64) else 128)
+    bn = 64 if (bm == 64 or Co <= 64) else 128
+    blocks = -(-M // bm) * -(-Co // bn)
+    ns = 2 if bm + bn > 192 else (3 if bm + bn > 128 else (4 if blocks <= _CUS * 5 // 2 else 3))
+    return bm, bn, ns
 
 
 def wgrad_tile(Co: int, Ci: int, ntaps: int) -> int:
@@ -87,10 +96,10 @@ def igemm_fwd(inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: i
               out_pre: Optional[torch.Tensor] = None, out_f32: bool = False) -> None:
     dy, dx, tw = zip(*taps)
     M = Nimg * Ha * Wa
-    bm, bn = igemm_fwd_tile(M, Co)
+    bm, bn, ns = igemm_fwd_tile(M, Co)
     _call("svsr_igemm_fwd", _p(inp), _p(wt), _p(out), _p(out_pre), _p(bias), _p(addend), _p(stats), Nimg, Hi, Wi, Ci, in_pitch,
           Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw),
-          int(gelu), int(out_f32), _stream(), label=f"k_igemm_fwd_glds<{bm},{bn}>", flops=2.0 * M * Co * Ci * len(taps))
+          int(gelu), int(out_f32), _stream(), label=f"k_igemm_fwd_glds<{bm},{bn},{ns}>", flops=2.0 * M * Co * Ci * len(taps))
 
 
 def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
