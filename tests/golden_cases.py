@@ -37,3 +37,36 @@ def build_case(name: str):
     batch = synthetic_batch(cfg, seed=dseed, **bkw)
     gold = np.load(os.path.join(GOLDEN, f"{name}.npz"))
     return cfg, sd, batch, training, gold
+
+
+# ---------------------------------------------------------------------------------------------
+# LRS (E2E) cases — mirrored by tests/golden/make_golden_lrs.py, which imports this table.
+# name: (arg overrides, odim, batch kwargs, weight seed, data seed, perturb_norm, training)
+# ---------------------------------------------------------------------------------------------
+_LRS_TINY = dict(adim=128, aheads=2, eunits=256, elayers=2, ddim=128, dheads=2, dunits=256, dlayers=1)
+LRS_CASES = {
+    "lrs_tiny": (_LRS_TINY, 41, dict(batch=2, t_max=9, size=24, label_len=(2, 4)), 11, 91, True, True),
+    "lrs_tiny_b3": (dict(_LRS_TINY, elayers=1, dlayers=2, cnn_module_kernel=7, lsm_weight=0.2, mtlalpha=0.3, audio_weight=2.0,
+                         codec="wav2vec2"), 23, dict(batch=3, t_max=14, size=16, label_len=(1, 5), min_len_frac=0.3), 12, 92, True, True),
+    "lrs_tiny_eval": (_LRS_TINY, 41, dict(batch=2, t_max=9, size=24, label_len=(2, 4)), 11, 91, True, False),
+    "lrs_full_b2": (dict(), 5049, dict(batch=2, t_max=12, size=88, label_len=(3, 6)), 0, 1234, False, True),
+}
+
+
+def build_lrs_case(name: str, load_golden: bool = True):
+    """-> (args, odim, state_dict, batch, training, golden npz | None)"""
+    from syncvsr_amd.lrs_init import default_lrs_args, lrs_init_state_dict, lrs_synthetic_batch
+
+    over, odim, bkw, wseed, dseed, perturb, training = LRS_CASES[name]
+    args = default_lrs_args(**over)
+    sd = lrs_init_state_dict(args, odim, seed=wseed, perturb_norm=perturb)
+    if not training:
+        g = torch.Generator().manual_seed(5)
+        for k in list(sd):
+            if k.endswith("running_mean"):
+                sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+            elif k.endswith("running_var"):
+                sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+    batch = lrs_synthetic_batch(args, odim=odim, seed=dseed, **bkw)
+    gold = np.load(os.path.join(GOLDEN, f"{name}.npz")) if load_golden else None
+    return args, odim, sd, batch, training, gold
