@@ -41,10 +41,12 @@ extern "C" {
  * svsr_igemm_fwd replaces: nn.Conv2d forward of resnet.layer{1..4} (reference LRW/video/src/tcn/models/resnet.py:8-16,
  *   59-72 / timm resnet18 via lightning.py:55,114-117), their input-gradient (autograd), and every nn.Linear forward /
  *   input-gradient of the BERT encoder and heads (lightning.py:92,107,82,161,168).  Optional epilogues: +bias, +addend
- *   (bf16 pixels laid out like `out`: residual-gradient merge; may alias `out`), exact
- *   GELU (with the pre-activation saved to out_pre), fp32 output, per-channel BatchNorm partial sums into
+ *   (bf16 pixels laid out like `out`: residual-gradient merge; may alias `out`), out = act(alpha*(acc+bias)+addend) with
+ *   act 0 none / 1 exact GELU (pre-activation saved to out_pre) / 2 ReLU (LRS PositionwiseFeedForward,
+ *   transformer/positionwise_feed_forward.py:28-30; alpha carries the Conformer's 0.5 macaron scale and the
+ *   sqrt(d) embedding scale, encoder_layer.py:97,131, embedding.py:208), fp32 output, per-channel BatchNorm partial sums into
  *   stats[SVSR_STAT_SLOTS][2][Co] (accumulated with atomics; zeroed by svsr_bn_finalize). */
-int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int gelu, int out_f32, hipStream_t stream);
+int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int act, int out_f32, float alpha, hipStream_t stream);
 
 /* svsr_igemm_wgrad replaces: the weight-gradient of the same Conv2d / Linear layers (torch autograd).
  * dw fp32 [Co][wt_taps][Ci] is ACCUMULATED (atomics).  x = forward input pixels, dyp = output-gradient pixels. */
@@ -77,29 +79,34 @@ int svsr_bn_finalize(float* slots, int C, float count, float eps, float momentum
 /* eval-mode statistics: mean = running_mean, rstd = rsqrt(running_var + eps). */
 int svsr_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd, hipStream_t stream);
 
-/* y = act(gamma*(x-mean)*rstd + beta [+ res]); act 0 none, 1 ReLU.  Replaces bn1/relu1, bn2/+residual/relu2 and the
+/* y = act(gamma*(x-mean)*rstd + beta [+ res]); act 0 none, 1 ReLU, 2 Swish (LRS backbones/modules/resnet.py:90-107,
+ * transformer/convolution.py:69); any C % 8 == 0 up to 2048.  Replaces bn1/relu1, bn2/+residual/relu2 and the
  * downsample BatchNorm of BasicBlock.forward (resnet.py:59-72). */
 int svsr_bn_act_fwd(const void* x, const void* res, void* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int64_t npix, int C, int act, hipStream_t stream);
 
 /* backward of the above: dgamma/dbeta accumulated; dx (grad of the conv output) and optional dres (= masked dy).
- * slots [SVSR_STAT_SLOTS][2][C] zeroed workspace (left zeroed); coef [3][C] scratch. */
-int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, float* slots, float* coef, float* dgamma, float* dbeta, void* dx, void* dres, int64_t npix, int C, int act, hipStream_t stream);
+ * slots [SVSR_STAT_SLOTS][2][C] zeroed workspace (left zeroed); coef [3][C] scratch.  Swish recomputes its
+ * pre-activation and therefore needs beta and the forward's residual input `res` (null if there was none). */
+int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, float* slots, float* coef, float* dgamma, float* dbeta, void* dx, void* dres, int64_t npix, int C, int act, const float* beta, const void* res, hipStream_t stream);
 
-/* stem3d[1..3]: BatchNorm3d -> nn.GELU() (exact) -> MaxPool3d((1,3,3),(1,2,2),(0,1,1)) fused (lightning.py:51-53).
+/* stem3d[1..3]: BatchNorm3d -> activation -> MaxPool3d((1,3,3),(1,2,2),(0,1,1)) fused; act 1 = exact nn.GELU()
+ * (LRW lightning.py:51-53), act 2 = Swish (LRS backbones/conv3d_extractor.py:30-36).
  * x [N][Hc][Wc][C] -> y [N][Hp][Wp][C], amax uint8 [N][Hp][Wp][C] = window-local argmax (first max wins). */
-int svsr_stem_bn_gelu_pool_fwd(const void* x, void* y, void* amax, const float* mean, const float* rstd, const float* gamma, const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, hipStream_t stream);
+int svsr_stem_bn_act_pool_fwd(const void* x, void* y, void* amax, const float* mean, const float* rstd, const float* gamma, const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, hipStream_t stream);
 
 /* backward of the fused stem pass: dx = gradient of the stem conv output. */
-int svsr_stem_bn_gelu_pool_bwd(const void* dpool, const void* amax, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* slots, float* coef, float* dgamma, float* dbeta, void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, hipStream_t stream);
+int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* slots, float* coef, float* dgamma, float* dbeta, void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, hipStream_t stream);
 
 /* hidden.mean((2,3)) (lightning.py:118) and its backward: [N][HW][C] <-> [N][C]. */
 int svsr_avgpool_fwd(const void* x, void* y, int64_t N, int HW, int C, hipStream_t stream);
 int svsr_avgpool_bwd(const void* dy, void* dx, int64_t N, int HW, int C, hipStream_t stream);
 
 /* ---- transformer encoder passes (bert.hip) --------------------------------------------------------------------
- * y = LayerNorm(a + r) (BertSelfOutput / BertOutput, reached from lightning.py:152-156); r may be null. */
+ * y = LayerNorm(a + r) (BertSelfOutput / BertOutput, reached from lightning.py:152-156; LRS transformer/layer_norm.py);
+ * r may be null; any D % 8 == 0 up to 2048.  The backward returns ds = dLN/d(a+r) (+ addend: the skip-path gradient of a
+ * pre-LN residual block, encoder_layer.py:93-137). */
 int svsr_add_ln_fwd(const void* a, const void* r, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int R, int D, float eps, hipStream_t stream);
-int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd, void* ds, float* dgamma, float* dbeta, int R, int D, hipStream_t stream);
+int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd, void* ds, float* dgamma, float* dbeta, int R, int D, const void* addend, hipStream_t stream);
 
 /* BertEmbeddings on inputs_embeds = cat(cls_token, feats) (lightning.py:149-156): y = LN(e + pos[s] + type[0]).
  * feats bf16 [B][S-1][D]; sum_out bf16 [B*S][D] keeps the pre-norm sum for the backward. */
@@ -111,8 +118,9 @@ int svsr_embed_bwd_scatter(const void* ds, void* dfeats, float* dcls, float* dpo
 int svsr_attn_fwd(const void* qkv, void* ctx, void* probs, int B, int S, int H, int dh, float scale, hipStream_t stream);
 int svsr_attn_bwd(const void* dctx, const void* qkv, const void* probs, void* dqkv, int B, int S, int H, int dh, float scale, hipStream_t stream);
 
-/* dz = dy * gelu'(z) when z != null (BertIntermediate), db[n] += column sums (bias gradient of any nn.Linear). */
-int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, hipStream_t stream);
+/* dz = dy * act'(z) when z != null: act 1 = GELU from the saved pre-activation (BertIntermediate), act 2 = ReLU from the
+ * saved output (PositionwiseFeedForward); db[n] += column sums (bias gradient of any nn.Linear; db may be null). */
+int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, hipStream_t stream);
 
 /* ---- losses / metric / optimiser (loss_optim.hip) --------------------------------------------------------------
  * F.cross_entropy(logits.float(), target, label_smoothing) mean over R rows (lightning.py:163-165,171): exactly one of
@@ -133,6 +141,51 @@ int svsr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, 
 int svsr_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
 int svsr_transpose_cast_multi(const float* src, void* dst, const void* table, int n_entries, hipStream_t stream);
 int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream);
+
+/* ---- LRS (E2E: Conformer encoder + CTC / attention decoder) -----------------------------------------------------
+ * Multi-head attention with 64-wide heads (mha.hip).  q rows [B*Lq] with pitch q_pitch (head h at column h*64), k/v rows
+ * [B*Lk] with pitch kv_pitch; klen[b] = number of valid keys (null: all), causal != 0 masks j > i.  With pe != null the
+ * Conformer's relative-position scores are used: ((q+u)·k_j + (q+v)·pe[Lq-1+j-i]) * scale, pe = linear_pos(pos_emb)
+ * [2*Lq-1][pe_pitch] (reference LRS/video/espnet/nets/pytorch_backend/transformer/attention.py:191-278 incl. rel_shift
+ * :216-236; plain MHA :38-108; mask semantics :71-78).  probs [B*H][Lq][ldp] bf16 is kept for the backward. */
+int svsr_mha_fwd(const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* ctx, int ctx_pitch, void* probs, hipStream_t stream);
+
+/* backward of svsr_mha_fwd: ds [B*H][Lq][ldp] workspace (score gradients); dq/dk/dv written (not accumulated); for the
+ * relative-position form also dq_ac / dq_bd (the two summands of dq, whose column sums are the pos_bias_u / pos_bias_v
+ * gradients) and dpe [2*Lq-1][dpe_pitch] (gradient of the projected position table, feeds linear_pos's weight gradient). */
+int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, hipStream_t stream);
+
+/* Conformer convolution module core (transformer/convolution.py:56-75): u [B*T][2D] = pointwise_cov1 output ->
+ * GLU -> depthwise Conv1d(K odd <= 31, pad (K-1)/2, weight [D][K], bias) -> c [B*T][D] bf16 + BatchNorm1d partial sums
+ * into stats[SVSR_STAT_SLOTS][2][D] (finalised by svsr_bn_finalize; BN+Swish itself is svsr_bn_act_fwd act 2). */
+int svsr_glu_dwconv_fwd(const void* u, const float* w, const float* bias, void* c, float* stats, int B, int T, int D, int K, hipStream_t stream);
+
+/* backward: dc = gradient of c -> du [B*T][2D]; dw [D][K] and dbias [D] accumulated.  part: fp32 workspace of
+ * nsplit * D * (K+1) floats. */
+int svsr_glu_dwconv_bwd(const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias, float* part, int nsplit, int B, int T, int D, int K, hipStream_t stream);
+
+/* CTC loss as the reference calls it (ctc.py:44-74,83-151): log_softmax over V, torch.nn.CTCLoss(reduction="sum",
+ * zero_infinity=True), blank 0, divided by the batch size.  logits fp32 [B*T][ld]; labels int64 [B][Lmax] padded with -1
+ * at the tail; ilen int32 [B].  Workspaces: lse [B*T], ab [B][T][2*Lmax+1], nll [B].  loss_sum += sum_b nll_b / B. */
+int svsr_ctc_fwd(const float* logits, int ld, const int64_t* labels, int Lmax, const int* ilen, int B, int T, int V, float* lse, float* ab, float* nll, float* loss_sum, hipStream_t stream);
+
+/* dlogits [B*T][ldo] bf16 = gout/B * (softmax - label occupancy) for t < ilen[b], 0 elsewhere (and for infeasible targets). */
+int svsr_ctc_grad(const float* logits, int ld, const int64_t* labels, int Lmax, const int* ilen, int B, int T, int V, const float* lse, const float* ab, const float* nll, const float* gout, void* dlogits, int ldo, hipStream_t stream);
+
+/* Decoder input: x[r] = emb[tok[r]] * scale + pe[r % L]  (torch.nn.Embedding + PositionalEncoding, decoder.py:80-84,
+ * embedding.py:78-89); backward scatter-adds scale * dx into demb. */
+int svsr_embed_pos_fwd(const int64_t* tok, const float* emb, const float* pe, void* x, int R, int L, int D, float scale, hipStream_t stream);
+int svsr_embed_pos_bwd(const int64_t* tok, const void* dx, float* demb, int R, int D, float scale, hipStream_t stream);
+
+/* ESPnet LabelSmoothingLoss (label_smoothing_loss.py:41-63): KL(true || softmax(logits)) summed over rows whose target
+ * is not -1, times inv_denom (1/batch, or 1/#tokens with length normalisation); true = 1-smoothing at the target and
+ * smoothing/(V-1) elsewhere.  counts[0] += rows whose argmax equals the target, counts[1] += live rows (th_accuracy,
+ * nets_utils.py:303-323).  logits fp32 [R][ld]; lse [R] saved for the backward. */
+int svsr_ls_loss_fwd(const float* logits, int ld, const int64_t* target, int R, int V, float smoothing, float inv_denom, float* loss_sum, float* lse, float* counts, hipStream_t stream);
+int svsr_ls_loss_bwd(const float* logits, int ld, const int64_t* target, int R, int V, float smoothing, float inv_denom, const float* lse, const float* gout, void* dlogits, int ldo, hipStream_t stream);
+
+/* y = alpha * x over n (multiple of 8) bf16 elements. */
+int svsr_scale_bf16(const void* x, void* y, int64_t n, float alpha, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -259,7 +259,7 @@ def label_smoothing_loss(pred: Tensor, target: Tensor, smoothing: float, normali
     ignore = t == ignore_id
     true = torch.full_like(x, smoothing / (V - 1))
     true.scatter_(1, t.masked_fill(ignore, 0).unsqueeze(1), 1.0 - smoothing)
-    kl = true * (torch.log(true) - torch.log_softmax(x, dim=1))
+    kl = torch.xlogy(true, true) - true * torch.log_softmax(x, dim=1)      # nn.KLDivLoss: 0 log 0 = 0
     denom = int((~ignore).sum()) if normalize_length else B
     return kl.masked_fill(ignore.unsqueeze(1), 0.0).sum() / denom
 

@@ -16,13 +16,13 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd(const bf16_t* __restrict__ a
                                                     bf16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                     int R, int D, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nv = D >> 9;
+    // lane owns columns (i*64 + lane)*8 .. +7 for i < LN_MAXV; any D % 8 == 0 up to 2048 (512 BERT, 768 Conformer)
     for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
         float v[LN_MAXV][8];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
-            if (i < nv) {
+            if ((i * 64 + lane) * 8 < D) {
                 const long o = ((long)row * D + (i * 64 + lane) * 8) >> 3;
                 float fa[8], fr[8];
                 unpack8(reinterpret_cast<const u32x4*>(a)[o], fa);
@@ -35,13 +35,13 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd(const bf16_t* __restrict__ a
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i)
-            if (i < nv)
+            if ((i * 64 + lane) * 8 < D)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
         const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
-            if (i < nv) {
+            if ((i * 64 + lane) * 8 < D) {
                 const int c0 = (i * 64 + lane) * 8;
                 float o[8];
 #pragma unroll
@@ -58,10 +58,10 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const bf16_t* __restrict__ d
                                                     const bf16_t* __restrict__ r, const float* __restrict__ gamma,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     bf16_t* __restrict__ ds, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                    int R, int D) {
+                                                    int R, int D, const bf16_t* __restrict__ addend) {
     extern __shared__ float sred_dyn[];          // [4 waves][2][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nv = D >> 9;
+    // lane owns columns (i*64 + lane)*8 .. +7 for i < LN_MAXV; any D % 8 == 0 up to 2048 (512 BERT, 768 Conformer)
     float ag[LN_MAXV][8], ab[LN_MAXV][8];
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i)
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const bf16_t* __restrict__ d
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
-            if (i < nv) {
+            if ((i * 64 + lane) * 8 < D) {
                 const int c0 = (i * 64 + lane) * 8;
                 const long o = ((long)row * D + c0) >> 3;
                 float fa[8], fr[8], fd[8];
@@ -95,17 +95,23 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const bf16_t* __restrict__ d
         m2 = wave_sum(m2) / (float)D;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
-            if (i < nv) {
+            if ((i * 64 + lane) * 8 < D) {
                 float o[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) o[k] = rs * (gd[i][k] - m1 - xh[i][k] * m2);
+                if (addend != nullptr) {       // pre-LN residual stream: grad(x) = grad through LN + grad of the skip path
+                    float ad[8];
+                    unpack8(reinterpret_cast<const u32x4*>(addend)[((long)row * D + (i * 64 + lane) * 8) >> 3], ad);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] += ad[k];
+                }
                 reinterpret_cast<u32x4*>(ds)[((long)row * D + (i * 64 + lane) * 8) >> 3] = pack8(o);
             }
         }
     }
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i)
-        if (i < nv)
+        if ((i * 64 + lane) * 8 < D)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 sred_dyn[(wave * 2 + 0) * D + (i * 64 + lane) * 8 + k] = ag[i][k];
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void k_embed_ln_fwd(const bf16_t* __restrict__
                                                       bf16_t* __restrict__ sum_out, bf16_t* __restrict__ y,
                                                       float* __restrict__ mean, float* __restrict__ rstd, int B, int S, int D, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nv = D >> 9;
+    // lane owns columns (i*64 + lane)*8 .. +7 for i < LN_MAXV; any D % 8 == 0 up to 2048 (512 BERT, 768 Conformer)
     const int R = B * S;
     for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
         const int b = row / S, s_ = row - b * S;
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) void k_embed_ln_fwd(const bf16_t* __restrict__
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
-            if (i < nv) {
+            if ((i * 64 + lane) * 8 < D) {
                 const int c0 = (i * 64 + lane) * 8;
                 float e[8];
                 if (s_ == 0) {
@@ -158,13 +164,13 @@ __global__ __launch_bounds__(256) void k_embed_ln_fwd(const bf16_t* __restrict__
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i)
-            if (i < nv)
+            if ((i * 64 + lane) * 8 < D)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
         const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
-            if (i < nv) {
+            if ((i * 64 + lane) * 8 < D) {
                 const int c0 = (i * 64 + lane) * 8;
                 float o[8];
 #pragma unroll
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const bf16_t* __restrict__ dct
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bias_act_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z,
                                                       bf16_t* __restrict__ dz, float* __restrict__ db, int R, int N, int n_valid,
-                                                      int ld, int rows_per_block) {
+                                                      int ld, int rows_per_block, int act) {
     // block = 8 row lanes x 32 column vectors: a wave reads 2 rows x 512 contiguous bytes per step
     __shared__ float sred[8][32][8];
     const int cv = N >> 3;
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(256) void k_bias_act_bwd(const bf16_t* __restrict__
                 float zz[8];
                 unpack8(*reinterpret_cast<const u32x4*>(z + (long)r * ld + v * 8), zz);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) g[k] *= gelu_erf_grad(zz[k]);
+                for (int k = 0; k < 8; ++k) g[k] = act == 2 ? (zz[k] > 0.f ? g[k] : 0.f) : g[k] * gelu_erf_grad(zz[k]);
                 *reinterpret_cast<u32x4*>(dz + (long)r * ld + v * 8) = pack8(g);
             }
 #pragma unroll
@@ -366,7 +372,7 @@ extern "C" {
 
 int svsr_add_ln_fwd(const void* a, const void* r, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                     int R, int D, float eps, hipStream_t stream) {
-    if (D % 512 != 0 || D > 512 * LN_MAXV) return SVSR_ERR_ARG;
+    if (D % 8 != 0 || D > 512 * LN_MAXV) return SVSR_ERR_ARG;
     int grid = (R + 3) / 4; if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(k_add_ln_fwd, dim3(grid), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)r, gamma, beta, (bf16_t*)y,
                        mean, rstd, R, D, eps);
@@ -374,11 +380,11 @@ int svsr_add_ln_fwd(const void* a, const void* r, const float* gamma, const floa
 }
 
 int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd,
-                    void* ds, float* dgamma, float* dbeta, int R, int D, hipStream_t stream) {
-    if (D % 512 != 0 || D > 512 * LN_MAXV) return SVSR_ERR_ARG;
+                    void* ds, float* dgamma, float* dbeta, int R, int D, const void* addend, hipStream_t stream) {
+    if (D % 8 != 0 || D > 512 * LN_MAXV) return SVSR_ERR_ARG;
     int grid = (R + 15) / 16; if (grid > 512) grid = 512;       // ~4 rows per wave so the dgamma/dbeta atomics stay few
     hipLaunchKernelGGL(k_add_ln_bwd, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), stream, (const bf16_t*)dy, (const bf16_t*)a, (const bf16_t*)r, gamma,
-                       mean, rstd, (bf16_t*)ds, dgamma, dbeta, R, D);
+                       mean, rstd, (bf16_t*)ds, dgamma, dbeta, R, D, (const bf16_t*)addend);
     return svsr_check_launch();
 }
 
@@ -421,7 +427,7 @@ int svsr_attn_bwd(const void* dctx, const void* qkv, const void* probs, void* dq
     return svsr_check_launch();
 }
 
-int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, hipStream_t stream) {
+int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, hipStream_t stream) {
     if (N % 8 != 0 || ld % 8 != 0) return SVSR_ERR_ARG;
     const int cv = N / 8;
     const int col_blocks = (cv + 31) / 32;
@@ -430,7 +436,7 @@ int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R,
     const int rpb = (R + splits - 1) / splits;
     splits = (R + rpb - 1) / rpb;
     hipLaunchKernelGGL(k_bias_act_bwd, dim3(col_blocks, splits), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)z,
-                       (bf16_t*)dz, db, R, N, n_valid, ld, rpb);
+                       (bf16_t*)dz, db, R, N, n_valid, ld, rpb, act);
     return svsr_check_launch();
 }
 

@@ -51,6 +51,19 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * 0.39894228040143267794f * ex;
 }
 
+// Swish / SiLU (LRS front-end and Conformer convolution module: transformer/convolution.py:78-83)
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float swish(float x) { return x * sigmoid_fast(x); }
+__device__ __forceinline__ float swish_grad(float x) {
+    const float s = sigmoid_fast(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+// activation codes shared by the BatchNorm/stem passes: 0 none, 1 ReLU (BN passes) or GELU (stem), 2 Swish
+#define SVSR_ACT_NONE 0
+#define SVSR_ACT_RELU 1
+#define SVSR_ACT_GELU 1
+#define SVSR_ACT_SWISH 2
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

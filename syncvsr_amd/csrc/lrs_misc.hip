@@ -1,0 +1,458 @@
+// LRS-only passes that are not contractions (gfx950, wave64):
+//   * Conformer convolution module core: GLU -> depthwise Conv1d(k, pad (k-1)/2) with BatchNorm1d partial sums, and its
+//     backward (reference LRS/video/espnet/nets/pytorch_backend/transformer/convolution.py:56-75)
+//   * CTC loss (torch.nn.CTCLoss(reduction="sum", zero_infinity=True) / batch, blank 0; ctc.py:44-74,83-151) with the
+//     gradient with respect to the logits
+//   * decoder token embedding * sqrt(d) + sinusoidal table (transformer/embedding.py:78-89) and its backward
+//   * ESPnet label-smoothing KL loss + token accuracy (label_smoothing_loss.py:41-63, nets_utils.py:303-323)
+//   * y = alpha * x
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GLU + depthwise conv.  u [B*T][2D] bf16 (value | gate), w [D][K] fp32, bias [D] -> c [B*T][D] bf16, BN partial sums.
+// block = (64-frame tile, 64-channel group, batch item); the gated input (tile + halo) is staged in LDS as fp32.
+// ---------------------------------------------------------------------------------------------------------------------
+#define DW_TT 64
+#define DW_MAXK 31
+
+__device__ __forceinline__ void dw_stage_glu(float* sG, const bf16_t* __restrict__ u, int b, int T, int D, int t_lo, int rows, int c0) {
+    // sG[r][ch] = a * sigmoid(gate) at frame t_lo + r (zero outside [0,T)), r < rows
+    for (int idx = threadIdx.x; idx < rows * 8; idx += 256) {
+        const int r = idx >> 3, c8 = idx & 7, t = t_lo + r;
+        float g[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = 0.f;
+        if (t >= 0 && t < T) {
+            const bf16_t* p = u + ((long)b * T + t) * (2 * D) + c0 + c8 * 8;
+            float av[8], bv[8];
+            unpack8(*reinterpret_cast<const u32x4*>(p), av);
+            unpack8(*reinterpret_cast<const u32x4*>(p + D), bv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = av[k] * sigmoid_fast(bv[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sG[r * 64 + c8 * 8 + k] = g[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_glu_dwconv_fwd(const bf16_t* __restrict__ u, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        bf16_t* __restrict__ c, float* __restrict__ stats, int B, int T, int D, int K) {
+    __shared__ float sG[(DW_TT + DW_MAXK - 1) * 64];
+    __shared__ float sRed[4][2][64];
+    const int pad = (K - 1) / 2;
+    const int t0 = blockIdx.x * DW_TT, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int rows = DW_TT + K - 1;
+    dw_stage_glu(sG, u, b, T, D, t0 - pad, rows, c0);
+    __syncthreads();
+    const int ch = threadIdx.x & 63, tq = threadIdx.x >> 6;
+    float wk[DW_MAXK];
+#pragma unroll
+    for (int k = 0; k < DW_MAXK; ++k) wk[k] = k < K ? w[(long)(c0 + ch) * K + k] : 0.f;
+    const float bs = bias[c0 + ch];
+    float s1 = 0.f, s2 = 0.f;
+    for (int tl = tq * 16; tl < tq * 16 + 16; ++tl) {
+        const int t = t0 + tl;
+        if (t >= T) break;
+        float acc = bs;
+#pragma unroll
+        for (int k = 0; k < DW_MAXK; ++k)
+            if (k < K) acc += wk[k] * sG[(tl + k) * 64 + ch];
+        c[((long)b * T + t) * D + c0 + ch] = f2bf(acc);
+        s1 += acc; s2 += acc * acc;
+    }
+    if (stats != nullptr) {
+        sRed[tq][0][ch] = s1; sRed[tq][1][ch] = s2;
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6;
+            const float v = sRed[0][which][ch] + sRed[1][which][ch] + sRed[2][which][ch] + sRed[3][which][ch];
+            const int slot = (blockIdx.x + blockIdx.z) & (SVSR_STAT_SLOTS - 1);
+            atomicAdd(stats + ((long)slot * 2 + which) * D + c0 + ch, v);
+        }
+    }
+}
+
+// backward: dc [B*T][D] -> du [B*T][2D]; per-block partial dw/dbias into part[split][D*(K+1)] (reduced by k_dw_reduce)
+__global__ __launch_bounds__(256) void k_glu_dwconv_bwd(const bf16_t* __restrict__ dc, const bf16_t* __restrict__ u, const float* __restrict__ w,
+                                                        bf16_t* __restrict__ du, float* __restrict__ part, int B, int T, int D, int K, int ntt) {
+    __shared__ float sAll[2 * (DW_TT + DW_MAXK - 1) * 64];
+    float* sG = sAll;
+    float* sDC = sAll + (DW_TT + DW_MAXK - 1) * 64;
+    const int pad = (K - 1) / 2;
+    const int c0 = blockIdx.x * 64, split = blockIdx.y, nsplit = gridDim.y;
+    const int ch = threadIdx.x & 63, tq = threadIdx.x >> 6;
+    const int rows = DW_TT + K - 1;
+    float wk[DW_MAXK], dwk[DW_MAXK];
+#pragma unroll
+    for (int k = 0; k < DW_MAXK; ++k) { wk[k] = k < K ? w[(long)(c0 + ch) * K + k] : 0.f; dwk[k] = 0.f; }
+    float dbs = 0.f;
+    for (int tile = split; tile < B * ntt; tile += nsplit) {
+        const int b = tile / ntt, t0 = (tile - b * ntt) * DW_TT;
+        __syncthreads();
+        dw_stage_glu(sG, u, b, T, D, t0 - pad, rows, c0);
+        for (int idx = threadIdx.x; idx < rows * 8; idx += 256) {
+            const int r = idx >> 3, c8 = idx & 7, t = t0 - pad + r;
+            float g[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = 0.f;
+            if (t >= 0 && t < T) unpack8(*reinterpret_cast<const u32x4*>(dc + ((long)b * T + t) * D + c0 + c8 * 8), g);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sDC[r * 64 + c8 * 8 + k] = g[k];
+        }
+        __syncthreads();
+        for (int tl = tq * 16; tl < tq * 16 + 16; ++tl) {
+            const int t = t0 + tl;
+            if (t >= T) break;
+            // c[t] = sum_k g[t+k-pad] w[k]  =>  dg[t] = sum_k dc[t-k+pad] w[k];  dw[k] += dc[t] g[t+k-pad]
+            const float dct = sDC[(tl + pad) * 64 + ch];
+            float dg = 0.f;
+#pragma unroll
+            for (int k = 0; k < DW_MAXK; ++k)
+                if (k < K) {
+                    dg += wk[k] * sDC[(tl + 2 * pad - k) * 64 + ch];
+                    dwk[k] += dct * sG[(tl + k) * 64 + ch];
+                }
+            dbs += dct;
+            const long o = ((long)b * T + t) * (2 * D) + c0 + ch;
+            const float av = bf2f(u[o]), sg = sigmoid_fast(bf2f(u[o + D]));
+            du[o] = f2bf(dg * sg);
+            du[o + D] = f2bf(dg * av * sg * (1.f - sg));
+        }
+    }
+    // reduce the four frame-quarters of the block through LDS, then one plain store per (channel, tap)
+    __syncthreads();
+    float* sR = sAll;    // [4][K+1][64] <= 32 KB of the 47 KB staging area
+#pragma unroll
+    for (int k = 0; k < DW_MAXK; ++k)
+        if (k < K) sR[(tq * (K + 1) + k) * 64 + ch] = dwk[k];
+    sR[(tq * (K + 1) + K) * 64 + ch] = dbs;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < (K + 1) * 64; idx += 256) {
+        const int k = idx >> 6, cc = idx & 63;
+        const float v = sR[(0 * (K + 1) + k) * 64 + cc] + sR[(1 * (K + 1) + k) * 64 + cc] + sR[(2 * (K + 1) + k) * 64 + cc] + sR[(3 * (K + 1) + k) * 64 + cc];
+        float* dst = part + (long)split * D * (K + 1);
+        if (k < K) dst[(long)(c0 + cc) * K + k] = v;
+        else dst[(long)D * K + c0 + cc] = v;
+    }
+}
+
+__global__ void k_dw_reduce(const float* __restrict__ part, int nsplit, int D, int K, float* __restrict__ dw, float* __restrict__ dbias) {
+    const int n = D * (K + 1);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < nsplit; ++p) s += part[(long)p * n + i];
+        if (i < D * K) dw[i] += s;
+        else dbias[i - D * K] += s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// row log-sum-exp over V columns of fp32 logits (pitch ld): one wave per row
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_lse(const float* __restrict__ z, int ld, int R, int V, float* __restrict__ lse) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        const float* p = z + (long)row * ld;
+        float m = -INFINITY;
+        for (int v = lane; v < V; v += 64) m = fmaxf(m, p[v]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int v = lane; v < V; v += 64) s += __expf(p[v] - m);
+        s = wave_sum(s);
+        if (lane == 0) lse[row] = m + __logf(s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// CTC: one block per batch item walks the lattice (alpha forward, beta backward) in log space.
+// ext[s] = blank for even s, y[s/2] for odd s;  S = 2*len+1.  ab [B][T][Smax] workspace: alpha, then posterior occupancy.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lae(float a, float b) {       // log(exp(a) + exp(b)) with -inf handling
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    const float m = fmaxf(a, b);
+    return m + __logf(__expf(a - m) + __expf(b - m));
+}
+
+__global__ __launch_bounds__(256) void k_ctc_lattice(const float* __restrict__ z, int ld, const float* __restrict__ lse,
+                                                     const long* __restrict__ labels, int Lmax, const int* __restrict__ ilen,
+                                                     int B, int T, int Smax, float* __restrict__ ab, float* __restrict__ nll_out,
+                                                     float* __restrict__ loss_sum) {
+    extern __shared__ float sm[];             // prev[Smax], cur[Smax], ext (int)[Smax]
+    float* prev = sm;
+    float* cur = sm + Smax;
+    int* ext = reinterpret_cast<int*>(sm + 2 * Smax);
+    __shared__ int s_len;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int n = 0;
+        while (n < Lmax && labels[(long)b * Lmax + n] >= 0) ++n;       // targets are padded with -1 at the tail
+        s_len = n;
+    }
+    __syncthreads();
+    const int len = s_len, S = 2 * len + 1, Tb = ilen[b];
+    for (int s = tid; s < Smax; s += 256) ext[s] = (s & 1) && s < S ? (int)labels[(long)b * Lmax + (s >> 1)] : 0;
+    __syncthreads();
+    const float* zb = z + (long)b * T * ld;
+    const float* lb = lse + (long)b * T;
+    float* abb = ab + (long)b * T * Smax;
+    // alpha
+    for (int s = tid; s < S; s += 256) {
+        float v = -INFINITY;
+        if (s == 0) v = zb[0] - lb[0];
+        else if (s == 1) v = zb[ext[1]] - lb[0];
+        prev[s] = v;
+        abb[s] = v;
+    }
+    __syncthreads();
+    for (int t = 1; t < Tb; ++t) {
+        for (int s = tid; s < S; s += 256) {
+            float v = prev[s];
+            if (s >= 1) v = lae(v, prev[s - 1]);
+            if (s >= 2 && (s & 1) && ext[s] != ext[s - 2]) v = lae(v, prev[s - 2]);
+            v = v == -INFINITY ? v : v + zb[(long)t * ld + ext[s]] - lb[t];
+            cur[s] = v;
+            abb[(long)t * Smax + s] = v;
+        }
+        __syncthreads();
+        float* tmp = prev; prev = cur; cur = tmp;
+    }
+    float nll;
+    {
+        const float a1 = prev[S - 1], a2 = S > 1 ? prev[S - 2] : -INFINITY;
+        nll = -lae(a1, a2);
+    }
+    __syncthreads();
+    const bool inf = !(nll < INFINITY);               // zero_infinity=True: infeasible alignments contribute 0 and no gradient
+    if (tid == 0) {
+        nll_out[b] = inf ? 0.f : nll;
+        if (!inf) atomicAdd(loss_sum, nll / (float)B);
+    }
+    // beta (including the emission at t), combined into occupancy  occ[t][s] = exp(alpha + beta + nll - lp[t][ext s])
+    for (int s = tid; s < S; s += 256) {
+        float v = -INFINITY;
+        if (s == S - 1 || s == S - 2) v = zb[(long)(Tb - 1) * ld + ext[s]] - lb[Tb - 1];
+        prev[s] = v;
+    }
+    __syncthreads();
+    for (int t = Tb - 1; t >= 0; --t) {
+        if (t < Tb - 1) {
+            for (int s = tid; s < S; s += 256) {
+                float v = prev[s];
+                if (s + 1 < S) v = lae(v, prev[s + 1]);
+                if (s + 2 < S && (s & 1) && ext[s] != ext[s + 2]) v = lae(v, prev[s + 2]);
+                v = v == -INFINITY ? v : v + zb[(long)t * ld + ext[s]] - lb[t];
+                cur[s] = v;
+            }
+            __syncthreads();
+            float* tmp = prev; prev = cur; cur = tmp;
+        }
+        for (int s = tid; s < S; s += 256) {
+            const float al = abb[(long)t * Smax + s], be = prev[s];
+            float occ = 0.f;
+            if (!inf && al > -INFINITY && be > -INFINITY) occ = __expf(al + be + nll - (zb[(long)t * ld + ext[s]] - lb[t]));
+            abb[(long)t * Smax + s] = occ;
+        }
+        __syncthreads();
+    }
+}
+
+// dlogits[b,t,v] = g/B * (softmax[v] - sum_{s: ext s = v} occ[t][s]) for t < ilen[b] (and a feasible target), else 0
+__global__ __launch_bounds__(256) void k_ctc_grad(const float* __restrict__ z, int ld, const float* __restrict__ lse,
+                                                  const long* __restrict__ labels, int Lmax, const int* __restrict__ ilen,
+                                                  const float* __restrict__ ab, const float* __restrict__ nll, int B, int T, int V, int Smax,
+                                                  const float* __restrict__ gout, bf16_t* __restrict__ dz, int ldo) {
+    extern __shared__ float sAcc[];          // [V]
+    const int row = blockIdx.x, b = row / T, t = row - b * T;
+    bf16_t* o = dz + (long)row * ldo;
+    const bool live = t < ilen[b] && nll[b] != 0.f;
+    if (!live) {
+        for (int v = threadIdx.x; v < ldo; v += 256) o[v] = 0;
+        return;
+    }
+    for (int v = threadIdx.x; v < V; v += 256) sAcc[v] = 0.f;
+    __syncthreads();
+    int len = 0;
+    while (len < Lmax && labels[(long)b * Lmax + len] >= 0) ++len;
+    const int S = 2 * len + 1;
+    const float* occ = ab + ((long)b * T + t) * Smax;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const int e = (s & 1) ? (int)labels[(long)b * Lmax + (s >> 1)] : 0;
+        atomicAdd(&sAcc[e], occ[s]);
+    }
+    __syncthreads();
+    const float g = gout[0] / (float)B, l = lse[row];
+    const float* zr = z + (long)row * ld;
+    for (int v = threadIdx.x; v < ldo; v += 256) o[v] = v < V ? f2bf(g * (__expf(zr[v] - l) - sAcc[v])) : (bf16_t)0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// decoder input embedding: x[b,l,:] = emb[tok[b,l]] * scale + pe[l]      (bf16 out);  backward scatter-adds into demb
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_embed_pos_fwd(const long* __restrict__ tok, const float* __restrict__ emb, const float* __restrict__ pe,
+                                                       bf16_t* __restrict__ x, int R, int L, int D, float scale) {
+    const int dv = D >> 3;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)R * dv; idx += (long)gridDim.x * 256) {
+        const int r = (int)(idx / dv), c0 = (int)(idx - (long)r * dv) * 8;
+        const long tk = tok[r];
+        const float* e = emb + tk * D + c0;
+        const float* p = pe + (long)(r % L) * D + c0;
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = e[k] * scale + p[k];
+        *reinterpret_cast<u32x4*>(x + (long)r * D + c0) = pack8(o);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_embed_pos_bwd(const long* __restrict__ tok, const bf16_t* __restrict__ dx, float* __restrict__ demb,
+                                                       int R, int D, float scale) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)R * D; idx += (long)gridDim.x * 256) {
+        const int r = (int)(idx / D), c = (int)(idx - (long)r * D);
+        atomicAdd(demb + tok[r] * D + c, bf2f(dx[idx]) * scale);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ESPnet label smoothing: true = conf at the target, smoothing/(V-1) elsewhere; loss = sum_rows KL(true || softmax) / denom
+// over rows whose target != ignore; counts[0] += correct argmax, counts[1] += live rows.  One wave per row.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ls_loss_fwd(const float* __restrict__ z, int ld, const long* __restrict__ target, int R, int V,
+                                                     float smoothing, float inv_denom, float* __restrict__ loss_sum, float* __restrict__ lse,
+                                                     float* __restrict__ counts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float conf = 1.f - smoothing, low = smoothing / (float)(V - 1);
+    const float ent = (conf > 0.f ? conf * __logf(conf) : 0.f) + (low > 0.f ? (float)(V - 1) * low * __logf(low) : 0.f);
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        const long t = target[row];
+        const float* p = z + (long)row * ld;
+        float m = -INFINITY;
+        int am = 0;
+        for (int v = lane; v < V; v += 64) { const float x = p[v]; if (x > m) { m = x; am = v; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float om = __shfl_xor(m, o, 64); const int oa = __shfl_xor(am, o, 64);
+            if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+        }
+        float se = 0.f, sz = 0.f;
+        for (int v = lane; v < V; v += 64) { se += __expf(p[v] - m); sz += p[v]; }
+        se = wave_sum(se); sz = wave_sum(sz);
+        const float l = m + __logf(se);
+        if (lane == 0) {
+            lse[row] = l;
+            if (t >= 0) {
+                const float zt = p[t];
+                // -sum true_v log p_v = conf (lse - z_t) + low ((V-1) lse - (sum z - z_t))
+                const float nl = conf * (l - zt) + low * ((float)(V - 1) * l - (sz - zt));
+                atomicAdd(loss_sum, (ent + nl) * inv_denom);
+                atomicAdd(counts + 0, am == (int)t ? 1.f : 0.f);
+                atomicAdd(counts + 1, 1.f);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ls_loss_bwd(const float* __restrict__ z, int ld, const long* __restrict__ target, int R, int V,
+                                                     float smoothing, float inv_denom, const float* __restrict__ lse, const float* __restrict__ gout,
+                                                     bf16_t* __restrict__ dz, int ldo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float conf = 1.f - smoothing, low = smoothing / (float)(V - 1);
+    const float g = gout[0] * inv_denom;
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        const long t = target[row];
+        const float* p = z + (long)row * ld;
+        bf16_t* o = dz + (long)row * ldo;
+        const float l = lse[row];
+        for (int v = lane; v < ldo; v += 64) {
+            float d = 0.f;
+            if (t >= 0 && v < V) d = g * (__expf(p[v] - l) - (v == t ? conf : low));
+            o[v] = f2bf(d);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scale_bf16(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long nvec, float alpha) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        float f[8];
+        unpack8(reinterpret_cast<const u32x4*>(x)[i], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] *= alpha;
+        reinterpret_cast<u32x4*>(y)[i] = pack8(f);
+    }
+}
+
+static inline int grid1d(long n, int cap = 2048) { long b = (n + 255) / 256; if (b > cap) b = cap; if (b < 1) b = 1; return (int)b; }
+
+extern "C" {
+
+int svsr_glu_dwconv_fwd(const void* u, const float* w, const float* bias, void* c, float* stats, int B, int T, int D, int K, hipStream_t stream) {
+    if (D % 64 != 0 || K < 1 || K > DW_MAXK || (K & 1) == 0) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_glu_dwconv_fwd, dim3((T + DW_TT - 1) / DW_TT, D / 64, B), dim3(256), 0, stream, (const bf16_t*)u, w, bias, (bf16_t*)c,
+                       stats, B, T, D, K);
+    return svsr_check_launch();
+}
+
+/* part: fp32 workspace of nsplit * D * (K+1) floats (any contents) */
+int svsr_glu_dwconv_bwd(const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias, float* part, int nsplit,
+                        int B, int T, int D, int K, hipStream_t stream) {
+    if (D % 64 != 0 || K < 1 || K > DW_MAXK || (K & 1) == 0 || nsplit < 1) return SVSR_ERR_ARG;
+    const int ntt = (T + DW_TT - 1) / DW_TT;
+    if (nsplit > B * ntt) nsplit = B * ntt;
+    hipLaunchKernelGGL(k_glu_dwconv_bwd, dim3(D / 64, nsplit), dim3(256), 0, stream, (const bf16_t*)dc, (const bf16_t*)u, w, (bf16_t*)du, part,
+                       B, T, D, K, ntt);
+    hipLaunchKernelGGL(k_dw_reduce, dim3(grid1d((long)D * (K + 1), 256)), dim3(256), 0, stream, part, nsplit, D, K, dw, dbias);
+    return svsr_check_launch();
+}
+
+/* logits fp32 [B*T][ld]; labels int64 [B][Lmax] padded with -1; ilen int32 [B]; ab workspace fp32 [B][T][2*Lmax+1];
+ * lse [B*T], nll [B] scratch; loss_sum += sum_b nll_b / B.  Then svsr_ctc_grad writes dlogits (bf16, pitch ldo). */
+int svsr_ctc_fwd(const float* logits, int ld, const int64_t* labels, int Lmax, const int* ilen, int B, int T, int V, float* lse,
+                 float* ab, float* nll, float* loss_sum, hipStream_t stream) {
+    if (Lmax < 1 || T < 1 || V < 2) return SVSR_ERR_ARG;
+    const int Smax = 2 * Lmax + 1;
+    hipLaunchKernelGGL(k_row_lse, dim3(grid1d((long)B * T * 64)), dim3(256), 0, stream, logits, ld, B * T, V, lse);
+    hipLaunchKernelGGL(k_ctc_lattice, dim3(B), dim3(256), (size_t)3 * Smax * sizeof(float), stream, logits, ld, lse, (const long*)labels, Lmax, ilen,
+                       B, T, Smax, ab, nll, loss_sum);
+    return svsr_check_launch();
+}
+
+int svsr_ctc_grad(const float* logits, int ld, const int64_t* labels, int Lmax, const int* ilen, int B, int T, int V, const float* lse,
+                  const float* ab, const float* nll, const float* gout, void* dlogits, int ldo, hipStream_t stream) {
+    if (Lmax < 1 || (size_t)V * sizeof(float) > 60 * 1024) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_ctc_grad, dim3(B * T), dim3(256), (size_t)V * sizeof(float), stream, logits, ld, lse, (const long*)labels, Lmax, ilen, ab,
+                       nll, B, T, V, 2 * Lmax + 1, gout, (bf16_t*)dlogits, ldo);
+    return svsr_check_launch();
+}
+
+int svsr_embed_pos_fwd(const int64_t* tok, const float* emb, const float* pe, void* x, int R, int L, int D, float scale, hipStream_t stream) {
+    if (D % 8 != 0) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_embed_pos_fwd, dim3(grid1d((long)R * (D / 8))), dim3(256), 0, stream, (const long*)tok, emb, pe, (bf16_t*)x, R, L, D, scale);
+    return svsr_check_launch();
+}
+
+int svsr_embed_pos_bwd(const int64_t* tok, const void* dx, float* demb, int R, int D, float scale, hipStream_t stream) {
+    hipLaunchKernelGGL(k_embed_pos_bwd, dim3(grid1d((long)R * D)), dim3(256), 0, stream, (const long*)tok, (const bf16_t*)dx, demb, R, D, scale);
+    return svsr_check_launch();
+}
+
+int svsr_ls_loss_fwd(const float* logits, int ld, const int64_t* target, int R, int V, float smoothing, float inv_denom, float* loss_sum,
+                     float* lse, float* counts, hipStream_t stream) {
+    if (V < 2) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_ls_loss_fwd, dim3(grid1d((long)R * 64)), dim3(256), 0, stream, logits, ld, (const long*)target, R, V, smoothing, inv_denom,
+                       loss_sum, lse, counts);
+    return svsr_check_launch();
+}
+
+int svsr_ls_loss_bwd(const float* logits, int ld, const int64_t* target, int R, int V, float smoothing, float inv_denom, const float* lse,
+                     const float* gout, void* dlogits, int ldo, hipStream_t stream) {
+    hipLaunchKernelGGL(k_ls_loss_bwd, dim3(grid1d((long)R * 64)), dim3(256), 0, stream, logits, ld, (const long*)target, R, V, smoothing, inv_denom,
+                       lse, gout, (bf16_t*)dlogits, ldo);
+    return svsr_check_launch();
+}
+
+int svsr_scale_bf16(const void* x, void* y, int64_t n, float alpha, hipStream_t stream) {
+    if (n % 8 != 0) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_scale_bf16, dim3(grid1d(n / 8)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (long)(n / 8), alpha);
+    return svsr_check_launch();
+}
+
+}  // extern "C"

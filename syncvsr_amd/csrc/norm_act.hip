@@ -43,7 +43,7 @@ __global__ void k_bn_eval_prepare(const float* running_mean, const float* runnin
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// y = act(gamma * (x - mean) * rstd + beta [+ res])         act: 0 none, 1 relu
+// y = act(gamma * (x - mean) * rstd + beta [+ res])         act: 0 none, 1 relu, 2 swish
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bn_act_fwd(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
                                                     bf16_t* __restrict__ y, const float* __restrict__ mean,
@@ -74,6 +74,9 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const bf16_t* __restrict__ x
         if (act == 1) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) f[k] = fmaxf(f[k], 0.f);
+        } else if (act == 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = swish(f[k]);
         }
         reinterpret_cast<u32x4*>(y)[idx] = pack8(f);
     }
@@ -81,17 +84,19 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const bf16_t* __restrict__ x
 
 // block-level reduction of per-thread 8-channel partials into the atomic slots
 __device__ __forceinline__ void reduce_to_slots(float* sred, const float* s1, const float* s2, int cv, int c0, int C,
-                                                float* slots) {
+                                                float* slots, int first_group = 0) {
     // sred: [256][16]
     const int tid = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sred[tid * 16 + k] = s1[k]; sred[tid * 16 + 8 + k] = s2[k]; }
     __syncthreads();
-    // threads sharing a channel group are tid = g, g + cv, g + 2cv, ...  (256 % cv == 0)
+    // thread t owns channel group (first_group + t) % cv; first_group = 0 whenever 256 % cv == 0
     for (int o = tid; o < cv * 16; o += 256) {
         const int g = o >> 4, k = o & 15;
         float acc = 0.f;
-        for (int t = g; t < 256; t += cv) acc += sred[t * 16 + k];
+        int t0 = g - first_group;
+        if (t0 < 0) t0 += cv;
+        for (int t = t0; t < 256; t += cv) acc += sred[t * 16 + k];
         const int slot = (blockIdx.x + blockIdx.y) & (SVSR_STAT_SLOTS - 1);
         const int which = k >> 3, c = g * 8 + (k & 7);
         atomicAdd(slots + ((long)slot * 2 + which) * C + c, acc);
@@ -103,15 +108,20 @@ __device__ __forceinline__ void reduce_to_slots(float* sred, const float* s1, co
 __global__ __launch_bounds__(256) void k_bn_act_bwd_reduce(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
                                                            const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, long nvec, int C, int act,
-                                                           float* slots) {
+                                                           float* slots, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const bf16_t* __restrict__ res) {
     __shared__ float sred[256 * 16];
     const int cv = C >> 3;
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long stride = (long)gridDim.x * 256;
+    const long stride = (long)gridDim.x * 256;       // a multiple of cv (host): a thread keeps its channel group
     const int c0 = (int)(idx % cv) * 8;
-    float mu[8], rs[8], s1[8], s2[8];
+    const int first_group = (int)(((long)blockIdx.x * 256) % cv);
+    float mu[8], rs[8], ga[8], be[8], s1[8], s2[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k]; s1[k] = 0.f; s2[k] = 0.f; }
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k]; s1[k] = 0.f; s2[k] = 0.f;
+        ga[k] = act == 2 ? gamma[c0 + k] : 0.f; be[k] = act == 2 ? beta[c0 + k] : 0.f;
+    }
     for (; idx < nvec; idx += stride) {
         float g[8], xv[8];
         unpack8(reinterpret_cast<const u32x4*>(dy)[idx], g);
@@ -121,11 +131,18 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_reduce(const bf16_t* __restr
             unpack8(reinterpret_cast<const u32x4*>(y)[idx], yv);
 #pragma unroll
             for (int k = 0; k < 8; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+        } else if (act == 2) {     // Swish: the pre-activation is recomputed from x (and the residual branch)
+            float rv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rv[k] = 0.f;
+            if (res != nullptr) unpack8(reinterpret_cast<const u32x4*>(res)[idx], rv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] *= swish_grad((xv[k] - mu[k]) * rs[k] * ga[k] + be[k] + rv[k]);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * (xv[k] - mu[k]) * rs[k]; }
     }
-    reduce_to_slots(sred, s1, s2, cv, c0, C, slots);
+    reduce_to_slots(sred, s1, s2, cv, c0, C, slots, first_group);
 }
 
 // finalise the backward statistics: dbeta += sum g, dgamma += sum g*xhat, coef = {gamma*rstd, sum g / n, sum g*xhat / n}
@@ -152,17 +169,19 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const bf16_t* __restri
                                                           const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ coef,
                                                           bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, long nvec,
-                                                          int C, int act) {
+                                                          int C, int act, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const bf16_t* __restrict__ res) {
     const int cv = C >> 3;
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const long stride = (long)gridDim.x * 256;
     if (idx >= nvec) return;
     const int c0 = (int)(idx % cv) * 8;
-    float mu[8], rs[8], k0[8], k1[8], k2[8];
+    float mu[8], rs[8], k0[8], k1[8], k2[8], ga[8], be[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k];
         k0[k] = coef[c0 + k]; k1[k] = coef[C + c0 + k]; k2[k] = coef[2 * C + c0 + k];
+        ga[k] = act == 2 ? gamma[c0 + k] : 0.f; be[k] = act == 2 ? beta[c0 + k] : 0.f;
     }
     for (; idx < nvec; idx += stride) {
         float g[8], xv[8], o[8];
@@ -173,6 +192,13 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const bf16_t* __restri
             unpack8(reinterpret_cast<const u32x4*>(y)[idx], yv);
 #pragma unroll
             for (int k = 0; k < 8; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+        } else if (act == 2) {
+            float rv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rv[k] = 0.f;
+            if (res != nullptr) unpack8(reinterpret_cast<const u32x4*>(res)[idx], rv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] *= swish_grad((xv[k] - mu[k]) * rs[k] * ga[k] + be[k] + rv[k]);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = k0[k] * (g[k] - k1[k] - (xv[k] - mu[k]) * rs[k] * k2[k]);
@@ -201,7 +227,8 @@ struct StemRowIter {
     }
 };
 
-__global__ __launch_bounds__(256) void k_stem_bn_gelu_pool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+template <int ACT>
+__global__ __launch_bounds__(256) void k_stem_bn_act_pool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                                unsigned char* __restrict__ amax,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -234,7 +261,7 @@ __global__ __launch_bounds__(256) void k_stem_bn_gelu_pool_fwd(const bf16_t* __r
                 unpack8(*reinterpret_cast<const u32x4*>(x + (((long)n * Hc + h) * Wc + w) * C + c0), f);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float v = gelu_erf(f[k] * sc[k] + sh[k]);
+                    const float v = ACT == 2 ? swish(f[k] * sc[k] + sh[k]) : gelu_erf(f[k] * sc[k] + sh[k]);
                     if (first || v > best[k]) { best[k] = v; bi[k] = i * 3 + j; }
                 }
                 first = false;
@@ -251,6 +278,7 @@ __global__ __launch_bounds__(256) void k_stem_bn_gelu_pool_fwd(const bf16_t* __r
 
 // gradient reaching the stem conv output element (n,h,w,c..c+7) through pool -> gelu:  g = (sum of dpool over the
 // windows whose argmax is this element) * gelu'(bn(x)).
+template <int ACT>
 __device__ __forceinline__ void stem_gather_g(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ amax,
                                               int n, int h, int w, int c0, int Hp, int Wp, int C, const float* z, float* g) {
     float acc[8];
@@ -277,9 +305,10 @@ __device__ __forceinline__ void stem_gather_g(const bf16_t* __restrict__ dpool, 
         }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) g[k] = acc[k] * gelu_erf_grad(z[k]);
+    for (int k = 0; k < 8; ++k) g[k] = acc[k] * (ACT == 2 ? swish_grad(z[k]) : gelu_erf_grad(z[k]));
 }
 
+template <int ACT>
 __global__ __launch_bounds__(256) void k_stem_pool_bwd_reduce(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ amax,
                                                               const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -301,13 +330,14 @@ __global__ __launch_bounds__(256) void k_stem_pool_bwd_reduce(const bf16_t* __re
         unpack8(*reinterpret_cast<const u32x4*>(x + (((long)n * Hc + h) * Wc + w) * C + c0), xv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { xh[k] = (xv[k] - mu[k]) * rs[k]; z[k] = ga[k] * xh[k] + be[k]; }
-        stem_gather_g(dpool, amax, n, h, w, c0, Hp, Wp, C, z, g);
+        stem_gather_g<ACT>(dpool, amax, n, h, w, c0, Hp, Wp, C, z, g);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * xh[k]; }
     }
     reduce_to_slots(sred, s1, s2, it.cv, c0, C, slots);
 }
 
+template <int ACT>
 __global__ __launch_bounds__(256) void k_stem_pool_bwd_apply(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ amax,
                                                              const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -333,7 +363,7 @@ __global__ __launch_bounds__(256) void k_stem_pool_bwd_apply(const bf16_t* __res
         unpack8(*reinterpret_cast<const u32x4*>(x + o), xv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { xh[k] = (xv[k] - mu[k]) * rs[k]; z[k] = ga[k] * xh[k] + be[k]; }
-        stem_gather_g(dpool, amax, n, h, w, c0, Hp, Wp, C, z, g);
+        stem_gather_g<ACT>(dpool, amax, n, h, w, c0, Hp, Wp, C, z, g);
 #pragma unroll
         for (int k = 0; k < 8; ++k) ov[k] = k0[k] * (g[k] - k1[k] - xh[k] * k2[k]);
         *reinterpret_cast<u32x4*>(dx + o) = pack8(ov);
@@ -388,6 +418,18 @@ static inline int ew_grid(long nvec) {
     return (int)b;
 }
 static inline bool chan_ok(int C) { return C >= 8 && C <= 2048 && (2048 % C) == 0; }
+// any C % 8 == 0 up to 2048 (e.g. 768): the grid is rounded so that gridDim.x * 256 is a multiple of C/8 and every
+// thread keeps one channel group across its grid-stride loop
+static inline bool chan_ok_any(int C) { return C >= 8 && C <= 2048 && (C % 8) == 0; }
+static inline int ew_grid_for(long nvec, int C) {
+    const int cv = C / 8;
+    int a = cv, b = 256;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int m = cv / a;                 // grid must be a multiple of cv / gcd(cv, 256)
+    int g = ew_grid(nvec);
+    g = (g + m - 1) / m * m;
+    return g;
+}
 
 // rows-per-block iteration for the stem passes: needs C/8 a power of two <= 256; ~1024 items per block
 static inline bool stem_iter(StemRowIter& it, int C, int W, int H) {
@@ -420,50 +462,64 @@ int svsr_bn_eval_prepare(const float* running_mean, const float* running_var, in
 
 int svsr_bn_act_fwd(const void* x, const void* res, void* y, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, int64_t npix, int C, int act, hipStream_t stream) {
-    if (!chan_ok(C)) return SVSR_ERR_ARG;
+    if (!chan_ok_any(C)) return SVSR_ERR_ARG;
     const long nvec = npix * (C / 8);
-    hipLaunchKernelGGL(k_bn_act_fwd, dim3(ew_grid(nvec)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y,
+    hipLaunchKernelGGL(k_bn_act_fwd, dim3(ew_grid_for(nvec, C)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y,
                        mean, rstd, gamma, beta, nvec, C, act);
     return svsr_check_launch();
 }
 
 int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma,
                     float* slots, float* coef, float* dgamma, float* dbeta, void* dx, void* dres, int64_t npix, int C, int act,
-                    hipStream_t stream) {
-    if (!chan_ok(C)) return SVSR_ERR_ARG;
+                    const float* beta, const void* res, hipStream_t stream) {
+    if (!chan_ok_any(C)) return SVSR_ERR_ARG;
+    if (act == 2 && beta == nullptr) return SVSR_ERR_ARG;
     const long nvec = npix * (C / 8);
-    const int grid = ew_grid(nvec);
+    const int grid = ew_grid_for(nvec, C);
     hipLaunchKernelGGL(k_bn_act_bwd_reduce, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x,
-                       mean, rstd, nvec, C, act, slots);
+                       mean, rstd, nvec, C, act, slots, gamma, beta, (const bf16_t*)res);
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 127) / 128), dim3(128), 0, stream, slots, C, (float)npix, gamma, rstd, dgamma, dbeta, coef);
     hipLaunchKernelGGL(k_bn_act_bwd_apply, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x,
-                       mean, rstd, coef, (bf16_t*)dx, (bf16_t*)dres, nvec, C, act);
+                       mean, rstd, coef, (bf16_t*)dx, (bf16_t*)dres, nvec, C, act, gamma, beta, (const bf16_t*)res);
     return svsr_check_launch();
 }
 
-int svsr_stem_bn_gelu_pool_fwd(const void* x, void* y, void* amax, const float* mean, const float* rstd, const float* gamma,
-                               const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, hipStream_t stream) {
-    if (!chan_ok(C)) return SVSR_ERR_ARG;
+int svsr_stem_bn_act_pool_fwd(const void* x, void* y, void* amax, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, hipStream_t stream) {
+    if (!chan_ok(C) || (act != SVSR_ACT_GELU && act != SVSR_ACT_SWISH)) return SVSR_ERR_ARG;
     StemRowIter it;
     if (!stem_iter(it, C, Wp, Hp)) return SVSR_ERR_ARG;
-    hipLaunchKernelGGL(k_stem_bn_gelu_pool_fwd, dim3((Hp + it.rpb - 1) / it.rpb, N), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y,
-                       (unsigned char*)amax, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, it);
+    const dim3 grid((Hp + it.rpb - 1) / it.rpb, N);
+    if (act == SVSR_ACT_SWISH)
+        hipLaunchKernelGGL(k_stem_bn_act_pool_fwd<2>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (unsigned char*)amax, mean,
+                           rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, it);
+    else
+        hipLaunchKernelGGL(k_stem_bn_act_pool_fwd<1>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (unsigned char*)amax, mean,
+                           rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, it);
     return svsr_check_launch();
 }
 
-int svsr_stem_bn_gelu_pool_bwd(const void* dpool, const void* amax, const void* x, const float* mean, const float* rstd,
-                               const float* gamma, const float* beta, float* slots, float* coef, float* dgamma, float* dbeta,
-                               void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, hipStream_t stream) {
-    if (!chan_ok(C)) return SVSR_ERR_ARG;
+int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, float* slots, float* coef, float* dgamma, float* dbeta,
+                              void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, hipStream_t stream) {
+    if (!chan_ok(C) || (act != SVSR_ACT_GELU && act != SVSR_ACT_SWISH)) return SVSR_ERR_ARG;
     StemRowIter it;
     if (!stem_iter(it, C, Wc, Hc)) return SVSR_ERR_ARG;
     const dim3 grid((Hc + it.rpb - 1) / it.rpb, N);
-    hipLaunchKernelGGL(k_stem_pool_bwd_reduce, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
-                       (const bf16_t*)x, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, slots, it);
+    if (act == SVSR_ACT_SWISH)
+        hipLaunchKernelGGL(k_stem_pool_bwd_reduce<2>, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
+                           (const bf16_t*)x, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, slots, it);
+    else
+        hipLaunchKernelGGL(k_stem_pool_bwd_reduce<1>, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
+                           (const bf16_t*)x, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, slots, it);
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 127) / 128), dim3(128), 0, stream, slots, C, (float)((long)N * Hc * Wc), gamma, rstd,
                        dgamma, dbeta, coef);
-    hipLaunchKernelGGL(k_stem_pool_bwd_apply, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
-                       (const bf16_t*)x, mean, rstd, gamma, beta, coef, (bf16_t*)dx, N, Hc, Wc, Hp, Wp, C, it);
+    if (act == SVSR_ACT_SWISH)
+        hipLaunchKernelGGL(k_stem_pool_bwd_apply<2>, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
+                           (const bf16_t*)x, mean, rstd, gamma, beta, coef, (bf16_t*)dx, N, Hc, Wc, Hp, Wp, C, it);
+    else
+        hipLaunchKernelGGL(k_stem_pool_bwd_apply<1>, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
+                           (const bf16_t*)x, mean, rstd, gamma, beta, coef, (bf16_t*)dx, N, Hc, Wc, Hp, Wp, C, it);
     return svsr_check_launch();
 }
 

@@ -93,13 +93,13 @@ def igemm_fwd(inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: i
               Co: int, Ho: int, Wo: int, out_pitch: int, Ha: int, Wa: int, S: int = 1, OS: int = 1, oy0: int = 0, ox0: int = 0,
               taps: Sequence[tuple[int, int, int]] = ((0, 0, 0),), wt_taps: int = 1, bias: Optional[torch.Tensor] = None,
               addend: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, gelu: bool = False,
-              out_pre: Optional[torch.Tensor] = None, out_f32: bool = False) -> None:
+              out_pre: Optional[torch.Tensor] = None, out_f32: bool = False, relu: bool = False, alpha: float = 1.0) -> None:
     dy, dx, tw = zip(*taps)
     M = Nimg * Ha * Wa
     bm, bn, ns = igemm_fwd_tile(M, Co)
     _call("svsr_igemm_fwd", _p(inp), _p(wt), _p(out), _p(out_pre), _p(bias), _p(addend), _p(stats), Nimg, Hi, Wi, Ci, in_pitch,
           Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw),
-          int(gelu), int(out_f32), _stream(), label=f"k_igemm_fwd_glds<{bm},{bn},{ns}>", flops=2.0 * M * Co * Ci * len(taps))
+          1 if gelu else (2 if relu else 0), int(out_f32), float(alpha), _stream(), label=f"k_igemm_fwd_glds<{bm},{bn},{ns}>", flops=2.0 * M * Co * Ci * len(taps))
 
 
 def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
@@ -206,8 +206,8 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: int, st
 def linear_fwd(x: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor], *, rows: int, K: int, N: int, x_pitch: int,
                out: Optional[torch.Tensor] = None, out_pitch: Optional[int] = None, gelu: bool = False,
                out_f32: bool = False, addend: Optional[torch.Tensor] = None,
-               seq: Optional[tuple[int, int, int]] = None) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """out[rows, N] = x[rows, K] @ w16[N, K]^T (+bias)(+addend)(gelu).  `seq=(S, s0, n)` selects rows s0..s0+n-1 of every
+               seq: Optional[tuple[int, int, int]] = None, relu: bool = False, alpha: float = 1.0) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """out[rows, N] = act(alpha * (x[rows, K] @ w16[N, K]^T + bias) + addend), act = gelu | relu | none.  `seq=(S, s0, n)` selects rows s0..s0+n-1 of every
     length-S sequence of x (x is [B*S, K]) as the source and writes a dense [B*n, N] result."""
     out_pitch = out_pitch or N
     if out is None:
@@ -219,12 +219,12 @@ def linear_fwd(x: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor],
         S, s0, n = seq
         geo = dict(Nimg=rows // n, Hi=1, Wi=S, Ha=1, Wa=n, Ho=1, Wo=n, taps=((0, s0, 0),))
     igemm_fwd(x, w16, out, Ci=K, in_pitch=x_pitch, Co=N, out_pitch=out_pitch, bias=bias, addend=addend, gelu=gelu, out_pre=pre,
-              out_f32=out_f32, **geo)
+              out_f32=out_f32, relu=relu, alpha=alpha, **geo)
     return out, pre
 
 
 def linear_dgrad(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, K: int, dy_pitch: int, out: Optional[torch.Tensor] = None,
-                 addend: Optional[torch.Tensor] = None, seq: Optional[tuple[int, int, int]] = None) -> torch.Tensor:
+                 addend: Optional[torch.Tensor] = None, seq: Optional[tuple[int, int, int]] = None, alpha: float = 1.0) -> torch.Tensor:
     """dx[rows, K] = dy[rows, N] @ w16t[K, Npad]^T-of-transpose, i.e. dy @ W.  With `seq=(S, s0, n)` the dense dy rows
     [B*n] are scattered to rows s0.. of every length-S sequence of dx [B*S, K]."""
     Np = w16t.shape[-1]
@@ -236,7 +236,7 @@ def linear_dgrad(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, K: 
         S, s0, n = seq
         assert out is not None
         geo = dict(Nimg=rows // n, Hi=1, Wi=n, Ha=1, Wa=n, Ho=1, Wo=S, ox0=s0)
-    igemm_fwd(dy, w16t, out, Ci=Np, in_pitch=dy_pitch, Co=K, out_pitch=K, addend=addend, **geo)
+    igemm_fwd(dy, w16t, out, Ci=Np, in_pitch=dy_pitch, Co=K, out_pitch=K, addend=addend, alpha=alpha, **geo)
     return out
 
 
@@ -269,21 +269,24 @@ def stem_conv_wgrad(videos: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, us
           label=f"k_stem_conv_wgrad<{'true' if use_tr else 'false'}>", flops=2.0 * B * T * (H // 2) * (W // 2) * 64 * 245)
 
 
-def stem_bn_gelu_pool_fwd(x: torch.Tensor, mean, rstd, gamma, beta) -> tuple[torch.Tensor, torch.Tensor]:
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SWISH = 0, 1, 1, 2     # ReLU/GELU share code 1: ReLU in the BN passes, GELU in the stem pass
+
+
+def stem_bn_gelu_pool_fwd(x: torch.Tensor, mean, rstd, gamma, beta, act: int = ACT_GELU) -> tuple[torch.Tensor, torch.Tensor]:
     N, Hc, Wc, C = x.shape
     Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
     y = torch.empty((N, Hp, Wp, C), dtype=BF16, device=x.device)
     amax = torch.empty((N, Hp, Wp, C), dtype=torch.uint8, device=x.device)
-    _call("svsr_stem_bn_gelu_pool_fwd", _p(x), _p(y), _p(amax), _p(mean), _p(rstd), _p(gamma), _p(beta), N, Hc, Wc, Hp, Wp, C, _stream())
+    _call("svsr_stem_bn_act_pool_fwd", _p(x), _p(y), _p(amax), _p(mean), _p(rstd), _p(gamma), _p(beta), N, Hc, Wc, Hp, Wp, C, act, _stream())
     return y, amax
 
 
-def stem_bn_gelu_pool_bwd(dpool, amax, x, mean, rstd, gamma, beta, slots, coef, dgamma, dbeta) -> torch.Tensor:
+def stem_bn_gelu_pool_bwd(dpool, amax, x, mean, rstd, gamma, beta, slots, coef, dgamma, dbeta, act: int = ACT_GELU) -> torch.Tensor:
     N, Hc, Wc, C = x.shape
     _, Hp, Wp, _ = dpool.shape
     dx = torch.empty_like(x)
-    _call("svsr_stem_bn_gelu_pool_bwd", _p(dpool), _p(amax), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slots), _p(coef),
-          _p(dgamma), _p(dbeta), _p(dx), N, Hc, Wc, Hp, Wp, C, _stream())
+    _call("svsr_stem_bn_act_pool_bwd", _p(dpool), _p(amax), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slots), _p(coef),
+          _p(dgamma), _p(dbeta), _p(dx), N, Hc, Wc, Hp, Wp, C, act, _stream())
     return dx
 
 
@@ -306,12 +309,12 @@ def bn_act_fwd(x, res, mean, rstd, gamma, beta, act: int) -> torch.Tensor:
     return y
 
 
-def bn_act_bwd(dy, y, x, mean, rstd, gamma, slots, coef, dgamma, dbeta, act: int, want_dres: bool):
+def bn_act_bwd(dy, y, x, mean, rstd, gamma, slots, coef, dgamma, dbeta, act: int, want_dres: bool, beta=None, res=None):
     C = x.shape[-1]
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     _call("svsr_bn_act_bwd", _p(dy), _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(slots), _p(coef), _p(dgamma), _p(dbeta), _p(dx),
-          _p(dres), x.numel() // C, C, act, _stream())
+          _p(dres), x.numel() // C, C, act, _p(beta), _p(res), _stream())
     return dx, dres
 
 
@@ -341,10 +344,10 @@ def add_ln_fwd(a, r, gamma, beta, eps: float):
     return y, mean, rstd
 
 
-def add_ln_bwd(dy, a, r, gamma, mean, rstd, dgamma, dbeta) -> torch.Tensor:
+def add_ln_bwd(dy, a, r, gamma, mean, rstd, dgamma, dbeta, addend=None, out=None) -> torch.Tensor:
     R, D = a.shape
-    ds = torch.empty_like(a)
-    _call("svsr_add_ln_bwd", _p(dy), _p(a), _p(r), _p(gamma), _p(mean), _p(rstd), _p(ds), _p(dgamma), _p(dbeta), R, D, _stream())
+    ds = torch.empty_like(a) if out is None else out
+    _call("svsr_add_ln_bwd", _p(dy), _p(a), _p(r), _p(gamma), _p(mean), _p(rstd), _p(ds), _p(dgamma), _p(dbeta), R, D, _p(addend), _stream())
     return ds
 
 
@@ -378,10 +381,11 @@ def attn_bwd(dctx, qkv, probs, B: int, S: int, H: int, dh: int) -> torch.Tensor:
     return dqkv
 
 
-def bias_act_bwd(dy, z, db, *, R: int, N: int, n_valid: int, ld: int) -> torch.Tensor:
-    """db[:n_valid] += column sums of dz, where dz = dy * gelu'(z) if z is given (returned) else dy."""
+def bias_act_bwd(dy, z, db, *, R: int, N: int, n_valid: int, ld: int, relu: bool = False) -> torch.Tensor:
+    """db[:n_valid] += column sums of dz, where dz = dy * act'(z) if z is given (returned) else dy; act = GELU from the
+    pre-activation z, or (relu=True) ReLU from the saved output z."""
     dz = torch.empty_like(dy) if z is not None else None
-    _call("svsr_bias_act_bwd", _p(dy), _p(z), _p(dz), _p(db), R, N, n_valid, ld, _stream())
+    _call("svsr_bias_act_bwd", _p(dy), _p(z), _p(dz), _p(db), R, N, n_valid, ld, 2 if relu else 1, _stream())
     return dz if z is not None else dy
 
 
@@ -427,3 +431,106 @@ def cast_bf16(src: torch.Tensor, dst: torch.Tensor) -> None:
 
 def transpose_cast_multi(src, dst, table: torch.Tensor, n_entries: int) -> None:
     _call("svsr_transpose_cast_multi", _p(src), _p(dst), _p(table), n_entries, _stream())
+
+
+# --------------------------------------------------------------------------------------------------
+# LRS: attention, Conformer convolution module, CTC, decoder embedding, label-smoothing loss
+# --------------------------------------------------------------------------------------------------
+def probs_pitch(Lk: int) -> int:
+    return (Lk + 7) // 8 * 8
+
+
+def mha_fwd(q, q_pitch: int, k, v, kv_pitch: int, *, B: int, H: int, Lq: int, Lk: int, pe=None, bias_u=None, bias_v=None, klen=None,
+            causal: bool = False):
+    """-> (ctx [B*Lq, H*64] bf16, probs [B*H, Lq, ldp] bf16).  q/k/v are views into (fused) projection outputs."""
+    ldp = probs_pitch(Lk)
+    ctx = torch.empty((B * Lq, H * 64), dtype=BF16, device=q.device)
+    probs = torch.empty((B * H, Lq, ldp), dtype=BF16, device=q.device)
+    _call("svsr_mha_fwd", _p(q), q_pitch, _p(k), _p(v), kv_pitch, _p(pe), 0 if pe is None else pe.stride(0), _p(bias_u), _p(bias_v),
+          _p(klen), int(causal), B, H, 64, Lq, Lk, ldp, 0.125, _p(ctx), H * 64, _p(probs), _stream(),
+          label="k_mha_fwd", flops=2.0 * B * H * Lq * Lk * 64 * (3 if pe is not None else 2))
+    return ctx, probs
+
+
+def mha_bwd(dctx, q, q_pitch: int, k, v, kv_pitch: int, probs, *, B: int, H: int, Lq: int, Lk: int, dq, dq_pitch: int, dk, dv,
+            dkv_pitch: int, pe=None, bias_u=None, bias_v=None):
+    """Writes dq/dk/dv (views with the given pitches).  Relative-position form returns (dq_ac, dq_bd, dpe) as well."""
+    ldp = probs.shape[-1]
+    ds = torch.empty_like(probs)
+    rel = pe is not None
+    D = H * 64
+    dq_ac = torch.empty((B * Lq, D), dtype=BF16, device=q.device) if rel else None
+    dq_bd = torch.empty((B * Lq, D), dtype=BF16, device=q.device) if rel else None
+    dpe = torch.empty((2 * Lq - 1, D), dtype=BF16, device=q.device) if rel else None
+    _call("svsr_mha_bwd", _p(dctx), dctx.stride(0), _p(q), q_pitch, _p(k), _p(v), kv_pitch, _p(pe), 0 if pe is None else pe.stride(0),
+          _p(bias_u), _p(bias_v), _p(probs), _p(ds), B, H, 64, Lq, Lk, ldp, 0.125, _p(dq), dq_pitch, _p(dq_ac), _p(dq_bd), D,
+          _p(dk), _p(dv), dkv_pitch, _p(dpe), D, _stream(), label="k_mha_bwd", flops=2.0 * B * H * Lq * Lk * 64 * (7 if rel else 4))
+    return dq_ac, dq_bd, dpe
+
+
+def glu_dwconv_fwd(u, w, bias, stats, B: int, T: int, D: int, K: int) -> torch.Tensor:
+    c = torch.empty((B * T, D), dtype=BF16, device=u.device)
+    _call("svsr_glu_dwconv_fwd", _p(u), _p(w), _p(bias), _p(c), _p(stats), B, T, D, K, _stream())
+    return c
+
+
+DW_SPLITS = 16
+
+
+def glu_dwconv_bwd(dc, u, w, dw, dbias, B: int, T: int, D: int, K: int) -> torch.Tensor:
+    du = torch.empty_like(u)
+    part = torch.empty(DW_SPLITS * D * (K + 1), dtype=torch.float32, device=u.device)
+    _call("svsr_glu_dwconv_bwd", _p(dc), _p(u), _p(w), _p(du), _p(dw), _p(dbias), _p(part), DW_SPLITS, B, T, D, K, _stream())
+    return du
+
+
+def ctc_fwd(logits, ld: int, labels, ilen, B: int, T: int, V: int):
+    """logits fp32 [B*T, ld]; labels int64 [B, Lmax] (-1 padded); ilen int32 [B] -> (loss 0-d, state for ctc_grad)."""
+    Lmax = labels.shape[1]
+    dev = logits.device
+    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    lse = torch.empty(B * T, dtype=torch.float32, device=dev)
+    ab = torch.empty((B, T, 2 * Lmax + 1), dtype=torch.float32, device=dev)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    _call("svsr_ctc_fwd", _p(logits), ld, _p(labels), Lmax, _p(ilen), B, T, V, _p(lse), _p(ab), _p(nll), _p(loss), _stream())
+    return loss, (lse, ab, nll)
+
+
+def ctc_grad(logits, ld: int, labels, ilen, B: int, T: int, V: int, state, gout, ldo: int) -> torch.Tensor:
+    lse, ab, nll = state
+    dz = torch.empty((B * T, ldo), dtype=BF16, device=logits.device)
+    _call("svsr_ctc_grad", _p(logits), ld, _p(labels), labels.shape[1], _p(ilen), B, T, V, _p(lse), _p(ab), _p(nll), _p(gout), _p(dz), ldo,
+          _stream())
+    return dz
+
+
+def embed_pos_fwd(tok, emb, pe, L: int, D: int, scale: float) -> torch.Tensor:
+    R = tok.numel()
+    x = torch.empty((R, D), dtype=BF16, device=emb.device)
+    _call("svsr_embed_pos_fwd", _p(tok), _p(emb), _p(pe), _p(x), R, L, D, float(scale), _stream())
+    return x
+
+
+def embed_pos_bwd(tok, dx, demb, D: int, scale: float) -> None:
+    _call("svsr_embed_pos_bwd", _p(tok), _p(dx), _p(demb), tok.numel(), D, float(scale), _stream())
+
+
+def ls_loss_fwd(logits, ld: int, target, R: int, V: int, smoothing: float, inv_denom: float):
+    dev = logits.device
+    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    lse = torch.empty(R, dtype=torch.float32, device=dev)
+    counts = torch.zeros(2, dtype=torch.float32, device=dev)
+    _call("svsr_ls_loss_fwd", _p(logits), ld, _p(target), R, V, float(smoothing), float(inv_denom), _p(loss), _p(lse), _p(counts), _stream())
+    return loss, lse, counts
+
+
+def ls_loss_bwd(logits, ld: int, target, R: int, V: int, smoothing: float, inv_denom: float, lse, gout, ldo: int) -> torch.Tensor:
+    dz = torch.empty((R, ldo), dtype=BF16, device=logits.device)
+    _call("svsr_ls_loss_bwd", _p(logits), ld, _p(target), R, V, float(smoothing), float(inv_denom), _p(lse), _p(gout), _p(dz), ldo, _stream())
+    return dz
+
+
+def scale_bf16(x: torch.Tensor, alpha: float) -> torch.Tensor:
+    y = torch.empty_like(x)
+    _call("svsr_scale_bf16", _p(x), _p(y), x.numel(), float(alpha), _stream())
+    return y
