@@ -1,0 +1,499 @@
+"""Drop-in module for the reference's LRS model ``E2E`` (LRS/video/espnet/nets/pytorch_backend/e2e_asr_transformer.py:43-227), HIP-native.
+
+Same constructor ``E2E(odim, args, ignore_id=-1)`` reading the ``model.visual_backbone`` keys of ``config/lrs3.yaml:14-39``, same
+``forward(x, lengths, audios, label) -> (loss, loss_ctc, loss_att, loss_audio, acc)`` and the same state-dict names
+(``encoder.frontend.{frontend3D,trunk}``, ``encoder.embed.0``, ``encoder.encoders.N.{self_attn,feed_forward,feed_forward_macaron,
+conv_module,norm_*}``, ``encoder.after_norm``, ``decoder.*``, ``ctc.ctc_lo``, ``audio_classifier``).  Deviations, both from
+SURVEY §8(b): the ``audios`` slot takes pre-computed audio tokens int64 [B, >=A*T, G] (the frozen wav2vec quantiser's weights are
+not available offline), and ``acc`` is a 0-d device tensor instead of a Python float (no host sync inside the step).
+
+As in ``model.py`` this file is orchestration only: one flat fp32 parameter buffer (+ gradient buffer + bf16 shadows), a hand
+written tape, and a single autograd node for the whole model; every computation is a launch into libsyncvsr_hip.so.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import Config
+from .lrs_init import LRS_ODIM, lrs_audio_dims, lrs_buffer_specs, lrs_init_state_dict, lrs_param_specs
+from .model import BF16, _SideStream, _ParamStore, _attach, _frontend_backward, _frontend_forward, _get, _bn_stats, _ready
+
+LN_EPS = 1e-12          # transformer/layer_norm.py:19
+
+
+def _sinusoid(positions: torch.Tensor, d_model: int) -> torch.Tensor:
+    """transformer/embedding.py:54-76 / :180-199 — sin on even, cos on odd columns, computed in fp32 like the reference."""
+    div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / d_model))
+    ang = positions.float().unsqueeze(1) * div
+    pe = torch.zeros(positions.numel(), d_model)
+    pe[:, 0::2] = torch.sin(ang)
+    pe[:, 1::2] = torch.cos(ang)
+    return pe
+
+
+class LrsTargets:
+    """Device-side target tensors derived from ``label`` once per batch (``E2E.prepare_targets``): CTC labels [B, L] padded
+    with -1, decoder input/output [B, L+1] (add_sos_eos.py:10-31)."""
+
+    def __init__(self, labels: torch.Tensor, ys_in: torch.Tensor, ys_out: torch.Tensor):
+        self.labels, self.ys_in, self.ys_out = labels, ys_in, ys_out
+
+
+class E2E(nn.Module):
+    def __init__(self, odim: int = LRS_ODIM, args: Any = None, ignore_id: int = -1, seed: Optional[int] = None):
+        super().__init__()
+        from .lrs_init import default_lrs_args
+
+        if args is None:
+            args = default_lrs_args()
+        if not isinstance(args, Config):
+            args = Config(vars(args) if hasattr(args, "__dict__") and not isinstance(args, dict) else args)
+        self.args = args
+        self.odim, self.ignore_id = int(odim), int(ignore_id)
+        self.sos = self.eos = self.odim - 1
+        self.adim, self.ddim = int(args.adim), int(args.ddim)
+        self.aheads, self.dheads = int(args.aheads), int(args.dheads)
+        self.eunits, self.dunits = int(args.eunits), int(args.dunits)
+        self.elayers, self.dlayers = int(args.elayers), int(args.dlayers)
+        self.kernel = int(args.cnn_module_kernel)
+        self.mtlalpha, self.lsm_weight = float(args.mtlalpha), float(args.lsm_weight)
+        self.length_norm = bool(args.transformer_length_normalized_loss)
+        self.audio_weight = float(args.audio_weight)
+        unsupported = []
+        if args.transformer_input_layer != "conv3d":
+            unsupported.append("transformer_input_layer must be conv3d")
+        if args.transformer_encoder_attn_layer_type != "rel_mha" or args.get("rel_pos_type", "latest") != "latest":
+            unsupported.append("encoder attention must be rel_mha with rel_pos_type latest")
+        if not args.macaron_style or not args.use_cnn_module:
+            unsupported.append("macaron_style and use_cnn_module must be on")
+        if args.get("relu_type", "swish") != "swish":
+            unsupported.append("relu_type must be swish")
+        if args.get("zero_triu", False):
+            unsupported.append("zero_triu is not supported")
+        if float(args.dropout_rate) or float(args.transformer_attn_dropout_rate or 0.0):
+            unsupported.append("dropout > 0 is not implemented in the HIP path yet")
+        if self.adim != self.ddim:
+            unsupported.append("adim != ddim (proj_decoder) is not implemented")
+        if self.adim % 64 or self.adim // self.aheads != 64 or self.ddim // self.dheads != 64:
+            unsupported.append("attention heads must be 64 wide")
+        if not (0.0 < self.mtlalpha < 1.0):
+            unsupported.append("mtlalpha must be in (0, 1) (both CTC and attention branches are built)")
+        if self.kernel % 2 == 0 or self.kernel > 31:
+            unsupported.append("cnn_module_kernel must be odd and <= 31")
+        if unsupported:
+            raise NotImplementedError("; ".join(unsupported))
+        self.audio_alignment, self.vq_groups, self.audio_vocab_size = lrs_audio_dims(args)
+        self.codec = "vq" if self.audio_alignment == 4 else "wav2vec2"
+
+        self._specs = lrs_param_specs(args, self.odim)
+        self._bspecs = lrs_buffer_specs(args, self.odim)
+        sd = lrs_init_state_dict(args, self.odim, seed=0 if seed is None else seed)
+        for name, shape, kind in self._specs:
+            t = sd[name]
+            if kind == "conv" and len(shape) == 4:
+                t = t.contiguous(memory_format=torch.channels_last)
+            _attach(self, name, t, True)
+        for name, shape, kind in self._bspecs:
+            _attach(self, name, sd[name], False)
+        self._store: Optional[_ParamStore] = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_params_dirty())
+        self.stem_name, self.trunk_name = "encoder.frontend.frontend3D", "encoder.frontend.trunk"
+        self.stem_act = self.trunk_act = ops.ACT_SWISH           # backbones/conv3d_extractor.py:34, modules/resnet.py:76-78
+        self.use_tr = True
+        self._side = _SideStream()
+        self.grad_ready_hook = None
+        self._pos_cache: dict[tuple[str, int, str], torch.Tensor] = {}
+
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _fwd_rank(name: str) -> int:
+        if name.startswith("encoder.frontend.frontend3D"):
+            return 0
+        if name.startswith("encoder.frontend"):
+            return 1
+        if name.startswith("encoder.embed"):
+            return 2
+        if name.startswith("encoder."):
+            return 3
+        if name.startswith(("ctc.", "audio_classifier")):
+            return 4
+        return 5                 # decoder: last in the forward pass, first to be final in the backward pass
+
+    def _transposed_entries(self, offsets) -> list[tuple[str, int, int, int]]:
+        D, Dd, out = self.adim, self.ddim, []
+
+        def one(name: str) -> None:
+            s = offsets[name][2]
+            out.append((name, offsets[name][0], s[0], math.prod(s[1:])))
+
+        def fused(key: str, names: list[str], d: int) -> None:
+            offs = [offsets[f"{n}.weight"][0] for n in names]
+            boffs = [offsets[f"{n}.bias"][0] for n in names]
+            assert all(offs[i + 1] == offs[i] + d * d for i in range(len(offs) - 1)), f"{key}: weights must be adjacent"
+            assert all(boffs[i + 1] == boffs[i] + d for i in range(len(boffs) - 1)), f"{key}: biases must be adjacent"
+            out.append((key, offs[0], len(names) * d, d))
+
+        one("encoder.embed.0.weight")
+        for i in range(self.elayers):
+            p = f"encoder.encoders.{i}"
+            fused(f"{p}.self_attn.qkv", [f"{p}.self_attn.linear_{x}" for x in "qkv"], D)
+            one(f"{p}.self_attn.linear_out.weight")
+            for ff in ("feed_forward", "feed_forward_macaron"):
+                one(f"{p}.{ff}.w_1.weight")
+                one(f"{p}.{ff}.w_2.weight")
+            one(f"{p}.conv_module.pointwise_cov1.weight")
+            one(f"{p}.conv_module.pointwise_cov2.weight")
+        for i in range(self.dlayers):
+            p = f"decoder.decoders.{i}"
+            fused(f"{p}.self_attn.qkv", [f"{p}.self_attn.linear_{x}" for x in "qkv"], Dd)
+            one(f"{p}.self_attn.linear_out.weight")
+            one(f"{p}.src_attn.linear_q.weight")
+            fused(f"{p}.src_attn.kv", [f"{p}.src_attn.linear_{x}" for x in "kv"], Dd)
+            one(f"{p}.src_attn.linear_out.weight")
+            one(f"{p}.feed_forward.w_1.weight")
+            one(f"{p}.feed_forward.w_2.weight")
+        for n in ("decoder.output_layer.weight", "ctc.ctc_lo.weight", "audio_classifier.weight"):
+            one(n)
+        return out
+
+    def configure_optimizers(self):
+        """LRS/video/lightning.py:89-96 — the two parameter groups (decay on ndim >= 2)."""
+        do_decay = [p for p in self.parameters() if p.requires_grad and p.ndim >= 2]
+        no_decay = [p for p in self.parameters() if p.requires_grad and p.ndim < 2]
+        return [{"params": do_decay}, {"params": no_decay, "weight_decay": 0.0}]
+
+    def mark_params_dirty(self) -> None:
+        if self._store is not None:
+            self._store.shadow_fresh = False
+
+    def store(self) -> _ParamStore:
+        dev = _get(self, self._specs[0][0]).device
+        if self._store is None or self._store.device != dev or not self._store.owns(self):
+            self._store = _ParamStore(self, dev)
+        return self._store
+
+    def _pos_table(self, kind: str, n: int, dev: torch.device) -> torch.Tensor:
+        """rel: bf16 [2n-1, adim], row r <-> relative position n-1-r (embedding.py:180-216); abs: fp32 [n, ddim]."""
+        key = (kind, n, str(dev))
+        if key not in self._pos_cache:
+            if kind == "rel":
+                t = _sinusoid(torch.arange(n - 1, -n, -1), self.adim).to(dev).to(BF16).contiguous()
+            else:
+                t = _sinusoid(torch.arange(n), self.ddim).to(dev).contiguous()
+            self._pos_cache[key] = t
+        return self._pos_cache[key]
+
+    def prepare_targets(self, label: torch.Tensor) -> LrsTargets:
+        """label int64 [B,1,L] or [B,L], padded with ignore_id at the tail -> device tensors (no host sync)."""
+        B = label.size(0)
+        lab = label.reshape(B, -1).long()
+        live = lab != self.ignore_id
+        n = live.sum(1, keepdim=True)
+        eos = torch.full_like(lab[:, :1], self.eos)
+        ys_in = torch.cat([eos, torch.where(live, lab, eos)], dim=1).contiguous()                  # sos == eos (e2e:111-112)
+        ys_out = torch.cat([lab, torch.full_like(lab[:, :1], self.ignore_id)], dim=1)
+        ys_out = torch.where(live.new_zeros(ys_out.shape).scatter_(1, n, True), torch.full_like(ys_out, self.eos), ys_out)
+        labels = torch.where(live, lab, torch.full_like(lab, -1)).contiguous()
+        return LrsTargets(labels, ys_in, ys_out.contiguous())
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, lengths: torch.Tensor, audios: torch.Tensor, label):
+        if x.device.type != "cuda":
+            raise RuntimeError("syncvsr_amd runs on an MI355X HIP device only; there is no CPU fallback (use oracle/ for checking)")
+        if x.dim() != 5 or x.size(2) != 1:
+            raise ValueError("x must be [B, T, 1, H, W]")
+        st = self.store()
+        B, T = x.shape[:2]
+        A = self.audio_alignment
+        if audios.dtype != torch.int64 or audios.dim() != 3:
+            raise ValueError("pass pre-computed audio tokens int64 [B, >= A*T, G] in the `audios` slot (SURVEY §8b)")
+        if audios.size(1) < T * A:
+            raise ValueError(f"audio tokens have {audios.size(1)} steps, need >= {T * A}")
+        tokens = audios[:, : T * A].contiguous()
+        tg = label if isinstance(label, LrsTargets) else self.prepare_targets(label.to(x.device))
+        ilen = lengths.to(device=x.device, dtype=torch.int32).contiguous()
+        anchor = _get(self, self._specs[0][0])
+        loss_ctc, loss_att, loss_audio, counts = _LrsFunction.apply(anchor, self, st, x.float().contiguous(), ilen, tokens, tg,
+                                                                    torch.is_grad_enabled())
+        loss = self.mtlalpha * loss_ctc + (1 - self.mtlalpha) * loss_att + self.audio_weight * loss_audio
+        acc = counts[0] / counts[1]
+        return loss, loss_ctc, loss_att, loss_audio, acc
+
+
+# ----------------------------------------------------------------------------------------------------
+# tape helpers
+# ----------------------------------------------------------------------------------------------------
+def _lin(st: _ParamStore, x, name: str, rows: int, K: int, N: int, *, wkey: Optional[str] = None, n_fused: int = 1, bias: bool = True, **kw):
+    """y = x @ W^T + b for the nn.Linear called `name` (or the `n_fused` adjacent linears starting at it)."""
+    o = st.offsets[f"{name}.weight"][0]
+    w16 = st.w16[o : o + N * K]
+    b = st.flat[st.offsets[f"{name}.bias"][0] :][:N] if bias else None
+    return ops.linear_fwd(x, w16, b, rows=rows, K=K, N=N, x_pitch=K, **kw)[0]
+
+
+def _lin_bwd(model, st: _ParamStore, name: str, x, dy, rows: int, K: int, N: int, *, tkey: Optional[str] = None, bias: bool = True,
+             need_dx: bool = True, dy_pitch: Optional[int] = None, addend=None, out=None):
+    """Weight / bias gradients of linear `name` into the flat gradient buffer; returns dx = dy @ W (or None)."""
+    dy_pitch = dy_pitch or N
+    gw = st.grad[st.offsets[f"{name}.weight"][0] :][: N * K]
+    ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=dy_pitch, use_tr=model.use_tr)
+    if bias:
+        gb = st.grad[st.offsets[f"{name}.bias"][0] :][:N]
+        ops.bias_act_bwd(dy, None, gb, R=rows, N=dy_pitch, n_valid=N, ld=dy_pitch)
+    if not need_dx:
+        return None
+    return ops.linear_dgrad(dy, st.t16(tkey or f"{name}.weight"), rows=rows, N=N, K=K, dy_pitch=dy_pitch, addend=addend, out=out)
+
+
+def _ln(st: _ParamStore, x, name: str):
+    return ops.add_ln_fwd(x, None, st.p32(f"{name}.weight"), st.p32(f"{name}.bias"), LN_EPS)
+
+
+def _ln_bwd(st: _ParamStore, dy, x, name: str, m, r, addend=None):
+    return ops.add_ln_bwd(dy, x, None, st.p32(f"{name}.weight"), m, r, st.g32(f"{name}.weight"), st.g32(f"{name}.bias"), addend=addend)
+
+
+def _ffn_fwd(st, t: dict, key: str, x, p: str, R: int, D: int, U: int, alpha: float, norm: str):
+    tn, m, r = _ln(st, x, norm)
+    h = _lin(st, tn, f"{p}.w_1", R, D, U, relu=True)
+    y = _lin(st, h, f"{p}.w_2", R, U, D, addend=x, alpha=alpha)
+    t[key] = dict(x=x, tn=tn, m=m, r=r, h=h)
+    return y
+
+
+def _ffn_bwd(model, st, t: dict, dy, p: str, R: int, D: int, U: int, alpha: float, norm: str):
+    """x' = x + alpha * FFN(LN(x)); dy = grad of x' -> grad of x."""
+    dys = ops.scale_bf16(dy, alpha) if alpha != 1.0 else dy
+    dh = _lin_bwd(model, st, f"{p}.w_2", t["h"], dys, R, U, D)
+    dz = ops.bias_act_bwd(dh, t["h"], st.g32(f"{p}.w_1.bias"), R=R, N=U, n_valid=U, ld=U, relu=True)
+    dtn = _lin_bwd(model, st, f"{p}.w_1", t["tn"], dz, R, D, U, bias=False)
+    return _ln_bwd(st, dtn, t["x"], norm, t["m"], t["r"], addend=dy)
+
+
+def _encoder_layer_fwd(model: E2E, st: _ParamStore, tape: dict, i: int, x, pos16, ilen, B: int, T: int, training: bool):
+    D, U, H, K = model.adim, model.eunits, model.aheads, model.kernel
+    R = B * T
+    p = f"encoder.encoders.{i}"
+    t: dict[str, Any] = {}
+    x1 = _ffn_fwd(st, t, "ffm", x, f"{p}.feed_forward_macaron", R, D, U, 0.5, f"{p}.norm_ff_macaron")
+    # relative-position self-attention
+    t2, m2, r2 = _ln(st, x1, f"{p}.norm_mha")
+    qkv = _lin(st, t2, f"{p}.self_attn.linear_q", R, D, 3 * D)
+    pe = _lin(st, pos16, f"{p}.self_attn.linear_pos", 2 * T - 1, D, D, bias=False)
+    bu, bv = st.p32(f"{p}.self_attn.pos_bias_u"), st.p32(f"{p}.self_attn.pos_bias_v")
+    ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=T, Lk=T, pe=pe, bias_u=bu, bias_v=bv, klen=ilen)
+    x2 = _lin(st, ctx, f"{p}.self_attn.linear_out", R, D, D, addend=x1)
+    t["mha"] = dict(x=x1, tn=t2, m=m2, r=r2, qkv=qkv, pe=pe, ctx=ctx, probs=probs)
+    # convolution module
+    t3, m3, r3 = _ln(st, x2, f"{p}.norm_conv")
+    cm = f"{p}.conv_module"
+    u = _lin(st, t3, f"{cm}.pointwise_cov1", R, D, 2 * D)
+    bn = f"{cm}.norm"
+    c = ops.glu_dwconv_fwd(u, st.p32(f"{cm}.depthwise_conv.weight"), st.p32(f"{cm}.depthwise_conv.bias"),
+                           st.bn[bn]["slots"] if training else None, B, T, D, K)
+    mean, rstd = _bn_stats(st, bn, training, R)
+    y = ops.bn_act_fwd(c, None, mean, rstd, st.p32(f"{bn}.weight"), st.p32(f"{bn}.bias"), ops.ACT_SWISH)
+    x3 = _lin(st, y, f"{cm}.pointwise_cov2", R, D, D, addend=x2)
+    t["conv"] = dict(x=x2, tn=t3, m=m3, r=r3, u=u, c=c, y=y, mean=mean, rstd=rstd)
+    x4 = _ffn_fwd(st, t, "ff", x3, f"{p}.feed_forward", R, D, U, 0.5, f"{p}.norm_ff")
+    xo, m5, r5 = _ln(st, x4, f"{p}.norm_final")
+    t["final"] = dict(x=x4, m=m5, r=r5)
+    tape[p] = t
+    return xo
+
+
+def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos16, B: int, T: int):
+    D, U, H, K = model.adim, model.eunits, model.aheads, model.kernel
+    R = B * T
+    p = f"encoder.encoders.{i}"
+    t = tape[p]
+    tf = t["final"]
+    dx4 = _ln_bwd(st, dxo, tf["x"], f"{p}.norm_final", tf["m"], tf["r"])
+    dx3 = _ffn_bwd(model, st, t["ff"], dx4, f"{p}.feed_forward", R, D, U, 0.5, f"{p}.norm_ff")
+    # convolution module
+    tc = t["conv"]
+    cm, bn = f"{p}.conv_module", f"{p}.conv_module.norm"
+    dy = _lin_bwd(model, st, f"{cm}.pointwise_cov2", tc["y"], dx3, R, D, D)
+    ws = st.bn[bn]
+    dc, _ = ops.bn_act_bwd(dy, tc["y"], tc["c"], tc["mean"], tc["rstd"], st.p32(f"{bn}.weight"), ws["slots"], ws["coef"], st.g32(f"{bn}.weight"),
+                           st.g32(f"{bn}.bias"), ops.ACT_SWISH, False, beta=st.p32(f"{bn}.bias"))
+    du = ops.glu_dwconv_bwd(dc, tc["u"], st.p32(f"{cm}.depthwise_conv.weight"), st.g32(f"{cm}.depthwise_conv.weight"),
+                            st.g32(f"{cm}.depthwise_conv.bias"), B, T, D, K)
+    dt3 = _lin_bwd(model, st, f"{cm}.pointwise_cov1", tc["tn"], du, R, D, 2 * D)
+    dx2 = _ln_bwd(st, dt3, tc["x"], f"{p}.norm_conv", tc["m"], tc["r"], addend=dx3)
+    # attention
+    tm = t["mha"]
+    sa = f"{p}.self_attn"
+    dctx = _lin_bwd(model, st, f"{sa}.linear_out", tm["ctx"], dx2, R, D, D)
+    qkv = tm["qkv"]
+    dqkv = torch.empty_like(qkv)
+    dq_ac, dq_bd, dpe = ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, tm["probs"], B=B, H=H, Lq=T, Lk=T, dq=dqkv,
+                                    dq_pitch=3 * D, dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, pe=tm["pe"],
+                                    bias_u=st.p32(f"{sa}.pos_bias_u"), bias_v=st.p32(f"{sa}.pos_bias_v"))
+    ops.bias_act_bwd(dq_ac, None, st.g32(f"{sa}.pos_bias_u"), R=R, N=D, n_valid=D, ld=D)
+    ops.bias_act_bwd(dq_bd, None, st.g32(f"{sa}.pos_bias_v"), R=R, N=D, n_valid=D, ld=D)
+    _lin_bwd(model, st, f"{sa}.linear_pos", pos16, dpe, 2 * T - 1, D, D, bias=False, need_dx=False)
+    dt2 = _lin_bwd(model, st, f"{sa}.linear_q", tm["tn"], dqkv, R, D, 3 * D, tkey=f"{sa}.qkv")
+    dx1 = _ln_bwd(st, dt2, tm["x"], f"{p}.norm_mha", tm["m"], tm["r"], addend=dx2)
+    dx = _ffn_bwd(model, st, t["ffm"], dx1, f"{p}.feed_forward_macaron", R, D, U, 0.5, f"{p}.norm_ff_macaron")
+    _ready(model, st, f"{p}.self_attn.linear_q.weight")
+    return dx
+
+
+def _decoder_fwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, memory, ilen, B: int, T: int):
+    D, U, H = model.ddim, model.dunits, model.dheads
+    L = tg.ys_in.size(1)
+    R = B * L
+    pe = model._pos_table("abs", L, memory.device)
+    x = ops.embed_pos_fwd(tg.ys_in, st.p32("decoder.embed.0.weight"), pe, L, D, math.sqrt(D))
+    for i in range(model.dlayers):
+        p = f"decoder.decoders.{i}"
+        t: dict[str, Any] = {}
+        t1, m1, r1 = _ln(st, x, f"{p}.norm1")
+        qkv = _lin(st, t1, f"{p}.self_attn.linear_q", R, D, 3 * D)
+        ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=L, Lk=L, causal=True)
+        x1 = _lin(st, ctx, f"{p}.self_attn.linear_out", R, D, D, addend=x)
+        t["self"] = dict(x=x, tn=t1, m=m1, r=r1, qkv=qkv, ctx=ctx, probs=probs)
+        t2, m2, r2 = _ln(st, x1, f"{p}.norm2")
+        q = _lin(st, t2, f"{p}.src_attn.linear_q", R, D, D)
+        kv = _lin(st, memory, f"{p}.src_attn.linear_k", B * T, D, 2 * D)
+        ctx2, probs2 = ops.mha_fwd(q, D, kv, kv[:, D:], 2 * D, B=B, H=H, Lq=L, Lk=T, klen=ilen)
+        x2 = _lin(st, ctx2, f"{p}.src_attn.linear_out", R, D, D, addend=x1)
+        t["src"] = dict(x=x1, tn=t2, m=m2, r=r2, q=q, kv=kv, ctx=ctx2, probs=probs2)
+        x = _ffn_fwd(st, t, "ff", x2, f"{p}.feed_forward", R, D, U, 1.0, f"{p}.norm3")
+        tape[p] = t
+    tn, m, r = _ln(st, x, "decoder.after_norm")
+    V = model.odim
+    Vp = (V + 63) // 64 * 64
+    pred = ops.linear_fwd(tn, st.s16("decoder.output_layer.weight"), st.p32("decoder.output_layer.bias"), rows=R, K=D, N=V, x_pitch=D,
+                          out_f32=True, out_pitch=Vp)[0]
+    tape["dec_out"] = dict(x=x, tn=tn, m=m, r=r, pred=pred, L=L, Vp=Vp)
+    return pred
+
+
+def _decoder_bwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, dpred, memory, dmem, B: int, T: int):
+    """dpred bf16 [B*L, Vp]; accumulates the source-attention key/value gradients into dmem [B*T, D]."""
+    D, U, H = model.ddim, model.dunits, model.dheads
+    to = tape["dec_out"]
+    L, Vp, V = to["L"], to["Vp"], model.odim
+    R = B * L
+    dtn = _lin_bwd(model, st, "decoder.output_layer", to["tn"], dpred, R, D, V, dy_pitch=Vp)
+    dx = _ln_bwd(st, dtn, to["x"], "decoder.after_norm", to["m"], to["r"])
+    _ready(model, st, "decoder.output_layer.weight")
+    for i in reversed(range(model.dlayers)):
+        p = f"decoder.decoders.{i}"
+        t = tape[p]
+        dx2 = _ffn_bwd(model, st, t["ff"], dx, f"{p}.feed_forward", R, D, U, 1.0, f"{p}.norm3")
+        ts = t["src"]
+        dctx2 = _lin_bwd(model, st, f"{p}.src_attn.linear_out", ts["ctx"], dx2, R, D, D)
+        dq = torch.empty_like(ts["q"])
+        dkv = torch.empty_like(ts["kv"])
+        ops.mha_bwd(dctx2, ts["q"], D, ts["kv"], ts["kv"][:, D:], 2 * D, ts["probs"], B=B, H=H, Lq=L, Lk=T, dq=dq, dq_pitch=D, dk=dkv,
+                    dv=dkv[:, D:], dkv_pitch=2 * D)
+        _lin_bwd(model, st, f"{p}.src_attn.linear_k", memory, dkv, B * T, D, 2 * D, tkey=f"{p}.src_attn.kv", addend=dmem, out=dmem)
+        dt2 = _lin_bwd(model, st, f"{p}.src_attn.linear_q", ts["tn"], dq, R, D, D)
+        dx1 = _ln_bwd(st, dt2, ts["x"], f"{p}.norm2", ts["m"], ts["r"], addend=dx2)
+        tsf = t["self"]
+        dctx = _lin_bwd(model, st, f"{p}.self_attn.linear_out", tsf["ctx"], dx1, R, D, D)
+        qkv = tsf["qkv"]
+        dqkv = torch.empty_like(qkv)
+        ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, tsf["probs"], B=B, H=H, Lq=L, Lk=L, dq=dqkv, dq_pitch=3 * D,
+                    dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D)
+        dt1 = _lin_bwd(model, st, f"{p}.self_attn.linear_q", tsf["tn"], dqkv, R, D, 3 * D, tkey=f"{p}.self_attn.qkv")
+        dx = _ln_bwd(st, dt1, tsf["x"], f"{p}.norm1", tsf["m"], tsf["r"], addend=dx1)
+        _ready(model, st, f"{p}.self_attn.linear_q.weight")
+    ops.embed_pos_bwd(tg.ys_in, dx, st.g32("decoder.embed.0.weight"), D, math.sqrt(D))
+    _ready(model, st, "decoder.embed.0.weight")
+
+
+class _LrsFunction(torch.autograd.Function):
+    """One autograd node for E2E.forward: returns (loss_ctc, loss_att, loss_audio, counts); backward replays the tape."""
+
+    @staticmethod
+    def forward(ctx, _anchor, model: E2E, st: _ParamStore, x, ilen, tokens, tg: LrsTargets, need_grad: bool):
+        training = model.training
+        B, T = x.shape[:2]
+        D = model.adim
+        R = B * T
+        A, G, V = model.audio_alignment, model.vq_groups, model.audio_vocab_size
+        if not st.shadow_fresh:
+            st.refresh_shadows()
+        tape: dict[str, Any] = {}
+        videos = x.view(B, 1, T, x.size(3), x.size(4))             # [B,T,1,H,W] and [B,1,T,H,W] are the same memory (C = 1)
+        feats = _frontend_forward(model, st, tape, videos, training)          # [R, 512] bf16
+        h = _lin(st, feats, "encoder.embed.0", R, 512, D, alpha=math.sqrt(D))                  # embedding.py:208 (x * xscale)
+        pos16 = model._pos_table("rel", T, x.device)
+        for i in range(model.elayers):
+            h = _encoder_layer_fwd(model, st, tape, i, h, pos16, ilen, B, T, training)
+        hx = h
+        h, mA, rA = _ln(st, hx, "encoder.after_norm")
+        # audio head (e2e_asr_transformer.py:194-201): every frame, no padding mask
+        NA = A * G * V
+        logits_a = _lin(st, h, "audio_classifier", R, D, NA)
+        tok = tokens.reshape(-1)
+        loss_a, lse_a = ops.ce_fwd(logits_a, V, tok, None, R * A * G, V, 0.0)
+        # CTC head (ctc.py:83-151)
+        Vo = model.odim
+        Vp = (Vo + 63) // 64 * 64
+        logits_c = ops.linear_fwd(h, st.s16("ctc.ctc_lo.weight"), st.p32("ctc.ctc_lo.bias"), rows=R, K=D, N=Vo, x_pitch=D, out_f32=True,
+                                  out_pitch=Vp)[0]
+        loss_c, ctc_state = ops.ctc_fwd(logits_c, Vp, tg.labels, ilen, B, T, Vo)
+        # attention decoder + label smoothing (decoder.py:122-151, label_smoothing_loss.py:41-63)
+        pred = _decoder_fwd(model, st, tape, tg, h, ilen, B, T)
+        L = tg.ys_out.size(1)
+        tgt = tg.ys_out.reshape(-1)
+        if model.length_norm:
+            raise NotImplementedError("transformer_length_normalized_loss needs the token count on the host")
+        inv_denom = 1.0 / B
+        loss_att, lse_p, counts = ops.ls_loss_fwd(pred, Vp, tgt, B * L, Vo, model.lsm_weight, inv_denom)
+        model._last = dict(feats=feats, enc_out=h, pred=pred, logits_audio=logits_a, logits_ctc=logits_c)
+        if need_grad:
+            tape["head"] = dict(hx=hx, h=h, mA=mA, rA=rA, logits_a=logits_a, lse_a=lse_a, tok=tok, logits_c=logits_c, ctc_state=ctc_state,
+                                pred=pred, lse_p=lse_p, tgt=tgt, inv_denom=inv_denom, dims=(B, T, L, Vp), pos16=pos16, ilen=ilen, feats=feats)
+            ctx.tape, ctx.model, ctx.st, ctx.tg = tape, model, st, tg
+        ctx.mark_non_differentiable(counts)
+        return loss_c, loss_att, loss_a, counts
+
+    @staticmethod
+    def backward(ctx, g_ctc, g_att, g_audio, _g_counts):
+        model, st, tape, tg = ctx.model, ctx.st, ctx.tape, ctx.tg
+        th = tape["head"]
+        B, T, L, Vp = th["dims"]
+        D, Vo = model.adim, model.odim
+        R = B * T
+        A, G, V = model.audio_alignment, model.vq_groups, model.audio_vocab_size
+        dev = th["h"].device
+        if not getattr(model, "accumulate_grads", False):
+            st.zero_grad()
+        st.rebind_grads()
+
+        def scalar(g):
+            return (g if g is not None else torch.zeros((), device=dev)).float().contiguous()
+
+        g_ctc, g_att, g_audio = scalar(g_ctc), scalar(g_att), scalar(g_audio)
+        h = th["h"]
+        dh = torch.zeros((R, D), dtype=BF16, device=dev)
+        # decoder first: its parameters sit at the end of the flat gradient buffer
+        dpred = ops.ls_loss_bwd(th["pred"], Vp, th["tgt"], B * L, Vo, model.lsm_weight, th["inv_denom"], th["lse_p"], g_att, Vp)
+        _decoder_bwd(model, st, tape, tg, dpred, h, dh, B, T)
+        # CTC and audio heads
+        dlc = ops.ctc_grad(th["logits_c"], Vp, tg.labels, th["ilen"], B, T, Vo, th["ctc_state"], g_ctc, Vp)
+        _lin_bwd(model, st, "ctc.ctc_lo", h, dlc, R, D, Vo, dy_pitch=Vp, addend=dh, out=dh)
+        NA = A * G * V
+        dla = torch.empty((R, NA), dtype=BF16, device=dev)
+        ops.ce_bwd(th["logits_a"], V, th["tok"], None, R * A * G, V, 0.0, th["lse_a"], g_audio, dla, V)
+        _lin_bwd(model, st, "audio_classifier", h, dla, R, D, NA, addend=dh, out=dh)
+        _ready(model, st, "ctc.ctc_lo.weight")
+        dx = _ln_bwd(st, dh, th["hx"], "encoder.after_norm", th["mA"], th["rA"])
+        for i in reversed(range(model.elayers)):
+            dx = _encoder_layer_bwd(model, st, tape, i, dx, th["pos16"], B, T)
+        dfeats = _lin_bwd(model, st, "encoder.embed.0", th["feats"], ops.scale_bf16(dx, math.sqrt(D)), R, 512, D)
+        _ready(model, st, "encoder.embed.0.weight")
+        _frontend_backward(model, st, tape, dfeats)
+        ctx.tape = None
+        return None, None, None, None, None, None, None, None

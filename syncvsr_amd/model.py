@@ -122,6 +122,8 @@ class TransformerLightningModule(nn.Module):
         self.cutmix = CutMix(self.word_labels).eval()          # lightning.py:85-88
         self._store: Optional[_ParamStore] = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_params_dirty())
+        self.stem_name, self.trunk_name = "stem3d", "resnet"
+        self.stem_act, self.trunk_act = ops.ACT_GELU, ops.ACT_RELU          # lightning.py:52, timm BasicBlock
         self.use_tr = True          # ds_read_b64_tr_b16 fragments in the weight-gradient kernels
         self._side = _SideStream()  # second stream for the trunk's weight-gradient launches (._side.enabled = False serialises)
         self.grad_ready_hook = None  # called as hook(lo, hi) when flat gradient range [lo, hi) is final (DDP buckets)
@@ -146,6 +148,36 @@ class TransformerLightningModule(nn.Module):
         """Call after changing parameters outside engine.TrainStep (load_state_dict does it): the bf16 shadows are re-cast."""
         if self._store is not None:
             self._store.shadow_fresh = False
+
+    @staticmethod
+    def _fwd_rank(name: str) -> int:
+        if name.startswith("stem3d"):
+            return 0
+        if name.startswith("resnet"):
+            return 1
+        if name == "cls_token" or name.startswith("encoder.embeddings"):
+            return 2
+        if name.startswith("encoder.encoder"):
+            return 3
+        return 4
+
+    def _transposed_entries(self, offsets) -> list[tuple[str, int, int, int]]:
+        """(key, source offset, out features, in features) of every linear weight whose data-gradient GEMM runs."""
+        D, out = self.dim, []
+        for i in range(self.layers):
+            p = f"encoder.encoder.layer.{i}"
+            out.append((f"{p}.qkv", offsets[f"{p}.attention.self.query.weight"][0], 3 * D, D))
+            out.append((f"{p}.attention.output.dense.weight", offsets[f"{p}.attention.output.dense.weight"][0], D, D))
+            out.append((f"{p}.intermediate.dense.weight", offsets[f"{p}.intermediate.dense.weight"][0], self.inter, D))
+            out.append((f"{p}.output.dense.weight", offsets[f"{p}.output.dense.weight"][0], D, self.inter))
+            q, k, v = (offsets[f"{p}.attention.self.{x}.weight"][0] for x in ("query", "key", "value"))
+            assert k == q + D * D and v == k + D * D, "q/k/v weights must be adjacent in the flat buffer"
+            qb, kb, vb = (offsets[f"{p}.attention.self.{x}.bias"][0] for x in ("query", "key", "value"))
+            assert kb == qb + D and vb == kb + D
+        for n in ("audio_projection.weight", "category_classifier.weight"):
+            s = offsets[n][2]
+            out.append((n, offsets[n][0], s[0], s[1]))
+        return out
 
     def store(self) -> "_ParamStore":
         dev = self.cls_token.device
@@ -192,23 +224,17 @@ Model = TransformerLightningModule
 # parameter store: flat fp32 master / gradient buffers + bf16 shadows
 # ----------------------------------------------------------------------------------------------------
 class _ParamStore:
-    def __init__(self, model: TransformerLightningModule, device: torch.device):
+    """Flat fp32 master / gradient buffers + bf16 shadows for one model.  The model supplies `_specs`, `_bspecs`,
+    `_fwd_rank(name)` (position of a tensor in the forward pass) and `_transposed_entries(offsets)` (which linear weights
+    need a transposed bf16 shadow for their data-gradient GEMM, and which tensors must be adjacent)."""
+
+    def __init__(self, model, device: torch.device):
         self.device = device
         specs = model._specs
-        L = model.layers
         # flat order: [decayed (ndim >= 2)] then [not decayed]; q/k/v of a layer adjacent so one GEMM covers them
         # decayed tensors are laid out in FORWARD order (stem, trunk, embeddings, encoder layers, heads) so the backward
         # pass finalises the buffer from its end towards its start — contiguous all-reduce buckets (engine.DataParallel).
-        def fwd_rank(name: str) -> int:
-            if name.startswith("stem3d"):
-                return 0
-            if name.startswith("resnet"):
-                return 1
-            if name == "cls_token" or name.startswith("encoder.embeddings"):
-                return 2
-            if name.startswith("encoder.encoder"):
-                return 3
-            return 4
+        fwd_rank = model._fwd_rank
         decay = sorted([(n, s) for n, s, k in specs if len(s) >= 2], key=lambda e: fwd_rank(e[0]))   # stable
         nodecay = [(n, s) for n, s, k in specs if len(s) < 2]
         self.offsets: dict[str, tuple[int, int, tuple[int, ...]]] = {}
@@ -253,20 +279,8 @@ class _ParamStore:
         for n, s, kind in specs:
             if kind == "conv" and len(s) == 4:
                 add_t(n, self.offsets[n][0], s[0], s[2] * s[3], s[1])
-        D = model.dim
-        for i in range(L):
-            p = f"encoder.encoder.layer.{i}"
-            add_t(f"{p}.qkv", self.offsets[f"{p}.attention.self.query.weight"][0], 3 * D, 1, D)
-            add_t(f"{p}.attention.output.dense.weight", self.offsets[f"{p}.attention.output.dense.weight"][0], D, 1, D)
-            add_t(f"{p}.intermediate.dense.weight", self.offsets[f"{p}.intermediate.dense.weight"][0], model.inter, 1, D)
-            add_t(f"{p}.output.dense.weight", self.offsets[f"{p}.output.dense.weight"][0], D, 1, model.inter)
-            q, k, v = (self.offsets[f"{p}.attention.self.{x}.weight"][0] for x in ("query", "key", "value"))
-            assert k == q + D * D and v == k + D * D, "q/k/v weights must be adjacent in the flat buffer"
-            qb, kb, vb = (self.offsets[f"{p}.attention.self.{x}.bias"][0] for x in ("query", "key", "value"))
-            assert kb == qb + D and vb == kb + D
-        for n in ("audio_projection.weight", "category_classifier.weight"):
-            s = self.offsets[n][2]
-            add_t(n, self.offsets[n][0], s[0], 1, s[1])
+        for key, src_off, A, Bd in model._transposed_entries(self.offsets):
+            add_t(key, src_off, A, 1, Bd)
         self.w16t = torch.zeros(max(toff, 1), dtype=BF16, device=device)
         import numpy as np
 
@@ -289,9 +303,10 @@ class _ParamStore:
                 )
         self.shadow_fresh = False     # True only while an optimiser that writes the shadows itself owns the step loop
 
-    def owns(self, model: TransformerLightningModule) -> bool:
+    def owns(self, model) -> bool:
         lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * 4
-        return all(lo <= p.data_ptr() < hi for p in self._params.values()) and model.cls_token is self._params["cls_token"]
+        anchor = model._specs[0][0]
+        return all(lo <= p.data_ptr() < hi for p in self._params.values()) and _get(model, anchor) is self._params[anchor]
 
     def _view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
         o, numel, shape = self.offsets[name]
@@ -355,43 +370,54 @@ def _conv_bn(st: _ParamStore, tape: dict, x: torch.Tensor, conv: str, bn: str, k
     c = ops.conv2d_fwd(x, w16, k, stride, pad, stats=st.bn[bn]["slots"] if training else None)
     mean, rstd = _bn_stats(st, bn, training, c.numel() // c.shape[-1])
     y = ops.bn_act_fwd(c, res, mean, rstd, st.p32(f"{bn}.weight"), st.p32(f"{bn}.bias"), act)
-    tape[conv] = dict(x=x, c=c, y=y, mean=mean, rstd=rstd, k=k, stride=stride, pad=pad, act=act, bn=bn)
+    tape[conv] = dict(x=x, c=c, y=y, mean=mean, rstd=rstd, k=k, stride=stride, pad=pad, act=act, bn=bn, res=res)
     return y
 
 
-def _frontend_forward(model: TransformerLightningModule, st: _ParamStore, tape: dict, videos: torch.Tensor, training: bool) -> torch.Tensor:
+def _trunk_blocks(model):
+    """(prefix, inplanes, planes, stride, has_downsample) with the model's own trunk name (`resnet` for LRW,
+    `encoder.frontend.trunk` for LRS — same BasicBlock topology, different activation)."""
+    for prefix, inp, planes, stride, down in resnet_block_specs():
+        yield model.trunk_name + prefix[len("resnet"):], inp, planes, stride, down
+
+
+def _frontend_forward(model, st: "_ParamStore", tape: dict, videos: torch.Tensor, training: bool) -> torch.Tensor:
+    """videos: fp32 [B,1,T,H,W] (LRW) — the LRS layout [B,T,1,H,W] is the same memory.  -> [B*T, 512] bf16."""
     B, _, T, H, W = videos.shape
     N = B * T
-    c = ops.stem_conv_fwd(videos, st.p32("stem3d.0.weight"), st.bn["stem3d.1"]["slots"] if training else None)
-    mean, rstd = _bn_stats(st, "stem3d.1", training, c.numel() // 64)
-    x, amax = ops.stem_bn_gelu_pool_fwd(c, mean, rstd, st.p32("stem3d.1.weight"), st.p32("stem3d.1.bias"))
+    sc, sb, act = model.stem_name + ".0", model.stem_name + ".1", model.trunk_act
+    c = ops.stem_conv_fwd(videos, st.p32(f"{sc}.weight"), st.bn[sb]["slots"] if training else None)
+    mean, rstd = _bn_stats(st, sb, training, c.numel() // 64)
+    x, amax = ops.stem_bn_gelu_pool_fwd(c, mean, rstd, st.p32(f"{sb}.weight"), st.p32(f"{sb}.bias"), model.stem_act)
     tape["stem"] = dict(videos=videos, c=c, amax=amax, mean=mean, rstd=rstd, pooled_shape=tuple(x.shape))
-    for prefix, inp, planes, stride, down in resnet_block_specs():
+    for prefix, inp, planes, stride, down in _trunk_blocks(model):
         xin = x
-        o1 = _conv_bn(st, tape, xin, f"{prefix}.conv1", f"{prefix}.bn1", 3, stride, 1, training, None, 1)
+        o1 = _conv_bn(st, tape, xin, f"{prefix}.conv1", f"{prefix}.bn1", 3, stride, 1, training, None, act)
         if down:
             idt = _conv_bn(st, tape, xin, f"{prefix}.downsample.0", f"{prefix}.downsample.1", 1, stride, 0, training, None, 0)
         else:
             idt = xin
-        x = _conv_bn(st, tape, o1, f"{prefix}.conv2", f"{prefix}.bn2", 3, 1, 1, training, idt, 1)
+        x = _conv_bn(st, tape, o1, f"{prefix}.conv2", f"{prefix}.bn2", 3, 1, 1, training, idt, act)
     tape["trunk_out_shape"] = tuple(x.shape)
     return ops.avgpool_fwd(x)            # [N, 512] bf16
 
 
-def _frontend_backward(model: TransformerLightningModule, st: _ParamStore, tape: dict, dfeats: torch.Tensor) -> None:
+def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tensor) -> None:
     use_tr = model.use_tr
+    act = model.trunk_act
     dx = ops.avgpool_bwd(dfeats, tape["trunk_out_shape"])
-    for prefix, inp, planes, stride, down in reversed(list(resnet_block_specs())):
+    for prefix, inp, planes, stride, down in reversed(list(_trunk_blocks(model))):
         t2 = tape[f"{prefix}.conv2"]
         ws2 = st.bn[t2["bn"]]
         dc2, dres = ops.bn_act_bwd(dx, t2["y"], t2["c"], t2["mean"], t2["rstd"], st.p32(f"{t2['bn']}.weight"), ws2["slots"], ws2["coef"],
-                                   st.g32(f"{t2['bn']}.weight"), st.g32(f"{t2['bn']}.bias"), 1, True)
+                                   st.g32(f"{t2['bn']}.weight"), st.g32(f"{t2['bn']}.bias"), act, True,
+                                   beta=st.p32(f"{t2['bn']}.bias"), res=t2["res"])
         _conv_wgrad(model, st, f"{prefix}.conv2", t2, dc2, use_tr)
         do1 = ops.conv2d_dgrad(dc2, st.t16(f"{prefix}.conv2.weight").view(planes, 3, 3, planes), 3, 1, 1, t2["x"].shape[1:3])
         t1 = tape[f"{prefix}.conv1"]
         ws1 = st.bn[t1["bn"]]
         dc1, _ = ops.bn_act_bwd(do1, t1["y"], t1["c"], t1["mean"], t1["rstd"], st.p32(f"{t1['bn']}.weight"), ws1["slots"], ws1["coef"],
-                                st.g32(f"{t1['bn']}.weight"), st.g32(f"{t1['bn']}.bias"), 1, False)
+                                st.g32(f"{t1['bn']}.weight"), st.g32(f"{t1['bn']}.bias"), act, False, beta=st.p32(f"{t1['bn']}.bias"))
         _conv_wgrad(model, st, f"{prefix}.conv1", t1, dc1, use_tr)
         in_hw = t1["x"].shape[1:3]
         w1t = st.t16(f"{prefix}.conv1.weight").view(inp, 3, 3, planes)
@@ -407,19 +433,20 @@ def _frontend_backward(model: TransformerLightningModule, st: _ParamStore, tape:
             dx = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw, addend=dres)
         _ready(model, st, f"{prefix}.conv1.weight")
     ts = tape["stem"]
-    ws = st.bn["stem3d.1"]
-    dconv = ops.stem_bn_gelu_pool_bwd(dx, ts["amax"], ts["c"], ts["mean"], ts["rstd"], st.p32("stem3d.1.weight"), st.p32("stem3d.1.bias"),
-                                      ws["slots"], ws["coef"], st.g32("stem3d.1.weight"), st.g32("stem3d.1.bias"))
-    ops.stem_conv_wgrad(ts["videos"], dconv, st.g32("stem3d.0.weight"), use_tr)
+    sc, sb = model.stem_name + ".0", model.stem_name + ".1"
+    ws = st.bn[sb]
+    dconv = ops.stem_bn_gelu_pool_bwd(dx, ts["amax"], ts["c"], ts["mean"], ts["rstd"], st.p32(f"{sb}.weight"), st.p32(f"{sb}.bias"),
+                                      ws["slots"], ws["coef"], st.g32(f"{sb}.weight"), st.g32(f"{sb}.bias"), model.stem_act)
+    ops.stem_conv_wgrad(ts["videos"], dconv, st.g32(f"{sc}.weight"), use_tr)
     model._side.join()
     _ready(model, st, None)
 
 
-def _conv_wgrad(model: TransformerLightningModule, st: _ParamStore, conv: str, t: dict, dc: torch.Tensor, use_tr: bool) -> None:
+def _conv_wgrad(model, st: "_ParamStore", conv: str, t: dict, dc: torch.Tensor, use_tr: bool) -> None:
     model._side.run(lambda: ops.conv2d_wgrad(t["x"], dc, st.g32(f"{conv}.weight"), t["k"], t["stride"], t["pad"], use_tr), dc)
 
 
-def _ready(model: TransformerLightningModule, st: _ParamStore, name: Optional[str]) -> None:
+def _ready(model, st: "_ParamStore", name: Optional[str]) -> None:
     """Gradient-ready notification for bucketed all-reduce: everything at or above `name`'s offset in the decayed
     region is final (backward walks the flat buffer from its end to its start); None = all gradients final."""
     if model.grad_ready_hook is not None:

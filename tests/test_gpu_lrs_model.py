@@ -1,0 +1,117 @@
+"""Whole-path parity (-m gpu) of the LRS model: syncvsr_amd.lrs_model.E2E (HIP) against oracle/lrs_oracle.py (fp32 CPU) on
+identical seeded inputs and weights, and against the committed goldens produced by the reference's own E2E.
+Tolerances (bf16 storage / fp32 accumulation through a 12-layer Conformer + 6-layer decoder):
+  * losses: |hip - oracle| <= 1e-2 * |oracle| on the tiny cases, 5e-3 on the full-width case
+  * encoder output / decoder logits: relative L2 error <= 5e-2
+  * parameter gradients (full-width case): median cosine >= 0.99, min cosine >= 0.8 over tensors whose oracle gradient is
+    not numerically zero, norm ratio within 20 %
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from golden_cases import build_lrs_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _run_pair(name, dev):
+    from oracle import lrs_oracle as O
+    from syncvsr_amd.lrs_model import E2E
+
+    args, odim, sd, batch, training, gold = build_lrs_case(name)
+    x, lengths, tokens, label = batch
+    model = E2E(odim, args)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).train(training)
+    out = model(x.to(dev), lengths.to(dev), tokens.to(dev), label.to(dev))
+    if training:
+        out[0].backward()
+    torch.cuda.synchronize()
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    keep, stats = {}, {}
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref = O.forward(osd, args, x, lengths, tokens, label, training=training, stats_out=stats, keep=keep)
+    if training:
+        ref["loss"].backward()
+    return args, model, out, osd, ref, keep, stats, gold
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu().flatten(), b.detach().float().flatten()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("name,loss_tol", [("lrs_tiny", 1e-2), ("lrs_tiny_b3", 1e-2), ("lrs_full_b2", 5e-3)])
+def test_lrs_model_matches_oracle(dev, name, loss_tol):
+    args, model, out, osd, ref, keep, stats, gold = _run_pair(name, dev)
+    names = ("loss", "loss_ctc", "loss_att", "loss_audio")
+    rows = {k: dict(hip=out[i].item(), oracle=ref[k].item(), golden=float(gold[k])) for i, k in enumerate(names)}
+    rows["acc"] = dict(hip=float(out[4]), oracle=ref["acc"])
+    last = model._last
+    B, T = keep["feats"].shape[:2]
+    V = model.odim
+    rows["rel.feats"] = _rel(last["feats"], keep["feats"])
+    rows["rel.enc_out"] = _rel(last["enc_out"], keep["enc_out"])
+    rows["rel.pred"] = _rel(last["pred"][:, :V], keep["pred"])
+    grads = {}
+    for n, p in model.named_parameters():
+        g = p.grad.detach().float().cpu().flatten()
+        r = osd[n].grad.flatten()
+        rn = r.norm().item()
+        grads[n] = dict(cos=float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)), ratio=float(g.norm() / (rn + 1e-30)), ref_norm=rn)
+    rows["grads"] = grads
+    bufs = {}
+    for n in ("encoder.frontend.frontend3D.1.running_var", "encoder.encoders.0.conv_module.norm.running_mean",
+              "encoder.encoders.0.conv_module.norm.running_var"):
+        bufs[n] = _rel(dict(model.named_buffers())[n], stats[n])
+    rows["buffers"] = bufs
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"parity_{name}.json"), "w") as f:
+        json.dump(rows, f, indent=1)
+    print(json.dumps({k: v for k, v in rows.items() if k != "grads"}, indent=1))
+    gmax = max(v["ref_norm"] for v in grads.values())
+    live = {n: v for n, v in grads.items() if v["ref_norm"] > 1e-6 * gmax}
+    worst = sorted((v["cos"], n) for n, v in live.items())[:8]
+    print("worst grad cosines:", worst)
+    for k in names:
+        assert abs(rows[k]["hip"] - rows[k]["oracle"]) <= loss_tol * abs(rows[k]["oracle"]), (k, rows[k])
+    assert rows["rel.feats"] <= 3e-2 and rows["rel.enc_out"] <= 5e-2 and rows["rel.pred"] <= 5e-2, rows
+    for n, v in bufs.items():
+        assert v <= 2e-2, (n, v)
+    coss = sorted(v["cos"] for v in live.values())
+    if name == "lrs_full_b2":
+        assert coss[len(coss) // 2] >= 0.99 and coss[0] >= 0.8, (coss[0], coss[len(coss) // 2])
+        for n, v in live.items():
+            assert 0.8 <= v["ratio"] <= 1.2, (n, v)
+    else:
+        assert coss[len(coss) // 2] >= 0.97, coss[len(coss) // 2]
+
+
+def test_lrs_eval_mode_matches_oracle(dev):
+    args, model, out, osd, ref, keep, stats, gold = _run_pair("lrs_tiny_eval", dev)
+    for i, k in enumerate(("loss", "loss_ctc", "loss_att", "loss_audio")):
+        assert abs(out[i].item() - ref[k].item()) <= 1e-2 * abs(ref[k].item()), (k, out[i].item(), ref[k].item())
+        assert abs(ref[k].item() - float(gold[k])) <= 1e-4 * abs(float(gold[k]))
+
+
+def test_lrs_state_dict_names_and_unsupported(dev):
+    from syncvsr_amd.lrs_init import default_lrs_args
+    from syncvsr_amd.lrs_model import E2E
+
+    args, odim, sd, batch, training, gold = build_lrs_case("lrs_tiny")
+    m = E2E(odim, args)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    with pytest.raises(NotImplementedError):
+        E2E(odim, default_lrs_args(dropout_rate=0.1))
+    with pytest.raises(RuntimeError):
+        m(batch[0], batch[1], batch[2], batch[3])          # CPU tensors: no fallback
