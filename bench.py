@@ -76,6 +76,58 @@ def cpu_baseline(cfg, batch_size: int, budget_s: float = 20.0) -> dict:
                       f"median step {med * 1e3:.0f} ms, {cores} torch threads"}
 
 
+def lrs_train_flops(B: int, T: int, L: int) -> float:
+    """Algorithmic FLOPs of one LRS training step: per frame 0.4996 GMAC forward (front-end 0.3162, embed,
+    Conformer 0.1772, audio + CTC heads), attention 36.9 k*T^2 MAC per clip, decoder 6*[(L+1)*8.26 M + T*1.18 M] + (L+1)*3.88 M MAC
+    per clip; training = forward + data-gradient + weight-gradient (the stem, 30.4 MMAC/frame, has no data-gradient)."""
+    fwd_mac = B * (T * 0.4996e9 + 36.9e3 * T * T + 6 * ((L + 1) * 8.26e6 + T * 1.18e6) + (L + 1) * 3.88e6)
+    return 2.0 * (3.0 * fwd_mac - B * T * 30.4e6)
+
+
+def cpu_baseline_lrs(lrs_args, odim: int, frames: int, budget_s: float = 20.0) -> dict:
+    """CPU port (oracle/lrs_oracle.py) of the LRS training step on one clip of `frames` frames."""
+    from oracle import lrs_oracle as OS
+    from oracle import lrw_oracle as O
+    from syncvsr_amd.lrs_init import lrs_init_state_dict, lrs_synthetic_batch
+
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    cores = max(1, min(32, allowed))
+    torch.set_num_threads(cores)
+    sd = lrs_init_state_dict(lrs_args, odim, seed=0)
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    params = [sd[k] for k in names]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    batch = lrs_synthetic_batch(lrs_args, 1, frames, odim=odim, seed=1234, label_len=(5, 20))
+    times = []
+    t_start = time.perf_counter()
+    step = 0
+    while True:
+        t0 = time.perf_counter()
+        for p in params:
+            p.grad = None
+        out = OS.forward(sd, lrs_args, *batch, training=True)
+        out["loss"].backward()
+        with torch.no_grad():
+            grads = [p.grad for p in params]
+            O.clip_grad_norm(grads, 5.0)
+            O.adamw_step(params, grads, m, v, step + 1, O.cosine_lr(step, 1e-3, 25000, 500000), (0.9, 0.98), 1e-6, 0.03)
+        times.append(time.perf_counter() - t0)
+        step += 1
+        if (time.perf_counter() - t_start > budget_s and step >= 2) or step >= 20 or time.perf_counter() - t_start > 4 * budget_s:
+            break
+    steady = sorted(times[1:] or times)
+    med = steady[len(steady) // 2]
+    return {"value": frames / med, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{step} training steps (fwd+bwd+clip+AdamW, fp32) of oracle/lrs_oracle.py on one {frames}-frame 88x88 clip, "
+                      f"median step {med * 1e3:.0f} ms, {cores} torch threads"}
+
+
 def pmc_traffic(kernel_label: str):
     """HBM bytes per launch of `kernel_label` from the committed rocprofv3 PMC passes (profiles/round1_pmc_per_kernel.json:
     FETCH_SIZE and WRITE_SIZE in KiB, separate --pmc runs).  gfx950 correction per MI355X_MICROARCH.md §HBM: FETCH_SIZE
@@ -106,7 +158,12 @@ def main() -> None:
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--profile-steps", type=int, default=2, help="eager steps with per-launch HIP events for the roofline leg")
     ap.add_argument("--force-collective", action="store_true", help="run the RCCL path even with one rank")
+    ap.add_argument("--workload", choices=("lrw", "lrs"), default="lrw", help="lrw = BASELINE.json's headline metric (default); lrs = the "
+                    "sentence-level E2E model (SURVEY §8 a13-a15, BASELINE configs[3]): --batch clips of up to --frames frames")
+    ap.add_argument("--frames", type=int, default=150, help="LRS: padded clip length T (lengths are drawn in [0.3 T, T])")
     args = ap.parse_args()
+    if args.workload == "lrs" and args.batch == 32 and "--batch" not in sys.argv:
+        args.batch = 16
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -128,11 +185,25 @@ def main() -> None:
     from syncvsr_amd.init import synthetic_batch
     from syncvsr_amd.model import Model
 
-    cfg = default_lrw_config()
-    cfg.train.batch_size = args.batch
-    model = Model(cfg, seed=0).to(dev).train()
-    batch = [t.to(dev) for t in synthetic_batch(cfg, args.batch, seed=1234 + rank)]
     use_graph = (not args.no_graph) and (world == 1 or args.graph or args.force_collective)
+    lrs = args.workload == "lrs"
+    if lrs:
+        from syncvsr_amd.engine import lrs_train_config
+        from syncvsr_amd.lrs_init import LRS_ODIM, default_lrs_args, lrs_synthetic_batch
+        from syncvsr_amd.lrs_model import E2E
+
+        lrs_args = default_lrs_args()
+        cfg = lrs_train_config()
+        model = E2E(LRS_ODIM, lrs_args, seed=0).to(dev).train()
+        cpu_batch = lrs_synthetic_batch(lrs_args, args.batch, args.frames, seed=1234 + rank, min_len_frac=0.3)
+        batch = [t.to(dev) for t in cpu_batch]
+        n_frames = int(cpu_batch[1].sum())
+        label_len = cpu_batch[3].shape[-1]
+    else:
+        cfg = default_lrw_config()
+        cfg.train.batch_size = args.batch
+        model = Model(cfg, seed=0).to(dev).train()
+        batch = [t.to(dev) for t in synthetic_batch(cfg, args.batch, seed=1234 + rank)]
     trainer = TrainStep(model, cfg, use_graph=use_graph, always_reduce=args.force_collective, bucket_mb=16.0)
 
     def barrier():
@@ -152,7 +223,7 @@ def main() -> None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = float(out["loss_total"].item())
+    loss = float((out[0] if lrs else out["loss_total"]).item())
     clips_per_s = args.batch * world * args.steps / elapsed
 
     result = {
@@ -175,6 +246,15 @@ def main() -> None:
         "step_mfma_frac": round(clips_per_s / world * TRAIN_FLOP_PER_CLIP / MFMA_PEAK_BF16, 5),
         "final_loss": round(loss, 4),
     }
+    if lrs:
+        step_flops = lrs_train_flops(args.batch, args.frames, label_len)
+        result["metric"] = f"lip-clips/sec training (LRS, <= {args.frames}x88x88)"
+        result["config"] = {"workload": "LRS training step (fwd+bwd+allreduce+clip+AdamW), Conv3d/ResNet18(Swish) front-end + 12-layer 768-d "
+                                        "Conformer + CTC + 6-layer attention decoder + vq audio-token CE head (config/lrs3.yaml), random-init "
+                                        f"weights, N(0,1) clips padded to {args.frames} frames, dropout 0",
+                            "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": use_graph,
+                            "padded_frames_per_s": round(clips_per_s * args.frames, 1), "valid_frames_per_step_rank0": n_frames}
+        result["step_mfma_frac"] = round(step_flops * args.steps / elapsed / MFMA_PEAK_BF16, 5)
 
     if rank == 0:
         # ---- roofline leg: eager steps with HIP events around every contraction launch -----------------------------
@@ -200,7 +280,7 @@ def main() -> None:
                                    "launches": v["launches"] // max(1, args.profile_steps)} for k, v in sorted(rows.items())},
             }
             if not args.no_cpu_baseline and world == 1:
-                result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch)
+                result["cpu_baseline"] = cpu_baseline_lrs(lrs_args, LRS_ODIM, 32) if lrs else cpu_baseline(cfg, args.cpu_batch)
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()

@@ -21,20 +21,40 @@ from .config import Config
 from .model import TransformerLightningModule
 
 
-class TrainStep:
-    """forward + backward + (all-reduce) + clip + AdamW for the LRW model; optionally one HIP graph per step."""
+def lrs_train_config(**kw) -> Config:
+    """Optimiser / schedule / clip values of LRS/video/config/lrs3.yaml:66-77,97 in the layout TrainStep reads."""
+    cfg = Config(optimizer=Config(lr=1e-3, betas=[0.9, 0.98], eps=1e-6, weight_decay=0.03),
+                 scheduler=Config(name="cosine", num_warmup_steps=25000, num_training_steps=500000),
+                 trainer=Config(gradient_clip_val=5.0))
+    for k, v in kw.items():
+        cfg.set_path(k.replace("__", "."), v)
+    return cfg
 
-    def __init__(self, model: TransformerLightningModule, config: Optional[Config] = None, process_group=None,
+
+class TrainStep:
+    """forward + backward + (all-reduce) + clip + AdamW for the LRW model (`TransformerLightningModule`; its step takes
+    (videos, audio_tokens, labels, word_mask)) or the LRS model (`lrs_model.E2E`; (x, lengths, audio_tokens, label));
+    optionally one HIP graph per step."""
+
+    def __init__(self, model, config: Optional[Config] = None, process_group=None,
                  use_graph: bool = True, bucket_mb: float = 32.0, always_reduce: bool = False):
         self.model = model
-        cfg = config or model.config
-        opt = cfg.optim.optimizer
-        sch = cfg.optim.get("scheduler", {}) or {}
+        self.is_lrw = isinstance(model, TransformerLightningModule)
+        if self.is_lrw:            # LRW/video/config/*.yaml: optim.optimizer / optim.scheduler / train.gradient_clip_val
+            cfg = config or model.config
+            opt = cfg.optim.optimizer
+            sch = cfg.optim.get("scheduler", {}) or {}
+            clip = cfg.train.get("gradient_clip_val", 0.0)
+        else:                      # LRS/video/config/lrs3.yaml: optimizer / scheduler / trainer.gradient_clip_val
+            cfg = config or lrs_train_config()
+            opt = cfg.optimizer
+            sch = cfg.get("scheduler", {}) or {}
+            clip = (cfg.get("trainer", {}) or {}).get("gradient_clip_val", 0.0)
         self.lr = float(opt.lr)
         self.betas = (float(opt.betas[0]), float(opt.betas[1]))
         self.eps = float(opt.eps)
         self.weight_decay = float(opt.weight_decay)
-        self.max_norm = float(cfg.train.get("gradient_clip_val", 0.0) or 0.0)
+        self.max_norm = float(clip or 0.0)
         self.warmup = int(sch.get("num_warmup_steps", 0) or 0)
         self.total_steps = int(sch.get("num_training_steps", 0) or 0)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -51,13 +71,13 @@ class TrainStep:
         self.opt_state = torch.zeros(4, dtype=torch.int32, device=dev)     # {step, sumsq, lr_last, gnorm_last}
 
     # -- one eager step -----------------------------------------------------------------------------
-    def _step_impl(self, videos, audio_tokens, labels, word_mask) -> dict[str, torch.Tensor]:
+    def _step_impl(self, *batch):
         model = self.model
         st = model.store()
         if self.dp is not None:
             self.dp.begin_step()
-        out = model(videos, audio_tokens, labels, word_mask)
-        out["loss_total"].backward()
+        out = model(*batch)
+        (out["loss_total"] if self.is_lrw else out[0]).backward()
         if self.dp is not None:
             self.dp.finish()
         ops.grad_sumsq(st.grad, self.opt_state)
@@ -65,22 +85,28 @@ class TrainStep:
                        self.max_norm, self.warmup, self.total_steps, self.opt_state)
         ops.transpose_cast_multi(st.flat, st.w16t, st.table, st.n_entries)
         st.shadow_fresh = True
-        return {k: v.detach() for k, v in out.items()}
+        if self.is_lrw:
+            return {k: v.detach() for k, v in out.items()}
+        return tuple(v.detach() for v in out)
 
-    def step(self, videos, audio_tokens, labels, word_mask) -> dict[str, torch.Tensor]:
+    def step(self, *batch):
+        """One optimisation step; returns the model's outputs (LRW: the dict of five scalars; LRS: the 5-tuple).
+        With use_graph the batch shapes are fixed by the first call (later batches are copied into the captured buffers)."""
         if not self.use_graph:
-            return self._step_impl(videos, audio_tokens, labels, word_mask)
+            return self._step_impl(*batch)
         if self._graph is None:
-            self._capture(videos, audio_tokens, labels, word_mask)
+            self._capture(*batch)
         else:
-            for dst, src in zip(self._static, (videos, audio_tokens, labels, word_mask)):
+            for dst, src in zip(self._static, batch):
+                if dst.shape != src.shape:
+                    raise ValueError("a captured TrainStep needs fixed batch shapes (pad to the captured size or use use_graph=False)")
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
         self._graph.replay()
         return self._out
 
-    def _capture(self, videos, audio_tokens, labels, word_mask) -> None:
-        self._static = [t.clone() for t in (videos, audio_tokens, labels, word_mask)]
+    def _capture(self, *batch) -> None:
+        self._static = [t.clone() for t in batch]
         # warm-up on a side stream (allocator pools, hipFuncSetAttribute, lazy module loads), state restored afterwards
         st = self.model.store()
         snap = (st.flat.clone(), self.m.clone(), self.v.clone(), self.opt_state.clone(),
@@ -117,7 +143,7 @@ class GradReducer:
     complete and reduced on a side stream.  `on_ready(0)` (end of backward) flushes the rest plus the 1-D tail.
     """
 
-    def __init__(self, model: TransformerLightningModule, process_group=None, bucket_mb: float = 32.0, always: bool = False):
+    def __init__(self, model, process_group=None, bucket_mb: float = 32.0, always: bool = False):
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1

@@ -65,3 +65,59 @@ def test_three_steps_match_oracle(use_graph):
         assert abs(a - b) <= 1e-2 * abs(b), (got, ref)
     assert ts.state()["step"] == 4
     assert got[3] < got[1], "the loss must decrease once the learning rate is non-zero"
+
+
+def _lrs_oracle_losses(args, sd, batch, steps, tcfg):
+    from oracle import lrs_oracle as OS
+    from oracle import lrw_oracle as O
+
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k in names:
+        sd[k].requires_grad_(True)
+    params = [sd[k] for k in names]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    opt, sch = tcfg.optimizer, tcfg.scheduler
+    losses = []
+    for step in range(steps):
+        for p in params:
+            p.grad = None
+        stats = {}
+        out = OS.forward(sd, args, *batch, training=True, stats_out=stats)
+        out["loss"].backward()
+        losses.append(out["loss"].item())
+        with torch.no_grad():
+            grads = [p.grad for p in params]
+            O.clip_grad_norm(grads, float(tcfg.trainer.gradient_clip_val))
+            lr = O.cosine_lr(step, float(opt.lr), int(sch.num_warmup_steps), int(sch.num_training_steps))
+            O.adamw_step(params, grads, m, v, step + 1, lr, tuple(opt.betas), float(opt.eps), float(opt.weight_decay))
+            for k, val in stats.items():
+                sd[k] = val
+    return losses
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_lrs_steps_match_oracle(use_graph):
+    """LRS recipe (AdamW beta2 0.98, wd 0.03, clip 5.0, cosine warm-up — LRS/video/config/lrs3.yaml:66-77,97)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from golden_cases import build_lrs_case
+    from syncvsr_amd.engine import TrainStep, lrs_train_config
+    from syncvsr_amd.lrs_model import E2E
+
+    dev = torch.device("cuda:0")
+    args, odim, sd, batch, training, gold = build_lrs_case("lrs_tiny_b3")
+    tcfg = lrs_train_config(optimizer__lr=5e-4, scheduler__num_warmup_steps=2, scheduler__num_training_steps=10)
+    ref = _lrs_oracle_losses(args, sd, batch, 4, tcfg)
+    model = E2E(odim, args)
+    model.load_state_dict(sd)
+    model.to(dev).train()
+    ts = TrainStep(model, tcfg, use_graph=use_graph)
+    gb = [t.to(dev) for t in batch]
+    got = [ts.step(*gb)[0].item() for _ in range(4)]
+    print("hip", got, "oracle", ref, ts.state())
+    for a, b in zip(got, ref):
+        assert abs(a - b) <= 1.5e-2 * abs(b), (got, ref)
+    assert ts.state()["step"] == 4
+    assert got[3] < got[1]
