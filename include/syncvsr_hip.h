@@ -152,8 +152,9 @@ int svsr_mha_fwd(const void* q, int q_pitch, const void* k, const void* v, int k
 
 /* backward of svsr_mha_fwd: ds [B*H][Lq][ldp] workspace (score gradients); dq/dk/dv written (not accumulated); for the
  * relative-position form also dq_ac / dq_bd (the two summands of dq, whose column sums are the pos_bias_u / pos_bias_v
- * gradients) and dpe [2*Lq-1][dpe_pitch] (gradient of the projected position table, feeds linear_pos's weight gradient). */
-int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, hipStream_t stream);
+ * gradients) and dpe [2*Lq-1][dpe_pitch] (gradient of the projected position table, feeds linear_pos's weight gradient);
+ * pe_part: fp32 workspace [B][2*Lq-1][dpe_pitch] (per-batch-item partials of dpe; dpe_pitch must equal H*64). */
+int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, hipStream_t stream);
 
 /* Conformer convolution module core (transformer/convolution.py:56-75): u [B*T][2D] = pointwise_cov1 output ->
  * GLU -> depthwise Conv1d(K odd <= 31, pad (K-1)/2, weight [D][K], bias) -> c [B*T][D] bf16 + BatchNorm1d partial sums

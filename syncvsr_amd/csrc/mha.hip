@@ -36,6 +36,7 @@ struct MhaArgs {
     bf16_t* dq_ac; bf16_t* dq_bd; int aux_pitch;   // rel-pos only: the two summands of dq (for the pos_bias_u / pos_bias_v gradients)
     bf16_t* dk; bf16_t* dv; int dkv_pitch;
     bf16_t* dpe; int dpe_pitch;
+    float* pe_part;                           // [B][2*Lq-1][dpe_pitch] fp32 per-batch-item partials of dpe
 };
 
 __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(64) void k_mha_bwd_kv(const MhaArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward, position table: dPE[r][h*64+d] = sum_b sum_i dS[b,h,i, r-(Lq-1)+i] * (q[b,i,h,d] + v_bias[h,d])
+// one wave per (32-row tile of the table, head, batch item) writes an fp32 partial; k_mha_pe_reduce sums over the batch.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_mha_bwd_pe(const MhaArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t sA[32 * MHA_TP], sQ[32 * MHA_VP];
@@ -371,7 +373,8 @@ __global__ __launch_bounds__(64) void k_mha_bwd_pe(const MhaArgs a) {
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
-    for (int b = 0; b < a.B; ++b) {
+    {
+        const int b = blockIdx.z;
         const bf16_t* dsb = a.ds + ((long)b * a.H + h) * a.Lq * a.ldp;
         for (int i0 = 0; i0 < a.Lq; i0 += 32) {
             // keys reachable from this (row-tile, query-tile): j = r - (Lq-1) + i
@@ -404,8 +407,16 @@ __global__ __launch_bounds__(64) void k_mha_bwd_pe(const MhaArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = r0 + acc_row(r, lane);
-            if (rr < 2 * a.Lq - 1) a.dpe[(long)rr * a.dpe_pitch + h * MHA_DH + nb * 32 + row] = f2bf(o[nb][r]);
+            if (rr < 2 * a.Lq - 1) a.pe_part[((long)blockIdx.z * (2 * a.Lq - 1) + rr) * a.dpe_pitch + h * MHA_DH + nb * 32 + row] = o[nb][r];
         }
+}
+
+__global__ __launch_bounds__(256) void k_mha_pe_reduce(const float* __restrict__ part, bf16_t* __restrict__ dpe, int B, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += part[(long)b * n + i];
+        dpe[i] = f2bf(s);
+    }
 }
 
 static inline size_t mha_lds_fwd(int Lk) { return ((size_t)32 * (((Lk + 31) & ~31) + 4) + 32 * 64 + 64) * sizeof(float) + (size_t)32 * MHA_VP * 2; }
@@ -439,10 +450,10 @@ int svsr_mha_fwd(const void* q, int q_pitch, const void* k, const void* v, int k
 int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch,
                  const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const void* probs, void* ds, int B, int H,
                  int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch,
-                 void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, hipStream_t stream) {
+                 void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, hipStream_t stream) {
     if (dh != MHA_DH || Lq < 1 || Lk < 1 || ldp < Lk || (q_pitch | kv_pitch | pe_pitch | dctx_pitch) % 8 != 0) return SVSR_ERR_ARG;
     const bool rel = pe != nullptr;
-    if (rel && (bias_u == nullptr || bias_v == nullptr || Lq != Lk || dq_ac == nullptr || dq_bd == nullptr || dpe == nullptr)) return SVSR_ERR_ARG;
+    if (rel && (bias_u == nullptr || bias_v == nullptr || Lq != Lk || dq_ac == nullptr || dq_bd == nullptr || dpe == nullptr || pe_part == nullptr)) return SVSR_ERR_ARG;
     const size_t lds = mha_lds_bwd(Lk);
     if (lds > MHA_MAX_LDS) return SVSR_ERR_ARG;
     MhaArgs a{};
@@ -451,14 +462,17 @@ int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, c
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldp = ldp; a.scale = scale; a.probs = (bf16_t*)const_cast<void*>(probs);
     a.dctx = (const bf16_t*)dctx; a.dctx_pitch = dctx_pitch; a.ds = (bf16_t*)ds; a.dq = (bf16_t*)dq; a.dq_pitch = dq_pitch;
     a.dq_ac = (bf16_t*)dq_ac; a.dq_bd = (bf16_t*)dq_bd; a.aux_pitch = aux_pitch; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dkv_pitch = dkv_pitch;
-    a.dpe = (bf16_t*)dpe; a.dpe_pitch = dpe_pitch;
+    a.dpe = (bf16_t*)dpe; a.dpe_pitch = dpe_pitch; a.pe_part = pe_part;
     static bool attr = false;
     if (!attr) { mha_allow_lds(k_mha_bwd_q<true>); mha_allow_lds(k_mha_bwd_q<false>); attr = true; }
     const dim3 gq((Lq + 31) / 32, B * H), gk((Lk + 31) / 32, B * H);
     if (rel) {
         hipLaunchKernelGGL(k_mha_bwd_q<true>, gq, dim3(64), lds, stream, a);
         hipLaunchKernelGGL(k_mha_bwd_kv<true>, gk, dim3(64), 0, stream, a);
-        hipLaunchKernelGGL(k_mha_bwd_pe, dim3((2 * Lq - 1 + 31) / 32, H), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL(k_mha_bwd_pe, dim3((2 * Lq - 1 + 31) / 32, H, B), dim3(64), 0, stream, a);
+        const long n = (long)(2 * Lq - 1) * dpe_pitch;
+        long blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_mha_pe_reduce, dim3((int)blocks), dim3(256), 0, stream, pe_part, (bf16_t*)dpe, B, n);
     } else {
         hipLaunchKernelGGL(k_mha_bwd_q<false>, gq, dim3(64), lds, stream, a);
         hipLaunchKernelGGL(k_mha_bwd_kv<false>, gk, dim3(64), 0, stream, a);

@@ -462,9 +462,10 @@ def mha_bwd(dctx, q, q_pitch: int, k, v, kv_pitch: int, probs, *, B: int, H: int
     dq_ac = torch.empty((B * Lq, D), dtype=BF16, device=q.device) if rel else None
     dq_bd = torch.empty((B * Lq, D), dtype=BF16, device=q.device) if rel else None
     dpe = torch.empty((2 * Lq - 1, D), dtype=BF16, device=q.device) if rel else None
+    pe_part = torch.empty((B, 2 * Lq - 1, D), dtype=torch.float32, device=q.device) if rel else None
     _call("svsr_mha_bwd", _p(dctx), dctx.stride(0), _p(q), q_pitch, _p(k), _p(v), kv_pitch, _p(pe), 0 if pe is None else pe.stride(0),
           _p(bias_u), _p(bias_v), _p(probs), _p(ds), B, H, 64, Lq, Lk, ldp, 0.125, _p(dq), dq_pitch, _p(dq_ac), _p(dq_bd), D,
-          _p(dk), _p(dv), dkv_pitch, _p(dpe), D, _stream(), label="k_mha_bwd", flops=2.0 * B * H * Lq * Lk * 64 * (7 if rel else 4))
+          _p(dk), _p(dv), dkv_pitch, _p(dpe), D, _p(pe_part), _stream(), label="k_mha_bwd", flops=2.0 * B * H * Lq * Lk * 64 * (7 if rel else 4))
     return dq_ac, dq_bd, dpe
 
 
