@@ -85,6 +85,37 @@ def main():
             dw = torch.zeros(Nn, K, device=dev)
             us = timeit(lambda: ops.linear_wgrad(x, dy, dw, rows=R, K=K, N=Nn, x_pitch=K, dy_pitch=Nn), iters=20)
             print(f"linear {nm:9s} wgrad {us:7.1f} us {fl / us / 1e6:7.1f} TF")
+    if "lrs" in which:
+        R = int(os.environ.get("OPB_ROWS", "2400"))
+        for nm, K, Nn in (("qkv", 768, 2304), ("attn_out", 768, 768), ("ffn1", 768, 3072), ("ffn2", 3072, 768), ("pw1", 768, 1536),
+                          ("audio", 768, 2560), ("ctc", 768, 5056)):
+            x = torch.randn(R, K, device=dev).to(BF); w = (torch.randn(Nn, K, device=dev) / math.sqrt(K)).to(BF)
+            b = torch.zeros(Nn, device=dev); dy = torch.randn(R, Nn, device=dev).to(BF)
+            wt = w.t().contiguous().view(K, 1, Nn)
+            fl = 2.0 * R * K * Nn
+            us = timeit(lambda: ops.linear_fwd(x, w, b, rows=R, K=K, N=Nn, x_pitch=K), iters=20)
+            print(f"lrs linear {nm:9s} fwd   {us:7.1f} us {fl / us / 1e6:7.1f} TF")
+            us = timeit(lambda: ops.linear_dgrad(dy, wt, rows=R, N=Nn, K=K, dy_pitch=Nn), iters=20)
+            print(f"lrs linear {nm:9s} dgrad {us:7.1f} us {fl / us / 1e6:7.1f} TF")
+            dw = torch.zeros(Nn, K, device=dev)
+            us = timeit(lambda: ops.linear_wgrad(x, dy, dw, rows=R, K=K, N=Nn, x_pitch=K, dy_pitch=Nn), iters=20)
+            print(f"lrs linear {nm:9s} wgrad {us:7.1f} us {fl / us / 1e6:7.1f} TF")
+    if "mha" in which:
+        B, T, H = 16, int(os.environ.get("OPB_T", "150")), 12
+        D = H * 64
+        qkv = torch.randn(B * T, 3 * D, device=dev).to(BF)
+        pe = torch.randn(2 * T - 1, D, device=dev).to(BF)
+        u = torch.randn(D, device=dev) * 0.1; v = torch.randn(D, device=dev) * 0.1
+        klen = torch.full((B,), T, dtype=torch.int32, device=dev)
+        dctx = torch.randn(B * T, D, device=dev).to(BF)
+        f = lambda: ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=T, Lk=T, pe=pe, bias_u=u, bias_v=v, klen=klen)
+        us = timeit(f)
+        print(f"mha rel fwd  {us:8.1f} us  {2.0 * B * H * T * T * 64 * 3 / us / 1e6:6.1f} TF")
+        ctx, probs = f()
+        dqkv = torch.empty_like(qkv)
+        us = timeit(lambda: ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, probs, B=B, H=H, Lq=T, Lk=T, dq=dqkv, dq_pitch=3 * D,
+                                        dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, pe=pe, bias_u=u, bias_v=v))
+        print(f"mha rel bwd  {us:8.1f} us  {2.0 * B * H * T * T * 64 * 7 / us / 1e6:6.1f} TF")
     if "stem" in which:
         vid = torch.randn(32, 1, 29, 88, 88, device=dev)
         w = torch.randn(64 * 245, device=dev) * 0.05

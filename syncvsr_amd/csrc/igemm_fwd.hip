@@ -469,7 +469,9 @@ static int igemm_fwd_tile_m(int M, int Co) {
     static const int thr = [] { const char* e = getenv("SVSR_IGEMM_M128"); return e ? atoi(e) : 8192; }();
     if (forced == 64 || forced == 128) return forced;
     if (Co <= 64) return M >= 16384 ? 128 : 64;
-    return M >= thr ? 128 : 64;
+    // 128x128 tiles once they still give ~a block per CU (LRS linears at 2,400 rows: qkv/ffn1/heads yes, 768-wide outputs no)
+    const long blocks128 = (long)((M + 127) / 128) * ((Co + 127) / 128);
+    return (M >= thr || blocks128 >= 224) ? 128 : 64;
 }
 
 static bool use_glds() {

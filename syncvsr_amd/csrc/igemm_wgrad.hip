@@ -167,7 +167,10 @@ static int launch_wgrad(IgemmWgradArgs& a, hipStream_t stream) {
     if (splits > total_chunks) splits = total_chunks;
     if (splits < 1) splits = 1;
     a.chunks_per_block = (total_chunks + splits - 1) / splits;
-    if (a.chunks_per_block < 4 && total_chunks >= 4) a.chunks_per_block = 4;      // keep the atomic epilogue amortised
+    // keep the BC*BC atomic epilogue amortised: >= 12 K-chunks per block when the problem has them (LRS linears: 2,400 rows =
+    // 38 chunks -> 3 splits measured best), >= 4 for the short LRW sequences
+    const int min_chunks = total_chunks >= 36 ? 12 : 4;
+    if (a.chunks_per_block < min_chunks && total_chunks >= min_chunks) a.chunks_per_block = min_chunks;
     splits = (total_chunks + a.chunks_per_block - 1) / a.chunks_per_block;
     hipLaunchKernelGGL((k_igemm_wgrad<USE_TR, BC>), dim3(splits, tasks), dim3(256), 0, stream, a);
     return svsr_check_launch();

@@ -105,9 +105,12 @@ __device__ __forceinline__ void reduce_to_slots(float* sred, const float* s1, co
 }
 
 // pass 1 of the backward: slots += (sum g, sum g * xhat) with g = dy * act'(.)   (relu mask from saved y)
+// (templated on the activation: the Swish variant's extra registers must not lower the occupancy of the ReLU passes,
+// which run at HBM speed in the LRW trunk)
+template <int act>
 __global__ __launch_bounds__(256) void k_bn_act_bwd_reduce(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
                                                            const bf16_t* __restrict__ x, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, long nvec, int C, int act,
+                                                           const float* __restrict__ rstd, long nvec, int C,
                                                            float* slots, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const bf16_t* __restrict__ res) {
     __shared__ float sred[256 * 16];
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_reduce(const bf16_t* __restr
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k]; s1[k] = 0.f; s2[k] = 0.f;
-        ga[k] = act == 2 ? gamma[c0 + k] : 0.f; be[k] = act == 2 ? beta[c0 + k] : 0.f;
+        if (act == 2) { ga[k] = gamma[c0 + k]; be[k] = beta[c0 + k]; }
     }
     for (; idx < nvec; idx += stride) {
         float g[8], xv[8];
@@ -165,11 +168,12 @@ __global__ void k_bn_bwd_finalize(float* slots, int C, float count, const float*
 }
 
 // pass 2: dx = gamma*rstd * (g - mean(g) - xhat * mean(g*xhat));  dres = g (optional)
+template <int act>
 __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
                                                           const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ coef,
                                                           bf16_t* __restrict__ dx, bf16_t* __restrict__ dres, long nvec,
-                                                          int C, int act, const float* __restrict__ gamma,
+                                                          int C, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const bf16_t* __restrict__ res) {
     const int cv = C >> 3;
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_apply(const bf16_t* __restri
     for (int k = 0; k < 8; ++k) {
         mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k];
         k0[k] = coef[c0 + k]; k1[k] = coef[C + c0 + k]; k2[k] = coef[2 * C + c0 + k];
-        ga[k] = act == 2 ? gamma[c0 + k] : 0.f; be[k] = act == 2 ? beta[c0 + k] : 0.f;
+        if (act == 2) { ga[k] = gamma[c0 + k]; be[k] = beta[c0 + k]; }
     }
     for (; idx < nvec; idx += stride) {
         float g[8], xv[8], o[8];
@@ -476,11 +480,14 @@ int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* m
     if (act == 2 && beta == nullptr) return SVSR_ERR_ARG;
     const long nvec = npix * (C / 8);
     const int grid = ew_grid_for(nvec, C);
-    hipLaunchKernelGGL(k_bn_act_bwd_reduce, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x,
-                       mean, rstd, nvec, C, act, slots, gamma, beta, (const bf16_t*)res);
+#define SVSR_BN_BWD_REDUCE(A) hipLaunchKernelGGL(k_bn_act_bwd_reduce<A>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, \
+                       (const bf16_t*)x, mean, rstd, nvec, C, slots, gamma, beta, (const bf16_t*)res)
+#define SVSR_BN_BWD_APPLY(A) hipLaunchKernelGGL(k_bn_act_bwd_apply<A>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, \
+                       (const bf16_t*)x, mean, rstd, coef, (bf16_t*)dx, (bf16_t*)dres, nvec, C, gamma, beta, (const bf16_t*)res)
+    if (act < 0 || act > 2) return SVSR_ERR_ARG;
+    if (act == 2) SVSR_BN_BWD_REDUCE(2); else if (act == 1) SVSR_BN_BWD_REDUCE(1); else SVSR_BN_BWD_REDUCE(0);
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 127) / 128), dim3(128), 0, stream, slots, C, (float)npix, gamma, rstd, dgamma, dbeta, coef);
-    hipLaunchKernelGGL(k_bn_act_bwd_apply, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x,
-                       mean, rstd, coef, (bf16_t*)dx, (bf16_t*)dres, nvec, C, act, gamma, beta, (const bf16_t*)res);
+    if (act == 2) SVSR_BN_BWD_APPLY(2); else if (act == 1) SVSR_BN_BWD_APPLY(1); else SVSR_BN_BWD_APPLY(0);
     return svsr_check_launch();
 }
 

@@ -73,7 +73,7 @@ def igemm_fwd_tile(M: int, Co: int) -> tuple[int, int, int]:
     global _CUS
     if _CUS is None:
         _CUS = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    bm = (128 if M >= 16384 else 64) if Co <= 64 else (128 if M >= 8192 else 64)
+    bm = (128 if M >= 16384 else 64) if Co <= 64 else (128 if (M >= 8192 or -(-M // 128) * -(-Co // 128) >= 224) else 64)
     bn = 64 if (bm == 64 or Co <= 64) else 128
     blocks = -(-M // bm) * -(-Co // bn)
     ns = 2 if bm + bn > 192 else (3 if bm + bn > 128 else (4 if blocks <= _CUS * 5 // 2 else 3))
