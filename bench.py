@@ -161,6 +161,7 @@ def main() -> None:
     ap.add_argument("--workload", choices=("lrw", "lrs"), default="lrw", help="lrw = BASELINE.json's headline metric (default); lrs = the "
                     "sentence-level E2E model (SURVEY §8 a13-a15, BASELINE configs[3]): --batch clips of up to --frames frames")
     ap.add_argument("--frames", type=int, default=150, help="LRS: padded clip length T (lengths are drawn in [0.3 T, T])")
+    ap.add_argument("--dropout", type=float, default=0.1, help="LRS: dropout_rate = transformer_attn_dropout_rate (config/lrs3.yaml:20-21)")
     args = ap.parse_args()
     if args.workload == "lrs" and args.batch == 32 and "--batch" not in sys.argv:
         args.batch = 16
@@ -192,9 +193,10 @@ def main() -> None:
         from syncvsr_amd.lrs_init import LRS_ODIM, default_lrs_args, lrs_synthetic_batch
         from syncvsr_amd.lrs_model import E2E
 
-        lrs_args = default_lrs_args()
+        lrs_args = default_lrs_args(dropout_rate=args.dropout, transformer_attn_dropout_rate=args.dropout)
         cfg = lrs_train_config()
         model = E2E(LRS_ODIM, lrs_args, seed=0).to(dev).train()
+        model.reseed_dropout(1000 + rank)
         cpu_batch = lrs_synthetic_batch(lrs_args, args.batch, args.frames, seed=1234 + rank, min_len_frac=0.3)
         batch = [t.to(dev) for t in cpu_batch]
         n_frames = int(cpu_batch[1].sum())
@@ -251,7 +253,7 @@ def main() -> None:
         result["metric"] = f"lip-clips/sec training (LRS, <= {args.frames}x88x88)"
         result["config"] = {"workload": "LRS training step (fwd+bwd+allreduce+clip+AdamW), Conv3d/ResNet18(Swish) front-end + 12-layer 768-d "
                                         "Conformer + CTC + 6-layer attention decoder + vq audio-token CE head (config/lrs3.yaml), random-init "
-                                        f"weights, N(0,1) clips padded to {args.frames} frames, dropout 0",
+                                        f"weights, N(0,1) clips padded to {args.frames} frames, dropout {args.dropout}",
                             "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": use_graph,
                             "padded_frames_per_s": round(clips_per_s * args.frames, 1), "valid_frames_per_step_rank0": n_frames}
         result["step_mfma_frac"] = round(step_flops * args.steps / elapsed / MFMA_PEAK_BF16, 5)

@@ -44,9 +44,10 @@ extern "C" {
  *   (bf16 pixels laid out like `out`: residual-gradient merge; may alias `out`), out = act(alpha*(acc+bias)+addend) with
  *   act 0 none / 1 exact GELU (pre-activation saved to out_pre) / 2 ReLU (LRS PositionwiseFeedForward,
  *   transformer/positionwise_feed_forward.py:28-30; alpha carries the Conformer's 0.5 macaron scale and the
- *   sqrt(d) embedding scale, encoder_layer.py:97,131, embedding.py:208), fp32 output, per-channel BatchNorm partial sums into
+ *   sqrt(d) embedding scale, encoder_layer.py:97,131, embedding.py:208); dropout(p) on act(acc+bias) with the keep decision
+ *   hash(*drop_seed, drop_site, output element index) (drop_seed null or p = 0: off; see svsr_scale_bf16), fp32 output, per-channel BatchNorm partial sums into
  *   stats[SVSR_STAT_SLOTS][2][Co] (accumulated with atomics; zeroed by svsr_bn_finalize). */
-int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int act, int out_f32, float alpha, hipStream_t stream);
+int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int act, int out_f32, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 
 /* svsr_igemm_wgrad replaces: the weight-gradient of the same Conv2d / Linear layers (torch autograd).
  * dw fp32 [Co][wt_taps][Ci] is ACCUMULATED (atomics).  x = forward input pixels, dyp = output-gradient pixels. */
@@ -119,8 +120,9 @@ int svsr_attn_fwd(const void* qkv, void* ctx, void* probs, int B, int S, int H, 
 int svsr_attn_bwd(const void* dctx, const void* qkv, const void* probs, void* dqkv, int B, int S, int H, int dh, float scale, hipStream_t stream);
 
 /* dz = dy * act'(z) when z != null: act 1 = GELU from the saved pre-activation (BertIntermediate), act 2 = ReLU from the
- * saved output (PositionwiseFeedForward); db[n] += column sums (bias gradient of any nn.Linear; db may be null). */
-int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, hipStream_t stream);
+ * saved output (PositionwiseFeedForward; gscale = 1/(1-p) when that output went through dropout — dropped elements are
+ * exactly the zeros of the saved output); db[n] += column sums (bias gradient of any nn.Linear; db may be null). */
+int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, float gscale, hipStream_t stream);
 
 /* ---- losses / metric / optimiser (loss_optim.hip) --------------------------------------------------------------
  * F.cross_entropy(logits.float(), target, label_smoothing) mean over R rows (lightning.py:163-165,171): exactly one of
@@ -147,14 +149,15 @@ int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream);
  * [B*Lk] with pitch kv_pitch; klen[b] = number of valid keys (null: all), causal != 0 masks j > i.  With pe != null the
  * Conformer's relative-position scores are used: ((q+u)·k_j + (q+v)·pe[Lq-1+j-i]) * scale, pe = linear_pos(pos_emb)
  * [2*Lq-1][pe_pitch] (reference LRS/video/espnet/nets/pytorch_backend/transformer/attention.py:191-278 incl. rel_shift
- * :216-236; plain MHA :38-108; mask semantics :71-78).  probs [B*H][Lq][ldp] bf16 is kept for the backward. */
-int svsr_mha_fwd(const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* ctx, int ctx_pitch, void* probs, hipStream_t stream);
+ * :216-236; plain MHA :38-108; mask semantics :71-78).  probs [B*H][Lq][ldp] bf16 (before dropout) is kept for the backward;
+ * attention dropout (attention.py:80) uses the keep decision hash(*drop_seed, drop_site, index into probs). */
+int svsr_mha_fwd(const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* ctx, int ctx_pitch, void* probs, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 
 /* backward of svsr_mha_fwd: ds [B*H][Lq][ldp] workspace (score gradients); dq/dk/dv written (not accumulated); for the
  * relative-position form also dq_ac / dq_bd (the two summands of dq, whose column sums are the pos_bias_u / pos_bias_v
  * gradients) and dpe [2*Lq-1][dpe_pitch] (gradient of the projected position table, feeds linear_pos's weight gradient);
  * pe_part: fp32 workspace [B][2*Lq-1][dpe_pitch] (per-batch-item partials of dpe; dpe_pitch must equal H*64). */
-int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, hipStream_t stream);
+int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 
 /* Conformer convolution module core (transformer/convolution.py:56-75): u [B*T][2D] = pointwise_cov1 output ->
  * GLU -> depthwise Conv1d(K odd <= 31, pad (K-1)/2, weight [D][K], bias) -> c [B*T][D] bf16 + BatchNorm1d partial sums
@@ -185,8 +188,12 @@ int svsr_embed_pos_bwd(const int64_t* tok, const void* dx, float* demb, int R, i
 int svsr_ls_loss_fwd(const float* logits, int ld, const int64_t* target, int R, int V, float smoothing, float inv_denom, float* loss_sum, float* lse, float* counts, hipStream_t stream);
 int svsr_ls_loss_bwd(const float* logits, int ld, const int64_t* target, int R, int V, float smoothing, float inv_denom, const float* lse, const float* gout, void* dlogits, int ldo, hipStream_t stream);
 
-/* y = alpha * x over n (multiple of 8) bf16 elements. */
-int svsr_scale_bf16(const void* x, void* y, int64_t n, float alpha, hipStream_t stream);
+/* y = alpha * dropout_p(x) over n (multiple of 8) contiguous bf16 elements (y may alias x).  Dropout everywhere in this
+ * library is counter based: element i of a tensor is kept iff mix(i * 2654435761 + key) >= p * 2^32 with
+ * key = mix(*drop_seed * 0x9E3779B9 + drop_site * 0x7F4A7C15 + 0x165667B1) and mix = the murmur3 finaliser; kept values are
+ * scaled by 1/(1-p).  The backward passes regenerate the mask from (seed, site); drop_seed is a device word the caller
+ * advances once per step.  drop_seed == null or p == 0 disables it. */
+int svsr_scale_bf16(const void* x, void* y, int64_t n, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 
 #ifdef __cplusplus
 }

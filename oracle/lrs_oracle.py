@@ -32,6 +32,34 @@ LN_EPS = 1e-12                       # transformer/layer_norm.py:19
 NEG = -1e10                          # attention.py:73 (min_value)
 
 
+class DropPlan:
+    """Replays the HIP library's counter-based dropout masks (syncvsr_amd/dropout.py is the numpy twin of csrc/common.h's
+    drop_keep) so a training forward WITH dropout can be compared element for element: the reference's nn.Dropout draws from
+    torch's generator, which no other implementation can reproduce — sharing the mask is the only way to pin the arithmetic
+    around it.  `probs_pitch` mirrors the row pitch of the library's probability buffer (keys padded to a multiple of 8)."""
+
+    def __init__(self, seed: int, p: float, attn_p: float, sites: dict[str, int]):
+        self.seed, self.p, self.attn_p, self.sites = int(seed), float(p), float(attn_p), sites
+
+    def __call__(self, x: Tensor, site: str, attn: bool = False) -> Tensor:
+        from syncvsr_amd.dropout import keep_mask
+
+        p = self.attn_p if attn else self.p
+        if p <= 0.0:
+            return x
+        if attn:
+            B, H, Lq, Lk = x.shape
+            pitch = (Lk + 7) // 8 * 8
+            m = keep_mask(self.seed, self.sites[site], p, B * H * Lq * pitch).reshape(B, H, Lq, pitch)[..., :Lk]
+        else:
+            m = keep_mask(self.seed, self.sites[site], p, x.numel()).reshape(tuple(x.shape))
+        return x * torch.from_numpy(m.copy()).to(x.dtype) / (1.0 - p)
+
+
+def _dp(dp, x: Tensor, site: str, attn: bool = False) -> Tensor:
+    return x if dp is None else dp(x, site, attn)
+
+
 def swish(x: Tensor) -> Tensor:
     """transformer/convolution.py:78-83."""
     return x * torch.sigmoid(x)
@@ -101,28 +129,29 @@ def abs_pos_emb(T: int, d_model: int) -> Tensor:
 # --------------------------------------------------------------------------------------------
 # attention: transformer/attention.py:38-108 (MHA), :191-278 (rel-pos MHA, rel_shift :216-236)
 # --------------------------------------------------------------------------------------------
-def _attend(scores: Tensor, v: Tensor, mask: Tensor | None) -> Tensor:
-    """attention.py:59-88: mask==0 -> -1e10 before softmax and 0 after; context = P·V, heads re-merged."""
+def _attend(scores: Tensor, v: Tensor, mask: Tensor | None, dp=None, site: str = "") -> Tensor:
+    """attention.py:59-88: mask==0 -> -1e10 before softmax and 0 after; dropout on the probabilities; context = P·V."""
     if mask is not None:
         m = mask.unsqueeze(1).eq(0)
         attn = torch.softmax(scores.masked_fill(m, NEG), dim=-1).masked_fill(m, 0.0)
     else:
         attn = torch.softmax(scores, dim=-1)
+    attn = _dp(dp, attn, site, attn=True)
     ctx = torch.matmul(attn, v)                                # [B,H,Tq,dk]
     return ctx.transpose(1, 2).reshape(ctx.size(0), ctx.size(2), -1)
 
 
-def mha(q_in: Tensor, kv_in: Tensor, mask: Tensor | None, sd: SD, p: str, heads: int) -> Tensor:
+def mha(q_in: Tensor, kv_in: Tensor, mask: Tensor | None, sd: SD, p: str, heads: int, dp=None, site: str = "") -> Tensor:
     B, Tq, D = q_in.shape
     dk = D // heads
     q = _lin(q_in, sd, f"{p}.linear_q").view(B, Tq, heads, dk).transpose(1, 2)
     k = _lin(kv_in, sd, f"{p}.linear_k").view(B, -1, heads, dk).transpose(1, 2)
     v = _lin(kv_in, sd, f"{p}.linear_v").view(B, -1, heads, dk).transpose(1, 2)
     scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(dk)
-    return _lin(_attend(scores, v, mask), sd, f"{p}.linear_out")
+    return _lin(_attend(scores, v, mask, dp, site), sd, f"{p}.linear_out")
 
 
-def rel_mha(x: Tensor, pos: Tensor, mask: Tensor | None, sd: SD, p: str, heads: int) -> Tensor:
+def rel_mha(x: Tensor, pos: Tensor, mask: Tensor | None, sd: SD, p: str, heads: int, dp=None, site: str = "") -> Tensor:
     """scores[i,j] = ((q_i+u)·k_j + (q_i+v)·p[T-1+j-i]) / sqrt(dk)   — the closed form of rel_shift (attention.py:216-236)."""
     B, T, D = x.shape
     dk = D // heads
@@ -137,14 +166,14 @@ def rel_mha(x: Tensor, pos: Tensor, mask: Tensor | None, sd: SD, p: str, heads: 
     idx = (T - 1) + torch.arange(T).view(1, T) - torch.arange(T).view(T, 1)                          # [T,T]
     bd = bd_full.gather(-1, idx.expand(B, heads, T, T))
     scores = (ac + bd) / math.sqrt(dk)
-    return _lin(_attend(scores, v, mask), sd, f"{p}.linear_out")
+    return _lin(_attend(scores, v, mask, dp, site), sd, f"{p}.linear_out")
 
 
 # --------------------------------------------------------------------------------------------
 # Conformer blocks: transformer/convolution.py:56-75, positionwise_feed_forward.py:28-30, encoder_layer.py:76-150
 # --------------------------------------------------------------------------------------------
-def ffn(x: Tensor, sd: SD, p: str) -> Tensor:
-    return _lin(torch.relu(_lin(x, sd, f"{p}.w_1")), sd, f"{p}.w_2")
+def ffn(x: Tensor, sd: SD, p: str, dp=None, site: str = "") -> Tensor:
+    return _lin(_dp(dp, torch.relu(_lin(x, sd, f"{p}.w_1")), f"{site}.hidden"), sd, f"{p}.w_2")
 
 
 def conv_module(x: Tensor, sd: SD, p: str, training: bool, stats_out: dict | None = None) -> Tensor:
@@ -159,25 +188,27 @@ def conv_module(x: Tensor, sd: SD, p: str, training: bool, stats_out: dict | Non
 
 
 def encoder_layer(x: Tensor, pos: Tensor, mask: Tensor | None, sd: SD, p: str, heads: int, training: bool,
-                  stats_out: dict | None = None) -> Tensor:
-    x = x + 0.5 * ffn(_ln(x, sd, f"{p}.norm_ff_macaron"), sd, f"{p}.feed_forward_macaron")
-    x = x + rel_mha(_ln(x, sd, f"{p}.norm_mha"), pos, mask, sd, f"{p}.self_attn", heads)
-    x = x + conv_module(_ln(x, sd, f"{p}.norm_conv"), sd, f"{p}.conv_module", training, stats_out)
-    x = x + 0.5 * ffn(_ln(x, sd, f"{p}.norm_ff"), sd, f"{p}.feed_forward")
+                  stats_out: dict | None = None, dp=None, s: str = "") -> Tensor:
+    x = x + 0.5 * _dp(dp, ffn(_ln(x, sd, f"{p}.norm_ff_macaron"), sd, f"{p}.feed_forward_macaron", dp, f"{s}.ffm"), f"{s}.ffm.out")
+    x = x + _dp(dp, rel_mha(_ln(x, sd, f"{p}.norm_mha"), pos, mask, sd, f"{p}.self_attn", heads, dp, f"{s}.attn.probs"), f"{s}.attn.out")
+    x = x + _dp(dp, conv_module(_ln(x, sd, f"{p}.norm_conv"), sd, f"{p}.conv_module", training, stats_out), f"{s}.conv.out")
+    x = x + 0.5 * _dp(dp, ffn(_ln(x, sd, f"{p}.norm_ff"), sd, f"{p}.feed_forward", dp, f"{s}.ff"), f"{s}.ff.out")
     return _ln(x, sd, f"{p}.norm_final")
 
 
 def encoder(x: Tensor, mask: Tensor | None, sd: SD, args: Any, training: bool, stats_out: dict | None = None,
-            keep: dict | None = None) -> Tensor:
+            keep: dict | None = None, dp=None) -> Tensor:
     """transformer/encoder.py:257-289 with input_layer conv3d, rel_mha, macaron, cnn module, normalize_before."""
     D = int(args.adim)
     feats = frontend(x, sd, training, stats_out, keep)
     if keep is not None:
         keep["feats"] = feats
-    h = _lin(feats, sd, "encoder.embed.0") * math.sqrt(D)                    # embedding.py:208
+    h = _dp(dp, _lin(feats, sd, "encoder.embed.0"), "enc.embed.x") * math.sqrt(D)       # dropout(x * xscale), embedding.py:208,217
     pos = rel_pos_emb(h.size(1), D).to(h.dtype)          # table computed in fp32 as the reference does
+    if dp is not None:
+        pos = _dp(dp, pos.to(torch.bfloat16).to(h.dtype), "enc.embed.pos")               # the HIP path keeps this table in bf16
     for i in range(int(args.elayers)):
-        h = encoder_layer(h, pos, mask, sd, f"encoder.encoders.{i}", int(args.aheads), training, stats_out)
+        h = encoder_layer(h, pos, mask, sd, f"encoder.encoders.{i}", int(args.aheads), training, stats_out, dp, f"enc.{i}")
         if keep is not None:
             keep[f"enc{i}"] = h
     return _ln(h, sd, "encoder.after_norm")
@@ -186,10 +217,10 @@ def encoder(x: Tensor, mask: Tensor | None, sd: SD, args: Any, training: bool, s
 # --------------------------------------------------------------------------------------------
 # heads and losses: e2e_asr_transformer.py:193-227, ctc.py:65-151, decoder.py:122-151, label_smoothing_loss.py:41-63
 # --------------------------------------------------------------------------------------------
-def ctc_loss(h: Tensor, hlens: Tensor, ys: list[Tensor], sd: SD) -> Tensor:
+def ctc_loss(h: Tensor, hlens: Tensor, ys: list[Tensor], sd: SD, dp=None) -> Tensor:
     """ctc_lo -> log_softmax -> CTC(sum, zero_infinity, blank 0) / B   (ctc.py:65-74).  The reference calls torch's builtin
     ``CTCLoss``; so does this restatement — ``ctc_nll_reference`` below spells the recursion out and is tested against it."""
-    lp = _lin(h, sd, "ctc.ctc_lo").transpose(0, 1).log_softmax(2)
+    lp = _lin(_dp(dp, h, "ctc.in"), sd, "ctc.ctc_lo").transpose(0, 1).log_softmax(2)                # ctc.py:97
     olens = torch.tensor([len(y) for y in ys], dtype=torch.long)
     loss = F.ctc_loss(lp, torch.cat(ys), hlens.long(), olens, blank=0, reduction="sum", zero_infinity=True)
     return loss / h.size(0)
@@ -233,19 +264,21 @@ def add_sos_eos(ys: list[Tensor], sos: int, eos: int, ignore_id: int = -1) -> tu
     return ys_in, ys_out
 
 
-def decoder(ys_in: Tensor, memory: Tensor, memory_mask: Tensor, sd: SD, args: Any, keep: dict | None = None) -> Tensor:
+def decoder(ys_in: Tensor, memory: Tensor, memory_mask: Tensor, sd: SD, args: Any, keep: dict | None = None, dp=None) -> Tensor:
     """decoder.py:122-151 + decoder_layer.py:60-121 (pre-LN).  Self-attention mask = causal (ys_in is eos-padded, never -1:
     mask.py:41-51); source mask = encoder padding mask."""
     D = int(args.ddim)
     L = ys_in.size(1)
     x = F.embedding(ys_in, sd["decoder.embed.0.weight"]) * math.sqrt(D) + abs_pos_emb(L, D).to(memory.dtype)       # embedding.py:78-89
+    x = _dp(dp, x, "dec.embed")
     causal = torch.tril(torch.ones(L, L, dtype=torch.bool)).unsqueeze(0)
     for i in range(int(args.dlayers)):
-        p = f"decoder.decoders.{i}"
+        p, s = f"decoder.decoders.{i}", f"dec.{i}"
         t = _ln(x, sd, f"{p}.norm1")
-        x = x + mha(t, t, causal, sd, f"{p}.self_attn", int(args.dheads))
-        x = x + mha(_ln(x, sd, f"{p}.norm2"), memory, memory_mask, sd, f"{p}.src_attn", int(args.dheads))
-        x = x + ffn(_ln(x, sd, f"{p}.norm3"), sd, f"{p}.feed_forward")
+        x = x + _dp(dp, mha(t, t, causal, sd, f"{p}.self_attn", int(args.dheads), dp, f"{s}.self.probs"), f"{s}.self.out")
+        x = x + _dp(dp, mha(_ln(x, sd, f"{p}.norm2"), memory, memory_mask, sd, f"{p}.src_attn", int(args.dheads), dp, f"{s}.src.probs"),
+                    f"{s}.src.out")
+        x = x + _dp(dp, ffn(_ln(x, sd, f"{p}.norm3"), sd, f"{p}.feed_forward", dp, f"{s}.ff"), f"{s}.ff.out")
         if keep is not None:
             keep[f"dec{i}"] = x
     return _lin(_ln(x, sd, "decoder.after_norm"), sd, "decoder.output_layer")
@@ -271,22 +304,24 @@ def th_accuracy(pred: Tensor, target: Tensor, ignore_id: int = -1) -> float:
 
 
 def forward(sd: SD, args: Any, x: Tensor, lengths: Tensor, audio_tokens: Tensor, label: Tensor, training: bool = True,
-            stats_out: dict | None = None, keep: dict | None = None) -> dict[str, Any]:
+            stats_out: dict | None = None, keep: dict | None = None, dp: DropPlan | None = None) -> dict[str, Any]:
     """``E2E.forward`` (e2e_asr_transformer.py:187-227) with pre-computed audio tokens in the ``audios`` slot."""
     from syncvsr_amd.lrs_init import lrs_audio_dims          # parameter-free helper (codec string -> (A,G,V))
     odim = sd["ctc.ctc_lo.weight"].size(0)
     B, T = x.shape[:2]
     mask = (torch.arange(T).unsqueeze(0) < lengths.view(-1, 1)).unsqueeze(-2)                 # make_non_pad_mask, [B,1,T]
-    h = encoder(x, mask, sd, args, training, stats_out, keep)
+    if not training:
+        dp = None
+    h = encoder(x, mask, sd, args, training, stats_out, keep, dp)
     if keep is not None:
         keep["enc_out"] = h
     A, G, V = lrs_audio_dims(args)
     logits_audio = _lin(h, sd, "audio_classifier").float().unflatten(2, (-1, V))
     loss_audio = F.cross_entropy(logits_audio.flatten(0, 2), audio_tokens[:, : T * A].flatten())
     ys = [y[y != -1] for y in label.view(B, -1)]
-    loss_ctc = ctc_loss(h, lengths, ys, sd)
+    loss_ctc = ctc_loss(h, lengths, ys, sd, dp)
     ys_in, ys_out = add_sos_eos(ys, odim - 1, odim - 1)
-    pred = decoder(ys_in, h, mask, sd, args, keep)
+    pred = decoder(ys_in, h, mask, sd, args, keep, dp)
     if keep is not None:
         keep["pred"] = pred
     loss_att = label_smoothing_loss(pred.float(), ys_out, float(args.lsm_weight), bool(args.transformer_length_normalized_loss))

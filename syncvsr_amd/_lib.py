@@ -15,6 +15,7 @@ _CTYPES = {
     "int": ctypes.c_int,
     "float": ctypes.c_float,
     "int64_t": ctypes.c_int64,
+    "unsigned": ctypes.c_uint,
     "hipStream_t": ctypes.c_void_p,
 }
 

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const bf16_t* __restrict__ dct
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bias_act_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z,
                                                       bf16_t* __restrict__ dz, float* __restrict__ db, int R, int N, int n_valid,
-                                                      int ld, int rows_per_block, int act) {
+                                                      int ld, int rows_per_block, int act, float gscale) {
     // block = 8 row lanes x 32 column vectors: a wave reads 2 rows x 512 contiguous bytes per step
     __shared__ float sred[8][32][8];
     const int cv = N >> 3;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_bias_act_bwd(const bf16_t* __restrict__
                 float zz[8];
                 unpack8(*reinterpret_cast<const u32x4*>(z + (long)r * ld + v * 8), zz);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) g[k] = act == 2 ? (zz[k] > 0.f ? g[k] : 0.f) : g[k] * gelu_erf_grad(zz[k]);
+                for (int k = 0; k < 8; ++k) g[k] = act == 2 ? (zz[k] > 0.f ? g[k] * gscale : 0.f) : g[k] * gelu_erf_grad(zz[k]) * gscale;
                 *reinterpret_cast<u32x4*>(dz + (long)r * ld + v * 8) = pack8(g);
             }
 #pragma unroll
@@ -427,7 +427,8 @@ int svsr_attn_bwd(const void* dctx, const void* qkv, const void* probs, void* dq
     return svsr_check_launch();
 }
 
-int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, hipStream_t stream) {
+int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, float gscale,
+                      hipStream_t stream) {
     if (N % 8 != 0 || ld % 8 != 0) return SVSR_ERR_ARG;
     const int cv = N / 8;
     const int col_blocks = (cv + 31) / 32;
@@ -436,7 +437,7 @@ int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R,
     const int rpb = (R + splits - 1) / splits;
     splits = (R + rpb - 1) / rpb;
     hipLaunchKernelGGL(k_bias_act_bwd, dim3(col_blocks, splits), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)z,
-                       (bf16_t*)dz, db, R, N, n_valid, ld, rpb, act);
+                       (bf16_t*)dz, db, R, N, n_valid, ld, rpb, act, gscale);
     return svsr_check_launch();
 }
 

@@ -64,6 +64,17 @@ __device__ __forceinline__ float swish_grad(float x) {
 #define SVSR_ACT_GELU 1
 #define SVSR_ACT_SWISH 2
 
+// Dropout: counter-based keep decision, reproducible from (seed, site, element index) alone, so the backward regenerates
+// the mask instead of storing it and the parity tests can replay it on the host (syncvsr_amd/dropout.py is the numpy twin).
+// keep(idx) <=> hash(key, idx) >= thresh, thresh = p * 2^32; kept values are scaled by 1/(1-p).
+struct DropArgs { const unsigned* seed; unsigned site; unsigned thresh; float scale; };
+__device__ __forceinline__ unsigned svsr_mix(unsigned h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ unsigned drop_key(const DropArgs& d) { return svsr_mix(d.seed[0] * 0x9E3779B9u + d.site * 0x7F4A7C15u + 0x165667B1u); }
+__device__ __forceinline__ bool drop_keep(unsigned key, unsigned thresh, unsigned idx) { return svsr_mix(idx * 2654435761u + key) >= thresh; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -88,6 +99,17 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
     u32x4 v;
     v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
     return v;
+}
+
+static inline DropArgs svsr_make_drop(const unsigned* seed, unsigned site, float p) {
+    DropArgs d;
+    const bool on = seed != nullptr && p > 0.f;
+    d.seed = on ? seed : nullptr;
+    d.site = site;
+    const double t = (double)p * 4294967296.0;
+    d.thresh = on ? (unsigned)(t > 4294967295.0 ? 4294967295.0 : t) : 0u;
+    d.scale = on ? 1.0f / (1.0f - p) : 1.0f;
+    return d;
 }
 
 static inline int svsr_check_launch() {

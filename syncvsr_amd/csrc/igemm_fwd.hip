@@ -27,7 +27,8 @@ struct IgemmFwdArgs {
     const bf16_t* addend;  // optional bf16 pixels with the geometry of `out`, added before the activation
     float* stats;          // optional BatchNorm partials: atomically accumulated slots [SVSR_STAT_SLOTS][2][Co]
     int act, out_f32;          // act: 0 none, 1 GELU(erf) (pre-activation kept in out_pre), 2 ReLU
-    float alpha;               // out = act(alpha * (acc + bias) + addend)
+    float alpha;               // out = alpha * dropout(act(acc + bias)) + addend
+    DropArgs drop;             // drop.seed == nullptr: no dropout
     int dbg;               // tuning aid (SVSR_IGEMM_DBG): bit0 skip the K loop, bit1 skip the epilogue stores
 };
 
@@ -86,6 +87,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
                 v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3]; v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
             }
+            if (p.act == 1) {
+                if (p.out_pre != nullptr) *reinterpret_cast<u32x4*>(p.out_pre + off + n) = pack8(v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (p.drop.seed != nullptr) {
+                const unsigned key = drop_key(p.drop);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = drop_keep(key, p.drop.thresh, (unsigned)(off + n + k)) ? v[k] * p.drop.scale : 0.f;
+            }
             if (p.alpha != 1.f) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] *= p.alpha;
@@ -95,14 +109,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
                 unpack8(*reinterpret_cast<const u32x4*>(p.addend + off + n), a8);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] += a8[k];
-            }
-            if (p.act == 1) {
-                if (p.out_pre != nullptr) *reinterpret_cast<u32x4*>(p.out_pre + off + n) = pack8(v);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
-            } else if (p.act == 2) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
             }
             if (p.out_f32) {
                 float* o = reinterpret_cast<float*>(p.out) + off + n;
@@ -117,14 +123,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
                 if (n + k >= g.Co) break;
                 float x = v[k];
                 if (p.bias != nullptr) x += p.bias[n + k];
-                x *= p.alpha;
-                if (p.addend != nullptr) x += bf2f(p.addend[off + n + k]);
                 if (p.act == 1) {
                     if (p.out_pre != nullptr) p.out_pre[off + n + k] = f2bf(x);
                     x = gelu_erf(x);
                 } else if (p.act == 2) {
                     x = fmaxf(x, 0.f);
                 }
+                if (p.drop.seed != nullptr) x = drop_keep(drop_key(p.drop), p.drop.thresh, (unsigned)(off + n + k)) ? x * p.drop.scale : 0.f;
+                x *= p.alpha;
+                if (p.addend != nullptr) x += bf2f(p.addend[off + n + k]);
                 if (p.out_f32) reinterpret_cast<float*>(p.out)[off + n + k] = x;
                 else reinterpret_cast<bf16_t*>(p.out)[off + n + k] = f2bf(x);
             }
@@ -482,12 +489,15 @@ static bool use_glds() {
 extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend,
                               float* stats, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch,
                               int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx,
-                              const int* tw, int act, int out_f32, float alpha, hipStream_t stream) {
+                              const int* tw, int act, int out_f32, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p,
+                              hipStream_t stream) {
     IgemmFwdArgs a;
     int rc = fill_geom(a.g, Nimg, Hi, Wi, Ci, in_pitch, Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, ntaps, wt_taps, dy, dx, tw);
     if (rc != SVSR_OK) return rc;
     a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = out; a.out_pre = (bf16_t*)out_pre;
     a.bias = bias; a.addend = (const bf16_t*)addend; a.stats = stats; a.act = act; a.out_f32 = out_f32; a.alpha = alpha;
+    if (act != 0 && (addend != nullptr || alpha != 1.f)) return SVSR_ERR_ARG;     // the activation is applied before alpha / addend
+    a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
     static const int dbg = [] { const char* e = getenv("SVSR_IGEMM_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
     const int bm = igemm_fwd_tile_m(a.g.M, Co);

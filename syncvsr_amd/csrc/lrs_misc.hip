@@ -370,12 +370,18 @@ __global__ __launch_bounds__(256) void k_ls_loss_bwd(const float* __restrict__ z
     }
 }
 
-__global__ __launch_bounds__(256) void k_scale_bf16(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long nvec, float alpha) {
+// y = alpha * dropout(x)   (dropout optional; element index = position in the contiguous tensor) ; y may alias x
+__global__ __launch_bounds__(256) void k_scale_bf16(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long nvec, float alpha, DropArgs drop) {
+    const bool on = drop.seed != nullptr;
+    const unsigned key = on ? drop_key(drop) : 0u;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
         float f[8];
         unpack8(reinterpret_cast<const u32x4*>(x)[i], f);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) f[k] *= alpha;
+        for (int k = 0; k < 8; ++k) {
+            if (on) f[k] = drop_keep(key, drop.thresh, (unsigned)(i * 8 + k)) ? f[k] * drop.scale : 0.f;
+            f[k] *= alpha;
+        }
         reinterpret_cast<u32x4*>(y)[i] = pack8(f);
     }
 }
@@ -449,9 +455,11 @@ int svsr_ls_loss_bwd(const float* logits, int ld, const int64_t* target, int R, 
     return svsr_check_launch();
 }
 
-int svsr_scale_bf16(const void* x, void* y, int64_t n, float alpha, hipStream_t stream) {
+int svsr_scale_bf16(const void* x, void* y, int64_t n, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p,
+                    hipStream_t stream) {
     if (n % 8 != 0) return SVSR_ERR_ARG;
-    hipLaunchKernelGGL(k_scale_bf16, dim3(grid1d(n / 8)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (long)(n / 8), alpha);
+    hipLaunchKernelGGL(k_scale_bf16, dim3(grid1d(n / 8)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (long)(n / 8), alpha,
+                       svsr_make_drop(drop_seed, drop_site, drop_p));
     return svsr_check_launch();
 }
 

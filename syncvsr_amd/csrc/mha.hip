@@ -37,6 +37,7 @@ struct MhaArgs {
     bf16_t* dk; bf16_t* dv; int dkv_pitch;
     bf16_t* dpe; int dpe_pitch;
     float* pe_part;                           // [B][2*Lq-1][dpe_pitch] fp32 per-batch-item partials of dpe
+    DropArgs drop;                            // attention-probability dropout (seed == nullptr: off); element index = position in probs
 };
 
 __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -162,14 +163,17 @@ __global__ __launch_bounds__(64) void k_mha_fwd(const MhaArgs a) {
     }
     __syncthreads();
     const int LkR = (a.Lk + 31) & ~31;
+    const bool drop_on = a.drop.seed != nullptr;
+    const unsigned dkey = drop_on ? drop_key(a.drop) : 0u;
     for (int il = 0; il < 32; ++il) {
         const float m = sStat[il * 2], inv = sStat[il * 2 + 1];
         const int i = i0 + il;
         for (int j = lane; j < LkR; j += 64) {
             float p = 0.f;
             if (j < a.Lk && inv > 0.f) p = __expf(sS[il * LkS + j] - m) * inv;
-            sS[il * LkS + j] = p;
             if (i < a.Lq && j < a.ldp) a.probs[((long)bh * a.Lq + i) * a.ldp + j] = f2bf(p);
+            if (drop_on) p = drop_keep(dkey, a.drop.thresh, (unsigned)(((long)bh * a.Lq + i) * a.ldp + j)) ? p * a.drop.scale : 0.f;
+            sS[il * LkS + j] = p;
         }
     }
     // ---- ctx = P·V ----
@@ -227,15 +231,24 @@ __global__ __launch_bounds__(64) void k_mha_bwd_q(const MhaArgs a) {
         for (int r = 0; r < 16; ++r) sS[acc_row(r, lane) * LkS + j0 + row] = acc[r];
     }
     __syncthreads();
-    // dS = P ∘ (dP - sum_j dP∘P) * scale, row by row (coalesced P reads, dS writes)
+    // dS = P ∘ (dP - sum_j dP∘P) * scale, row by row (coalesced P reads, dS writes); with dropout dP = mask/(1-p) ∘ d(dropped P)
     const int LkR = (a.Lk + 31) & ~31;
+    const bool drop_on = a.drop.seed != nullptr;
+    const unsigned dkey = drop_on ? drop_key(a.drop) : 0u;
     for (int il = 0; il < 32; ++il) {
         const int i = i0 + il;
         const bool live = i < a.Lq;
         const bf16_t* prow = a.probs + ((long)bh * a.Lq + (live ? i : 0)) * a.ldp;
         float part = 0.f;
         if (live)
-            for (int j = lane; j < a.Lk; j += 64) part += bf2f(prow[j]) * sS[il * LkS + j];
+            for (int j = lane; j < a.Lk; j += 64) {
+                float dp = sS[il * LkS + j];
+                if (drop_on) {
+                    dp = drop_keep(dkey, a.drop.thresh, (unsigned)(((long)bh * a.Lq + i) * a.ldp + j)) ? dp * a.drop.scale : 0.f;
+                    sS[il * LkS + j] = dp;
+                }
+                part += bf2f(prow[j]) * dp;
+            }
         const float dsum = wave_sum(part);
         for (int j = lane; j < LkR; j += 64) {
             float d = 0.f;
@@ -326,6 +339,14 @@ __global__ __launch_bounds__(64) void k_mha_bwd_kv(const MhaArgs a) {
     for (int i0 = 0; i0 < a.Lq; i0 += 32) {
         __syncthreads();
         stage_block32(sP, a.probs + (long)bh * a.Lq * a.ldp, i0, a.Lq, j0, a.Lk, a.ldp, lane);
+        if (a.drop.seed != nullptr) {       // dV = (dropped P)^T · dctx
+            const unsigned dkey = drop_key(a.drop);
+            for (int idx = lane; idx < 32 * 32; idx += 64) {
+                const int r = idx >> 5, c = idx & 31;
+                const unsigned e = (unsigned)(((long)bh * a.Lq + i0 + r) * a.ldp + j0 + c);
+                sP[r * MHA_TP + c] = drop_keep(dkey, a.drop.thresh, e) ? f2bf(bf2f(sP[r * MHA_TP + c]) * a.drop.scale) : (bf16_t)0;
+            }
+        }
         stage_block32(sD, a.ds + (long)bh * a.Lq * a.ldp, i0, a.Lq, j0, a.Lk, a.ldp, lane);
         stage_rows64(sDC, a.dctx, (long)b * a.Lq + i0, b * a.Lq + a.Lq, a.dctx_pitch, h * MHA_DH, lane);
         stage_rows64(sQ, a.q, (long)b * a.Lq + i0, b * a.Lq + a.Lq, a.q_pitch, h * MHA_DH, lane);
@@ -430,7 +451,8 @@ extern "C" {
 
 int svsr_mha_fwd(const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch,
                  const float* bias_u, const float* bias_v, const int* klen, int causal, int B, int H, int dh, int Lq, int Lk, int ldp,
-                 float scale, void* ctx, int ctx_pitch, void* probs, hipStream_t stream) {
+                 float scale, void* ctx, int ctx_pitch, void* probs, const unsigned* drop_seed, unsigned drop_site, float drop_p,
+                 hipStream_t stream) {
     if (dh != MHA_DH || Lq < 1 || Lk < 1 || ldp < Lk || (q_pitch | kv_pitch | pe_pitch) % 8 != 0) return SVSR_ERR_ARG;
     if (pe != nullptr && (bias_u == nullptr || bias_v == nullptr || Lq != Lk)) return SVSR_ERR_ARG;
     const size_t lds = mha_lds_fwd(Lk);
@@ -439,6 +461,7 @@ int svsr_mha_fwd(const void* q, int q_pitch, const void* k, const void* v, int k
     a.q = (const bf16_t*)q; a.q_pitch = q_pitch; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.kv_pitch = kv_pitch;
     a.pe = (const bf16_t*)pe; a.pe_pitch = pe_pitch; a.bias_u = bias_u; a.bias_v = bias_v; a.klen = klen; a.causal = causal;
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldp = ldp; a.scale = scale; a.ctx = (bf16_t*)ctx; a.ctx_pitch = ctx_pitch; a.probs = (bf16_t*)probs;
+    a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
     static bool attr = false;
     if (!attr) { mha_allow_lds(k_mha_fwd<true>); mha_allow_lds(k_mha_fwd<false>); attr = true; }
     const dim3 grid((Lq + 31) / 32, B * H);
@@ -450,7 +473,8 @@ int svsr_mha_fwd(const void* q, int q_pitch, const void* k, const void* v, int k
 int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch,
                  const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const void* probs, void* ds, int B, int H,
                  int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch,
-                 void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, hipStream_t stream) {
+                 void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, const unsigned* drop_seed, unsigned drop_site,
+                 float drop_p, hipStream_t stream) {
     if (dh != MHA_DH || Lq < 1 || Lk < 1 || ldp < Lk || (q_pitch | kv_pitch | pe_pitch | dctx_pitch) % 8 != 0) return SVSR_ERR_ARG;
     const bool rel = pe != nullptr;
     if (rel && (bias_u == nullptr || bias_v == nullptr || Lq != Lk || dq_ac == nullptr || dq_bd == nullptr || dpe == nullptr || pe_part == nullptr)) return SVSR_ERR_ARG;
@@ -463,6 +487,7 @@ int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, c
     a.dctx = (const bf16_t*)dctx; a.dctx_pitch = dctx_pitch; a.ds = (bf16_t*)ds; a.dq = (bf16_t*)dq; a.dq_pitch = dq_pitch;
     a.dq_ac = (bf16_t*)dq_ac; a.dq_bd = (bf16_t*)dq_bd; a.aux_pitch = aux_pitch; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dkv_pitch = dkv_pitch;
     a.dpe = (bf16_t*)dpe; a.dpe_pitch = dpe_pitch; a.pe_part = pe_part;
+    a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
     static bool attr = false;
     if (!attr) { mha_allow_lds(k_mha_bwd_q<true>); mha_allow_lds(k_mha_bwd_q<false>); attr = true; }
     const dim3 gq((Lq + 31) / 32, B * H), gk((Lk + 31) / 32, B * H);

@@ -21,7 +21,7 @@ LRS_ODIM = 5049          # len(unigram5000_units) + blank/unk/eos as the referen
 
 
 def default_lrs_args(**kw) -> Config:
-    """``config/lrs3.yaml:14-39`` (``model.visual_backbone``); dropout defaults to 0 (see DESIGN: dropout is not built yet)."""
+    """``config/lrs3.yaml:14-39`` (``model.visual_backbone``); dropout defaults to 0 here (the goldens and parity cases need a deterministic forward); the shipped recipe's 0.1 is what bench.py --workload lrs uses."""
     a = Config(
         audio_weight=10.0, adim=768, aheads=12, eunits=3072, elayers=12, transformer_input_layer="conv3d",
         dropout_rate=0.0, transformer_attn_dropout_rate=0.0, transformer_encoder_attn_layer_type="rel_mha",

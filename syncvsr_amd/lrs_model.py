@@ -75,8 +75,6 @@ class E2E(nn.Module):
             unsupported.append("relu_type must be swish")
         if args.get("zero_triu", False):
             unsupported.append("zero_triu is not supported")
-        if float(args.dropout_rate) or float(args.transformer_attn_dropout_rate or 0.0):
-            unsupported.append("dropout > 0 is not implemented in the HIP path yet")
         if self.adim != self.ddim:
             unsupported.append("adim != ddim (proj_decoder) is not implemented")
         if self.adim % 64 or self.adim // self.aheads != 64 or self.ddim // self.dheads != 64:
@@ -87,6 +85,15 @@ class E2E(nn.Module):
             unsupported.append("cnn_module_kernel must be odd and <= 31")
         if unsupported:
             raise NotImplementedError("; ".join(unsupported))
+        # nn.Dropout sites (all p = dropout_rate except the attention probabilities: transformer_attn_dropout_rate; e2e:54-55)
+        from .dropout import lrs_sites
+
+        self.drop_p = float(args.dropout_rate)
+        attn_p = args.transformer_attn_dropout_rate
+        self.attn_drop_p = self.drop_p if attn_p is None else float(attn_p)
+        self._sites = lrs_sites(self.elayers, self.dlayers)
+        self.dropout_seed = 0                     # base seed; the device-side word advances by one per training forward
+        self._drop_word: Optional[torch.Tensor] = None
         self.audio_alignment, self.vq_groups, self.audio_vocab_size = lrs_audio_dims(args)
         self.codec = "vq" if self.audio_alignment == 4 else "wav2vec2"
 
@@ -177,6 +184,22 @@ class E2E(nn.Module):
             self._store = _ParamStore(self, dev)
         return self._store
 
+    def _advance_dropout(self, dev: torch.device) -> None:
+        if self._drop_word is None or self._drop_word.device != dev:
+            self._drop_word = torch.tensor([self.dropout_seed], dtype=torch.int32, device=dev)
+        self._drop_word.add_(1)                   # a device op: graph replays keep drawing fresh masks
+
+    def reseed_dropout(self, seed: int) -> None:
+        self.dropout_seed = int(seed)
+        self._drop_word = None
+
+    def _d(self, site: str, attn: bool = False):
+        """(seed word, site id, p) for ops.*(drop=...) or None when dropout is off (eval mode / p = 0)."""
+        p = self.attn_drop_p if attn else self.drop_p
+        if not self.training or p <= 0.0:
+            return None
+        return (self._drop_word, self._sites[site], p)
+
     def _pos_table(self, kind: str, n: int, dev: torch.device) -> torch.Tensor:
         """rel: bf16 [2n-1, adim], row r <-> relative position n-1-r (embedding.py:180-216); abs: fp32 [n, ddim]."""
         key = (kind, n, str(dev))
@@ -237,7 +260,7 @@ def _lin(st: _ParamStore, x, name: str, rows: int, K: int, N: int, *, wkey: Opti
 
 
 def _lin_bwd(model, st: _ParamStore, name: str, x, dy, rows: int, K: int, N: int, *, tkey: Optional[str] = None, bias: bool = True,
-             need_dx: bool = True, dy_pitch: Optional[int] = None, addend=None, out=None):
+             need_dx: bool = True, dy_pitch: Optional[int] = None, addend=None, out=None, drop=None):
     """Weight / bias gradients of linear `name` into the flat gradient buffer; returns dx = dy @ W (or None)."""
     dy_pitch = dy_pitch or N
     gw = st.grad[st.offsets[f"{name}.weight"][0] :][: N * K]
@@ -247,7 +270,7 @@ def _lin_bwd(model, st: _ParamStore, name: str, x, dy, rows: int, K: int, N: int
         ops.bias_act_bwd(dy, None, gb, R=rows, N=dy_pitch, n_valid=N, ld=dy_pitch)
     if not need_dx:
         return None
-    return ops.linear_dgrad(dy, st.t16(tkey or f"{name}.weight"), rows=rows, N=N, K=K, dy_pitch=dy_pitch, addend=addend, out=out)
+    return ops.linear_dgrad(dy, st.t16(tkey or f"{name}.weight"), rows=rows, N=N, K=K, dy_pitch=dy_pitch, addend=addend, out=out, drop=drop)
 
 
 def _ln(st: _ParamStore, x, name: str):
@@ -258,19 +281,26 @@ def _ln_bwd(st: _ParamStore, dy, x, name: str, m, r, addend=None):
     return ops.add_ln_bwd(dy, x, None, st.p32(f"{name}.weight"), m, r, st.g32(f"{name}.weight"), st.g32(f"{name}.bias"), addend=addend)
 
 
-def _ffn_fwd(st, t: dict, key: str, x, p: str, R: int, D: int, U: int, alpha: float, norm: str):
+def _branch_grad(dy, alpha: float, drop):
+    """x' = x + alpha * dropout(y)  ->  dL/dy = alpha * mask/(1-p) * dL/dx'  (the mask is regenerated from its site id)."""
+    return ops.scale_bf16(dy, alpha, drop=drop) if (alpha != 1.0 or drop is not None) else dy
+
+
+def _ffn_fwd(model, st, t: dict, key: str, x, p: str, R: int, D: int, U: int, alpha: float, norm: str, site: str):
     tn, m, r = _ln(st, x, norm)
-    h = _lin(st, tn, f"{p}.w_1", R, D, U, relu=True)
-    y = _lin(st, h, f"{p}.w_2", R, U, D, addend=x, alpha=alpha)
-    t[key] = dict(x=x, tn=tn, m=m, r=r, h=h)
+    dh, do = model._d(f"{site}.hidden"), model._d(f"{site}.out")
+    h = _lin(st, tn, f"{p}.w_1", R, D, U, relu=True, drop=dh)                  # dropout(relu(w_1 x)), positionwise_feed_forward.py:30
+    y = _lin(st, h, f"{p}.w_2", R, U, D, addend=x, alpha=alpha, drop=do)       # x + ff_scale * dropout(w_2 h)
+    t[key] = dict(x=x, tn=tn, m=m, r=r, h=h, dh=dh, do=do)
     return y
 
 
 def _ffn_bwd(model, st, t: dict, dy, p: str, R: int, D: int, U: int, alpha: float, norm: str):
-    """x' = x + alpha * FFN(LN(x)); dy = grad of x' -> grad of x."""
-    dys = ops.scale_bf16(dy, alpha) if alpha != 1.0 else dy
+    """x' = x + alpha * dropout(FFN(LN(x))); dy = grad of x' -> grad of x."""
+    dys = _branch_grad(dy, alpha, t["do"])
     dh = _lin_bwd(model, st, f"{p}.w_2", t["h"], dys, R, U, D)
-    dz = ops.bias_act_bwd(dh, t["h"], st.g32(f"{p}.w_1.bias"), R=R, N=U, n_valid=U, ld=U, relu=True)
+    gs = 1.0 / (1.0 - t["dh"][2]) if t["dh"] is not None else 1.0           # dropped hidden units are the zeros of the saved h
+    dz = ops.bias_act_bwd(dh, t["h"], st.g32(f"{p}.w_1.bias"), R=R, N=U, n_valid=U, ld=U, relu=True, gscale=gs)
     dtn = _lin_bwd(model, st, f"{p}.w_1", t["tn"], dz, R, D, U, bias=False)
     return _ln_bwd(st, dtn, t["x"], norm, t["m"], t["r"], addend=dy)
 
@@ -280,15 +310,17 @@ def _encoder_layer_fwd(model: E2E, st: _ParamStore, tape: dict, i: int, x, pos16
     R = B * T
     p = f"encoder.encoders.{i}"
     t: dict[str, Any] = {}
-    x1 = _ffn_fwd(st, t, "ffm", x, f"{p}.feed_forward_macaron", R, D, U, 0.5, f"{p}.norm_ff_macaron")
+    x1 = _ffn_fwd(model, st, t, "ffm", x, f"{p}.feed_forward_macaron", R, D, U, 0.5, f"{p}.norm_ff_macaron", f"enc.{i}.ffm")
     # relative-position self-attention
     t2, m2, r2 = _ln(st, x1, f"{p}.norm_mha")
     qkv = _lin(st, t2, f"{p}.self_attn.linear_q", R, D, 3 * D)
     pe = _lin(st, pos16, f"{p}.self_attn.linear_pos", 2 * T - 1, D, D, bias=False)
     bu, bv = st.p32(f"{p}.self_attn.pos_bias_u"), st.p32(f"{p}.self_attn.pos_bias_v")
-    ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=T, Lk=T, pe=pe, bias_u=bu, bias_v=bv, klen=ilen)
-    x2 = _lin(st, ctx, f"{p}.self_attn.linear_out", R, D, D, addend=x1)
-    t["mha"] = dict(x=x1, tn=t2, m=m2, r=r2, qkv=qkv, pe=pe, ctx=ctx, probs=probs)
+    dpr, dao = model._d(f"enc.{i}.attn.probs", attn=True), model._d(f"enc.{i}.attn.out")
+    ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=T, Lk=T, pe=pe, bias_u=bu, bias_v=bv, klen=ilen,
+                             drop=dpr)
+    x2 = _lin(st, ctx, f"{p}.self_attn.linear_out", R, D, D, addend=x1, drop=dao)
+    t["mha"] = dict(x=x1, tn=t2, m=m2, r=r2, qkv=qkv, pe=pe, ctx=ctx, probs=probs, dpr=dpr, dao=dao)
     # convolution module
     t3, m3, r3 = _ln(st, x2, f"{p}.norm_conv")
     cm = f"{p}.conv_module"
@@ -298,9 +330,10 @@ def _encoder_layer_fwd(model: E2E, st: _ParamStore, tape: dict, i: int, x, pos16
                            st.bn[bn]["slots"] if training else None, B, T, D, K)
     mean, rstd = _bn_stats(st, bn, training, R)
     y = ops.bn_act_fwd(c, None, mean, rstd, st.p32(f"{bn}.weight"), st.p32(f"{bn}.bias"), ops.ACT_SWISH)
-    x3 = _lin(st, y, f"{cm}.pointwise_cov2", R, D, D, addend=x2)
-    t["conv"] = dict(x=x2, tn=t3, m=m3, r=r3, u=u, c=c, y=y, mean=mean, rstd=rstd)
-    x4 = _ffn_fwd(st, t, "ff", x3, f"{p}.feed_forward", R, D, U, 0.5, f"{p}.norm_ff")
+    dco = model._d(f"enc.{i}.conv.out")
+    x3 = _lin(st, y, f"{cm}.pointwise_cov2", R, D, D, addend=x2, drop=dco)
+    t["conv"] = dict(x=x2, tn=t3, m=m3, r=r3, u=u, c=c, y=y, mean=mean, rstd=rstd, dco=dco)
+    x4 = _ffn_fwd(model, st, t, "ff", x3, f"{p}.feed_forward", R, D, U, 0.5, f"{p}.norm_ff", f"enc.{i}.ff")
     xo, m5, r5 = _ln(st, x4, f"{p}.norm_final")
     t["final"] = dict(x=x4, m=m5, r=r5)
     tape[p] = t
@@ -318,7 +351,7 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
     # convolution module
     tc = t["conv"]
     cm, bn = f"{p}.conv_module", f"{p}.conv_module.norm"
-    dy = _lin_bwd(model, st, f"{cm}.pointwise_cov2", tc["y"], dx3, R, D, D)
+    dy = _lin_bwd(model, st, f"{cm}.pointwise_cov2", tc["y"], _branch_grad(dx3, 1.0, tc["dco"]), R, D, D)
     ws = st.bn[bn]
     dc, _ = ops.bn_act_bwd(dy, tc["y"], tc["c"], tc["mean"], tc["rstd"], st.p32(f"{bn}.weight"), ws["slots"], ws["coef"], st.g32(f"{bn}.weight"),
                            st.g32(f"{bn}.bias"), ops.ACT_SWISH, False, beta=st.p32(f"{bn}.bias"))
@@ -329,12 +362,12 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
     # attention
     tm = t["mha"]
     sa = f"{p}.self_attn"
-    dctx = _lin_bwd(model, st, f"{sa}.linear_out", tm["ctx"], dx2, R, D, D)
+    dctx = _lin_bwd(model, st, f"{sa}.linear_out", tm["ctx"], _branch_grad(dx2, 1.0, tm["dao"]), R, D, D)
     qkv = tm["qkv"]
     dqkv = torch.empty_like(qkv)
     dq_ac, dq_bd, dpe = ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, tm["probs"], B=B, H=H, Lq=T, Lk=T, dq=dqkv,
                                     dq_pitch=3 * D, dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, pe=tm["pe"],
-                                    bias_u=st.p32(f"{sa}.pos_bias_u"), bias_v=st.p32(f"{sa}.pos_bias_v"))
+                                    bias_u=st.p32(f"{sa}.pos_bias_u"), bias_v=st.p32(f"{sa}.pos_bias_v"), drop=tm["dpr"])
     ops.bias_act_bwd(dq_ac, None, st.g32(f"{sa}.pos_bias_u"), R=R, N=D, n_valid=D, ld=D)
     ops.bias_act_bwd(dq_bd, None, st.g32(f"{sa}.pos_bias_v"), R=R, N=D, n_valid=D, ld=D)
     _lin_bwd(model, st, f"{sa}.linear_pos", pos16, dpe, 2 * T - 1, D, D, bias=False, need_dx=False)
@@ -351,21 +384,27 @@ def _decoder_fwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, memory
     R = B * L
     pe = model._pos_table("abs", L, memory.device)
     x = ops.embed_pos_fwd(tg.ys_in, st.p32("decoder.embed.0.weight"), pe, L, D, math.sqrt(D))
+    dde = model._d("dec.embed")
+    if dde is not None:
+        ops.scale_bf16(x, 1.0, drop=dde, out=x)                                 # PositionalEncoding's dropout, embedding.py:89
+    tape["dec_embed_drop"] = dde
     for i in range(model.dlayers):
         p = f"decoder.decoders.{i}"
         t: dict[str, Any] = {}
         t1, m1, r1 = _ln(st, x, f"{p}.norm1")
         qkv = _lin(st, t1, f"{p}.self_attn.linear_q", R, D, 3 * D)
-        ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=L, Lk=L, causal=True)
-        x1 = _lin(st, ctx, f"{p}.self_attn.linear_out", R, D, D, addend=x)
-        t["self"] = dict(x=x, tn=t1, m=m1, r=r1, qkv=qkv, ctx=ctx, probs=probs)
+        dsp, dso = model._d(f"dec.{i}.self.probs", attn=True), model._d(f"dec.{i}.self.out")
+        ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=L, Lk=L, causal=True, drop=dsp)
+        x1 = _lin(st, ctx, f"{p}.self_attn.linear_out", R, D, D, addend=x, drop=dso)
+        t["self"] = dict(x=x, tn=t1, m=m1, r=r1, qkv=qkv, ctx=ctx, probs=probs, dpr=dsp, dao=dso)
         t2, m2, r2 = _ln(st, x1, f"{p}.norm2")
         q = _lin(st, t2, f"{p}.src_attn.linear_q", R, D, D)
         kv = _lin(st, memory, f"{p}.src_attn.linear_k", B * T, D, 2 * D)
-        ctx2, probs2 = ops.mha_fwd(q, D, kv, kv[:, D:], 2 * D, B=B, H=H, Lq=L, Lk=T, klen=ilen)
-        x2 = _lin(st, ctx2, f"{p}.src_attn.linear_out", R, D, D, addend=x1)
-        t["src"] = dict(x=x1, tn=t2, m=m2, r=r2, q=q, kv=kv, ctx=ctx2, probs=probs2)
-        x = _ffn_fwd(st, t, "ff", x2, f"{p}.feed_forward", R, D, U, 1.0, f"{p}.norm3")
+        dcp, dco = model._d(f"dec.{i}.src.probs", attn=True), model._d(f"dec.{i}.src.out")
+        ctx2, probs2 = ops.mha_fwd(q, D, kv, kv[:, D:], 2 * D, B=B, H=H, Lq=L, Lk=T, klen=ilen, drop=dcp)
+        x2 = _lin(st, ctx2, f"{p}.src_attn.linear_out", R, D, D, addend=x1, drop=dco)
+        t["src"] = dict(x=x1, tn=t2, m=m2, r=r2, q=q, kv=kv, ctx=ctx2, probs=probs2, dpr=dcp, dao=dco)
+        x = _ffn_fwd(model, st, t, "ff", x2, f"{p}.feed_forward", R, D, U, 1.0, f"{p}.norm3", f"dec.{i}.ff")
         tape[p] = t
     tn, m, r = _ln(st, x, "decoder.after_norm")
     V = model.odim
@@ -390,24 +429,24 @@ def _decoder_bwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, dpred,
         t = tape[p]
         dx2 = _ffn_bwd(model, st, t["ff"], dx, f"{p}.feed_forward", R, D, U, 1.0, f"{p}.norm3")
         ts = t["src"]
-        dctx2 = _lin_bwd(model, st, f"{p}.src_attn.linear_out", ts["ctx"], dx2, R, D, D)
+        dctx2 = _lin_bwd(model, st, f"{p}.src_attn.linear_out", ts["ctx"], _branch_grad(dx2, 1.0, ts["dao"]), R, D, D)
         dq = torch.empty_like(ts["q"])
         dkv = torch.empty_like(ts["kv"])
         ops.mha_bwd(dctx2, ts["q"], D, ts["kv"], ts["kv"][:, D:], 2 * D, ts["probs"], B=B, H=H, Lq=L, Lk=T, dq=dq, dq_pitch=D, dk=dkv,
-                    dv=dkv[:, D:], dkv_pitch=2 * D)
+                    dv=dkv[:, D:], dkv_pitch=2 * D, drop=ts["dpr"])
         _lin_bwd(model, st, f"{p}.src_attn.linear_k", memory, dkv, B * T, D, 2 * D, tkey=f"{p}.src_attn.kv", addend=dmem, out=dmem)
         dt2 = _lin_bwd(model, st, f"{p}.src_attn.linear_q", ts["tn"], dq, R, D, D)
         dx1 = _ln_bwd(st, dt2, ts["x"], f"{p}.norm2", ts["m"], ts["r"], addend=dx2)
         tsf = t["self"]
-        dctx = _lin_bwd(model, st, f"{p}.self_attn.linear_out", tsf["ctx"], dx1, R, D, D)
+        dctx = _lin_bwd(model, st, f"{p}.self_attn.linear_out", tsf["ctx"], _branch_grad(dx1, 1.0, tsf["dao"]), R, D, D)
         qkv = tsf["qkv"]
         dqkv = torch.empty_like(qkv)
         ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, tsf["probs"], B=B, H=H, Lq=L, Lk=L, dq=dqkv, dq_pitch=3 * D,
-                    dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D)
+                    dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, drop=tsf["dpr"])
         dt1 = _lin_bwd(model, st, f"{p}.self_attn.linear_q", tsf["tn"], dqkv, R, D, 3 * D, tkey=f"{p}.self_attn.qkv")
         dx = _ln_bwd(st, dt1, tsf["x"], f"{p}.norm1", tsf["m"], tsf["r"], addend=dx1)
         _ready(model, st, f"{p}.self_attn.linear_q.weight")
-    ops.embed_pos_bwd(tg.ys_in, dx, st.g32("decoder.embed.0.weight"), D, math.sqrt(D))
+    ops.embed_pos_bwd(tg.ys_in, _branch_grad(dx, 1.0, tape["dec_embed_drop"]), st.g32("decoder.embed.0.weight"), D, math.sqrt(D))
     _ready(model, st, "decoder.embed.0.weight")
 
 
@@ -426,8 +465,14 @@ class _LrsFunction(torch.autograd.Function):
         tape: dict[str, Any] = {}
         videos = x.view(B, 1, T, x.size(3), x.size(4))             # [B,T,1,H,W] and [B,1,T,H,W] are the same memory (C = 1)
         feats = _frontend_forward(model, st, tape, videos, training)          # [R, 512] bf16
-        h = _lin(st, feats, "encoder.embed.0", R, 512, D, alpha=math.sqrt(D))                  # embedding.py:208 (x * xscale)
+        if training and (model.drop_p > 0.0 or model.attn_drop_p > 0.0):
+            model._advance_dropout(x.device)
+        dex = model._d("enc.embed.x")
+        h = _lin(st, feats, "encoder.embed.0", R, 512, D, alpha=math.sqrt(D), drop=dex)        # dropout(x * xscale), embedding.py:208,217
         pos16 = model._pos_table("rel", T, x.device)
+        dpos = model._d("enc.embed.pos")
+        if dpos is not None:
+            pos16 = ops.scale_bf16(pos16, 1.0, drop=dpos)                                      # dropout(pos_emb), embedding.py:217
         for i in range(model.elayers):
             h = _encoder_layer_fwd(model, st, tape, i, h, pos16, ilen, B, T, training)
         hx = h
@@ -440,7 +485,9 @@ class _LrsFunction(torch.autograd.Function):
         # CTC head (ctc.py:83-151)
         Vo = model.odim
         Vp = (Vo + 63) // 64 * 64
-        logits_c = ops.linear_fwd(h, st.s16("ctc.ctc_lo.weight"), st.p32("ctc.ctc_lo.bias"), rows=R, K=D, N=Vo, x_pitch=D, out_f32=True,
+        dctc = model._d("ctc.in")
+        h_ctc = ops.scale_bf16(h, 1.0, drop=dctc) if dctc is not None else h                   # ctc_lo(dropout(hs_pad)), ctc.py:97
+        logits_c = ops.linear_fwd(h_ctc, st.s16("ctc.ctc_lo.weight"), st.p32("ctc.ctc_lo.bias"), rows=R, K=D, N=Vo, x_pitch=D, out_f32=True,
                                   out_pitch=Vp)[0]
         loss_c, ctc_state = ops.ctc_fwd(logits_c, Vp, tg.labels, ilen, B, T, Vo)
         # attention decoder + label smoothing (decoder.py:122-151, label_smoothing_loss.py:41-63)
@@ -454,7 +501,8 @@ class _LrsFunction(torch.autograd.Function):
         model._last = dict(feats=feats, enc_out=h, pred=pred, logits_audio=logits_a, logits_ctc=logits_c)
         if need_grad:
             tape["head"] = dict(hx=hx, h=h, mA=mA, rA=rA, logits_a=logits_a, lse_a=lse_a, tok=tok, logits_c=logits_c, ctc_state=ctc_state,
-                                pred=pred, lse_p=lse_p, tgt=tgt, inv_denom=inv_denom, dims=(B, T, L, Vp), pos16=pos16, ilen=ilen, feats=feats)
+                                pred=pred, lse_p=lse_p, tgt=tgt, inv_denom=inv_denom, dims=(B, T, L, Vp), pos16=pos16, ilen=ilen, feats=feats,
+                                h_ctc=h_ctc, dctc=dctc, dex=dex)
             ctx.tape, ctx.model, ctx.st, ctx.tg = tape, model, st, tg
         ctx.mark_non_differentiable(counts)
         return loss_c, loss_att, loss_a, counts
@@ -483,7 +531,7 @@ class _LrsFunction(torch.autograd.Function):
         _decoder_bwd(model, st, tape, tg, dpred, h, dh, B, T)
         # CTC and audio heads
         dlc = ops.ctc_grad(th["logits_c"], Vp, tg.labels, th["ilen"], B, T, Vo, th["ctc_state"], g_ctc, Vp)
-        _lin_bwd(model, st, "ctc.ctc_lo", h, dlc, R, D, Vo, dy_pitch=Vp, addend=dh, out=dh)
+        _lin_bwd(model, st, "ctc.ctc_lo", th["h_ctc"], dlc, R, D, Vo, dy_pitch=Vp, addend=dh, out=dh, drop=th["dctc"])   # dh += mask/(1-p) * (dlc W)
         NA = A * G * V
         dla = torch.empty((R, NA), dtype=BF16, device=dev)
         ops.ce_bwd(th["logits_a"], V, th["tok"], None, R * A * G, V, 0.0, th["lse_a"], g_audio, dla, V)
@@ -492,7 +540,7 @@ class _LrsFunction(torch.autograd.Function):
         dx = _ln_bwd(st, dh, th["hx"], "encoder.after_norm", th["mA"], th["rA"])
         for i in reversed(range(model.elayers)):
             dx = _encoder_layer_bwd(model, st, tape, i, dx, th["pos16"], B, T)
-        dfeats = _lin_bwd(model, st, "encoder.embed.0", th["feats"], ops.scale_bf16(dx, math.sqrt(D)), R, 512, D)
+        dfeats = _lin_bwd(model, st, "encoder.embed.0", th["feats"], _branch_grad(dx, math.sqrt(D), th["dex"]), R, 512, D)
         _ready(model, st, "encoder.embed.0.weight")
         _frontend_backward(model, st, tape, dfeats)
         ctx.tape = None

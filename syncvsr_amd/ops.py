@@ -27,6 +27,13 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _drop(drop) -> tuple:
+    """drop = None | (seed tensor [1] int32/uint32 on the device, site id, p) -> the three C arguments."""
+    if drop is None or drop[2] <= 0.0:
+        return None, 0, 0.0
+    return drop[0].data_ptr(), int(drop[1]), float(drop[2])
+
+
 def _ints(v: Sequence[int]):
     return (ctypes.c_int * len(v))(*v)
 
@@ -93,13 +100,13 @@ def igemm_fwd(inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: i
               Co: int, Ho: int, Wo: int, out_pitch: int, Ha: int, Wa: int, S: int = 1, OS: int = 1, oy0: int = 0, ox0: int = 0,
               taps: Sequence[tuple[int, int, int]] = ((0, 0, 0),), wt_taps: int = 1, bias: Optional[torch.Tensor] = None,
               addend: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, gelu: bool = False,
-              out_pre: Optional[torch.Tensor] = None, out_f32: bool = False, relu: bool = False, alpha: float = 1.0) -> None:
+              out_pre: Optional[torch.Tensor] = None, out_f32: bool = False, relu: bool = False, alpha: float = 1.0, drop=None) -> None:
     dy, dx, tw = zip(*taps)
     M = Nimg * Ha * Wa
     bm, bn, ns = igemm_fwd_tile(M, Co)
     _call("svsr_igemm_fwd", _p(inp), _p(wt), _p(out), _p(out_pre), _p(bias), _p(addend), _p(stats), Nimg, Hi, Wi, Ci, in_pitch,
           Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw),
-          1 if gelu else (2 if relu else 0), int(out_f32), float(alpha), _stream(), label=f"k_igemm_fwd_glds<{bm},{bn},{ns}>", flops=2.0 * M * Co * Ci * len(taps))
+          1 if gelu else (2 if relu else 0), int(out_f32), float(alpha), *_drop(drop), _stream(), label=f"k_igemm_fwd_glds<{bm},{bn},{ns}>", flops=2.0 * M * Co * Ci * len(taps))
 
 
 def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
@@ -206,8 +213,9 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: int, st
 def linear_fwd(x: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor], *, rows: int, K: int, N: int, x_pitch: int,
                out: Optional[torch.Tensor] = None, out_pitch: Optional[int] = None, gelu: bool = False,
                out_f32: bool = False, addend: Optional[torch.Tensor] = None,
-               seq: Optional[tuple[int, int, int]] = None, relu: bool = False, alpha: float = 1.0) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """out[rows, N] = act(alpha * (x[rows, K] @ w16[N, K]^T + bias) + addend), act = gelu | relu | none.  `seq=(S, s0, n)` selects rows s0..s0+n-1 of every
+               seq: Optional[tuple[int, int, int]] = None, relu: bool = False, alpha: float = 1.0,
+               drop=None) -> tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """out[rows, N] = alpha * dropout(act(x[rows, K] @ w16[N, K]^T + bias)) + addend, act = gelu | relu | none.  `seq=(S, s0, n)` selects rows s0..s0+n-1 of every
     length-S sequence of x (x is [B*S, K]) as the source and writes a dense [B*n, N] result."""
     out_pitch = out_pitch or N
     if out is None:
@@ -219,12 +227,13 @@ def linear_fwd(x: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor],
         S, s0, n = seq
         geo = dict(Nimg=rows // n, Hi=1, Wi=S, Ha=1, Wa=n, Ho=1, Wo=n, taps=((0, s0, 0),))
     igemm_fwd(x, w16, out, Ci=K, in_pitch=x_pitch, Co=N, out_pitch=out_pitch, bias=bias, addend=addend, gelu=gelu, out_pre=pre,
-              out_f32=out_f32, relu=relu, alpha=alpha, **geo)
+              out_f32=out_f32, relu=relu, alpha=alpha, drop=drop, **geo)
     return out, pre
 
 
 def linear_dgrad(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, K: int, dy_pitch: int, out: Optional[torch.Tensor] = None,
-                 addend: Optional[torch.Tensor] = None, seq: Optional[tuple[int, int, int]] = None, alpha: float = 1.0) -> torch.Tensor:
+                 addend: Optional[torch.Tensor] = None, seq: Optional[tuple[int, int, int]] = None, alpha: float = 1.0,
+                 drop=None) -> torch.Tensor:
     """dx[rows, K] = dy[rows, N] @ w16t[K, Npad]^T-of-transpose, i.e. dy @ W.  With `seq=(S, s0, n)` the dense dy rows
     [B*n] are scattered to rows s0.. of every length-S sequence of dx [B*S, K]."""
     Np = w16t.shape[-1]
@@ -236,7 +245,7 @@ def linear_dgrad(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, K: 
         S, s0, n = seq
         assert out is not None
         geo = dict(Nimg=rows // n, Hi=1, Wi=n, Ha=1, Wa=n, Ho=1, Wo=S, ox0=s0)
-    igemm_fwd(dy, w16t, out, Ci=Np, in_pitch=dy_pitch, Co=K, out_pitch=K, addend=addend, alpha=alpha, **geo)
+    igemm_fwd(dy, w16t, out, Ci=Np, in_pitch=dy_pitch, Co=K, out_pitch=K, addend=addend, alpha=alpha, drop=drop, **geo)
     return out
 
 
@@ -381,11 +390,11 @@ def attn_bwd(dctx, qkv, probs, B: int, S: int, H: int, dh: int) -> torch.Tensor:
     return dqkv
 
 
-def bias_act_bwd(dy, z, db, *, R: int, N: int, n_valid: int, ld: int, relu: bool = False) -> torch.Tensor:
+def bias_act_bwd(dy, z, db, *, R: int, N: int, n_valid: int, ld: int, relu: bool = False, gscale: float = 1.0) -> torch.Tensor:
     """db[:n_valid] += column sums of dz, where dz = dy * act'(z) if z is given (returned) else dy; act = GELU from the
     pre-activation z, or (relu=True) ReLU from the saved output z."""
     dz = torch.empty_like(dy) if z is not None else None
-    _call("svsr_bias_act_bwd", _p(dy), _p(z), _p(dz), _p(db), R, N, n_valid, ld, 2 if relu else 1, _stream())
+    _call("svsr_bias_act_bwd", _p(dy), _p(z), _p(dz), _p(db), R, N, n_valid, ld, 2 if relu else 1, float(gscale), _stream())
     return dz if z is not None else dy
 
 
@@ -441,19 +450,19 @@ def probs_pitch(Lk: int) -> int:
 
 
 def mha_fwd(q, q_pitch: int, k, v, kv_pitch: int, *, B: int, H: int, Lq: int, Lk: int, pe=None, bias_u=None, bias_v=None, klen=None,
-            causal: bool = False):
+            causal: bool = False, drop=None):
     """-> (ctx [B*Lq, H*64] bf16, probs [B*H, Lq, ldp] bf16).  q/k/v are views into (fused) projection outputs."""
     ldp = probs_pitch(Lk)
     ctx = torch.empty((B * Lq, H * 64), dtype=BF16, device=q.device)
     probs = torch.empty((B * H, Lq, ldp), dtype=BF16, device=q.device)
     _call("svsr_mha_fwd", _p(q), q_pitch, _p(k), _p(v), kv_pitch, _p(pe), 0 if pe is None else pe.stride(0), _p(bias_u), _p(bias_v),
-          _p(klen), int(causal), B, H, 64, Lq, Lk, ldp, 0.125, _p(ctx), H * 64, _p(probs), _stream(),
+          _p(klen), int(causal), B, H, 64, Lq, Lk, ldp, 0.125, _p(ctx), H * 64, _p(probs), *_drop(drop), _stream(),
           label="k_mha_fwd", flops=2.0 * B * H * Lq * Lk * 64 * (3 if pe is not None else 2))
     return ctx, probs
 
 
 def mha_bwd(dctx, q, q_pitch: int, k, v, kv_pitch: int, probs, *, B: int, H: int, Lq: int, Lk: int, dq, dq_pitch: int, dk, dv,
-            dkv_pitch: int, pe=None, bias_u=None, bias_v=None):
+            dkv_pitch: int, pe=None, bias_u=None, bias_v=None, drop=None):
     """Writes dq/dk/dv (views with the given pitches).  Relative-position form returns (dq_ac, dq_bd, dpe) as well."""
     ldp = probs.shape[-1]
     ds = torch.empty_like(probs)
@@ -465,7 +474,7 @@ def mha_bwd(dctx, q, q_pitch: int, k, v, kv_pitch: int, probs, *, B: int, H: int
     pe_part = torch.empty((B, 2 * Lq - 1, D), dtype=torch.float32, device=q.device) if rel else None
     _call("svsr_mha_bwd", _p(dctx), dctx.stride(0), _p(q), q_pitch, _p(k), _p(v), kv_pitch, _p(pe), 0 if pe is None else pe.stride(0),
           _p(bias_u), _p(bias_v), _p(probs), _p(ds), B, H, 64, Lq, Lk, ldp, 0.125, _p(dq), dq_pitch, _p(dq_ac), _p(dq_bd), D,
-          _p(dk), _p(dv), dkv_pitch, _p(dpe), D, _p(pe_part), _stream(), label="k_mha_bwd", flops=2.0 * B * H * Lq * Lk * 64 * (7 if rel else 4))
+          _p(dk), _p(dv), dkv_pitch, _p(dpe), D, _p(pe_part), *_drop(drop), _stream(), label="k_mha_bwd", flops=2.0 * B * H * Lq * Lk * 64 * (7 if rel else 4))
     return dq_ac, dq_bd, dpe
 
 
@@ -531,7 +540,8 @@ def ls_loss_bwd(logits, ld: int, target, R: int, V: int, smoothing: float, inv_d
     return dz
 
 
-def scale_bf16(x: torch.Tensor, alpha: float) -> torch.Tensor:
-    y = torch.empty_like(x)
-    _call("svsr_scale_bf16", _p(x), _p(y), x.numel(), float(alpha), _stream())
+def scale_bf16(x: torch.Tensor, alpha: float, drop=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = alpha * dropout(x) (x contiguous; the dropout element index is the position in x)."""
+    y = torch.empty_like(x) if out is None else out
+    _call("svsr_scale_bf16", _p(x), _p(y), x.numel(), float(alpha), *_drop(drop), _stream())
     return y

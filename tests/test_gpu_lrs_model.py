@@ -112,6 +112,51 @@ def test_lrs_state_dict_names_and_unsupported(dev):
     m = E2E(odim, args)
     assert set(m.state_dict().keys()) == set(sd.keys())
     with pytest.raises(NotImplementedError):
-        E2E(odim, default_lrs_args(dropout_rate=0.1))
+        E2E(odim, default_lrs_args(macaron_style=False))
     with pytest.raises(RuntimeError):
         m(batch[0], batch[1], batch[2], batch[3])          # CPU tensors: no fallback
+
+
+def test_lrs_dropout_matches_oracle_with_shared_masks(dev):
+    """Training forward/backward with dropout 0.1 / attention dropout 0.15: the oracle replays the library's counter-based
+    masks (oracle.lrs_oracle.DropPlan), so losses and gradients must agree as tightly as without dropout; and the masks
+    must have the right keep rate and change from step to step."""
+    from oracle import lrs_oracle as O
+    from syncvsr_amd.dropout import keep_mask, lrs_sites
+    from syncvsr_amd.lrs_model import E2E
+
+    args, odim, sd, batch, training, gold = build_lrs_case("lrs_tiny_b3")
+    args = args.copy()
+    args.dropout_rate, args.transformer_attn_dropout_rate = 0.1, 0.15
+    x, lengths, tokens, label = batch
+    model = E2E(odim, args)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).train()
+    model.reseed_dropout(41)
+    out = model(x.to(dev), lengths.to(dev), tokens.to(dev), label.to(dev))
+    out[0].backward()
+    torch.cuda.synchronize()
+    assert int(model._drop_word.item()) == 42
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    dp = O.DropPlan(42, 0.1, 0.15, lrs_sites(int(args.elayers), int(args.dlayers)))
+    keep = {}
+    ref = O.forward(osd, args, x, lengths, tokens, label, training=True, keep=keep, dp=dp)
+    ref["loss"].backward()
+    nodrop = O.forward(sd, args, x, lengths, tokens, label, training=True)
+    for i, k in enumerate(("loss", "loss_ctc", "loss_att", "loss_audio")):
+        assert abs(out[i].item() - ref[k].item()) <= 1e-2 * abs(ref[k].item()), (k, out[i].item(), ref[k].item())
+    assert abs(ref["loss"].item() - nodrop["loss"].item()) > 1e-3 * abs(nodrop["loss"].item()), "dropout had no effect on the oracle"
+    assert _rel(model._last["enc_out"], keep["enc_out"]) <= 5e-2
+    coss = []
+    for n, p in model.named_parameters():
+        g, r = p.grad.detach().float().cpu().flatten(), osd[n].grad.flatten()
+        if r.norm() > 1e-6:
+            coss.append((float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)), n))
+    coss.sort()
+    print("worst cosines with dropout:", coss[:5])
+    assert coss[len(coss) // 2][0] >= 0.97 and coss[0][0] >= 0.8, coss[:5]
+    # second step draws different masks; eval mode draws none
+    out2 = model(x.to(dev), lengths.to(dev), tokens.to(dev), label.to(dev))
+    assert int(model._drop_word.item()) == 43 and abs(out2[0].item() - out[0].item()) > 1e-4
+    m = keep_mask(42, 7, 0.1, 200000)
+    assert abs(m.mean() - 0.9) < 3e-3

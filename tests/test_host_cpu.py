@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name, args in decls.items():
         assert hasattr(lib, name), f"{name} is declared in include/syncvsr_hip.h but not exported"
         for ctype, argname in args:
-            assert "*" in ctype or ctype.replace("const", "").strip() in ("int", "float", "int64_t", "hipStream_t"), (name, ctype)
+            assert "*" in ctype or ctype.replace("const", "").strip() in ("int", "float", "int64_t", "unsigned", "hipStream_t"), (name, ctype)
     handle = _lib.load()
     assert handle.svsr_igemm_fwd.argtypes is not None and len(handle.svsr_igemm_fwd.argtypes) == len(decls["svsr_igemm_fwd"])
 
