@@ -382,7 +382,10 @@ int svsr_add_ln_fwd(const void* a, const void* r, const float* gamma, const floa
 int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd,
                     void* ds, float* dgamma, float* dbeta, int R, int D, const void* addend, hipStream_t stream) {
     if (D % 8 != 0 || D > 512 * LN_MAXV) return SVSR_ERR_ARG;
-    int grid = (R + 15) / 16; if (grid > 512) grid = 512;       // ~4 rows per wave so the dgamma/dbeta atomics stay few
+    // every workgroup ends with 2*D fp32 atomics (dgamma/dbeta); measured flat between 4 and 16 rows per workgroup at
+    // 2,400 x 768, slower at 64 (too few workgroups) — 16 keeps the atomics few
+    static const int rpb = [] { const char* e = getenv("SVSR_LN_RPB"); return e ? atoi(e) : 16; }();
+    int grid = (R + rpb - 1) / rpb; if (grid > 512) grid = 512;
     hipLaunchKernelGGL(k_add_ln_bwd, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), stream, (const bf16_t*)dy, (const bf16_t*)a, (const bf16_t*)r, gamma,
                        mean, rstd, (bf16_t*)ds, dgamma, dbeta, R, D, (const bf16_t*)addend);
     return svsr_check_launch();

@@ -177,3 +177,49 @@ def test_grad_reducer_two_process_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
+
+
+# ---------------------------------------------------------------------------------------------------------
+# LRS host logic (no GPU): state-dict names, target preparation, dropout twin, unsupported configs, layout
+# ---------------------------------------------------------------------------------------------------------
+def test_lrs_host_logic():
+    import numpy as np
+    import torch
+
+    from golden_cases import build_lrs_case
+    from oracle import lrs_oracle as O
+    from syncvsr_amd.dropout import keep_mask, lrs_sites
+    from syncvsr_amd.lrs_init import default_lrs_args, lrs_param_specs
+    from syncvsr_amd.lrs_model import E2E
+
+    args, odim, sd, batch, training, gold = build_lrs_case("lrs_tiny_b3")
+    m = E2E(odim, args)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    # decay split follows the reference (p.ndim >= 2, LRS/video/lightning.py:89-96)
+    groups = m.configure_optimizers()
+    assert all(p.ndim >= 2 for p in groups[0]["params"]) and all(p.ndim < 2 for p in groups[1]["params"])
+    assert groups[1]["weight_decay"] == 0.0
+    # targets: same tensors as the reference's add_sos_eos (restated in the oracle)
+    label = batch[3]
+    tg = m.prepare_targets(label)
+    ys = [y[y != -1] for y in label.view(label.size(0), -1)]
+    ys_in, ys_out = O.add_sos_eos(ys, odim - 1, odim - 1)
+    assert torch.equal(tg.ys_in, ys_in) and torch.equal(tg.ys_out, ys_out)
+    assert torch.equal(tg.labels, label.view(label.size(0), -1))
+    # CPU tensors are refused (no fallback); unsupported configurations raise
+    with pytest.raises(RuntimeError):
+        m(*batch)
+    for bad in (dict(macaron_style=False), dict(adim=128, aheads=2, ddim=256, dheads=4), dict(cnn_module_kernel=33), dict(mtlalpha=1.0),
+                dict(transformer_input_layer="conv1d")):
+        with pytest.raises(NotImplementedError):
+            E2E(odim, default_lrs_args(**bad))
+    # the shipped config: 250.38 M parameters + the 1.97 M audio_classifier
+    n = sum(int(np.prod(s)) for _, s, _ in lrs_param_specs(default_lrs_args(), 5049))
+    assert abs(n - 252.35e6) < 0.05e6, n
+    # dropout twin: keep rate, determinism, site separation
+    sites = lrs_sites(12, 6)
+    assert len(set(sites.values())) == len(sites) == 4 + 12 * 7 + 6 * 6
+    a, b = keep_mask(5, sites["enc.0.ff.out"], 0.1, 100000), keep_mask(5, sites["enc.0.ff.out"], 0.1, 100000)
+    c = keep_mask(5, sites["enc.1.ff.out"], 0.1, 100000)
+    assert (a == b).all() and abs(a.mean() - 0.9) < 5e-3 and abs((a == c).mean() - 0.82) < 1e-2
