@@ -50,8 +50,9 @@ extern "C" {
 int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int act, int out_f32, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 
 /* svsr_igemm_wgrad replaces: the weight-gradient of the same Conv2d / Linear layers (torch autograd).
- * dw fp32 [Co][wt_taps][Ci] is ACCUMULATED (atomics).  x = forward input pixels, dyp = output-gradient pixels. */
-int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int use_tr, hipStream_t stream);
+ * dw fp32 [Co][wt_taps][Ci] is ACCUMULATED (atomics).  x = forward input pixels, dyp = output-gradient pixels.
+ * dbias (optional, fp32 [Co]) += column sums of dyp = the bias gradient of an nn.Linear, taken from tiles the kernel stages anyway. */
+int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int use_tr, float* dbias, hipStream_t stream);
 
 /* svsr_conv3x3_c64: conv3x3(64, 64), stride 1, pad 1 (layer1 of the trunk, resnet.py:8-10,36,53) forward and, with the
  * transposed weights and mirrored taps, its input-gradient; persistent workgroups, weights resident in LDS

@@ -17,6 +17,8 @@ struct IgemmWgradArgs {
     const bf16_t* x;       // source pixels (pitch in_pitch)
     const bf16_t* dy;      // target pixels (pitch out_pitch)
     float* dw;             // [Co][wt_taps][Ci] fp32, accumulated
+    float* db;             // optional [Co] fp32: += column sums of dY (the bias gradient of an nn.Linear), taken from the dY tiles
+                           // the ci-tile-0 / tap-0 workgroups stage anyway
     int chunks_per_block;  // 64-position chunks each block reduces
 };
 
@@ -107,6 +109,12 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad(const IgemmWgradArgs p) {
             }
         }
     };
+    const bool do_bias = p.db != nullptr && cit == 0 && t == 0;
+    float bsum[NL][8];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bsum[l][k] = 0.f;
     auto store_chunk = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -115,6 +123,12 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad(const IgemmWgradArgs p) {
                 const bool oky = (ld_ok >> (i * NL + l)) & 1u, okx = (ld_ok >> (8 + i * NL + l)) & 1u;
                 u32x4 y = vy[i][l], x = vx[i][l];
                 y.x = oky ? y.x : 0u; y.y = oky ? y.y : 0u; y.z = oky ? y.z : 0u; y.w = oky ? y.w : 0u;
+                if (do_bias) {
+                    float f[8];
+                    unpack8(y, f);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) bsum[l][k] += f[k];
+                }
                 x.x = okx ? x.x : 0u; x.y = okx ? x.y : 0u; x.z = okx ? x.z : 0u; x.w = okx ? x.w : 0u;
                 *reinterpret_cast<u32x4*>(sY + (r0 + 32 * i) * PITCH + (chunk + 8 * l) * 8) = y;
                 *reinterpret_cast<u32x4*>(sX + (r0 + 32 * i) * PITCH + (chunk + 8 * l) * 8) = x;
@@ -140,6 +154,23 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad(const IgemmWgradArgs p) {
                 for (int j = 0; j < TT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+    }
+    if (do_bias) {          // threads with the same `chunk` (tid & 7) hold the same channels: reduce over r0 through LDS
+        __syncthreads();
+        float* sred = reinterpret_cast<float*>(sm);          // [256][8*NL] floats <= the tile buffers
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sred[tid * (8 * NL) + l * 8 + k] = bsum[l][k];
+        __syncthreads();
+        if (tid < BC) {
+            const int grp = tid >> 3, k = tid & 7;            // channel tid of the tile = 16-byte group grp, element k
+            const int chk = grp & 7, l = grp >> 3;
+            float s = 0.f;
+            for (int r = 0; r < 32; ++r) s += sred[(r * 8 + chk) * (8 * NL) + l * 8 + k];
+            if (co0 + tid < g.Co) atomicAdd(p.db + co0 + tid, s);
+        }
+        __syncthreads();
     }
     // D[row = co][col = ci]
 #pragma unroll
@@ -178,12 +209,12 @@ static int launch_wgrad(IgemmWgradArgs& a, hipStream_t stream) {
 
 extern "C" int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co,
                                 int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps,
-                                const int* dy, const int* dx, const int* tw, int use_tr, hipStream_t stream) {
+                                const int* dy, const int* dx, const int* tw, int use_tr, float* dbias, hipStream_t stream) {
     IgemmWgradArgs a;
     int rc = fill_geom(a.g, Nimg, Hi, Wi, Ci, in_pitch, Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, ntaps, wt_taps, dy, dx, tw);
     if (rc != SVSR_OK) return rc;
     if (out_pitch % 8 != 0) return SVSR_ERR_ARG;
-    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dyp; a.dw = dw;
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dyp; a.dw = dw; a.db = dbias;
     const int tasks128 = ((Co + 127) / 128) * ((Ci + 127) / 128) * ntaps;
     const bool big = Co >= 128 && Ci >= 128 && tasks128 >= 36;
     if (use_tr) return big ? launch_wgrad<true, 128>(a, stream) : launch_wgrad<true, 64>(a, stream);

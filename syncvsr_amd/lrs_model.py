@@ -264,10 +264,8 @@ def _lin_bwd(model, st: _ParamStore, name: str, x, dy, rows: int, K: int, N: int
     """Weight / bias gradients of linear `name` into the flat gradient buffer; returns dx = dy @ W (or None)."""
     dy_pitch = dy_pitch or N
     gw = st.grad[st.offsets[f"{name}.weight"][0] :][: N * K]
-    ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=dy_pitch, use_tr=model.use_tr)
-    if bias:
-        gb = st.grad[st.offsets[f"{name}.bias"][0] :][:N]
-        ops.bias_act_bwd(dy, None, gb, R=rows, N=dy_pitch, n_valid=N, ld=dy_pitch)
+    gb = st.grad[st.offsets[f"{name}.bias"][0] :][:N] if bias else None          # column sums of dy, fused into the wgrad launch
+    ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=dy_pitch, use_tr=model.use_tr, db=gb)
     if not need_dx:
         return None
     return ops.linear_dgrad(dy, st.t16(tkey or f"{name}.weight"), rows=rows, N=N, K=K, dy_pitch=dy_pitch, addend=addend, out=out, drop=drop)

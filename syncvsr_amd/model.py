@@ -491,22 +491,21 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
         t = tape[p]
         ds2 = ops.add_ln_bwd(dx, t["f"], t["x1"], st.p32(f"{p}.output.LayerNorm.weight"), t["m2"], t["r2"],
                              st.g32(f"{p}.output.LayerNorm.weight"), st.g32(f"{p}.output.LayerNorm.bias"))
-        ops.linear_wgrad(t["hg"], ds2, st.g32(f"{p}.output.dense.weight"), rows=R, K=I, N=D, x_pitch=I, dy_pitch=D, use_tr=use_tr)
-        ops.bias_act_bwd(ds2, None, st.g32(f"{p}.output.dense.bias"), R=R, N=D, n_valid=D, ld=D)
+        ops.linear_wgrad(t["hg"], ds2, st.g32(f"{p}.output.dense.weight"), rows=R, K=I, N=D, x_pitch=I, dy_pitch=D, use_tr=use_tr,
+                         db=st.g32(f"{p}.output.dense.bias"))
         dhg = ops.linear_dgrad(ds2, st.t16(f"{p}.output.dense.weight"), rows=R, N=D, K=I, dy_pitch=D)
         dz = ops.bias_act_bwd(dhg, t["z"], st.g32(f"{p}.intermediate.dense.bias"), R=R, N=I, n_valid=I, ld=I)
         ops.linear_wgrad(t["x1"], dz, st.g32(f"{p}.intermediate.dense.weight"), rows=R, K=D, N=I, x_pitch=D, dy_pitch=I, use_tr=use_tr)
         dx1 = ops.linear_dgrad(dz, st.t16(f"{p}.intermediate.dense.weight"), rows=R, N=I, K=D, dy_pitch=I, addend=ds2, out=ds2)
         ds1 = ops.add_ln_bwd(dx1, t["ao"], t["x"], st.p32(f"{p}.attention.output.LayerNorm.weight"), t["m1"], t["r1"],
                              st.g32(f"{p}.attention.output.LayerNorm.weight"), st.g32(f"{p}.attention.output.LayerNorm.bias"))
-        ops.linear_wgrad(t["ctx"], ds1, st.g32(f"{p}.attention.output.dense.weight"), rows=R, K=D, N=D, x_pitch=D, dy_pitch=D, use_tr=use_tr)
-        ops.bias_act_bwd(ds1, None, st.g32(f"{p}.attention.output.dense.bias"), R=R, N=D, n_valid=D, ld=D)
+        ops.linear_wgrad(t["ctx"], ds1, st.g32(f"{p}.attention.output.dense.weight"), rows=R, K=D, N=D, x_pitch=D, dy_pitch=D, use_tr=use_tr,
+                         db=st.g32(f"{p}.attention.output.dense.bias"))
         dctx = ops.linear_dgrad(ds1, st.t16(f"{p}.attention.output.dense.weight"), rows=R, N=D, K=D, dy_pitch=D)
         dqkv = ops.attn_bwd(dctx, t["qkv"], t["probs"], B, S, H, D // H)
         gq = st.grad[st.offsets[f"{p}.attention.self.query.weight"][0] :][: 3 * D * D]
         gqb = st.grad[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
-        ops.linear_wgrad(t["x"], dqkv, gq, rows=R, K=D, N=3 * D, x_pitch=D, dy_pitch=3 * D, use_tr=use_tr)
-        ops.bias_act_bwd(dqkv, None, gqb, R=R, N=3 * D, n_valid=3 * D, ld=3 * D)
+        ops.linear_wgrad(t["x"], dqkv, gq, rows=R, K=D, N=3 * D, x_pitch=D, dy_pitch=3 * D, use_tr=use_tr, db=gqb)
         dx = ops.linear_dgrad(dqkv, st.t16(f"{p}.qkv"), rows=R, N=3 * D, K=D, dy_pitch=3 * D, addend=ds1, out=ds1)
         _ready(model, st, f"{p}.attention.self.query.weight")
     te = tape["emb"]
@@ -577,10 +576,10 @@ class _LrwFunction(torch.autograd.Function):
         dlc = torch.zeros((B, Cp), dtype=BF16, device=dev)
         ops.ce_bwd(th["logits_c"], C, th["lab_idx"], th["lab_prob"], B, C, model.label_smoothing, th["lse_c"], g_cat, dlc, Cp)
         h = th["h"]
-        ops.linear_wgrad(h, dla, st.g32("audio_projection.weight"), rows=B * T, K=D, N=NA, x_pitch=D, dy_pitch=NA, seq=(S, 1, T), use_tr=use_tr)
-        ops.bias_act_bwd(dla, None, st.g32("audio_projection.bias"), R=B * T, N=NA, n_valid=NA, ld=NA)
-        ops.linear_wgrad(h, dlc, st.g32("category_classifier.weight"), rows=B, K=D, N=C, x_pitch=D, dy_pitch=Cp, seq=(S, 0, 1), use_tr=use_tr)
-        ops.bias_act_bwd(dlc, None, st.g32("category_classifier.bias"), R=B, N=Cp, n_valid=C, ld=Cp)
+        ops.linear_wgrad(h, dla, st.g32("audio_projection.weight"), rows=B * T, K=D, N=NA, x_pitch=D, dy_pitch=NA, seq=(S, 1, T), use_tr=use_tr,
+                         db=st.g32("audio_projection.bias"))
+        ops.linear_wgrad(h, dlc, st.g32("category_classifier.weight"), rows=B, K=D, N=C, x_pitch=D, dy_pitch=Cp, seq=(S, 0, 1), use_tr=use_tr,
+                         db=st.g32("category_classifier.bias"))
         dh = torch.empty((B * S, D), dtype=BF16, device=dev)
         ops.linear_dgrad(dla, st.t16("audio_projection.weight"), rows=B * T, N=NA, K=D, dy_pitch=NA, out=dh, seq=(S, 1, T))
         ops.linear_dgrad(dlc, st.t16("category_classifier.weight"), rows=B, N=C, K=D, dy_pitch=Cp, out=dh, seq=(S, 0, 1))

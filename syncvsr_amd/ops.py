@@ -111,10 +111,11 @@ def igemm_fwd(inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: i
 
 def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
                 Co: int, Ho: int, Wo: int, out_pitch: int, Ha: int, Wa: int, S: int = 1, OS: int = 1, oy0: int = 0, ox0: int = 0,
-                taps: Sequence[tuple[int, int, int]] = ((0, 0, 0),), wt_taps: int = 1, use_tr: bool = True) -> None:
+                taps: Sequence[tuple[int, int, int]] = ((0, 0, 0),), wt_taps: int = 1, use_tr: bool = True,
+                db: Optional[torch.Tensor] = None) -> None:
     dy, dx, tw = zip(*taps)
     _call("svsr_igemm_wgrad", _p(x), _p(dyp), _p(dw), Nimg, Hi, Wi, Ci, in_pitch, Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0,
-          len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw), int(use_tr), _stream(),
+          len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw), int(use_tr), _p(db), _stream(),
           label=f"k_igemm_wgrad<{'true' if use_tr else 'false'},{wgrad_tile(Co, Ci, len(taps))}>",
           flops=2.0 * Nimg * Ha * Wa * Co * Ci * len(taps))
 
@@ -250,14 +251,14 @@ def linear_dgrad(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, K: 
 
 
 def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, rows: int, K: int, N: int, x_pitch: int, dy_pitch: int,
-                 seq: Optional[tuple[int, int, int]] = None, use_tr: bool = True) -> None:
-    """dw fp32 [N][K] += dy[rows, N]^T @ x[rows, K]."""
+                 seq: Optional[tuple[int, int, int]] = None, use_tr: bool = True, db: Optional[torch.Tensor] = None) -> None:
+    """dw fp32 [N][K] += dy[rows, N]^T @ x[rows, K];  db fp32 [N] += column sums of dy (bias gradient), if given."""
     if seq is None:
         geo = dict(Nimg=rows, Hi=1, Wi=1, Ha=1, Wa=1, Ho=1, Wo=1, taps=((0, 0, 0),))
     else:
         S, s0, n = seq
         geo = dict(Nimg=rows // n, Hi=1, Wi=S, Ha=1, Wa=n, Ho=1, Wo=n, taps=((0, s0, 0),))
-    igemm_wgrad(x, dy, dw, Ci=K, in_pitch=x_pitch, Co=N, out_pitch=dy_pitch, use_tr=use_tr, **geo)
+    igemm_wgrad(x, dy, dw, Ci=K, in_pitch=x_pitch, Co=N, out_pitch=dy_pitch, use_tr=use_tr, db=db, **geo)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -272,3 +272,19 @@ def test_bn_swish(C, res):
     if res:
         assert _rel_err(dres.float().cpu().view(N, C), rf.grad) < 6e-3
     assert float(slots.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("R,K,N,pitch", [(960, 512, 1536, 1536), (2400, 768, 5049, 5056), (70, 768, 256, 256), (32, 512, 500, 512)])
+def test_wgrad_fused_bias_gradient(R, K, N, pitch):
+    """svsr_igemm_wgrad's optional dbias output = column sums of dy (accumulated), alongside the weight gradient."""
+    from syncvsr_amd import ops
+    dev = _dev()
+    x = _r(R, K, seed=1).to(BF)
+    dy = torch.zeros(R, pitch)
+    dy[:, :N] = _r(R, N, seed=2)
+    dy = dy.to(BF)
+    dw = torch.zeros(N, K, device=dev)
+    db = torch.full((N,), 0.5, device=dev)
+    ops.linear_wgrad(x.to(dev), dy.to(dev), dw, rows=R, K=K, N=N, x_pitch=K, dy_pitch=pitch, db=db)
+    assert _rel_err(dw.cpu(), dy.float()[:, :N].t() @ x.float()) < 3e-3
+    assert _rel_err(db.cpu() - 0.5, dy.float()[:, :N].sum(0)) < 2e-3
