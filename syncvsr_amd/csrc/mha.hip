@@ -12,6 +12,8 @@
 // MFMA fragments (lane l: row l&31, k = (l>>5)*8..+7 = one 16-byte load); operands that are "k-major" (V for P·V, K for
 // dS·K, the transposed P/dS) are staged through LDS and gathered.  Sequences here are short (<= ~600 frames), so the
 // whole score row of a tile lives in LDS and the softmax is exact (no online rescaling).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define MHA_DH 64
@@ -440,6 +442,14 @@ __global__ __launch_bounds__(256) void k_mha_pe_reduce(const float* __restrict__
     }
 }
 
+#include "mha_coop.h"
+
+static inline size_t mha_lds_fwd4(int Lk) { return ((size_t)32 * (((Lk + 31) & ~31) + 4) + 4 * 32 * 64 + 64) * sizeof(float) + (size_t)32 * MHA_VP * 2; }
+static inline size_t mha_lds_bwd4(int Lk) { return ((size_t)32 * (((Lk + 31) & ~31) + 4) + 2 * 1024) * sizeof(float) + (size_t)32 * MHA_VP * 2; }
+static inline bool mha_coop() {
+    static const bool v = [] { const char* e = getenv("SVSR_MHA_COOP"); return !(e != nullptr && e[0] == '0'); }();
+    return v;
+}
 static inline size_t mha_lds_fwd(int Lk) { return ((size_t)32 * (((Lk + 31) & ~31) + 4) + 32 * 64 + 64) * sizeof(float) + (size_t)32 * MHA_VP * 2; }
 static inline size_t mha_lds_bwd(int Lk) { return ((size_t)32 * (((Lk + 31) & ~31) + 4)) * sizeof(float) + (size_t)32 * MHA_VP * 2; }
 #define MHA_MAX_LDS (150 * 1024)
@@ -455,7 +465,8 @@ int svsr_mha_fwd(const void* q, int q_pitch, const void* k, const void* v, int k
                  hipStream_t stream) {
     if (dh != MHA_DH || Lq < 1 || Lk < 1 || ldp < Lk || (q_pitch | kv_pitch | pe_pitch) % 8 != 0) return SVSR_ERR_ARG;
     if (pe != nullptr && (bias_u == nullptr || bias_v == nullptr || Lq != Lk)) return SVSR_ERR_ARG;
-    const size_t lds = mha_lds_fwd(Lk);
+    const bool coop = mha_coop();
+    const size_t lds = coop ? mha_lds_fwd4(Lk) : mha_lds_fwd(Lk);
     if (lds > MHA_MAX_LDS) return SVSR_ERR_ARG;
     MhaArgs a{};
     a.q = (const bf16_t*)q; a.q_pitch = q_pitch; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.kv_pitch = kv_pitch;
@@ -463,10 +474,18 @@ int svsr_mha_fwd(const void* q, int q_pitch, const void* k, const void* v, int k
     a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldp = ldp; a.scale = scale; a.ctx = (bf16_t*)ctx; a.ctx_pitch = ctx_pitch; a.probs = (bf16_t*)probs;
     a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
     static bool attr = false;
-    if (!attr) { mha_allow_lds(k_mha_fwd<true>); mha_allow_lds(k_mha_fwd<false>); attr = true; }
+    if (!attr) {
+        mha_allow_lds(k_mha_fwd<true>); mha_allow_lds(k_mha_fwd<false>); mha_allow_lds(k_mha_fwd4<true>); mha_allow_lds(k_mha_fwd4<false>);
+        attr = true;
+    }
     const dim3 grid((Lq + 31) / 32, B * H);
-    if (pe != nullptr) hipLaunchKernelGGL(k_mha_fwd<true>, grid, dim3(64), lds, stream, a);
-    else hipLaunchKernelGGL(k_mha_fwd<false>, grid, dim3(64), lds, stream, a);
+    if (coop) {
+        if (pe != nullptr) hipLaunchKernelGGL(k_mha_fwd4<true>, grid, dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL(k_mha_fwd4<false>, grid, dim3(256), lds, stream, a);
+    } else {
+        if (pe != nullptr) hipLaunchKernelGGL(k_mha_fwd<true>, grid, dim3(64), lds, stream, a);
+        else hipLaunchKernelGGL(k_mha_fwd<false>, grid, dim3(64), lds, stream, a);
+    }
     return svsr_check_launch();
 }
 
@@ -478,7 +497,8 @@ int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, c
     if (dh != MHA_DH || Lq < 1 || Lk < 1 || ldp < Lk || (q_pitch | kv_pitch | pe_pitch | dctx_pitch) % 8 != 0) return SVSR_ERR_ARG;
     const bool rel = pe != nullptr;
     if (rel && (bias_u == nullptr || bias_v == nullptr || Lq != Lk || dq_ac == nullptr || dq_bd == nullptr || dpe == nullptr || pe_part == nullptr)) return SVSR_ERR_ARG;
-    const size_t lds = mha_lds_bwd(Lk);
+    const bool coop = mha_coop();
+    const size_t lds = coop ? mha_lds_bwd4(Lk) : mha_lds_bwd(Lk);
     if (lds > MHA_MAX_LDS) return SVSR_ERR_ARG;
     MhaArgs a{};
     a.q = (const bf16_t*)q; a.q_pitch = q_pitch; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.kv_pitch = kv_pitch;
@@ -489,8 +509,25 @@ int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, c
     a.dpe = (bf16_t*)dpe; a.dpe_pitch = dpe_pitch; a.pe_part = pe_part;
     a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
     static bool attr = false;
-    if (!attr) { mha_allow_lds(k_mha_bwd_q<true>); mha_allow_lds(k_mha_bwd_q<false>); attr = true; }
+    if (!attr) {
+        mha_allow_lds(k_mha_bwd_q<true>); mha_allow_lds(k_mha_bwd_q<false>); mha_allow_lds(k_mha_bwd_q4<true>); mha_allow_lds(k_mha_bwd_q4<false>);
+        attr = true;
+    }
     const dim3 gq((Lq + 31) / 32, B * H), gk((Lk + 31) / 32, B * H);
+    if (coop) {
+        const long n = (long)(2 * Lq - 1) * dpe_pitch;
+        long blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+        if (rel) {
+            hipLaunchKernelGGL(k_mha_bwd_q4<true>, gq, dim3(256), lds, stream, a);
+            hipLaunchKernelGGL(k_mha_bwd_kv4<true>, gk, dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(k_mha_bwd_pe4, dim3((2 * Lq - 1 + 31) / 32, H, B), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(k_mha_pe_reduce, dim3((int)blocks), dim3(256), 0, stream, pe_part, (bf16_t*)dpe, B, n);
+        } else {
+            hipLaunchKernelGGL(k_mha_bwd_q4<false>, gq, dim3(256), lds, stream, a);
+            hipLaunchKernelGGL(k_mha_bwd_kv4<false>, gk, dim3(256), 0, stream, a);
+        }
+        return svsr_check_launch();
+    }
     if (rel) {
         hipLaunchKernelGGL(k_mha_bwd_q<true>, gq, dim3(64), lds, stream, a);
         hipLaunchKernelGGL(k_mha_bwd_kv<true>, gk, dim3(64), 0, stream, a);
