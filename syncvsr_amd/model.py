@@ -11,6 +11,7 @@ so ``loss_total.backward()`` works as in the reference loops while no per-op aut
 from __future__ import annotations
 
 import math
+import os
 from typing import Any, Optional
 
 import torch
@@ -21,6 +22,7 @@ from .config import Config, audio_codec_dims
 from .init import buffer_specs, hidden_dim, init_state_dict, param_specs, resnet_block_specs
 
 BF16 = torch.bfloat16
+USE_MFMA_ATTENTION = os.environ.get("SVSR_LRW_MFMA_ATTN", "1") != "0"
 
 
 class _SideStream:
@@ -467,7 +469,10 @@ def _encoder_forward(model: TransformerLightningModule, st: _ParamStore, tape: d
         wqkv = st.s16(f"{p}.attention.self.query.weight", 3 * D * D)
         bqkv = st.flat[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
         qkv, _ = ops.linear_fwd(x, wqkv, bqkv, rows=R, K=D, N=3 * D, x_pitch=D)
-        ctx, probs = ops.attn_fwd(qkv, B, S, H, D // H)
+        if USE_MFMA_ATTENTION:      # the MFMA attention kernels written for LRS (csrc/mha.hip); bert.hip's k_attn_* is the scalar first version
+            ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=S, Lk=S)
+        else:
+            ctx, probs = ops.attn_fwd(qkv, B, S, H, D // H)
         ao, _ = ops.linear_fwd(ctx, st.s16(f"{p}.attention.output.dense.weight"), st.p32(f"{p}.attention.output.dense.bias"),
                                rows=R, K=D, N=D, x_pitch=D)
         x1, m1, r1 = ops.add_ln_fwd(ao, x, st.p32(f"{p}.attention.output.LayerNorm.weight"), st.p32(f"{p}.attention.output.LayerNorm.bias"), model.ln_eps)
@@ -502,7 +507,13 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
         ops.linear_wgrad(t["ctx"], ds1, st.g32(f"{p}.attention.output.dense.weight"), rows=R, K=D, N=D, x_pitch=D, dy_pitch=D, use_tr=use_tr,
                          db=st.g32(f"{p}.attention.output.dense.bias"))
         dctx = ops.linear_dgrad(ds1, st.t16(f"{p}.attention.output.dense.weight"), rows=R, N=D, K=D, dy_pitch=D)
-        dqkv = ops.attn_bwd(dctx, t["qkv"], t["probs"], B, S, H, D // H)
+        if USE_MFMA_ATTENTION:
+            qkv = t["qkv"]
+            dqkv = torch.empty_like(qkv)
+            ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, t["probs"], B=B, H=H, Lq=S, Lk=S, dq=dqkv, dq_pitch=3 * D,
+                        dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D)
+        else:
+            dqkv = ops.attn_bwd(dctx, t["qkv"], t["probs"], B, S, H, D // H)
         gq = st.grad[st.offsets[f"{p}.attention.self.query.weight"][0] :][: 3 * D * D]
         gqb = st.grad[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
         ops.linear_wgrad(t["x"], dqkv, gq, rows=R, K=D, N=3 * D, x_pitch=D, dy_pitch=3 * D, use_tr=use_tr, db=gqb)
