@@ -225,6 +225,22 @@ class E2E(nn.Module):
         return LrsTargets(labels, ys_in, ys_out.contiguous())
 
     # ------------------------------------------------------------------------------------------------
+    def encode(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`self.encoder(xs, masks)[0]` of the reference (what its inference path calls, LRS/video/lightning.py:100-101,113-116):
+        x [B,T,1,H,W] -> fp32 [B,T,adim]; forward only (no autograd), honours train/eval mode for BatchNorm and dropout."""
+        if x.device.type != "cuda":
+            raise RuntimeError("syncvsr_amd runs on an MI355X HIP device only; there is no CPU fallback (use oracle/ for checking)")
+        st = self.store()
+        if not st.shadow_fresh:
+            st.refresh_shadows()
+        B, T = x.shape[:2]
+        if lengths is None:
+            lengths = torch.full((B,), T, dtype=torch.int32, device=x.device)
+        ilen = lengths.to(device=x.device, dtype=torch.int32).contiguous()
+        with torch.no_grad():
+            h = _encoder_fwd(self, st, {}, x.float().contiguous(), ilen, self.training)[2]
+        return h.float().view(B, T, self.adim)
+
     def forward(self, x: torch.Tensor, lengths: torch.Tensor, audios: torch.Tensor, label):
         if x.device.type != "cuda":
             raise RuntimeError("syncvsr_amd runs on an MI355X HIP device only; there is no CPU fallback (use oracle/ for checking)")
@@ -448,6 +464,27 @@ def _decoder_bwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, dpred,
     _ready(model, st, "decoder.embed.0.weight")
 
 
+def _encoder_fwd(model: E2E, st: _ParamStore, tape: dict, x, ilen, training: bool):
+    """`Encoder.forward` (transformer/encoder.py:257-289): front-end, embed, Conformer layers, after_norm."""
+    B, T = x.shape[:2]
+    D, R = model.adim, B * T
+    videos = x.view(B, 1, T, x.size(3), x.size(4))             # [B,T,1,H,W] and [B,1,T,H,W] are the same memory (C = 1)
+    feats = _frontend_forward(model, st, tape, videos, training)          # [R, 512] bf16
+    if training and (model.drop_p > 0.0 or model.attn_drop_p > 0.0):
+        model._advance_dropout(x.device)
+    dex = model._d("enc.embed.x")
+    h = _lin(st, feats, "encoder.embed.0", R, 512, D, alpha=math.sqrt(D), drop=dex)        # dropout(x * xscale), embedding.py:208,217
+    pos16 = model._pos_table("rel", T, x.device)
+    dpos = model._d("enc.embed.pos")
+    if dpos is not None:
+        pos16 = ops.scale_bf16(pos16, 1.0, drop=dpos)                                      # dropout(pos_emb), embedding.py:217
+    for i in range(model.elayers):
+        h = _encoder_layer_fwd(model, st, tape, i, h, pos16, ilen, B, T, training)
+    hx = h
+    h, mA, rA = _ln(st, hx, "encoder.after_norm")
+    return feats, hx, h, mA, rA, pos16, dex
+
+
 class _LrsFunction(torch.autograd.Function):
     """One autograd node for E2E.forward: returns (loss_ctc, loss_att, loss_audio, counts); backward replays the tape."""
 
@@ -461,20 +498,7 @@ class _LrsFunction(torch.autograd.Function):
         if not st.shadow_fresh:
             st.refresh_shadows()
         tape: dict[str, Any] = {}
-        videos = x.view(B, 1, T, x.size(3), x.size(4))             # [B,T,1,H,W] and [B,1,T,H,W] are the same memory (C = 1)
-        feats = _frontend_forward(model, st, tape, videos, training)          # [R, 512] bf16
-        if training and (model.drop_p > 0.0 or model.attn_drop_p > 0.0):
-            model._advance_dropout(x.device)
-        dex = model._d("enc.embed.x")
-        h = _lin(st, feats, "encoder.embed.0", R, 512, D, alpha=math.sqrt(D), drop=dex)        # dropout(x * xscale), embedding.py:208,217
-        pos16 = model._pos_table("rel", T, x.device)
-        dpos = model._d("enc.embed.pos")
-        if dpos is not None:
-            pos16 = ops.scale_bf16(pos16, 1.0, drop=dpos)                                      # dropout(pos_emb), embedding.py:217
-        for i in range(model.elayers):
-            h = _encoder_layer_fwd(model, st, tape, i, h, pos16, ilen, B, T, training)
-        hx = h
-        h, mA, rA = _ln(st, hx, "encoder.after_norm")
+        feats, hx, h, mA, rA, pos16, dex = _encoder_fwd(model, st, tape, x, ilen, training)
         # audio head (e2e_asr_transformer.py:194-201): every frame, no padding mask
         NA = A * G * V
         logits_a = _lin(st, h, "audio_classifier", R, D, NA)
