@@ -80,3 +80,28 @@ class CutMix(torch.nn.Module):
         wm = word_mask.float()
         mixed_word_mask = (1.0 - mix).view(B, *([1] * (wm.dim() - 1))) * wm + mix.view(B, *([1] * (wm.dim() - 1))) * wm[tgt]
         return mixed_videos, mixed_audios, mixed_labels, mixed_word_mask
+
+
+class TimeMask(torch.nn.Module):
+    """The reference's TimeMask (LRW/video/src/augment.py:120-141; `train.use_timemask`, T = 0.6 * 25 frames, one mask):
+    a random run of up to T frames of one clip [T, ...] is replaced by the clip's mean (or zero).  The run is drawn from
+    Python's `random` exactly as the reference does (same calls, same order), so a seeded run reproduces it; the fill is one
+    device op per mask and works on CPU or HIP tensors alike (no host sync: the mean stays a 0-d tensor)."""
+
+    def __init__(self, T: float = 6400, n_mask: int = 2, replace_with_zero: bool = False):
+        super().__init__()
+        self.T, self.n_mask, self.replace_with_zero = T, n_mask, replace_with_zero
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        import random
+
+        cloned = x.clone()
+        len_raw = cloned.size(0)
+        for _ in range(self.n_mask):
+            t = random.randint(0, min(self.T, len_raw))
+            t_zero = random.randint(0, len_raw - t)
+            if self.replace_with_zero:
+                cloned[t_zero : t_zero + t] = 0
+            else:
+                cloned[t_zero : t_zero + t] = cloned.mean()      # the mean is taken AFTER earlier masks, as in the reference
+        return cloned

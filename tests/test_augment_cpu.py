@@ -26,3 +26,19 @@ def test_cutmix_matches_reference(seed):
     np.testing.assert_allclose(l.numpy(), gold[f"labels_{seed}"], rtol=0, atol=1e-7)
     np.testing.assert_allclose(w.numpy(), gold[f"word_mask_{seed}"], rtol=0, atol=1e-7)
     assert any((gold[f"videos_{s}"][:, 0, :, 0, 0] // 100 != np.arange(B)[:, None]).any() for s in (7, 8, 9)), "goldens must exercise a splice"
+
+
+@pytest.mark.parametrize("seed,kw", [(1, dict(T=15, n_mask=1)), (2, dict(T=15, n_mask=2)), (3, dict(T=40, n_mask=1, replace_with_zero=True)),
+                                     (4, dict(T=15, n_mask=1))])
+def test_timemask_matches_reference(seed, kw):
+    """syncvsr_amd.augment.TimeMask == the reference's TimeMask under the same `random` seed (golden from the imported reference)."""
+    import random
+
+    from syncvsr_amd.augment import TimeMask
+
+    gold = np.load(os.path.join(os.path.dirname(GOLD), "timemask.npz"))
+    clip = torch.from_numpy(gold["clip"])
+    random.seed(seed)
+    out = TimeMask(**kw)(clip)
+    np.testing.assert_allclose(out.numpy(), gold[f"out_{seed}"], rtol=0, atol=1e-7)
+    assert not np.array_equal(gold[f"out_{seed}"], gold["clip"]) or seed == 0
