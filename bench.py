@@ -283,6 +283,11 @@ def main() -> None:
             }
             if not args.no_cpu_baseline and world == 1:
                 result["cpu_baseline"] = cpu_baseline_lrs(lrs_args, LRS_ODIM, 32) if lrs else cpu_baseline(cfg, args.cpu_batch)
+        try:        # RCCL prints its version banner through C stdio, which is flushed at exit: push it out first so the JSON line is last
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
