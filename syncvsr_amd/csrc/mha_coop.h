@@ -1,11 +1,11 @@
-// Four-wave cooperative variants of the attention kernels in mha.hip (included from there; default path).
+// The attention kernels of mha.hip (included from there): four waves cooperate on one 32-row tile.
 //
-// The one-wave-per-tile kernels leave ~4 waves per CU at LRS sizes (B*H*ceil(T/32) ~ 1,000 tiles) and every wave walks a
-// serial chain of global loads -> MFMA -> LDS round trips, so a launch takes as long as one wave's latency chain.  Here the
-// four waves of a workgroup share one 32-row tile: score / dP blocks are dealt out over the waves, the row passes (softmax,
-// dS) take eight rows each, staging of the k-major operand is one 16-byte load per thread, and in the contractions with a
+// A first version ran one wave per tile: ~4 waves per CU at LRS sizes (B*H*ceil(T/32) ~ 1,000 tiles), every wave walking a
+// serial chain of global loads -> MFMA -> LDS round trips, so a launch took as long as one wave's latency chain (rel-pos
+// backward 244 us vs 97 us now).  Here the four waves of a workgroup share one 32-row tile: score / dP blocks are dealt out
+// over the waves, the row passes (softmax, dS) take eight rows each, staging of the k-major operand is one 16-byte load per thread, and in the contractions with a
 // staged operand wave w takes output half (w & 1) and k-slice (w >> 1) of every staged block; the two k-slice partials are
-// summed through LDS at the end.  Same arithmetic, same LDS layouts, same HBM buffers as the one-wave kernels.
+// summed through LDS at the end.
 
 // stage 32 rows x 64 columns with all 256 threads: one 16-byte load each
 __device__ __forceinline__ void stage_rows64_256(bf16_t* dst, const bf16_t* src, long row0, long row_end, int pitch, int col0, int tid) {
