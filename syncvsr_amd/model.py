@@ -33,10 +33,13 @@ class _SideStream:
     def __init__(self) -> None:
         self.stream: Optional[torch.cuda.Stream] = None
         self.keep: list = []
-        self.enabled = False     # measured: concurrent trunk kernels contend for LDS/CU slots, 8.28 -> 8.52 ms; kept as an option
+        self.enabled = False     # trunk: concurrent conv kernels contend for LDS/CU slots, 8.28 -> 8.52 ms; kept as an option
+        # encoder weight gradients on the side stream: measured 7.91 -> 8.27 ms under HIP-graph replay (forked graph branches cost
+        # more than the idle gaps they fill) and no gain in eager mode; off by default
+        self.enabled_small = os.environ.get("SVSR_SIDE_ENCODER", "0") == "1"
 
-    def run(self, fn, *keep) -> None:
-        if not self.enabled:
+    def run(self, fn, *keep, small: bool = False) -> None:
+        if not (self.enabled or (small and self.enabled_small)):
             fn()
             return
         if self.stream is None:
@@ -47,7 +50,7 @@ class _SideStream:
         self.keep.extend(keep)
 
     def join(self) -> None:
-        if self.stream is not None and self.enabled:
+        if self.stream is not None and (self.enabled or self.enabled_small):
             torch.cuda.current_stream().wait_stream(self.stream)
         self.keep.clear()
 
@@ -496,16 +499,19 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
         t = tape[p]
         ds2 = ops.add_ln_bwd(dx, t["f"], t["x1"], st.p32(f"{p}.output.LayerNorm.weight"), t["m2"], t["r2"],
                              st.g32(f"{p}.output.LayerNorm.weight"), st.g32(f"{p}.output.LayerNorm.bias"))
-        ops.linear_wgrad(t["hg"], ds2, st.g32(f"{p}.output.dense.weight"), rows=R, K=I, N=D, x_pitch=I, dy_pitch=D, use_tr=use_tr,
-                         db=st.g32(f"{p}.output.dense.bias"))
+        side = model._side
+        side.run(lambda: ops.linear_wgrad(t["hg"], ds2, st.g32(f"{p}.output.dense.weight"), rows=R, K=I, N=D, x_pitch=I, dy_pitch=D, use_tr=use_tr,
+                                          db=st.g32(f"{p}.output.dense.bias")), ds2, small=True)
         dhg = ops.linear_dgrad(ds2, st.t16(f"{p}.output.dense.weight"), rows=R, N=D, K=I, dy_pitch=D)
         dz = ops.bias_act_bwd(dhg, t["z"], st.g32(f"{p}.intermediate.dense.bias"), R=R, N=I, n_valid=I, ld=I)
-        ops.linear_wgrad(t["x1"], dz, st.g32(f"{p}.intermediate.dense.weight"), rows=R, K=D, N=I, x_pitch=D, dy_pitch=I, use_tr=use_tr)
-        dx1 = ops.linear_dgrad(dz, st.t16(f"{p}.intermediate.dense.weight"), rows=R, N=I, K=D, dy_pitch=I, addend=ds2, out=ds2)
+        side.run(lambda: ops.linear_wgrad(t["x1"], dz, st.g32(f"{p}.intermediate.dense.weight"), rows=R, K=D, N=I, x_pitch=D, dy_pitch=I,
+                                          use_tr=use_tr), dz, small=True)
+        # (not in place: the side stream may still be reading ds2 / ds1 for the weight gradients)
+        dx1 = ops.linear_dgrad(dz, st.t16(f"{p}.intermediate.dense.weight"), rows=R, N=I, K=D, dy_pitch=I, addend=ds2)
         ds1 = ops.add_ln_bwd(dx1, t["ao"], t["x"], st.p32(f"{p}.attention.output.LayerNorm.weight"), t["m1"], t["r1"],
                              st.g32(f"{p}.attention.output.LayerNorm.weight"), st.g32(f"{p}.attention.output.LayerNorm.bias"))
-        ops.linear_wgrad(t["ctx"], ds1, st.g32(f"{p}.attention.output.dense.weight"), rows=R, K=D, N=D, x_pitch=D, dy_pitch=D, use_tr=use_tr,
-                         db=st.g32(f"{p}.attention.output.dense.bias"))
+        side.run(lambda: ops.linear_wgrad(t["ctx"], ds1, st.g32(f"{p}.attention.output.dense.weight"), rows=R, K=D, N=D, x_pitch=D, dy_pitch=D,
+                                          use_tr=use_tr, db=st.g32(f"{p}.attention.output.dense.bias")), ds1, small=True)
         dctx = ops.linear_dgrad(ds1, st.t16(f"{p}.attention.output.dense.weight"), rows=R, N=D, K=D, dy_pitch=D)
         if USE_MFMA_ATTENTION:
             qkv = t["qkv"]
@@ -516,8 +522,8 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
             dqkv = ops.attn_bwd(dctx, t["qkv"], t["probs"], B, S, H, D // H)
         gq = st.grad[st.offsets[f"{p}.attention.self.query.weight"][0] :][: 3 * D * D]
         gqb = st.grad[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
-        ops.linear_wgrad(t["x"], dqkv, gq, rows=R, K=D, N=3 * D, x_pitch=D, dy_pitch=3 * D, use_tr=use_tr, db=gqb)
-        dx = ops.linear_dgrad(dqkv, st.t16(f"{p}.qkv"), rows=R, N=3 * D, K=D, dy_pitch=3 * D, addend=ds1, out=ds1)
+        side.run(lambda: ops.linear_wgrad(t["x"], dqkv, gq, rows=R, K=D, N=3 * D, x_pitch=D, dy_pitch=3 * D, use_tr=use_tr, db=gqb), dqkv, small=True)
+        dx = ops.linear_dgrad(dqkv, st.t16(f"{p}.qkv"), rows=R, N=3 * D, K=D, dy_pitch=3 * D, addend=ds1)
         _ready(model, st, f"{p}.attention.self.query.weight")
     te = tape["emb"]
     ds0 = ops.add_ln_bwd(dx, te["sum"], None, st.p32("encoder.embeddings.LayerNorm.weight"), te["mean"], te["rstd"],
