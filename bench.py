@@ -186,8 +186,10 @@ def main() -> None:
     from syncvsr_amd.init import synthetic_batch
     from syncvsr_amd.model import Model
 
-    use_graph = (not args.no_graph) and (world == 1 or args.graph or args.force_collective)
     lrs = args.workload == "lrs"
+    use_graph = (not args.no_graph) and (world == 1 or args.graph or args.force_collective)
+    if lrs and not args.graph:
+        use_graph = False        # LRS: eager launches + side-stream weight gradients are faster than a replayed graph (engine.TrainStep)
     if lrs:
         from syncvsr_amd.engine import lrs_train_config
         from syncvsr_amd.lrs_init import LRS_ODIM, default_lrs_args, lrs_synthetic_batch

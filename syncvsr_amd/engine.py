@@ -61,6 +61,12 @@ class TrainStep:
         # always_reduce: run the collective path even for a 1-rank group (exercises RCCL + graph capture on one GPU)
         self.dp = GradReducer(model, process_group, bucket_mb, always_reduce) if (self.world > 1 or always_reduce) else None
         self.use_graph = use_graph
+        if not self.is_lrw:
+            # LRS linears are 20-40 us GEMMs that fill about half the chip each: their weight gradients run next to the
+            # data-gradient chain on a side stream in eager mode (31.9 -> 30.3 ms); under graph replay the forked branches cost
+            # more than they hide (33.2 ms), so a captured step keeps them in line
+            import os
+            model._side.enabled_small = (not use_graph) and os.environ.get("SVSR_SIDE_ENCODER", "1") != "0"
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._static: Optional[list[torch.Tensor]] = None
         self._out: Optional[dict[str, torch.Tensor]] = None

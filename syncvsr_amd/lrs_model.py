@@ -281,7 +281,9 @@ def _lin_bwd(model, st: _ParamStore, name: str, x, dy, rows: int, K: int, N: int
     dy_pitch = dy_pitch or N
     gw = st.grad[st.offsets[f"{name}.weight"][0] :][: N * K]
     gb = st.grad[st.offsets[f"{name}.bias"][0] :][:N] if bias else None          # column sums of dy, fused into the wgrad launch
-    ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=dy_pitch, use_tr=model.use_tr, db=gb)
+    # weight gradients only feed the flat gradient buffer: optionally on the side stream, next to the data-gradient GEMM
+    model._side.run(lambda: ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=dy_pitch, use_tr=model.use_tr, db=gb),
+                    x, dy, small=True)
     if not need_dx:
         return None
     return ops.linear_dgrad(dy, st.t16(tkey or f"{name}.weight"), rows=rows, N=N, K=K, dy_pitch=dy_pitch, addend=addend, out=out, drop=drop)
