@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = forward + backward + (RCCL gradient all-reduce) + global-norm clip + AdamW on a synthetic batch of 32
-clips of 29x88x88 per GPU, replayed as one HIP graph.  Rank 0 prints ONE JSON line.  Besides the
+clips of 29x88x88 per GPU; eager launches by default, `--graph` replays one HIP graph per step.  Rank 0 prints ONE JSON line.  Besides the
 contract fields it carries:
   roofline      — dominant kernel of the step (by summed HIP-event time over profiled eager steps), its algorithmic
                   FLOPs / time against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md), plus the per-kernel table
@@ -151,13 +151,14 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per step")
-    ap.add_argument("--graph", action="store_true", help="force HIP-graph replay also for N > 1 (default there: eager; the step is "
-                                                         "GPU-bound either way, eager keeps RCCL out of stream capture)")
+    ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
+    ap.add_argument("--graph", action="store_true", help="capture the whole step into one HIP graph and replay it (measured slower than the "
+                                                         "eager default, whose weight-gradient launches overlap on a side stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--profile-steps", type=int, default=2, help="eager steps with per-launch HIP events for the roofline leg")
     ap.add_argument("--force-collective", action="store_true", help="run the RCCL path even with one rank")
+    ap.add_argument("--bucket-mb", type=float, default=16.0, help="gradient all-reduce bucket size (MiB of fp32)")
     ap.add_argument("--workload", choices=("lrw", "lrs"), default="lrw", help="lrw = BASELINE.json's headline metric (default); lrs = the "
                     "sentence-level E2E model (SURVEY §8 a13-a15, BASELINE configs[3]): --batch clips of up to --frames frames")
     ap.add_argument("--frames", type=int, default=150, help="LRS: padded clip length T (lengths are drawn in [0.3 T, T])")
@@ -187,9 +188,7 @@ def main() -> None:
     from syncvsr_amd.model import Model
 
     lrs = args.workload == "lrs"
-    use_graph = (not args.no_graph) and (world == 1 or args.graph or args.force_collective)
-    if lrs and not args.graph:
-        use_graph = False        # LRS: eager launches + side-stream weight gradients are faster than a replayed graph (engine.TrainStep)
+    use_graph = args.graph and not args.no_graph     # default: eager launches + side-stream weight gradients (faster, see engine.TrainStep)
     if lrs:
         from syncvsr_amd.engine import lrs_train_config
         from syncvsr_amd.lrs_init import LRS_ODIM, default_lrs_args, lrs_synthetic_batch
@@ -208,7 +207,7 @@ def main() -> None:
         cfg.train.batch_size = args.batch
         model = Model(cfg, seed=0).to(dev).train()
         batch = [t.to(dev) for t in synthetic_batch(cfg, args.batch, seed=1234 + rank)]
-    trainer = TrainStep(model, cfg, use_graph=use_graph, always_reduce=args.force_collective, bucket_mb=16.0)
+    trainer = TrainStep(model, cfg, use_graph=use_graph, always_reduce=args.force_collective, bucket_mb=args.bucket_mb)
 
     def barrier():
         if use_dist:
@@ -265,6 +264,7 @@ def main() -> None:
         prof = TrainStep(model, cfg, use_graph=False, always_reduce=False)
         prof.dp = None
         model.grad_ready_hook = None
+        model._side.enabled = model._side.enabled_small = False        # time every kernel alone, not overlapped with a side-stream neighbour
         if True:
             prof._step_impl(*batch)
             ops.start_event_timing()

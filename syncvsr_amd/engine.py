@@ -7,7 +7,9 @@ for one process per GPU:
     while the rest of the backward still runs;
   * clip + AdamW + schedule + bf16 shadow refresh are two kernels over the flat buffers, with the step counter, the gradient
     norm and the learning rate kept on the device — nothing in a step depends on host values, so
-  * the whole step (forward, backward, collectives, optimiser) is captured once into a HIP graph and replayed.
+  * the whole step (forward, backward, collectives, optimiser) CAN be captured once into a HIP graph and replayed
+    (`use_graph=True`); the default is eager launches with the weight-gradient kernels on a side stream, which measures faster
+    (host enqueue time is about half the GPU time of a step).
 """
 from __future__ import annotations
 
@@ -37,7 +39,7 @@ class TrainStep:
     optionally one HIP graph per step."""
 
     def __init__(self, model, config: Optional[Config] = None, process_group=None,
-                 use_graph: bool = True, bucket_mb: float = 32.0, always_reduce: bool = False):
+                 use_graph: bool = False, bucket_mb: float = 32.0, always_reduce: bool = False):
         self.model = model
         self.is_lrw = isinstance(model, TransformerLightningModule)
         if self.is_lrw:            # LRW/video/config/*.yaml: optim.optimizer / optim.scheduler / train.gradient_clip_val
@@ -61,11 +63,13 @@ class TrainStep:
         # always_reduce: run the collective path even for a 1-rank group (exercises RCCL + graph capture on one GPU)
         self.dp = GradReducer(model, process_group, bucket_mb, always_reduce) if (self.world > 1 or always_reduce) else None
         self.use_graph = use_graph
+        # Weight-gradient launches only feed the flat gradient buffer, so in EAGER mode they run on a side stream next to the
+        # data-gradient chain and fill its tails: LRW 8.06 -> 7.39 ms (trunk convs), LRS 31.9 -> 30.4 ms (trunk convs + the
+        # 20-40 us linear GEMMs that fill about half the chip each).  Under HIP-graph replay the forked branches cost more than
+        # they hide (LRW 7.85 -> 8.5 ms, LRS 33.2 ms), so a captured step keeps everything in line.
+        import os
+        model._side.enabled = (not use_graph) and os.environ.get("SVSR_SIDE_TRUNK", "1") != "0"
         if not self.is_lrw:
-            # LRS linears are 20-40 us GEMMs that fill about half the chip each: their weight gradients run next to the
-            # data-gradient chain on a side stream in eager mode (31.9 -> 30.3 ms); under graph replay the forked branches cost
-            # more than they hide (33.2 ms), so a captured step keeps them in line
-            import os
             model._side.enabled_small = (not use_graph) and os.environ.get("SVSR_SIDE_ENCODER", "1") != "0"
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._static: Optional[list[torch.Tensor]] = None
@@ -177,7 +181,10 @@ class GradReducer:
             return
         backend = dist.get_backend(self.group)
         if seg.is_cuda:
-            self.comm_stream.wait_stream(torch.cuda.current_stream())     # the segment's producers are enqueued there
+            self.comm_stream.wait_stream(torch.cuda.current_stream())     # the segment's producers are enqueued there ...
+            side = getattr(self.model, "_side", None)
+            if side is not None and side.stream is not None and (side.enabled or side.enabled_small):
+                self.comm_stream.wait_stream(side.stream)                 # ... and, for weight gradients, on the model's side stream
             with torch.cuda.stream(self.comm_stream):
                 if backend == "nccl":
                     dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group)

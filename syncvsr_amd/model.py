@@ -33,10 +33,9 @@ class _SideStream:
     def __init__(self) -> None:
         self.stream: Optional[torch.cuda.Stream] = None
         self.keep: list = []
-        self.enabled = False     # trunk: concurrent conv kernels contend for LDS/CU slots, 8.28 -> 8.52 ms; kept as an option
-        # encoder weight gradients on the side stream: measured 7.91 -> 8.27 ms under HIP-graph replay (forked graph branches cost
-        # more than the idle gaps they fill) and no gain in eager mode; off by default
-        self.enabled_small = os.environ.get("SVSR_SIDE_ENCODER", "0") == "1"
+        self.enabled = False     # set by engine.TrainStep: on for eager steps (7.39 vs 8.06 ms), off under graph replay (8.5 vs 7.85 ms)
+        # linear-layer weight gradients: neutral for the LRW encoder, a gain for the LRS linears (engine.TrainStep turns it on there)
+        self.enabled_small = False
 
     def run(self, fn, *keep, small: bool = False) -> None:
         if not (self.enabled or (small and self.enabled_small)):
@@ -454,8 +453,7 @@ def _conv_wgrad(model, st: "_ParamStore", conv: str, t: dict, dc: torch.Tensor, 
 def _ready(model, st: "_ParamStore", name: Optional[str]) -> None:
     """Gradient-ready notification for bucketed all-reduce: everything at or above `name`'s offset in the decayed
     region is final (backward walks the flat buffer from its end to its start); None = all gradients final."""
-    if model.grad_ready_hook is not None:
-        model._side.join()            # the bucket's weight gradients were produced on the side stream
+    if model.grad_ready_hook is not None:     # (the reducer's comm stream waits for the side stream itself: engine.GradReducer._reduce)
         model.grad_ready_hook(0 if name is None else st.offsets[name][0])
 
 
