@@ -2,6 +2,8 @@
 # PMC passes (separate runs, kernel-trace only) over one eager training step: HBM bytes and MFMA busy per kernel.
 mkdir -p gpurun_out/pmc
 export PYTHONUNBUFFERED=1
+# per-kernel numbers are taken with every launch in line (no side-stream overlap), like bench.py's roofline leg
+export SVSR_SIDE_TRUNK=0 SVSR_SIDE_ENCODER=0
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" ; do
   tag=$(echo $ctr | tr ' ' '_')
