@@ -127,3 +127,31 @@ def test_state_dict_roundtrip_and_determinism(dev):
     m2.to(dev).train()
     l2 = m2(*gb)["loss_total"].item()
     assert abs(l1 - l2) <= 1e-4 * abs(l1)
+
+
+@pytest.mark.parametrize("B,T,size", [(1, 29, 88), (3, 11, 96), (5, 7, 40), (2, 30, 64)])
+def test_lrw_other_shapes(dev, B, T, size):
+    """Clip geometries besides the headline 29 x 88 x 88: the 96 x 96 variant of the shipped yaml, a single clip,
+    odd batch / frame counts, T = 30 (31 encoder tokens) — losses and feature parity against the oracle."""
+    from oracle import lrw_oracle as O
+    from syncvsr_amd.config import default_lrw_config
+    from syncvsr_amd.init import init_state_dict, synthetic_batch
+    from syncvsr_amd.model import Model
+
+    cfg = default_lrw_config(model__bert__num_hidden_layers=2)
+    sd = init_state_dict(cfg, seed=21, perturb_norm=True)
+    batch = synthetic_batch(cfg, batch=B, frames=T, size=size, seed=33)
+    model = Model(cfg)
+    model.load_state_dict(sd)
+    model.to(dev).train()
+    out = model(*[t.to(dev) for t in batch])
+    out["loss_total"].backward()
+    torch.cuda.synchronize()
+    keep = {}
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref = O.forward(sd, cfg, *batch, training=True, keep=keep)
+    for k in ("loss_total", "loss_category", "loss_audio"):
+        assert abs(out[k].item() - ref[k].item()) <= 2e-2 * abs(ref[k].item()), (k, out[k].item(), ref[k].item())
+    a, b = model._last["feats"].float().cpu().flatten(), keep["feats"].flatten()
+    assert float((a - b).norm() / b.norm()) <= 4e-2
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
