@@ -321,7 +321,8 @@ def forward(sd: SD, args: Any, x: Tensor, lengths: Tensor, audio_tokens: Tensor,
     ys = [y[y != -1] for y in label.view(B, -1)]
     loss_ctc = ctc_loss(h, lengths, ys, sd, dp)
     ys_in, ys_out = add_sos_eos(ys, odim - 1, odim - 1)
-    pred = decoder(ys_in, h, mask, sd, args, keep, dp)
+    memory = _lin(h, sd, "proj_decoder") if "proj_decoder.weight" in sd else h               # e2e_asr_transformer.py:209-210
+    pred = decoder(ys_in, memory, mask, sd, args, keep, dp)
     if keep is not None:
         keep["pred"] = pred
     loss_att = label_smoothing_loss(pred.float(), ys_out, float(args.lsm_weight), bool(args.transformer_length_normalized_loss))

@@ -114,6 +114,8 @@ def lrs_param_specs(args: Config, odim: int = LRS_ODIM) -> list[Spec]:
         for n in ("norm_ff", "norm_mha", "norm_ff_macaron", "norm_conv", "norm_final"):
             specs += _ln_specs(f"{p}.{n}", D)
     specs += _ln_specs("encoder.after_norm", D)
+    if D != Dd:            # e2e_asr_transformer.py:93-95
+        specs += [("proj_decoder.weight", (Dd, D), "linear_w"), ("proj_decoder.bias", (Dd,), "linear_b")]
     specs += [("decoder.embed.0.weight", (odim, Dd), "emb")]
     for i in range(int(args.dlayers)):
         p = f"decoder.decoders.{i}"

@@ -75,9 +75,7 @@ class E2E(nn.Module):
             unsupported.append("relu_type must be swish")
         if args.get("zero_triu", False):
             unsupported.append("zero_triu is not supported")
-        if self.adim != self.ddim:
-            unsupported.append("adim != ddim (proj_decoder) is not implemented")
-        if self.adim % 64 or self.adim // self.aheads != 64 or self.ddim // self.dheads != 64:
+        if self.adim % 64 or self.ddim % 64 or self.adim // self.aheads != 64 or self.ddim // self.dheads != 64:
             unsupported.append("attention heads must be 64 wide")
         if not (0.0 < self.mtlalpha < 1.0):
             unsupported.append("mtlalpha must be in (0, 1) (both CTC and attention branches are built)")
@@ -127,7 +125,7 @@ class E2E(nn.Module):
             return 2
         if name.startswith("encoder."):
             return 3
-        if name.startswith(("ctc.", "audio_classifier")):
+        if name.startswith(("ctc.", "audio_classifier", "proj_decoder")):
             return 4
         return 5                 # decoder: last in the forward pass, first to be final in the backward pass
 
@@ -166,6 +164,8 @@ class E2E(nn.Module):
             one(f"{p}.feed_forward.w_2.weight")
         for n in ("decoder.output_layer.weight", "ctc.ctc_lo.weight", "audio_classifier.weight"):
             one(n)
+        if self.adim != self.ddim:
+            one("proj_decoder.weight")
         return out
 
     def configure_optimizers(self):
@@ -515,18 +515,22 @@ class _LrsFunction(torch.autograd.Function):
                                   out_pitch=Vp)[0]
         loss_c, ctc_state = ops.ctc_fwd(logits_c, Vp, tg.labels, ilen, B, T, Vo)
         # attention decoder + label smoothing (decoder.py:122-151, label_smoothing_loss.py:41-63)
-        pred = _decoder_fwd(model, st, tape, tg, h, ilen, B, T)
+        # proj_decoder when the decoder is narrower/wider than the encoder (e2e_asr_transformer.py:93-95,209-210)
+        memory = _lin(st, h, "proj_decoder", R, D, model.ddim) if model.adim != model.ddim else h
+        pred = _decoder_fwd(model, st, tape, tg, memory, ilen, B, T)
         L = tg.ys_out.size(1)
         tgt = tg.ys_out.reshape(-1)
-        if model.length_norm:
-            raise NotImplementedError("transformer_length_normalized_loss needs the token count on the host")
-        inv_denom = 1.0 / B
+        # label_smoothing_loss.py:62: / batch size, or / number of live tokens (transformer_length_normalized_loss); the token
+        # count stays on the device (counts[1]), so the division is a 0-d tensor op and nothing syncs
+        inv_denom = 1.0 if model.length_norm else 1.0 / B
         loss_att, lse_p, counts = ops.ls_loss_fwd(pred, Vp, tgt, B * L, Vo, model.lsm_weight, inv_denom)
+        if model.length_norm:
+            loss_att = loss_att / counts[1]
         model._last = dict(feats=feats, enc_out=h, pred=pred, logits_audio=logits_a, logits_ctc=logits_c)
         if need_grad:
             tape["head"] = dict(hx=hx, h=h, mA=mA, rA=rA, logits_a=logits_a, lse_a=lse_a, tok=tok, logits_c=logits_c, ctc_state=ctc_state,
                                 pred=pred, lse_p=lse_p, tgt=tgt, inv_denom=inv_denom, dims=(B, T, L, Vp), pos16=pos16, ilen=ilen, feats=feats,
-                                h_ctc=h_ctc, dctc=dctc, dex=dex)
+                                h_ctc=h_ctc, dctc=dctc, dex=dex, memory=memory, counts=counts)
             ctx.tape, ctx.model, ctx.st, ctx.tg = tape, model, st, tg
         ctx.mark_non_differentiable(counts)
         return loss_c, loss_att, loss_a, counts
@@ -551,8 +555,15 @@ class _LrsFunction(torch.autograd.Function):
         h = th["h"]
         dh = torch.zeros((R, D), dtype=BF16, device=dev)
         # decoder first: its parameters sit at the end of the flat gradient buffer
+        if model.length_norm:
+            g_att = (g_att / th["counts"][1]).contiguous()
         dpred = ops.ls_loss_bwd(th["pred"], Vp, th["tgt"], B * L, Vo, model.lsm_weight, th["inv_denom"], th["lse_p"], g_att, Vp)
-        _decoder_bwd(model, st, tape, tg, dpred, h, dh, B, T)
+        if model.adim != model.ddim:
+            dmem = torch.zeros((R, model.ddim), dtype=BF16, device=dev)
+            _decoder_bwd(model, st, tape, tg, dpred, th["memory"], dmem, B, T)
+            _lin_bwd(model, st, "proj_decoder", h, dmem, R, D, model.ddim, addend=dh, out=dh)
+        else:
+            _decoder_bwd(model, st, tape, tg, dpred, h, dh, B, T)
         # CTC and audio heads
         dlc = ops.ctc_grad(th["logits_c"], Vp, tg.labels, th["ilen"], B, T, Vo, th["ctc_state"], g_ctc, Vp)
         _lin_bwd(model, st, "ctc.ctc_lo", th["h_ctc"], dlc, R, D, Vo, dy_pitch=Vp, addend=dh, out=dh, drop=th["dctc"])   # dh += mask/(1-p) * (dlc W)

@@ -50,6 +50,9 @@ LRS_CASES = {
                          codec="wav2vec2"), 23, dict(batch=3, t_max=14, size=16, label_len=(1, 5), min_len_frac=0.3), 12, 92, True, True),
     "lrs_tiny_eval": (_LRS_TINY, 41, dict(batch=2, t_max=9, size=24, label_len=(2, 4)), 11, 91, True, False),
     "lrs_full_b2": (dict(), 5049, dict(batch=2, t_max=12, size=88, label_len=(3, 6)), 0, 1234, False, True),
+    # adim != ddim (proj_decoder, e2e_asr_transformer.py:93-95) and the length-normalised attention loss
+    "lrs_tiny_proj": (dict(_LRS_TINY, ddim=192, dheads=3, dlayers=2, transformer_length_normalized_loss=True), 37,
+                      dict(batch=3, t_max=10, size=16, label_len=(2, 5), min_len_frac=0.5), 13, 93, True, True),
 }
 
 

@@ -51,7 +51,7 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-@pytest.mark.parametrize("name,loss_tol", [("lrs_tiny", 1e-2), ("lrs_tiny_b3", 1e-2), ("lrs_full_b2", 5e-3)])
+@pytest.mark.parametrize("name,loss_tol", [("lrs_tiny", 1e-2), ("lrs_tiny_b3", 1e-2), ("lrs_tiny_proj", 1e-2), ("lrs_full_b2", 5e-3)])
 def test_lrs_model_matches_oracle(dev, name, loss_tol):
     args, model, out, osd, ref, keep, stats, gold = _run_pair(name, dev)
     names = ("loss", "loss_ctc", "loss_att", "loss_audio")
@@ -85,7 +85,7 @@ def test_lrs_model_matches_oracle(dev, name, loss_tol):
     print("worst grad cosines:", worst)
     for k in names:
         assert abs(rows[k]["hip"] - rows[k]["oracle"]) <= loss_tol * abs(rows[k]["oracle"]), (k, rows[k])
-    assert rows["rel.feats"] <= 3e-2 and rows["rel.enc_out"] <= 5e-2 and rows["rel.pred"] <= 5e-2, rows
+    assert rows["rel.feats"] <= (3e-2 if name == "lrs_full_b2" else 4e-2) and rows["rel.enc_out"] <= 5e-2 and rows["rel.pred"] <= 5e-2, rows
     for n, v in bufs.items():
         assert v <= 2e-2, (n, v)
     coss = sorted(v["cos"] for v in live.values())

@@ -210,7 +210,7 @@ def test_lrs_host_logic():
     # CPU tensors are refused (no fallback); unsupported configurations raise
     with pytest.raises(RuntimeError):
         m(*batch)
-    for bad in (dict(macaron_style=False), dict(adim=128, aheads=2, ddim=256, dheads=4), dict(cnn_module_kernel=33), dict(mtlalpha=1.0),
+    for bad in (dict(macaron_style=False), dict(adim=128, aheads=2, ddim=256, dheads=2), dict(cnn_module_kernel=33), dict(mtlalpha=1.0),
                 dict(transformer_input_layer="conv1d")):
         with pytest.raises(NotImplementedError):
             E2E(odim, default_lrs_args(**bad))
