@@ -44,8 +44,13 @@ class _SideStream:
         if self.stream is None:
             self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
+        # launches of fn() go to the side stream through ops.STREAM_OVERRIDE (fn allocates nothing on the device), which is
+        # much cheaper on the host than entering a torch.cuda.stream() context per weight-gradient launch
+        ops.STREAM_OVERRIDE = self.stream.cuda_stream
+        try:
             fn()
+        finally:
+            ops.STREAM_OVERRIDE = None
         self.keep.extend(keep)
 
     def join(self) -> None:

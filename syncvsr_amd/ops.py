@@ -20,12 +20,15 @@ HALO_WGRAD = True      # nine-taps-per-pass weight gradient for stride-1 3x3 con
 
 
 _DEV_INDEX: Optional[int] = None
+STREAM_OVERRIDE: Optional[int] = None      # raw hipStream_t that launches go to instead of torch's current stream (model._SideStream)
 
 
 def _stream() -> int:
     """Raw hipStream_t of torch's current stream.  `torch.cuda.current_stream().cuda_stream` builds a Stream object per call
     (~9 us, a fifth of the host time of an eager step); the raw getter is ~0.3 us.  One device per process."""
     global _DEV_INDEX
+    if STREAM_OVERRIDE is not None:
+        return STREAM_OVERRIDE
     if _DEV_INDEX is None:
         _DEV_INDEX = torch.cuda.current_device()
     return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
@@ -42,8 +45,16 @@ def _drop(drop) -> tuple:
     return drop[0].data_ptr(), int(drop[1]), float(drop[2])
 
 
+_INT_ARRAYS: dict = {}
+
+
 def _ints(v: Sequence[int]):
-    return (ctypes.c_int * len(v))(*v)
+    """ctypes int array for a tap list; cached (the same few tap tables recur every step and building one costs ~1 us)."""
+    key = tuple(v)
+    arr = _INT_ARRAYS.get(key)
+    if arr is None:
+        arr = _INT_ARRAYS[key] = (ctypes.c_int * len(key))(*key)
+    return arr
 
 
 # Optional per-launch timing with HIP events (bench.py's roofline leg): {kernel label: [(start, end, flops, bytes)]}.
@@ -111,10 +122,13 @@ def igemm_fwd(inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: i
               out_pre: Optional[torch.Tensor] = None, out_f32: bool = False, relu: bool = False, alpha: float = 1.0, drop=None) -> None:
     dy, dx, tw = zip(*taps)
     M = Nimg * Ha * Wa
-    bm, bn, ns = igemm_fwd_tile(M, Co)
+    label = None
+    if _TIMING is not None:
+        bm, bn, ns = igemm_fwd_tile(M, Co)
+        label = f"k_igemm_fwd_glds<{bm},{bn},{ns}>"
     _call("svsr_igemm_fwd", _p(inp), _p(wt), _p(out), _p(out_pre), _p(bias), _p(addend), _p(stats), Nimg, Hi, Wi, Ci, in_pitch,
           Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw),
-          1 if gelu else (2 if relu else 0), int(out_f32), float(alpha), *_drop(drop), _stream(), label=f"k_igemm_fwd_glds<{bm},{bn},{ns}>", flops=2.0 * M * Co * Ci * len(taps))
+          1 if gelu else (2 if relu else 0), int(out_f32), float(alpha), *_drop(drop), _stream(), label=label, flops=2.0 * M * Co * Ci * len(taps))
 
 
 def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
