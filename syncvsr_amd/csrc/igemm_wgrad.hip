@@ -3,8 +3,9 @@
 // for every nn.Conv2d / nn.Linear of the path (autograd of reference LRW/video/src/tcn/models/resnet.py:8-16,59-72 and
 // lightning.py:82,92,107).  The reduction index m (positions) is the slow index of both operands, so
 // the MFMA fragments (8 consecutive positions for one channel per lane) are produced from position-major LDS tiles by
-// the gfx950 transpose read ds_read_b64_tr_b16; rows are padded by 16 elements so its 4 x 32-byte accesses per
-// 16-lane group fall on disjoint banks.
+// the gfx950 transpose read ds_read_b64_tr_b16.  A 32-lane group of that read touches 4 consecutive rows x 64 bytes, so the
+// row pitch must be 16 * odd banks (mod 64) for the four 16-bank windows to be disjoint: rows are padded by 32 elements
+// (with 16, PMC showed SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.33).
 //
 // Grid: x = split of the position range (64-position chunks), y = (co tile, ci tile, tap).  Block = 4 waves (2x2), tile
 // BC x BC channels of one tap; the next chunk's global loads are issued before the MFMA block of the current one.
@@ -49,7 +50,7 @@ __device__ __forceinline__ bf16x8 load_frag_T(const bf16_t* tile, int ch0, int p
 
 template <bool USE_TR, int BC>
 __global__ __launch_bounds__(256) void k_igemm_wgrad(const IgemmWgradArgs p) {
-    constexpr int PITCH = BC + 16;          // bf16 elements per LDS row
+    constexpr int PITCH = BC + 32;          // bf16 elements per LDS row: 48 (BC 64) / 80 (BC 128) banks = 16 * odd, see below
     constexpr int CPR = BC / 8;             // 16-byte chunks per row
     constexpr int NL = CPR / 8;             // loads per (operand, row) per thread: thread covers chunks c, c+8, ...
     constexpr int WT = BC / 2, TT = WT / 32;  // wave tile edge, 32x32 MFMA tiles per edge

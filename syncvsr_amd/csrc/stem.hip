@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_stem_conv_fwd(const StemFwdArgs p) {
 // even/odd column planes.
 // ------------------------------------------------------------------------------------------------------------
 #define SW_RB 4            // output rows per tile
-#define SW_DPITCH 80       // dY tile row pitch (bf16): 64 + 16 pad
+#define SW_DPITCH 96       // dY tile row pitch (bf16): 192 B = 48 banks -> conflict-free transpose reads (see wgrad3x3.hip)
 
 struct StemWgradArgs {
     const float* vid;

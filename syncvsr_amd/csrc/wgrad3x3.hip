@@ -15,7 +15,9 @@
 #include "common.h"
 
 #define W3_CH 128         // padded positions per chunk
-#define W3_PITCH 80        // bf16 elements per LDS row (64 channels + 16 pad: conflict-free 4 x 32-byte tr-reads)
+#define W3_PITCH 96        // bf16 elements per LDS row: 192 B = 48 banks, so the 4 rows a 32-lane ds_read_b64_tr_b16 group touches
+                           // start at banks 0/48/32/16 and their 16-bank windows are disjoint (pitch 80 = 40 banks made row 3 wrap
+                           // onto row 0: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.45)
 #define W3_MAXXR 192       // max X-tile rows: 128 + 2*(WP+1), i.e. W <= 29
 
 struct Wgrad3Args {
