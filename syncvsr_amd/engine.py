@@ -138,6 +138,19 @@ class TrainStep:
         with torch.cuda.graph(self._graph):
             self._out = self._step_impl(*self._static)
 
+    # -- checkpoint / resume -------------------------------------------------------------------------
+    def state_dict(self) -> dict[str, torch.Tensor]:
+        """Optimiser state for checkpointing (what Lightning stores next to the model's state_dict): AdamW moments as flat
+        fp32 vectors in the parameter store's order, and the 16-byte device state {step, -, lr, grad-norm}."""
+        return {"exp_avg": self.m.detach().clone(), "exp_avg_sq": self.v.detach().clone(), "opt_state": self.opt_state.detach().clone()}
+
+    def load_state_dict(self, sd: dict[str, torch.Tensor]) -> None:
+        if sd["exp_avg"].numel() != self.m.numel():
+            raise ValueError("optimiser state belongs to a different parameter layout")
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+        self.opt_state.copy_(sd["opt_state"])
+
     # -- introspection ------------------------------------------------------------------------------
     def state(self) -> dict[str, float]:
         raw = self.opt_state.cpu()

@@ -168,3 +168,41 @@ def test_side_stream_weight_gradients_equal_inline(which):
     side_cos = min(cos(s_, i_) for s_ in sided for i_ in inline)
     print(which, "inline-vs-inline cosine", base_cos, "side-vs-inline cosine", side_cos)
     assert side_cos >= base_cos - 1.5e-2 and side_cos >= 0.95, (base_cos, side_cos)
+
+
+def test_checkpoint_resume_lrs():
+    """model.state_dict() + TrainStep.state_dict() restore a run exactly: two more steps after a resume give the same losses
+    as the uninterrupted run (the tiny LRS case is bit-stable run to run)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from golden_cases import build_lrs_case
+    from syncvsr_amd.engine import TrainStep, lrs_train_config
+    from syncvsr_amd.lrs_model import E2E
+
+    dev = torch.device("cuda:0")
+    args, odim, sd, batch, training, gold = build_lrs_case("lrs_tiny_b3")
+    tcfg = lrs_train_config(optimizer__lr=5e-4, scheduler__num_warmup_steps=1, scheduler__num_training_steps=10)
+    gb = [t.to(dev) for t in batch]
+
+    def fresh():
+        m = E2E(odim, args)
+        m.load_state_dict(sd)
+        m.to(dev).train()
+        return m, TrainStep(m, tcfg, use_graph=False)
+
+    m1, ts1 = fresh()
+    ref = [ts1.step(*gb)[0].item() for _ in range(4)]
+    m2, ts2 = fresh()
+    first = [ts2.step(*gb)[0].item() for _ in range(2)]
+    ckpt_model = {k: v.detach().cpu().clone() for k, v in m2.state_dict().items()}
+    ckpt_opt = {k: v.cpu() for k, v in ts2.state_dict().items()}
+    m3 = E2E(odim, args)
+    m3.load_state_dict(ckpt_model)
+    m3.to(dev).train()
+    ts3 = TrainStep(m3, tcfg, use_graph=False)
+    ts3.load_state_dict({k: v.to(dev) for k, v in ckpt_opt.items()})
+    resumed = [ts3.step(*gb)[0].item() for _ in range(2)]
+    print("uninterrupted", ref, "resumed", first + resumed)
+    assert ts3.state()["step"] == 4
+    for a, b in zip(first + resumed, ref):
+        assert abs(a - b) <= 2e-4 * abs(b), (first + resumed, ref)
