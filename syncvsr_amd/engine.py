@@ -23,6 +23,11 @@ from .config import Config
 from .model import TransformerLightningModule
 
 
+import os as _os
+
+_ROCTX = _os.environ.get("SVSR_ROCTX", "0") == "1"
+
+
 def lrs_train_config(**kw) -> Config:
     """Optimiser / schedule / clip values of LRS/video/config/lrs3.yaml:66-77,97 in the layout TrainStep reads."""
     cfg = Config(optimizer=Config(lr=1e-3, betas=[0.9, 0.98], eps=1e-6, weight_decay=0.03),
@@ -84,10 +89,19 @@ class TrainStep:
     def _step_impl(self, *batch):
         model = self.model
         st = model.store()
+        trace = _ROCTX                                   # SVSR_ROCTX=1: roctx ranges (rocprofv3 --marker-trace) around the phases
         if self.dp is not None:
             self.dp.begin_step()
+        if trace:
+            torch.cuda.nvtx.range_push("svsr.forward")
         out = model(*batch)
+        if trace:
+            torch.cuda.nvtx.range_pop()
+            torch.cuda.nvtx.range_push("svsr.backward")
         (out["loss_total"] if self.is_lrw else out[0]).backward()
+        if trace:
+            torch.cuda.nvtx.range_pop()
+            torch.cuda.nvtx.range_push("svsr.allreduce_join+optimizer")
         if self.dp is not None:
             self.dp.finish()
         ops.grad_sumsq(st.grad, self.opt_state)
@@ -95,6 +109,8 @@ class TrainStep:
                        self.max_norm, self.warmup, self.total_steps, self.opt_state)
         ops.transpose_cast_multi(st.flat, st.w16t, st.table, st.n_entries)
         st.shadow_fresh = True
+        if trace:
+            torch.cuda.nvtx.range_pop()
         if self.is_lrw:
             return {k: v.detach() for k, v in out.items()}
         return tuple(v.detach() for v in out)
