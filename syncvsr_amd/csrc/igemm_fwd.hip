@@ -502,6 +502,10 @@ extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* o
     a.dbg = dbg;
     const int bm = igemm_fwd_tile_m(a.g.M, Co);
     const bool glds = use_glds();
+    // few-tile convolutions (LRW layer4: 66 x 4 tiles of 128x128 = about one workgroup per CU): 128x64 tiles with a 2-deep ring
+    // fit three workgroups per CU and measure 82 -> 77 us; with more tiles the 128x128 shape wins (layer2 61 vs 66 us)
+    if (glds && bm == 128 && Co > 64 && ntaps > 1 && (long)((a.g.M + 127) / 128) * ((Co + 127) / 128) < 300)
+        return launch_glds<128, 64, 2>(a, (a.g.M + 127) / 128, (Co + 63) / 64, stream);
     if (bm == 128) return Co <= 64 ? launch_fwd<128, 64>(a, glds, stream) : launch_fwd<128, 128>(a, glds, stream);
     return launch_fwd<64, 64>(a, glds, stream);
 }

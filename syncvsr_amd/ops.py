@@ -94,12 +94,14 @@ def _call(name: str, *args, label: Optional[str] = None, flops: float = 0.0, nby
 _CUS: Optional[int] = None
 
 
-def igemm_fwd_tile(M: int, Co: int) -> tuple[int, int, int]:
+def igemm_fwd_tile(M: int, Co: int, ntaps: int = 1) -> tuple[int, int, int]:
     """Mirror of igemm_fwd.hip's tile / ring-depth choice — only used to label launches with the kernel instantiation."""
     global _CUS
     if _CUS is None:
         _CUS = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     bm = (128 if M >= 16384 else 64) if Co <= 64 else (128 if (M >= 8192 or -(-M // 128) * -(-Co // 128) >= 224) else 64)
+    if bm == 128 and Co > 64 and ntaps > 1 and -(-M // 128) * -(-Co // 128) < 300:
+        return 128, 64, 2
     bn = 64 if (bm == 64 or Co <= 64) else 128
     blocks = -(-M // bm) * -(-Co // bn)
     ns = 2 if bm + bn > 192 else (3 if bm + bn > 128 else (4 if blocks <= _CUS * 5 // 2 else 3))
@@ -124,7 +126,7 @@ def igemm_fwd(inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: i
     M = Nimg * Ha * Wa
     label = None
     if _TIMING is not None:
-        bm, bn, ns = igemm_fwd_tile(M, Co)
+        bm, bn, ns = igemm_fwd_tile(M, Co, len(taps))
         label = f"k_igemm_fwd_glds<{bm},{bn},{ns}>"
     _call("svsr_igemm_fwd", _p(inp), _p(wt), _p(out), _p(out_pre), _p(bias), _p(addend), _p(stats), Nimg, Hi, Wi, Ci, in_pitch,
           Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw),
