@@ -157,7 +157,7 @@ extern "C" int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int 
     a.inv_q = 1.0f / (float)a.Q; a.inv_wp = 1.0f / (float)a.WP;
     a.total_chunks = (a.Qtot + W3_CH - 1) / W3_CH;
     const int tasks = (Co / 64) * (Ci / 64);
-    static const int target_blocks = [] { const char* e = getenv("SVSR_W3_BLOCKS"); return e ? atoi(e) : 512; }();
+    static const int target_blocks = [] { const char* e = getenv("SVSR_W3_BLOCKS"); return e ? atoi(e) : 384; }();   // measured optimum (256..1024 swept)
     int splits = (target_blocks + tasks - 1) / tasks;         // every workgroup ends with 9*64*64 atomics
     if (splits > a.total_chunks) splits = a.total_chunks;
     a.chunks_per_block = (a.total_chunks + splits - 1) / splits;
