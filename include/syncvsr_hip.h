@@ -7,8 +7,14 @@
  *   - arguments are raw device pointers + explicit sizes; `void*` activations are bf16 unless stated; parameters,
  *     statistics and gradients are fp32.  The caller owns every buffer, including workspaces.
  *   - asynchronous: work is enqueued on `stream`; the call returns 0, SVSR_ERR_ARG (1001) for an unsupported
- *     shape/argument, or a hipError_t value if the launch failed.  Nothing throws; no global mutable state.
+ *     shape/argument, or a hipError_t value if the launch failed.  Nothing throws; the only global mutable state is the
+ *     table of result-preserving tuning knobs behind svsr_tune() (the library never reads the environment).
  *   - activations are NHWC ("pixels x channels"); a frame index is just the leading pixel index.
+ *   - REPRODUCIBLE: no kernel accumulates floating-point values with atomics.  Grid-wide sums (BatchNorm statistics, split-K
+ *     weight gradients, bias / LayerNorm gradients, losses, the gradient norm) are written as one partial row per workgroup
+ *     into a caller-owned workspace and added in a fixed order by a second small launch (svsr_colsum_rows or a specialised
+ *     finaliser), so two identical calls give bit-identical results.  Entry points named *_rows / *_plan are HOST-side
+ *     queries (no launch) that tell the caller how large such a workspace must be for a shape.
  *
  * The declarations are kept one per statement in a regular form because syncvsr_amd/_lib.py derives its ctypes
  * signatures from this file.
@@ -26,11 +32,18 @@ typedef void* hipStream_t;
 
 #define SVSR_OK 0
 #define SVSR_ERR_ARG 1001
-#define SVSR_STAT_SLOTS 16
 
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* ---- plumbing (runtime.hip) ------------------------------------------------------------------------------------
+ * svsr_tune: sets a result-preserving tuning knob ("igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb",
+ * "stem_lds_fwd", "stem_lds_bwd"); unknown key -> SVSR_ERR_ARG.
+ * svsr_colsum_rows: out[c] (+)= scale * sum_{r<nrows} ws[r*ld + c], rows added in a fixed order; columns [0,n0) go to out0,
+ * [n0,n0+n1) to out1 (may be null when n1 = 0); accumulate != 0 adds to the existing values. */
+int svsr_tune(const char* key, int value);
+int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale, hipStream_t stream);
 
 /* ---- implicit-GEMM contractions (igemm.hip) ------------------------------------------------------------------
  * Iteration space: M = Nimg*Ha*Wa positions (n,a,b); source pixel (a*S+dy[t], b*S+dx[t]) of `in` [Nimg][Hi][Wi]
@@ -45,38 +58,53 @@ extern "C" {
  *   act 0 none / 1 exact GELU (pre-activation saved to out_pre) / 2 ReLU (LRS PositionwiseFeedForward,
  *   transformer/positionwise_feed_forward.py:28-30; alpha carries the Conformer's 0.5 macaron scale and the
  *   sqrt(d) embedding scale, encoder_layer.py:97,131, embedding.py:208); dropout(p) on act(acc+bias) with the keep decision
- *   hash(*drop_seed, drop_site, output element index) (drop_seed null or p = 0: off; see svsr_scale_bf16), fp32 output, per-channel BatchNorm partial sums into
- *   stats[SVSR_STAT_SLOTS][2][Co] (accumulated with atomics; zeroed by svsr_bn_finalize). */
+ *   hash(*drop_seed, drop_site, output element index) (drop_seed null or p = 0: off; see svsr_scale_bf16), fp32 output, per-channel BatchNorm partial sums:
+ *   stats[rows][2][Co], row = M tile (plain stores; rows from svsr_igemm_fwd_plan; reduced by svsr_bn_finalize).
+ * svsr_igemm_fwd_plan (host query): the kernel instantiation chosen for (M = Nimg*Ha*Wa, Co, ntaps) — tile bm x bn, ring
+ *   depth ns — and stat_rows = number of partial rows written. */
+int svsr_igemm_fwd_plan(int M, int Co, int ntaps, int* bm, int* bn, int* ns, int* stat_rows);
 int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int act, int out_f32, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 
 /* svsr_igemm_wgrad replaces: the weight-gradient of the same Conv2d / Linear layers (torch autograd).
- * dw fp32 [Co][wt_taps][Ci] is ACCUMULATED (atomics).  x = forward input pixels, dyp = output-gradient pixels.
- * dbias (optional, fp32 [Co]) += column sums of dyp = the bias gradient of an nn.Linear, taken from tiles the kernel stages anyway. */
-int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int use_tr, float* dbias, hipStream_t stream);
+ * dw fp32 [Co][wt_taps][Ci] is ACCUMULATED (dw += ...).  x = forward input pixels, dyp = output-gradient pixels.
+ * dbias (optional, fp32 [Co]) += column sums of dyp = the bias gradient of an nn.Linear, taken from tiles the kernel stages anyway.
+ * Split-K slabs go to `part` (part_floats >= the value svsr_igemm_wgrad_plan reports for M = Nimg*Ha*Wa; any contents) and are
+ * added into dw / dbias in a fixed order. */
+int svsr_igemm_wgrad_plan(int M, int Co, int Ci, int ntaps, int wt_taps, int has_bias, int* bc, int* splits, int64_t* part_floats);
+int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int use_tr, float* dbias, float* part, int64_t part_floats, hipStream_t stream);
 
 /* svsr_conv3x3_c64: conv3x3(64, 64), stride 1, pad 1 (layer1 of the trunk, resnet.py:8-10,36,53) forward and, with the
  * transposed weights and mirrored taps, its input-gradient; persistent workgroups, weights resident in LDS
  * (conv3x3_c64.hip).  in/out/addend bf16 [Nimg][H][W][64]; wt bf16 [64][9][64]; tap t reads pixel (y+dy[t], x+dx[t]) with
- * weight tap tw[t] (HOST arrays of 9 ints); out = conv (+ addend); stats as in svsr_igemm_fwd.  Requires W <= 29. */
+ * weight tap tw[t] (HOST arrays of 9 ints); out = conv (+ addend); stats [rows][2][64] with rows =
+ * svsr_conv3x3_c64_stat_rows(Nimg, H, W) (one per persistent workgroup).  Requires W <= 29. */
+int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W);
 int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, const int* dy, const int* dx, const int* tw, hipStream_t stream);
 
 /* svsr_conv3x3_wgrad: weight gradient of a 3x3 / stride-1 / pad-1 Conv2d (resnet.py:8-10) with all nine taps sharing one
  * pass over x [Nimg][H][W][Ci] and dy [Nimg][H][W][Co] (zero-padded coordinates, wgrad3x3.hip).  dw fp32 [Co][9][Ci] is
- * ACCUMULATED.  Requires Ci, Co multiples of 64 and W <= 29; other shapes go through svsr_igemm_wgrad. */
-int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Ci, int Co, hipStream_t stream);
+ * ACCUMULATED; split-K slabs go through `part` (size from svsr_conv3x3_wgrad_plan) and are added in a fixed order.
+ * Requires Ci, Co multiples of 64 and W <= 29; other shapes go through svsr_igemm_wgrad. */
+int svsr_conv3x3_wgrad_plan(int Nimg, int H, int W, int Ci, int Co, int* splits, int64_t* part_floats);
+int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Ci, int Co, float* part, int64_t part_floats, hipStream_t stream);
 
 /* ---- 3-D stem (stem.hip) --------------------------------------------------------------------------------------
  * svsr_stem_conv_fwd replaces stem3d[0] = nn.Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3),bias=False) (lightning.py:50).
- * vid fp32 [B][1][T][H][W]; w fp32 [64][1][5][7][7]; out bf16 [B*T][H/2][W/2][64]; stats as above (64 channels). */
+ * vid fp32 [B][1][T][H][W]; w fp32 [64][1][5][7][7]; out bf16 [B*T][H/2][W/2][64]; stats [rows][2][64] with rows =
+ * svsr_stem_conv_fwd_stat_rows(B, T, H, W). */
+int svsr_stem_conv_fwd_stat_rows(int B, int T, int H, int W);
 int svsr_stem_conv_fwd(const float* vid, const float* w, void* out, float* stats, int B, int T, int H, int W, hipStream_t stream);
 
-/* weight gradient of the stem conv (autograd of lightning.py:50); dw fp32 [64][245] accumulated. */
-int svsr_stem_conv_wgrad(const float* vid, const void* dy, float* dw, int B, int T, int H, int W, int use_tr, hipStream_t stream);
+/* weight gradient of the stem conv (autograd of lightning.py:50); dw fp32 [64][245] accumulated (per-workgroup slabs in
+ * `part`, size from svsr_stem_conv_wgrad_plan, added in a fixed order). */
+int svsr_stem_conv_wgrad_plan(int B, int T, int H, int W, int* splits, int64_t* part_floats);
+int svsr_stem_conv_wgrad(const float* vid, const void* dy, float* dw, int B, int T, int H, int W, int use_tr, float* part, int64_t part_floats, hipStream_t stream);
 
 /* ---- BatchNorm / activation / pooling passes (norm_act.hip) ---------------------------------------------------
- * svsr_bn_finalize: train-mode statistics of nn.BatchNorm2d/3d (lightning.py:51; resnet.py:37,54,14): reduces the
- * slots, writes mean/rstd, updates running_mean/var (momentum, unbiased var) and num_batches_tracked, zeroes slots. */
-int svsr_bn_finalize(float* slots, int C, float count, float eps, float momentum, float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, hipStream_t stream);
+ * svsr_bn_finalize: train-mode statistics of nn.BatchNorm2d/3d (lightning.py:51; resnet.py:37,54,14): adds the nrows
+ * partial rows part[nrows][2][C] written by the producing convolution in a fixed order (double accumulation), writes
+ * mean/rstd, updates running_mean/var (momentum, unbiased var) and num_batches_tracked. */
+int svsr_bn_finalize(const float* part, int nrows, int C, float count, float eps, float momentum, float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, hipStream_t stream);
 
 /* eval-mode statistics: mean = running_mean, rstd = rsqrt(running_var + eps). */
 int svsr_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd, hipStream_t stream);
@@ -87,8 +115,9 @@ int svsr_bn_eval_prepare(const float* running_mean, const float* running_var, in
 int svsr_bn_act_fwd(const void* x, const void* res, void* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int64_t npix, int C, int act, hipStream_t stream);
 
 /* backward of the above: dgamma/dbeta accumulated; dx (grad of the conv output) and optional dres (= masked dy).
- * slots [SVSR_STAT_SLOTS][2][C] zeroed workspace (left zeroed); coef [3][C] scratch.  Swish recomputes its
+ * slots: workspace of svsr_bn_act_bwd_rows(npix, C) rows of [2][C] floats (any contents); coef [3][C] scratch.  Swish recomputes its
  * pre-activation and therefore needs beta and the forward's residual input `res` (null if there was none). */
+int svsr_bn_act_bwd_rows(int64_t npix, int C);
 int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, float* slots, float* coef, float* dgamma, float* dbeta, void* dx, void* dres, int64_t npix, int C, int act, const float* beta, const void* res, hipStream_t stream);
 
 /* stem3d[1..3]: BatchNorm3d -> activation -> MaxPool3d((1,3,3),(1,2,2),(0,1,1)) fused; act 1 = exact nn.GELU()
@@ -96,7 +125,9 @@ int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* m
  * x [N][Hc][Wc][C] -> y [N][Hp][Wp][C], amax uint8 [N][Hp][Wp][C] = window-local argmax (first max wins). */
 int svsr_stem_bn_act_pool_fwd(const void* x, void* y, void* amax, const float* mean, const float* rstd, const float* gamma, const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, hipStream_t stream);
 
-/* backward of the fused stem pass: dx = gradient of the stem conv output. */
+/* backward of the fused stem pass: dx = gradient of the stem conv output; slots: workspace of
+ * svsr_stem_bn_act_pool_bwd_rows(N, Hc, Wc, C) rows of [2][C] floats. */
+int svsr_stem_bn_act_pool_bwd_rows(int N, int Hc, int Wc, int C);
 int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* slots, float* coef, float* dgamma, float* dbeta, void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, hipStream_t stream);
 
 /* hidden.mean((2,3)) (lightning.py:118) and its backward: [N][HW][C] <-> [N][C]. */
@@ -106,36 +137,37 @@ int svsr_avgpool_bwd(const void* dy, void* dx, int64_t N, int HW, int C, hipStre
 /* ---- transformer encoder passes (bert.hip) --------------------------------------------------------------------
  * y = LayerNorm(a + r) (BertSelfOutput / BertOutput, reached from lightning.py:152-156; LRS transformer/layer_norm.py);
  * r may be null; any D % 8 == 0 up to 2048.  The backward returns ds = dLN/d(a+r) (+ addend: the skip-path gradient of a
- * pre-LN residual block, encoder_layer.py:93-137). */
+ * pre-LN residual block, encoder_layer.py:93-137); dgamma/dbeta are accumulated from per-workgroup partial rows in `part`
+ * (svsr_add_ln_bwd_rows(R) rows of [2][D] floats). */
 int svsr_add_ln_fwd(const void* a, const void* r, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int R, int D, float eps, hipStream_t stream);
-int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd, void* ds, float* dgamma, float* dbeta, int R, int D, const void* addend, hipStream_t stream);
+int svsr_add_ln_bwd_rows(int R);
+int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd, void* ds, float* dgamma, float* dbeta, int R, int D, const void* addend, float* part, hipStream_t stream);
 
 /* BertEmbeddings on inputs_embeds = cat(cls_token, feats) (lightning.py:149-156): y = LN(e + pos[s] + type[0]).
- * feats bf16 [B][S-1][D]; sum_out bf16 [B*S][D] keeps the pre-norm sum for the backward. */
+ * feats bf16 [B][S-1][D]; sum_out bf16 [B*S][D] keeps the pre-norm sum for the backward (part: [S][D] float workspace). */
 int svsr_embed_ln_fwd(const void* feats, const float* cls, const float* pos, const float* type0, const float* gamma, const float* beta, void* sum_out, void* y, float* mean, float* rstd, int B, int S, int D, float eps, hipStream_t stream);
-int svsr_embed_bwd_scatter(const void* ds, void* dfeats, float* dcls, float* dpos, float* dtype0, int B, int S, int D, hipStream_t stream);
-
-/* BertSelfAttention core for S <= 64, head dim 64: qkv bf16 [B*S][3*H*64] (q|k|v), ctx bf16 [B*S][H*64],
- * probs bf16 [B*H][S][S] (saved softmax). */
-int svsr_attn_fwd(const void* qkv, void* ctx, void* probs, int B, int S, int H, int dh, float scale, hipStream_t stream);
-int svsr_attn_bwd(const void* dctx, const void* qkv, const void* probs, void* dqkv, int B, int S, int H, int dh, float scale, hipStream_t stream);
+int svsr_embed_bwd_scatter(const void* ds, void* dfeats, float* dcls, float* dpos, float* dtype0, int B, int S, int D, float* part, hipStream_t stream);
 
 /* dz = dy * act'(z) when z != null: act 1 = GELU from the saved pre-activation (BertIntermediate), act 2 = ReLU from the
  * saved output (PositionwiseFeedForward; gscale = 1/(1-p) when that output went through dropout — dropped elements are
- * exactly the zeros of the saved output); db[n] += column sums (bias gradient of any nn.Linear; db may be null). */
-int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, float gscale, hipStream_t stream);
+ * exactly the zeros of the saved output); db[n] += column sums (bias gradient of any nn.Linear; db may be null), via
+ * svsr_bias_act_bwd_rows(R, N) partial rows of [N] floats in `part` (0 rows: a single row slab adds into db directly). */
+int svsr_bias_act_bwd_rows(int R, int N);
+int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, float gscale, float* part, hipStream_t stream);
 
 /* ---- losses / metric / optimiser (loss_optim.hip) --------------------------------------------------------------
  * F.cross_entropy(logits.float(), target, label_smoothing) mean over R rows (lightning.py:163-165,171): exactly one of
- * target_idx (int64 [R]) / target_prob (fp32 [R][V], pitch ldt) is non-null.  loss_sum += mean loss (zero it first). */
-int svsr_ce_fwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt, int R, int V, float smoothing, float* loss_sum, float* lse, hipStream_t stream);
+ * target_idx (int64 [R]) / target_prob (fp32 [R][V], pitch ldt) is non-null.  *loss = mean loss (row losses land in
+ * row_loss [R] and are added in a fixed order).  A target index outside [0, V) yields NaN (torch raises a device assert). */
+int svsr_ce_fwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt, int R, int V, float smoothing, float* loss, float* lse, float* row_loss, hipStream_t stream);
 int svsr_ce_bwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt, int R, int V, float smoothing, const float* lse, const float* gout, void* dlogits, int ldo, hipStream_t stream);
 
-/* top-1 / top-5 accuracy (lightning.py:177-183); out2 += {top1, top5} (zero it first). */
-int svsr_topk_acc(const float* logits, const int64_t* labels, const float* soft_labels, int B, int C, float* out2, hipStream_t stream);
+/* top-1 / top-5 accuracy (lightning.py:177-183); out2 = {top1, top5}; rows2: [B][2] float workspace. */
+int svsr_topk_acc(const float* logits, const int64_t* labels, const float* soft_labels, int B, int C, float* out2, float* rows2, hipStream_t stream);
 
 /* clip_grad_norm_ + AdamW + HF cosine-with-warm-up (lightning.py:216-223; Lightning gradient_clip_val).
- * opt_state: 16-byte device struct {int step; float sumsq; float lr_last; float gnorm_last}, zero-initialised. */
+ * opt_state: device struct {int step; float sumsq; float lr_last; float gnorm_last; float part[1024]} (4112 bytes),
+ * zero-initialised; svsr_grad_sumsq writes the 1024 partial sums of squares, svsr_adamw_step adds them in a fixed order. */
 int svsr_grad_sumsq(const float* g, int64_t n, void* opt_state, hipStream_t stream);
 int svsr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, int64_t decay_end, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, int warmup, int total_steps, void* opt_state, hipStream_t stream);
 
@@ -162,7 +194,8 @@ int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, c
 
 /* Conformer convolution module core (transformer/convolution.py:56-75): u [B*T][2D] = pointwise_cov1 output ->
  * GLU -> depthwise Conv1d(K odd <= 31, pad (K-1)/2, weight [D][K], bias) -> c [B*T][D] bf16 + BatchNorm1d partial sums
- * into stats[SVSR_STAT_SLOTS][2][D] (finalised by svsr_bn_finalize; BN+Swish itself is svsr_bn_act_fwd act 2). */
+ * stats[rows][2][D], rows = svsr_glu_dwconv_fwd_stat_rows(B, T) (finalised by svsr_bn_finalize; BN+Swish itself is svsr_bn_act_fwd act 2). */
+int svsr_glu_dwconv_fwd_stat_rows(int B, int T);
 int svsr_glu_dwconv_fwd(const void* u, const float* w, const float* bias, void* c, float* stats, int B, int T, int D, int K, hipStream_t stream);
 
 /* backward: dc = gradient of c -> du [B*T][2D]; dw [D][K] and dbias [D] accumulated.  part: fp32 workspace of
@@ -171,8 +204,8 @@ int svsr_glu_dwconv_bwd(const void* dc, const void* u, const float* w, void* du,
 
 /* CTC loss as the reference calls it (ctc.py:44-74,83-151): log_softmax over V, torch.nn.CTCLoss(reduction="sum",
  * zero_infinity=True), blank 0, divided by the batch size.  logits fp32 [B*T][ld]; labels int64 [B][Lmax] padded with -1
- * at the tail; ilen int32 [B].  Workspaces: lse [B*T], ab [B][T][2*Lmax+1], nll [B].  loss_sum += sum_b nll_b / B. */
-int svsr_ctc_fwd(const float* logits, int ld, const int64_t* labels, int Lmax, const int* ilen, int B, int T, int V, float* lse, float* ab, float* nll, float* loss_sum, hipStream_t stream);
+ * at the tail; ilen int32 [B].  Workspaces: lse [B*T], ab [B][T][2*Lmax+1], nll [B].  *loss = sum_b nll_b / B. */
+int svsr_ctc_fwd(const float* logits, int ld, const int64_t* labels, int Lmax, const int* ilen, int B, int T, int V, float* lse, float* ab, float* nll, float* loss, hipStream_t stream);
 
 /* dlogits [B*T][ldo] bf16 = gout/B * (softmax - label occupancy) for t < ilen[b], 0 elsewhere (and for infeasible targets). */
 int svsr_ctc_grad(const float* logits, int ld, const int64_t* labels, int Lmax, const int* ilen, int B, int T, int V, const float* lse, const float* ab, const float* nll, const float* gout, void* dlogits, int ldo, hipStream_t stream);
@@ -184,9 +217,9 @@ int svsr_embed_pos_bwd(const int64_t* tok, const void* dx, float* demb, int R, i
 
 /* ESPnet LabelSmoothingLoss (label_smoothing_loss.py:41-63): KL(true || softmax(logits)) summed over rows whose target
  * is not -1, times inv_denom (1/batch, or 1/#tokens with length normalisation); true = 1-smoothing at the target and
- * smoothing/(V-1) elsewhere.  counts[0] += rows whose argmax equals the target, counts[1] += live rows (th_accuracy,
- * nets_utils.py:303-323).  logits fp32 [R][ld]; lse [R] saved for the backward. */
-int svsr_ls_loss_fwd(const float* logits, int ld, const int64_t* target, int R, int V, float smoothing, float inv_denom, float* loss_sum, float* lse, float* counts, hipStream_t stream);
+ * smoothing/(V-1) elsewhere.  counts[0] = rows whose argmax equals the target, counts[1] = live rows (th_accuracy,
+ * nets_utils.py:303-323).  logits fp32 [R][ld]; lse [R] saved for the backward; rows3: [R][3] float workspace. */
+int svsr_ls_loss_fwd(const float* logits, int ld, const int64_t* target, int R, int V, float smoothing, float inv_denom, float* loss, float* lse, float* counts, float* rows3, hipStream_t stream);
 int svsr_ls_loss_bwd(const float* logits, int ld, const int64_t* target, int R, int V, float smoothing, float inv_denom, const float* lse, const float* gout, void* dlogits, int ldo, hipStream_t stream);
 
 /* y = alpha * dropout_p(x) over n (multiple of 8) contiguous bf16 elements (y may alias x).  Dropout everywhere in this

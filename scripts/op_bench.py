@@ -57,8 +57,7 @@ def main():
         wt = w.permute(3, 1, 2, 0).contiguous()
         flops = 2.0 * N * hw * hw * ci * co * 9
         if "fwd" in which:
-            slots = torch.zeros(ops.STAT_SLOTS * 2 * co, device=dev)
-            us = timeit(lambda: ops.conv2d_fwd(x, w, 3, 1, 1, stats=slots))
+            us = timeit(lambda: ops.conv2d_fwd(x, w, 3, 1, 1, want_stats=True))
             print(f"{name} conv3x3 fwd   {us:8.1f} us  {flops / us / 1e6:7.1f} TF")
         if "dgrad" in which:
             us = timeit(lambda: ops.conv2d_dgrad(dy, wt, 3, 1, 1, (hw, hw)))
@@ -119,9 +118,8 @@ def main():
     if "stem" in which:
         vid = torch.randn(32, 1, 29, 88, 88, device=dev)
         w = torch.randn(64 * 245, device=dev) * 0.05
-        slots = torch.zeros(ops.STAT_SLOTS * 2 * 64, device=dev)
         flops = 2.0 * N * 44 * 44 * 64 * 245
-        us = timeit(lambda: ops.stem_conv_fwd(vid, w, slots))
+        us = timeit(lambda: ops.stem_conv_fwd(vid, w, want_stats=True))
         print(f"stem conv fwd   {us:8.1f} us  {flops / us / 1e6:7.1f} TF")
         dy = torch.randn(N, 44, 44, 64, device=dev).to(BF)
         dw = torch.zeros(64 * 245, device=dev)
@@ -134,7 +132,7 @@ def main():
         y, amax = ops.stem_bn_gelu_pool_fwd(c, mean, rstd, g, b)
         dp = torch.randn_like(y)
         coef = torch.empty(192, device=dev); dg = torch.zeros(64, device=dev); db = torch.zeros(64, device=dev)
-        us = timeit(lambda: ops.stem_bn_gelu_pool_bwd(dp, amax, c, mean, rstd, g, b, slots, coef, dg, db))
+        us = timeit(lambda: ops.stem_bn_gelu_pool_bwd(dp, amax, c, mean, rstd, g, b, coef, dg, db))
         print(f"stem bn+gelu+pool bwd {us:8.1f} us")
     if "ew" in which:
         for name, hw, ci, co in LAYERS:
@@ -144,9 +142,9 @@ def main():
             us = timeit(lambda: ops.bn_act_fwd(x, res, mean, rstd, g, b, 1))
             print(f"{name} bn_act_fwd(+res) {us:7.1f} us  {x.numel() * 2 * 3 / us / 1e6:5.2f} TB/s")
             y = ops.bn_act_fwd(x, res, mean, rstd, g, b, 1)
-            slots = torch.zeros(ops.STAT_SLOTS * 2 * co, device=dev); coef = torch.empty(3 * co, device=dev)
+            coef = torch.empty(3 * co, device=dev)
             dg = torch.zeros(co, device=dev); db = torch.zeros(co, device=dev)
-            us = timeit(lambda: ops.bn_act_bwd(res, y, x, mean, rstd, g, slots, coef, dg, db, 1, True))
+            us = timeit(lambda: ops.bn_act_bwd(res, y, x, mean, rstd, g, coef, dg, db, 1, True))
             print(f"{name} bn_act_bwd(+res) {us:7.1f} us  {x.numel() * 2 * 8 / us / 1e6:5.2f} TB/s")
 
 

@@ -1,6 +1,7 @@
 // Transformer-encoder passes that are not plain contractions (gfx950, wave64):
-//   embeddings (+position +token-type) -> LayerNorm; residual add -> LayerNorm; softmax attention for short
-//   sequences (one workgroup per (batch, head), everything LDS-resident); bias/GELU backward with column sums.
+//   embeddings (+position +token-type) -> LayerNorm; residual add -> LayerNorm; bias/GELU backward with column sums.
+// (Attention itself is csrc/mha.hip.)  Parameter gradients that are column sums over the rows (LayerNorm gamma/beta, biases,
+// the token-type embedding) are written as one partial row per workgroup and added by svsr_colsum_rows in a fixed order.
 // Replaces HF BertModel's BertEmbeddings / BertSelfAttention / BertSelfOutput / BertOutput non-GEMM work as
 // reached from reference LRW/video/src/lightning.py:92,152-156.  LayerNorm eps is
 // 1e-12 (BertConfig default), far below bf16 resolution, so all statistics are fp32.
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd(const bf16_t* __restrict__ a
 __global__ __launch_bounds__(256) void k_add_ln_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ a,
                                                     const bf16_t* __restrict__ r, const float* __restrict__ gamma,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                    bf16_t* __restrict__ ds, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                    bf16_t* __restrict__ ds, float* __restrict__ part,
                                                     int R, int D, const bf16_t* __restrict__ addend) {
     extern __shared__ float sred_dyn[];          // [4 waves][2][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -118,9 +119,10 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const bf16_t* __restrict__ d
                 sred_dyn[(wave * 2 + 1) * D + (i * 64 + lane) * 8 + k] = ab[i][k];
             }
     __syncthreads();
+    float* row = part + (long)blockIdx.x * 2 * D;          // this workgroup's partial [dgamma | dbeta]
     for (int c = threadIdx.x; c < D; c += 256) {
-        atomicAdd(dgamma + c, sred_dyn[0 * D + c] + sred_dyn[2 * D + c] + sred_dyn[4 * D + c] + sred_dyn[6 * D + c]);
-        atomicAdd(dbeta + c, sred_dyn[1 * D + c] + sred_dyn[3 * D + c] + sred_dyn[5 * D + c] + sred_dyn[7 * D + c]);
+        row[c] = ((sred_dyn[0 * D + c] + sred_dyn[2 * D + c]) + sred_dyn[4 * D + c]) + sred_dyn[6 * D + c];
+        row[D + c] = ((sred_dyn[1 * D + c] + sred_dyn[3 * D + c]) + sred_dyn[5 * D + c]) + sred_dyn[7 * D + c];
     }
 }
 
@@ -183,10 +185,11 @@ __global__ __launch_bounds__(256) void k_embed_ln_fwd(const bf16_t* __restrict__
 }
 
 // scatter of the embedding-sum gradient ds [B*S][D] (bf16):  dfeats = ds[:,1:], dcls += sum_b ds[b,0],
-// dpos[s] += sum_b ds[b,s], dtype0 += sum ds.   One thread per 8 columns, loops over the batch.
+// dpos[s] += sum_b ds[b,s]; part[s] = sum_b ds[b,s] (the token-type gradient is its column sum, added by svsr_colsum_rows).
+// One thread per 8 columns, loops over the batch.
 __global__ __launch_bounds__(256) void k_embed_bwd_scatter(const bf16_t* __restrict__ ds, bf16_t* __restrict__ dfeats,
                                                            float* __restrict__ dcls, float* __restrict__ dpos,
-                                                           float* __restrict__ dtype0, int B, int S, int D) {
+                                                           float* __restrict__ part, int B, int S, int D) {
     const int cv = D >> 3;
     const int idx = blockIdx.x * 256 + threadIdx.x;       // over S * cv
     if (idx >= S * cv) return;
@@ -205,120 +208,8 @@ __global__ __launch_bounds__(256) void k_embed_bwd_scatter(const bf16_t* __restr
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         dpos[(long)s_ * D + c0 + k] += acc[k];              // each (s, c) is owned by exactly one thread
-        atomicAdd(dtype0 + c0 + k, acc[k]);
+        part[(long)s_ * D + c0 + k] = acc[k];
         if (s_ == 0) dcls[c0 + k] += acc[k];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// softmax attention, S <= 64, head dim 64: one workgroup per (b, h).  qkv: [B*S][3*D] (q | k | v), ctx: [B*S][D].
-// ---------------------------------------------------------------------------------------------------------
-#define AT_DH 64
-#define AT_LD 65
-
-__global__ __launch_bounds__(256) void k_attn_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                  bf16_t* __restrict__ probs, int B, int S, int H, float scale) {
-    extern __shared__ float sm[];
-    float* sQ = sm;
-    float* sK = sQ + S * AT_LD;
-    float* sV = sK + S * AT_LD;
-    float* sP = sV + S * AT_LD;          // [S][S+1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const int D = H * AT_DH;
-    for (int e = tid; e < S * 8 * 3; e += 256) {
-        const int which = e / (S * 8), rem = e - which * (S * 8);
-        const int i = rem >> 3, c = (rem & 7) * 8;
-        float f[8];
-        unpack8(*reinterpret_cast<const u32x4*>(qkv + ((long)(b * S + i) * 3 + which) * D + h * AT_DH + c), f);
-        float* dst = (which == 0 ? sQ : which == 1 ? sK : sV) + i * AT_LD + c;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dst[k] = f[k];
-    }
-    __syncthreads();
-    for (int e = tid; e < S * S; e += 256) {
-        const int i = e / S, j = e - i * S;
-        float acc = 0.f;
-#pragma unroll 16
-        for (int d = 0; d < AT_DH; ++d) acc += sQ[i * AT_LD + d] * sK[j * AT_LD + d];
-        sP[i * (S + 1) + j] = acc * scale;
-    }
-    __syncthreads();
-    for (int i = wave; i < S; i += 4) {
-        const float v = lane < S ? sP[i * (S + 1) + lane] : -INFINITY;
-        const float m = wave_max(v);
-        const float ex = lane < S ? __expf(v - m) : 0.f;
-        const float sum = wave_sum(ex);
-        const float pr = ex / sum;
-        if (lane < S) {
-            sP[i * (S + 1) + lane] = pr;
-            if (probs != nullptr) probs[((long)blockIdx.x * S + i) * S + lane] = f2bf(pr);
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < S * AT_DH; e += 256) {
-        const int i = e >> 6, d = e & 63;
-        float acc = 0.f;
-        for (int j = 0; j < S; ++j) acc += sP[i * (S + 1) + j] * sV[j * AT_LD + d];
-        ctx[(long)(b * S + i) * D + h * AT_DH + d] = f2bf(acc);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_attn_bwd(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ qkv,
-                                                  const bf16_t* __restrict__ probs, bf16_t* __restrict__ dqkv,
-                                                  int B, int S, int H, float scale) {
-    extern __shared__ float sm[];
-    float* sQ = sm;
-    float* sK = sQ + S * AT_LD;
-    float* sV = sK + S * AT_LD;
-    float* sO = sV + S * AT_LD;          // dO
-    float* sP = sO + S * AT_LD;          // [S][S+1]
-    float* sD = sP + S * (S + 1);        // dS
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const int D = H * AT_DH;
-    for (int e = tid; e < S * 8 * 4; e += 256) {
-        const int which = e / (S * 8), rem = e - which * (S * 8);
-        const int i = rem >> 3, c = (rem & 7) * 8;
-        float f[8];
-        if (which < 3) unpack8(*reinterpret_cast<const u32x4*>(qkv + ((long)(b * S + i) * 3 + which) * D + h * AT_DH + c), f);
-        else unpack8(*reinterpret_cast<const u32x4*>(dctx + (long)(b * S + i) * D + h * AT_DH + c), f);
-        float* dst = (which == 0 ? sQ : which == 1 ? sK : which == 2 ? sV : sO) + i * AT_LD + c;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dst[k] = f[k];
-    }
-    for (int e = tid; e < S * S; e += 256) {
-        const int i = e / S, j = e - i * S;
-        sP[i * (S + 1) + j] = bf2f(probs[((long)blockIdx.x * S + i) * S + j]);
-    }
-    __syncthreads();
-    for (int e = tid; e < S * S; e += 256) {       // dP = dO V^T
-        const int i = e / S, j = e - i * S;
-        float acc = 0.f;
-#pragma unroll 16
-        for (int d = 0; d < AT_DH; ++d) acc += sO[i * AT_LD + d] * sV[j * AT_LD + d];
-        sD[i * (S + 1) + j] = acc;
-    }
-    __syncthreads();
-    for (int i = wave; i < S; i += 4) {            // dS = P * (dP - sum_j dP*P) * scale
-        const float pr = lane < S ? sP[i * (S + 1) + lane] : 0.f;
-        const float dp = lane < S ? sD[i * (S + 1) + lane] : 0.f;
-        const float rs = wave_sum(pr * dp);
-        if (lane < S) sD[i * (S + 1) + lane] = pr * (dp - rs) * scale;
-    }
-    __syncthreads();
-    for (int e = tid; e < S * AT_DH; e += 256) {
-        const int i = e >> 6, d = e & 63;
-        float dq = 0.f, dk = 0.f, dv = 0.f;
-        for (int j = 0; j < S; ++j) {
-            dq += sD[i * (S + 1) + j] * sK[j * AT_LD + d];
-            dk += sD[j * (S + 1) + i] * sQ[j * AT_LD + d];
-            dv += sP[j * (S + 1) + i] * sO[j * AT_LD + d];
-        }
-        bf16_t* o = dqkv + (long)(b * S + i) * 3 * D + h * AT_DH + d;
-        o[0] = f2bf(dq);
-        o[D] = f2bf(dk);
-        o[2 * D] = f2bf(dv);
     }
 }
 
@@ -326,8 +217,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd(const bf16_t* __restrict__ dct
 // dz = dy * gelu'(z) (optional), db[n] += sum_rows dz      — thread owns 8 columns, block covers a row slab
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bias_act_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ z,
-                                                      bf16_t* __restrict__ dz, float* __restrict__ db, int R, int N, int n_valid,
-                                                      int ld, int rows_per_block, int act, float gscale) {
+                                                      bf16_t* __restrict__ dz, float* __restrict__ db, float* __restrict__ part, int R, int N,
+                                                      int n_valid, int ld, int rows_per_block, int act, float gscale) {
     // block = 8 row lanes x 32 column vectors: a wave reads 2 rows x 512 contiguous bytes per step
     __shared__ float sred[8][32][8];
     const int cv = N >> 3;
@@ -365,7 +256,10 @@ __global__ __launch_bounds__(256) void k_bias_act_bwd(const bf16_t* __restrict__
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += sred[i][vv][kk];
     const int col = (blockIdx.x * 32 + vv) * 8 + kk;
-    if (col < n_valid) atomicAdd(db + col, s);
+    if (col < N) {
+        if (gridDim.y > 1) part[(long)blockIdx.y * N + col] = s;       // one partial row per row slab, added in a fixed order afterwards
+        else if (col < n_valid) db[col] += s;
+    }
 }
 
 extern "C" {
@@ -379,16 +273,30 @@ int svsr_add_ln_fwd(const void* a, const void* r, const float* gamma, const floa
     return svsr_check_launch();
 }
 
-int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd,
-                    void* ds, float* dgamma, float* dbeta, int R, int D, const void* addend, hipStream_t stream) {
-    if (D % 8 != 0 || D > 512 * LN_MAXV) return SVSR_ERR_ARG;
-    // every workgroup ends with 2*D fp32 atomics (dgamma/dbeta); measured flat between 4 and 16 rows per workgroup at
-    // 2,400 x 768, slower at 64 (too few workgroups) — 16 keeps the atomics few
-    static const int rpb = [] { const char* e = getenv("SVSR_LN_RPB"); return e ? atoi(e) : 16; }();
+static int ln_bwd_grid(int R) {
+    // every workgroup ends with one partial row of 2*D floats; measured flat between 4 and 16 rows per workgroup at
+    // 2,400 x 768, slower at 64 (too few workgroups) — 16 keeps the partials few
+    int rpb = svsr_tune_get(SVSR_TUNE_LN_RPB);
+    if (rpb < 1) rpb = 16;
     int grid = (R + rpb - 1) / rpb; if (grid > 512) grid = 512;
+    return grid < 1 ? 1 : grid;
+}
+
+/* rows of [2][D] partials svsr_add_ln_bwd needs in `part` for R rows */
+int svsr_add_ln_bwd_rows(int R) { return ln_bwd_grid(R); }
+
+int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale,
+                     hipStream_t stream);
+
+int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd,
+                    void* ds, float* dgamma, float* dbeta, int R, int D, const void* addend, float* part, hipStream_t stream) {
+    if (D % 8 != 0 || D > 512 * LN_MAXV || part == nullptr) return SVSR_ERR_ARG;
+    const int grid = ln_bwd_grid(R);
     hipLaunchKernelGGL(k_add_ln_bwd, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), stream, (const bf16_t*)dy, (const bf16_t*)a, (const bf16_t*)r, gamma,
-                       mean, rstd, (bf16_t*)ds, dgamma, dbeta, R, D, (const bf16_t*)addend);
-    return svsr_check_launch();
+                       mean, rstd, (bf16_t*)ds, part, R, D, (const bf16_t*)addend);
+    const int rc = svsr_check_launch();
+    if (rc != SVSR_OK) return rc;
+    return svsr_colsum_rows(part, grid, 2 * D, dgamma, D, dbeta, D, 1, 1.0f, stream);
 }
 
 int svsr_embed_ln_fwd(const void* feats, const float* cls, const float* pos, const float* type0, const float* gamma,
@@ -401,47 +309,45 @@ int svsr_embed_ln_fwd(const void* feats, const float* cls, const float* pos, con
     return svsr_check_launch();
 }
 
-int svsr_embed_bwd_scatter(const void* ds, void* dfeats, float* dcls, float* dpos, float* dtype0, int B, int S, int D,
+int svsr_embed_bwd_scatter(const void* ds, void* dfeats, float* dcls, float* dpos, float* dtype0, int B, int S, int D, float* part,
                            hipStream_t stream) {
-    if (D % 8 != 0) return SVSR_ERR_ARG;
+    if (D % 8 != 0 || part == nullptr) return SVSR_ERR_ARG;       // part: [S][D] floats
     const int n = S * (D / 8);
     hipLaunchKernelGGL(k_embed_bwd_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)ds, (bf16_t*)dfeats, dcls,
-                       dpos, dtype0, B, S, D);
-    return svsr_check_launch();
+                       dpos, part, B, S, D);
+    const int rc = svsr_check_launch();
+    if (rc != SVSR_OK) return rc;
+    return svsr_colsum_rows(part, S, D, dtype0, D, nullptr, 0, 1, 1.0f, stream);
 }
 
-int svsr_attn_fwd(const void* qkv, void* ctx, void* probs, int B, int S, int H, int dh, float scale, hipStream_t stream) {
-    if (dh != AT_DH || S < 1 || S > 64) return SVSR_ERR_ARG;
-    const size_t lds = ((size_t)3 * S * AT_LD + (size_t)S * (S + 1)) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); attr = true; }
-    hipLaunchKernelGGL(k_attn_fwd, dim3(B * H), dim3(256), lds, stream, (const bf16_t*)qkv, (bf16_t*)ctx, (bf16_t*)probs, B, S, H, scale);
-    return svsr_check_launch();
+static void bias_bwd_grid(int R, int N, int& col_blocks, int& splits, int& rpb) {
+    const int cv = N / 8;
+    col_blocks = (cv + 31) / 32;
+    splits = (R + 63) / 64;                                  // ~64 rows (8 per thread) per block ...
+    while (splits > 1 && col_blocks * splits > 2048) splits = (splits + 1) / 2;
+    rpb = (R + splits - 1) / splits;
+    splits = (R + rpb - 1) / rpb;
 }
 
-int svsr_attn_bwd(const void* dctx, const void* qkv, const void* probs, void* dqkv, int B, int S, int H, int dh, float scale,
-                  hipStream_t stream) {
-    if (dh != AT_DH || S < 1 || S > 64) return SVSR_ERR_ARG;
-    const size_t lds = ((size_t)4 * S * AT_LD + (size_t)2 * S * (S + 1)) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); attr = true; }
-    hipLaunchKernelGGL(k_attn_bwd, dim3(B * H), dim3(256), lds, stream, (const bf16_t*)dctx, (const bf16_t*)qkv, (const bf16_t*)probs,
-                       (bf16_t*)dqkv, B, S, H, scale);
-    return svsr_check_launch();
+/* rows of [N] partials svsr_bias_act_bwd needs in `part` (0: a single row slab adds into db directly) */
+int svsr_bias_act_bwd_rows(int R, int N) {
+    if (R < 1 || N < 8) return 0;
+    int cb, sp, rpb;
+    bias_bwd_grid(R, N, cb, sp, rpb);
+    return sp > 1 ? sp : 0;
 }
 
 int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, float gscale,
-                      hipStream_t stream) {
+                      float* part, hipStream_t stream) {
     if (N % 8 != 0 || ld % 8 != 0) return SVSR_ERR_ARG;
-    const int cv = N / 8;
-    const int col_blocks = (cv + 31) / 32;
-    int splits = (R + 63) / 64;                                  // ~64 rows (8 per thread) per block ...
-    while (splits > 1 && col_blocks * splits > 2048) splits = (splits + 1) / 2;
-    const int rpb = (R + splits - 1) / splits;
-    splits = (R + rpb - 1) / rpb;
+    int col_blocks, splits, rpb;
+    bias_bwd_grid(R, N, col_blocks, splits, rpb);
+    if (db != nullptr && splits > 1 && part == nullptr) return SVSR_ERR_ARG;
     hipLaunchKernelGGL(k_bias_act_bwd, dim3(col_blocks, splits), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)z,
-                       (bf16_t*)dz, db, R, N, n_valid, ld, rpb, act, gscale);
-    return svsr_check_launch();
+                       (bf16_t*)dz, db, part, R, N, n_valid, ld, rpb, act, gscale);
+    const int rc = svsr_check_launch();
+    if (rc != SVSR_OK || db == nullptr || splits <= 1) return rc;
+    return svsr_colsum_rows(part, splits, N, db, n_valid, nullptr, 0, 1, 1.0f, stream);
 }
 
 }  // extern "C"

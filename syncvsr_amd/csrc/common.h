@@ -12,7 +12,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define SVSR_OK 0
 #define SVSR_ERR_ARG 1001      // unsupported shape / argument
 #define SVSR_ERR_LAUNCH 1002
-#define SVSR_STAT_SLOTS 16   // BatchNorm partial-sum slots: blocks accumulate atomically into slot (blockIdx & 15)
+
+// Result-preserving tuning knobs (runtime.hip): a process-wide table set through svsr_tune(); the library never reads the
+// environment.
+enum { SVSR_TUNE_IGEMM_TILE = 0, SVSR_TUNE_IGEMM_M128, SVSR_TUNE_WG_BLOCKS, SVSR_TUNE_W3_BLOCKS, SVSR_TUNE_LN_RPB,
+       SVSR_TUNE_STEM_LDS_FWD, SVSR_TUNE_STEM_LDS_BWD, SVSR_TUNE_N };
+int svsr_tune_get(int id);
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((unsigned)u) << 16); }
 

@@ -25,7 +25,7 @@ struct Conv64Args {
     const bf16_t* wt;       // [64][9][64]   (row = output channel, then tap, then input channel)
     bf16_t* out;            // [Nimg][H][W][64]
     const bf16_t* addend;   // optional, laid out like out (may alias it)
-    float* stats;           // optional BatchNorm slots [SVSR_STAT_SLOTS][2][64]
+    float* stats;           // optional BatchNorm partials [gridDim.x][2][64]: one row per (persistent) workgroup
     int Nimg, H, W, WP, Q, Qtot, total_chunks;
     float inv_q, inv_wp;
     int dy[9], dx[9], tw[9];
@@ -170,7 +170,8 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
         }
     }
     if (p.stats != nullptr) {
-        // threads tid = slot + 8*m share a channel group: reduce through LDS, then one atomic per channel and statistic
+        // threads tid = slot + 8*m share a channel group: reduce through LDS in a fixed order, then one plain store per channel
+        // and statistic into this workgroup's row of the partials (svsr_bn_finalize adds the rows)
         __syncthreads();
         float* sred = reinterpret_cast<float*>(sA);        // [512][16]
 #pragma unroll
@@ -180,9 +181,20 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
             const int which = tid >> 6, ch = tid & 63, sl8 = ch >> 3, k = ch & 7;
             float s = 0.f;
             for (int m = 0; m < 64; ++m) s += sred[(sl8 + 8 * m) * 16 + which * 8 + k];
-            atomicAdd(p.stats + ((blockIdx.x & (SVSR_STAT_SLOTS - 1)) * 2 + which) * 64 + ch, s);
+            p.stats[((long)blockIdx.x * 2 + which) * 64 + ch] = s;
         }
     }
+}
+
+static int c64_grid(long total_chunks) {
+    static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+    return (int)(total_chunks < cus ? total_chunks : cus);
+}
+
+/* rows of [2][64] BatchNorm partials svsr_conv3x3_c64 writes for this shape (= its persistent workgroups) */
+extern "C" int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W) {
+    if (Nimg < 1 || H < 1 || W < 1) return 0;
+    return c64_grid(((long)Nimg * (H + 2) * (W + 2) + C64_CH - 1) / C64_CH);
 }
 
 extern "C" int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
@@ -203,10 +215,7 @@ extern "C" int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int grid = a.total_chunks < cus ? a.total_chunks : cus;
+    const int grid = c64_grid(a.total_chunks);
     hipLaunchKernelGGL(k_conv3x3_c64, dim3(grid), dim3(C64_THREADS), lds, stream, a);
     return svsr_check_launch();
 }

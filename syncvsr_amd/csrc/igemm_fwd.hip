@@ -11,9 +11,9 @@
 // (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave instruction) into a 3-deep ring, two tiles in flight behind a
 // counted s_waitcnt vmcnt(N) + one s_barrier per K step; the XOR swizzle that makes the ds_read_b128 fragment reads
 // conflict-free is applied on the per-lane SOURCE address (the LDS image of a DMA is lane-linear), rows outside the grid
-// read a zero page.  k_igemm_fwd (register-staged, double-buffered) is kept as the reference variant (SVSR_IGEMM_GLDS=0).
-// Epilogue (shared): accumulators -> LDS fp32 -> +bias +addend, exact GELU, 16-byte stores; optional BatchNorm partial sums.
-#include <stdlib.h>
+// read a zero page.
+// Epilogue: accumulators -> LDS fp32 -> +bias +addend, exact GELU, 16-byte stores; optional BatchNorm partial sums, one row
+// of [2][Co] per M tile (plain stores, no atomics: svsr_bn_finalize adds the rows in a fixed order, so a step is reproducible).
 
 #include "igemm_common.h"
 
@@ -25,11 +25,10 @@ struct IgemmFwdArgs {
     bf16_t* out_pre;       // optional pre-activation copy (GELU epilogue)
     const float* bias;     // optional [Co]
     const bf16_t* addend;  // optional bf16 pixels with the geometry of `out`, added before the activation
-    float* stats;          // optional BatchNorm partials: atomically accumulated slots [SVSR_STAT_SLOTS][2][Co]
+    float* stats;          // optional BatchNorm partials [gridDim.x][2][Co]: row blockIdx.x = this M tile's column sums / sums of squares
     int act, out_f32;          // act: 0 none, 1 GELU(erf) (pre-activation kept in out_pre), 2 ReLU
     float alpha;               // out = alpha * dropout(act(acc + bias)) + addend
     DropArgs drop;             // drop.seed == nullptr: no dropout
-    int dbg;               // tuning aid (SVSR_IGEMM_DBG): bit0 skip the K loop, bit1 skip the epilogue stores
 };
 
 __device__ unsigned g_zero_page[64];     // 256 zero bytes: DMA source for rows outside the grid
@@ -152,9 +151,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
             const float s = red[((0 * 2 + wcol) * WN + cc) * 2 + 0] + red[((1 * 2 + wcol) * WN + cc) * 2 + 0];
             const float q = red[((0 * 2 + wcol) * WN + cc) * 2 + 1] + red[((1 * 2 + wcol) * WN + cc) * 2 + 1];
             if (n0 + c < g.Co) {
-                const int slot = blockIdx.x & (SVSR_STAT_SLOTS - 1);
-                atomicAdd(p.stats + ((long)slot * 2 + 0) * g.Co + n0 + c, s);
-                atomicAdd(p.stats + ((long)slot * 2 + 1) * g.Co + n0 + c, q);
+                p.stats[((long)blockIdx.x * 2 + 0) * g.Co + n0 + c] = s;
+                p.stats[((long)blockIdx.x * 2 + 1) * g.Co + n0 + c] = q;
             }
         }
     }
@@ -269,7 +267,7 @@ __global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
     igemm_fill_tables<BM>(g, sRow, sTap, m0);
     __syncthreads();
 
-    const int KT = (p.dbg & 1) ? 0 : g.ntaps * (g.Ci / BK);
+    const int KT = g.ntaps * (g.Ci / BK);
     int t_next = 0, c_next = 0;
     auto stage = [&](int buf) {
         const int t = t_next, tw = sTap[18 + t_next];
@@ -318,115 +316,6 @@ __global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
         buf = buf + 1 == NS ? 0 : buf + 1;
     }
     __syncthreads();
-    if (p.dbg & 2) return;
-    igemm_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, sRow, wm0, wn0, n0);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// register-staged, double-buffered reference variant
-// ---------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void k_igemm_fwd(const IgemmFwdArgs p) {
-    constexpr int BK = 64;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;
-    constexpr int AR = BM / 32, BR = BN / 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);
-    bf16_t* sB = sA + 2 * A_ELEMS;
-    long* sRow = reinterpret_cast<long*>(sB + 2 * B_ELEMS);
-    int* sTap = reinterpret_cast<int*>(sRow + BM);
-
-    const IgemmGeom& g = p.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int chunk = tid & 7, r0 = tid >> 3;
-
-    long a_base[AR];
-    int a_y[AR], a_x[AR];
-    unsigned row_ok = 0;          // bit i: A row i exists; bit 8+i: B row i exists
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int m = m0 + r0 + 32 * i;
-        const bool ok = m < g.M;
-        int n, a, b;
-        decode_pos(g, ok ? m : 0, n, a, b);
-        a_base[i] = (long)n * g.Hi * g.Wi;
-        a_y[i] = a * g.S;
-        a_x[i] = b * g.S;
-        row_ok |= (ok ? 1u : 0u) << i;
-    }
-    const bf16_t* b_ptr[BR];
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-        const int n = n0 + r0 + 32 * i;
-        const bool ok = n < g.Co;
-        b_ptr[i] = p.wt + (long)(ok ? n : 0) * g.wt_taps * g.Ci + chunk * 8;
-        row_ok |= (ok ? 1u : 0u) << (8 + i);
-    }
-    igemm_fill_tables<BM>(g, sRow, sTap, m0);
-    __syncthreads();
-
-    const int KT = g.ntaps * (g.Ci / BK);
-    u32x4 ra[AR], rb[BR];
-    unsigned ld_ok = 0;              // validity of the rows held in ra/rb (applied when they are written to LDS)
-    int t_next = 0, c_next = 0;
-
-    auto load_tiles = [&]() {
-        const int dy = sTap[t_next], dx = sTap[9 + t_next], tw = sTap[18 + t_next];
-        const int c0 = c_next;
-        ld_ok = row_ok & 0xff00u;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int iy = a_y[i] + dy, ix = a_x[i] + dx;
-            const bool ok = ((row_ok >> i) & 1u) && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-            const long pix = ok ? a_base[i] + (long)iy * g.Wi + ix : 0;
-            ra[i] = *reinterpret_cast<const u32x4*>(p.in + pix * g.in_pitch + c0 + chunk * 8);
-            ld_ok |= (ok ? 1u : 0u) << i;
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + (long)tw * g.Ci + c0);
-        c_next += BK;
-        if (c_next >= g.Ci) { c_next = 0; ++t_next; }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int r = r0 + 32 * i;
-            const bool ok = (ld_ok >> i) & 1u;
-            u32x4 v = ra[i];
-            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-            *reinterpret_cast<u32x4*>(sA + buf * A_ELEMS + LDS_SWZ(r, chunk)) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const int r = r0 + 32 * i;
-            const bool ok = (ld_ok >> (8 + i)) & 1u;
-            u32x4 v = rb[i];
-            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-            *reinterpret_cast<u32x4*>(sB + buf * B_ELEMS + LDS_SWZ(r, chunk)) = v;
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    load_tiles();
-    store_tiles(0);
-    __syncthreads();
-    for (int it = 0; it < KT; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < KT) load_tiles();
-        igemm_mma_tile<BM, BN, TM, TN>(sA + cur * A_ELEMS, sB + cur * B_ELEMS, acc, wm0, wn0, lane);
-        if (it + 1 < KT) store_tiles(cur ^ 1);
-        __syncthreads();
-    }
     igemm_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, sRow, wm0, wn0, n0);
 }
 
@@ -443,47 +332,45 @@ static int launch_glds(const IgemmFwdArgs& a, int gx, int gy, hipStream_t stream
     return svsr_check_launch();
 }
 
-// Ring depth per launch.  One K step of a block costs max(MFMA time, LDS-DMA round trip / tiles in flight) and the round
-// trip is ~1.1 us, so what matters is the number of tiles in flight PER CU: with at least ~2 blocks per CU a shallow ring
-// and several co-resident blocks is best; with about one block per CU (small M*N, long K) the whole 160 KiB goes to one
-// deep ring.  SHALLOW / DEEP stage counts: 128x128 -> 2 / 4, 128x64 -> 3 / 5, 64x64 -> 4 (3 if many blocks) / 8.
-template <int BM, int BN>
-static int launch_fwd(const IgemmFwdArgs& a, bool glds, hipStream_t stream) {
-    const int gx = (a.g.M + BM - 1) / BM, gy = (a.g.Co + BN - 1) / BN;
-    if (!glds) {
-        const size_t lds_reg = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t) + (size_t)BM * sizeof(long) + 128;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_fwd<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((k_igemm_fwd<BM, BN>), dim3(gx, gy), dim3(256), lds_reg, stream, a);
-        return svsr_check_launch();
+// Tile / ring-depth choice.  One K step of a block costs max(MFMA time, LDS-DMA issue + round trip / tiles in flight):
+// with at least ~2 blocks per CU a shallow ring and several co-resident blocks is best.  Stage counts: 128x128 -> 2,
+// 128x64 -> 3 (2 for the few-tile convolutions), 64x64 -> 4 (3 if many blocks).
+struct IgemmFwdPlan { int bm, bn, ns, gx, gy; };
+
+static IgemmFwdPlan igemm_fwd_plan(int M, int Co, int ntaps) {
+    static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+    IgemmFwdPlan pl;
+    const int forced = svsr_tune_get(SVSR_TUNE_IGEMM_TILE);            // 0 auto, 64 / 128 forced
+    const int thr = svsr_tune_get(SVSR_TUNE_IGEMM_M128);
+    int bm;
+    if (forced == 64 || forced == 128) bm = forced;
+    else if (Co <= 64) bm = M >= 16384 ? 128 : 64;
+    else {
+        // 128x128 tiles once they still give ~a block per CU (LRS linears at 2,400 rows: qkv/ffn1/heads yes, 768-wide outputs no)
+        const long blocks128 = (long)((M + 127) / 128) * ((Co + 127) / 128);
+        bm = (M >= thr || blocks128 >= 224) ? 128 : 64;
     }
-    static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-    static const int deep_env = [] { const char* e = getenv("SVSR_IGEMM_DEEP"); return e ? atoi(e) : -1; }();   // tuning: 0 never, 1 always
-    const long blocks = (long)gx * gy;
-    const bool deep = deep_env == 1;      // measured: deep rings do not help (the K step was VALU-bound on address generation, not DMA-latency-bound)
-    constexpr int TILE = BM + BN;
-    if (TILE > 192) return deep ? launch_glds<BM, BN, 4>(a, gx, gy, stream) : launch_glds<BM, BN, 2>(a, gx, gy, stream);
-    if (TILE > 128) return deep ? launch_glds<BM, BN, 5>(a, gx, gy, stream) : launch_glds<BM, BN, 3>(a, gx, gy, stream);
-    if (deep) return launch_glds<BM, BN, 8>(a, gx, gy, stream);
-    return blocks <= (long)cus * 5 / 2 ? launch_glds<BM, BN, 4>(a, gx, gy, stream) : launch_glds<BM, BN, 3>(a, gx, gy, stream);
+    // few-tile convolutions (LRW layer4: 66 x 4 tiles of 128x128 = about one workgroup per CU): 128x64 tiles with a 2-deep ring
+    // fit three workgroups per CU and measure 82 -> 77 us; with more tiles the 128x128 shape wins (layer2 61 vs 66 us)
+    if (bm == 128 && Co > 64 && ntaps > 1 && (long)((M + 127) / 128) * ((Co + 127) / 128) < 300) { pl.bm = 128; pl.bn = 64; pl.ns = 2; }
+    else if (bm == 128 && Co <= 64) { pl.bm = 128; pl.bn = 64; pl.ns = 3; }
+    else if (bm == 128) { pl.bm = 128; pl.bn = 128; pl.ns = 2; }
+    else { pl.bm = 64; pl.bn = 64; pl.ns = 0; }
+    pl.gx = (M + pl.bm - 1) / pl.bm; pl.gy = (Co + pl.bn - 1) / pl.bn;
+    if (pl.ns == 0) pl.ns = (long)pl.gx * pl.gy <= (long)cus * 5 / 2 ? 4 : 3;
+    return pl;
 }
 
-static int igemm_fwd_tile_m(int M, int Co) {
-    static const int forced = [] { const char* e = getenv("SVSR_IGEMM_TILE"); return e ? atoi(e) : 0; }();   // tuning knob
-    static const int thr = [] { const char* e = getenv("SVSR_IGEMM_M128"); return e ? atoi(e) : 8192; }();
-    if (forced == 64 || forced == 128) return forced;
-    if (Co <= 64) return M >= 16384 ? 128 : 64;
-    // 128x128 tiles once they still give ~a block per CU (LRS linears at 2,400 rows: qkv/ffn1/heads yes, 768-wide outputs no)
-    const long blocks128 = (long)((M + 127) / 128) * ((Co + 127) / 128);
-    return (M >= thr || blocks128 >= 224) ? 128 : 64;
-}
-
-static bool use_glds() {
-    static const bool v = [] { const char* e = getenv("SVSR_IGEMM_GLDS"); return !(e != nullptr && e[0] == '0'); }();
-    return v;
+/* svsr_igemm_fwd_plan: which kernel instantiation svsr_igemm_fwd launches for (M positions, Co outputs, ntaps) — tile
+ * BM x BN, ring depth NS — and how many rows of [2][Co] BatchNorm partials it writes when `stats` is given (= M tiles). */
+extern "C" int svsr_igemm_fwd_plan(int M, int Co, int ntaps, int* bm, int* bn, int* ns, int* stat_rows) {
+    if (M <= 0 || Co <= 0 || ntaps < 1) return SVSR_ERR_ARG;
+    const IgemmFwdPlan pl = igemm_fwd_plan(M, Co, ntaps);
+    if (bm) *bm = pl.bm;
+    if (bn) *bn = pl.bn;
+    if (ns) *ns = pl.ns;
+    if (stat_rows) *stat_rows = pl.gx;
+    return SVSR_OK;
 }
 
 extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend,
@@ -498,14 +385,13 @@ extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* o
     a.bias = bias; a.addend = (const bf16_t*)addend; a.stats = stats; a.act = act; a.out_f32 = out_f32; a.alpha = alpha;
     if (act != 0 && (addend != nullptr || alpha != 1.f)) return SVSR_ERR_ARG;     // the activation is applied before alpha / addend
     a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
-    static const int dbg = [] { const char* e = getenv("SVSR_IGEMM_DBG"); return e ? atoi(e) : 0; }();
-    a.dbg = dbg;
-    const int bm = igemm_fwd_tile_m(a.g.M, Co);
-    const bool glds = use_glds();
-    // few-tile convolutions (LRW layer4: 66 x 4 tiles of 128x128 = about one workgroup per CU): 128x64 tiles with a 2-deep ring
-    // fit three workgroups per CU and measure 82 -> 77 us; with more tiles the 128x128 shape wins (layer2 61 vs 66 us)
-    if (glds && bm == 128 && Co > 64 && ntaps > 1 && (long)((a.g.M + 127) / 128) * ((Co + 127) / 128) < 300)
-        return launch_glds<128, 64, 2>(a, (a.g.M + 127) / 128, (Co + 63) / 64, stream);
-    if (bm == 128) return Co <= 64 ? launch_fwd<128, 64>(a, glds, stream) : launch_fwd<128, 128>(a, glds, stream);
-    return launch_fwd<64, 64>(a, glds, stream);
+    const IgemmFwdPlan pl = igemm_fwd_plan(a.g.M, Co, ntaps);
+#define SVSR_IGEMM_CASE(BM_, BN_, NS_) if (pl.bm == BM_ && pl.bn == BN_ && pl.ns == NS_) return launch_glds<BM_, BN_, NS_>(a, pl.gx, pl.gy, stream)
+    SVSR_IGEMM_CASE(128, 128, 2);
+    SVSR_IGEMM_CASE(128, 64, 2);
+    SVSR_IGEMM_CASE(128, 64, 3);
+    SVSR_IGEMM_CASE(64, 64, 4);
+    SVSR_IGEMM_CASE(64, 64, 3);
+#undef SVSR_IGEMM_CASE
+    return SVSR_ERR_ARG;
 }

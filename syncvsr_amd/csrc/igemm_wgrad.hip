@@ -1,5 +1,8 @@
 // Weight-gradient contraction on MFMA (gfx950):
-//     dW[co][tw[t]][ci] += sum_m dY[target(m)][co] * X[source(m, t)][ci]            (fp32, accumulated with atomics)
+//     dW[co][tw[t]][ci] += sum_m dY[target(m)][co] * X[source(m, t)][ci]            (fp32)
+// Split-K without atomics: the workgroups of split s store their tiles into slab s of a caller-owned workspace with plain
+// stores and svsr_colsum_rows (runtime.hip) adds the slabs into dW in a fixed order, so the gradient is reproducible; with a
+// single split the tile is added to dW directly (one writer per element).
 // for every nn.Conv2d / nn.Linear of the path (autograd of reference LRW/video/src/tcn/models/resnet.py:8-16,59-72 and
 // lightning.py:82,92,107).  The reduction index m (positions) is the slow index of both operands, so
 // the MFMA fragments (8 consecutive positions for one channel per lane) are produced from position-major LDS tiles by
@@ -9,8 +12,6 @@
 //
 // Grid: x = split of the position range (64-position chunks), y = (co tile, ci tile, tap).  Block = 4 waves (2x2), tile
 // BC x BC channels of one tap; the next chunk's global loads are issued before the MFMA block of the current one.
-#include <stdlib.h>
-
 #include "igemm_common.h"
 
 struct IgemmWgradArgs {
@@ -20,6 +21,9 @@ struct IgemmWgradArgs {
     float* dw;             // [Co][wt_taps][Ci] fp32, accumulated
     float* db;             // optional [Co] fp32: += column sums of dY (the bias gradient of an nn.Linear), taken from the dY tiles
                            // the ci-tile-0 / tap-0 workgroups stage anyway
+    float* part;           // splits > 1: slabs [splits][slab], slab = Co*wt_taps*Ci (+ Co when db != null) floats
+    long slab;
+    int splits;
     int chunks_per_block;  // 64-position chunks each block reduces
 };
 
@@ -169,11 +173,16 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad(const IgemmWgradArgs p) {
             const int chk = grp & 7, l = grp >> 3;
             float s = 0.f;
             for (int r = 0; r < 32; ++r) s += sred[(r * 8 + chk) * (8 * NL) + l * 8 + k];
-            if (co0 + tid < g.Co) atomicAdd(p.db + co0 + tid, s);
+            if (co0 + tid < g.Co) {
+                if (p.splits > 1) p.part[(long)blockIdx.x * p.slab + (long)g.Co * g.wt_taps * g.Ci + co0 + tid] = s;
+                else p.db[co0 + tid] += s;
+            }
         }
         __syncthreads();
     }
-    // D[row = co][col = ci]
+    // D[row = co][col = ci]: one writer per element — slab `blockIdx.x` (plain store) or, without a split, dW itself
+    float* dst = p.splits > 1 ? p.part + (long)blockIdx.x * p.slab : p.dw;
+    const bool direct = p.splits <= 1;
 #pragma unroll
     for (int j = 0; j < TT; ++j) {
         const int ci = ci0 + wci + j * 32 + (lane & 31);
@@ -183,41 +192,73 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad(const IgemmWgradArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < g.Co) atomicAdd(p.dw + ((long)co * g.wt_taps + tw) * g.Ci + ci, acc[i][j][r]);
+                if (co < g.Co) {
+                    float* d = dst + ((long)co * g.wt_taps + tw) * g.Ci + ci;
+                    *d = direct ? *d + acc[i][j][r] : acc[i][j][r];
+                }
             }
     }
 }
 
-template <bool USE_TR, int BC>
-static int launch_wgrad(IgemmWgradArgs& a, hipStream_t stream) {
-    const IgemmGeom& g = a.g;
-    const int tasks = ((g.Co + BC - 1) / BC) * ((g.Ci + BC - 1) / BC) * g.ntaps;
-    const int total_chunks = (g.M + 63) / 64;
-    static const int target_env = [] { const char* e = getenv("SVSR_WG_BLOCKS"); return e ? atoi(e) : 0; }();
+struct WgradPlan { int bc, splits, chunks_per_block, tasks; long slab; };
+
+static WgradPlan wgrad_plan(int M, int Co, int Ci, int ntaps, int wt_taps, bool bias) {
+    WgradPlan pl;
+    const int tasks128 = ((Co + 127) / 128) * ((Ci + 127) / 128) * ntaps;
+    pl.bc = (Co >= 128 && Ci >= 128 && tasks128 >= 36) ? 128 : 64;
+    const int BC = pl.bc;
+    pl.tasks = ((Co + BC - 1) / BC) * ((Ci + BC - 1) / BC) * ntaps;
+    const int total_chunks = (M + 63) / 64;
+    const int target_env = svsr_tune_get(SVSR_TUNE_WG_BLOCKS);
     const int target_blocks = target_env > 0 ? target_env : (BC == 128 ? 512 : 1024);    // measured optimum per tile size
-    int splits = (target_blocks + tasks - 1) / tasks;   // every block ends with BC*BC fp32 atomics (~2.5 ns each chip-wide)
+    int splits = (target_blocks + pl.tasks - 1) / pl.tasks;   // every split costs a slab of Co*taps*Ci floats written and re-read
     if (splits > total_chunks) splits = total_chunks;
     if (splits < 1) splits = 1;
-    a.chunks_per_block = (total_chunks + splits - 1) / splits;
-    // keep the BC*BC atomic epilogue amortised: >= 12 K-chunks per block when the problem has them (LRS linears: 2,400 rows =
+    pl.chunks_per_block = (total_chunks + splits - 1) / splits;
+    // keep the epilogue amortised: >= 12 K-chunks per block when the problem has them (LRS linears: 2,400 rows =
     // 38 chunks -> 3 splits measured best), >= 4 for the short LRW sequences
     const int min_chunks = total_chunks >= 36 ? 12 : 4;
-    if (a.chunks_per_block < min_chunks && total_chunks >= min_chunks) a.chunks_per_block = min_chunks;
-    splits = (total_chunks + a.chunks_per_block - 1) / a.chunks_per_block;
-    hipLaunchKernelGGL((k_igemm_wgrad<USE_TR, BC>), dim3(splits, tasks), dim3(256), 0, stream, a);
+    if (pl.chunks_per_block < min_chunks && total_chunks >= min_chunks) pl.chunks_per_block = min_chunks;
+    pl.splits = (total_chunks + pl.chunks_per_block - 1) / pl.chunks_per_block;
+    pl.slab = (long)Co * wt_taps * Ci + (bias ? Co : 0);
+    return pl;
+}
+
+template <bool USE_TR, int BC>
+static int launch_wgrad(IgemmWgradArgs& a, const WgradPlan& pl, hipStream_t stream) {
+    hipLaunchKernelGGL((k_igemm_wgrad<USE_TR, BC>), dim3(pl.splits, pl.tasks), dim3(256), 0, stream, a);
     return svsr_check_launch();
 }
 
+/* svsr_igemm_wgrad_plan: tile edge, number of K splits and the workspace (floats) svsr_igemm_wgrad needs for this shape
+ * (0 floats when a single split writes dW directly). */
+extern "C" int svsr_igemm_wgrad_plan(int M, int Co, int Ci, int ntaps, int wt_taps, int has_bias, int* bc, int* splits, int64_t* part_floats) {
+    if (M <= 0 || Co <= 0 || Ci <= 0 || ntaps < 1 || wt_taps < ntaps) return SVSR_ERR_ARG;
+    const WgradPlan pl = wgrad_plan(M, Co, Ci, ntaps, wt_taps, has_bias != 0);
+    if (bc) *bc = pl.bc;
+    if (splits) *splits = pl.splits;
+    if (part_floats) *part_floats = pl.splits > 1 ? (int64_t)pl.splits * pl.slab : 0;
+    return SVSR_OK;
+}
+
+extern "C" int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate,
+                                float scale, hipStream_t stream);
+
 extern "C" int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co,
                                 int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps,
-                                const int* dy, const int* dx, const int* tw, int use_tr, float* dbias, hipStream_t stream) {
+                                const int* dy, const int* dx, const int* tw, int use_tr, float* dbias, float* part, int64_t part_floats,
+                                hipStream_t stream) {
     IgemmWgradArgs a;
     int rc = fill_geom(a.g, Nimg, Hi, Wi, Ci, in_pitch, Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, ntaps, wt_taps, dy, dx, tw);
     if (rc != SVSR_OK) return rc;
     if (out_pitch % 8 != 0) return SVSR_ERR_ARG;
+    const WgradPlan pl = wgrad_plan(a.g.M, Co, Ci, ntaps, wt_taps, dbias != nullptr);
+    if (pl.splits > 1 && (part == nullptr || part_floats < (int64_t)pl.splits * pl.slab)) return SVSR_ERR_ARG;
     a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dyp; a.dw = dw; a.db = dbias;
-    const int tasks128 = ((Co + 127) / 128) * ((Ci + 127) / 128) * ntaps;
-    const bool big = Co >= 128 && Ci >= 128 && tasks128 >= 36;
-    if (use_tr) return big ? launch_wgrad<true, 128>(a, stream) : launch_wgrad<true, 64>(a, stream);
-    return big ? launch_wgrad<false, 128>(a, stream) : launch_wgrad<false, 64>(a, stream);
+    a.part = part; a.slab = pl.slab; a.splits = pl.splits; a.chunks_per_block = pl.chunks_per_block;
+    if (use_tr) rc = pl.bc == 128 ? launch_wgrad<true, 128>(a, pl, stream) : launch_wgrad<true, 64>(a, pl, stream);
+    else rc = pl.bc == 128 ? launch_wgrad<false, 128>(a, pl, stream) : launch_wgrad<false, 64>(a, pl, stream);
+    if (rc != SVSR_OK || pl.splits <= 1) return rc;
+    const int64_t n = (int64_t)Co * wt_taps * Ci;
+    return svsr_colsum_rows(part, pl.splits, pl.slab, dw, n, dbias, dbias != nullptr ? Co : 0, 1, 1.0f, stream);
 }

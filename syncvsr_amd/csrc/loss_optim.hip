@@ -16,7 +16,7 @@ struct CeArgs {
     const float* target_prob; int ldt;             // soft targets [R][V] or null
     int R, V;
     float smoothing;
-    float* loss_sum;       // += sum_rows loss_r / R
+    float* row_loss;       // [R] per-row losses (svsr_colsum_rows adds them in a fixed order: loss = mean)
     float* lse;            // [R] saved for the backward
 };
 
@@ -25,9 +25,7 @@ __device__ __forceinline__ float ce_load(const CeArgs& a, long off) {
 }
 
 __global__ __launch_bounds__(256) void k_ce_fwd(const CeArgs a) {
-    __shared__ float spart[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float block_loss = 0.f;
     for (int row = blockIdx.x * 4 + wave; row < a.R; row += gridDim.x * 4) {
         float z[CE_MAXPER];
         float m = -INFINITY;
@@ -50,7 +48,8 @@ __global__ __launch_bounds__(256) void k_ce_fwd(const CeArgs a) {
         if (a.target_idx != nullptr) {
             sz = wave_sum(sz);
             const long t = a.target_idx[row];
-            const float zt = ce_load(a, (long)row * a.ld + t);
+            // a target outside [0, V) (torch raises a device assert) poisons the loss instead of reading out of bounds
+            const float zt = (t >= 0 && t < a.V) ? ce_load(a, (long)row * a.ld + t) : __uint_as_float(0x7fc00000u);
             loss = (1.f - a.smoothing) * (lse - zt) + a.smoothing * (lse - sz / (float)a.V);
         } else {
             float st = 0.f, stz = 0.f;
@@ -65,11 +64,8 @@ __global__ __launch_bounds__(256) void k_ce_fwd(const CeArgs a) {
             st = wave_sum(st); stz = wave_sum(stz);
             loss = lse * st - stz;
         }
-        if (lane == 0) { a.lse[row] = lse; block_loss += loss; }
+        if (lane == 0) { a.lse[row] = lse; a.row_loss[row] = loss; }
     }
-    if (lane == 0) spart[wave] = block_loss;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(a.loss_sum, (spart[0] + spart[1] + spart[2] + spart[3]) / (float)a.R);
 }
 
 // dlogits = gout * (softmax * sum(t') - t') / R      (bf16 out, pitch ldo)
@@ -101,9 +97,8 @@ __global__ __launch_bounds__(256) void k_ce_bwd(const CeArgs a, const float* gou
 
 // top-1 / top-5 accuracy of f32 logits [B][C]; labels are class indices, or (soft) the argmax of [B][C] probabilities
 __global__ __launch_bounds__(256) void k_topk_acc(const float* __restrict__ logits, const long* __restrict__ labels,
-                                                  const float* __restrict__ soft, int B, int C, float* out2) {
+                                                  const float* __restrict__ soft, int B, int C, float* rows2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float t1 = 0.f, t5 = 0.f;
     for (int row = blockIdx.x * 4 + wave; row < B; row += gridDim.x * 4) {
         long lab;
         if (labels != nullptr) lab = labels[row];
@@ -116,6 +111,7 @@ __global__ __launch_bounds__(256) void k_topk_acc(const float* __restrict__ logi
             }
             lab = bi;
         }
+        if (lab < 0 || lab >= C) lab = 0;
         const float zl = logits[(long)row * C + lab];
         float cnt = 0.f;
         for (int v = lane; v < C; v += 64) {
@@ -123,16 +119,25 @@ __global__ __launch_bounds__(256) void k_topk_acc(const float* __restrict__ logi
             if (z > zl || (z == zl && v < lab)) cnt += 1.f;
         }
         cnt = wave_sum(cnt);
-        t1 += cnt < 0.5f ? 1.f : 0.f;
-        t5 += cnt < 4.5f ? 1.f : 0.f;
+        if (lane == 0) { rows2[row * 2 + 0] = cnt < 0.5f ? 1.f : 0.f; rows2[row * 2 + 1] = cnt < 4.5f ? 1.f : 0.f; }
     }
-    if (lane == 0) { atomicAdd(out2 + 0, t1 / (float)B); atomicAdd(out2 + 1, t5 / (float)B); }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // optimiser
 // ---------------------------------------------------------------------------------------------------------
-struct OptState { int step; float sumsq; float lr_last; float gnorm_last; };   // device-resident, 16 bytes
+#define OPT_PARTS 1024      // workgroups of k_grad_sumsq = partial sums of squares kept in the device state
+struct OptState { int step; float sumsq; float lr_last; float gnorm_last; float part[OPT_PARTS]; };   // device-resident
+
+// sum of the OPT_PARTS partials in a fixed order (every thread of a 256-thread block gets the same value)
+__device__ __forceinline__ float opt_sumsq(const OptState* st, float* s4) {
+    const int t = threadIdx.x;
+    float v = ((st->part[t] + st->part[t + 256]) + st->part[t + 512]) + st->part[t + 768];
+    v = wave_sum(v);                       // xor-butterfly: the same association on every lane and every launch
+    if ((t & 63) == 0) s4[t >> 6] = v;
+    __syncthreads();
+    return ((s4[0] + s4[1]) + s4[2]) + s4[3];
+}
 
 __global__ __launch_bounds__(256) void k_grad_sumsq(const float* __restrict__ g, long n, OptState* st) {
     __shared__ float spart[4];
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void k_grad_sumsq(const float* __restrict__ g,
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) spart[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&st->sumsq, spart[0] + spart[1] + spart[2] + spart[3]);
+    if (threadIdx.x == 0) st->part[blockIdx.x] = ((spart[0] + spart[1]) + spart[2]) + spart[3];
 }
 
 struct AdamArgs {
@@ -166,8 +171,9 @@ __device__ __forceinline__ float sched_lr(const AdamArgs& a, int step /* 0-based
 }
 
 __global__ __launch_bounds__(256) void k_adamw(const AdamArgs a) {
+    __shared__ float s4[4];
     const int step = a.st->step;             // steps already taken
-    const float gnorm = sqrtf(a.st->sumsq);
+    const float gnorm = sqrtf(opt_sumsq(a.st, s4));
     const float clip = a.max_norm > 0.f ? fminf(1.f, a.max_norm / (gnorm + 1e-6f)) : 1.f;
     const float lr = sched_lr(a, step);
     const float t = (float)(step + 1);
@@ -185,12 +191,15 @@ __global__ __launch_bounds__(256) void k_adamw(const AdamArgs a) {
     }
 }
 
-__global__ void k_opt_advance(OptState* st, float lr_base, int warmup, int total_steps) {
+__global__ __launch_bounds__(256) void k_opt_advance(OptState* st, float lr_base, int warmup, int total_steps) {
+    __shared__ float s4[4];
+    const float sumsq = opt_sumsq(st, s4);
+    if (threadIdx.x != 0) return;
     AdamArgs a; a.lr = lr_base; a.warmup = warmup; a.total_steps = total_steps;
     st->lr_last = sched_lr(a, st->step);
-    st->gnorm_last = sqrtf(st->sumsq);
+    st->sumsq = sumsq;
+    st->gnorm_last = sqrtf(sumsq);
     st->step += 1;
-    st->sumsq = 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -242,13 +251,18 @@ static inline int grid_for(long n) { long b = (n + 255) / 256; if (b > 4096) b =
 
 extern "C" {
 
+int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale,
+                     hipStream_t stream);
+
 int svsr_ce_fwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt,
-                int R, int V, float smoothing, float* loss_sum, float* lse, hipStream_t stream) {
-    if (V > 64 * CE_MAXPER || V < 1 || (target_idx == nullptr) == (target_prob == nullptr)) return SVSR_ERR_ARG;
-    CeArgs a{logits, logits_f32, ld, (const long*)target_idx, target_prob, ldt, R, V, smoothing, loss_sum, lse};
+                int R, int V, float smoothing, float* loss, float* lse, float* row_loss, hipStream_t stream) {
+    if (V > 64 * CE_MAXPER || V < 1 || R < 1 || (target_idx == nullptr) == (target_prob == nullptr) || row_loss == nullptr) return SVSR_ERR_ARG;
+    CeArgs a{logits, logits_f32, ld, (const long*)target_idx, target_prob, ldt, R, V, smoothing, row_loss, lse};
     int grid = (R + 3) / 4; if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(k_ce_fwd, dim3(grid), dim3(256), 0, stream, a);
-    return svsr_check_launch();
+    const int rc = svsr_check_launch();
+    if (rc != SVSR_OK) return rc;
+    return svsr_colsum_rows(row_loss, R, 1, loss, 1, nullptr, 0, 0, 1.0f / (float)R, stream);     // *loss = mean of the row losses
 }
 
 int svsr_ce_bwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt,
@@ -260,16 +274,19 @@ int svsr_ce_bwd(const void* logits, int logits_f32, int ld, const int64_t* targe
     return svsr_check_launch();
 }
 
-int svsr_topk_acc(const float* logits, const int64_t* labels, const float* soft_labels, int B, int C, float* out2, hipStream_t stream) {
-    if ((labels == nullptr) == (soft_labels == nullptr)) return SVSR_ERR_ARG;
+int svsr_topk_acc(const float* logits, const int64_t* labels, const float* soft_labels, int B, int C, float* out2, float* rows2,
+                  hipStream_t stream) {
+    if ((labels == nullptr) == (soft_labels == nullptr) || rows2 == nullptr || B < 1) return SVSR_ERR_ARG;      // rows2: [B][2] floats
     int grid = (B + 3) / 4; if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(k_topk_acc, dim3(grid), dim3(256), 0, stream, logits, (const long*)labels, soft_labels, B, C, out2);
-    return svsr_check_launch();
+    hipLaunchKernelGGL(k_topk_acc, dim3(grid), dim3(256), 0, stream, logits, (const long*)labels, soft_labels, B, C, rows2);
+    const int rc = svsr_check_launch();
+    if (rc != SVSR_OK) return rc;
+    return svsr_colsum_rows(rows2, B, 2, out2, 2, nullptr, 0, 0, 1.0f / (float)B, stream);
 }
 
 int svsr_grad_sumsq(const float* g, int64_t n, void* opt_state, hipStream_t stream) {
     if (((uintptr_t)g & 15) != 0) return SVSR_ERR_ARG;
-    hipLaunchKernelGGL(k_grad_sumsq, dim3(grid_for(n / 4)), dim3(256), 0, stream, g, (long)n, (OptState*)opt_state);
+    hipLaunchKernelGGL(k_grad_sumsq, dim3(OPT_PARTS), dim3(256), 0, stream, g, (long)n, (OptState*)opt_state);
     return svsr_check_launch();
 }
 
@@ -279,7 +296,7 @@ int svsr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, 
     AdamArgs a{p, g, m, v, (bf16_t*)shadow, (long)n, (long)decay_end, lr, beta1, beta2, eps, weight_decay, max_norm, warmup,
                total_steps, (OptState*)opt_state};
     hipLaunchKernelGGL(k_adamw, dim3(grid_for(n)), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(k_opt_advance, dim3(1), dim3(1), 0, stream, (OptState*)opt_state, lr, warmup, total_steps);
+    hipLaunchKernelGGL(k_opt_advance, dim3(1), dim3(256), 0, stream, (OptState*)opt_state, lr, warmup, total_steps);
     return svsr_check_launch();
 }
 

@@ -65,9 +65,9 @@ __global__ __launch_bounds__(256) void k_glu_dwconv_fwd(const bf16_t* __restrict
         __syncthreads();
         if (threadIdx.x < 128) {
             const int which = threadIdx.x >> 6;
-            const float v = sRed[0][which][ch] + sRed[1][which][ch] + sRed[2][which][ch] + sRed[3][which][ch];
-            const int slot = (blockIdx.x + blockIdx.z) & (SVSR_STAT_SLOTS - 1);
-            atomicAdd(stats + ((long)slot * 2 + which) * D + c0 + ch, v);
+            const float v = ((sRed[0][which][ch] + sRed[1][which][ch]) + sRed[2][which][ch]) + sRed[3][which][ch];
+            const long row = (long)blockIdx.z * gridDim.x + blockIdx.x;      // one row of partials per (clip, 64-frame tile)
+            stats[(row * 2 + which) * D + c0 + ch] = v;
         }
     }
 }
@@ -176,8 +176,7 @@ __device__ __forceinline__ float lae(float a, float b) {       // log(exp(a) + e
 
 __global__ __launch_bounds__(256) void k_ctc_lattice(const float* __restrict__ z, int ld, const float* __restrict__ lse,
                                                      const long* __restrict__ labels, int Lmax, const int* __restrict__ ilen,
-                                                     int B, int T, int Smax, float* __restrict__ ab, float* __restrict__ nll_out,
-                                                     float* __restrict__ loss_sum) {
+                                                     int B, int T, int Smax, float* __restrict__ ab, float* __restrict__ nll_out) {
     extern __shared__ float sm[];             // prev[Smax], cur[Smax], ext (int)[Smax]
     float* prev = sm;
     float* cur = sm + Smax;
@@ -224,10 +223,7 @@ __global__ __launch_bounds__(256) void k_ctc_lattice(const float* __restrict__ z
     }
     __syncthreads();
     const bool inf = !(nll < INFINITY);               // zero_infinity=True: infeasible alignments contribute 0 and no gradient
-    if (tid == 0) {
-        nll_out[b] = inf ? 0.f : nll;
-        if (!inf) atomicAdd(loss_sum, nll / (float)B);
-    }
+    if (tid == 0) nll_out[b] = inf ? 0.f : nll;          // the loss is the fixed-order sum of nll_out / B (svsr_colsum_rows)
     // beta (including the emission at t), combined into occupancy  occ[t][s] = exp(alpha + beta + nll - lp[t][ext s])
     for (int s = tid; s < S; s += 256) {
         float v = -INFINITY;
@@ -262,7 +258,7 @@ __global__ __launch_bounds__(256) void k_ctc_grad(const float* __restrict__ z, i
                                                   const long* __restrict__ labels, int Lmax, const int* __restrict__ ilen,
                                                   const float* __restrict__ ab, const float* __restrict__ nll, int B, int T, int V, int Smax,
                                                   const float* __restrict__ gout, bf16_t* __restrict__ dz, int ldo) {
-    extern __shared__ float sAcc[];          // [V]
+    extern __shared__ float sAcc[];          // [V] occupancy per class, then [Smax] staged (class, occupancy) pairs
     const int row = blockIdx.x, b = row / T, t = row - b * T;
     bf16_t* o = dz + (long)row * ldo;
     const bool live = t < ilen[b] && nll[b] != 0.f;
@@ -276,9 +272,23 @@ __global__ __launch_bounds__(256) void k_ctc_grad(const float* __restrict__ z, i
     while (len < Lmax && labels[(long)b * Lmax + len] >= 0) ++len;
     const int S = 2 * len + 1;
     const float* occ = ab + ((long)b * T + t) * Smax;
+    // lattice states that emit the same class (every blank; repeated labels) are added in increasing state order by the
+    // thread of the FIRST such state — no atomics, so the gradient is reproducible
+    int* sExt = reinterpret_cast<int*>(sAcc + V);
+    float* sOcc = sAcc + V + Smax;
     for (int s = threadIdx.x; s < S; s += 256) {
-        const int e = (s & 1) ? (int)labels[(long)b * Lmax + (s >> 1)] : 0;
-        atomicAdd(&sAcc[e], occ[s]);
+        sExt[s] = (s & 1) ? (int)labels[(long)b * Lmax + (s >> 1)] : 0;
+        sOcc[s] = occ[s];
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const int e = sExt[s];
+        bool first = true;
+        for (int s2 = 0; s2 < s; ++s2) first = first && sExt[s2] != e;
+        if (!first) continue;
+        float acc = 0.f;
+        for (int s2 = s; s2 < S; ++s2) acc += sExt[s2] == e ? sOcc[s2] : 0.f;
+        if (e >= 0 && e < V) sAcc[e] = acc;
     }
     __syncthreads();
     const float g = gout[0] / (float)B, l = lse[row];
@@ -304,11 +314,19 @@ __global__ __launch_bounds__(256) void k_embed_pos_fwd(const long* __restrict__ 
     }
 }
 
+// Rows of a repeated token are added in increasing row order by the threads of its FIRST occurrence (no atomics).
 __global__ __launch_bounds__(256) void k_embed_pos_bwd(const long* __restrict__ tok, const bf16_t* __restrict__ dx, float* __restrict__ demb,
                                                        int R, int D, float scale) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)R * D; idx += (long)gridDim.x * 256) {
         const int r = (int)(idx / D), c = (int)(idx - (long)r * D);
-        atomicAdd(demb + tok[r] * D + c, bf2f(dx[idx]) * scale);
+        const long tk = tok[r];
+        bool first = true;
+        for (int r2 = 0; r2 < r; ++r2) first = first && tok[r2] != tk;
+        if (!first) continue;
+        float acc = 0.f;
+        for (int r2 = r; r2 < R; ++r2)
+            if (tok[r2] == tk) acc += bf2f(dx[(long)r2 * D + c]) * scale;
+        demb[tk * D + c] += acc;
     }
 }
 
@@ -317,8 +335,7 @@ __global__ __launch_bounds__(256) void k_embed_pos_bwd(const long* __restrict__ 
 // over rows whose target != ignore; counts[0] += correct argmax, counts[1] += live rows.  One wave per row.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ls_loss_fwd(const float* __restrict__ z, int ld, const long* __restrict__ target, int R, int V,
-                                                     float smoothing, float inv_denom, float* __restrict__ loss_sum, float* __restrict__ lse,
-                                                     float* __restrict__ counts) {
+                                                     float smoothing, float inv_denom, float* __restrict__ rows3, float* __restrict__ lse) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float conf = 1.f - smoothing, low = smoothing / (float)(V - 1);
     const float ent = (conf > 0.f ? conf * __logf(conf) : 0.f) + (low > 0.f ? (float)(V - 1) * low * __logf(low) : 0.f);
@@ -339,14 +356,14 @@ __global__ __launch_bounds__(256) void k_ls_loss_fwd(const float* __restrict__ z
         const float l = m + __logf(se);
         if (lane == 0) {
             lse[row] = l;
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f;       // (loss, correct, live) of this row; the totals are their fixed-order column sums
             if (t >= 0) {
-                const float zt = p[t];
+                const float zt = t < V ? p[t] : __uint_as_float(0x7fc00000u);      // out-of-range target: poison, do not read out of bounds
                 // -sum true_v log p_v = conf (lse - z_t) + low ((V-1) lse - (sum z - z_t))
                 const float nl = conf * (l - zt) + low * ((float)(V - 1) * l - (sz - zt));
-                atomicAdd(loss_sum, (ent + nl) * inv_denom);
-                atomicAdd(counts + 0, am == (int)t ? 1.f : 0.f);
-                atomicAdd(counts + 1, 1.f);
+                r0 = (ent + nl) * inv_denom; r1 = am == (int)t ? 1.f : 0.f; r2 = 1.f;
             }
+            rows3[row * 3 + 0] = r0; rows3[row * 3 + 1] = r1; rows3[row * 3 + 2] = r2;
         }
     }
 }
@@ -390,6 +407,12 @@ static inline int grid1d(long n, int cap = 2048) { long b = (n + 255) / 256; if 
 
 extern "C" {
 
+int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale,
+                     hipStream_t stream);
+
+/* rows of [2][D] BatchNorm1d partials svsr_glu_dwconv_fwd writes (one per clip and 64-frame tile) */
+int svsr_glu_dwconv_fwd_stat_rows(int B, int T) { return (B < 1 || T < 1) ? 0 : B * ((T + DW_TT - 1) / DW_TT); }
+
 int svsr_glu_dwconv_fwd(const void* u, const float* w, const float* bias, void* c, float* stats, int B, int T, int D, int K, hipStream_t stream) {
     if (D % 64 != 0 || K < 1 || K > DW_MAXK || (K & 1) == 0) return SVSR_ERR_ARG;
     hipLaunchKernelGGL(k_glu_dwconv_fwd, dim3((T + DW_TT - 1) / DW_TT, D / 64, B), dim3(256), 0, stream, (const bf16_t*)u, w, bias, (bf16_t*)c,
@@ -410,21 +433,24 @@ int svsr_glu_dwconv_bwd(const void* dc, const void* u, const float* w, void* du,
 }
 
 /* logits fp32 [B*T][ld]; labels int64 [B][Lmax] padded with -1; ilen int32 [B]; ab workspace fp32 [B][T][2*Lmax+1];
- * lse [B*T], nll [B] scratch; loss_sum += sum_b nll_b / B.  Then svsr_ctc_grad writes dlogits (bf16, pitch ldo). */
+ * lse [B*T], nll [B] scratch; *loss = sum_b nll_b / B (fixed order).  Then svsr_ctc_grad writes dlogits (bf16, pitch ldo). */
 int svsr_ctc_fwd(const float* logits, int ld, const int64_t* labels, int Lmax, const int* ilen, int B, int T, int V, float* lse,
-                 float* ab, float* nll, float* loss_sum, hipStream_t stream) {
+                 float* ab, float* nll, float* loss, hipStream_t stream) {
     if (Lmax < 1 || T < 1 || V < 2) return SVSR_ERR_ARG;
     const int Smax = 2 * Lmax + 1;
     hipLaunchKernelGGL(k_row_lse, dim3(grid1d((long)B * T * 64)), dim3(256), 0, stream, logits, ld, B * T, V, lse);
     hipLaunchKernelGGL(k_ctc_lattice, dim3(B), dim3(256), (size_t)3 * Smax * sizeof(float), stream, logits, ld, lse, (const long*)labels, Lmax, ilen,
-                       B, T, Smax, ab, nll, loss_sum);
-    return svsr_check_launch();
+                       B, T, Smax, ab, nll);
+    const int rc = svsr_check_launch();
+    if (rc != SVSR_OK) return rc;
+    return svsr_colsum_rows(nll, B, 1, loss, 1, nullptr, 0, 0, 1.0f / (float)B, stream);
 }
 
 int svsr_ctc_grad(const float* logits, int ld, const int64_t* labels, int Lmax, const int* ilen, int B, int T, int V, const float* lse,
                   const float* ab, const float* nll, const float* gout, void* dlogits, int ldo, hipStream_t stream) {
-    if (Lmax < 1 || (size_t)V * sizeof(float) > 60 * 1024) return SVSR_ERR_ARG;
-    hipLaunchKernelGGL(k_ctc_grad, dim3(B * T), dim3(256), (size_t)V * sizeof(float), stream, logits, ld, lse, (const long*)labels, Lmax, ilen, ab,
+    const size_t lds = ((size_t)V + 2 * (2 * Lmax + 1)) * sizeof(float);
+    if (Lmax < 1 || lds > 60 * 1024) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_ctc_grad, dim3(B * T), dim3(256), lds, stream, logits, ld, lse, (const long*)labels, Lmax, ilen, ab,
                        nll, B, T, V, 2 * Lmax + 1, gout, (bf16_t*)dlogits, ldo);
     return svsr_check_launch();
 }
@@ -440,12 +466,14 @@ int svsr_embed_pos_bwd(const int64_t* tok, const void* dx, float* demb, int R, i
     return svsr_check_launch();
 }
 
-int svsr_ls_loss_fwd(const float* logits, int ld, const int64_t* target, int R, int V, float smoothing, float inv_denom, float* loss_sum,
-                     float* lse, float* counts, hipStream_t stream) {
-    if (V < 2) return SVSR_ERR_ARG;
+int svsr_ls_loss_fwd(const float* logits, int ld, const int64_t* target, int R, int V, float smoothing, float inv_denom, float* loss,
+                     float* lse, float* counts, float* rows3, hipStream_t stream) {
+    if (V < 2 || R < 1 || rows3 == nullptr) return SVSR_ERR_ARG;          // rows3: [R][3] floats
     hipLaunchKernelGGL(k_ls_loss_fwd, dim3(grid1d((long)R * 64)), dim3(256), 0, stream, logits, ld, (const long*)target, R, V, smoothing, inv_denom,
-                       loss_sum, lse, counts);
-    return svsr_check_launch();
+                       rows3, lse);
+    const int rc = svsr_check_launch();
+    if (rc != SVSR_OK) return rc;
+    return svsr_colsum_rows(rows3, R, 3, loss, 1, counts, 2, 0, 1.0f, stream);
 }
 
 int svsr_ls_loss_bwd(const float* logits, int ld, const int64_t* target, int R, int V, float smoothing, float inv_denom, const float* lse,

@@ -8,20 +8,46 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------------------
-// statistics finalisation.  slots: [SVSR_STAT_SLOTS][2][C] (sum, sum of squares) accumulated by the producing
-// conv's epilogue.  Writes mean / rstd, updates the running statistics exactly as torch does
-// (momentum 0.1, unbiased variance for the running estimate) and re-zeroes the slots for the next step.
+// statistics finalisation.  part: [nrows][2][C] (sum, sum of squares), one row per workgroup of the producing conv's
+// epilogue (plain stores).  Rows are added in a FIXED order — 32 row lanes each walking rows rl, rl+32, ... then the lane
+// sums in lane order, in double — so the statistics, and with them the whole step, are reproducible run to run.
+// Writes mean / rstd and updates the running statistics exactly as torch does (momentum 0.1, unbiased variance for the
+// running estimate).  Block = 32 channels x 32 row lanes.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void k_bn_finalize(float* slots, int C, float count, float eps, float momentum, float* mean, float* rstd,
-                              float* running_mean, float* running_var, long* num_batches_tracked) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < SVSR_STAT_SLOTS; ++k) {
-            s += (double)slots[(k * 2 + 0) * C + c];
-            q += (double)slots[(k * 2 + 1) * C + c];
-            slots[(k * 2 + 0) * C + c] = 0.f;
-            slots[(k * 2 + 1) * C + c] = 0.f;
+__device__ __forceinline__ void bn_rows_sum(const float* __restrict__ part, int nrows, int C, int c, bool live, int rl, int cl,
+                                            double (*sred)[2][32], double& s, double& q) {
+    double a = 0.0, b = 0.0;
+    if (live) {
+        int r = rl;
+        for (; r + 96 < nrows; r += 128) {           // four independent row pairs in flight, added in row order
+            const float a0 = part[((long)r * 2 + 0) * C + c], b0 = part[((long)r * 2 + 1) * C + c];
+            const float a1 = part[((long)(r + 32) * 2 + 0) * C + c], b1 = part[((long)(r + 32) * 2 + 1) * C + c];
+            const float a2 = part[((long)(r + 64) * 2 + 0) * C + c], b2 = part[((long)(r + 64) * 2 + 1) * C + c];
+            const float a3 = part[((long)(r + 96) * 2 + 0) * C + c], b3 = part[((long)(r + 96) * 2 + 1) * C + c];
+            a = (((a + (double)a0) + (double)a1) + (double)a2) + (double)a3;
+            b = (((b + (double)b0) + (double)b1) + (double)b2) + (double)b3;
         }
+        for (; r < nrows; r += 32) { a += (double)part[((long)r * 2 + 0) * C + c]; b += (double)part[((long)r * 2 + 1) * C + c]; }
+    }
+    sred[rl][0][cl] = a;
+    sred[rl][1][cl] = b;
+    __syncthreads();
+    s = 0.0; q = 0.0;
+    if (rl == 0) {
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) { s += sred[k][0][cl]; q += sred[k][1][cl]; }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ part, int nrows, int C, float count, float eps, float momentum,
+                                                      float* mean, float* rstd, float* running_mean, float* running_var,
+                                                      long* num_batches_tracked) {
+    __shared__ double sred[32][2][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s, q;
+    bn_rows_sum(part, nrows, C, c, c < C, rl, cl, sred, s, q);
+    if (rl == 0 && c < C) {
         const double m = s / (double)count;
         double var = q / (double)count - m * m;
         if (var < 0.0) var = 0.0;
@@ -82,26 +108,26 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const bf16_t* __restrict__ x
     }
 }
 
-// block-level reduction of per-thread 8-channel partials into the atomic slots
-__device__ __forceinline__ void reduce_to_slots(float* sred, const float* s1, const float* s2, int cv, int c0, int C,
-                                                float* slots, int first_group = 0) {
+// block-level reduction of per-thread 8-channel partials into this workgroup's row of the partials [rows][2][C]
+// (fixed order inside the block; k_bn_bwd_finalize adds the rows in a fixed order)
+__device__ __forceinline__ void reduce_to_row(float* sred, const float* s1, const float* s2, int cv, int C, float* part,
+                                              int first_group = 0) {
     // sred: [256][16]
     const int tid = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sred[tid * 16 + k] = s1[k]; sred[tid * 16 + 8 + k] = s2[k]; }
     __syncthreads();
     // thread t owns channel group (first_group + t) % cv; first_group = 0 whenever 256 % cv == 0
+    const long row = (long)blockIdx.y * gridDim.x + blockIdx.x;
     for (int o = tid; o < cv * 16; o += 256) {
         const int g = o >> 4, k = o & 15;
         float acc = 0.f;
         int t0 = g - first_group;
         if (t0 < 0) t0 += cv;
         for (int t = t0; t < 256; t += cv) acc += sred[t * 16 + k];
-        const int slot = (blockIdx.x + blockIdx.y) & (SVSR_STAT_SLOTS - 1);
         const int which = k >> 3, c = g * 8 + (k & 7);
-        atomicAdd(slots + ((long)slot * 2 + which) * C + c, acc);
+        part[(row * 2 + which) * C + c] = acc;
     }
-    (void)c0;
 }
 
 // pass 1 of the backward: slots += (sum g, sum g * xhat) with g = dy * act'(.)   (relu mask from saved y)
@@ -145,20 +171,19 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_reduce(const bf16_t* __restr
 #pragma unroll
         for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * (xv[k] - mu[k]) * rs[k]; }
     }
-    reduce_to_slots(sred, s1, s2, cv, c0, C, slots, first_group);
+    reduce_to_row(sred, s1, s2, cv, C, slots, first_group);
 }
 
-// finalise the backward statistics: dbeta += sum g, dgamma += sum g*xhat, coef = {gamma*rstd, sum g / n, sum g*xhat / n}
-__global__ void k_bn_bwd_finalize(float* slots, int C, float count, const float* gamma, const float* rstd,
-                                  float* dgamma, float* dbeta, float* coef) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < SVSR_STAT_SLOTS; ++k) {
-            s += (double)slots[(k * 2 + 0) * C + c];
-            q += (double)slots[(k * 2 + 1) * C + c];
-            slots[(k * 2 + 0) * C + c] = 0.f;
-            slots[(k * 2 + 1) * C + c] = 0.f;
-        }
+// finalise the backward statistics (rows added in the same fixed order as k_bn_finalize):
+// dbeta += sum g, dgamma += sum g*xhat, coef = {gamma*rstd, sum g / n, sum g*xhat / n}
+__global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float* __restrict__ part, int nrows, int C, float count, const float* gamma,
+                                                          const float* rstd, float* dgamma, float* dbeta, float* coef) {
+    __shared__ double sred[32][2][32];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s, q;
+    bn_rows_sum(part, nrows, C, c, c < C, rl, cl, sred, s, q);
+    if (rl == 0 && c < C) {
         dbeta[c] += (float)s;
         dgamma[c] += (float)q;
         coef[c] = gamma[c] * rstd[c];
@@ -338,7 +363,7 @@ __global__ __launch_bounds__(256) void k_stem_pool_bwd_reduce(const bf16_t* __re
 #pragma unroll
         for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * xh[k]; }
     }
-    reduce_to_slots(sred, s1, s2, it.cv, c0, C, slots);
+    reduce_to_row(sred, s1, s2, it.cv, C, slots);
 }
 
 template <int ACT>
@@ -530,7 +555,7 @@ __global__ __launch_bounds__(256) void k_stem_bwd_lds(const bf16_t* __restrict__
             for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * xh[k]; }
         }
     }
-    if (!APPLY) reduce_to_slots(sred, s1, s2, cv, c0, C, slots);
+    if (!APPLY) reduce_to_row(sred, s1, s2, cv, C, slots);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -582,27 +607,25 @@ static inline int ew_grid(long nvec) {
 }
 // measured at 928 x 44 x 44 x 64: forward 191 us (direct) vs 225 us (LDS-tiled) — the pass is bound by the erf/exp VALU work,
 // not by the redundant window reads; backward 411 us (direct) vs 360 us (LDS-tiled).  Defaults follow the measurement.
-static inline bool stem_lds_fwd() {
-    static const bool v = [] { const char* e = getenv("SVSR_STEM_LDS_FWD"); return e != nullptr && e[0] == '1'; }();
-    return v;
-}
-static inline bool stem_lds_bwd() {
-    static const bool v = [] { const char* e = getenv("SVSR_STEM_LDS_BWD"); return !(e != nullptr && e[0] == '0'); }();
-    return v;
-}
+static inline bool stem_lds_fwd() { return svsr_tune_get(SVSR_TUNE_STEM_LDS_FWD) != 0; }
+static inline bool stem_lds_bwd() { return svsr_tune_get(SVSR_TUNE_STEM_LDS_BWD) != 0; }
 static inline bool chan_ok(int C) { return C >= 8 && C <= 2048 && (2048 % C) == 0; }
 // any C % 8 == 0 up to 2048 (e.g. 768): the grid is rounded so that gridDim.x * 256 is a multiple of C/8 and every
 // thread keeps one channel group across its grid-stride loop
 static inline bool chan_ok_any(int C) { return C >= 8 && C <= 2048 && (C % 8) == 0; }
-static inline int ew_grid_for(long nvec, int C) {
+static inline int ew_grid_for(long nvec, int C, int cap = 2048) {
     const int cv = C / 8;
     int a = cv, b = 256;
     while (b) { const int t = a % b; a = b; b = t; }
     const int m = cv / a;                 // grid must be a multiple of cv / gcd(cv, 256)
     int g = ew_grid(nvec);
+    if (g > cap) g = cap;
     g = (g + m - 1) / m * m;
     return g;
 }
+// reduction passes write one row of partials per workgroup: 1024 workgroups (4 per CU) still stream at HBM speed and keep the
+// fixed-order finalisation short
+static inline int bn_bwd_grid(long nvec, int C) { return ew_grid_for(nvec, C, 1024); }
 
 // rows-per-block iteration for the stem passes: needs C/8 a power of two <= 256; ~1024 items per block
 static inline bool stem_iter(StemRowIter& it, int C, int W, int H) {
@@ -620,9 +643,10 @@ static inline bool stem_iter(StemRowIter& it, int C, int W, int H) {
 
 extern "C" {
 
-int svsr_bn_finalize(float* slots, int C, float count, float eps, float momentum, float* mean, float* rstd,
+int svsr_bn_finalize(const float* part, int nrows, int C, float count, float eps, float momentum, float* mean, float* rstd,
                      float* running_mean, float* running_var, int64_t* num_batches_tracked, hipStream_t stream) {
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 127) / 128), dim3(128), 0, stream, slots, C, count, eps, momentum, mean, rstd,
+    if (nrows < 1 || C < 1) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 31) / 32), dim3(1024), 0, stream, part, nrows, C, count, eps, momentum, mean, rstd,
                        running_mean, running_var, (long*)num_batches_tracked);
     return svsr_check_launch();
 }
@@ -642,20 +666,24 @@ int svsr_bn_act_fwd(const void* x, const void* res, void* y, const float* mean, 
     return svsr_check_launch();
 }
 
+/* rows of [2][C] partials svsr_bn_act_bwd needs in its workspace for this shape */
+int svsr_bn_act_bwd_rows(int64_t npix, int C) { return chan_ok_any(C) && npix > 0 ? bn_bwd_grid(npix * (C / 8), C) : 0; }
+
 int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma,
                     float* slots, float* coef, float* dgamma, float* dbeta, void* dx, void* dres, int64_t npix, int C, int act,
                     const float* beta, const void* res, hipStream_t stream) {
     if (!chan_ok_any(C)) return SVSR_ERR_ARG;
     if (act == 2 && beta == nullptr) return SVSR_ERR_ARG;
     const long nvec = npix * (C / 8);
-    const int grid = ew_grid_for(nvec, C);
+    const int grid = bn_bwd_grid(nvec, C);
+    const int grid_apply = ew_grid_for(nvec, C);
 #define SVSR_BN_BWD_REDUCE(A) hipLaunchKernelGGL(k_bn_act_bwd_reduce<A>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, \
                        (const bf16_t*)x, mean, rstd, nvec, C, slots, gamma, beta, (const bf16_t*)res)
-#define SVSR_BN_BWD_APPLY(A) hipLaunchKernelGGL(k_bn_act_bwd_apply<A>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, \
+#define SVSR_BN_BWD_APPLY(A) hipLaunchKernelGGL(k_bn_act_bwd_apply<A>, dim3(grid_apply), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)y, \
                        (const bf16_t*)x, mean, rstd, coef, (bf16_t*)dx, (bf16_t*)dres, nvec, C, gamma, beta, (const bf16_t*)res)
     if (act < 0 || act > 2) return SVSR_ERR_ARG;
     if (act == 2) SVSR_BN_BWD_REDUCE(2); else if (act == 1) SVSR_BN_BWD_REDUCE(1); else SVSR_BN_BWD_REDUCE(0);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 127) / 128), dim3(128), 0, stream, slots, C, (float)npix, gamma, rstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(1024), 0, stream, slots, grid, C, (float)npix, gamma, rstd, dgamma, dbeta, coef);
     if (act == 2) SVSR_BN_BWD_APPLY(2); else if (act == 1) SVSR_BN_BWD_APPLY(1); else SVSR_BN_BWD_APPLY(0);
     return svsr_check_launch();
 }
@@ -694,6 +722,16 @@ int svsr_stem_bn_act_pool_fwd(const void* x, void* y, void* amax, const float* m
     return svsr_check_launch();
 }
 
+static inline bool stem_bwd_uses_lds(int Wp, int C) { return stem_lds_bwd() && (size_t)(STEM_BR / 2 + 1) * Wp * C * 3 <= 60 * 1024; }
+
+/* rows of [2][C] partials svsr_stem_bn_act_pool_bwd needs in its workspace for this shape */
+int svsr_stem_bn_act_pool_bwd_rows(int N, int Hc, int Wc, int C) {
+    StemRowIter it;
+    if (!chan_ok(C) || !stem_iter(it, C, Wc, Hc) || N < 1) return 0;
+    const int Wp = (Wc - 1) / 2 + 1;
+    return N * (stem_bwd_uses_lds(Wp, C) ? (Hc + STEM_BR - 1) / STEM_BR : (Hc + it.rpb - 1) / it.rpb);
+}
+
 int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x, const float* mean, const float* rstd,
                               const float* gamma, const float* beta, float* slots, float* coef, float* dgamma, float* dbeta,
                               void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, hipStream_t stream) {
@@ -701,12 +739,13 @@ int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x
     StemRowIter it;
     if (!stem_iter(it, C, Wc, Hc)) return SVSR_ERR_ARG;
     const size_t lds_b = (size_t)(STEM_BR / 2 + 1) * Wp * C * 3;
-    if (stem_lds_bwd() && lds_b <= 60 * 1024) {
+    const int nrows = svsr_stem_bn_act_pool_bwd_rows(N, Hc, Wc, C);
+    if (stem_bwd_uses_lds(Wp, C)) {
         const dim3 g2((Hc + STEM_BR - 1) / STEM_BR, N);
 #define SVSR_STEM_BWD(A, AP) hipLaunchKernelGGL((k_stem_bwd_lds<A, AP>), g2, dim3(256), lds_b, stream, (const bf16_t*)dpool, (const unsigned char*)amax, \
                        (const bf16_t*)x, mean, rstd, gamma, beta, coef, (bf16_t*)dx, slots, Hc, Wc, Hp, Wp, C)
         if (act == SVSR_ACT_SWISH) SVSR_STEM_BWD(2, false); else SVSR_STEM_BWD(1, false);
-        hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 127) / 128), dim3(128), 0, stream, slots, C, (float)((long)N * Hc * Wc), gamma, rstd,
+        hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(1024), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
                            dgamma, dbeta, coef);
         if (act == SVSR_ACT_SWISH) SVSR_STEM_BWD(2, true); else SVSR_STEM_BWD(1, true);
         return svsr_check_launch();
@@ -718,7 +757,7 @@ int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x
     else
         hipLaunchKernelGGL(k_stem_pool_bwd_reduce<1>, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
                            (const bf16_t*)x, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, slots, it);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 127) / 128), dim3(128), 0, stream, slots, C, (float)((long)N * Hc * Wc), gamma, rstd,
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(1024), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
                        dgamma, dbeta, coef);
     if (act == SVSR_ACT_SWISH)
         hipLaunchKernelGGL(k_stem_pool_bwd_apply<2>, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,

@@ -1,0 +1,87 @@
+// Library-wide plumbing (gfx950): the tuning table, and the fixed-order reductions that make a training step
+// reproducible.
+//
+// No kernel of this library accumulates floating-point values with atomics.  Every grid-wide sum (BatchNorm statistics,
+// split-K weight gradients, bias / LayerNorm-parameter gradients, losses, the gradient norm) is produced in two steps:
+// each workgroup writes its partial result to its OWN row of a caller-owned workspace with plain stores, and a second,
+// tiny launch adds the rows in a fixed order (k_colsum below, or the specialised BatchNorm finalisers in norm_act.hip).
+// Two identical steps therefore give bit-identical results, which torch's own GPU kernels do not promise for the
+// reference path (DistributedDataParallel over cuDNN/MIOpen; reference LRW/video/src/train.py:23-40).
+#include <string.h>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tuning table: result-preserving knobs only (tile shapes, split counts, variant switches); set by svsr_tune(), never read
+// from the environment.
+// ---------------------------------------------------------------------------------------------------------------------
+static int g_tune[SVSR_TUNE_N] = {
+    /* IGEMM_TILE   */ 0,      // 0 auto, 64 / 128: force the M tile of svsr_igemm_fwd
+    /* IGEMM_M128   */ 8192,   // rows from which 128-row tiles are used
+    /* WG_BLOCKS    */ 0,      // target workgroups of svsr_igemm_wgrad (0: built-in per tile size)
+    /* W3_BLOCKS    */ 384,    // target workgroups of svsr_conv3x3_wgrad
+    /* LN_RPB       */ 16,     // rows per workgroup of svsr_add_ln_bwd
+    /* STEM_LDS_FWD */ 0,      // LDS-tiled stem BN+act+pool forward (measured slower)
+    /* STEM_LDS_BWD */ 1,      // LDS-tiled stem BN+act+pool backward (measured faster)
+};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd"};
+
+int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
+
+extern "C" int svsr_tune(const char* key, int value) {
+    if (key == nullptr) return SVSR_ERR_ARG;
+    for (int i = 0; i < SVSR_TUNE_N; ++i)
+        if (strcmp(key, g_tune_names[i]) == 0) { g_tune[i] = value; return SVSR_OK; }
+    return SVSR_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out[c] (+)= scale * sum_{r < nrows} ws[r * ld + c]   for c < n0 + n1; columns [0, n0) go to out0, [n0, n0 + n1) to out1.
+// Block = 256 threads = CL columns x RL row lanes (RL = 256 / CL): lane rl adds rows rl, rl + RL, ... in increasing order,
+// then the RL lane sums are added in increasing lane order — a fixed association whatever the launch order.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CL>
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ ws, int nrows, long ld, float* __restrict__ out0, long n0,
+                                                 float* __restrict__ out1, long n1, int accumulate, float scale) {
+    constexpr int RL = 256 / CL;
+    __shared__ float sred[256];
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const long c = (long)blockIdx.x * CL + cl;
+    const bool live = c < n0 + n1;
+    float acc = 0.f;
+    if (live) {
+        const float* src = ws + c;
+        int r = rl;
+        for (; r + 3 * RL < nrows; r += 4 * RL) {      // four independent loads in flight, added in row order
+            const float a = src[(long)r * ld], b = src[(long)(r + RL) * ld], d = src[(long)(r + 2 * RL) * ld], e = src[(long)(r + 3 * RL) * ld];
+            acc = (((acc + a) + b) + d) + e;
+        }
+        for (; r < nrows; r += RL) acc += src[(long)r * ld];
+    }
+    if (RL > 1) {
+        sred[threadIdx.x] = acc;
+        __syncthreads();
+        if (rl != 0) return;
+        acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < RL; ++k) acc += sred[k * CL + cl];
+    }
+    if (!live) return;
+    float* dst = c < n0 ? out0 + c : out1 + (c - n0);
+    const float v = acc * scale;
+    *dst = accumulate ? *dst + v : v;
+}
+
+extern "C" int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate,
+                                float scale, hipStream_t stream) {
+    const long n = (long)n0 + (long)n1;
+    if (nrows < 0 || n <= 0 || ld < n || (n1 > 0 && out1 == nullptr) || out0 == nullptr) return SVSR_ERR_ARG;
+    // many columns, few rows (split-K slabs): one thread per column.  Few columns, many rows (statistics, losses): row lanes.
+#define SVSR_COLSUM(CL_) hipLaunchKernelGGL(k_colsum<CL_>, dim3((unsigned)((n + CL_ - 1) / CL_)), dim3(256), 0, stream, ws, nrows, (long)ld, out0, (long)n0, out1, (long)n1, accumulate, scale)
+    if (nrows <= 8 || n >= 65536) SVSR_COLSUM(256);
+    else if (nrows <= 64 || n >= 8192) SVSR_COLSUM(32);
+    else if (n >= 8) SVSR_COLSUM(8);
+    else SVSR_COLSUM(1);
+#undef SVSR_COLSUM
+    return svsr_check_launch();
+}

@@ -14,7 +14,7 @@ struct StemFwdArgs {
     const float* vid;   // [B][T][H][W] fp32 (C = 1)
     const float* w;     // [64][5][7][7] fp32
     bf16_t* out;        // [B*T][Ho][Wo][64] bf16
-    float* stats;       // optional BatchNorm slots [SVSR_STAT_SLOTS][2][64]
+    float* stats;       // optional BatchNorm partials [gridDim.x][2][64]: one row per (persistent) workgroup
     int B, T, H, W, Ho, Wo;
     int tiles_per_frame, total_tiles;
     int rows_in_max, WP;   // LDS input tile: [5][rows_in_max][WP]
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_stem_conv_fwd(const StemFwdArgs p) {
         sW[c * STEM_WPITCH + r * 8 + kw] = f2bf(v);
     }
 
-    float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};
+    float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};   // this lane's channel (jt*32 + lane&31), over the rows this lane holds
 
     for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
         const int f = tile / p.tiles_per_frame, tp = tile - f * p.tiles_per_frame;
@@ -119,15 +119,25 @@ __global__ __launch_bounds__(256) void k_stem_conv_fwd(const StemFwdArgs p) {
         }
     }
     if (p.stats != nullptr) {
+        // the four waves hold disjoint positions of the same 64 channels: add them in wave order through LDS, then one plain
+        // store per channel and statistic into this workgroup's row (svsr_bn_finalize adds the rows in a fixed order)
+        __syncthreads();
+        float* sred = reinterpret_cast<float*>(smem_raw);          // [4 waves][2][64]
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
-            float s = st_s[jt] + __shfl_xor(st_s[jt], 32, 64);
-            float q = st_q[jt] + __shfl_xor(st_q[jt], 32, 64);
+            const float s = st_s[jt] + __shfl_xor(st_s[jt], 32, 64);
+            const float q = st_q[jt] + __shfl_xor(st_q[jt], 32, 64);
             if (lane < 32) {
-                const int slot = blockIdx.x & (SVSR_STAT_SLOTS - 1);
-                atomicAdd(p.stats + (slot * 2 + 0) * STEM_C + jt * 32 + lane, s);
-                atomicAdd(p.stats + (slot * 2 + 1) * STEM_C + jt * 32 + lane, q);
+                sred[(wave * 2 + 0) * STEM_C + jt * 32 + lane] = s;
+                sred[(wave * 2 + 1) * STEM_C + jt * 32 + lane] = q;
             }
+        }
+        __syncthreads();
+        if (tid < 2 * STEM_C) {
+            const int which = tid >> 6, c = tid & 63;
+            const float v = ((sred[(0 * 2 + which) * STEM_C + c] + sred[(1 * 2 + which) * STEM_C + c]) + sred[(2 * 2 + which) * STEM_C + c]) +
+                            sred[(3 * 2 + which) * STEM_C + c];
+            p.stats[((long)blockIdx.x * 2 + which) * STEM_C + c] = v;
         }
     }
 }
@@ -146,6 +156,7 @@ struct StemWgradArgs {
     const float* vid;
     const bf16_t* dy;   // [B*T][Ho][Wo][64]
     float* dw;          // [64][245] fp32, accumulated
+    float* part;        // slabs [gridDim.x][64*245]: one per (persistent) workgroup, added into dw by svsr_colsum_rows
     int B, T, H, W, Ho, Wo;
     int WoP;            // Wo rounded up to 16
     int PW;             // plane row width (elements, even): WoP + 8
@@ -282,7 +293,8 @@ __global__ __launch_bounds__(256) void k_stem_conv_wgrad(const StemWgradArgs p) 
             }
         }
     }
-    // D[row = channel][col = tap]
+    // D[row = channel][col = tap] -> this workgroup's slab (plain stores; the slabs are added in a fixed order afterwards)
+    float* dst = p.part + (long)blockIdx.x * (STEM_C * 245);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int k = (wave * 2 + q) * 32 + (lane & 31);
@@ -292,12 +304,20 @@ __global__ __launch_bounds__(256) void k_stem_conv_wgrad(const StemWgradArgs p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                atomicAdd(p.dw + c * 245 + k, acc[i][q][r]);
+                dst[c * 245 + k] = acc[i][q][r];
             }
     }
 }
 
 extern "C" {
+
+static int stem_fwd_grid(int B, int T, int H, int W) {
+    const long tiles = (long)(((H / 2) * (W / 2) + 127) / 128) * B * T;
+    return (int)(tiles < 768 ? tiles : 768);      // persistent blocks (3 per CU), weights staged once each
+}
+
+/* rows of [2][64] BatchNorm partials svsr_stem_conv_fwd writes for this shape (= its persistent workgroups) */
+int svsr_stem_conv_fwd_stat_rows(int B, int T, int H, int W) { return (B < 1 || T < 1 || H < 8 || W < 8) ? 0 : stem_fwd_grid(B, T, H, W); }
 
 int svsr_stem_conv_fwd(const float* vid, const float* w, void* out, float* stats, int B, int T, int H, int W, hipStream_t stream) {
     if ((H & 1) || (W & 1) || H < 8 || W < 8) return SVSR_ERR_ARG;
@@ -317,15 +337,35 @@ int svsr_stem_conv_fwd(const float* vid, const float* w, void* out, float* stats
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem_conv_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set = lds;
     }
-    int grid = a.total_tiles < 768 ? a.total_tiles : 768;     // persistent blocks (3 per CU), weights staged once each
+    const int grid = stem_fwd_grid(B, T, H, W);
     hipLaunchKernelGGL(k_stem_conv_fwd, dim3(grid), dim3(256), lds, stream, a);
     return svsr_check_launch();
 }
 
-int svsr_stem_conv_wgrad(const float* vid, const void* dy, float* dw, int B, int T, int H, int W, int use_tr, hipStream_t stream) {
+static int stem_wgrad_grid(int B, int T, int H) {
+    const long tiles = (long)((H / 2 + SW_RB - 1) / SW_RB) * B * T;
+    return (int)(tiles < 512 ? tiles : 512);
+}
+
+/* workspace (floats) svsr_stem_conv_wgrad needs: one [64][245] slab per persistent workgroup */
+int svsr_stem_conv_wgrad_plan(int B, int T, int H, int W, int* splits, int64_t* part_floats) {
+    if ((H & 1) || (W & 1) || H < 8 || W < 8 || B < 1 || T < 1) return SVSR_ERR_ARG;
+    const int g = stem_wgrad_grid(B, T, H);
+    if (splits) *splits = g;
+    if (part_floats) *part_floats = (int64_t)g * STEM_C * 245;
+    return SVSR_OK;
+}
+
+int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale,
+                     hipStream_t stream);
+
+int svsr_stem_conv_wgrad(const float* vid, const void* dy, float* dw, int B, int T, int H, int W, int use_tr, float* part,
+                         int64_t part_floats, hipStream_t stream) {
     if ((H & 1) || (W & 1) || H < 8 || W < 8) return SVSR_ERR_ARG;
+    const int grid = stem_wgrad_grid(B, T, H);
+    if (part == nullptr || part_floats < (int64_t)grid * STEM_C * 245) return SVSR_ERR_ARG;
     StemWgradArgs a;
-    a.vid = vid; a.dy = (const bf16_t*)dy; a.dw = dw;
+    a.vid = vid; a.dy = (const bf16_t*)dy; a.dw = dw; a.part = part;
     a.B = B; a.T = T; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2;
     a.WoP = (a.Wo + 15) / 16 * 16;
     a.PW = a.WoP + 8;
@@ -340,10 +380,11 @@ int svsr_stem_conv_wgrad(const float* vid, const void* dy, float* dw, int B, int
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set[use_tr ? 1 : 0] = lds;
     }
-    int grid = a.total_tiles < 512 ? a.total_tiles : 512;
     if (use_tr) hipLaunchKernelGGL(k_stem_conv_wgrad<true>, dim3(grid), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(k_stem_conv_wgrad<false>, dim3(grid), dim3(256), lds, stream, a);
-    return svsr_check_launch();
+    const int rc = svsr_check_launch();
+    if (rc != SVSR_OK) return rc;
+    return svsr_colsum_rows(part, grid, STEM_C * 245, dw, STEM_C * 245, nullptr, 0, 1, 1.0f, stream);
 }
 
 }  // extern "C"

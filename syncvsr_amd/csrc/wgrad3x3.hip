@@ -10,7 +10,8 @@
 // positions needs one dY tile [128][64 co] and ONE X tile [128 + 2(W+3)][64 ci] for all nine taps.  Per 16-position
 // step a wave reads one dY^T fragment and nine shifted X^T fragments (ds_read_b64_tr_b16) and issues nine MFMAs into
 // nine 32x32 accumulators.  The next chunk's rows are fetched into registers while the current one is contracted.
-#include <stdlib.h>
+// Split-K without atomics: split s stores its nine tiles into slab s of a caller-owned workspace and svsr_colsum_rows
+// (runtime.hip) adds the slabs into dW in a fixed order (reproducible gradients).
 
 #include "common.h"
 
@@ -24,6 +25,8 @@ struct Wgrad3Args {
     const bf16_t* x;       // [Nimg][H][W][Ci]
     const bf16_t* dy;      // [Nimg][H][W][Co]
     float* dw;             // [Co][9][Ci] fp32, accumulated
+    float* part;           // splits > 1: slabs [splits][Co*9*Ci]
+    int splits;
     int Nimg, H, W, Ci, Co;
     int WP, Q, Qtot, XR;   // padded row length, padded pixels per image, total, X-tile rows
     float inv_q, inv_wp;
@@ -135,17 +138,49 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_halo(const Wgrad3Args p) {
     }
     // D[row = co][col = ci]
     const int ci = ci0 + wci + (lane & 31);
+    const bool direct = p.splits <= 1;
+    float* dst = direct ? p.dw : p.part + (long)blockIdx.x * ((long)p.Co * 9 * p.Ci);
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            atomicAdd(p.dw + ((long)co * 9 + t) * p.Ci + ci, acc[t][r]);
+            float* d = dst + ((long)co * 9 + t) * p.Ci + ci;
+            *d = direct ? *d + acc[t][r] : acc[t][r];
         }
 }
 
-extern "C" int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Ci, int Co, hipStream_t stream) {
-    if (Ci % 64 || Co % 64 || W + 2 > (W3_MAXXR - W3_CH) / 2 - 1 || H < 1 || W < 1) return SVSR_ERR_ARG;
+struct W3Plan { int splits, chunks_per_block, total_chunks, tasks; };
+
+static W3Plan w3_plan(int Nimg, int H, int W, int Ci, int Co) {
+    W3Plan pl;
+    const long qtot = (long)Nimg * (H + 2) * (W + 2);
+    pl.total_chunks = (int)((qtot + W3_CH - 1) / W3_CH);
+    pl.tasks = (Co / 64) * (Ci / 64);
+    const int target_blocks = svsr_tune_get(SVSR_TUNE_W3_BLOCKS);      // measured optimum 384 (256..1024 swept)
+    int splits = ((target_blocks > 0 ? target_blocks : 384) + pl.tasks - 1) / pl.tasks;   // every split costs a slab written and re-read
+    if (splits > pl.total_chunks) splits = pl.total_chunks;
+    if (splits < 1) splits = 1;
+    pl.chunks_per_block = (pl.total_chunks + splits - 1) / splits;
+    pl.splits = (pl.total_chunks + pl.chunks_per_block - 1) / pl.chunks_per_block;
+    return pl;
+}
+
+/* workspace (floats) svsr_conv3x3_wgrad needs for this shape: splits * Co*9*Ci (0 when a single split writes dW directly) */
+extern "C" int svsr_conv3x3_wgrad_plan(int Nimg, int H, int W, int Ci, int Co, int* splits, int64_t* part_floats) {
+    if (Ci % 64 || Co % 64 || Ci <= 0 || Co <= 0 || H < 1 || W < 1 || Nimg < 1) return SVSR_ERR_ARG;
+    const W3Plan pl = w3_plan(Nimg, H, W, Ci, Co);
+    if (splits) *splits = pl.splits;
+    if (part_floats) *part_floats = pl.splits > 1 ? (int64_t)pl.splits * Co * 9 * Ci : 0;
+    return SVSR_OK;
+}
+
+extern "C" int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate,
+                                float scale, hipStream_t stream);
+
+extern "C" int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Ci, int Co, float* part,
+                                  int64_t part_floats, hipStream_t stream) {
+    if (Ci % 64 || Co % 64 || Ci <= 0 || Co <= 0 || W + 2 > (W3_MAXXR - W3_CH) / 2 - 1 || H < 1 || W < 1 || Nimg < 1) return SVSR_ERR_ARG;
     Wgrad3Args a;
     a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw;
     a.Nimg = Nimg; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
@@ -155,19 +190,18 @@ extern "C" int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int 
     a.Qtot = (int)qtot;
     a.XR = W3_CH + 2 * (a.WP + 1);
     a.inv_q = 1.0f / (float)a.Q; a.inv_wp = 1.0f / (float)a.WP;
-    a.total_chunks = (a.Qtot + W3_CH - 1) / W3_CH;
-    const int tasks = (Co / 64) * (Ci / 64);
-    static const int target_blocks = [] { const char* e = getenv("SVSR_W3_BLOCKS"); return e ? atoi(e) : 384; }();   // measured optimum (256..1024 swept)
-    int splits = (target_blocks + tasks - 1) / tasks;         // every workgroup ends with 9*64*64 atomics
-    if (splits > a.total_chunks) splits = a.total_chunks;
-    a.chunks_per_block = (a.total_chunks + splits - 1) / splits;
-    splits = (a.total_chunks + a.chunks_per_block - 1) / a.chunks_per_block;
+    const W3Plan pl = w3_plan(Nimg, H, W, Ci, Co);
+    const int64_t n = (int64_t)Co * 9 * Ci;
+    if (pl.splits > 1 && (part == nullptr || part_floats < (int64_t)pl.splits * n)) return SVSR_ERR_ARG;
+    a.total_chunks = pl.total_chunks; a.chunks_per_block = pl.chunks_per_block; a.splits = pl.splits; a.part = part;
     const size_t lds = (size_t)(W3_CH + a.XR) * W3_PITCH * sizeof(bf16_t);
     static size_t lds_set = 0;
     if (lds > lds_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3x3_halo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set = lds;
     }
-    hipLaunchKernelGGL(k_wgrad3x3_halo, dim3(splits, tasks), dim3(256), lds, stream, a);
-    return svsr_check_launch();
+    hipLaunchKernelGGL(k_wgrad3x3_halo, dim3(pl.splits, pl.tasks), dim3(256), lds, stream, a);
+    int rc = svsr_check_launch();
+    if (rc != SVSR_OK || pl.splits <= 1) return rc;
+    return svsr_colsum_rows(part, pl.splits, n, dw, n, nullptr, 0, 1, 1.0f, stream);
 }

@@ -57,6 +57,9 @@ class TrainStep:
             opt = cfg.optimizer
             sch = cfg.get("scheduler", {}) or {}
             clip = (cfg.get("trainer", {}) or {}).get("gradient_clip_val", 0.0)
+        accum = (cfg.get("train", {}) or {}).get("accumulate_grad_batches", 1) if self.is_lrw else (cfg.get("trainer", {}) or {}).get("accumulate_grad_batches", 1)
+        if int(accum or 1) != 1:
+            raise NotImplementedError("accumulate_grad_batches != 1 is not supported by TrainStep (one optimiser step per batch)")
         self.lr = float(opt.lr)
         self.betas = (float(opt.betas[0]), float(opt.betas[1]))
         self.eps = float(opt.eps)
@@ -83,7 +86,8 @@ class TrainStep:
         dev = st.flat.device
         self.m = torch.zeros_like(st.flat)
         self.v = torch.zeros_like(st.flat)
-        self.opt_state = torch.zeros(4, dtype=torch.int32, device=dev)     # {step, sumsq, lr_last, gnorm_last}
+        # device state of the optimiser kernels: {step, sumsq, lr_last, gnorm_last, 1024 partial sums of squares}
+        self.opt_state = torch.zeros(4 + 1024, dtype=torch.int32, device=dev)
 
     # -- one eager step -----------------------------------------------------------------------------
     def _step_impl(self, *batch):
@@ -165,7 +169,7 @@ class TrainStep:
             raise ValueError("optimiser state belongs to a different parameter layout")
         self.m.copy_(sd["exp_avg"])
         self.v.copy_(sd["exp_avg_sq"])
-        self.opt_state.copy_(sd["opt_state"])
+        self.opt_state[:4].copy_(sd["opt_state"][:4])
 
     # -- introspection ------------------------------------------------------------------------------
     def state(self) -> dict[str, float]:
@@ -188,10 +192,29 @@ class GradReducer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.always = always and dist.is_initialized()
         self.bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
+        self._buffers_pending = False
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self.top = 0
         self.launched: list[tuple[int, int]] = []
         model.grad_ready_hook = self.on_ready
+        # DDP construction semantics (torch DistributedDataParallel behind Lightning's strategy="ddp", reference
+        # LRW/video/src/train.py:28): every rank starts from rank 0's parameters AND buffers, whatever its own seed or a
+        # per-rank load_state_dict left behind.
+        if dist.is_initialized() and (self.world > 1 or self.always):
+            st = model.store()
+            dist.broadcast(st.flat, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+            self._broadcast_buffers(st)
+            for b in st.buffers.values():
+                if not b.is_floating_point():
+                    dist.broadcast(b, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+            st.shadow_fresh = False          # the bf16 shadows follow the broadcast weights at the next forward
+
+    def _broadcast_buffers(self, st) -> None:
+        """broadcast_buffers=True of DDP: the BatchNorm running statistics of every rank follow rank 0's — one collective over
+        the flat buffer vector (model._ParamStore.bufflat).  num_batches_tracked advances identically on every rank."""
+        if st.bufflat.numel():
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast(st.bufflat, src=src, group=self.group)
 
     def begin_step(self) -> None:
         st = self.model.store()
@@ -199,6 +222,9 @@ class GradReducer:
         self.launched = []
         if self.comm_stream is None and st.flat.is_cuda:
             self.comm_stream = torch.cuda.Stream(device=st.flat.device)
+        if (self.world > 1 or self.always) and st.flat.is_cuda and self._buffers_pending:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)     # last step's buffer broadcast precedes this forward's BN updates
+            self._buffers_pending = False
 
     def _reduce(self, lo: int, hi: int) -> None:
         if hi <= lo:
@@ -238,3 +264,12 @@ class GradReducer:
     def finish(self) -> None:
         if (self.world > 1 or self.always) and self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+            # DDP re-broadcasts the buffers before every forward; here the collective is enqueued right after the backward's
+            # BatchNorm updates on the comm stream, where it overlaps the optimiser and the host's enqueue of the next step
+            st = self.model.store()
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self._broadcast_buffers(st)
+            self._buffers_pending = True
+        elif self.world > 1 or self.always:
+            self._broadcast_buffers(self.model.store())

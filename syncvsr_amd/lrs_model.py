@@ -217,6 +217,12 @@ class E2E(nn.Module):
         lab = label.reshape(B, -1).long()
         live = lab != self.ignore_id
         n = live.sum(1, keepdim=True)
+        if lab.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # what torch's Embedding / CTCLoss / index ops would trap with a device assert: token ids must lie in [1, odim) (0 is
+            # the CTC blank) and the ignore_id padding must be a tail (the kernels index with these values)
+            torch._assert_async(((lab >= 1) & (lab < self.odim) | ~live).all(), "E2E: target token outside [1, odim)")
+            torch._assert_async((live.long().cumsum(1) == torch.arange(1, lab.size(1) + 1, device=lab.device)).eq(live).all(),
+                                "E2E: ignore_id padding must be at the tail of every target")
         eos = torch.full_like(lab[:, :1], self.eos)
         ys_in = torch.cat([eos, torch.where(live, lab, eos)], dim=1).contiguous()                  # sos == eos (e2e:111-112)
         ys_out = torch.cat([lab, torch.full_like(lab[:, :1], self.ignore_id)], dim=1)
@@ -342,9 +348,8 @@ def _encoder_layer_fwd(model: E2E, st: _ParamStore, tape: dict, i: int, x, pos16
     cm = f"{p}.conv_module"
     u = _lin(st, t3, f"{cm}.pointwise_cov1", R, D, 2 * D)
     bn = f"{cm}.norm"
-    c = ops.glu_dwconv_fwd(u, st.p32(f"{cm}.depthwise_conv.weight"), st.p32(f"{cm}.depthwise_conv.bias"),
-                           st.bn[bn]["slots"] if training else None, B, T, D, K)
-    mean, rstd = _bn_stats(st, bn, training, R)
+    c, stats = ops.glu_dwconv_fwd(u, st.p32(f"{cm}.depthwise_conv.weight"), st.p32(f"{cm}.depthwise_conv.bias"), training, B, T, D, K)
+    mean, rstd = _bn_stats(st, bn, training, R, stats)
     y = ops.bn_act_fwd(c, None, mean, rstd, st.p32(f"{bn}.weight"), st.p32(f"{bn}.bias"), ops.ACT_SWISH)
     dco = model._d(f"enc.{i}.conv.out")
     x3 = _lin(st, y, f"{cm}.pointwise_cov2", R, D, D, addend=x2, drop=dco)
@@ -369,7 +374,7 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
     cm, bn = f"{p}.conv_module", f"{p}.conv_module.norm"
     dy = _lin_bwd(model, st, f"{cm}.pointwise_cov2", tc["y"], _branch_grad(dx3, 1.0, tc["dco"]), R, D, D)
     ws = st.bn[bn]
-    dc, _ = ops.bn_act_bwd(dy, tc["y"], tc["c"], tc["mean"], tc["rstd"], st.p32(f"{bn}.weight"), ws["slots"], ws["coef"], st.g32(f"{bn}.weight"),
+    dc, _ = ops.bn_act_bwd(dy, tc["y"], tc["c"], tc["mean"], tc["rstd"], st.p32(f"{bn}.weight"), ws["coef"], st.g32(f"{bn}.weight"),
                            st.g32(f"{bn}.bias"), ops.ACT_SWISH, False, beta=st.p32(f"{bn}.bias"))
     du = ops.glu_dwconv_bwd(dc, tc["u"], st.p32(f"{cm}.depthwise_conv.weight"), st.g32(f"{cm}.depthwise_conv.weight"),
                             st.g32(f"{cm}.depthwise_conv.bias"), B, T, D, K)

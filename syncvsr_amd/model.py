@@ -22,7 +22,6 @@ from .config import Config, audio_codec_dims
 from .init import buffer_specs, hidden_dim, init_state_dict, param_specs, resnet_block_specs
 
 BF16 = torch.bfloat16
-USE_MFMA_ATTENTION = os.environ.get("SVSR_LRW_MFMA_ATTN", "1") != "0"
 
 
 class _SideStream:
@@ -111,7 +110,9 @@ class TransformerLightningModule(nn.Module):
         self.layers = int(bert.num_hidden_layers)
         self.inter = int(bert.intermediate_size)
         self.ln_eps = float(bert.get("layer_norm_eps", 1e-12))
-        if float(bert.get("emb_dropout", 0.0)) or float(bert.get("hidden_dropout_prob", 0.0)) or float(bert.get("attention_probs_dropout_prob", 0.0)):
+        # missing keys take the reference's defaults: emb_dropout is read directly (lightning.py:45); the other two are
+        # BertConfig(**config.model.bert) defaults, 0.1 each (lightning.py:92)
+        if float(bert.get("emb_dropout", 0.0)) or float(bert.get("hidden_dropout_prob", 0.1)) or float(bert.get("attention_probs_dropout_prob", 0.1)):
             raise NotImplementedError("dropout > 0 is not implemented in the HIP path yet (BASELINE configs use p = 0)")
         if self.dim % 512 or self.dim // self.heads != 64:
             raise NotImplementedError("encoder width must be a multiple of 512 with 64-wide heads")
@@ -273,6 +274,16 @@ class _ParamStore:
         for n, b in self.buffers.items():
             if b.device != device:
                 raise RuntimeError("move the module to the GPU before the first forward (model.to('cuda'))")
+        # the floating-point buffers (BatchNorm running statistics) are views of ONE flat vector, so data-parallel training can
+        # broadcast them from rank 0 in a single collective (DDP's broadcast_buffers, engine.GradReducer)
+        fbufs = [(n, b) for n, b in self.buffers.items() if b.is_floating_point()]
+        self.bufflat = torch.empty(sum(b.numel() for _, b in fbufs), dtype=torch.float32, device=device)
+        o = 0
+        for n, b in fbufs:
+            view = self.bufflat[o : o + b.numel()].view(b.shape)
+            view.copy_(b)
+            b.data = view
+            o += b.numel()
         # transposed shadows for the data-gradient contractions
         entries = []
         toff = 0
@@ -305,7 +316,6 @@ class _ParamStore:
                 C = s[0]
                 base = n[: -len(".weight")]
                 self.bn[base] = dict(
-                    slots=torch.zeros(ops.STAT_SLOTS * 2 * C, dtype=torch.float32, device=device),
                     coef=torch.empty(3 * C, dtype=torch.float32, device=device),
                     mean=torch.empty(C, dtype=torch.float32, device=device),
                     rstd=torch.empty(C, dtype=torch.float32, device=device),
@@ -315,7 +325,9 @@ class _ParamStore:
     def owns(self, model) -> bool:
         lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * 4
         anchor = model._specs[0][0]
-        return all(lo <= p.data_ptr() < hi for p in self._params.values()) and _get(model, anchor) is self._params[anchor]
+        blo, bhi = self.bufflat.data_ptr(), self.bufflat.data_ptr() + self.bufflat.numel() * 4
+        bufs_ok = all(blo <= b.data_ptr() < bhi for b in self.buffers.values() if b.is_floating_point() and b.numel())
+        return bufs_ok and all(lo <= p.data_ptr() < hi for p in self._params.values()) and _get(model, anchor) is self._params[anchor]
 
     def _view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
         o, numel, shape = self.offsets[name]
@@ -362,10 +374,11 @@ class _ParamStore:
 # ----------------------------------------------------------------------------------------------------
 # forward / backward tape
 # ----------------------------------------------------------------------------------------------------
-def _bn_stats(st: _ParamStore, base: str, training: bool, count: int):
+def _bn_stats(st: _ParamStore, base: str, training: bool, count: int, stats):
+    """stats: the partial sums (buffer, rows) the producing convolution just wrote on this stream (training mode)."""
     ws = st.bn[base]
     if training:
-        ops.bn_finalize(ws["slots"], ws["mean"].numel(), count, ws["mean"], ws["rstd"], st.buffers[f"{base}.running_mean"],
+        ops.bn_finalize(stats, ws["mean"].numel(), count, ws["mean"], ws["rstd"], st.buffers[f"{base}.running_mean"],
                         st.buffers[f"{base}.running_var"], st.buffers[f"{base}.num_batches_tracked"])
     else:
         ops.bn_eval_prepare(st.buffers[f"{base}.running_mean"], st.buffers[f"{base}.running_var"], ws["mean"], ws["rstd"])
@@ -376,8 +389,8 @@ def _conv_bn(st: _ParamStore, tape: dict, x: torch.Tensor, conv: str, bn: str, k
              res: Optional[torch.Tensor], act: int) -> torch.Tensor:
     o, n, shape = st.offsets[f"{conv}.weight"]
     w16 = st.w16[o : o + n].view(shape[0], k, k, shape[1])
-    c = ops.conv2d_fwd(x, w16, k, stride, pad, stats=st.bn[bn]["slots"] if training else None)
-    mean, rstd = _bn_stats(st, bn, training, c.numel() // c.shape[-1])
+    c, stats = ops.conv2d_fwd(x, w16, k, stride, pad, want_stats=training)
+    mean, rstd = _bn_stats(st, bn, training, c.numel() // c.shape[-1], stats)
     y = ops.bn_act_fwd(c, res, mean, rstd, st.p32(f"{bn}.weight"), st.p32(f"{bn}.bias"), act)
     tape[conv] = dict(x=x, c=c, y=y, mean=mean, rstd=rstd, k=k, stride=stride, pad=pad, act=act, bn=bn, res=res)
     return y
@@ -395,8 +408,8 @@ def _frontend_forward(model, st: "_ParamStore", tape: dict, videos: torch.Tensor
     B, _, T, H, W = videos.shape
     N = B * T
     sc, sb, act = model.stem_name + ".0", model.stem_name + ".1", model.trunk_act
-    c = ops.stem_conv_fwd(videos, st.p32(f"{sc}.weight"), st.bn[sb]["slots"] if training else None)
-    mean, rstd = _bn_stats(st, sb, training, c.numel() // 64)
+    c, stats = ops.stem_conv_fwd(videos, st.p32(f"{sc}.weight"), want_stats=training)
+    mean, rstd = _bn_stats(st, sb, training, c.numel() // 64, stats)
     x, amax = ops.stem_bn_gelu_pool_fwd(c, mean, rstd, st.p32(f"{sb}.weight"), st.p32(f"{sb}.bias"), model.stem_act)
     tape["stem"] = dict(videos=videos, c=c, amax=amax, mean=mean, rstd=rstd, pooled_shape=tuple(x.shape))
     for prefix, inp, planes, stride, down in _trunk_blocks(model):
@@ -418,14 +431,14 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
     for prefix, inp, planes, stride, down in reversed(list(_trunk_blocks(model))):
         t2 = tape[f"{prefix}.conv2"]
         ws2 = st.bn[t2["bn"]]
-        dc2, dres = ops.bn_act_bwd(dx, t2["y"], t2["c"], t2["mean"], t2["rstd"], st.p32(f"{t2['bn']}.weight"), ws2["slots"], ws2["coef"],
+        dc2, dres = ops.bn_act_bwd(dx, t2["y"], t2["c"], t2["mean"], t2["rstd"], st.p32(f"{t2['bn']}.weight"), ws2["coef"],
                                    st.g32(f"{t2['bn']}.weight"), st.g32(f"{t2['bn']}.bias"), act, True,
                                    beta=st.p32(f"{t2['bn']}.bias"), res=t2["res"])
         _conv_wgrad(model, st, f"{prefix}.conv2", t2, dc2, use_tr)
         do1 = ops.conv2d_dgrad(dc2, st.t16(f"{prefix}.conv2.weight").view(planes, 3, 3, planes), 3, 1, 1, t2["x"].shape[1:3])
         t1 = tape[f"{prefix}.conv1"]
         ws1 = st.bn[t1["bn"]]
-        dc1, _ = ops.bn_act_bwd(do1, t1["y"], t1["c"], t1["mean"], t1["rstd"], st.p32(f"{t1['bn']}.weight"), ws1["slots"], ws1["coef"],
+        dc1, _ = ops.bn_act_bwd(do1, t1["y"], t1["c"], t1["mean"], t1["rstd"], st.p32(f"{t1['bn']}.weight"), ws1["coef"],
                                 st.g32(f"{t1['bn']}.weight"), st.g32(f"{t1['bn']}.bias"), act, False, beta=st.p32(f"{t1['bn']}.bias"))
         _conv_wgrad(model, st, f"{prefix}.conv1", t1, dc1, use_tr)
         in_hw = t1["x"].shape[1:3]
@@ -433,7 +446,7 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
         if down:
             td = tape[f"{prefix}.downsample.0"]
             wsd = st.bn[td["bn"]]
-            dcd, _ = ops.bn_act_bwd(dres, None, td["c"], td["mean"], td["rstd"], st.p32(f"{td['bn']}.weight"), wsd["slots"], wsd["coef"],
+            dcd, _ = ops.bn_act_bwd(dres, None, td["c"], td["mean"], td["rstd"], st.p32(f"{td['bn']}.weight"), wsd["coef"],
                                     st.g32(f"{td['bn']}.weight"), st.g32(f"{td['bn']}.bias"), 0, False)
             _conv_wgrad(model, st, f"{prefix}.downsample.0", td, dcd, use_tr)
             dxa = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw)
@@ -445,7 +458,7 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
     sc, sb = model.stem_name + ".0", model.stem_name + ".1"
     ws = st.bn[sb]
     dconv = ops.stem_bn_gelu_pool_bwd(dx, ts["amax"], ts["c"], ts["mean"], ts["rstd"], st.p32(f"{sb}.weight"), st.p32(f"{sb}.bias"),
-                                      ws["slots"], ws["coef"], st.g32(f"{sb}.weight"), st.g32(f"{sb}.bias"), model.stem_act)
+                                      ws["coef"], st.g32(f"{sb}.weight"), st.g32(f"{sb}.bias"), model.stem_act)
     ops.stem_conv_wgrad(ts["videos"], dconv, st.g32(f"{sc}.weight"), use_tr)
     model._side.join()
     _ready(model, st, None)
@@ -475,10 +488,7 @@ def _encoder_forward(model: TransformerLightningModule, st: _ParamStore, tape: d
         wqkv = st.s16(f"{p}.attention.self.query.weight", 3 * D * D)
         bqkv = st.flat[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
         qkv, _ = ops.linear_fwd(x, wqkv, bqkv, rows=R, K=D, N=3 * D, x_pitch=D)
-        if USE_MFMA_ATTENTION:      # the MFMA attention kernels written for LRS (csrc/mha.hip); bert.hip's k_attn_* is the scalar first version
-            ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=S, Lk=S)
-        else:
-            ctx, probs = ops.attn_fwd(qkv, B, S, H, D // H)
+        ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=S, Lk=S)      # csrc/mha.hip
         ao, _ = ops.linear_fwd(ctx, st.s16(f"{p}.attention.output.dense.weight"), st.p32(f"{p}.attention.output.dense.bias"),
                                rows=R, K=D, N=D, x_pitch=D)
         x1, m1, r1 = ops.add_ln_fwd(ao, x, st.p32(f"{p}.attention.output.LayerNorm.weight"), st.p32(f"{p}.attention.output.LayerNorm.bias"), model.ln_eps)
@@ -516,13 +526,10 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
         side.run(lambda: ops.linear_wgrad(t["ctx"], ds1, st.g32(f"{p}.attention.output.dense.weight"), rows=R, K=D, N=D, x_pitch=D, dy_pitch=D,
                                           use_tr=use_tr, db=st.g32(f"{p}.attention.output.dense.bias")), ds1, small=True)
         dctx = ops.linear_dgrad(ds1, st.t16(f"{p}.attention.output.dense.weight"), rows=R, N=D, K=D, dy_pitch=D)
-        if USE_MFMA_ATTENTION:
-            qkv = t["qkv"]
-            dqkv = torch.empty_like(qkv)
-            ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, t["probs"], B=B, H=H, Lq=S, Lk=S, dq=dqkv, dq_pitch=3 * D,
-                        dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D)
-        else:
-            dqkv = ops.attn_bwd(dctx, t["qkv"], t["probs"], B, S, H, D // H)
+        qkv = t["qkv"]
+        dqkv = torch.empty_like(qkv)
+        ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, t["probs"], B=B, H=H, Lq=S, Lk=S, dq=dqkv, dq_pitch=3 * D,
+                    dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D)
         gq = st.grad[st.offsets[f"{p}.attention.self.query.weight"][0] :][: 3 * D * D]
         gqb = st.grad[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
         side.run(lambda: ops.linear_wgrad(t["x"], dqkv, gq, rows=R, K=D, N=3 * D, x_pitch=D, dy_pitch=3 * D, use_tr=use_tr, db=gqb), dqkv, small=True)

@@ -13,7 +13,6 @@ import torch
 from . import _lib
 
 BF16 = torch.bfloat16
-STAT_SLOTS = 16
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 HALO_WGRAD = True      # nine-taps-per-pass weight gradient for stride-1 3x3 convs (False: generic per-tap kernel)
@@ -43,6 +42,56 @@ def _drop(drop) -> tuple:
     if drop is None or drop[2] <= 0.0:
         return None, 0, 0.0
     return drop[0].data_ptr(), int(drop[1]), float(drop[2])
+
+
+# Per-stream fp32 scratch for the partial rows / split-K slabs of the reproducible reductions (include/syncvsr_hip.h): every
+# producer and its fixed-order finaliser are enqueued back to back on one stream, so one buffer per stream serves them all.
+# Outgrown buffers are kept alive: a captured HIP graph may still hold their address.
+_SCRATCH: dict[int, torch.Tensor] = {}
+_SCRATCH_KEEP: list[torch.Tensor] = []
+
+
+def scratch(nfloats: int) -> torch.Tensor:
+    key = _stream()
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < nfloats:
+        if t is not None:
+            _SCRATCH_KEEP.append(t)
+        t = _SCRATCH[key] = torch.empty(max(int(nfloats), 1 << 22), dtype=torch.float32, device="cuda")
+    return t
+
+
+_PLAN_CACHE: dict = {}
+
+
+def _query(name: str, *args) -> tuple:
+    """Cached host-side shape query (svsr_*_plan / svsr_*_rows): returns the int outputs (or the returned row count)."""
+    key = (name, args)
+    hit = _PLAN_CACHE.get(key)
+    if hit is not None:
+        return hit
+    fn = getattr(_lib.load(), name)
+    if name.endswith("_rows"):
+        out = (int(fn(*args)),)
+    else:
+        nout = {"svsr_igemm_fwd_plan": (4, 0), "svsr_igemm_wgrad_plan": (2, 1), "svsr_conv3x3_wgrad_plan": (1, 1),
+                "svsr_stem_conv_wgrad_plan": (1, 1)}[name]
+        ints = [ctypes.c_int(0) for _ in range(nout[0])]
+        longs = [ctypes.c_int64(0) for _ in range(nout[1])]
+        rc = fn(*args, *[ctypes.byref(v) for v in ints], *[ctypes.byref(v) for v in longs])
+        if rc != 0:
+            _lib.check(rc, name)
+        out = tuple(int(v.value) for v in ints) + tuple(int(v.value) for v in longs)
+    _PLAN_CACHE[key] = out
+    return out
+
+
+def tune(key: str, value: int) -> None:
+    """Result-preserving tuning knob of the library (svsr_tune); invalidates cached plans."""
+    rc = _lib.load().svsr_tune(key.encode(), int(value))
+    if rc != 0:
+        _lib.check(rc, f"svsr_tune({key})")
+    _PLAN_CACHE.clear()
 
 
 _INT_ARRAYS: dict = {}
@@ -91,27 +140,19 @@ def _call(name: str, *args, label: Optional[str] = None, flops: float = 0.0, nby
         _lib.check(rc, name)
 
 
-_CUS: Optional[int] = None
-
-
 def igemm_fwd_tile(M: int, Co: int, ntaps: int = 1) -> tuple[int, int, int]:
-    """Mirror of igemm_fwd.hip's tile / ring-depth choice — only used to label launches with the kernel instantiation."""
-    global _CUS
-    if _CUS is None:
-        _CUS = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    bm = (128 if M >= 16384 else 64) if Co <= 64 else (128 if (M >= 8192 or -(-M // 128) * -(-Co // 128) >= 224) else 64)
-    if bm == 128 and Co > 64 and ntaps > 1 and -(-M // 128) * -(-Co // 128) < 300:
-        return 128, 64, 2
-    bn = 64 if (bm == 64 or Co <= 64) else 128
-    blocks = -(-M // bm) * -(-Co // bn)
-    ns = 2 if bm + bn > 192 else (3 if bm + bn > 128 else (4 if blocks <= _CUS * 5 // 2 else 3))
-    return bm, bn, ns
+    """(BM, BN, ring depth) of the k_igemm_fwd_glds instantiation svsr_igemm_fwd launches for this shape — asked from the
+    library itself (svsr_igemm_fwd_plan), so labels and tests cannot drift from the launch logic."""
+    return _query("svsr_igemm_fwd_plan", int(M), int(Co), int(ntaps))[:3]
 
 
-def wgrad_tile(Co: int, Ci: int, ntaps: int) -> int:
-    """Mirror of igemm_wgrad.hip's tile choice (label only)."""
-    tasks128 = ((Co + 127) // 128) * ((Ci + 127) // 128) * ntaps
-    return 128 if (Co >= 128 and Ci >= 128 and tasks128 >= 36) else 64
+def igemm_fwd_stat_rows(M: int, Co: int, ntaps: int) -> int:
+    return _query("svsr_igemm_fwd_plan", int(M), int(Co), int(ntaps))[3]
+
+
+def wgrad_plan(M: int, Co: int, Ci: int, ntaps: int, wt_taps: int, has_bias: bool) -> tuple[int, int, int]:
+    """(tile edge, K splits, workspace floats) of svsr_igemm_wgrad for this shape."""
+    return _query("svsr_igemm_wgrad_plan", int(M), int(Co), int(Ci), int(ntaps), int(wt_taps), int(has_bias))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -120,10 +161,16 @@ def wgrad_tile(Co: int, Ci: int, ntaps: int) -> int:
 def igemm_fwd(inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
               Co: int, Ho: int, Wo: int, out_pitch: int, Ha: int, Wa: int, S: int = 1, OS: int = 1, oy0: int = 0, ox0: int = 0,
               taps: Sequence[tuple[int, int, int]] = ((0, 0, 0),), wt_taps: int = 1, bias: Optional[torch.Tensor] = None,
-              addend: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None, gelu: bool = False,
-              out_pre: Optional[torch.Tensor] = None, out_f32: bool = False, relu: bool = False, alpha: float = 1.0, drop=None) -> None:
+              addend: Optional[torch.Tensor] = None, want_stats: bool = False, gelu: bool = False,
+              out_pre: Optional[torch.Tensor] = None, out_f32: bool = False, relu: bool = False, alpha: float = 1.0, drop=None):
+    """-> None, or with want_stats the BatchNorm partials (buffer, rows) for bn_finalize."""
     dy, dx, tw = zip(*taps)
     M = Nimg * Ha * Wa
+    stats = st = None
+    if want_stats:
+        rows = igemm_fwd_stat_rows(M, Co, len(taps))
+        stats = scratch(rows * 2 * Co)
+        st = (stats, rows)
     label = None
     if _TIMING is not None:
         bm, bn, ns = igemm_fwd_tile(M, Co, len(taps))
@@ -131,6 +178,7 @@ def igemm_fwd(inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: i
     _call("svsr_igemm_fwd", _p(inp), _p(wt), _p(out), _p(out_pre), _p(bias), _p(addend), _p(stats), Nimg, Hi, Wi, Ci, in_pitch,
           Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw),
           1 if gelu else (2 if relu else 0), int(out_f32), float(alpha), *_drop(drop), _stream(), label=label, flops=2.0 * M * Co * Ci * len(taps))
+    return st
 
 
 def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
@@ -138,9 +186,11 @@ def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: i
                 taps: Sequence[tuple[int, int, int]] = ((0, 0, 0),), wt_taps: int = 1, use_tr: bool = True,
                 db: Optional[torch.Tensor] = None) -> None:
     dy, dx, tw = zip(*taps)
+    bc, splits, nfl = wgrad_plan(Nimg * Ha * Wa, Co, Ci, len(taps), wt_taps, db is not None)
+    part = scratch(nfl) if nfl else None
     _call("svsr_igemm_wgrad", _p(x), _p(dyp), _p(dw), Nimg, Hi, Wi, Ci, in_pitch, Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0,
-          len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw), int(use_tr), _p(db), _stream(),
-          label=f"k_igemm_wgrad<{'true' if use_tr else 'false'},{wgrad_tile(Co, Ci, len(taps))}>",
+          len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw), int(use_tr), _p(db), _p(part), nfl, _stream(),
+          label=f"k_igemm_wgrad<{'true' if use_tr else 'false'},{bc}>",
           flops=2.0 * Nimg * Ha * Wa * Co * Ci * len(taps))
 
 
@@ -148,19 +198,29 @@ def conv_out_size(n: int, k: int, stride: int, pad: int) -> int:
     return (n + 2 * pad - k) // stride + 1
 
 
-def conv2d_fwd(x: torch.Tensor, w16: torch.Tensor, k: int, stride: int, pad: int, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [N,H,W,Ci] bf16, w16 bf16 [Co][k][k][Ci] -> [N,Ho,Wo,Co] bf16 (+ BatchNorm partial sums into `stats`)."""
+def conv2d_fwd(x: torch.Tensor, w16: torch.Tensor, k: int, stride: int, pad: int, want_stats: bool = False):
+    """x [N,H,W,Ci] bf16, w16 bf16 [Co][k][k][Ci] -> ([N,Ho,Wo,Co] bf16, stats) where stats is None or the BatchNorm partial
+    sums (buffer, rows) to hand to bn_finalize next on this stream."""
     N, H, W, Ci = x.shape
     Co = w16.shape[0]
     Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
     out = torch.empty((N, Ho, Wo, Co), dtype=BF16, device=x.device)
-    taps = [(kh - pad, kw - pad, kh * k + kw) for kh in range(k) for kw in range(k)]
+    taps = _conv_taps(k, pad)
     if _c64_ok(Ci, Co, k, stride, pad, W):
-        conv3x3_c64(x, w16, out, None, stats, taps)
-        return out
-    igemm_fwd(x, w16, out, Nimg=N, Hi=H, Wi=W, Ci=Ci, in_pitch=Ci, Co=Co, Ho=Ho, Wo=Wo, out_pitch=Co, Ha=Ho, Wa=Wo,
-              S=stride, taps=taps, wt_taps=k * k, stats=stats)
-    return out
+        return out, conv3x3_c64(x, w16, out, None, want_stats, taps)
+    st = igemm_fwd(x, w16, out, Nimg=N, Hi=H, Wi=W, Ci=Ci, in_pitch=Ci, Co=Co, Ho=Ho, Wo=Wo, out_pitch=Co, Ha=Ho, Wa=Wo,
+                   S=stride, taps=taps, wt_taps=k * k, want_stats=want_stats)
+    return out, st
+
+
+_TAPS: dict = {}
+
+
+def _conv_taps(k: int, pad: int) -> tuple:
+    t = _TAPS.get((k, pad))
+    if t is None:
+        t = _TAPS[(k, pad)] = tuple((kh - pad, kw - pad, kh * k + kw) for kh in range(k) for kw in range(k))
+    return t
 
 
 C64_CONV = True        # persistent weights-in-LDS kernel for conv3x3(64, 64) stride 1 (False: generic implicit GEMM)
@@ -170,12 +230,18 @@ def _c64_ok(Ci: int, Co: int, k: int, stride: int, pad: int, W: int) -> bool:
     return C64_CONV and Ci == 64 and Co == 64 and k == 3 and stride == 1 and pad == 1 and W <= 29
 
 
-def conv3x3_c64(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, addend: Optional[torch.Tensor], stats: Optional[torch.Tensor],
-                taps: Sequence[tuple[int, int, int]]) -> None:
+def conv3x3_c64(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, addend: Optional[torch.Tensor], want_stats: bool,
+                taps: Sequence[tuple[int, int, int]]):
     N, H, W, _ = x.shape
     dy, dx, tw = zip(*taps)
+    stats = st = None
+    if want_stats:
+        rows = _query("svsr_conv3x3_c64_stat_rows", N, H, W)[0]
+        stats = scratch(rows * 2 * 64)
+        st = (stats, rows)
     _call("svsr_conv3x3_c64", _p(x), _p(wt), _p(out), _p(addend), _p(stats), N, H, W, _ints(dy), _ints(dx), _ints(tw), _stream(),
           label="k_conv3x3_c64", flops=2.0 * N * H * W * 64 * 64 * 9)
+    return st
 
 
 def conv2d_dgrad(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad: int, in_hw: tuple[int, int],
@@ -208,7 +274,7 @@ def conv2d_dgrad(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad:
     if addend is not None and not full:
         pass  # classes without taps keep the addend's values (dx aliases addend)
     if stride == 1 and _c64_ok(Ci, Co, k, stride, pad, W):
-        conv3x3_c64(dy, w16t, dx, addend, None, plans[0][2])
+        conv3x3_c64(dy, w16t, dx, addend, False, plans[0][2])
         return dx
     for py, px, taps in plans:
         if not taps:
@@ -227,10 +293,12 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: int, st
     _, Ho, Wo, Co = dy.shape
     if HALO_WGRAD and use_tr and k == 3 and stride == 1 and pad == 1 and W <= 29 and H * W >= 100 and Ci % 64 == 0 and Co % 64 == 0:
         # all nine taps in one pass over zero-padded coordinates (wgrad3x3.hip)
-        _call("svsr_conv3x3_wgrad", _p(x), _p(dy), _p(dw), N, H, W, Ci, Co, _stream(), label="k_wgrad3x3_halo",
+        _, nfl = _query("svsr_conv3x3_wgrad_plan", N, H, W, Ci, Co)
+        part = scratch(nfl) if nfl else None
+        _call("svsr_conv3x3_wgrad", _p(x), _p(dy), _p(dw), N, H, W, Ci, Co, _p(part), nfl, _stream(), label="k_wgrad3x3_halo",
               flops=2.0 * N * H * W * Co * Ci * 9)
         return
-    taps = [(kh - pad, kw - pad, kh * k + kw) for kh in range(k) for kw in range(k)]
+    taps = _conv_taps(k, pad)
     igemm_wgrad(x, dy, dw, Nimg=N, Hi=H, Wi=W, Ci=Ci, in_pitch=Ci, Co=Co, Ho=Ho, Wo=Wo, out_pitch=Co, Ha=Ho, Wa=Wo, S=stride,
                 taps=taps, wt_taps=k * k, use_tr=use_tr)
 
@@ -288,18 +356,25 @@ def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, rows: i
 # --------------------------------------------------------------------------------------------------
 # stem
 # --------------------------------------------------------------------------------------------------
-def stem_conv_fwd(videos: torch.Tensor, w: torch.Tensor, stats: Optional[torch.Tensor]) -> torch.Tensor:
+def stem_conv_fwd(videos: torch.Tensor, w: torch.Tensor, want_stats: bool = False):
+    """-> (out [B*T,H/2,W/2,64] bf16, BatchNorm partials (buffer, rows) or None)"""
     B, C, T, H, W = videos.shape
     assert C == 1 and videos.dtype == torch.float32 and videos.is_contiguous()
     out = torch.empty((B * T, H // 2, W // 2, 64), dtype=BF16, device=videos.device)
+    stats = st = None
+    if want_stats:
+        rows = _query("svsr_stem_conv_fwd_stat_rows", B, T, H, W)[0]
+        stats = scratch(rows * 2 * 64)
+        st = (stats, rows)
     _call("svsr_stem_conv_fwd", _p(videos), _p(w), _p(out), _p(stats), B, T, H, W, _stream(),
           label="k_stem_conv_fwd", flops=2.0 * B * T * (H // 2) * (W // 2) * 64 * 245)
-    return out
+    return out, st
 
 
 def stem_conv_wgrad(videos: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, use_tr: bool = True) -> None:
     B, _, T, H, W = videos.shape
-    _call("svsr_stem_conv_wgrad", _p(videos), _p(dy), _p(dw), B, T, H, W, int(use_tr), _stream(),
+    _, nfl = _query("svsr_stem_conv_wgrad_plan", B, T, H, W)
+    _call("svsr_stem_conv_wgrad", _p(videos), _p(dy), _p(dw), B, T, H, W, int(use_tr), _p(scratch(nfl)), nfl, _stream(),
           label=f"k_stem_conv_wgrad<{'true' if use_tr else 'false'}>", flops=2.0 * B * T * (H // 2) * (W // 2) * 64 * 245)
 
 
@@ -315,10 +390,11 @@ def stem_bn_gelu_pool_fwd(x: torch.Tensor, mean, rstd, gamma, beta, act: int = A
     return y, amax
 
 
-def stem_bn_gelu_pool_bwd(dpool, amax, x, mean, rstd, gamma, beta, slots, coef, dgamma, dbeta, act: int = ACT_GELU) -> torch.Tensor:
+def stem_bn_gelu_pool_bwd(dpool, amax, x, mean, rstd, gamma, beta, coef, dgamma, dbeta, act: int = ACT_GELU) -> torch.Tensor:
     N, Hc, Wc, C = x.shape
     _, Hp, Wp, _ = dpool.shape
     dx = torch.empty_like(x)
+    slots = scratch(_query("svsr_stem_bn_act_pool_bwd_rows", N, Hc, Wc, C)[0] * 2 * C)
     _call("svsr_stem_bn_act_pool_bwd", _p(dpool), _p(amax), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slots), _p(coef),
           _p(dgamma), _p(dbeta), _p(dx), N, Hc, Wc, Hp, Wp, C, act, _stream())
     return dx
@@ -327,8 +403,10 @@ def stem_bn_gelu_pool_bwd(dpool, amax, x, mean, rstd, gamma, beta, slots, coef, 
 # --------------------------------------------------------------------------------------------------
 # BatchNorm / activation / pooling
 # --------------------------------------------------------------------------------------------------
-def bn_finalize(slots, C: int, count: int, mean, rstd, running_mean=None, running_var=None, nbt=None) -> None:
-    _call("svsr_bn_finalize", _p(slots), C, float(count), BN_EPS, BN_MOMENTUM, _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+def bn_finalize(stats, C: int, count: int, mean, rstd, running_mean=None, running_var=None, nbt=None) -> None:
+    """stats = (buffer, rows): the partial sums [rows][2][C] the producing convolution just wrote on this stream."""
+    part, rows = stats
+    _call("svsr_bn_finalize", _p(part), rows, C, float(count), BN_EPS, BN_MOMENTUM, _p(mean), _p(rstd), _p(running_mean), _p(running_var),
           _p(nbt), _stream())
 
 
@@ -343,10 +421,11 @@ def bn_act_fwd(x, res, mean, rstd, gamma, beta, act: int) -> torch.Tensor:
     return y
 
 
-def bn_act_bwd(dy, y, x, mean, rstd, gamma, slots, coef, dgamma, dbeta, act: int, want_dres: bool, beta=None, res=None):
+def bn_act_bwd(dy, y, x, mean, rstd, gamma, coef, dgamma, dbeta, act: int, want_dres: bool, beta=None, res=None):
     C = x.shape[-1]
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
+    slots = scratch(_query("svsr_bn_act_bwd_rows", x.numel() // C, C)[0] * 2 * C)
     _call("svsr_bn_act_bwd", _p(dy), _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(slots), _p(coef), _p(dgamma), _p(dbeta), _p(dx),
           _p(dres), x.numel() // C, C, act, _p(beta), _p(res), _stream())
     return dx, dres
@@ -381,7 +460,9 @@ def add_ln_fwd(a, r, gamma, beta, eps: float):
 def add_ln_bwd(dy, a, r, gamma, mean, rstd, dgamma, dbeta, addend=None, out=None) -> torch.Tensor:
     R, D = a.shape
     ds = torch.empty_like(a) if out is None else out
-    _call("svsr_add_ln_bwd", _p(dy), _p(a), _p(r), _p(gamma), _p(mean), _p(rstd), _p(ds), _p(dgamma), _p(dbeta), R, D, _p(addend), _stream())
+    part = scratch(_query("svsr_add_ln_bwd_rows", R)[0] * 2 * D)
+    _call("svsr_add_ln_bwd", _p(dy), _p(a), _p(r), _p(gamma), _p(mean), _p(rstd), _p(ds), _p(dgamma), _p(dbeta), R, D, _p(addend), _p(part),
+          _stream())
     return ds
 
 
@@ -398,28 +479,17 @@ def embed_ln_fwd(feats, cls, pos, type0, gamma, beta, B: int, S: int, D: int, ep
 
 def embed_bwd_scatter(ds, dcls, dpos, dtype0, B: int, S: int, D: int) -> torch.Tensor:
     dfeats = torch.empty((B * (S - 1), D), dtype=BF16, device=ds.device)
-    _call("svsr_embed_bwd_scatter", _p(ds), _p(dfeats), _p(dcls), _p(dpos), _p(dtype0), B, S, D, _stream())
+    _call("svsr_embed_bwd_scatter", _p(ds), _p(dfeats), _p(dcls), _p(dpos), _p(dtype0), B, S, D, _p(scratch(S * D)), _stream())
     return dfeats
-
-
-def attn_fwd(qkv, B: int, S: int, H: int, dh: int):
-    ctx = torch.empty((B * S, H * dh), dtype=BF16, device=qkv.device)
-    probs = torch.empty((B * H, S, S), dtype=BF16, device=qkv.device)
-    _call("svsr_attn_fwd", _p(qkv), _p(ctx), _p(probs), B, S, H, dh, 1.0 / (dh ** 0.5), _stream())
-    return ctx, probs
-
-
-def attn_bwd(dctx, qkv, probs, B: int, S: int, H: int, dh: int) -> torch.Tensor:
-    dqkv = torch.empty_like(qkv)
-    _call("svsr_attn_bwd", _p(dctx), _p(qkv), _p(probs), _p(dqkv), B, S, H, dh, 1.0 / (dh ** 0.5), _stream())
-    return dqkv
 
 
 def bias_act_bwd(dy, z, db, *, R: int, N: int, n_valid: int, ld: int, relu: bool = False, gscale: float = 1.0) -> torch.Tensor:
     """db[:n_valid] += column sums of dz, where dz = dy * act'(z) if z is given (returned) else dy; act = GELU from the
     pre-activation z, or (relu=True) ReLU from the saved output z."""
     dz = torch.empty_like(dy) if z is not None else None
-    _call("svsr_bias_act_bwd", _p(dy), _p(z), _p(dz), _p(db), R, N, n_valid, ld, 2 if relu else 1, float(gscale), _stream())
+    rows = _query("svsr_bias_act_bwd_rows", R, N)[0] if db is not None else 0
+    part = scratch(rows * N) if rows else None
+    _call("svsr_bias_act_bwd", _p(dy), _p(z), _p(dz), _p(db), R, N, n_valid, ld, 2 if relu else 1, float(gscale), _p(part), _stream())
     return dz if z is not None else dy
 
 
@@ -428,11 +498,11 @@ def bias_act_bwd(dy, z, db, *, R: int, N: int, n_valid: int, ld: int, relu: bool
 # --------------------------------------------------------------------------------------------------
 def ce_fwd(logits, ld: int, target_idx, target_prob, R: int, V: int, smoothing: float):
     dev = logits.device
-    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
     lse = torch.empty(R, dtype=torch.float32, device=dev)
     ldt = 0 if target_prob is None else target_prob.shape[-1]
     _call("svsr_ce_fwd", _p(logits), int(logits.dtype == torch.float32), ld, _p(target_idx), _p(target_prob), ldt, R, V,
-          float(smoothing), _p(loss), _p(lse), _stream())
+          float(smoothing), _p(loss), _p(lse), _p(scratch(R)), _stream())
     return loss, lse
 
 
@@ -444,8 +514,8 @@ def ce_bwd(logits, ld: int, target_idx, target_prob, R: int, V: int, smoothing: 
 
 def topk_acc(logits_f32, labels, soft_labels) -> torch.Tensor:
     B, C = logits_f32.shape
-    out = torch.zeros(2, dtype=torch.float32, device=logits_f32.device)
-    _call("svsr_topk_acc", _p(logits_f32), _p(labels), _p(soft_labels), B, C, _p(out), _stream())
+    out = torch.empty(2, dtype=torch.float32, device=logits_f32.device)
+    _call("svsr_topk_acc", _p(logits_f32), _p(labels), _p(soft_labels), B, C, _p(out), _p(scratch(2 * B)), _stream())
     return out
 
 
@@ -503,10 +573,16 @@ def mha_bwd(dctx, q, q_pitch: int, k, v, kv_pitch: int, probs, *, B: int, H: int
     return dq_ac, dq_bd, dpe
 
 
-def glu_dwconv_fwd(u, w, bias, stats, B: int, T: int, D: int, K: int) -> torch.Tensor:
+def glu_dwconv_fwd(u, w, bias, want_stats: bool, B: int, T: int, D: int, K: int):
+    """-> (c [B*T, D] bf16, BatchNorm1d partials (buffer, rows) or None)"""
     c = torch.empty((B * T, D), dtype=BF16, device=u.device)
+    stats = st = None
+    if want_stats:
+        rows = _query("svsr_glu_dwconv_fwd_stat_rows", B, T)[0]
+        stats = scratch(rows * 2 * D)
+        st = (stats, rows)
     _call("svsr_glu_dwconv_fwd", _p(u), _p(w), _p(bias), _p(c), _p(stats), B, T, D, K, _stream())
-    return c
+    return c, st
 
 
 DW_SPLITS = 16
@@ -523,7 +599,7 @@ def ctc_fwd(logits, ld: int, labels, ilen, B: int, T: int, V: int):
     """logits fp32 [B*T, ld]; labels int64 [B, Lmax] (-1 padded); ilen int32 [B] -> (loss 0-d, state for ctc_grad)."""
     Lmax = labels.shape[1]
     dev = logits.device
-    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
     lse = torch.empty(B * T, dtype=torch.float32, device=dev)
     ab = torch.empty((B, T, 2 * Lmax + 1), dtype=torch.float32, device=dev)
     nll = torch.empty(B, dtype=torch.float32, device=dev)
@@ -552,10 +628,11 @@ def embed_pos_bwd(tok, dx, demb, D: int, scale: float) -> None:
 
 def ls_loss_fwd(logits, ld: int, target, R: int, V: int, smoothing: float, inv_denom: float):
     dev = logits.device
-    loss = torch.zeros((), dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
     lse = torch.empty(R, dtype=torch.float32, device=dev)
-    counts = torch.zeros(2, dtype=torch.float32, device=dev)
-    _call("svsr_ls_loss_fwd", _p(logits), ld, _p(target), R, V, float(smoothing), float(inv_denom), _p(loss), _p(lse), _p(counts), _stream())
+    counts = torch.empty(2, dtype=torch.float32, device=dev)
+    _call("svsr_ls_loss_fwd", _p(logits), ld, _p(target), R, V, float(smoothing), float(inv_denom), _p(loss), _p(lse), _p(counts),
+          _p(scratch(3 * R)), _stream())
     return loss, lse, counts
 
 

@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 REF = "/root/reference/LRS/video"
 
-from golden_cases import LRS_CASES, build_lrs_case  # noqa: E402
+from golden_cases import LRS_CASES, build_lrs_case, sample_idx  # noqa: E402
 from syncvsr_amd.lrs_init import lrs_audio_dims, lrs_param_specs  # noqa: E402
 
 
@@ -100,13 +100,13 @@ def run_case(E2E, name: str) -> dict[str, np.ndarray]:
                                   "loss_att": np.float64(loss_att.item()), "loss_audio": np.float64(loss_audio.item()),
                                   "acc": np.float64(acc)}
     keep["stem_out"] = keep.pop("stem_out5d").transpose(1, 2).flatten(0, 1)
-    small = name != "lrs_full_b2"
+    small = not name.startswith("lrs_full")
     for k, v in keep.items():
         v = v.double()
         res[f"sum.{k}"] = np.float64(v.sum().item())
         res[f"abssum.{k}"] = np.float64(v.abs().sum().item())
         flat = v.flatten()
-        idx = torch.linspace(0, flat.numel() - 1, 16).long()
+        idx = sample_idx(flat.numel())
         res[f"sample.{k}"] = flat[idx].numpy()
         if small and v.numel() <= 8000:
             res[f"full.{k}"] = v.float().numpy()

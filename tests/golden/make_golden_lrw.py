@@ -7,7 +7,7 @@ installed; ``timm.create_model`` is mapped to the reference's own in-tree ResNet
 outputs and gradients as small ``.npz`` fixtures next to this file.  Weights are never stored: the tests
 re-create them from the seed.  Nothing of the reference's source is copied — only numbers it computes.
 
-    python tests/golden/make_golden_lrw.py
+    python tests/golden/make_golden_lrw.py [case ...]
 """
 from __future__ import annotations
 
@@ -56,19 +56,11 @@ def import_reference():
     return ref
 
 
-CASES = {
-    # name: (config overrides, batch kwargs, weight seed, data seed, perturb_norm, training)
-    "lrw_full_b2": (dict(), dict(batch=2, frames=29, size=88), 0, 1234, False, True),
-    "lrw_tiny": (dict(model__bert__num_hidden_layers=2), dict(batch=2, frames=5, size=24), 1, 77, True, True),
-    "lrw_tiny_soft_ls": (dict(model__bert__num_hidden_layers=2, train__label_smoothing=0.1, train__use_cutmix=True),
-                         dict(batch=3, frames=4, size=24, soft_labels=True), 2, 78, True, True),
-    "lrw_tiny_hard_ls": (dict(model__bert__num_hidden_layers=1, train__label_smoothing=0.1),
-                         dict(batch=2, frames=3, size=16), 3, 79, True, True),
-    # NOTE: use_word_boundary=True cannot be combined with the `type: huggingface` encoder in the reference
-    # (BertConfig.hidden_size stays 512 while the features become 513-wide, lightning.py:92,145), so there is
-    # no word-boundary golden for this encoder branch.
-    "lrw_tiny_eval": (dict(model__bert__num_hidden_layers=2), dict(batch=2, frames=5, size=24), 1, 77, True, False),
-}
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from golden_cases import CASES, sample_idx  # noqa: E402  (name: config overrides, batch kwargs, weight seed, data seed, perturb_norm, training)
+# NOTE: use_word_boundary=True cannot be combined with the `type: huggingface` encoder in the reference
+# (BertConfig.hidden_size stays 512 while the features become 513-wide, lightning.py:92,145), so there is
+# no word-boundary golden for this encoder branch.
 
 
 def run_case(ref, name: str) -> dict[str, np.ndarray]:
@@ -118,13 +110,13 @@ def run_case(ref, name: str) -> dict[str, np.ndarray]:
         out["loss_total"].backward()
 
     res: dict[str, np.ndarray] = {k: np.float64(v.item()) for k, v in out.items()}
-    small = name != "lrw_full_b2"
+    small = not name.startswith("lrw_full")
     for k, v in keep.items():
         v = v.double()
         res[f"sum.{k}"] = np.float64(v.double().sum().item())
         res[f"abssum.{k}"] = np.float64(v.double().abs().sum().item())
         flat = v.flatten()
-        idx = torch.linspace(0, flat.numel() - 1, 16).long()
+        idx = sample_idx(flat.numel())
         res[f"sample.{k}"] = flat[idx].double().numpy()
         if small and v.numel() <= 40000:
             res[f"full.{k}"] = v.float().numpy()
@@ -152,7 +144,7 @@ def run_case(ref, name: str) -> dict[str, np.ndarray]:
 def main() -> None:
     ref = import_reference()
     torch.set_num_threads(8)
-    for name in CASES:
+    for name in (sys.argv[1:] or list(CASES)):
         res = run_case(ref, name)
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **res)

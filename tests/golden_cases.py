@@ -1,4 +1,4 @@
-"""Shared description of the committed golden cases (must mirror tests/golden/make_golden_lrw.py::CASES)."""
+"""Shared description of the committed golden cases (tests/golden/make_golden_{lrw,lrs}.py import these tables)."""
 from __future__ import annotations
 
 import os
@@ -19,7 +19,18 @@ CASES = {
     "lrw_tiny_hard_ls": (dict(model__bert__num_hidden_layers=1, train__label_smoothing=0.1),
                          dict(batch=2, frames=3, size=16), 3, 79, True, True),
     "lrw_tiny_eval": (dict(model__bert__num_hidden_layers=2), dict(batch=2, frames=5, size=24), 1, 77, True, False),
+    # BASELINE.json configs[1] at its full batch: the shape bench.py times (B = 32 -> 928 frames), so every kernel instantiation
+    # the benchmark launches is the one this case runs.  Too heavy for the CPU suite: pinned on the GPU box (fp32 oracle vs golden).
+    "lrw_full_b32": (dict(), dict(batch=32, frames=29, size=88), 0, 1234, False, True),
 }
+
+HEAVY_CASES = ("lrw_full_b32", "lrs_full_t150")      # excluded from the `-m "not gpu"` parametrisations (minutes of fp64 CPU work)
+
+
+def sample_idx(n: int) -> torch.Tensor:
+    """16 evenly spaced flat indices (the `sample.*` entries of the goldens).  float32 linspace as the first fixtures used;
+    float64 once n - 1 is no longer exactly representable in float32 (the B = 32 stem tensor has 1.15e8 elements)."""
+    return torch.linspace(0, n - 1, 16, dtype=torch.float32 if n <= (1 << 24) else torch.float64).long()
 
 
 def build_case(name: str):
@@ -51,6 +62,8 @@ LRS_CASES = {
     "lrs_tiny_eval": (_LRS_TINY, 41, dict(batch=2, t_max=9, size=24, label_len=(2, 4)), 11, 91, True, False),
     "lrs_full_b2": (dict(), 5049, dict(batch=2, t_max=12, size=88, label_len=(3, 6)), 0, 1234, False, True),
     # adim != ddim (proj_decoder, e2e_asr_transformer.py:93-95) and the length-normalised attention loss
+    # the shipped 252 M-parameter config at a realistic clip length (two ragged clips padded to 150 frames)
+    "lrs_full_t150": (dict(), 5049, dict(batch=2, t_max=150, size=88, label_len=(10, 30), min_len_frac=0.6), 0, 1235, False, True),
     "lrs_tiny_proj": (dict(_LRS_TINY, ddim=192, dheads=3, dlayers=2, transformer_length_normalized_loss=True), 37,
                       dict(batch=3, t_max=10, size=16, label_len=(2, 5), min_len_frac=0.5), 13, 93, True, True),
 }

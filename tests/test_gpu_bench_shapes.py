@@ -1,0 +1,235 @@
+"""Kernel parity AT THE BENCHMARK SHAPES (-m gpu): every contraction launch of the B = 32 LRW step (928 frames; BASELINE.json
+configs[1]) and the large LRS linears (2,400 rows), each against torch fp32 on the same bf16-rounded operands.
+
+bench.py's kernel instantiations are chosen from the problem shape (svsr_igemm_fwd_plan / svsr_igemm_wgrad_plan), so running
+the benchmark's own shapes here runs the benchmark's own instantiations; each test also asks the library which instantiation it
+launched, asserts the ones the step is known to depend on and records all of them in gpurun_out/bench_shape_instantiations.json
+so that coverage cannot silently move when the launch heuristics change.  Tolerances are those of tests/test_gpu_kernels.py.
+"""
+import json
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+N_FRAMES = 928          # 32 clips x 29 frames
+_SEEN: dict = {}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from syncvsr_amd import _lib
+
+    _lib.load()
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    yield torch.device("cuda:0")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "bench_shape_instantiations.json"), "w") as f:
+        json.dump(_SEEN, f, indent=1, sort_keys=True)
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(BF)
+
+
+def check(got, ref, name, max_tol=1.5e-2, l2_tol=6e-3):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite values"
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    l2 = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+    assert err <= max_tol * scale and l2 <= l2_tol, f"{name}: max err {err:.3e} (scale {scale:.3e}), rel L2 {l2:.3e}"
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+# every convolution of the ResNet18 trunk at 928 frames of 22x22 after the stem (88x88 clips):
+# name: (H, W, Ci, Co, k, stride, pad)
+TRUNK = {
+    "layer1.conv": (22, 22, 64, 64, 3, 1, 1),
+    "layer2.0.conv1": (22, 22, 64, 128, 3, 2, 1),
+    "layer2.0.downsample": (22, 22, 64, 128, 1, 2, 0),
+    "layer2.conv": (11, 11, 128, 128, 3, 1, 1),
+    "layer3.0.conv1": (11, 11, 128, 256, 3, 2, 1),
+    "layer3.0.downsample": (11, 11, 128, 256, 1, 2, 0),
+    "layer3.conv": (6, 6, 256, 256, 3, 1, 1),
+    "layer4.0.conv1": (6, 6, 256, 512, 3, 2, 1),
+    "layer4.0.downsample": (6, 6, 256, 512, 1, 2, 0),
+    "layer4.conv": (3, 3, 512, 512, 3, 1, 1),
+}
+# the instantiations the B = 32 step is known to run today; a change of the launch heuristics must update this table
+# deliberately (and keeps the parity coverage, because the shapes stay the benchmark's)
+EXPECT_FWD = {
+    "layer2.conv": "k_igemm_fwd_glds<128,128,2>",
+    "layer3.conv": "k_igemm_fwd_glds<128,128,2>",
+}
+
+
+def _fwd_label(ops, M, Co, ntaps):
+    bm, bn, ns = ops.igemm_fwd_tile(M, Co, ntaps)
+    return f"k_igemm_fwd_glds<{bm},{bn},{ns}>"
+
+
+@pytest.mark.parametrize("name", list(TRUNK))
+def test_trunk_conv_fwd_dgrad_wgrad_at_928_frames(dev, name):
+    from syncvsr_amd import ops
+
+    H, W, Ci, Co, k, s, p = TRUNK[name]
+    N = N_FRAMES
+    Ho, Wo = ops.conv_out_size(H, k, s, p), ops.conv_out_size(W, k, s, p)
+    x = rnd((N, H, W, Ci), 1)
+    w = rnd((Co, k, k, Ci), 2, 1.0 / math.sqrt(k * k * Ci))
+    wf = w.float().permute(0, 3, 1, 2)
+    xd, wd = x.to(dev), w.to(dev)
+    # ---- forward + BatchNorm partial sums --------------------------------------------------------------------------
+    out, stats = ops.conv2d_fwd(xd, wd, k, s, p, want_stats=True)
+    c64 = ops._c64_ok(Ci, Co, k, s, p, W)
+    _SEEN[f"{name}.fwd"] = "k_conv3x3_c64" if c64 else _fwd_label(ops, N * Ho * Wo, Co, k * k)
+    if name in EXPECT_FWD:
+        assert _SEEN[f"{name}.fwd"] == EXPECT_FWD[name], _SEEN[f"{name}.fwd"]
+    ref = F.conv2d(nchw(x.float()), wf, stride=s, padding=p)
+    check(out, nhwc(ref), f"{name}.fwd")
+    buf, rows = stats
+    st = buf[: rows * 2 * Co].view(rows, 2, Co).double().sum(0).float().cpu()
+    count = ref.numel() // Co
+    q_ref = (ref * ref).sum((0, 2, 3))
+    assert bool(((st[0] - ref.sum((0, 2, 3))).abs() <= 2e-3 * torch.sqrt(count * q_ref)).all()), f"{name}.stats.sum"
+    check(st[1], q_ref, f"{name}.stats.sumsq", 3e-3, 2e-3)
+    # ---- data gradient (stride 2: one launch per input-parity class) ----------------------------------------------
+    dy = rnd((N, Ho, Wo, Co), 3)
+    w2 = rnd((Co, k, k, Ci), 4, 1.0 / math.sqrt(k * k * Co))
+    wt = w2.permute(3, 1, 2, 0).contiguous()
+    xs = torch.zeros(N, Ci, H, W, requires_grad=True)
+    F.conv2d(xs, w2.float().permute(0, 3, 1, 2), stride=s, padding=p).backward(nchw(dy.float()))
+    add = rnd((N, H, W, Ci), 5)
+    dx = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), k, s, p, (H, W), addend=add.to(dev).clone())
+    labels = []
+    if c64:
+        labels.append("k_conv3x3_c64")
+    else:
+        for py in range(s):
+            for px in range(s):
+                nt = sum(1 for kh in range(k) for kw in range(k) if (py + p - kh) % s == 0 and (px + p - kw) % s == 0)
+                Ha, Wa = (H - py + s - 1) // s, (W - px + s - 1) // s
+                if nt and Ha > 0 and Wa > 0:
+                    labels.append(_fwd_label(ops, N * Ha * Wa, Ci, nt))
+    _SEEN[f"{name}.dgrad"] = sorted(set(labels))
+    check(dx, nhwc(xs.grad) + add.float(), f"{name}.dgrad+addend")
+    # ---- weight gradient ------------------------------------------------------------------------------------------
+    ws = torch.zeros(Co, Ci, k, k, requires_grad=True)
+    F.conv2d(nchw(x.float()), ws, stride=s, padding=p).backward(nchw(dy.float()))
+    dw = torch.zeros(Co, k, k, Ci, device=dev)
+    ops.conv2d_wgrad(xd, dy.to(dev), dw, k, s, p, use_tr=True)
+    halo = ops.HALO_WGRAD and k == 3 and s == 1 and p == 1 and W <= 29 and H * W >= 100
+    if halo:
+        _SEEN[f"{name}.wgrad"] = "k_wgrad3x3_halo"
+    else:
+        bc, splits, _ = ops.wgrad_plan(N * Ho * Wo, Co, Ci, k * k, k * k, False)
+        _SEEN[f"{name}.wgrad"] = f"k_igemm_wgrad<true,{bc}> x{splits} splits"
+    check(dw, ws.grad.permute(0, 2, 3, 1), f"{name}.wgrad", 3e-3, 2e-3)
+    # a second identical launch gives the bit-identical result (fixed-order split-K reduction; accumulate semantics -> 2x)
+    dw2 = torch.zeros_like(dw)
+    ops.conv2d_wgrad(xd, dy.to(dev), dw2, k, s, p, use_tr=True)
+    assert torch.equal(dw, dw2), f"{name}.wgrad is not reproducible"
+
+
+def test_benchmark_instantiations_cover_the_big_tiles(dev):
+    """The B = 32 shapes must select the 128-row tiles bench.py reports as dominant: layer2/3 forward and data-gradient on
+    <128,128,2>, layer4 on <128,64,2>, the generic weight gradient on 128-wide tiles."""
+    from syncvsr_amd import ops
+
+    assert ops.igemm_fwd_tile(N_FRAMES * 121, 128, 9) == (128, 128, 2)
+    assert ops.igemm_fwd_tile(N_FRAMES * 36, 256, 9) == (128, 128, 2)
+    assert ops.igemm_fwd_tile(N_FRAMES * 9, 512, 9) == (128, 64, 2)
+    assert ops.wgrad_plan(N_FRAMES * 36, 256, 256, 9, 9, False)[0] == 128
+    assert ops.wgrad_plan(N_FRAMES * 9, 512, 512, 9, 9, False)[0] == 128
+
+
+# (rows, K, N, gelu, bias): the linear layers of the LRW encoder + heads at 32 x 30 tokens, and the LRS ones at 16 x 150 frames
+LINEARS = [
+    (960, 512, 1536, False, True), (960, 512, 512, False, True), (960, 512, 2048, True, True), (960, 2048, 512, False, True),
+    (928, 512, 2560, False, True),
+    (2400, 768, 2304, False, True), (2400, 768, 3072, False, True), (2400, 3072, 768, False, True), (2400, 768, 5049, False, True),
+]
+
+
+@pytest.mark.parametrize("rows,K,N,gelu,bias", LINEARS)
+def test_linear_fwd_dgrad_wgrad_at_benchmark_rows(dev, rows, K, N, gelu, bias):
+    from syncvsr_amd import ops
+
+    x = rnd((rows, K), 8)
+    w = rnd((N, K), 9, 1 / math.sqrt(K))
+    b = torch.randn(N, generator=torch.Generator().manual_seed(10))
+    ref = F.linear(x.float(), w.float(), b)
+    Np = (N + 7) // 8 * 8
+    out, pre = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), rows=rows, K=K, N=N, x_pitch=K, out_pitch=Np, gelu=gelu)
+    _SEEN[f"linear {rows}x{K}->{N}.fwd"] = _fwd_label(ops, rows, N, 1)
+    if gelu:
+        check(pre[:, :N], ref, "linear.pre")
+        check(out[:, :N], F.gelu(ref), "linear.gelu")
+    else:
+        check(out[:, :N], ref, "linear")
+    # data gradient through the transposed (64-padded) shadow
+    dy = torch.zeros(rows, Np, dtype=BF)
+    dy[:, :N] = rnd((rows, N), 12)
+    Npad = (N + 63) // 64 * 64
+    wt = torch.zeros(K, 1, Npad, dtype=BF)
+    wt[:, 0, :N] = w.t()
+    dyp = torch.zeros(rows, Npad, dtype=BF)
+    dyp[:, :N] = dy[:, :N]
+    dx = ops.linear_dgrad(dyp.to(dev), wt.to(dev), rows=rows, N=N, K=K, dy_pitch=Npad)
+    _SEEN[f"linear {rows}x{K}->{N}.dgrad"] = _fwd_label(ops, rows, K, 1)
+    check(dx, dy[:, :N].float() @ w.float(), "linear.dgrad")
+    dw = torch.zeros(N, K, device=dev)
+    db = torch.zeros(N, device=dev)
+    ops.linear_wgrad(x.to(dev), dyp.to(dev), dw, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=Npad, db=db)
+    bc, splits, _ = ops.wgrad_plan(rows, N, K, 1, 1, True)
+    _SEEN[f"linear {rows}x{K}->{N}.wgrad"] = f"k_igemm_wgrad<true,{bc}> x{splits} splits"
+    check(dw, dy[:, :N].float().t() @ x.float(), "linear.wgrad", 3e-3, 2e-3)
+    check(db, dy[:, :N].float().sum(0), "linear.bias_grad", 1e-2, 6e-3)
+    dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
+    ops.linear_wgrad(x.to(dev), dyp.to(dev), dw2, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=Npad, db=db2)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "linear.wgrad is not reproducible"
+
+
+def test_stem_at_benchmark_batch(dev):
+    """Stem conv forward (+statistics) and weight gradient on a full B = 32 batch of 29 x 88 x 88 clips (the persistent grids
+    and slab counts of the benchmark launch)."""
+    from syncvsr_amd import ops
+
+    B, T, H, W = 32, 29, 88, 88
+    g = torch.Generator().manual_seed(20)
+    vid = torch.randn(B, 1, T, H, W, generator=g)
+    w = (torch.rand(64, 1, 5, 7, 7, generator=g) - 0.5) * 0.2
+    out, stats = ops.stem_conv_fwd(vid.to(dev), w.to(dev).reshape(-1), want_stats=True)
+    ref = F.conv3d(vid.to(BF).float(), w.to(BF).float(), stride=(1, 2, 2), padding=(2, 3, 3))      # [B,64,T,44,44]
+    ref_nhwc = ref.permute(0, 2, 3, 4, 1).reshape(B * T, H // 2, W // 2, 64)
+    check(out, ref_nhwc, "stem_conv_fwd@B32")
+    buf, rows = stats
+    st = buf[: rows * 128].view(rows, 2, 64).double().sum(0).float().cpu()
+    check(st[1], (ref * ref).sum((0, 2, 3, 4)), "stem.stats.sumsq", 3e-3, 2e-3)
+    dy = rnd((B * T, H // 2, W // 2, 64), 21)
+    ws = w.to(BF).float().clone().requires_grad_(True)
+    F.conv3d(vid.to(BF).float(), ws, stride=(1, 2, 2), padding=(2, 3, 3)).backward(dy.float().view(B, T, H // 2, W // 2, 64).permute(0, 4, 1, 2, 3))
+    dw = torch.zeros(64 * 245, device=dev)
+    ops.stem_conv_wgrad(vid.to(dev), dy.to(dev), dw, use_tr=True)
+    check(dw.view(64, 1, 5, 7, 7), ws.grad, "stem_conv_wgrad@B32", 4e-3, 3e-3)
+    dw2 = torch.zeros_like(dw)
+    ops.stem_conv_wgrad(vid.to(dev), dy.to(dev), dw2, use_tr=True)
+    assert torch.equal(dw, dw2), "stem wgrad is not reproducible"

@@ -1,10 +1,12 @@
 """Whole-path parity (-m gpu) of the LRS model: syncvsr_amd.lrs_model.E2E (HIP) against oracle/lrs_oracle.py (fp32 CPU) on
 identical seeded inputs and weights, and against the committed goldens produced by the reference's own E2E.
 Tolerances (bf16 storage / fp32 accumulation through a 12-layer Conformer + 6-layer decoder):
-  * losses: |hip - oracle| <= 1e-2 * |oracle| on the tiny cases, 5e-3 on the full-width case
+  * losses: |hip - oracle| <= 1e-3 * |oracle| on the full-width cases (north_star's bound; measured <= 5.4e-4),
+    5e-3 on the tiny cases (measured <= 1.4e-3)
   * encoder output / decoder logits: relative L2 error <= 5e-2
-  * parameter gradients (full-width case): median cosine >= 0.99, min cosine >= 0.8 over tensors whose oracle gradient is
-    not numerically zero, norm ratio within 20 %
+  * parameter gradients (full-width cases): median cosine >= 0.995, min cosine >= 0.97 over tensors whose oracle gradient
+    is not numerically zero, norm ratio within 5 % (measured: min 0.989 / median 0.998, ratios 0.984 .. 1.020)
+  * token accuracy: within two tokens of the oracle's (an argmax can flip where two logits tie to bf16 resolution)
 """
 import json
 import os
@@ -51,7 +53,8 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-@pytest.mark.parametrize("name,loss_tol", [("lrs_tiny", 1e-2), ("lrs_tiny_b3", 1e-2), ("lrs_tiny_proj", 1e-2), ("lrs_full_b2", 5e-3)])
+@pytest.mark.parametrize("name,loss_tol", [("lrs_tiny", 5e-3), ("lrs_tiny_b3", 5e-3), ("lrs_tiny_proj", 5e-3), ("lrs_full_b2", 1e-3),
+                                           ("lrs_full_t150", 1e-3)])
 def test_lrs_model_matches_oracle(dev, name, loss_tol):
     args, model, out, osd, ref, keep, stats, gold = _run_pair(name, dev)
     names = ("loss", "loss_ctc", "loss_att", "loss_audio")
@@ -85,14 +88,16 @@ def test_lrs_model_matches_oracle(dev, name, loss_tol):
     print("worst grad cosines:", worst)
     for k in names:
         assert abs(rows[k]["hip"] - rows[k]["oracle"]) <= loss_tol * abs(rows[k]["oracle"]), (k, rows[k])
-    assert rows["rel.feats"] <= (3e-2 if name == "lrs_full_b2" else 4e-2) and rows["rel.enc_out"] <= 5e-2 and rows["rel.pred"] <= 5e-2, rows
+        if name.startswith("lrs_full"):      # the fp32 oracle itself against the golden the reference produced (fp64) for this case
+            assert abs(rows[k]["oracle"] - rows[k]["golden"]) <= 1e-4 * abs(rows[k]["golden"]), ("oracle vs reference golden", k, rows[k])
+    assert rows["rel.feats"] <= (3e-2 if name.startswith("lrs_full") else 4e-2) and rows["rel.enc_out"] <= 5e-2 and rows["rel.pred"] <= 5e-2, rows
     for n, v in bufs.items():
         assert v <= 2e-2, (n, v)
     coss = sorted(v["cos"] for v in live.values())
-    if name == "lrs_full_b2":
-        assert coss[len(coss) // 2] >= 0.99 and coss[0] >= 0.8, (coss[0], coss[len(coss) // 2])
+    if name.startswith("lrs_full"):
+        assert coss[len(coss) // 2] >= 0.995 and coss[0] >= 0.97, (coss[0], coss[len(coss) // 2])
         for n, v in live.items():
-            assert 0.8 <= v["ratio"] <= 1.2, (n, v)
+            assert 0.95 <= v["ratio"] <= 1.05, (n, v)
     else:
         assert coss[len(coss) // 2] >= 0.97, coss[len(coss) // 2]
 
@@ -186,14 +191,16 @@ def test_lrs_ragged_shapes(dev, B, T, size, label_len):
     ref["loss"].backward()
     for i, k in enumerate(("loss", "loss_ctc", "loss_att", "loss_audio")):
         assert abs(out[i].item() - ref[k].item()) <= 1.5e-2 * abs(ref[k].item()) + 1e-3, (k, out[i].item(), ref[k].item())
-    assert abs(float(out[4]) - ref["acc"]) < 1e-6 or True
+    n_live = int((label != -1).sum()) + B          # target tokens + one <eos> per clip
+    assert abs(float(out[4]) - ref["acc"]) <= 2.0 / n_live + 1e-6, (float(out[4]), ref["acc"], n_live)
     coss = []
     for n, p in model.named_parameters():
         g, r = p.grad.detach().float().cpu().flatten(), osd[n].grad.flatten()
         if r.norm() > 1e-5 * max(1.0, float(ref["loss"].item())):
             coss.append((float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)), n))
     coss.sort()
-    assert coss[len(coss) // 2][0] >= 0.97 and coss[0][0] >= 0.7, coss[:5]
+    print("ragged", (B, T, size), "worst cosines", coss[:3], "median", coss[len(coss) // 2][0])
+    assert coss[len(coss) // 2][0] >= 0.98 and coss[0][0] >= 0.9, coss[:5]
 
 
 def test_lrs_encode_api(dev):

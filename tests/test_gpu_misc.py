@@ -98,13 +98,12 @@ def test_conv3x3_c64_persistent(dev, case):
     x = torch.randn(N, H, W, 64, generator=g).to(BF)
     w = (torch.randn(64, 3, 3, 64, generator=g) / math.sqrt(576)).to(BF)
     assert ops.C64_CONV
-    slots = torch.zeros(ops.STAT_SLOTS * 2 * 64, device=dev)
-    out = ops.conv2d_fwd(x.to(dev), w.to(dev), 3, 1, 1, stats=slots)
+    out, stats = ops.conv2d_fwd(x.to(dev), w.to(dev), 3, 1, 1, want_stats=True)
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=1)
     refn = ref.permute(0, 2, 3, 1)
     err = (out.float().cpu() - refn).abs().max().item()
     assert err <= 1.5e-2 * refn.abs().max().item(), err
-    st = slots.view(ops.STAT_SLOTS, 2, 64).sum(0).cpu()
+    st = stats[0][: stats[1] * 128].view(stats[1], 2, 64).double().sum(0).float().cpu()
     q_ref = (ref * ref).sum((0, 2, 3))
     assert ((st[1] - q_ref).abs() <= 3e-3 * q_ref).all()
     assert ((st[0] - ref.sum((0, 2, 3))).abs() <= 2e-3 * torch.sqrt(ref[0].numel() / 64 * N * q_ref)).all()
@@ -121,7 +120,7 @@ def test_conv3x3_c64_persistent(dev, case):
     # and the generic implicit-GEMM kernel agrees
     ops.C64_CONV = False
     try:
-        out2 = ops.conv2d_fwd(x.to(dev), w.to(dev), 3, 1, 1)
+        out2, _ = ops.conv2d_fwd(x.to(dev), w.to(dev), 3, 1, 1)
     finally:
         ops.C64_CONV = True
     assert (out2.float() - out.float()).abs().max().item() <= 1e-2 * refn.abs().max().item()

@@ -1,10 +1,12 @@
 """Whole-path parity (-m gpu): the HIP model against oracle/lrw_oracle.py (fp32 CPU) on identical seeded inputs and
 weights, plus the committed reference goldens.  The HIP path computes in bf16 storage / fp32 accumulation, so:
-  * losses: |hip - oracle| <= 3e-3 * |oracle|   (north_star asks 1e-3 on the loss; measured deviations are printed)
+  * losses: |hip - oracle| <= 1e-3 * |oracle| on the full-size cases (north_star's bound; measured 6e-4 and below) and
+    <= 6e-3 on the tiny cases, whose BatchNorm statistics come from as few as 96 values per channel (measured <= 2e-3)
   * features / word logits: relative L2 error <= 3e-2; audio logits (after 6 more bf16 layers) <= 8e-2
-  * parameter gradients: min cosine >= 0.85, median cosine >= 0.995, norm ratio within 15 % for every tensor whose oracle
-    norm is not numerically zero (key biases are analytically zero) — the fidelity of torch's own bf16 autocast on this
-    case is min 0.878 / median 0.998, see DESIGN.md.
+  * parameter gradients at B = 2: min cosine >= 0.85, median cosine >= 0.995, norm ratio within 15 % for every tensor whose
+    oracle norm is not numerically zero (key biases are analytically zero) — the fidelity of torch's own bf16 autocast on
+    this case is min 0.878 / median 0.998; at the benchmark batch (B = 32, test_benchmark_batch_matches_*)
+    the statistics average over 16x more values and the bounds are min cosine >= 0.95, norm ratio within 10 %.
 """
 import json
 import os
@@ -53,7 +55,7 @@ def _report(name, rows):
         json.dump(rows, f, indent=1)
 
 
-@pytest.mark.parametrize("name,loss_tol", [("lrw_full_b2", 3e-3), ("lrw_tiny", 2e-2), ("lrw_tiny_soft_ls", 2e-2), ("lrw_tiny_hard_ls", 2e-2)])
+@pytest.mark.parametrize("name,loss_tol", [("lrw_full_b2", 1e-3), ("lrw_tiny", 6e-3), ("lrw_tiny_soft_ls", 6e-3), ("lrw_tiny_hard_ls", 6e-3)])
 def test_model_matches_oracle(dev, name, loss_tol):
     cfg, model, out, osd, ref, keep, stats, gold = _run_pair(name, dev)
     rows = {}
@@ -99,6 +101,50 @@ def test_model_matches_oracle(dev, name, loss_tol):
                 assert 0.85 <= v["ratio"] <= 1.15, (n, v)
         for n, v in bufs.items():
             assert v <= 1e-2, (n, v)
+
+
+def test_benchmark_batch_matches_oracle_and_reference_golden(dev):
+    """BASELINE.json configs[1] at its full batch (32 clips = 928 frames): the HIP step launches exactly the kernel
+    instantiations bench.py times.  The fp32 oracle is pinned to the golden the reference itself produced for this batch
+    (tests/golden/make_golden_lrw.py lrw_full_b32, fp64) and the HIP path is compared with the oracle."""
+    cfg, model, out, osd, ref, keep, stats, gold = _run_pair("lrw_full_b32", dev)
+    for k in ("loss_total", "loss_category", "loss_audio", "accuracy_top1", "accuracy_top5"):
+        assert abs(ref[k].item() - float(gold[k])) <= 2e-5 * max(1.0, abs(float(gold[k]))), ("oracle vs reference golden", k)
+    names = [str(n) for n in gold["grad_names"]]
+    onorm = np.array([osd[n].grad.double().norm().item() for n in names])
+    big = gold["grad_norms"] > 1e-6 * gold["grad_norms"].max()          # key biases have analytically zero gradients
+    np.testing.assert_allclose(onorm[big], gold["grad_norms"][big], rtol=5e-3)      # fp32 oracle vs fp64 reference
+    rows = {}
+    for k in ("loss_total", "loss_category", "loss_audio"):
+        rows[k] = dict(hip=out[k].item(), oracle=ref[k].item(), golden=float(gold[k]))
+        assert abs(rows[k]["hip"] - rows[k]["oracle"]) <= 1e-3 * abs(rows[k]["oracle"]), (k, rows[k])
+    assert abs(out["accuracy_top1"].item() - ref["accuracy_top1"].item()) < 1e-6
+
+    def rel(a, b):
+        a, b = a.detach().float().cpu().flatten(), b.detach().float().flatten()
+        return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+    last = model._last
+    for k, tol in (("feats", 3e-2), ("logits_category", 3e-2), ("logits_audio", 8e-2)):
+        rows[f"rel.{k}"] = rel(last[k], keep[k])
+        assert rows[f"rel.{k}"] <= tol, (k, rows[f"rel.{k}"])
+    grads = {}
+    for n, p in model.named_parameters():
+        g = p.grad.detach().float().cpu().flatten()
+        r = osd[n].grad.flatten()
+        rn = r.norm().item()
+        grads[n] = dict(cos=float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)), ratio=float(g.norm() / (rn + 1e-30)), ref_norm=rn)
+    rows["grads"] = grads
+    _report("lrw_full_b32", rows)
+    live = {n: v for n, v in grads.items() if v["ref_norm"] > 1e-6}
+    coss = sorted((v["cos"], n) for n, v in live.items())
+    print(json.dumps({k: v for k, v in rows.items() if k != "grads"}, indent=1))
+    print("worst grad cosines:", coss[:5], "median", coss[len(coss) // 2][0])
+    assert coss[0][0] >= 0.95 and coss[len(coss) // 2][0] >= 0.998, (coss[:3], coss[len(coss) // 2])
+    for n, v in live.items():
+        assert 0.9 <= v["ratio"] <= 1.1, (n, v)
+    for n in ("stem3d.1.running_var", "resnet.layer1.0.bn1.running_mean", "resnet.layer4.1.bn2.running_var"):
+        assert rel(dict(model.named_buffers())[n], stats[n]) <= 1e-2, n
 
 
 def test_eval_mode_matches_oracle(dev):
