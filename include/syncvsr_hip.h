@@ -45,25 +45,33 @@ extern "C" {
 int svsr_tune(const char* key, int value);
 int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale, hipStream_t stream);
 
-/* ---- implicit-GEMM contractions (igemm.hip) ------------------------------------------------------------------
- * Iteration space: M = Nimg*Ha*Wa positions (n,a,b); source pixel (a*S+dy[t], b*S+dx[t]) of `in` [Nimg][Hi][Wi]
- * (pitch in_pitch, Ci channels per tap, zero outside the grid); target pixel (a*OS+oy0, b*OS+ox0) of `out`
- * [Nimg][Ho][Wo] (pitch out_pitch, Co channels).  wt: bf16 [Co][wt_taps][Ci]; tap t uses weight tap tw[t].
- * dy/dx/tw are HOST arrays of ntaps ints.
- *
+/* ---- implicit-GEMM contractions (igemm_fwd.hip) -------------------------------------------------------------------
  * svsr_igemm_fwd replaces: nn.Conv2d forward of resnet.layer{1..4} (reference LRW/video/src/tcn/models/resnet.py:8-16,
  *   59-72 / timm resnet18 via lightning.py:55,114-117), their input-gradient (autograd), and every nn.Linear forward /
- *   input-gradient of the BERT encoder and heads (lightning.py:92,107,82,161,168).  Optional epilogues: +bias, +addend
- *   (bf16 pixels laid out like `out`: residual-gradient merge; may alias `out`), out = act(alpha*(acc+bias)+addend) with
- *   act 0 none / 1 exact GELU (pre-activation saved to out_pre) / 2 ReLU (LRS PositionwiseFeedForward,
- *   transformer/positionwise_feed_forward.py:28-30; alpha carries the Conformer's 0.5 macaron scale and the
- *   sqrt(d) embedding scale, encoder_layer.py:97,131, embedding.py:208); dropout(p) on act(acc+bias) with the keep decision
- *   hash(*drop_seed, drop_site, output element index) (drop_seed null or p = 0: off; see svsr_scale_bf16), fp32 output, per-channel BatchNorm partial sums:
- *   stats[rows][2][Co], row = M tile (plain stores; rows from svsr_igemm_fwd_plan; reduced by svsr_bn_finalize).
- * svsr_igemm_fwd_plan (host query): the kernel instantiation chosen for (M = Nimg*Ha*Wa, Co, ntaps) — tile bm x bn, ring
- *   depth ns — and stat_rows = number of partial rows written. */
-int svsr_igemm_fwd_plan(int M, int Co, int ntaps, int* bm, int* bn, int* ns, int* stat_rows);
-int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int act, int out_f32, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
+ *   input-gradient of the BERT encoder and heads (lightning.py:92,107,82,161,168).
+ * The rows of the contraction come from a PLAN built on the host once per shape (svsr_conv_plan / svsr_rows_plan) and kept
+ *   on the device: output positions are grouped into classes that share the same set of in-grid taps, so the kernel never
+ *   multiplies by a convolution's zero padding and a stride-2 input-gradient (four output-parity classes) is one launch.
+ *   svsr_*_plan(words = null) returns the number of int32 words; a second call fills `words` (host) and meta[8] =
+ *   {bm, bn, ns, tiles, grid_y, classes, max taps, rows}: the kernel instantiation k_igemm_fwd_glds<bm,bn,ns> the launch will
+ *   use and `tiles` = rows of BatchNorm partials it writes.  Negative return = -SVSR_ERR_ARG.
+ *   svsr_conv_plan: k x k / stride / pad convolution over Nimg images whose FORWARD input is H x W; mode 0 forward
+ *   (in = x [H][W] -> out = y [Ho][Wo], wt [Co][k*k][Ci]), mode 1 input-gradient (in = dy [Ho][Wo] -> out = dx [H][W], wt =
+ *   transposed weights [Ci][k*k][Co]; pixels no tap reaches are written as 0 (+ bias / addend)), mode 2 the same for an
+ *   in-place accumulation (addend aliases out): pixels no tap reaches are left alone.
+ *   svsr_rows_plan: dense layer over Nimg sequences, row (n, j < P) reads source row n*in_pix + src0 + j and writes target row
+ *   n*out_pix + dst0 + j (plain linear: P = 1, in_pix = out_pix = 1).
+ * svsr_igemm_fwd(plan_dev = device copy of the words, meta = the host meta): in [Nimg][in_pix] pixels of pitch in_pitch with
+ *   Ci channels per tap, out [Nimg][out_pix] pixels of pitch out_pitch with Co channels; wt bf16 [Co][wt_taps][Ci].
+ *   Optional epilogues: +bias, +addend (bf16 pixels laid out like `out`: residual-gradient merge; may alias `out`),
+ *   out = alpha * dropout(act(acc + bias)) + addend with act 0 none / 1 exact GELU (pre-activation saved to out_pre) / 2 ReLU
+ *   (LRS PositionwiseFeedForward, transformer/positionwise_feed_forward.py:28-30; alpha carries the Conformer's 0.5 macaron
+ *   scale and the sqrt(d) embedding scale, encoder_layer.py:97,131, embedding.py:208); dropout(p) with the keep decision
+ *   hash(*drop_seed, drop_site, output element index) (drop_seed null or p = 0: off; see svsr_scale_bf16), fp32 output,
+ *   per-channel BatchNorm partial sums stats[tiles][2][Co] (plain stores; reduced by svsr_bn_finalize). */
+int svsr_conv_plan(int mode, int Nimg, int H, int W, int Co_out, int k, int stride, int pad, int* words, int cap_words, int* meta);
+int svsr_rows_plan(int Nimg, int P, int src0, int dst0, int Co_out, int* words, int cap_words, int* meta);
+int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 
 /* svsr_igemm_wgrad replaces: the weight-gradient of the same Conv2d / Linear layers (torch autograd).
  * dw fp32 [Co][wt_taps][Ci] is ACCUMULATED (dw += ...).  x = forward input pixels, dyp = output-gradient pixels.

@@ -15,10 +15,28 @@
 // Epilogue: accumulators -> LDS fp32 -> +bias +addend, exact GELU, 16-byte stores; optional BatchNorm partial sums, one row
 // of [2][Co] per M tile (plain stores, no atomics: svsr_bn_finalize adds the rows in a fixed order, so a step is reproducible).
 
+#include <algorithm>
+#include <map>
+#include <vector>
+
 #include "igemm_common.h"
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Launch plan (host-built, device-resident int32 words): the rows of the contraction are grouped into CLASSES of output
+// positions that share the same set of in-grid taps, so the kernel never multiplies by the zero padding of a convolution
+// (3x3 / pad 1 on 3x3, 6x6, 11x11 maps: 40 %, 21 %, 12 % of an im2col contraction are zeros) and needs no per-row masks:
+//   words[0] = number of classes, words[1] = word offset of the position table
+//   class c at words[2 + 24 c]: { ntaps, P, pos_off, tile_begin, delta[9], tw[9], pad[2] }
+//       rows of the class: m = n * P + j  (image n, j-th position of the class), M_c = Nimg * P, tiled by BM from tile_begin
+//       tap t reads source pixel src + delta[t] with weight tap tw[t]
+//   position table: pairs (src, dst) = source-centre / target pixel index inside one image, per class at pos_off
+// A stride-2 data gradient is ONE launch: its four output-parity classes are just more classes (with their own taps).
+// Classes are ordered by decreasing tap count, so the short ones fill the tail of the launch.
+// ---------------------------------------------------------------------------------------------------------------------
+#define PLAN_CLS_WORDS 24
+#define PLAN_HDR_WORDS 2
+
 struct IgemmFwdArgs {
-    IgemmGeom g;
     const bf16_t* in;
     const bf16_t* wt;      // [Co][wt_taps][Ci]
     void* out;             // bf16 or f32 pixels
@@ -26,6 +44,9 @@ struct IgemmFwdArgs {
     const float* bias;     // optional [Co]
     const bf16_t* addend;  // optional bf16 pixels with the geometry of `out`, added before the activation
     float* stats;          // optional BatchNorm partials [gridDim.x][2][Co]: row blockIdx.x = this M tile's column sums / sums of squares
+    const int* plan;       // device copy of the plan words
+    int Nimg, in_pix, Ci, in_pitch;      // images, pixels per source image, contraction channels per tap (multiple of 64), source pitch
+    int Co, out_pix, out_pitch, wt_taps; // output channels, pixels per target image, target pitch, taps physically present in wt
     int act, out_f32;          // act: 0 none, 1 GELU(erf) (pre-activation kept in out_pre), 2 ReLU
     float alpha;               // out = alpha * dropout(act(acc + bias)) + addend
     DropArgs drop;             // drop.seed == nullptr: no dropout
@@ -42,7 +63,6 @@ template <int BM, int BN, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&acc)[TM][TN], unsigned char* smem_raw, const long* sRow,
                                                int wm0, int wn0, int n0) {
     constexpr int WN = BN / 2;
-    const IgemmGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // per-channel statistics from the fp32 accumulators (rows outside M carry exact zeros)
     float st_s[TN], st_q[TN];
@@ -70,18 +90,18 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
                 sOut[row * BN + wn0 + j * 32 + (lane & 31)] = acc[i][j][r];
             }
     __syncthreads();
-    const bool vec_pitch = (g.out_pitch & 7) == 0;
+    const bool vec_pitch = (p.out_pitch & 7) == 0;
     constexpr int CV = BN / 8;
     for (int task = tid; task < BM * CV; task += 256) {
         const int r = task / CV, c8 = task - r * CV;
         const long off = sRow[r];
         const int n = n0 + c8 * 8;
-        if (off < 0 || n >= g.Co) continue;
+        if (off < 0 || n >= p.Co) continue;
         float v[8];
         const f32x4 lo = *reinterpret_cast<const f32x4*>(sOut + r * BN + c8 * 8);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(sOut + r * BN + c8 * 8 + 4);
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-        if (vec_pitch && n + 8 <= g.Co) {
+        if (vec_pitch && n + 8 <= p.Co) {
             if (p.bias != nullptr) {
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
                 v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3]; v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
@@ -119,7 +139,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if (n + k >= g.Co) break;
+                if (n + k >= p.Co) break;
                 float x = v[k];
                 if (p.bias != nullptr) x += p.bias[n + k];
                 if (p.act == 1) {
@@ -150,31 +170,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
             const int wcol = c / WN, cc = c - wcol * WN;      // waves (0,wcol) and (1,wcol) own this column
             const float s = red[((0 * 2 + wcol) * WN + cc) * 2 + 0] + red[((1 * 2 + wcol) * WN + cc) * 2 + 0];
             const float q = red[((0 * 2 + wcol) * WN + cc) * 2 + 1] + red[((1 * 2 + wcol) * WN + cc) * 2 + 1];
-            if (n0 + c < g.Co) {
-                p.stats[((long)blockIdx.x * 2 + 0) * g.Co + n0 + c] = s;
-                p.stats[((long)blockIdx.x * 2 + 1) * g.Co + n0 + c] = q;
+            if (n0 + c < p.Co) {
+                p.stats[((long)blockIdx.x * 2 + 0) * p.Co + n0 + c] = s;
+                p.stats[((long)blockIdx.x * 2 + 1) * p.Co + n0 + c] = q;
             }
         }
-    }
-}
-
-// fills sRow (target pixel offsets) and sTap; every thread calls it, followed by a barrier in the caller
-template <int BM>
-__device__ __forceinline__ void igemm_fill_tables(const IgemmGeom& g, long* sRow, int* sTap, int m0) {
-    const int tid = threadIdx.x;
-    for (int r = tid; r < BM; r += 256) {
-        const int m = m0 + r;
-        long off = -1;
-        if (m < g.M) {
-            int n, a, b;
-            decode_pos(g, m, n, a, b);
-            off = (((long)n * g.Ho + (a * g.OS + g.oy0)) * g.Wo + (b * g.OS + g.ox0)) * g.out_pitch;
-        }
-        sRow[r] = off;
-    }
-    if (tid == 0) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { sTap[i] = g.dy[i]; sTap[9 + i] = g.dx[i]; sTap[18 + i] = g.tw[i]; }
     }
 }
 
@@ -216,6 +216,13 @@ __device__ __forceinline__ void wait_tiles_barrier(int later) {
     }
 }
 
+// m -> (image, index inside the class), exact for m < 2^24 rows
+__device__ __forceinline__ void split_row(int m, int P, float inv_p, int& n, int& j) {
+    n = (int)((float)m * inv_p);
+    j = m - n * P;
+    if (j < 0) { n--; j += P; } else if (j >= P) { n++; j -= P; }
+}
+
 template <int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
     constexpr int BK = 64;
@@ -226,69 +233,82 @@ __global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sStage = reinterpret_cast<bf16_t*>(smem_raw);                 // [NS][A | B]
     long* sRow = reinterpret_cast<long*>(sStage + NS * S_ELEMS);
-    int* sTap = reinterpret_cast<int*>(sRow + BM);
+    int* sTap = reinterpret_cast<int*>(sRow + BM);                        // delta[9], tw[9]
 
-    const IgemmGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * BN;
     const int slot = tid & 7, r0 = tid >> 3;                 // lane writes LDS chunk `slot` of row r0 + 32*i ...
     const int csw = slot ^ ((r0 >> 1) & 7);                  // ... which must hold global chunk csw (swizzle on the source)
     const int wrow = __builtin_amdgcn_readfirstlane(wave) * 8;   // first row of this wave's 8-row group
 
-    // Everything that depends on the row is hoisted out of the K loop: a pointer to the row's centre pixel and one validity
-    // bit per tap.  A K step then costs one 64-bit add + one select per DMA (the first version redid the bounds checks and a
-    // 64-bit multiply per DMA per step, which left the MFMA pipe idle behind ~200 VALU instructions per step).
+    // this block's class (wave-uniform scalar loads; tile_begin is ascending)
+    const int ncls = p.plan[0];
+    int cls = 0;
+    for (int c = 1; c < ncls; ++c)
+        if ((int)blockIdx.x >= p.plan[PLAN_HDR_WORDS + c * PLAN_CLS_WORDS + 3]) cls = c;
+    const int* cw = p.plan + PLAN_HDR_WORDS + cls * PLAN_CLS_WORDS;
+    const int ntaps = cw[0], P = cw[1];
+    const int* pos = p.plan + p.plan[1] + 2 * cw[2];
+    const int m0 = ((int)blockIdx.x - cw[3]) * BM;
+    const int Mc = p.Nimg * P;
+    const float inv_p = 1.0f / (float)P;
+    if (tid < 18) sTap[tid] = cw[4 + tid];
+
+    // Everything that depends on the row is hoisted out of the K loop: a pointer to the row's centre pixel (rows beyond the
+    // class read the zero page for every tap).  A K step then costs one 64-bit add per DMA.
+    const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_page) + slot * 8;
     const bf16_t* a_ptr[AR];
-    unsigned a_mask[AR];           // bit t: tap t of this row reads inside the grid
+    unsigned a_ok = 0;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + r0 + 32 * i;
-        const bool ok = m < g.M;
-        int n, a, b;
-        decode_pos(g, ok ? m : 0, n, a, b);
-        const int y = a * g.S, x = b * g.S;
-        a_ptr[i] = p.in + (((long)n * g.Hi + y) * g.Wi + x) * g.in_pitch + csw * 8;
-        unsigned mk = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = y + g.dy[t], ix = x + g.dx[t];
-            mk |= ((ok && t < g.ntaps && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi) ? 1u : 0u) << t;
-        }
-        a_mask[i] = mk;
+        const bool ok = m < Mc;
+        int n, j;
+        split_row(ok ? m : 0, P, inv_p, n, j);
+        a_ptr[i] = p.in + ((long)n * p.in_pix + pos[2 * j]) * p.in_pitch + csw * 8;
+        a_ok |= (ok ? 1u : 0u) << i;
     }
-    const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_page) + slot * 8;
     const bf16_t* b_ptr[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
         const int n = n0 + r0 + 32 * i;
-        b_ptr[i] = n < g.Co ? p.wt + (long)n * g.wt_taps * g.Ci + csw * 8 : nullptr;
+        b_ptr[i] = n < p.Co ? p.wt + (long)n * p.wt_taps * p.Ci + csw * 8 : nullptr;
     }
-    igemm_fill_tables<BM>(g, sRow, sTap, m0);
+    for (int r = tid; r < BM; r += 256) {          // target pixel offsets for the epilogue
+        const int m = m0 + r;
+        long off = -1;
+        if (m < Mc) {
+            int n, j;
+            split_row(m, P, inv_p, n, j);
+            off = ((long)n * p.out_pix + pos[2 * j + 1]) * p.out_pitch;
+        }
+        sRow[r] = off;
+    }
     __syncthreads();
 
-    const int KT = g.ntaps * (g.Ci / BK);
+    const int KT = ntaps * (p.Ci / BK);
     int t_next = 0, c_next = 0;
     auto stage = [&](int buf) {
-        const int t = t_next, tw = sTap[18 + t_next];
+        const int tw = sTap[9 + t_next];
         const int c0 = c_next;
-        const long a_off = (long)(sTap[t] * g.Wi + sTap[9 + t]) * g.in_pitch + c0;     // wave-uniform
+        const long a_off = (long)sTap[t_next] * p.in_pitch + c0;     // wave-uniform
         bf16_t* dstA = sStage + buf * S_ELEMS + wrow * 64;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const bf16_t* src = ((a_mask[i] >> t) & 1u) ? a_ptr[i] + a_off : zero_src;
+            const bf16_t* src = ((a_ok >> i) & 1u) ? a_ptr[i] + a_off : zero_src;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dstA + i * 32 * 64), 16, 0, 0);
         }
         bf16_t* dstB = sStage + buf * S_ELEMS + A_ELEMS + wrow * 64;
 #pragma unroll
         for (int i = 0; i < BR; ++i) {
-            const bf16_t* src = b_ptr[i] != nullptr ? b_ptr[i] + (long)tw * g.Ci + c0 : zero_src;
+            const bf16_t* src = b_ptr[i] != nullptr ? b_ptr[i] + (long)tw * p.Ci + c0 : zero_src;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dstB + i * 32 * 64), 16, 0, 0);
         }
         c_next += BK;
-        if (c_next >= g.Ci) { c_next = 0; ++t_next; }
+        if (c_next >= p.Ci) { c_next = 0; ++t_next; }
     };
 
     f32x16 acc[TM][TN];
@@ -335,9 +355,9 @@ static int launch_glds(const IgemmFwdArgs& a, int gx, int gy, hipStream_t stream
 // Tile / ring-depth choice.  One K step of a block costs max(MFMA time, LDS-DMA issue + round trip / tiles in flight):
 // with at least ~2 blocks per CU a shallow ring and several co-resident blocks is best.  Stage counts: 128x128 -> 2,
 // 128x64 -> 3 (2 for the few-tile convolutions), 64x64 -> 4 (3 if many blocks).
-struct IgemmFwdPlan { int bm, bn, ns, gx, gy; };
+struct IgemmFwdPlan { int bm, bn, ns, gy; };
 
-static IgemmFwdPlan igemm_fwd_plan(int M, int Co, int ntaps) {
+static IgemmFwdPlan igemm_fwd_plan(long M, int Co, int max_taps) {
     static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
     IgemmFwdPlan pl;
     const int forced = svsr_tune_get(SVSR_TUNE_IGEMM_TILE);            // 0 auto, 64 / 128 forced
@@ -347,46 +367,163 @@ static IgemmFwdPlan igemm_fwd_plan(int M, int Co, int ntaps) {
     else if (Co <= 64) bm = M >= 16384 ? 128 : 64;
     else {
         // 128x128 tiles once they still give ~a block per CU (LRS linears at 2,400 rows: qkv/ffn1/heads yes, 768-wide outputs no)
-        const long blocks128 = (long)((M + 127) / 128) * ((Co + 127) / 128);
+        const long blocks128 = ((M + 127) / 128) * ((Co + 127) / 128);
         bm = (M >= thr || blocks128 >= 224) ? 128 : 64;
     }
     // few-tile convolutions (LRW layer4: 66 x 4 tiles of 128x128 = about one workgroup per CU): 128x64 tiles with a 2-deep ring
     // fit three workgroups per CU and measure 82 -> 77 us; with more tiles the 128x128 shape wins (layer2 61 vs 66 us)
-    if (bm == 128 && Co > 64 && ntaps > 1 && (long)((M + 127) / 128) * ((Co + 127) / 128) < 300) { pl.bm = 128; pl.bn = 64; pl.ns = 2; }
+    if (bm == 128 && Co > 64 && max_taps > 1 && ((M + 127) / 128) * ((Co + 127) / 128) < 300) { pl.bm = 128; pl.bn = 64; pl.ns = 2; }
     else if (bm == 128 && Co <= 64) { pl.bm = 128; pl.bn = 64; pl.ns = 3; }
     else if (bm == 128) { pl.bm = 128; pl.bn = 128; pl.ns = 2; }
     else { pl.bm = 64; pl.bn = 64; pl.ns = 0; }
-    pl.gx = (M + pl.bm - 1) / pl.bm; pl.gy = (Co + pl.bn - 1) / pl.bn;
-    if (pl.ns == 0) pl.ns = (long)pl.gx * pl.gy <= (long)cus * 5 / 2 ? 4 : 3;
+    pl.gy = (Co + pl.bn - 1) / pl.bn;
+    if (pl.ns == 0) pl.ns = ((M + pl.bm - 1) / pl.bm) * pl.gy <= (long)cus * 5 / 2 ? 4 : 3;
     return pl;
 }
 
-/* svsr_igemm_fwd_plan: which kernel instantiation svsr_igemm_fwd launches for (M positions, Co outputs, ntaps) — tile
- * BM x BN, ring depth NS — and how many rows of [2][Co] BatchNorm partials it writes when `stats` is given (= M tiles). */
-extern "C" int svsr_igemm_fwd_plan(int M, int Co, int ntaps, int* bm, int* bn, int* ns, int* stat_rows) {
-    if (M <= 0 || Co <= 0 || ntaps < 1) return SVSR_ERR_ARG;
-    const IgemmFwdPlan pl = igemm_fwd_plan(M, Co, ntaps);
-    if (bm) *bm = pl.bm;
-    if (bn) *bn = pl.bn;
-    if (ns) *ns = pl.ns;
-    if (stat_rows) *stat_rows = pl.gx;
-    return SVSR_OK;
+// ---- host-side plan builder ------------------------------------------------------------------------------------------
+struct PlanClass { int ntaps; int delta[9], tw[9]; std::vector<int> pos; };     // pos: (src, dst) pairs
+
+// meta: {bm, bn, ns, tiles (= grid.x = BatchNorm partial rows), grid.y, classes, max taps of a class, total rows / 2^0 (low 31 bits)}
+static int plan_emit(std::vector<PlanClass>& cls, int Nimg, int Co, int* words, int cap_words, int* meta) {
+    std::stable_sort(cls.begin(), cls.end(), [](const PlanClass& a, const PlanClass& b) { return a.ntaps > b.ntaps; });
+    long M = 0;
+    int max_taps = 0;
+    for (const PlanClass& c : cls) { M += (long)Nimg * (long)(c.pos.size() / 2); if (c.ntaps > max_taps) max_taps = c.ntaps; }
+    if (M >= (1L << 24) * 64 || cls.empty()) return -SVSR_ERR_ARG;
+    const IgemmFwdPlan pl = igemm_fwd_plan(M, Co, max_taps);
+    const int ncls = (int)cls.size();
+    int nwords = PLAN_HDR_WORDS + ncls * PLAN_CLS_WORDS;
+    const int pos_word0 = nwords;
+    for (const PlanClass& c : cls) nwords += (int)c.pos.size();
+    long tiles = 0;
+    if (words != nullptr) {
+        if (cap_words < nwords) return -SVSR_ERR_ARG;
+        words[0] = ncls; words[1] = pos_word0;
+        int pos_off = 0;
+        for (int i = 0; i < ncls; ++i) {
+            const PlanClass& c = cls[i];
+            int* w = words + PLAN_HDR_WORDS + i * PLAN_CLS_WORDS;
+            const int P = (int)(c.pos.size() / 2);
+            if ((long)Nimg * P >= (1L << 24)) return -SVSR_ERR_ARG;          // split_row's float reciprocal is exact below 2^24 rows
+            w[0] = c.ntaps; w[1] = P; w[2] = pos_off; w[3] = (int)tiles;
+            for (int t = 0; t < 9; ++t) { w[4 + t] = t < c.ntaps ? c.delta[t] : 0; w[13 + t] = t < c.ntaps ? c.tw[t] : 0; }
+            w[22] = 0; w[23] = 0;
+            std::copy(c.pos.begin(), c.pos.end(), words + pos_word0 + 2 * pos_off);
+            pos_off += P;
+            tiles += ((long)Nimg * P + pl.bm - 1) / pl.bm;
+        }
+    } else {
+        for (const PlanClass& c : cls) tiles += ((long)Nimg * (long)(c.pos.size() / 2) + pl.bm - 1) / pl.bm;
+    }
+    if (tiles > 0x7fffffffL) return -SVSR_ERR_ARG;
+    if (meta != nullptr) {
+        meta[0] = pl.bm; meta[1] = pl.bn; meta[2] = pl.ns; meta[3] = (int)tiles; meta[4] = pl.gy; meta[5] = ncls; meta[6] = max_taps;
+        meta[7] = (int)(M & 0x7fffffff);
+    }
+    return nwords;
 }
 
+/* svsr_conv_plan (host): launch plan of a k x k / stride / pad convolution over Nimg images whose FORWARD input is H x W.
+ *   mode 0: forward        in = x  [H][W],   out = y  [Ho][Wo]      (weights [Co][k*k][Ci])
+ *   mode 1: data gradient  in = dy [Ho][Wo], out = dx [H][W]        (transposed weights [Ci][k*k][Co]); every pixel of dx is
+ *           written, also those no tap reaches (k < stride): they get 0 (+ bias / addend)
+ *   mode 2: as mode 1 for an IN-PLACE accumulation (addend aliases out): pixels no tap reaches are left alone
+ * Co_out = output channels of the launch (tile choice).  words == null: only counts.  Returns the number of int32 words, or a
+ * negative error.  meta[8] = {bm, bn, ns, tiles, grid_y, classes, max taps, rows}. */
+extern "C" int svsr_conv_plan(int mode, int Nimg, int H, int W, int Co_out, int k, int stride, int pad, int* words, int cap_words, int* meta) {
+    if (Nimg < 1 || H < 1 || W < 1 || k < 1 || k > 3 || stride < 1 || pad < 0 || Co_out < 1 || mode < 0 || mode > 2) return -SVSR_ERR_ARG;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    if (Ho < 1 || Wo < 1) return -SVSR_ERR_ARG;
+    std::vector<PlanClass> cls;
+    std::map<std::vector<int>, int> index;      // key: the tap list (delta, tw)* of a position -> class
+    auto add = [&](const std::vector<int>& key, int src, int dst) {
+        auto it = index.find(key);
+        if (it == index.end()) {
+            PlanClass c;
+            c.ntaps = (int)(key.size() / 2);
+            for (int t = 0; t < c.ntaps; ++t) { c.delta[t] = key[2 * t]; c.tw[t] = key[2 * t + 1]; }
+            cls.push_back(c);
+            it = index.emplace(key, (int)cls.size() - 1).first;
+        }
+        cls[it->second].pos.push_back(src);
+        cls[it->second].pos.push_back(dst);
+    };
+    std::vector<int> key;
+    if (mode == 0) {
+        for (int a = 0; a < Ho; ++a)
+            for (int b = 0; b < Wo; ++b) {
+                key.clear();
+                for (int kh = 0; kh < k; ++kh)
+                    for (int kw = 0; kw < k; ++kw) {
+                        const int iy = a * stride + kh - pad, ix = b * stride + kw - pad;
+                        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                        key.push_back((kh - pad) * W + (kw - pad));
+                        key.push_back(kh * k + kw);
+                    }
+                // centre pixel (a*stride, b*stride) may itself lie outside the grid only through the taps; deltas are relative to it
+                add(key, (a * stride) * W + b * stride, a * Wo + b);
+            }
+    } else {
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                key.clear();
+                const int a = y / stride, b = x / stride, py = y % stride, px = x % stride;
+                for (int kh = 0; kh < k; ++kh) {
+                    if ((py + pad - kh) % stride) continue;
+                    for (int kw = 0; kw < k; ++kw) {
+                        if ((px + pad - kw) % stride) continue;
+                        // floor division: (py + pad - kh) may be negative but is a multiple of stride
+                        const int dq = (py + pad - kh) / stride, dp = (px + pad - kw) / stride;
+                        const int oy = a + dq, ox = b + dp;
+                        if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
+                        key.push_back(dq * Wo + dp);
+                        key.push_back(kh * k + kw);
+                    }
+                }
+                // the centre (a, b) of dy may lie outside its grid (odd H with stride 2): clamp it and fold the shift into nothing —
+                // positions whose centre is out of range get their own key via the deltas being relative to the clamped centre
+                int ca = a < Ho ? a : Ho - 1, cb = b < Wo ? b : Wo - 1;
+                if (ca != a || cb != b) {
+                    const int shift = (a - ca) * Wo + (b - cb);
+                    for (size_t t = 0; t < key.size(); t += 2) key[t] += shift;
+                }
+                if (mode == 2 && key.empty()) continue;
+                add(key, ca * Wo + cb, y * W + x);
+            }
+    }
+    return plan_emit(cls, Nimg, Co_out, words, cap_words, meta);
+}
+
+/* svsr_rows_plan (host): plan of a dense layer over rows grouped in Nimg sequences: row (n, j), j < P, reads source row
+ * n * in_pix + src0 + j and writes target row n * out_pix + dst0 + j (one tap).  A plain linear layer is P = 1, src0 = dst0 = 0
+ * with in_pix = out_pix = 1; picking / scattering a slice of every sequence uses P = slice length. */
+extern "C" int svsr_rows_plan(int Nimg, int P, int src0, int dst0, int Co_out, int* words, int cap_words, int* meta) {
+    if (Nimg < 1 || P < 1 || Co_out < 1) return -SVSR_ERR_ARG;
+    std::vector<PlanClass> cls(1);
+    cls[0].ntaps = 1; cls[0].delta[0] = 0; cls[0].tw[0] = 0;
+    cls[0].pos.reserve(2 * (size_t)P);
+    for (int j = 0; j < P; ++j) { cls[0].pos.push_back(src0 + j); cls[0].pos.push_back(dst0 + j); }
+    return plan_emit(cls, Nimg, Co_out, words, cap_words, meta);
+}
+
+/* svsr_igemm_fwd: runs a plan.  plan_dev = device copy of the words, meta = the host meta[8] svsr_*_plan returned with them. */
 extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend,
-                              float* stats, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch,
-                              int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx,
-                              const int* tw, int act, int out_f32, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p,
-                              hipStream_t stream) {
-    IgemmFwdArgs a;
-    int rc = fill_geom(a.g, Nimg, Hi, Wi, Ci, in_pitch, Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, ntaps, wt_taps, dy, dx, tw);
-    if (rc != SVSR_OK) return rc;
-    a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = out; a.out_pre = (bf16_t*)out_pre;
-    a.bias = bias; a.addend = (const bf16_t*)addend; a.stats = stats; a.act = act; a.out_f32 = out_f32; a.alpha = alpha;
+                              float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co,
+                              int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed,
+                              unsigned drop_site, float drop_p, hipStream_t stream) {
+    if (plan_dev == nullptr || meta == nullptr || Ci % 64 != 0 || Ci <= 0 || Co <= 0 || in_pitch % 8 != 0 || Nimg <= 0 || wt_taps < 1)
+        return SVSR_ERR_ARG;
     if (act != 0 && (addend != nullptr || alpha != 1.f)) return SVSR_ERR_ARG;     // the activation is applied before alpha / addend
+    IgemmFwdArgs a;
+    a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = out; a.out_pre = (bf16_t*)out_pre;
+    a.bias = bias; a.addend = (const bf16_t*)addend; a.stats = stats; a.plan = plan_dev;
+    a.Nimg = Nimg; a.in_pix = in_pix; a.Ci = Ci; a.in_pitch = in_pitch; a.Co = Co; a.out_pix = out_pix; a.out_pitch = out_pitch;
+    a.wt_taps = wt_taps; a.act = act; a.out_f32 = out_f32; a.alpha = alpha;
     a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
-    const IgemmFwdPlan pl = igemm_fwd_plan(a.g.M, Co, ntaps);
-#define SVSR_IGEMM_CASE(BM_, BN_, NS_) if (pl.bm == BM_ && pl.bn == BN_ && pl.ns == NS_) return launch_glds<BM_, BN_, NS_>(a, pl.gx, pl.gy, stream)
+    const int bm = meta[0], bn = meta[1], ns = meta[2], gx = meta[3], gy = (Co + bn - 1) / bn;
+    if (gx < 1) return SVSR_ERR_ARG;
+#define SVSR_IGEMM_CASE(BM_, BN_, NS_) if (bm == BM_ && bn == BN_ && ns == NS_) return launch_glds<BM_, BN_, NS_>(a, gx, gy, stream)
     SVSR_IGEMM_CASE(128, 128, 2);
     SVSR_IGEMM_CASE(128, 64, 2);
     SVSR_IGEMM_CASE(128, 64, 3);

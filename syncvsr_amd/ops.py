@@ -74,7 +74,7 @@ def _query(name: str, *args) -> tuple:
     if name.endswith("_rows"):
         out = (int(fn(*args)),)
     else:
-        nout = {"svsr_igemm_fwd_plan": (4, 0), "svsr_igemm_wgrad_plan": (2, 1), "svsr_conv3x3_wgrad_plan": (1, 1),
+        nout = {"svsr_igemm_wgrad_plan": (2, 1), "svsr_conv3x3_wgrad_plan": (1, 1),
                 "svsr_stem_conv_wgrad_plan": (1, 1)}[name]
         ints = [ctypes.c_int(0) for _ in range(nout[0])]
         longs = [ctypes.c_int64(0) for _ in range(nout[1])]
@@ -140,14 +140,41 @@ def _call(name: str, *args, label: Optional[str] = None, flops: float = 0.0, nby
         _lib.check(rc, name)
 
 
-def igemm_fwd_tile(M: int, Co: int, ntaps: int = 1) -> tuple[int, int, int]:
-    """(BM, BN, ring depth) of the k_igemm_fwd_glds instantiation svsr_igemm_fwd launches for this shape — asked from the
-    library itself (svsr_igemm_fwd_plan), so labels and tests cannot drift from the launch logic."""
-    return _query("svsr_igemm_fwd_plan", int(M), int(Co), int(ntaps))[:3]
+class Plan:
+    """Launch plan of svsr_igemm_fwd for one shape: device copy of the plan words + the host meta record."""
+    __slots__ = ("words", "meta", "bm", "bn", "ns", "tiles", "label")
+
+    def __init__(self, builder: str, *args):
+        fn = getattr(_lib.load(), builder)
+        meta = (ctypes.c_int * 8)()
+        n = fn(*args, None, 0, meta)
+        if n <= 0:
+            _lib.check(-n if n < 0 else 1001, builder)
+        host = torch.empty(n, dtype=torch.int32)
+        n2 = fn(*args, host.data_ptr(), n, meta)
+        if n2 != n:
+            _lib.check(1001, builder)
+        self.words = host.to("cuda")
+        self.meta = meta
+        self.bm, self.bn, self.ns, self.tiles = int(meta[0]), int(meta[1]), int(meta[2]), int(meta[3])
+        self.label = f"k_igemm_fwd_glds<{self.bm},{self.bn},{self.ns}>"
 
 
-def igemm_fwd_stat_rows(M: int, Co: int, ntaps: int) -> int:
-    return _query("svsr_igemm_fwd_plan", int(M), int(Co), int(ntaps))[3]
+def conv_plan(mode: int, N: int, H: int, W: int, Co_out: int, k: int, stride: int, pad: int) -> Plan:
+    """mode 0: forward convolution of N images [H, W]; mode 1: its input-gradient (svsr_conv_plan)."""
+    key = ("conv", mode, N, H, W, Co_out, k, stride, pad)
+    pl = _PLAN_CACHE.get(key)
+    if pl is None:
+        pl = _PLAN_CACHE[key] = Plan("svsr_conv_plan", mode, N, H, W, Co_out, k, stride, pad)
+    return pl
+
+
+def rows_plan(Nimg: int, P: int, src0: int, dst0: int, Co_out: int) -> Plan:
+    key = ("rows", Nimg, P, src0, dst0, Co_out)
+    pl = _PLAN_CACHE.get(key)
+    if pl is None:
+        pl = _PLAN_CACHE[key] = Plan("svsr_rows_plan", Nimg, P, src0, dst0, Co_out)
+    return pl
 
 
 def wgrad_plan(M: int, Co: int, Ci: int, ntaps: int, wt_taps: int, has_bias: bool) -> tuple[int, int, int]:
@@ -158,26 +185,19 @@ def wgrad_plan(M: int, Co: int, Ci: int, ntaps: int, wt_taps: int, has_bias: boo
 # --------------------------------------------------------------------------------------------------
 # implicit GEMM
 # --------------------------------------------------------------------------------------------------
-def igemm_fwd(inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
-              Co: int, Ho: int, Wo: int, out_pitch: int, Ha: int, Wa: int, S: int = 1, OS: int = 1, oy0: int = 0, ox0: int = 0,
-              taps: Sequence[tuple[int, int, int]] = ((0, 0, 0),), wt_taps: int = 1, bias: Optional[torch.Tensor] = None,
+def igemm_fwd(plan: Plan, inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, Nimg: int, in_pix: int, Ci: int, in_pitch: int,
+              Co: int, out_pix: int, out_pitch: int, wt_taps: int = 1, bias: Optional[torch.Tensor] = None,
               addend: Optional[torch.Tensor] = None, want_stats: bool = False, gelu: bool = False,
-              out_pre: Optional[torch.Tensor] = None, out_f32: bool = False, relu: bool = False, alpha: float = 1.0, drop=None):
-    """-> None, or with want_stats the BatchNorm partials (buffer, rows) for bn_finalize."""
-    dy, dx, tw = zip(*taps)
-    M = Nimg * Ha * Wa
+              out_pre: Optional[torch.Tensor] = None, out_f32: bool = False, relu: bool = False, alpha: float = 1.0, drop=None,
+              flops: float = 0.0):
+    """Runs a plan.  -> None, or with want_stats the BatchNorm partials (buffer, rows) for bn_finalize."""
     stats = st = None
     if want_stats:
-        rows = igemm_fwd_stat_rows(M, Co, len(taps))
-        stats = scratch(rows * 2 * Co)
-        st = (stats, rows)
-    label = None
-    if _TIMING is not None:
-        bm, bn, ns = igemm_fwd_tile(M, Co, len(taps))
-        label = f"k_igemm_fwd_glds<{bm},{bn},{ns}>"
-    _call("svsr_igemm_fwd", _p(inp), _p(wt), _p(out), _p(out_pre), _p(bias), _p(addend), _p(stats), Nimg, Hi, Wi, Ci, in_pitch,
-          Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw),
-          1 if gelu else (2 if relu else 0), int(out_f32), float(alpha), *_drop(drop), _stream(), label=label, flops=2.0 * M * Co * Ci * len(taps))
+        stats = scratch(plan.tiles * 2 * Co)
+        st = (stats, plan.tiles)
+    _call("svsr_igemm_fwd", _p(inp), _p(wt), _p(out), _p(out_pre), _p(bias), _p(addend), _p(stats), plan.words.data_ptr(), plan.meta,
+          Nimg, in_pix, Ci, in_pitch, Co, out_pix, out_pitch, wt_taps, 1 if gelu else (2 if relu else 0), int(out_f32), float(alpha),
+          *_drop(drop), _stream(), label=plan.label, flops=flops)
     return st
 
 
@@ -205,11 +225,10 @@ def conv2d_fwd(x: torch.Tensor, w16: torch.Tensor, k: int, stride: int, pad: int
     Co = w16.shape[0]
     Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
     out = torch.empty((N, Ho, Wo, Co), dtype=BF16, device=x.device)
-    taps = _conv_taps(k, pad)
     if _c64_ok(Ci, Co, k, stride, pad, W):
-        return out, conv3x3_c64(x, w16, out, None, want_stats, taps)
-    st = igemm_fwd(x, w16, out, Nimg=N, Hi=H, Wi=W, Ci=Ci, in_pitch=Ci, Co=Co, Ho=Ho, Wo=Wo, out_pitch=Co, Ha=Ho, Wa=Wo,
-                   S=stride, taps=taps, wt_taps=k * k, want_stats=want_stats)
+        return out, conv3x3_c64(x, w16, out, None, want_stats, _conv_taps(k, pad))
+    st = igemm_fwd(conv_plan(0, N, H, W, Co, k, stride, pad), x, w16, out, Nimg=N, in_pix=H * W, Ci=Ci, in_pitch=Ci, Co=Co,
+                   out_pix=Ho * Wo, out_pitch=Co, wt_taps=k * k, want_stats=want_stats, flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
     return out, st
 
 
@@ -246,44 +265,20 @@ def conv3x3_c64(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, addend: Op
 
 def conv2d_dgrad(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad: int, in_hw: tuple[int, int],
                  addend: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dy [N,Ho,Wo,Co], w16t bf16 [Ci][k][k][Co] (transposed shadow) -> dx [N,H,W,Ci] (+ addend).
+    """dy [N,Ho,Wo,Co], w16t bf16 [Ci][k][k][Co] (transposed shadow) -> dx [N,H,W,Ci] (+ addend, in place when given).
 
-    Stride 1 is one launch; stride 2 is one launch per input-parity class with that class's taps
-    (the transposed convolution never multiplies by the inserted zeros)."""
+    One launch for any stride: the plan's classes cover the output-parity classes of a strided convolution with their own
+    taps (the transposed convolution never multiplies by the inserted zeros), and pixels no tap reaches are written as 0."""
     N, Ho, Wo, Co = dy.shape
     Ci = w16t.shape[0]
     H, W = in_hw
-    dx = None
-    classes = [(py, px) for py in range(stride) for px in range(stride)]
-    plans = []
-    for py, px in classes:
-        taps = []
-        for kh in range(k):
-            if (py + pad - kh) % stride:
-                continue
-            for kw in range(k):
-                if (px + pad - kw) % stride:
-                    continue
-                taps.append(((py + pad - kh) // stride, (px + pad - kw) // stride, kh * k + kw))
-        plans.append((py, px, taps))
-    full = all(len(t) > 0 for _, _, t in plans)
-    if full or addend is not None:
-        dx = torch.empty((N, H, W, Ci), dtype=BF16, device=dy.device) if addend is None else addend
-    else:
-        dx = torch.zeros((N, H, W, Ci), dtype=BF16, device=dy.device)
-    if addend is not None and not full:
-        pass  # classes without taps keep the addend's values (dx aliases addend)
+    dx = torch.empty((N, H, W, Ci), dtype=BF16, device=dy.device) if addend is None else addend
     if stride == 1 and _c64_ok(Ci, Co, k, stride, pad, W):
-        conv3x3_c64(dy, w16t, dx, addend, False, plans[0][2])
+        taps = tuple((pad - kh, pad - kw, kh * k + kw) for kh in range(k) for kw in range(k))
+        conv3x3_c64(dy, w16t, dx, addend, False, taps)
         return dx
-    for py, px, taps in plans:
-        if not taps:
-            continue
-        Ha, Wa =(H - py + stride - 1) // stride, (W - px + stride - 1) // stride
-        if Ha <= 0 or Wa <= 0:
-            continue
-        igemm_fwd(dy, w16t, dx, Nimg=N, Hi=Ho, Wi=Wo, Ci=Co, in_pitch=Co, Co=Ci, Ho=H, Wo=W, out_pitch=Ci, Ha=Ha, Wa=Wa,
-                  S=1, OS=stride, oy0=py, ox0=px, taps=taps, wt_taps=k * k, addend=addend)
+    igemm_fwd(conv_plan(1 if addend is None else 2, N, H, W, Ci, k, stride, pad), dy, w16t, dx, Nimg=N, in_pix=Ho * Wo, Ci=Co, in_pitch=Co, Co=Ci, out_pix=H * W,
+              out_pitch=Ci, wt_taps=k * k, addend=addend, flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
     return dx
 
 
@@ -315,12 +310,12 @@ def linear_fwd(x: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor],
         out = torch.empty((rows, out_pitch), dtype=torch.float32 if out_f32 else BF16, device=x.device)
     pre = torch.empty_like(out) if gelu else None
     if seq is None:
-        geo = dict(Nimg=rows, Hi=1, Wi=1, Ha=1, Wa=1, Ho=1, Wo=1, taps=((0, 0, 0),))
+        plan, geo = rows_plan(rows, 1, 0, 0, N), dict(Nimg=rows, in_pix=1, out_pix=1)
     else:
         S, s0, n = seq
-        geo = dict(Nimg=rows // n, Hi=1, Wi=S, Ha=1, Wa=n, Ho=1, Wo=n, taps=((0, s0, 0),))
-    igemm_fwd(x, w16, out, Ci=K, in_pitch=x_pitch, Co=N, out_pitch=out_pitch, bias=bias, addend=addend, gelu=gelu, out_pre=pre,
-              out_f32=out_f32, relu=relu, alpha=alpha, drop=drop, **geo)
+        plan, geo = rows_plan(rows // n, n, s0, 0, N), dict(Nimg=rows // n, in_pix=S, out_pix=n)
+    igemm_fwd(plan, x, w16, out, Ci=K, in_pitch=x_pitch, Co=N, out_pitch=out_pitch, bias=bias, addend=addend, gelu=gelu, out_pre=pre,
+              out_f32=out_f32, relu=relu, alpha=alpha, drop=drop, flops=2.0 * rows * N * K, **geo)
     return out, pre
 
 
@@ -333,12 +328,13 @@ def linear_dgrad(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, K: 
     if seq is None:
         if out is None:
             out = torch.empty((rows, K), dtype=BF16, device=dy.device)
-        geo = dict(Nimg=rows, Hi=1, Wi=1, Ha=1, Wa=1, Ho=1, Wo=1, ox0=0)
+        plan, geo = rows_plan(rows, 1, 0, 0, K), dict(Nimg=rows, in_pix=1, out_pix=1)
     else:
         S, s0, n = seq
         assert out is not None
-        geo = dict(Nimg=rows // n, Hi=1, Wi=n, Ha=1, Wa=n, Ho=1, Wo=S, ox0=s0)
-    igemm_fwd(dy, w16t, out, Ci=Np, in_pitch=dy_pitch, Co=K, out_pitch=K, addend=addend, alpha=alpha, drop=drop, **geo)
+        plan, geo = rows_plan(rows // n, n, 0, s0, K), dict(Nimg=rows // n, in_pix=n, out_pix=S)
+    igemm_fwd(plan, dy, w16t, out, Ci=Np, in_pitch=dy_pitch, Co=K, out_pitch=K, addend=addend, alpha=alpha, drop=drop,
+              flops=2.0 * rows * N * K, **geo)
     return out
 
 

@@ -1,7 +1,7 @@
 """Kernel parity AT THE BENCHMARK SHAPES (-m gpu): every contraction launch of the B = 32 LRW step (928 frames; BASELINE.json
 configs[1]) and the large LRS linears (2,400 rows), each against torch fp32 on the same bf16-rounded operands.
 
-bench.py's kernel instantiations are chosen from the problem shape (svsr_igemm_fwd_plan / svsr_igemm_wgrad_plan), so running
+bench.py's kernel instantiations are chosen from the problem shape (svsr_conv_plan / svsr_rows_plan / svsr_igemm_wgrad_plan), so running
 the benchmark's own shapes here runs the benchmark's own instantiations; each test also asks the library which instantiation it
 launched, asserts the ones the step is known to depend on and records all of them in gpurun_out/bench_shape_instantiations.json
 so that coverage cannot silently move when the launch heuristics change.  Tolerances are those of tests/test_gpu_kernels.py.
@@ -81,9 +81,6 @@ EXPECT_FWD = {
 }
 
 
-def _fwd_label(ops, M, Co, ntaps):
-    bm, bn, ns = ops.igemm_fwd_tile(M, Co, ntaps)
-    return f"k_igemm_fwd_glds<{bm},{bn},{ns}>"
 
 
 @pytest.mark.parametrize("name", list(TRUNK))
@@ -100,7 +97,7 @@ def test_trunk_conv_fwd_dgrad_wgrad_at_928_frames(dev, name):
     # ---- forward + BatchNorm partial sums --------------------------------------------------------------------------
     out, stats = ops.conv2d_fwd(xd, wd, k, s, p, want_stats=True)
     c64 = ops._c64_ok(Ci, Co, k, s, p, W)
-    _SEEN[f"{name}.fwd"] = "k_conv3x3_c64" if c64 else _fwd_label(ops, N * Ho * Wo, Co, k * k)
+    _SEEN[f"{name}.fwd"] = "k_conv3x3_c64" if c64 else ops.conv_plan(0, N, H, W, Co, k, s, p).label
     if name in EXPECT_FWD:
         assert _SEEN[f"{name}.fwd"] == EXPECT_FWD[name], _SEEN[f"{name}.fwd"]
     ref = F.conv2d(nchw(x.float()), wf, stride=s, padding=p)
@@ -119,18 +116,10 @@ def test_trunk_conv_fwd_dgrad_wgrad_at_928_frames(dev, name):
     F.conv2d(xs, w2.float().permute(0, 3, 1, 2), stride=s, padding=p).backward(nchw(dy.float()))
     add = rnd((N, H, W, Ci), 5)
     dx = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), k, s, p, (H, W), addend=add.to(dev).clone())
-    labels = []
-    if c64:
-        labels.append("k_conv3x3_c64")
-    else:
-        for py in range(s):
-            for px in range(s):
-                nt = sum(1 for kh in range(k) for kw in range(k) if (py + p - kh) % s == 0 and (px + p - kw) % s == 0)
-                Ha, Wa = (H - py + s - 1) // s, (W - px + s - 1) // s
-                if nt and Ha > 0 and Wa > 0:
-                    labels.append(_fwd_label(ops, N * Ha * Wa, Ci, nt))
-    _SEEN[f"{name}.dgrad"] = sorted(set(labels))
+    _SEEN[f"{name}.dgrad"] = "k_conv3x3_c64" if c64 else ops.conv_plan(2, N, H, W, Ci, k, s, p).label
     check(dx, nhwc(xs.grad) + add.float(), f"{name}.dgrad+addend")
+    dx0 = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), k, s, p, (H, W))          # without addend: untouched pixels (k < stride) are zeros
+    check(dx0, nhwc(xs.grad), f"{name}.dgrad")
     # ---- weight gradient ------------------------------------------------------------------------------------------
     ws = torch.zeros(Co, Ci, k, k, requires_grad=True)
     F.conv2d(nchw(x.float()), ws, stride=s, padding=p).backward(nchw(dy.float()))
@@ -154,9 +143,10 @@ def test_benchmark_instantiations_cover_the_big_tiles(dev):
     <128,128,2>, layer4 on <128,64,2>, the generic weight gradient on 128-wide tiles."""
     from syncvsr_amd import ops
 
-    assert ops.igemm_fwd_tile(N_FRAMES * 121, 128, 9) == (128, 128, 2)
-    assert ops.igemm_fwd_tile(N_FRAMES * 36, 256, 9) == (128, 128, 2)
-    assert ops.igemm_fwd_tile(N_FRAMES * 9, 512, 9) == (128, 64, 2)
+    assert ops.conv_plan(0, N_FRAMES, 11, 11, 128, 3, 1, 1).label == "k_igemm_fwd_glds<128,128,2>"
+    assert ops.conv_plan(0, N_FRAMES, 6, 6, 256, 3, 1, 1).label == "k_igemm_fwd_glds<128,128,2>"
+    assert ops.conv_plan(2, N_FRAMES, 6, 6, 256, 3, 1, 1).label == "k_igemm_fwd_glds<128,128,2>"
+    assert ops.conv_plan(0, N_FRAMES, 3, 3, 512, 3, 1, 1).label == "k_igemm_fwd_glds<128,64,2>"
     assert ops.wgrad_plan(N_FRAMES * 36, 256, 256, 9, 9, False)[0] == 128
     assert ops.wgrad_plan(N_FRAMES * 9, 512, 512, 9, 9, False)[0] == 128
 
@@ -179,7 +169,7 @@ def test_linear_fwd_dgrad_wgrad_at_benchmark_rows(dev, rows, K, N, gelu, bias):
     ref = F.linear(x.float(), w.float(), b)
     Np = (N + 7) // 8 * 8
     out, pre = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), rows=rows, K=K, N=N, x_pitch=K, out_pitch=Np, gelu=gelu)
-    _SEEN[f"linear {rows}x{K}->{N}.fwd"] = _fwd_label(ops, rows, N, 1)
+    _SEEN[f"linear {rows}x{K}->{N}.fwd"] = ops.rows_plan(rows, 1, 0, 0, N).label
     if gelu:
         check(pre[:, :N], ref, "linear.pre")
         check(out[:, :N], F.gelu(ref), "linear.gelu")
@@ -194,7 +184,7 @@ def test_linear_fwd_dgrad_wgrad_at_benchmark_rows(dev, rows, K, N, gelu, bias):
     dyp = torch.zeros(rows, Npad, dtype=BF)
     dyp[:, :N] = dy[:, :N]
     dx = ops.linear_dgrad(dyp.to(dev), wt.to(dev), rows=rows, N=N, K=K, dy_pitch=Npad)
-    _SEEN[f"linear {rows}x{K}->{N}.dgrad"] = _fwd_label(ops, rows, K, 1)
+    _SEEN[f"linear {rows}x{K}->{N}.dgrad"] = ops.rows_plan(rows, 1, 0, 0, K).label
     check(dx, dy[:, :N].float() @ w.float(), "linear.dgrad")
     dw = torch.zeros(N, K, device=dev)
     db = torch.zeros(N, device=dev)
