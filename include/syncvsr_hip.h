@@ -74,12 +74,18 @@ int svsr_rows_plan(int Nimg, int P, int src0, int dst0, int Co_out, int* words, 
 int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 
 /* svsr_igemm_wgrad replaces: the weight-gradient of the same Conv2d / Linear layers (torch autograd).
- * dw fp32 [Co][wt_taps][Ci] is ACCUMULATED (dw += ...).  x = forward input pixels, dyp = output-gradient pixels.
- * dbias (optional, fp32 [Co]) += column sums of dyp = the bias gradient of an nn.Linear, taken from tiles the kernel stages anyway.
- * Split-K slabs go to `part` (part_floats >= the value svsr_igemm_wgrad_plan reports for M = Nimg*Ha*Wa; any contents) and are
- * added into dw / dbias in a fixed order. */
-int svsr_igemm_wgrad_plan(int M, int Co, int Ci, int ntaps, int wt_taps, int has_bias, int* bc, int* splits, int64_t* part_floats);
-int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co, int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps, const int* dy, const int* dx, const int* tw, int use_tr, float* dbias, float* part, int64_t part_floats, hipStream_t stream);
+ * dw fp32 [Co][wt_taps][Ci] is ACCUMULATED (dw += ...).  x = forward input pixels [Nimg][in_pix] (pitch in_pitch, Ci channels),
+ * dyp = output-gradient pixels [Nimg][out_pix] (pitch out_pitch, Co channels).  dbias (optional, fp32 [Co]) += column sums of
+ * dyp = the bias gradient of an nn.Linear, from the tiles the kernel stages anyway (one MFMA against a fragment of ones).
+ * Rows come from a host-built plan, per tap the (source pixel, target pixel) pairs whose source lies inside the grid (no products
+ * with the zero padding): svsr_wgrad_plan for a k x k / stride / pad convolution of Nimg images [H][W], svsr_wgrad_rows_plan for
+ * a dense layer over Nimg sequences (row (n, j < P): source row n*in_pix + src0 + j, target row n*out_pix + dst0 + j).  Both
+ * return the number of int32 words (words = null: count only; negative = error), meta[8] = {tile edge, ring depth, K splits,
+ * chunks per split, tasks, taps, max positions per tap} and *part_floats = the workspace svsr_igemm_wgrad needs for its split-K
+ * slabs (any contents; added into dw / dbias in a fixed order; 0 when a single split writes dw directly). */
+int svsr_wgrad_plan(int Nimg, int H, int W, int Ci, int Co, int k, int stride, int pad, int* words, int cap_words, int* meta, int64_t* part_floats);
+int svsr_wgrad_rows_plan(int Nimg, int P, int src0, int dst0, int Ci, int Co, int has_bias, int* words, int cap_words, int* meta, int64_t* part_floats);
+int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, float* dbias, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, float* part, int64_t part_floats, hipStream_t stream);
 
 /* svsr_conv3x3_c64: conv3x3(64, 64), stride 1, pad 1 (layer1 of the trunk, resnet.py:8-10,36,53) forward and, with the
  * transposed weights and mirrored taps, its input-gradient; persistent workgroups, weights resident in LDS

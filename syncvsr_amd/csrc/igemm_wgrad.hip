@@ -1,264 +1,371 @@
 // Weight-gradient contraction on MFMA (gfx950):
 //     dW[co][tw[t]][ci] += sum_m dY[target(m)][co] * X[source(m, t)][ci]            (fp32)
+// for every nn.Conv2d / nn.Linear of the path (autograd of reference LRW/video/src/tcn/models/resnet.py:8-16,59-72 and
+// lightning.py:82,92,107).
+//
+// Rows come from a host-built PLAN (svsr_wgrad_plan): for every tap, the list of (source pixel, target pixel) pairs of the
+// output positions whose source lies inside the grid — the reduction never runs over a convolution's zero padding (3x3 / pad 1
+// on 3x3, 6x6, 11x11 maps: 40 %, 21 %, 12 % of the products of a padded formulation are zeros) and needs no masks.
+//
+// Grid: x = K split (ranges of 64-row chunks), y = (co tile, ci tile, tap).  Block = 4 waves (2x2), tile BC x BC channels of one
+// tap.  Both operand tiles [64 rows][BC channels] go global -> LDS by direct DMA (global_load_lds_dwordx4) into an NS-deep ring
+// behind a counted s_waitcnt vmcnt(N) + one s_barrier per chunk: the first version staged them through registers and was bound
+// by the ds_write path (32 KiB of ds_write_b128 per chunk at ~79 B/clk/CU against 512 MFMA cycles).  The reduction index (rows)
+// is the slow index of both operands, so the MFMA fragments (8 consecutive rows of one channel per lane) are produced by the
+// gfx950 transpose read ds_read_b64_tr_b16.  A 32-lane group of that read touches 4 consecutive rows x 64 bytes; a DMA image is
+// lane-linear (no row padding possible), so the 64-byte units of a row are XOR-swizzled with the row index — on the per-lane
+// SOURCE address of the DMA and on the read address — which puts the four rows on the four bank quarters (conflict-free).
+//
 // Split-K without atomics: the workgroups of split s store their tiles into slab s of a caller-owned workspace with plain
 // stores and svsr_colsum_rows (runtime.hip) adds the slabs into dW in a fixed order, so the gradient is reproducible; with a
-// single split the tile is added to dW directly (one writer per element).
-// for every nn.Conv2d / nn.Linear of the path (autograd of reference LRW/video/src/tcn/models/resnet.py:8-16,59-72 and
-// lightning.py:82,92,107).  The reduction index m (positions) is the slow index of both operands, so
-// the MFMA fragments (8 consecutive positions for one channel per lane) are produced from position-major LDS tiles by
-// the gfx950 transpose read ds_read_b64_tr_b16.  A 32-lane group of that read touches 4 consecutive rows x 64 bytes, so the
-// row pitch must be 16 * odd banks (mod 64) for the four 16-bank windows to be disjoint: rows are padded by 32 elements
-// (with 16, PMC showed SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.33).
-//
-// Grid: x = split of the position range (64-position chunks), y = (co tile, ci tile, tap).  Block = 4 waves (2x2), tile
-// BC x BC channels of one tap; the next chunk's global loads are issued before the MFMA block of the current one.
-#include "igemm_common.h"
+// single split the tile is added to dW directly (one writer per element).  The bias gradient of an nn.Linear (column sums of dY)
+// comes out of the same staged dY tiles through one extra MFMA per step against a fragment of ones.
+#include <algorithm>
+#include <vector>
 
-struct IgemmWgradArgs {
-    IgemmGeom g;
+#include "common.h"
+
+#define WPLAN_HDR 2           // words[0] = taps, words[1] = word offset of the position table
+#define WPLAN_TAP_WORDS 4     // per tap: { P, pos_off (pairs), tw, 0 }
+#define WG_MAXP 1024          // positions per image and tap the LDS copy of the table can hold
+
+struct WgradArgs {
     const bf16_t* x;       // source pixels (pitch in_pitch)
     const bf16_t* dy;      // target pixels (pitch out_pitch)
     float* dw;             // [Co][wt_taps][Ci] fp32, accumulated
-    float* db;             // optional [Co] fp32: += column sums of dY (the bias gradient of an nn.Linear), taken from the dY tiles
-                           // the ci-tile-0 / tap-0 workgroups stage anyway
+    float* db;             // optional [Co] fp32: += column sums of dY (the bias gradient of an nn.Linear)
     float* part;           // splits > 1: slabs [splits][slab], slab = Co*wt_taps*Ci (+ Co when db != null) floats
+    const int* plan;       // device plan words
     long slab;
-    int splits;
-    int chunks_per_block;  // 64-position chunks each block reduces
+    int splits, chunks_per_split;      // 64-row chunks per split (of the longest tap; shorter taps end early)
+    int Nimg, in_pix, Ci, in_pitch, Co, out_pix, out_pitch, wt_taps;
 };
 
-__device__ __forceinline__ bf16x4 lds_tr_read(const bf16_t* addr) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(addr));
+__device__ unsigned g_wg_zero_page[64];     // 256 zero bytes: DMA source for rows beyond the end of a tap's row list
+
+// row-major [64][BC] bf16 tile whose 64-byte units (32 channels) are XOR-swizzled by the row: element offset of (row, ch)
+template <int BC>
+__device__ __forceinline__ int wg_swz(int row, int ch) {
+    constexpr int U = BC / 32;                       // 64-byte units per row: 4 (BC 128) or 2 (BC 64)
+    const int f = U == 4 ? (row & 3) : ((row >> 1) & 1);
+    return row * BC + ((((ch >> 5) ^ f) << 5) | (ch & 31));
 }
 
-// fragment for MFMA 32x32x16: lane l supplies matrix row (l&31) = channel, k = (l>>5)*8 .. +7 = positions.
-template <bool USE_TR, int PITCH>
-__device__ __forceinline__ bf16x8 load_frag_T(const bf16_t* tile, int ch0, int pos0, int lane) {
+// fragment for MFMA 32x32x16: lane l supplies matrix row (l&31) = channel ch0 + (l&31), k = (l>>5)*8 .. +7 = rows pos0 + ...
+// 16-lane group gq: channels ch0 + (gq&1)*16 .., rows pos0 + (gq>>1)*8 ..; lane s of the group addresses row (s>>2) of a
+// [4 rows][16 ch] block at channel sub-block (s&3)*4 and receives channel column s.  Rows r and r + 4 share their swizzle.
+template <int BC>
+__device__ __forceinline__ bf16x8 wg_frag_T(const bf16_t* tile, int ch0, int pos0, int lane) {
+    const int gq = lane >> 4, s = lane & 15;
+    const int row = pos0 + (gq >> 1) * 8 + (s >> 2), ch = ch0 + (gq & 1) * 16 + (s & 3) * 4;
+    const bf16_t* base = tile + wg_swz<BC>(row, ch);
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(base));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(base + 4 * BC));
     bf16x8 f;
-    if (USE_TR) {
-        // 16-lane group gq: channels ch0 + (gq&1)*16 .., positions pos0 + (gq>>1)*8 ..; lane s of the group addresses
-        // row (s>>2) of a [4 pos][16 ch] block at channel sub-block (s&3)*4 and receives channel column s.
-        const int gq = lane >> 4, s = lane & 15;
-        const bf16_t* base = tile + (pos0 + (gq >> 1) * 8 + (s >> 2)) * PITCH + ch0 + (gq & 1) * 16 + (s & 3) * 4;
-        const bf16x4 lo = lds_tr_read(base);
-        const bf16x4 hi = lds_tr_read(base + 4 * PITCH);
-        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-    } else {
-        const bf16_t* base = tile + (pos0 + (lane >> 5) * 8) * PITCH + ch0 + (lane & 31);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) f[k] = (short)base[k * PITCH];
-    }
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
 }
 
-template <bool USE_TR, int BC>
-__global__ __launch_bounds__(256) void k_igemm_wgrad(const IgemmWgradArgs p) {
-    constexpr int PITCH = BC + 32;          // bf16 elements per LDS row: 48 (BC 64) / 80 (BC 128) banks = 16 * odd, see below
-    constexpr int CPR = BC / 8;             // 16-byte chunks per row
-    constexpr int NL = CPR / 8;             // loads per (operand, row) per thread: thread covers chunks c, c+8, ...
-    constexpr int WT = BC / 2, TT = WT / 32;  // wave tile edge, 32x32 MFMA tiles per edge
-    __shared__ __attribute__((aligned(16))) bf16_t sm[2 * 64 * PITCH];
-    bf16_t* sY = sm;
-    bf16_t* sX = sm + 64 * PITCH;
-    const IgemmGeom& g = p.g;
+template <int LPT, int MAXL>
+__device__ __forceinline__ void wg_wait_tiles_barrier(int later) {
+    if constexpr (MAXL > 0) {
+        if (later == MAXL) { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPT * MAXL) : "memory"); return; }
+        wg_wait_tiles_barrier<LPT, MAXL - 1>(later);
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+template <int BC, int NS, bool BIAS>
+__device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_raw) {
+    constexpr int T_ELEMS = 64 * BC;                 // one operand tile
+    constexpr int S_ELEMS = 2 * T_ELEMS;             // stage = dY tile | X tile
+    constexpr int RPI = 1024 / (BC * 2);             // rows per DMA instruction (1 KiB): 4 (BC 128) or 8 (BC 64)
+    constexpr int AR = 64 / RPI / 4;                 // DMA instructions per thread, operand and chunk: 4 (BC 128) or 2 (BC 64)
+    constexpr int LPT = 2 * AR;
+    constexpr int CPR = BC / 8;                      // 16-byte pieces per row
+    constexpr int U = BC / 32;                       // 64-byte units per row
+    constexpr int WT = BC / 2, TT = WT / 32;         // wave tile edge, 32x32 MFMA tiles per edge
+    static_assert(NS >= 2 && LPT * (NS - 2) <= 63, "vmcnt immediate is 6 bits");
+    bf16_t* sStage = reinterpret_cast<bf16_t*>(smem_raw);                 // [NS][dY | X]
+    int* sPos = reinterpret_cast<int*>(sStage + NS * S_ELEMS);            // [P][2] (x pixel, dY pixel) of this tap
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int co_tiles = (g.Co + BC - 1) / BC, ci_tiles = (g.Ci + BC - 1) / BC;
+    const int co_tiles = (p.Co + BC - 1) / BC, ci_tiles = (p.Ci + BC - 1) / BC;
     int rest = blockIdx.y;
     const int cot = rest % co_tiles; rest /= co_tiles;
     const int cit = rest % ci_tiles; rest /= ci_tiles;
     const int t = rest;
     const int co0 = cot * BC, ci0 = cit * BC;
     const int wco = (wave >> 1) * WT, wci = (wave & 1) * WT;
-    int dyt = 0, dxt = 0, tw = 0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i)          // compile-time indices only (see igemm_common.h)
-        if (i == t) { dyt = g.dy[i]; dxt = g.dx[i]; tw = g.tw[i]; }
-    const int chunk = tid & 7, r0 = tid >> 3;
+    const int* tapw = p.plan + WPLAN_HDR + t * WPLAN_TAP_WORDS;
+    const int P = tapw[0], tw = tapw[2];
+    const int* pos = p.plan + p.plan[1] + 2 * tapw[1];
+    for (int i = tid; i < 2 * P; i += 256) sPos[i] = pos[i];
+    const int Mt = p.Nimg * P;                       // rows of this tap (0 for a tap no position reaches)
+    const float inv_p = P > 0 ? 1.0f / (float)P : 0.f;
+    const int total_chunks = (Mt + 63) / 64;
+    const int c_begin = blockIdx.x * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > total_chunks) c_end = total_chunks;
+    const int KT = c_end > c_begin ? c_end - c_begin : 0;
 
-    f32x16 acc[TT][TT];
+    // lane -> (row inside a DMA instruction's row group, 16-byte piece); the piece a lane FETCHES is the swizzle image of the piece
+    // it writes (the LDS image of a DMA is lane-linear)
+    const int lrow = lane / CPR, lpiece = lane % CPR;
+    const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_wg_zero_page);
+    const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * RPI;        // instruction i of wave w covers rows (i*4 + w)*RPI ..
+    __syncthreads();
+
+    auto stage = [&](int c, int buf) {
+        bf16_t* dstY = sStage + buf * S_ELEMS;
+        bf16_t* dstX = dstY + T_ELEMS;
 #pragma unroll
-    for (int i = 0; i < TT; ++i)
+        for (int i = 0; i < AR; ++i) {
+            const int rt = i * 4 * RPI + wrow0 + lrow;                  // row inside the tile
+            const int m = c * 64 + rt;
+            const bool ok = m < Mt;
+            const int mm = ok ? m : 0;
+            int n = (int)((float)mm * inv_p);
+            int j = mm - n * P;
+            if (j < 0) { n--; j += P; } else if (j >= P) { n++; j -= P; }
+            const int xp = sPos[2 * j], yp = sPos[2 * j + 1];
+            const int f = U == 4 ? (rt & 3) : ((rt >> 1) & 1);
+            const int gpiece = (((lpiece >> 2) ^ f) << 2) | (lpiece & 3);
+            const int cy = co0 + gpiece * 8, cx = ci0 + gpiece * 8;
+            const bf16_t* sy = (ok && cy < p.Co) ? p.dy + ((long)n * p.out_pix + yp) * p.out_pitch + cy : zero_src;
+            const bf16_t* sx = (ok && cx < p.Ci) ? p.x + ((long)n * p.in_pix + xp) * p.in_pitch + cx : zero_src;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy,
+                                             (__attribute__((address_space(3))) void*)(dstY + (i * 4 * RPI + wrow0) * BC), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
+                                             (__attribute__((address_space(3))) void*)(dstX + (i * 4 * RPI + wrow0) * BC), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TT][TT], accb[BIAS ? TT : 1];
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        if (BIAS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < TT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ones[k] = (short)0x3f80;                        // bf16 1.0
 
-    const int c_begin = blockIdx.x * p.chunks_per_block;
-    int c_end = c_begin + p.chunks_per_block;
-    const int total_chunks = (g.M + 63) / 64;
-    if (c_end > total_chunks) c_end = total_chunks;
-
-    u32x4 vy[2][NL], vx[2][NL];
-    unsigned ld_ok = 0;        // bits: (row i, load l) of dY at i*NL+l, of X at 8 + i*NL+l
-    auto load_chunk = [&](int c) {
-        ld_ok = 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = c * 64 + r0 + 32 * i;
-            const bool ok_m = m < g.M;
-            int n, a, b;
-            decode_pos(g, ok_m ? m : 0, n, a, b);
-            const long opix = ((long)n * g.Ho + (a * g.OS + g.oy0)) * g.Wo + (b * g.OS + g.ox0);
-            const int iy = a * g.S + dyt, ix = b * g.S + dxt;
-            const bool okp = ok_m && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-            const long ipix = okp ? ((long)n * g.Hi + iy) * g.Wi + ix : 0;
-#pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                const int cy = co0 + (chunk + 8 * l) * 8, cx = ci0 + (chunk + 8 * l) * 8;
-                const bool oky = ok_m && cy < g.Co, okx = okp && cx < g.Ci;
-                vy[i][l] = *reinterpret_cast<const u32x4*>(p.dy + (oky ? opix * g.out_pitch + cy : 0));
-                vx[i][l] = *reinterpret_cast<const u32x4*>(p.x + (okx ? ipix * g.in_pitch + cx : 0));
-                ld_ok |= (oky ? 1u : 0u) << (i * NL + l);
-                ld_ok |= (okx ? 1u : 0u) << (8 + i * NL + l);
-            }
-        }
-    };
-    const bool do_bias = p.db != nullptr && cit == 0 && t == 0;
-    float bsum[NL][8];
-#pragma unroll
-    for (int l = 0; l < NL; ++l)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) bsum[l][k] = 0.f;
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                const bool oky = (ld_ok >> (i * NL + l)) & 1u, okx = (ld_ok >> (8 + i * NL + l)) & 1u;
-                u32x4 y = vy[i][l], x = vx[i][l];
-                y.x = oky ? y.x : 0u; y.y = oky ? y.y : 0u; y.z = oky ? y.z : 0u; y.w = oky ? y.w : 0u;
-                if (do_bias) {
-                    float f[8];
-                    unpack8(y, f);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) bsum[l][k] += f[k];
-                }
-                x.x = okx ? x.x : 0u; x.y = okx ? x.y : 0u; x.z = okx ? x.z : 0u; x.w = okx ? x.w : 0u;
-                *reinterpret_cast<u32x4*>(sY + (r0 + 32 * i) * PITCH + (chunk + 8 * l) * 8) = y;
-                *reinterpret_cast<u32x4*>(sX + (r0 + 32 * i) * PITCH + (chunk + 8 * l) * 8) = x;
-            }
-    };
-
-    if (c_begin < c_end) load_chunk(c_begin);
-    for (int c = c_begin; c < c_end; ++c) {
-        __syncthreads();                           // previous chunk's fragment reads are done
-        store_chunk();
-        __syncthreads();
-        if (c + 1 < c_end) load_chunk(c + 1);      // in flight while this chunk is contracted
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < KT) stage(c_begin + s, s);
+    int buf = 0;
+    for (int it = 0; it < KT; ++it) {
+        // chunk `it` has landed once at most min(NS-2, chunks left) later chunks' DMAs are still outstanding; the barrier makes
+        // every wave's part visible and proves everybody is done reading the buffer the next stage() overwrites
+        const int later = KT - 1 - it < NS - 2 ? KT - 1 - it : NS - 2;
+        wg_wait_tiles_barrier<LPT, NS - 2>(later);
+        if (it + NS - 1 < KT) stage(c_begin + it + NS - 1, buf >= 1 ? buf - 1 : NS - 1);
+        const bf16_t* sY = sStage + buf * S_ELEMS;
+        const bf16_t* sX = sY + T_ELEMS;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 fa[TT], fb[TT];
 #pragma unroll
-            for (int i = 0; i < TT; ++i) fa[i] = load_frag_T<USE_TR, PITCH>(sY, wco + i * 32, ks * 16, lane);
+            for (int i = 0; i < TT; ++i) fa[i] = wg_frag_T<BC>(sY, wco + i * 32, ks * 16, lane);
 #pragma unroll
-            for (int j = 0; j < TT; ++j) fb[j] = load_frag_T<USE_TR, PITCH>(sX, wci + j * 32, ks * 16, lane);
+            for (int j = 0; j < TT; ++j) fb[j] = wg_frag_T<BC>(sX, wci + j * 32, ks * 16, lane);
 #pragma unroll
             for (int i = 0; i < TT; ++i)
 #pragma unroll
                 for (int j = 0; j < TT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    if (do_bias) {          // threads with the same `chunk` (tid & 7) hold the same channels: reduce over r0 through LDS
-        __syncthreads();
-        float* sred = reinterpret_cast<float*>(sm);          // [256][8*NL] floats <= the tile buffers
+            if (BIAS) {          // (every wave of a bias block: a lane-dependent condition here costs an AGPR round trip per step)
 #pragma unroll
-        for (int l = 0; l < NL; ++l)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sred[tid * (8 * NL) + l * 8 + k] = bsum[l][k];
-        __syncthreads();
-        if (tid < BC) {
-            const int grp = tid >> 3, k = tid & 7;            // channel tid of the tile = 16-byte group grp, element k
-            const int chk = grp & 7, l = grp >> 3;
-            float s = 0.f;
-            for (int r = 0; r < 32; ++r) s += sred[(r * 8 + chk) * (8 * NL) + l * 8 + k];
-            if (co0 + tid < g.Co) {
-                if (p.splits > 1) p.part[(long)blockIdx.x * p.slab + (long)g.Co * g.wt_taps * g.Ci + co0 + tid] = s;
-                else p.db[co0 + tid] += s;
+                for (int i = 0; i < TT; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], ones, accb[i], 0, 0, 0);
             }
         }
-        __syncthreads();
+        buf = buf + 1 == NS ? 0 : buf + 1;
     }
     // D[row = co][col = ci]: one writer per element — slab `blockIdx.x` (plain store) or, without a split, dW itself
-    float* dst = p.splits > 1 ? p.part + (long)blockIdx.x * p.slab : p.dw;
     const bool direct = p.splits <= 1;
+    float* dst = direct ? p.dw : p.part + (long)blockIdx.x * p.slab;
 #pragma unroll
     for (int j = 0; j < TT; ++j) {
         const int ci = ci0 + wci + j * 32 + (lane & 31);
-        if (ci >= g.Ci) continue;
+        if (ci >= p.Ci) continue;
 #pragma unroll
         for (int i = 0; i < TT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < g.Co) {
-                    float* d = dst + ((long)co * g.wt_taps + tw) * g.Ci + ci;
+                if (co < p.Co) {
+                    float* d = dst + ((long)co * p.wt_taps + tw) * p.Ci + ci;
                     *d = direct ? *d + acc[i][j][r] : acc[i][j][r];
                 }
             }
     }
+    if (BIAS && wci == 0 && (lane & 31) == 0) {      // every column of accb holds the same sums: lanes 0 and 32 own 16 rows each
+        float* dbd = direct ? p.db : p.part + (long)blockIdx.x * p.slab + (long)p.Co * p.wt_taps * p.Ci;
+#pragma unroll
+        for (int i = 0; i < TT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < p.Co) dbd[co] = direct ? dbd[co] + accb[i][r] : accb[i][r];
+            }
+    }
 }
 
-struct WgradPlan { int bc, splits, chunks_per_block, tasks; long slab; };
+template <int BC, int NS>
+__global__ __launch_bounds__(256) void k_igemm_wgrad(const WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // the workgroups of ci tile 0 / tap 0 also produce the bias gradient: a scalar (blockIdx) branch between two instantiations
+    const int co_tiles = (p.Co + BC - 1) / BC, ci_tiles = (p.Ci + BC - 1) / BC;
+    const int rest = (int)blockIdx.y / co_tiles;
+    if (p.db != nullptr && rest % ci_tiles == 0 && rest / ci_tiles == 0) wg_body<BC, NS, true>(p, smem_raw);
+    else wg_body<BC, NS, false>(p, smem_raw);
+}
 
-static WgradPlan wgrad_plan(int M, int Co, int Ci, int ntaps, int wt_taps, bool bias) {
-    WgradPlan pl;
+// ---- host side -------------------------------------------------------------------------------------------------------
+struct WgradLaunch { int bc, ns, splits, chunks_per_split, tasks; long slab; };
+
+static WgradLaunch wgrad_launch(long max_rows, int Co, int Ci, int ntaps, int wt_taps, bool bias) {
+    WgradLaunch pl;
     const int tasks128 = ((Co + 127) / 128) * ((Ci + 127) / 128) * ntaps;
     pl.bc = (Co >= 128 && Ci >= 128 && tasks128 >= 36) ? 128 : 64;
+    pl.ns = pl.bc == 128 ? 2 : 3;
     const int BC = pl.bc;
     pl.tasks = ((Co + BC - 1) / BC) * ((Ci + BC - 1) / BC) * ntaps;
-    const int total_chunks = (M + 63) / 64;
+    const int total_chunks = (int)((max_rows + 63) / 64);
+    // one round of resident workgroups: 2 per CU for the 128-wide tile (64 KiB of LDS ring, ~200 VGPRs), 3 per CU for the 64-wide
+    // one — a grid a little above that runs a second, almost empty round (layer4: 576 workgroups on 512 slots took 1.4x longer)
+    static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
     const int target_env = svsr_tune_get(SVSR_TUNE_WG_BLOCKS);
-    const int target_blocks = target_env > 0 ? target_env : (BC == 128 ? 512 : 1024);    // measured optimum per tile size
-    int splits = (target_blocks + pl.tasks - 1) / pl.tasks;   // every split costs a slab of Co*taps*Ci floats written and re-read
+    const int target_blocks = target_env > 0 ? target_env : cus * (BC == 128 ? 2 : 3);
+    int splits = target_blocks / pl.tasks;                    // every split costs a slab of Co*taps*Ci floats written and re-read
     if (splits > total_chunks) splits = total_chunks;
     if (splits < 1) splits = 1;
-    pl.chunks_per_block = (total_chunks + splits - 1) / splits;
+    pl.chunks_per_split = (total_chunks + splits - 1) / splits;
     // keep the epilogue amortised: >= 12 K-chunks per block when the problem has them (LRS linears: 2,400 rows =
     // 38 chunks -> 3 splits measured best), >= 4 for the short LRW sequences
     const int min_chunks = total_chunks >= 36 ? 12 : 4;
-    if (pl.chunks_per_block < min_chunks && total_chunks >= min_chunks) pl.chunks_per_block = min_chunks;
-    pl.splits = (total_chunks + pl.chunks_per_block - 1) / pl.chunks_per_block;
+    if (pl.chunks_per_split < min_chunks && total_chunks >= min_chunks) pl.chunks_per_split = min_chunks;
+    pl.splits = (total_chunks + pl.chunks_per_split - 1) / pl.chunks_per_split;
+    if (pl.splits < 1) pl.splits = 1;
     pl.slab = (long)Co * wt_taps * Ci + (bias ? Co : 0);
     return pl;
 }
 
-template <bool USE_TR, int BC>
-static int launch_wgrad(IgemmWgradArgs& a, const WgradPlan& pl, hipStream_t stream) {
-    hipLaunchKernelGGL((k_igemm_wgrad<USE_TR, BC>), dim3(pl.splits, pl.tasks), dim3(256), 0, stream, a);
+// meta: {tile edge, ring depth, K splits, chunks per split, tasks, taps, max positions of a tap, 0}
+static int wplan_emit(const std::vector<std::vector<int>>& taps_pos, const std::vector<int>& tws, int Nimg, int Co, int Ci, int wt_taps,
+                      int has_bias, int* words, int cap_words, int* meta, int64_t* part_floats) {
+    const int ntaps = (int)taps_pos.size();
+    int nwords = WPLAN_HDR + ntaps * WPLAN_TAP_WORDS;
+    const int pos_word0 = nwords;
+    long maxP = 0;
+    for (const auto& v : taps_pos) { nwords += (int)v.size(); if ((long)v.size() / 2 > maxP) maxP = (long)v.size() / 2; }
+    if (maxP < 1 || maxP > WG_MAXP || (long)Nimg * maxP >= (1L << 24)) return -SVSR_ERR_ARG;
+    const WgradLaunch pl = wgrad_launch((long)Nimg * maxP, Co, Ci, ntaps, wt_taps, has_bias != 0);
+    if (words != nullptr) {
+        if (cap_words < nwords) return -SVSR_ERR_ARG;
+        words[0] = ntaps; words[1] = pos_word0;
+        int pos_off = 0;
+        for (int t = 0; t < ntaps; ++t) {
+            int* w = words + WPLAN_HDR + t * WPLAN_TAP_WORDS;
+            const int P = (int)(taps_pos[t].size() / 2);
+            w[0] = P; w[1] = pos_off; w[2] = tws[t]; w[3] = 0;
+            std::copy(taps_pos[t].begin(), taps_pos[t].end(), words + pos_word0 + 2 * pos_off);
+            pos_off += P;
+        }
+    }
+    if (meta != nullptr) {
+        meta[0] = pl.bc; meta[1] = pl.ns; meta[2] = pl.splits; meta[3] = pl.chunks_per_split; meta[4] = pl.tasks; meta[5] = ntaps;
+        meta[6] = (int)maxP; meta[7] = 0;
+    }
+    if (part_floats != nullptr) *part_floats = pl.splits > 1 ? (int64_t)pl.splits * pl.slab : 0;
+    return nwords;
+}
+
+template <int BC, int NS>
+static int launch_wgrad(const WgradArgs& a, int tasks, int maxP, hipStream_t stream) {
+    const size_t lds_max = (size_t)NS * 2 * 64 * BC * sizeof(bf16_t) + (size_t)WG_MAXP * 2 * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_wgrad<BC, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        attr_set = true;
+    }
+    const size_t lds = (size_t)NS * 2 * 64 * BC * sizeof(bf16_t) + (((size_t)maxP * 2 * sizeof(int) + 127) & ~(size_t)127);
+    hipLaunchKernelGGL((k_igemm_wgrad<BC, NS>), dim3(a.splits, tasks), dim3(256), lds, stream, a);
     return svsr_check_launch();
 }
 
-/* svsr_igemm_wgrad_plan: tile edge, number of K splits and the workspace (floats) svsr_igemm_wgrad needs for this shape
- * (0 floats when a single split writes dW directly). */
-extern "C" int svsr_igemm_wgrad_plan(int M, int Co, int Ci, int ntaps, int wt_taps, int has_bias, int* bc, int* splits, int64_t* part_floats) {
-    if (M <= 0 || Co <= 0 || Ci <= 0 || ntaps < 1 || wt_taps < ntaps) return SVSR_ERR_ARG;
-    const WgradPlan pl = wgrad_plan(M, Co, Ci, ntaps, wt_taps, has_bias != 0);
-    if (bc) *bc = pl.bc;
-    if (splits) *splits = pl.splits;
-    if (part_floats) *part_floats = pl.splits > 1 ? (int64_t)pl.splits * pl.slab : 0;
-    return SVSR_OK;
+extern "C" {
+
+/* svsr_wgrad_plan (host): plan of the weight gradient of a k x k / stride / pad convolution over Nimg images [H][W] -> [Ho][Wo]
+ * (x = forward input pixels, dy = output-gradient pixels; dw [Co][k*k][Ci]).  words == null: only counts.  Returns the number
+ * of int32 words or a negative error; meta[8] = {tile edge, ring depth, K splits, chunks per split, tasks, taps, max positions};
+ * *part_floats = workspace floats svsr_igemm_wgrad needs (0 when a single split writes dW directly). */
+int svsr_wgrad_plan(int Nimg, int H, int W, int Ci, int Co, int k, int stride, int pad, int* words, int cap_words, int* meta,
+                    int64_t* part_floats) {
+    if (Nimg < 1 || H < 1 || W < 1 || k < 1 || k > 3 || stride < 1 || pad < 0 || Ci < 1 || Co < 1) return -SVSR_ERR_ARG;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    if (Ho < 1 || Wo < 1) return -SVSR_ERR_ARG;
+    std::vector<std::vector<int>> tp;
+    std::vector<int> tws;
+    for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw) {
+            std::vector<int> v;      // stays empty for a tap no position reaches (its slab tiles are written as zeros)
+            for (int a = 0; a < Ho; ++a)
+                for (int b = 0; b < Wo; ++b) {
+                    const int iy = a * stride + kh - pad, ix = b * stride + kw - pad;
+                    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                    v.push_back(iy * W + ix);
+                    v.push_back(a * Wo + b);
+                }
+            tp.push_back(v);
+            tws.push_back(kh * k + kw);
+        }
+    return wplan_emit(tp, tws, Nimg, Co, Ci, k * k, 0, words, cap_words, meta, part_floats);
 }
 
-extern "C" int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate,
-                                float scale, hipStream_t stream);
+/* svsr_wgrad_rows_plan (host): dense layer over Nimg sequences: row (n, j < P) pairs source row n*in_pix + src0 + j with
+ * target row n*out_pix + dst0 + j (plain linear: P = 1, in_pix = out_pix = 1). */
+int svsr_wgrad_rows_plan(int Nimg, int P, int src0, int dst0, int Ci, int Co, int has_bias, int* words, int cap_words, int* meta,
+                         int64_t* part_floats) {
+    if (Nimg < 1 || P < 1 || Ci < 1 || Co < 1) return -SVSR_ERR_ARG;
+    std::vector<std::vector<int>> tp(1);
+    for (int j = 0; j < P; ++j) { tp[0].push_back(src0 + j); tp[0].push_back(dst0 + j); }
+    return wplan_emit(tp, std::vector<int>{0}, Nimg, Co, Ci, 1, has_bias, words, cap_words, meta, part_floats);
+}
 
-extern "C" int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, int Nimg, int Hi, int Wi, int Ci, int in_pitch, int Co,
-                                int Ho, int Wo, int out_pitch, int Ha, int Wa, int S, int OS, int oy0, int ox0, int ntaps, int wt_taps,
-                                const int* dy, const int* dx, const int* tw, int use_tr, float* dbias, float* part, int64_t part_floats,
-                                hipStream_t stream) {
-    IgemmWgradArgs a;
-    int rc = fill_geom(a.g, Nimg, Hi, Wi, Ci, in_pitch, Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0, ntaps, wt_taps, dy, dx, tw);
-    if (rc != SVSR_OK) return rc;
-    if (out_pitch % 8 != 0) return SVSR_ERR_ARG;
-    const WgradPlan pl = wgrad_plan(a.g.M, Co, Ci, ntaps, wt_taps, dbias != nullptr);
-    if (pl.splits > 1 && (part == nullptr || part_floats < (int64_t)pl.splits * pl.slab)) return SVSR_ERR_ARG;
-    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dyp; a.dw = dw; a.db = dbias;
-    a.part = part; a.slab = pl.slab; a.splits = pl.splits; a.chunks_per_block = pl.chunks_per_block;
-    if (use_tr) rc = pl.bc == 128 ? launch_wgrad<true, 128>(a, pl, stream) : launch_wgrad<true, 64>(a, pl, stream);
-    else rc = pl.bc == 128 ? launch_wgrad<false, 128>(a, pl, stream) : launch_wgrad<false, 64>(a, pl, stream);
-    if (rc != SVSR_OK || pl.splits <= 1) return rc;
+int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale,
+                     hipStream_t stream);
+
+/* svsr_igemm_wgrad: runs a plan (plan_dev = device copy of the words, meta = the host meta of svsr_wgrad_*plan).
+ * dw fp32 [Co][wt_taps][Ci] += ...; dbias (optional, fp32 [Co]) += column sums of dy.  part: workspace of *part_floats floats. */
+int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, float* dbias, const int* plan_dev, const int* meta, int Nimg, int in_pix,
+                     int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, float* part, int64_t part_floats,
+                     hipStream_t stream) {
+    if (plan_dev == nullptr || meta == nullptr || Ci < 1 || Co < 1 || in_pitch % 8 != 0 || out_pitch % 8 != 0 || Ci % 8 != 0 || Nimg < 1)
+        return SVSR_ERR_ARG;
+    WgradArgs a;
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dyp; a.dw = dw; a.db = dbias; a.part = part; a.plan = plan_dev;
+    a.splits = meta[2]; a.chunks_per_split = meta[3];
+    a.slab = (long)Co * wt_taps * Ci + (dbias != nullptr ? Co : 0);
+    a.Nimg = Nimg; a.in_pix = in_pix; a.Ci = Ci; a.in_pitch = in_pitch; a.Co = Co; a.out_pix = out_pix; a.out_pitch = out_pitch; a.wt_taps = wt_taps;
+    if (a.splits > 1 && (part == nullptr || part_floats < (int64_t)a.splits * a.slab)) return SVSR_ERR_ARG;
+    const int bc = meta[0], ns = meta[1], tasks = meta[4], maxP = meta[6];
+    int rc;
+    if (bc == 128 && ns == 2) rc = launch_wgrad<128, 2>(a, tasks, maxP, stream);
+    else if (bc == 64 && ns == 3) rc = launch_wgrad<64, 3>(a, tasks, maxP, stream);
+    else return SVSR_ERR_ARG;
+    if (rc != SVSR_OK || a.splits <= 1) return rc;
     const int64_t n = (int64_t)Co * wt_taps * Ci;
-    return svsr_colsum_rows(part, pl.splits, pl.slab, dw, n, dbias, dbias != nullptr ? Co : 0, 1, 1.0f, stream);
+    return svsr_colsum_rows(part, a.splits, a.slab, dw, n, dbias, dbias != nullptr ? Co : 0, 1, 1.0f, stream);
 }
+
+}  // extern "C"

@@ -74,7 +74,7 @@ def _query(name: str, *args) -> tuple:
     if name.endswith("_rows"):
         out = (int(fn(*args)),)
     else:
-        nout = {"svsr_igemm_wgrad_plan": (2, 1), "svsr_conv3x3_wgrad_plan": (1, 1),
+        nout = {"svsr_conv3x3_wgrad_plan": (1, 1),
                 "svsr_stem_conv_wgrad_plan": (1, 1)}[name]
         ints = [ctypes.c_int(0) for _ in range(nout[0])]
         longs = [ctypes.c_int64(0) for _ in range(nout[1])]
@@ -177,9 +177,40 @@ def rows_plan(Nimg: int, P: int, src0: int, dst0: int, Co_out: int) -> Plan:
     return pl
 
 
-def wgrad_plan(M: int, Co: int, Ci: int, ntaps: int, wt_taps: int, has_bias: bool) -> tuple[int, int, int]:
-    """(tile edge, K splits, workspace floats) of svsr_igemm_wgrad for this shape."""
-    return _query("svsr_igemm_wgrad_plan", int(M), int(Co), int(Ci), int(ntaps), int(wt_taps), int(has_bias))
+class WPlan:
+    """Launch plan of svsr_igemm_wgrad for one shape (device words + host meta + workspace size)."""
+    __slots__ = ("words", "meta", "bc", "splits", "part_floats", "label")
+
+    def __init__(self, builder: str, *args):
+        fn = getattr(_lib.load(), builder)
+        meta = (ctypes.c_int * 8)()
+        nfl = ctypes.c_int64(0)
+        n = fn(*args, None, 0, meta, ctypes.byref(nfl))
+        if n <= 0:
+            _lib.check(-n if n < 0 else 1001, builder)
+        host = torch.empty(n, dtype=torch.int32)
+        if fn(*args, host.data_ptr(), n, meta, ctypes.byref(nfl)) != n:
+            _lib.check(1001, builder)
+        self.words = host.to("cuda")
+        self.meta = meta
+        self.bc, self.splits, self.part_floats = int(meta[0]), int(meta[2]), int(nfl.value)
+        self.label = f"k_igemm_wgrad<{self.bc},{int(meta[1])}>"
+
+
+def wgrad_conv_plan(N: int, H: int, W: int, Ci: int, Co: int, k: int, stride: int, pad: int) -> WPlan:
+    key = ("wconv", N, H, W, Ci, Co, k, stride, pad)
+    pl = _PLAN_CACHE.get(key)
+    if pl is None:
+        pl = _PLAN_CACHE[key] = WPlan("svsr_wgrad_plan", N, H, W, Ci, Co, k, stride, pad)
+    return pl
+
+
+def wgrad_rows_plan(Nimg: int, P: int, src0: int, dst0: int, Ci: int, Co: int, has_bias: bool) -> WPlan:
+    key = ("wrows", Nimg, P, src0, dst0, Ci, Co, bool(has_bias))
+    pl = _PLAN_CACHE.get(key)
+    if pl is None:
+        pl = _PLAN_CACHE[key] = WPlan("svsr_wgrad_rows_plan", Nimg, P, src0, dst0, Ci, Co, int(has_bias))
+    return pl
 
 
 # --------------------------------------------------------------------------------------------------
@@ -201,17 +232,11 @@ def igemm_fwd(plan: Plan, inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor
     return st
 
 
-def igemm_wgrad(x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: int, Hi: int, Wi: int, Ci: int, in_pitch: int,
-                Co: int, Ho: int, Wo: int, out_pitch: int, Ha: int, Wa: int, S: int = 1, OS: int = 1, oy0: int = 0, ox0: int = 0,
-                taps: Sequence[tuple[int, int, int]] = ((0, 0, 0),), wt_taps: int = 1, use_tr: bool = True,
-                db: Optional[torch.Tensor] = None) -> None:
-    dy, dx, tw = zip(*taps)
-    bc, splits, nfl = wgrad_plan(Nimg * Ha * Wa, Co, Ci, len(taps), wt_taps, db is not None)
-    part = scratch(nfl) if nfl else None
-    _call("svsr_igemm_wgrad", _p(x), _p(dyp), _p(dw), Nimg, Hi, Wi, Ci, in_pitch, Co, Ho, Wo, out_pitch, Ha, Wa, S, OS, oy0, ox0,
-          len(taps), wt_taps, _ints(dy), _ints(dx), _ints(tw), int(use_tr), _p(db), _p(part), nfl, _stream(),
-          label=f"k_igemm_wgrad<{'true' if use_tr else 'false'},{bc}>",
-          flops=2.0 * Nimg * Ha * Wa * Co * Ci * len(taps))
+def igemm_wgrad(plan: WPlan, x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tensor, *, Nimg: int, in_pix: int, Ci: int, in_pitch: int,
+                Co: int, out_pix: int, out_pitch: int, wt_taps: int = 1, db: Optional[torch.Tensor] = None, flops: float = 0.0) -> None:
+    part = scratch(plan.part_floats) if plan.part_floats else None
+    _call("svsr_igemm_wgrad", _p(x), _p(dyp), _p(dw), _p(db), plan.words.data_ptr(), plan.meta, Nimg, in_pix, Ci, in_pitch, Co, out_pix,
+          out_pitch, wt_taps, _p(part), plan.part_floats, _stream(), label=plan.label, flops=flops)
 
 
 def conv_out_size(n: int, k: int, stride: int, pad: int) -> int:
@@ -293,9 +318,8 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: int, st
         _call("svsr_conv3x3_wgrad", _p(x), _p(dy), _p(dw), N, H, W, Ci, Co, _p(part), nfl, _stream(), label="k_wgrad3x3_halo",
               flops=2.0 * N * H * W * Co * Ci * 9)
         return
-    taps = _conv_taps(k, pad)
-    igemm_wgrad(x, dy, dw, Nimg=N, Hi=H, Wi=W, Ci=Ci, in_pitch=Ci, Co=Co, Ho=Ho, Wo=Wo, out_pitch=Co, Ha=Ho, Wa=Wo, S=stride,
-                taps=taps, wt_taps=k * k, use_tr=use_tr)
+    igemm_wgrad(wgrad_conv_plan(N, H, W, Ci, Co, k, stride, pad), x, dy, dw, Nimg=N, in_pix=H * W, Ci=Ci, in_pitch=Ci, Co=Co,
+                out_pix=Ho * Wo, out_pitch=Co, wt_taps=k * k, flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
 
 
 def linear_fwd(x: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor], *, rows: int, K: int, N: int, x_pitch: int,
@@ -340,13 +364,14 @@ def linear_dgrad(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, K: 
 
 def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, rows: int, K: int, N: int, x_pitch: int, dy_pitch: int,
                  seq: Optional[tuple[int, int, int]] = None, use_tr: bool = True, db: Optional[torch.Tensor] = None) -> None:
-    """dw fp32 [N][K] += dy[rows, N]^T @ x[rows, K];  db fp32 [N] += column sums of dy (bias gradient), if given."""
+    """dw fp32 [N][K] += dy[rows, N]^T @ x[rows, K];  db fp32 [N] += column sums of dy (bias gradient), if given.
+    (`use_tr` is accepted for the callers' sake: the generic kernel always builds its fragments with transpose reads.)"""
     if seq is None:
-        geo = dict(Nimg=rows, Hi=1, Wi=1, Ha=1, Wa=1, Ho=1, Wo=1, taps=((0, 0, 0),))
+        plan, geo = wgrad_rows_plan(rows, 1, 0, 0, K, N, db is not None), dict(Nimg=rows, in_pix=1, out_pix=1)
     else:
         S, s0, n = seq
-        geo = dict(Nimg=rows // n, Hi=1, Wi=S, Ha=1, Wa=n, Ho=1, Wo=n, taps=((0, s0, 0),))
-    igemm_wgrad(x, dy, dw, Ci=K, in_pitch=x_pitch, Co=N, out_pitch=dy_pitch, use_tr=use_tr, db=db, **geo)
+        plan, geo = wgrad_rows_plan(rows // n, n, s0, 0, K, N, db is not None), dict(Nimg=rows // n, in_pix=S, out_pix=n)
+    igemm_wgrad(plan, x, dy, dw, Ci=K, in_pitch=x_pitch, Co=N, out_pitch=dy_pitch, db=db, flops=2.0 * rows * N * K, **geo)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 """Kernel parity AT THE BENCHMARK SHAPES (-m gpu): every contraction launch of the B = 32 LRW step (928 frames; BASELINE.json
 configs[1]) and the large LRS linears (2,400 rows), each against torch fp32 on the same bf16-rounded operands.
 
-bench.py's kernel instantiations are chosen from the problem shape (svsr_conv_plan / svsr_rows_plan / svsr_igemm_wgrad_plan), so running
+bench.py's kernel instantiations are chosen from the problem shape (svsr_conv_plan / svsr_rows_plan / svsr_wgrad_plan), so running
 the benchmark's own shapes here runs the benchmark's own instantiations; each test also asks the library which instantiation it
 launched, asserts the ones the step is known to depend on and records all of them in gpurun_out/bench_shape_instantiations.json
 so that coverage cannot silently move when the launch heuristics change.  Tolerances are those of tests/test_gpu_kernels.py.
@@ -129,8 +129,8 @@ def test_trunk_conv_fwd_dgrad_wgrad_at_928_frames(dev, name):
     if halo:
         _SEEN[f"{name}.wgrad"] = "k_wgrad3x3_halo"
     else:
-        bc, splits, _ = ops.wgrad_plan(N * Ho * Wo, Co, Ci, k * k, k * k, False)
-        _SEEN[f"{name}.wgrad"] = f"k_igemm_wgrad<true,{bc}> x{splits} splits"
+        wp = ops.wgrad_conv_plan(N, H, W, Ci, Co, k, s, p)
+        _SEEN[f"{name}.wgrad"] = f"{wp.label} x{wp.splits} splits"
     check(dw, ws.grad.permute(0, 2, 3, 1), f"{name}.wgrad", 3e-3, 2e-3)
     # a second identical launch gives the bit-identical result (fixed-order split-K reduction; accumulate semantics -> 2x)
     dw2 = torch.zeros_like(dw)
@@ -147,8 +147,8 @@ def test_benchmark_instantiations_cover_the_big_tiles(dev):
     assert ops.conv_plan(0, N_FRAMES, 6, 6, 256, 3, 1, 1).label == "k_igemm_fwd_glds<128,128,2>"
     assert ops.conv_plan(2, N_FRAMES, 6, 6, 256, 3, 1, 1).label == "k_igemm_fwd_glds<128,128,2>"
     assert ops.conv_plan(0, N_FRAMES, 3, 3, 512, 3, 1, 1).label == "k_igemm_fwd_glds<128,64,2>"
-    assert ops.wgrad_plan(N_FRAMES * 36, 256, 256, 9, 9, False)[0] == 128
-    assert ops.wgrad_plan(N_FRAMES * 9, 512, 512, 9, 9, False)[0] == 128
+    assert ops.wgrad_conv_plan(N_FRAMES, 6, 6, 256, 256, 3, 1, 1).bc == 128
+    assert ops.wgrad_conv_plan(N_FRAMES, 3, 3, 512, 512, 3, 1, 1).bc == 128
 
 
 # (rows, K, N, gelu, bias): the linear layers of the LRW encoder + heads at 32 x 30 tokens, and the LRS ones at 16 x 150 frames
@@ -189,8 +189,8 @@ def test_linear_fwd_dgrad_wgrad_at_benchmark_rows(dev, rows, K, N, gelu, bias):
     dw = torch.zeros(N, K, device=dev)
     db = torch.zeros(N, device=dev)
     ops.linear_wgrad(x.to(dev), dyp.to(dev), dw, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=Npad, db=db)
-    bc, splits, _ = ops.wgrad_plan(rows, N, K, 1, 1, True)
-    _SEEN[f"linear {rows}x{K}->{N}.wgrad"] = f"k_igemm_wgrad<true,{bc}> x{splits} splits"
+    wp = ops.wgrad_rows_plan(rows, 1, 0, 0, K, N, True)
+    _SEEN[f"linear {rows}x{K}->{N}.wgrad"] = f"{wp.label} x{wp.splits} splits"
     check(dw, dy[:, :N].float().t() @ x.float(), "linear.wgrad", 3e-3, 2e-3)
     check(db, dy[:, :N].float().sum(0), "linear.bias_grad", 1e-2, 6e-3)
     dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
