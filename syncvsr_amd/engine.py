@@ -76,9 +76,10 @@ class TrainStep:
         # 20-40 us linear GEMMs that fill about half the chip each).  Under HIP-graph replay the forked branches cost more than
         # they hide (LRW 7.85 -> 8.5 ms, LRS 33.2 ms), so a captured step keeps everything in line.
         import os
-        model._side.enabled = (not use_graph) and os.environ.get("SVSR_SIDE_TRUNK", "1") != "0"
+        graph_side = os.environ.get("SVSR_GRAPH_SIDE", "0") == "1"
+        model._side.enabled = (not use_graph or graph_side) and os.environ.get("SVSR_SIDE_TRUNK", "1") != "0"
         if not self.is_lrw:
-            model._side.enabled_small = (not use_graph) and os.environ.get("SVSR_SIDE_ENCODER", "1") != "0"
+            model._side.enabled_small = (not use_graph or graph_side) and os.environ.get("SVSR_SIDE_ENCODER", "1") != "0"
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._static: Optional[list[torch.Tensor]] = None
         self._out: Optional[dict[str, torch.Tensor]] = None

@@ -32,27 +32,43 @@ class _SideStream:
     def __init__(self) -> None:
         self.stream: Optional[torch.cuda.Stream] = None
         self.keep: list = []
-        self.enabled = False     # set by engine.TrainStep: on for eager steps (7.39 vs 8.06 ms), off under graph replay (8.5 vs 7.85 ms)
+        self.pending: list = []
+        self.enabled = False     # set by engine.TrainStep
         # linear-layer weight gradients: neutral for the LRW encoder, a gain for the LRS linears (engine.TrainStep turns it on there)
         self.enabled_small = False
+        # launches are handed to the side stream in groups: every hand-over is one cross-stream dependency (an event record +
+        # wait: host time in eager mode, a cross-branch edge in a captured graph), and a weight gradient is in no hurry
+        self.group = int(os.environ.get("SVSR_SIDE_GROUP", "1"))     # measured (LRW, B = 32): eager 6.62 / 6.72 / 7.72 ms at 1 / 4 / all; graph 7.56 / 7.20 / 7.41
 
     def run(self, fn, *keep, small: bool = False) -> None:
+        """fn must not depend on variables that are rebound before flush() (bind them as arguments); the tensors it reads
+        must not be written in place before join()."""
         if not (self.enabled or (small and self.enabled_small)):
             fn()
+            return
+        self.pending.append(fn)
+        self.keep.extend(keep)
+        if len(self.pending) >= self.group:
+            self.flush()
+
+    def flush(self) -> None:
+        if not self.pending:
             return
         if self.stream is None:
             self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
-        # launches of fn() go to the side stream through ops.STREAM_OVERRIDE (fn allocates nothing on the device), which is
+        # launches go to the side stream through ops.STREAM_OVERRIDE (they allocate nothing on the device), which is
         # much cheaper on the host than entering a torch.cuda.stream() context per weight-gradient launch
         ops.STREAM_OVERRIDE = self.stream.cuda_stream
         try:
-            fn()
+            for fn in self.pending:
+                fn()
         finally:
             ops.STREAM_OVERRIDE = None
-        self.keep.extend(keep)
+            self.pending.clear()
 
     def join(self) -> None:
+        self.flush()
         if self.stream is not None and (self.enabled or self.enabled_small):
             torch.cuda.current_stream().wait_stream(self.stream)
         self.keep.clear()
@@ -468,10 +484,17 @@ def _conv_wgrad(model, st: "_ParamStore", conv: str, t: dict, dc: torch.Tensor, 
     model._side.run(lambda: ops.conv2d_wgrad(t["x"], dc, st.g32(f"{conv}.weight"), t["k"], t["stride"], t["pad"], use_tr), dc)
 
 
+def _lin_wgrad(model, x, dy, gw, gb, rows: int, K: int, N: int, x_pitch: int, dy_pitch: int) -> None:
+    """Weight (+ bias) gradient of an encoder linear layer, handed to the side stream (a function call, so that the deferred
+    launch sees THIS layer's tensors and not the loop variables of a later one)."""
+    model._side.run(lambda: ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=x_pitch, dy_pitch=dy_pitch, db=gb), x, dy, small=True)
+
+
 def _ready(model, st: "_ParamStore", name: Optional[str]) -> None:
     """Gradient-ready notification for bucketed all-reduce: everything at or above `name`'s offset in the decayed
     region is final (backward walks the flat buffer from its end to its start); None = all gradients final."""
     if model.grad_ready_hook is not None:     # (the reducer's comm stream waits for the side stream itself: engine.GradReducer._reduce)
+        model._side.flush()
         model.grad_ready_hook(0 if name is None else st.offsets[name][0])
 
 
@@ -512,19 +535,15 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
         t = tape[p]
         ds2 = ops.add_ln_bwd(dx, t["f"], t["x1"], st.p32(f"{p}.output.LayerNorm.weight"), t["m2"], t["r2"],
                              st.g32(f"{p}.output.LayerNorm.weight"), st.g32(f"{p}.output.LayerNorm.bias"))
-        side = model._side
-        side.run(lambda: ops.linear_wgrad(t["hg"], ds2, st.g32(f"{p}.output.dense.weight"), rows=R, K=I, N=D, x_pitch=I, dy_pitch=D, use_tr=use_tr,
-                                          db=st.g32(f"{p}.output.dense.bias")), ds2, small=True)
+        _lin_wgrad(model, t["hg"], ds2, st.g32(f"{p}.output.dense.weight"), st.g32(f"{p}.output.dense.bias"), R, I, D, I, D)
         dhg = ops.linear_dgrad(ds2, st.t16(f"{p}.output.dense.weight"), rows=R, N=D, K=I, dy_pitch=D)
         dz = ops.bias_act_bwd(dhg, t["z"], st.g32(f"{p}.intermediate.dense.bias"), R=R, N=I, n_valid=I, ld=I)
-        side.run(lambda: ops.linear_wgrad(t["x1"], dz, st.g32(f"{p}.intermediate.dense.weight"), rows=R, K=D, N=I, x_pitch=D, dy_pitch=I,
-                                          use_tr=use_tr), dz, small=True)
+        _lin_wgrad(model, t["x1"], dz, st.g32(f"{p}.intermediate.dense.weight"), None, R, D, I, D, I)
         # (not in place: the side stream may still be reading ds2 / ds1 for the weight gradients)
         dx1 = ops.linear_dgrad(dz, st.t16(f"{p}.intermediate.dense.weight"), rows=R, N=I, K=D, dy_pitch=I, addend=ds2)
         ds1 = ops.add_ln_bwd(dx1, t["ao"], t["x"], st.p32(f"{p}.attention.output.LayerNorm.weight"), t["m1"], t["r1"],
                              st.g32(f"{p}.attention.output.LayerNorm.weight"), st.g32(f"{p}.attention.output.LayerNorm.bias"))
-        side.run(lambda: ops.linear_wgrad(t["ctx"], ds1, st.g32(f"{p}.attention.output.dense.weight"), rows=R, K=D, N=D, x_pitch=D, dy_pitch=D,
-                                          use_tr=use_tr, db=st.g32(f"{p}.attention.output.dense.bias")), ds1, small=True)
+        _lin_wgrad(model, t["ctx"], ds1, st.g32(f"{p}.attention.output.dense.weight"), st.g32(f"{p}.attention.output.dense.bias"), R, D, D, D, D)
         dctx = ops.linear_dgrad(ds1, st.t16(f"{p}.attention.output.dense.weight"), rows=R, N=D, K=D, dy_pitch=D)
         qkv = t["qkv"]
         dqkv = torch.empty_like(qkv)
@@ -532,7 +551,7 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
                     dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D)
         gq = st.grad[st.offsets[f"{p}.attention.self.query.weight"][0] :][: 3 * D * D]
         gqb = st.grad[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
-        side.run(lambda: ops.linear_wgrad(t["x"], dqkv, gq, rows=R, K=D, N=3 * D, x_pitch=D, dy_pitch=3 * D, use_tr=use_tr, db=gqb), dqkv, small=True)
+        _lin_wgrad(model, t["x"], dqkv, gq, gqb, R, D, 3 * D, D, 3 * D)
         dx = ops.linear_dgrad(dqkv, st.t16(f"{p}.qkv"), rows=R, N=3 * D, K=D, dy_pitch=3 * D, addend=ds1)
         _ready(model, st, f"{p}.attention.self.query.weight")
     te = tape["emb"]
