@@ -157,10 +157,14 @@ int svsr_add_ln_fwd(const void* a, const void* r, const float* gamma, const floa
 int svsr_add_ln_bwd_rows(int R);
 int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd, void* ds, float* dgamma, float* dbeta, int R, int D, const void* addend, float* part, hipStream_t stream);
 
-/* BertEmbeddings on inputs_embeds = cat(cls_token, feats) (lightning.py:149-156): y = LN(e + pos[s] + type[0]).
- * feats bf16 [B][S-1][D]; sum_out bf16 [B*S][D] keeps the pre-norm sum for the backward (part: [S][D] float workspace). */
-int svsr_embed_ln_fwd(const void* feats, const float* cls, const float* pos, const float* type0, const float* gamma, const float* beta, void* sum_out, void* y, float* mean, float* rstd, int B, int S, int D, float eps, hipStream_t stream);
-int svsr_embed_bwd_scatter(const void* ds, void* dfeats, float* dcls, float* dpos, float* dtype0, int B, int S, int D, float* part, hipStream_t stream);
+/* BertEmbeddings on inputs_embeds = emb_dropout(cat(cls_token, feats)) (lightning.py:149-156):
+ * y = dropout_out(LN(dropout_in(e) + pos[s] + type[0])); dropout_in = the module's emb_dropout (site_in, p_in), dropout_out =
+ * BertEmbeddings' hidden dropout (site_out, p_out); both off when drop_seed is null or p = 0 (mask semantics: svsr_scale_bf16,
+ * element index = position in the [B*S][D] tensor).  feats bf16 [B][S-1][D]; sum_out bf16 [B*S][D] keeps the pre-norm sum for the
+ * backward.  svsr_embed_bwd_scatter takes ds = gradient of that sum and regenerates the dropout_in mask for dfeats / dcls
+ * (part: [S][D] float workspace). */
+int svsr_embed_ln_fwd(const void* feats, const float* cls, const float* pos, const float* type0, const float* gamma, const float* beta, void* sum_out, void* y, float* mean, float* rstd, int B, int S, int D, float eps, const unsigned* drop_seed, unsigned site_in, float p_in, unsigned site_out, float p_out, hipStream_t stream);
+int svsr_embed_bwd_scatter(const void* ds, void* dfeats, float* dcls, float* dpos, float* dtype0, int B, int S, int D, float* part, const unsigned* drop_seed, unsigned site_in, float p_in, hipStream_t stream);
 
 /* dz = dy * act'(z) when z != null: act 1 = GELU from the saved pre-activation (BertIntermediate), act 2 = ReLU from the
  * saved output (PositionwiseFeedForward; gscale = 1/(1-p) when that output went through dropout — dropped elements are

@@ -118,13 +118,43 @@ def forward_videos(videos: Tensor, sd: SD, training: bool, stats_out: dict | Non
 # --------------------------------------------------------------------------------------------
 # BERT-style encoder  (lightning.py:92,152-156; HF BertModel(inputs_embeds=...))
 # --------------------------------------------------------------------------------------------
-def bert_embeddings(x: Tensor, sd: SD, eps: float) -> Tensor:
+class DropPlan:
+    """Replays the HIP library's counter-based dropout masks (syncvsr_amd/dropout.py is the numpy twin of csrc/common.h's
+    drop_keep) so a training forward WITH dropout can be compared element for element: the reference's nn.Dropout modules
+    (lightning.py:45,150; HF BertEmbeddings / BertSelfAttention / BertSelfOutput / BertOutput dropouts, :92,152-156) draw from
+    torch's generator, which no other implementation can reproduce — sharing the mask is the only way to pin the arithmetic
+    around it.  Attention masks are indexed through the library's probability buffer (row pitch = keys padded to 8)."""
+
+    def __init__(self, seed: int, p_hidden: float, p_attn: float, p_emb: float, sites: dict[str, int]):
+        self.seed, self.p = int(seed), {"hidden": float(p_hidden), "attn": float(p_attn), "emb": float(p_emb)}
+        self.sites = sites
+
+    def __call__(self, x: Tensor, site: str, kind: str = "hidden") -> Tensor:
+        from syncvsr_amd.dropout import keep_mask
+
+        p = self.p[kind]
+        if p <= 0.0:
+            return x
+        if kind == "attn":
+            B, H, Lq, Lk = x.shape
+            pitch = (Lk + 7) // 8 * 8
+            m = keep_mask(self.seed, self.sites[site], p, B * H * Lq * pitch).reshape(B, H, Lq, pitch)[..., :Lk]
+        else:
+            m = keep_mask(self.seed, self.sites[site], p, x.numel()).reshape(tuple(x.shape))
+        return x * torch.from_numpy(m.copy()).to(x.dtype) / (1.0 - p)
+
+
+def _dp(dp, x: Tensor, site: str, kind: str = "hidden") -> Tensor:
+    return x if dp is None else dp(x, site, kind)
+
+
+def bert_embeddings(x: Tensor, sd: SD, eps: float, dp=None) -> Tensor:
     S = x.size(1)
     e = x + sd["encoder.embeddings.position_embeddings.weight"][:S] + sd["encoder.embeddings.token_type_embeddings.weight"][0]
-    return layer_norm(e, sd["encoder.embeddings.LayerNorm.weight"], sd["encoder.embeddings.LayerNorm.bias"], eps)
+    return _dp(dp, layer_norm(e, sd["encoder.embeddings.LayerNorm.weight"], sd["encoder.embeddings.LayerNorm.bias"], eps), "emb.out")
 
 
-def bert_layer(x: Tensor, sd: SD, p: str, heads: int, eps: float, keep: dict | None = None) -> Tensor:
+def bert_layer(x: Tensor, sd: SD, p: str, heads: int, eps: float, keep: dict | None = None, dp=None, i: int = 0) -> Tensor:
     B, S, D = x.shape
     dh = D // heads
 
@@ -135,25 +165,25 @@ def bert_layer(x: Tensor, sd: SD, p: str, heads: int, eps: float, keep: dict | N
     k = lin(x, "attention.self.key").view(B, S, heads, dh).transpose(1, 2)
     v = lin(x, "attention.self.value").view(B, S, heads, dh).transpose(1, 2)
     scores = q @ k.transpose(-1, -2) / math.sqrt(dh)
-    probs = torch.softmax(scores, dim=-1)
+    probs = _dp(dp, torch.softmax(scores, dim=-1), f"enc.{i}.attn.probs", "attn")
     ctx = (probs @ v).transpose(1, 2).reshape(B, S, D)
     if keep is not None:
         keep[f"{p}.ctx"] = ctx
-    x = layer_norm(lin(ctx, "attention.output.dense") + x, sd[f"{p}.attention.output.LayerNorm.weight"],
+    x = layer_norm(_dp(dp, lin(ctx, "attention.output.dense"), f"enc.{i}.attn.out") + x, sd[f"{p}.attention.output.LayerNorm.weight"],
                    sd[f"{p}.attention.output.LayerNorm.bias"], eps)
     h = gelu_erf(lin(x, "intermediate.dense"))
-    x = layer_norm(lin(h, "output.dense") + x, sd[f"{p}.output.LayerNorm.weight"], sd[f"{p}.output.LayerNorm.bias"], eps)
+    x = layer_norm(_dp(dp, lin(h, "output.dense"), f"enc.{i}.ff.out") + x, sd[f"{p}.output.LayerNorm.weight"], sd[f"{p}.output.LayerNorm.bias"], eps)
     return x
 
 
-def bert_encoder(x: Tensor, sd: SD, cfg: Any, keep: dict | None = None) -> Tensor:
+def bert_encoder(x: Tensor, sd: SD, cfg: Any, keep: dict | None = None, dp=None) -> Tensor:
     bert = cfg.model.bert
     eps = float(bert.get("layer_norm_eps", 1e-12))
-    x = bert_embeddings(x, sd, eps)
+    x = bert_embeddings(x, sd, eps, dp)
     if keep is not None:
         keep["emb"] = x
     for i in range(int(bert.num_hidden_layers)):
-        x = bert_layer(x, sd, f"encoder.encoder.layer.{i}", int(bert.num_attention_heads), eps, keep)
+        x = bert_layer(x, sd, f"encoder.encoder.layer.{i}", int(bert.num_attention_heads), eps, keep, dp, i)
     return x
 
 
@@ -181,8 +211,9 @@ def audio_dims(cfg: Any) -> tuple[int, int, int]:
 
 def forward(sd: SD, cfg: Any, videos: Tensor, audio_tokens: Tensor, labels: Tensor, word_mask: Tensor,
             training: bool = True, use_cutmix_metric: bool = False, keep: dict | None = None,
-            stats_out: dict | None = None) -> dict[str, Tensor]:
-    """TransformerLightningModule.forward (lightning.py:133-191) with dropout p = 0."""
+            stats_out: dict | None = None, dp=None) -> dict[str, Tensor]:
+    """TransformerLightningModule.forward (lightning.py:133-191); dropout only through `dp` (a DropPlan replaying the
+    library's masks), otherwise p = 0."""
     A, G, V = audio_dims(cfg)
     feats = forward_videos(videos, sd, training, stats_out, keep)                      # :136
     if keep is not None:
@@ -191,8 +222,8 @@ def forward(sd: SD, cfg: Any, videos: Tensor, audio_tokens: Tensor, labels: Tens
         feats = torch.cat((feats, word_mask.unsqueeze(-1).to(feats.dtype)), dim=-1)
     B, T, D = feats.shape
     audio_tokens = audio_tokens[:, : T * A]                                              # :148
-    x = torch.cat((sd["cls_token"].expand(B, -1, -1), feats), dim=1)                     # :149-150
-    h = bert_encoder(x, sd, cfg, keep)                                                   # :152-156
+    x = _dp(dp, torch.cat((sd["cls_token"].expand(B, -1, -1), feats), dim=1), "emb.in", "emb")      # :149-150
+    h = bert_encoder(x, sd, cfg, keep, dp)                                               # :152-156
     logits_category = F.linear(h[:, 0], sd["category_classifier.weight"], sd["category_classifier.bias"]).float()
     loss_category = cross_entropy(logits_category, labels, float(cfg.train.label_smoothing))     # :161-165
     logits_audio = F.linear(h[:, 1:], sd["audio_projection.weight"], sd["audio_projection.bias"]).float()

@@ -134,8 +134,13 @@ __global__ __launch_bounds__(256) void k_embed_ln_fwd(const bf16_t* __restrict__
                                                       const float* __restrict__ pos, const float* __restrict__ type0,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       bf16_t* __restrict__ sum_out, bf16_t* __restrict__ y,
-                                                      float* __restrict__ mean, float* __restrict__ rstd, int B, int S, int D, float eps) {
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int B, int S, int D, float eps,
+                                                      DropArgs din, DropArgs dout) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // emb_dropout on cat(cls, feats) (lightning.py:150) and BertEmbeddings' dropout on the LayerNorm output: element index =
+    // position in the [B*S][D] tensor
+    const bool on_in = din.seed != nullptr, on_out = dout.seed != nullptr;
+    const unsigned key_in = on_in ? drop_key(din) : 0u, key_out = on_out ? drop_key(dout) : 0u;
     // lane owns columns (i*64 + lane)*8 .. +7 for i < LN_MAXV; any D % 8 == 0 up to 2048 (512 BERT, 768 Conformer)
     const int R = B * S;
     for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
@@ -152,6 +157,10 @@ __global__ __launch_bounds__(256) void k_embed_ln_fwd(const bf16_t* __restrict__
                     for (int k = 0; k < 8; ++k) e[k] = bf2f(f2bf(cls[c0 + k]));   // the encoder input is a bf16 tensor
                 } else {
                     unpack8(reinterpret_cast<const u32x4*>(feats)[(((long)b * (S - 1) + s_ - 1) * D + c0) >> 3], e);
+                }
+                if (on_in) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e[k] = drop_keep(key_in, din.thresh, (unsigned)((long)row * D + c0 + k)) ? e[k] * din.scale : 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -177,6 +186,10 @@ __global__ __launch_bounds__(256) void k_embed_ln_fwd(const bf16_t* __restrict__
                 float o[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) o[k] = (v[i][k] - mu) * rs * gamma[c0 + k] + beta[c0 + k];
+                if (on_out) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = drop_keep(key_out, dout.thresh, (unsigned)((long)row * D + c0 + k)) ? o[k] * dout.scale : 0.f;
+                }
                 reinterpret_cast<u32x4*>(y)[((long)row * D + c0) >> 3] = pack8(o);
             }
         }
@@ -189,27 +202,37 @@ __global__ __launch_bounds__(256) void k_embed_ln_fwd(const bf16_t* __restrict__
 // One thread per 8 columns, loops over the batch.
 __global__ __launch_bounds__(256) void k_embed_bwd_scatter(const bf16_t* __restrict__ ds, bf16_t* __restrict__ dfeats,
                                                            float* __restrict__ dcls, float* __restrict__ dpos,
-                                                           float* __restrict__ part, int B, int S, int D) {
+                                                           float* __restrict__ part, int B, int S, int D, DropArgs din) {
+    const bool on_in = din.seed != nullptr;          // emb_dropout mask of the forward, regenerated: applies to dfeats / dcls only
+    const unsigned key_in = on_in ? drop_key(din) : 0u;
     const int cv = D >> 3;
     const int idx = blockIdx.x * 256 + threadIdx.x;       // over S * cv
     if (idx >= S * cv) return;
     const int s_ = idx / cv, c0 = (idx - s_ * cv) * 8;
-    float acc[8];
+    float acc[8], accm[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int k = 0; k < 8; ++k) { acc[k] = 0.f; accm[k] = 0.f; }
     for (int b = 0; b < B; ++b) {
-        const u32x4 raw = reinterpret_cast<const u32x4*>(ds)[(((long)b * S + s_) * D + c0) >> 3];
+        const long e0 = ((long)b * S + s_) * D + c0;
+        u32x4 raw = reinterpret_cast<const u32x4*>(ds)[e0 >> 3];
         float f[8];
         unpack8(raw, f);
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] += f[k];
+        if (on_in) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = drop_keep(key_in, din.thresh, (unsigned)(e0 + k)) ? f[k] * din.scale : 0.f;
+            raw = pack8(f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) accm[k] += f[k];
         if (s_ > 0) reinterpret_cast<u32x4*>(dfeats)[(((long)b * (S - 1) + s_ - 1) * D + c0) >> 3] = raw;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         dpos[(long)s_ * D + c0 + k] += acc[k];              // each (s, c) is owned by exactly one thread
         part[(long)s_ * D + c0 + k] = acc[k];
-        if (s_ == 0) dcls[c0 + k] += acc[k];
+        if (s_ == 0) dcls[c0 + k] += accm[k];
     }
 }
 
@@ -301,20 +324,21 @@ int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* g
 
 int svsr_embed_ln_fwd(const void* feats, const float* cls, const float* pos, const float* type0, const float* gamma,
                       const float* beta, void* sum_out, void* y, float* mean, float* rstd, int B, int S, int D, float eps,
-                      hipStream_t stream) {
+                      const unsigned* drop_seed, unsigned site_in, float p_in, unsigned site_out, float p_out, hipStream_t stream) {
     if (D % 512 != 0 || D > 512 * LN_MAXV || S < 2) return SVSR_ERR_ARG;
     int grid = (B * S + 3) / 4; if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(k_embed_ln_fwd, dim3(grid), dim3(256), 0, stream, (const bf16_t*)feats, cls, pos, type0, gamma, beta,
-                       (bf16_t*)sum_out, (bf16_t*)y, mean, rstd, B, S, D, eps);
+                       (bf16_t*)sum_out, (bf16_t*)y, mean, rstd, B, S, D, eps, svsr_make_drop(drop_seed, site_in, p_in),
+                       svsr_make_drop(drop_seed, site_out, p_out));
     return svsr_check_launch();
 }
 
 int svsr_embed_bwd_scatter(const void* ds, void* dfeats, float* dcls, float* dpos, float* dtype0, int B, int S, int D, float* part,
-                           hipStream_t stream) {
+                           const unsigned* drop_seed, unsigned site_in, float p_in, hipStream_t stream) {
     if (D % 8 != 0 || part == nullptr) return SVSR_ERR_ARG;       // part: [S][D] floats
     const int n = S * (D / 8);
     hipLaunchKernelGGL(k_embed_bwd_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)ds, (bf16_t*)dfeats, dcls,
-                       dpos, part, B, S, D);
+                       dpos, part, B, S, D, svsr_make_drop(drop_seed, site_in, p_in));
     const int rc = svsr_check_launch();
     if (rc != SVSR_OK) return rc;
     return svsr_colsum_rows(part, S, D, dtype0, D, nullptr, 0, 1, 1.0f, stream);

@@ -1,5 +1,5 @@
 """Host-side twin of the library's counter-based dropout (csrc/common.h: `drop_key`, `drop_keep`) and the numbering of the
-LRS model's dropout sites.  The product path only uses `lrs_sites`; `keep_mask` exists so that parity tests (and the
+LRW / LRS models' dropout sites.  The product path only uses `lrw_sites` / `lrs_sites`; `keep_mask` exists so that parity tests (and the
 oracle) can replay exactly the masks the kernels generate.
 
 keep(i) <=> mix(i * 2654435761 + key) >= p * 2^32,   key = mix(seed * 0x9E3779B9 + site * 0x7F4A7C15 + 0x165667B1),
@@ -29,6 +29,16 @@ def keep_mask(seed: int, site: int, p: float, numel: int) -> np.ndarray:
     h = _mix((idx * np.uint64(2654435761) + key) & _M)
     thresh = min(int(p * 4294967296.0), 4294967295)
     return h >= np.uint64(thresh)
+
+
+def lrw_sites(layers: int) -> dict[str, int]:
+    """Stable site ids of every nn.Dropout the LRW training forward executes with the `type: huggingface` encoder:
+    `emb_dropout_bert` on cat(cls, feats) (reference LRW/video/src/lightning.py:45,150); HF BertEmbeddings.dropout,
+    BertSelfAttention.dropout (attention probabilities), BertSelfOutput.dropout and BertOutput.dropout (lightning.py:92,152-156)."""
+    names = ["emb.in", "emb.out"]
+    for i in range(layers):
+        names += [f"enc.{i}.{s}" for s in ("attn.probs", "attn.out", "ff.out")]
+    return {n: k + 1 for k, n in enumerate(names)}
 
 
 def lrs_sites(elayers: int, dlayers: int) -> dict[str, int]:

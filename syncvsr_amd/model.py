@@ -126,10 +126,17 @@ class TransformerLightningModule(nn.Module):
         self.layers = int(bert.num_hidden_layers)
         self.inter = int(bert.intermediate_size)
         self.ln_eps = float(bert.get("layer_norm_eps", 1e-12))
-        # missing keys take the reference's defaults: emb_dropout is read directly (lightning.py:45); the other two are
-        # BertConfig(**config.model.bert) defaults, 0.1 each (lightning.py:92)
-        if float(bert.get("emb_dropout", 0.0)) or float(bert.get("hidden_dropout_prob", 0.1)) or float(bert.get("attention_probs_dropout_prob", 0.1)):
-            raise NotImplementedError("dropout > 0 is not implemented in the HIP path yet (BASELINE configs use p = 0)")
+        # Dropout.  Missing keys take the reference's defaults: emb_dropout is read directly (lightning.py:45); the other two are
+        # BertConfig(**config.model.bert) defaults, 0.1 each (lightning.py:92).  Masks are counter based (csrc/common.h): element i
+        # of site s is kept iff hash(seed, s, i) >= p * 2^32; the seed is a device word advanced once per training forward.
+        from .dropout import lrw_sites
+
+        self.emb_drop_p = float(bert.get("emb_dropout", 0.0))
+        self.drop_p = float(bert.get("hidden_dropout_prob", 0.1))
+        self.attn_drop_p = float(bert.get("attention_probs_dropout_prob", 0.1))
+        self._sites = lrw_sites(self.layers)
+        self.dropout_seed = 0 if seed is None else int(seed)
+        self._drop_word: Optional[torch.Tensor] = None
         if self.dim % 512 or self.dim // self.heads != 64:
             raise NotImplementedError("encoder width must be a multiple of 512 with 64-wide heads")
 
@@ -169,6 +176,22 @@ class TransformerLightningModule(nn.Module):
         if self.config.train.use_cutmix:
             batch = self.cutmix(*batch)
         return self(*batch)["loss_total"]
+
+    def _advance_dropout(self, dev: torch.device) -> None:
+        if self._drop_word is None or self._drop_word.device != dev:
+            self._drop_word = torch.tensor([self.dropout_seed], dtype=torch.int32, device=dev)
+        self._drop_word.add_(1)                   # a device op: graph replays keep drawing fresh masks
+
+    def reseed_dropout(self, seed: int) -> None:
+        self.dropout_seed = int(seed)
+        self._drop_word = None
+
+    def _d(self, site: str, kind: str = "hidden"):
+        """(seed word, site id, p) for ops.*(drop=...) or None when dropout is off (eval mode / p = 0)."""
+        p = {"hidden": self.drop_p, "attn": self.attn_drop_p, "emb": self.emb_drop_p}[kind]
+        if not self.training or p <= 0.0:
+            return None
+        return (self._drop_word, self._sites[site], p)
 
     def mark_params_dirty(self) -> None:
         """Call after changing parameters outside engine.TrainStep (load_state_dict does it): the bf16 shadows are re-cast."""
@@ -503,24 +526,26 @@ def _encoder_forward(model: TransformerLightningModule, st: _ParamStore, tape: d
     R = B * S
     pos = st.p32("encoder.embeddings.position_embeddings.weight")
     type0 = st.p32("encoder.embeddings.token_type_embeddings.weight")
+    d_in, d_out = model._d("emb.in", "emb"), model._d("emb.out")
     s0, x, mean0, rstd0 = ops.embed_ln_fwd(feats, st.p32("cls_token"), pos, type0, st.p32("encoder.embeddings.LayerNorm.weight"),
-                                           st.p32("encoder.embeddings.LayerNorm.bias"), B, S, D, model.ln_eps)
-    tape["emb"] = dict(sum=s0, mean=mean0, rstd=rstd0)
+                                           st.p32("encoder.embeddings.LayerNorm.bias"), B, S, D, model.ln_eps, drop_in=d_in, drop_out=d_out)
+    tape["emb"] = dict(sum=s0, mean=mean0, rstd=rstd0, d_in=d_in, d_out=d_out)
     for i in range(model.layers):
         p = f"encoder.encoder.layer.{i}"
         wqkv = st.s16(f"{p}.attention.self.query.weight", 3 * D * D)
         bqkv = st.flat[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
         qkv, _ = ops.linear_fwd(x, wqkv, bqkv, rows=R, K=D, N=3 * D, x_pitch=D)
-        ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=S, Lk=S)      # csrc/mha.hip
+        dpr, dao, dfo = model._d(f"enc.{i}.attn.probs", "attn"), model._d(f"enc.{i}.attn.out"), model._d(f"enc.{i}.ff.out")
+        ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=S, Lk=S, drop=dpr)      # csrc/mha.hip
         ao, _ = ops.linear_fwd(ctx, st.s16(f"{p}.attention.output.dense.weight"), st.p32(f"{p}.attention.output.dense.bias"),
-                               rows=R, K=D, N=D, x_pitch=D)
+                               rows=R, K=D, N=D, x_pitch=D, drop=dao)                      # BertSelfOutput: dropout(dense(ctx))
         x1, m1, r1 = ops.add_ln_fwd(ao, x, st.p32(f"{p}.attention.output.LayerNorm.weight"), st.p32(f"{p}.attention.output.LayerNorm.bias"), model.ln_eps)
         hg, z = ops.linear_fwd(x1, st.s16(f"{p}.intermediate.dense.weight"), st.p32(f"{p}.intermediate.dense.bias"),
                                rows=R, K=D, N=model.inter, x_pitch=D, gelu=True)
         f, _ = ops.linear_fwd(hg, st.s16(f"{p}.output.dense.weight"), st.p32(f"{p}.output.dense.bias"), rows=R, K=model.inter, N=D,
-                              x_pitch=model.inter)
+                              x_pitch=model.inter, drop=dfo)                               # BertOutput: dropout(dense(h))
         x2, m2, r2 = ops.add_ln_fwd(f, x1, st.p32(f"{p}.output.LayerNorm.weight"), st.p32(f"{p}.output.LayerNorm.bias"), model.ln_eps)
-        tape[p] = dict(x=x, qkv=qkv, ctx=ctx, probs=probs, ao=ao, x1=x1, m1=m1, r1=r1, z=z, hg=hg, f=f, m2=m2, r2=r2)
+        tape[p] = dict(x=x, qkv=qkv, ctx=ctx, probs=probs, ao=ao, x1=x1, m1=m1, r1=r1, z=z, hg=hg, f=f, m2=m2, r2=r2, dpr=dpr, dao=dao, dfo=dfo)
         x = x2
     return x
 
@@ -535,30 +560,35 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
         t = tape[p]
         ds2 = ops.add_ln_bwd(dx, t["f"], t["x1"], st.p32(f"{p}.output.LayerNorm.weight"), t["m2"], t["r2"],
                              st.g32(f"{p}.output.LayerNorm.weight"), st.g32(f"{p}.output.LayerNorm.bias"))
-        _lin_wgrad(model, t["hg"], ds2, st.g32(f"{p}.output.dense.weight"), st.g32(f"{p}.output.dense.bias"), R, I, D, I, D)
-        dhg = ops.linear_dgrad(ds2, st.t16(f"{p}.output.dense.weight"), rows=R, N=D, K=I, dy_pitch=D)
+        # ds2 is the gradient of (dropout(f) + x1): the dense layer sees it through the regenerated mask, the skip path as it is
+        df = ds2 if t["dfo"] is None else ops.scale_bf16(ds2, 1.0, drop=t["dfo"])
+        _lin_wgrad(model, t["hg"], df, st.g32(f"{p}.output.dense.weight"), st.g32(f"{p}.output.dense.bias"), R, I, D, I, D)
+        dhg = ops.linear_dgrad(df, st.t16(f"{p}.output.dense.weight"), rows=R, N=D, K=I, dy_pitch=D)
         dz = ops.bias_act_bwd(dhg, t["z"], st.g32(f"{p}.intermediate.dense.bias"), R=R, N=I, n_valid=I, ld=I)
         _lin_wgrad(model, t["x1"], dz, st.g32(f"{p}.intermediate.dense.weight"), None, R, D, I, D, I)
         # (not in place: the side stream may still be reading ds2 / ds1 for the weight gradients)
         dx1 = ops.linear_dgrad(dz, st.t16(f"{p}.intermediate.dense.weight"), rows=R, N=I, K=D, dy_pitch=I, addend=ds2)
         ds1 = ops.add_ln_bwd(dx1, t["ao"], t["x"], st.p32(f"{p}.attention.output.LayerNorm.weight"), t["m1"], t["r1"],
                              st.g32(f"{p}.attention.output.LayerNorm.weight"), st.g32(f"{p}.attention.output.LayerNorm.bias"))
-        _lin_wgrad(model, t["ctx"], ds1, st.g32(f"{p}.attention.output.dense.weight"), st.g32(f"{p}.attention.output.dense.bias"), R, D, D, D, D)
-        dctx = ops.linear_dgrad(ds1, st.t16(f"{p}.attention.output.dense.weight"), rows=R, N=D, K=D, dy_pitch=D)
+        dao_ = ds1 if t["dao"] is None else ops.scale_bf16(ds1, 1.0, drop=t["dao"])
+        _lin_wgrad(model, t["ctx"], dao_, st.g32(f"{p}.attention.output.dense.weight"), st.g32(f"{p}.attention.output.dense.bias"), R, D, D, D, D)
+        dctx = ops.linear_dgrad(dao_, st.t16(f"{p}.attention.output.dense.weight"), rows=R, N=D, K=D, dy_pitch=D)
         qkv = t["qkv"]
         dqkv = torch.empty_like(qkv)
         ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, t["probs"], B=B, H=H, Lq=S, Lk=S, dq=dqkv, dq_pitch=3 * D,
-                    dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D)
+                    dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, drop=t["dpr"])
         gq = st.grad[st.offsets[f"{p}.attention.self.query.weight"][0] :][: 3 * D * D]
         gqb = st.grad[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
         _lin_wgrad(model, t["x"], dqkv, gq, gqb, R, D, 3 * D, D, 3 * D)
         dx = ops.linear_dgrad(dqkv, st.t16(f"{p}.qkv"), rows=R, N=3 * D, K=D, dy_pitch=3 * D, addend=ds1)
         _ready(model, st, f"{p}.attention.self.query.weight")
     te = tape["emb"]
+    if te["d_out"] is not None:
+        dx = ops.scale_bf16(dx, 1.0, drop=te["d_out"])
     ds0 = ops.add_ln_bwd(dx, te["sum"], None, st.p32("encoder.embeddings.LayerNorm.weight"), te["mean"], te["rstd"],
                          st.g32("encoder.embeddings.LayerNorm.weight"), st.g32("encoder.embeddings.LayerNorm.bias"))
     dfeats = ops.embed_bwd_scatter(ds0, st.g32("cls_token"), st.g32("encoder.embeddings.position_embeddings.weight"),
-                                   st.g32("encoder.embeddings.token_type_embeddings.weight"), B, S, D)
+                                   st.g32("encoder.embeddings.token_type_embeddings.weight"), B, S, D, drop_in=te["d_in"])
     _ready(model, st, "cls_token")
     return dfeats
 
@@ -575,6 +605,8 @@ class _LrwFunction(torch.autograd.Function):
         A, G, V = model.audio_alignment, model.vq_groups, model.audio_vocab_size
         if not st.shadow_fresh:          # engine.TrainStep keeps the bf16 shadows current from its optimiser kernel
             st.refresh_shadows()
+        if training and (model.drop_p > 0.0 or model.attn_drop_p > 0.0 or model.emb_drop_p > 0.0):
+            model._advance_dropout(videos.device)
         tape: dict[str, Any] = {}
         feats = _frontend_forward(model, st, tape, videos, training)
         h = _encoder_forward(model, st, tape, feats, B, T)              # [B*S, D] bf16

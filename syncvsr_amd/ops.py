@@ -487,20 +487,25 @@ def add_ln_bwd(dy, a, r, gamma, mean, rstd, dgamma, dbeta, addend=None, out=None
     return ds
 
 
-def embed_ln_fwd(feats, cls, pos, type0, gamma, beta, B: int, S: int, D: int, eps: float):
+def embed_ln_fwd(feats, cls, pos, type0, gamma, beta, B: int, S: int, D: int, eps: float, drop_in=None, drop_out=None):
+    """drop_in / drop_out = (seed word, site, p) of emb_dropout and BertEmbeddings' dropout (same seed word), or None."""
     dev = feats.device
+    seed = (drop_in or drop_out or (None,))[0]
+    si, pi = (drop_in[1], drop_in[2]) if drop_in is not None else (0, 0.0)
+    so, po = (drop_out[1], drop_out[2]) if drop_out is not None else (0, 0.0)
     s = torch.empty((B * S, D), dtype=BF16, device=dev)
     y = torch.empty((B * S, D), dtype=BF16, device=dev)
     mean = torch.empty(B * S, dtype=torch.float32, device=dev)
     rstd = torch.empty(B * S, dtype=torch.float32, device=dev)
     _call("svsr_embed_ln_fwd", _p(feats), _p(cls), _p(pos), _p(type0), _p(gamma), _p(beta), _p(s), _p(y), _p(mean), _p(rstd), B, S, D,
-          eps, _stream())
+          eps, _p(seed), int(si), float(pi), int(so), float(po), _stream())
     return s, y, mean, rstd
 
 
-def embed_bwd_scatter(ds, dcls, dpos, dtype0, B: int, S: int, D: int) -> torch.Tensor:
+def embed_bwd_scatter(ds, dcls, dpos, dtype0, B: int, S: int, D: int, drop_in=None) -> torch.Tensor:
     dfeats = torch.empty((B * (S - 1), D), dtype=BF16, device=ds.device)
-    _call("svsr_embed_bwd_scatter", _p(ds), _p(dfeats), _p(dcls), _p(dpos), _p(dtype0), B, S, D, _p(scratch(S * D)), _stream())
+    _call("svsr_embed_bwd_scatter", _p(ds), _p(dfeats), _p(dcls), _p(dpos), _p(dtype0), B, S, D, _p(scratch(S * D)), *_drop(drop_in),
+          _stream())
     return dfeats
 
 

@@ -152,6 +152,57 @@ def test_benchmark_batch_matches_oracle_and_reference_golden(dev):
         assert rel(dict(model.named_buffers())[n], stats[n]) <= 1e-2, n
 
 
+def test_dropout_matches_oracle_with_shared_masks(dev):
+    """Training forward/backward with emb_dropout 0.05, hidden dropout 0.1, attention dropout 0.15 (HF BertConfig's defaults are
+    0.1 / 0.1): the oracle replays the library's counter-based masks (oracle.lrw_oracle.DropPlan), so losses and gradients must
+    agree as tightly as without dropout; masks change from step to step and eval mode draws none."""
+    from oracle import lrw_oracle as O
+    from syncvsr_amd.dropout import keep_mask, lrw_sites
+    from syncvsr_amd.model import Model
+
+    cfg, sd, batch, training, gold = build_case("lrw_full_b2")
+    cfg = cfg.copy()
+    cfg.model.bert.emb_dropout, cfg.model.bert.hidden_dropout_prob, cfg.model.bert.attention_probs_dropout_prob = 0.05, 0.1, 0.15
+    model = Model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).train()
+    model.reseed_dropout(41)
+    gb = [t.to(dev) for t in batch]
+    out = model(*gb)
+    out["loss_total"].backward()
+    torch.cuda.synchronize()
+    assert int(model._drop_word.item()) == 42
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    dp = O.DropPlan(42, 0.1, 0.15, 0.05, lrw_sites(int(cfg.model.bert.num_hidden_layers)))
+    keep = {}
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref = O.forward(osd, cfg, *batch, training=True, keep=keep, dp=dp)
+    ref["loss_total"].backward()
+    nodrop = O.forward(sd, cfg, *batch, training=True)
+    for k in ("loss_total", "loss_category", "loss_audio"):
+        assert abs(out[k].item() - ref[k].item()) <= 2e-3 * abs(ref[k].item()), (k, out[k].item(), ref[k].item())
+    assert abs(ref["loss_audio"].item() - nodrop["loss_audio"].item()) > 1e-4 * abs(nodrop["loss_audio"].item()), "dropout had no effect"
+    a, b = model._last["hidden"].float().cpu().flatten(), keep["hidden"].flatten()
+    assert float((a - b).norm() / b.norm()) <= 7e-2
+    coss = []
+    for n, p in model.named_parameters():
+        if n.startswith(("resnet.", "stem3d.")):
+            continue                                   # below the encoder the comparison is the dropout-free one (bf16 ReLU-mask noise)
+        g, r = p.grad.detach().float().cpu().flatten(), osd[n].grad.flatten()
+        if r.norm() > 1e-6:
+            coss.append((float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)), n))
+    coss.sort()
+    print("worst encoder/head cosines with dropout:", coss[:5])
+    assert coss[0][0] >= 0.985 and coss[len(coss) // 2][0] >= 0.997, coss[:5]
+    out2 = model(*gb)
+    assert int(model._drop_word.item()) == 43 and abs(out2["loss_total"].item() - out["loss_total"].item()) > 1e-5
+    model.eval()
+    e1, e2 = model(*gb)["loss_total"].item(), model(*gb)["loss_total"].item()
+    assert e1 == e2 and int(model._drop_word.item()) == 43
+    m = keep_mask(42, 3, 0.1, 200000)
+    assert abs(m.mean() - 0.9) < 3e-3
+
+
 def test_eval_mode_matches_oracle(dev):
     cfg, model, out, osd, ref, keep, stats, gold = _run_pair("lrw_tiny_eval", dev)
     for k in ("loss_total", "loss_category", "loss_audio"):

@@ -81,8 +81,14 @@ def test_unsupported_configs_raise():
         Model(default_lrw_config(model__bert__type="x-transformers"))
     with pytest.raises(NotImplementedError):
         Model(default_lrw_config(data__use_word_boundary=True))
-    with pytest.raises(NotImplementedError):
-        Model(default_lrw_config(model__bert__hidden_dropout_prob=0.1))
+    # dropout is supported; keys a reference-style config omits take the reference's defaults (BertConfig: 0.1 / 0.1;
+    # emb_dropout is read directly and must be present, lightning.py:45,92)
+    cfg = default_lrw_config()
+    del cfg.model.bert["hidden_dropout_prob"], cfg.model.bert["attention_probs_dropout_prob"]
+    m = Model(cfg)
+    assert (m.drop_p, m.attn_drop_p, m.emb_drop_p) == (0.1, 0.1, 0.0)
+    m = Model(default_lrw_config(model__bert__hidden_dropout_prob=0.2, model__bert__emb_dropout=0.3))
+    assert (m.drop_p, m.attn_drop_p, m.emb_drop_p) == (0.2, 0.0, 0.3)
 
 
 def test_param_store_layout_on_cpu():
