@@ -198,7 +198,16 @@ def main() -> None:
         cfg = lrs_train_config()
         model = E2E(LRS_ODIM, lrs_args, seed=0).to(dev).train()
         model.reseed_dropout(1000 + rank)
-        cpu_batch = lrs_synthetic_batch(lrs_args, args.batch, args.frames, seed=1234 + rank, min_len_frac=0.3)
+        # BASELINE configs[4]: length-bucketed batches — every rank draws its clips from the same length bucket, so all ranks pad
+        # to the same number of frames in a step (syncvsr_amd/lrs_data.py; the hook is reference datamodule/data_module.py:66-74)
+        from syncvsr_amd.lrs_data import LengthBucketBatchSampler, reference_length_histogram
+
+        pool = reference_length_histogram(4096, seed=7) * args.frames // 155            # the reference's length histogram, rescaled to --frames
+        sampler = LengthBucketBatchSampler(pool, args.batch, world, rank, width=16, seed=11)
+        step_idx = max(range(len(sampler)), key=lambda i: sampler.padded_frames()[i])   # time the longest bucket (the padded length --frames names)
+        mine = list(sampler)[step_idx]
+        args.frames = sampler.padded_frames()[step_idx]
+        cpu_batch = lrs_synthetic_batch(lrs_args, args.batch, args.frames, seed=1234 + rank, lengths=pool[mine])
         batch = [t.to(dev) for t in cpu_batch]
         n_frames = int(cpu_batch[1].sum())
         label_len = cpu_batch[3].shape[-1]

@@ -183,13 +183,18 @@ def lrs_init_state_dict(args: Config, odim: int = LRS_ODIM, seed: int = 0, pertu
 
 
 def lrs_synthetic_batch(args: Config, batch: int, t_max: int, odim: int = LRS_ODIM, size: int = 88, seed: int = 1234,
-                        min_len_frac: float = 0.5, label_len: tuple[int, int] = (5, 40)):
+                        min_len_frac: float = 0.5, label_len: tuple[int, int] = (5, 40), lengths=None):
     """SURVEY §8(d) LRS inputs: x [B,T,1,H,W] N(0,1) zero-padded past each length; lengths in [min_len_frac·T, T]
-    (first clip full length); audio tokens [B, A·T, G]; targets in [1, odim-2] with length U{lo..hi}, padded with -1."""
+    (first clip full length) unless `lengths` (<= t_max, e.g. one step of lrs_data.LengthBucketBatchSampler) is given;
+    audio tokens [B, A·T, G]; targets in [1, odim-2] with length U{lo..hi}, padded with -1."""
     g = torch.Generator(device="cpu").manual_seed(int(seed))
     A, G, V = lrs_audio_dims(args)
-    lengths = torch.randint(max(1, int(t_max * min_len_frac)), t_max + 1, (batch,), generator=g)
-    lengths[0] = t_max
+    if lengths is not None:
+        lengths = torch.as_tensor(lengths, dtype=torch.long).clone()
+        assert lengths.numel() == batch and int(lengths.max()) <= t_max
+    else:
+        lengths = torch.randint(max(1, int(t_max * min_len_frac)), t_max + 1, (batch,), generator=g)
+        lengths[0] = t_max
     x = torch.randn(batch, t_max, 1, size, size, generator=g)
     for b in range(batch):
         x[b, int(lengths[b]):] = 0.0
