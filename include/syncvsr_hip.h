@@ -195,6 +195,12 @@ int svsr_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
 int svsr_transpose_cast_multi(const float* src, void* dst, const void* table, int n_entries, hipStream_t stream);
 int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream);
 
+/* Device-side input pipeline (reference LRW/video/src/data.py:150,157-171: x/255 -> RandomHorizontalFlip ->
+ * RandomResizedCrop | CenterCrop -> Normalize(0.421, 0.165)): stored uint8 clips [B][T][Hs][Ws] -> fp32 model input
+ * [B][1][T][H][W].  params: device int32 [B][5] = {top, left, h, w, flip} chosen by the host per clip; the window is resized to
+ * H x W with bilinear sampling (align_corners = False, no antialias; a window of exactly H x W is a plain crop). */
+int svsr_clip_prep(const void* src_u8, const int* params, float* dst, int B, int T, int Hs, int Ws, int H, int W, float mean, float std, hipStream_t stream);
+
 /* ---- LRS (E2E: Conformer encoder + CTC / attention decoder) -----------------------------------------------------
  * Multi-head attention with 64-wide heads (mha.hip).  q rows [B*Lq] with pitch q_pitch (head h at column h*64), k/v rows
  * [B*Lk] with pitch kv_pitch; klen[b] = number of valid keys (null: all), causal != 0 masks j > i.  With pe != null the

@@ -82,26 +82,86 @@ class CutMix(torch.nn.Module):
         return mixed_videos, mixed_audios, mixed_labels, mixed_word_mask
 
 
+def draw_time_runs(n_frames: int, max_run, n_mask: int) -> list[tuple[int, int]]:
+    """(start, length) of every masked run, drawn from Python's `random` with the two calls per mask the reference makes
+    (LRW/video/src/augment.py:130-132): the run length first, then where it starts."""
+    import random
+
+    runs = []
+    for _ in range(n_mask):
+        length = random.randint(0, min(max_run, n_frames))
+        runs.append((random.randint(0, n_frames - length), length))
+    return runs
+
+
 class TimeMask(torch.nn.Module):
     """The reference's TimeMask (LRW/video/src/augment.py:120-141; `train.use_timemask`, T = 0.6 * 25 frames, one mask):
-    a random run of up to T frames of one clip [T, ...] is replaced by the clip's mean (or zero).  The run is drawn from
-    Python's `random` exactly as the reference does (same calls, same order), so a seeded run reproduces it; the fill is one
-    device op per mask and works on CPU or HIP tensors alike (no host sync: the mean stays a 0-d tensor)."""
+    random runs of up to T frames of one clip [T, ...] are replaced by the clip's mean (or zero).  `draw_time_runs` makes the
+    random decisions in the reference's order, so a seeded run reproduces it; every run is then one fill on the clip's device
+    (CPU or HIP; no host sync: the mean stays a 0-d tensor)."""
 
     def __init__(self, T: float = 6400, n_mask: int = 2, replace_with_zero: bool = False):
         super().__init__()
         self.T, self.n_mask, self.replace_with_zero = T, n_mask, replace_with_zero
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        import random
+        out = x.clone()
+        for start, length in draw_time_runs(out.size(0), self.T, self.n_mask):
+            # the mean is that of the clip as masked so far: a later run sees the earlier fills, as in the reference
+            out[start : start + length] = 0 if self.replace_with_zero else out.mean()
+        return out
 
-        cloned = x.clone()
-        len_raw = cloned.size(0)
-        for _ in range(self.n_mask):
-            t = random.randint(0, min(self.T, len_raw))
-            t_zero = random.randint(0, len_raw - t)
-            if self.replace_with_zero:
-                cloned[t_zero : t_zero + t] = 0
+
+class DeviceClipPipeline:
+    """The reference's per-clip transform chain (LRW/video/src/data.py:150,157-171) on the device in one kernel: stored uint8 mouth
+    crops [B, T, Hs, Ws] -> fp32 [B, 1, T, H, W] = Normalize(RandomResizedCrop | CenterCrop(flip(x / 255))) — the host only draws
+    five integers per clip, and the uint8 clips cross PCIe at a quarter of the fp32 size.
+
+    train=True:  RandomHorizontalFlip(0.5) and, with use_rrc, RandomResizedCrop(size, scale=(0.6, 1.0), ratio=(3/4, 4/3)) with
+                 torchvision's rejection sampling (10 tries, then the central fallback); without use_rrc the whole frame is resized.
+    train=False: CenterCrop(size) (or Resize with use_val_resize).
+    The draws come from a numpy generator (torchvision, whose RNG order the reference follows, is not available to pin them);
+    the resize is bilinear without antialias."""
+
+    def __init__(self, size: int, train: bool, use_rrc: bool = True, use_val_resize: bool = False, mean: float = 0.421,
+                 std: float = 0.165, seed: int = 0):
+        import numpy as np
+
+        self.size, self.train, self.use_rrc, self.use_val_resize, self.mean, self.std = int(size), train, use_rrc, use_val_resize, mean, std
+        self.rng = np.random.default_rng(seed)
+
+    def draw(self, B: int, Hs: int, Ws: int) -> torch.Tensor:
+        """int32 [B, 5] = (top, left, h, w, flip) per clip."""
+        import math
+
+        import numpy as np
+
+        out = np.zeros((B, 5), dtype=np.int32)
+        for b in range(B):
+            if self.train and self.use_rrc:
+                area = Hs * Ws
+                for _ in range(10):
+                    target = area * self.rng.uniform(0.6, 1.0)
+                    ratio = math.exp(self.rng.uniform(math.log(3 / 4), math.log(4 / 3)))
+                    w, h = int(round(math.sqrt(target * ratio))), int(round(math.sqrt(target / ratio)))
+                    if 0 < w <= Ws and 0 < h <= Hs:
+                        out[b, :4] = (self.rng.integers(0, Hs - h + 1), self.rng.integers(0, Ws - w + 1), h, w)
+                        break
+                else:       # torchvision's fallback: the central crop with the nearest admissible ratio
+                    ratio = Ws / Hs
+                    w, h = (Ws, int(round(Ws / (4 / 3)))) if ratio > 4 / 3 else ((int(round(Hs * 3 / 4)), Hs) if ratio < 3 / 4 else (Ws, Hs))
+                    out[b, :4] = ((Hs - h) // 2, (Ws - w) // 2, h, w)
+            elif (self.train and not self.use_rrc) or (not self.train and self.use_val_resize):
+                out[b, :4] = (0, 0, Hs, Ws)
             else:
-                cloned[t_zero : t_zero + t] = cloned.mean()      # the mean is taken AFTER earlier masks, as in the reference
-        return cloned
+                out[b, :4] = ((Hs - self.size) // 2, (Ws - self.size) // 2, self.size, self.size)
+            out[b, 4] = int(self.train and self.rng.random() < 0.5)
+        return torch.from_numpy(out)
+
+    def __call__(self, frames_u8: torch.Tensor, params: Optional[torch.Tensor] = None) -> torch.Tensor:
+        from . import ops
+
+        B, T, Hs, Ws = frames_u8.shape
+        if params is None:
+            params = self.draw(B, Hs, Ws)
+        return ops.clip_prep(frames_u8.contiguous(), params.to(frames_u8.device, non_blocking=True), self.size, self.size, self.mean, self.std)

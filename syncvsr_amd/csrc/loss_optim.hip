@@ -247,6 +247,42 @@ __global__ __launch_bounds__(256) void k_video_cast(const float* __restrict__ sr
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = f2bf(src[i]);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Device-side input pipeline: stored uint8 mouth crops -> model input.  Per clip: crop window (top, left, h, w) resized to
+// H x W with bilinear sampling (align_corners = False, no antialias), horizontal flip, x / 255, (x - mean) / std — the chain
+// x/255 -> RandomHorizontalFlip -> RandomResizedCrop | CenterCrop -> Normalize of reference LRW/video/src/data.py:150,157-171
+// in one pass; the random decisions are made on the host and arrive as params [B][5] = {top, left, h, w, flip}.
+// A window of exactly H x W is a plain crop (the sampling weights degenerate to 1 / 0).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_clip_prep(const unsigned char* __restrict__ src, const int* __restrict__ params,
+                                                   float* __restrict__ dst, int B, int T, int Hs, int Ws, int H, int W, float mean,
+                                                   float inv_std) {
+    const long total = (long)B * T * H * W;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int x = (int)(idx % W);
+        long r = idx / W;
+        const int y = (int)(r % H);
+        r /= H;
+        const int t = (int)(r % T), b = (int)(r / T);
+        const int top = params[b * 5 + 0], left = params[b * 5 + 1], ch = params[b * 5 + 2], cw = params[b * 5 + 3], flip = params[b * 5 + 4];
+        const int xo = flip ? W - 1 - x : x;
+        // source coordinates inside the window (pixel centres), clamped to the window like torch's upsample_bilinear2d
+        float fy = ((float)y + 0.5f) * ((float)ch / (float)H) - 0.5f;
+        float fx = ((float)xo + 0.5f) * ((float)cw / (float)W) - 0.5f;
+        fy = fmaxf(fy, 0.f); fx = fmaxf(fx, 0.f);
+        int y0 = (int)fy, x0 = (int)fx;
+        if (y0 > ch - 1) y0 = ch - 1;
+        if (x0 > cw - 1) x0 = cw - 1;
+        const int y1 = y0 + 1 < ch ? y0 + 1 : ch - 1, x1 = x0 + 1 < cw ? x0 + 1 : cw - 1;
+        const float wy = fy - (float)y0, wx = fx - (float)x0;
+        const unsigned char* f = src + ((long)b * T + t) * Hs * Ws;
+        const float v00 = f[(top + y0) * Ws + left + x0], v01 = f[(top + y0) * Ws + left + x1];
+        const float v10 = f[(top + y1) * Ws + left + x0], v11 = f[(top + y1) * Ws + left + x1];
+        const float v = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+        dst[idx] = (v * (1.0f / 255.0f) - mean) * inv_std;
+    }
+}
+
 static inline int grid_for(long n) { long b = (n + 255) / 256; if (b > 4096) b = 4096; if (b < 1) b = 1; return (int)b; }
 
 extern "C" {
@@ -309,6 +345,16 @@ int svsr_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {
 int svsr_transpose_cast_multi(const float* src, void* dst, const void* table, int n_entries, hipStream_t stream) {
     if (n_entries < 1) return SVSR_OK;
     hipLaunchKernelGGL(k_transpose_cast_multi, dim3(128, n_entries), dim3(256), 0, stream, src, (bf16_t*)dst, (const TransEntry*)table);
+    return svsr_check_launch();
+}
+
+/* uint8 clips [B][T][Hs][Ws] -> fp32 model input [B][1][T][H][W]; params: device int32 [B][5] = {top, left, h, w, flip}, every
+ * window inside the stored frame. */
+int svsr_clip_prep(const void* src_u8, const int* params, float* dst, int B, int T, int Hs, int Ws, int H, int W, float mean, float std,
+                   hipStream_t stream) {
+    if (B < 1 || T < 1 || Hs < 1 || Ws < 1 || H < 1 || W < 1 || !(std > 0.f)) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_clip_prep, dim3(grid_for((long)B * T * H * W)), dim3(256), 0, stream, (const unsigned char*)src_u8, params, dst,
+                       B, T, Hs, Ws, H, W, mean, 1.0f / std);
     return svsr_check_launch();
 }
 

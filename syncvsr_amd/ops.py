@@ -555,6 +555,15 @@ def adamw_step(p, g, m, v, shadow, decay_end: int, lr: float, betas, eps: float,
           max_norm, warmup, total_steps, _p(opt_state), _stream())
 
 
+def clip_prep(frames_u8: torch.Tensor, params: torch.Tensor, H: int, W: int, mean: float = 0.421, std: float = 0.165) -> torch.Tensor:
+    """uint8 clips [B, T, Hs, Ws] + int32 params [B, 5] = (top, left, h, w, flip) -> fp32 [B, 1, T, H, W] (svsr_clip_prep)."""
+    B, T, Hs, Ws = frames_u8.shape
+    assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and params.dtype == torch.int32 and params.shape == (B, 5)
+    out = torch.empty((B, 1, T, H, W), dtype=torch.float32, device=frames_u8.device)
+    _call("svsr_clip_prep", _p(frames_u8), _p(params), _p(out), B, T, Hs, Ws, H, W, float(mean), float(std), _stream())
+    return out
+
+
 def cast_bf16(src: torch.Tensor, dst: torch.Tensor) -> None:
     _call("svsr_cast_bf16", _p(src), _p(dst), src.numel(), _stream())
 

@@ -42,3 +42,18 @@ def test_timemask_matches_reference(seed, kw):
     out = TimeMask(**kw)(clip)
     np.testing.assert_allclose(out.numpy(), gold[f"out_{seed}"], rtol=0, atol=1e-7)
     assert not np.array_equal(gold[f"out_{seed}"], gold["clip"]) or seed == 0
+
+
+def test_clip_pipeline_draws_are_valid_windows():
+    """DeviceClipPipeline.draw: RandomResizedCrop windows lie inside the stored frame with area in [0.6, 1] and ratio in
+    [3/4, 4/3]; evaluation draws the centre crop without a flip."""
+    from syncvsr_amd.augment import DeviceClipPipeline
+
+    p = DeviceClipPipeline(88, train=True, seed=3).draw(500, 96, 112).numpy()
+    top, left, h, w, flip = p.T
+    assert (top >= 0).all() and (left >= 0).all() and (top + h <= 96).all() and (left + w <= 112).all()
+    area = h * w / (96 * 112)
+    assert area.min() >= 0.58 and area.max() <= 1.0 and 0.74 <= (w / h).min() and (w / h).max() <= 1.34
+    assert 0.4 < flip.mean() < 0.6
+    e = DeviceClipPipeline(88, train=False).draw(3, 96, 112).numpy()
+    assert (e == np.array([4, 12, 88, 88, 0])).all()

@@ -149,3 +149,37 @@ def test_wgrad3x3_halo(dev, case):
     ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw, 3, 1, 1, use_tr=True)
     l2 = ((dw.cpu() - 2 * ref).norm() / (2 * ref).norm()).item()
     assert l2 <= 2e-3, l2
+
+
+def test_device_clip_pipeline(dev):
+    """svsr_clip_prep: uint8 stored frames -> x/255 -> flip -> crop window resized (bilinear, align_corners=False) -> normalise,
+    against torch's F.interpolate on the CPU (reference chain: LRW/video/src/data.py:150,157-171)."""
+    import torch.nn.functional as F
+
+    from syncvsr_amd import ops
+    from syncvsr_amd.augment import DeviceClipPipeline
+
+    g = torch.Generator().manual_seed(5)
+    B, T, Hs, Ws, S = 5, 7, 96, 112, 88
+    frames = torch.randint(0, 256, (B, T, Hs, Ws), dtype=torch.uint8, generator=g)
+    pipe = DeviceClipPipeline(S, train=True, seed=11)
+    params = pipe.draw(B, Hs, Ws)
+    params[0] = torch.tensor([4, 12, 88, 88, 0])            # a plain centre crop
+    params[1] = torch.tensor([0, 0, 96, 112, 1])            # whole frame, flipped
+    out = pipe(frames.to(dev), params).cpu()
+    assert out.shape == (B, 1, T, S, S)
+    for b in range(B):
+        top, left, h, w, flip = (int(v) for v in params[b])
+        x = frames[b].float() / 255.0
+        # windows are in stored-frame coordinates and the flip mirrors the output: the same distribution as the reference's
+        # flip-then-crop, whose window position is uniform
+        crop = x[:, top:top + h, left:left + w]
+        ref = F.interpolate(crop.unsqueeze(1), size=(S, S), mode="bilinear", align_corners=False, antialias=False).squeeze(1)
+        if flip:
+            ref = ref.flip(-1)
+        ref = (ref - 0.421) / 0.165
+        err = (out[b, 0] - ref).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (b, err)
+    assert torch.equal(out[0, 0], ((frames[0, :, 4:92, 12:100].float() / 255.0) - 0.421) / 0.165) or (out[0, 0] - ((frames[0, :, 4:92, 12:100].float() / 255.0) - 0.421) / 0.165).abs().max() < 1e-6
+    ev = DeviceClipPipeline(S, train=False)(frames.to(dev)).cpu()
+    assert (ev[:, 0] - ((frames[:, :, 4:92, 12:100].float() / 255.0) - 0.421) / 0.165).abs().max() < 1e-6
