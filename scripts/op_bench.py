@@ -48,6 +48,10 @@ def timeit(fn, iters=10, warm=2):
 
 def main():
     which = set(sys.argv[1:]) or {"wgrad", "fwd", "dgrad", "stem", "ew"}
+    for kv in os.environ.get("OPB_TUNE", "").split(","):        # e.g. OPB_TUNE=wg_blocks=512,w3_blocks=256
+        if "=" in kv:
+            k, v = kv.split("=")
+            ops.tune(k, int(v))
     tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("SVSR_"))
     print(f"== op_bench {tag}")
     for name, hw, ci, co in LAYERS:

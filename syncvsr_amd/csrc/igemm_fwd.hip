@@ -92,6 +92,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
     __syncthreads();
     const bool vec_pitch = (p.out_pitch & 7) == 0;
     constexpr int CV = BN / 8;
+    static_assert(256 % CV == 0, "a thread keeps its column group across the store loop");
+    // a thread's 8 output channels are the same in every iteration: their bias is fetched once, ahead of the loop (inside it
+    // the load's L2 round trip was paid per iteration — half of a small linear layer's epilogue)
+    float bias8[8];
+    {
+        const int nb = n0 + (tid % CV) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bias8[k] = (p.bias != nullptr && nb + k < p.Co) ? p.bias[nb + k] : 0.f;
+    }
     for (int task = tid; task < BM * CV; task += 256) {
         const int r = task / CV, c8 = task - r * CV;
         const long off = sRow[r];
@@ -102,10 +111,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
         const f32x4 hi = *reinterpret_cast<const f32x4*>(sOut + r * BN + c8 * 8 + 4);
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
         if (vec_pitch && n + 8 <= p.Co) {
-            if (p.bias != nullptr) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-                v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3]; v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
-            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += bias8[k];
             if (p.act == 1) {
                 if (p.out_pre != nullptr) *reinterpret_cast<u32x4*>(p.out_pre + off + n) = pack8(v);
 #pragma unroll
@@ -140,8 +147,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (n + k >= p.Co) break;
-                float x = v[k];
-                if (p.bias != nullptr) x += p.bias[n + k];
+                float x = v[k] + bias8[k];
                 if (p.act == 1) {
                     if (p.out_pre != nullptr) p.out_pre[off + n + k] = f2bf(x);
                     x = gelu_erf(x);

@@ -12,22 +12,25 @@
 // epilogue (plain stores).  Rows are added in a FIXED order — 32 row lanes each walking rows rl, rl+32, ... then the lane
 // sums in lane order, in double — so the statistics, and with them the whole step, are reproducible run to run.
 // Writes mean / rstd and updates the running statistics exactly as torch does (momentum 0.1, unbiased variance for the
-// running estimate).  Block = 32 channels x 32 row lanes.
+// running estimate).  Block = 16 channels x 64 row lanes (1024 threads): with ~1000 partial rows every lane walks ~16 rows, four
+// row pairs in flight — the launch is a few microseconds of pure latency, and there are 40 of them per step.
 // ---------------------------------------------------------------------------------------------------------
+#define BNF_CL 16
+#define BNF_RL 64
 __device__ __forceinline__ void bn_rows_sum(const float* __restrict__ part, int nrows, int C, int c, bool live, int rl, int cl,
-                                            double (*sred)[2][32], double& s, double& q) {
+                                            double (*sred)[2][BNF_CL], double& s, double& q) {
     double a = 0.0, b = 0.0;
     if (live) {
         int r = rl;
-        for (; r + 96 < nrows; r += 128) {           // four independent row pairs in flight, added in row order
+        for (; r + 3 * BNF_RL < nrows; r += 4 * BNF_RL) {           // four independent row pairs in flight, added in row order
             const float a0 = part[((long)r * 2 + 0) * C + c], b0 = part[((long)r * 2 + 1) * C + c];
-            const float a1 = part[((long)(r + 32) * 2 + 0) * C + c], b1 = part[((long)(r + 32) * 2 + 1) * C + c];
-            const float a2 = part[((long)(r + 64) * 2 + 0) * C + c], b2 = part[((long)(r + 64) * 2 + 1) * C + c];
-            const float a3 = part[((long)(r + 96) * 2 + 0) * C + c], b3 = part[((long)(r + 96) * 2 + 1) * C + c];
+            const float a1 = part[((long)(r + BNF_RL) * 2 + 0) * C + c], b1 = part[((long)(r + BNF_RL) * 2 + 1) * C + c];
+            const float a2 = part[((long)(r + 2 * BNF_RL) * 2 + 0) * C + c], b2 = part[((long)(r + 2 * BNF_RL) * 2 + 1) * C + c];
+            const float a3 = part[((long)(r + 3 * BNF_RL) * 2 + 0) * C + c], b3 = part[((long)(r + 3 * BNF_RL) * 2 + 1) * C + c];
             a = (((a + (double)a0) + (double)a1) + (double)a2) + (double)a3;
             b = (((b + (double)b0) + (double)b1) + (double)b2) + (double)b3;
         }
-        for (; r < nrows; r += 32) { a += (double)part[((long)r * 2 + 0) * C + c]; b += (double)part[((long)r * 2 + 1) * C + c]; }
+        for (; r < nrows; r += BNF_RL) { a += (double)part[((long)r * 2 + 0) * C + c]; b += (double)part[((long)r * 2 + 1) * C + c]; }
     }
     sred[rl][0][cl] = a;
     sred[rl][1][cl] = b;
@@ -35,16 +38,16 @@ __device__ __forceinline__ void bn_rows_sum(const float* __restrict__ part, int 
     s = 0.0; q = 0.0;
     if (rl == 0) {
 #pragma unroll 8
-        for (int k = 0; k < 32; ++k) { s += sred[k][0][cl]; q += sred[k][1][cl]; }
+        for (int k = 0; k < BNF_RL; ++k) { s += sred[k][0][cl]; q += sred[k][1][cl]; }
     }
 }
 
 __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ part, int nrows, int C, float count, float eps, float momentum,
                                                       float* mean, float* rstd, float* running_mean, float* running_var,
                                                       long* num_batches_tracked) {
-    __shared__ double sred[32][2][32];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double sred[BNF_RL][2][BNF_CL];
+    const int cl = threadIdx.x % BNF_CL, rl = threadIdx.x / BNF_CL;
+    const int c = blockIdx.x * BNF_CL + cl;
     double s, q;
     bn_rows_sum(part, nrows, C, c, c < C, rl, cl, sred, s, q);
     if (rl == 0 && c < C) {
@@ -178,9 +181,9 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_reduce(const bf16_t* __restr
 // dbeta += sum g, dgamma += sum g*xhat, coef = {gamma*rstd, sum g / n, sum g*xhat / n}
 __global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float* __restrict__ part, int nrows, int C, float count, const float* gamma,
                                                           const float* rstd, float* dgamma, float* dbeta, float* coef) {
-    __shared__ double sred[32][2][32];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double sred[BNF_RL][2][BNF_CL];
+    const int cl = threadIdx.x % BNF_CL, rl = threadIdx.x / BNF_CL;
+    const int c = blockIdx.x * BNF_CL + cl;
     double s, q;
     bn_rows_sum(part, nrows, C, c, c < C, rl, cl, sred, s, q);
     if (rl == 0 && c < C) {
@@ -623,9 +626,9 @@ static inline int ew_grid_for(long nvec, int C, int cap = 2048) {
     g = (g + m - 1) / m * m;
     return g;
 }
-// reduction passes write one row of partials per workgroup: 1024 workgroups (4 per CU) still stream at HBM speed and keep the
+// reduction passes write one row of partials per workgroup: 768 workgroups (3 per CU) still stream at HBM speed and keep the
 // fixed-order finalisation short
-static inline int bn_bwd_grid(long nvec, int C) { return ew_grid_for(nvec, C, 1024); }
+static inline int bn_bwd_grid(long nvec, int C) { return ew_grid_for(nvec, C, 768); }
 
 // rows-per-block iteration for the stem passes: needs C/8 a power of two <= 256; ~1024 items per block
 static inline bool stem_iter(StemRowIter& it, int C, int W, int H) {
@@ -646,7 +649,7 @@ extern "C" {
 int svsr_bn_finalize(const float* part, int nrows, int C, float count, float eps, float momentum, float* mean, float* rstd,
                      float* running_mean, float* running_var, int64_t* num_batches_tracked, hipStream_t stream) {
     if (nrows < 1 || C < 1) return SVSR_ERR_ARG;
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 31) / 32), dim3(1024), 0, stream, part, nrows, C, count, eps, momentum, mean, rstd,
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, part, nrows, C, count, eps, momentum, mean, rstd,
                        running_mean, running_var, (long*)num_batches_tracked);
     return svsr_check_launch();
 }
@@ -683,7 +686,7 @@ int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* m
                        (const bf16_t*)x, mean, rstd, coef, (bf16_t*)dx, (bf16_t*)dres, nvec, C, gamma, beta, (const bf16_t*)res)
     if (act < 0 || act > 2) return SVSR_ERR_ARG;
     if (act == 2) SVSR_BN_BWD_REDUCE(2); else if (act == 1) SVSR_BN_BWD_REDUCE(1); else SVSR_BN_BWD_REDUCE(0);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(1024), 0, stream, slots, grid, C, (float)npix, gamma, rstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, slots, grid, C, (float)npix, gamma, rstd, dgamma, dbeta, coef);
     if (act == 2) SVSR_BN_BWD_APPLY(2); else if (act == 1) SVSR_BN_BWD_APPLY(1); else SVSR_BN_BWD_APPLY(0);
     return svsr_check_launch();
 }
@@ -745,7 +748,7 @@ int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x
 #define SVSR_STEM_BWD(A, AP) hipLaunchKernelGGL((k_stem_bwd_lds<A, AP>), g2, dim3(256), lds_b, stream, (const bf16_t*)dpool, (const unsigned char*)amax, \
                        (const bf16_t*)x, mean, rstd, gamma, beta, coef, (bf16_t*)dx, slots, Hc, Wc, Hp, Wp, C)
         if (act == SVSR_ACT_SWISH) SVSR_STEM_BWD(2, false); else SVSR_STEM_BWD(1, false);
-        hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(1024), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
+        hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
                            dgamma, dbeta, coef);
         if (act == SVSR_ACT_SWISH) SVSR_STEM_BWD(2, true); else SVSR_STEM_BWD(1, true);
         return svsr_check_launch();
@@ -757,7 +760,7 @@ int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x
     else
         hipLaunchKernelGGL(k_stem_pool_bwd_reduce<1>, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
                            (const bf16_t*)x, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, slots, it);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 31) / 32), dim3(1024), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
                        dgamma, dbeta, coef);
     if (act == SVSR_ACT_SWISH)
         hipLaunchKernelGGL(k_stem_pool_bwd_apply<2>, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
