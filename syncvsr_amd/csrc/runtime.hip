@@ -19,7 +19,7 @@ static int g_tune[SVSR_TUNE_N] = {
     /* IGEMM_TILE   */ 0,      // 0 auto, 64 / 128: force the M tile of svsr_igemm_fwd
     /* IGEMM_M128   */ 8192,   // rows from which 128-row tiles are used
     /* WG_BLOCKS    */ 0,      // target workgroups of svsr_igemm_wgrad (0: built-in per tile size)
-    /* W3_BLOCKS    */ 384,    // target workgroups of svsr_conv3x3_wgrad
+    /* W3_BLOCKS    */ 512,    // target workgroups of svsr_conv3x3_wgrad: one round at 2 per CU (swept 192..768 with slab epilogues: 110 / 92 / 81 / 74 / 98 us)
     /* LN_RPB       */ 16,     // rows per workgroup of svsr_add_ln_bwd
     /* STEM_LDS_FWD */ 0,      // LDS-tiled stem BN+act+pool forward (measured slower)
     /* STEM_LDS_BWD */ 1,      // LDS-tiled stem BN+act+pool backward (measured faster)

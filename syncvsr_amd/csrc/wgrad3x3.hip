@@ -157,8 +157,8 @@ static W3Plan w3_plan(int Nimg, int H, int W, int Ci, int Co) {
     const long qtot = (long)Nimg * (H + 2) * (W + 2);
     pl.total_chunks = (int)((qtot + W3_CH - 1) / W3_CH);
     pl.tasks = (Co / 64) * (Ci / 64);
-    const int target_blocks = svsr_tune_get(SVSR_TUNE_W3_BLOCKS);      // measured optimum 384 (256..1024 swept)
-    int splits = ((target_blocks > 0 ? target_blocks : 384) + pl.tasks - 1) / pl.tasks;   // every split costs a slab written and re-read
+    const int target_blocks = svsr_tune_get(SVSR_TUNE_W3_BLOCKS);      // one round of 2 workgroups per CU
+    int splits = ((target_blocks > 0 ? target_blocks : 512) + pl.tasks - 1) / pl.tasks;   // every split costs a slab written and re-read
     if (splits > pl.total_chunks) splits = pl.total_chunks;
     if (splits < 1) splits = 1;
     pl.chunks_per_block = (pl.total_chunks + splits - 1) / splits;
