@@ -166,6 +166,33 @@ int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* g
 int svsr_embed_ln_fwd(const void* feats, const float* cls, const float* pos, const float* type0, const float* gamma, const float* beta, void* sum_out, void* y, float* mean, float* rstd, int B, int S, int D, float eps, const unsigned* drop_seed, unsigned site_in, float p_in, unsigned site_out, float p_out, hipStream_t stream);
 int svsr_embed_bwd_scatter(const void* ds, void* dfeats, float* dcls, float* dpos, float* dtype0, int B, int S, int D, float* part, const unsigned* drop_seed, unsigned site_in, float p_in, hipStream_t stream);
 
+/* ---- `model.bert.type: x-transformers` encoder passes (csrc/xt.hip) ----------------------------------------------------
+ * The reference instantiates x_transformers.Encoder(dim, depth, heads, attn_dropout, layer_dropout, ff_dropout, use_rmsnorm,
+ * ff_glu, rotary_pos_emb) (lightning.py:93-105) — a third-party package absent from the reference tree, so these restate its
+ * published algorithm (parity unpinned).  Activations are bf16 [R][ld] with ld = D rounded up to 64 and pad columns zero.
+ *
+ * RMSNorm: y = x / max(||x||_2 * D^-0.5, eps) * g; inv [R] keeps 1 / max(...) for the backward.  The backward returns
+ * dx (+ addend, the gradient that bypasses the block through the residual connection) and accumulates dg from
+ * svsr_rmsnorm_bwd_rows(R) partial rows of [ld] floats in `part`. */
+int svsr_rmsnorm_fwd(const void* x, const float* g, void* y, float* inv, int R, int D, int ld, float eps, hipStream_t stream);
+int svsr_rmsnorm_bwd_rows(int R);
+int svsr_rmsnorm_bwd(const void* dy, const void* x, const float* g, const float* inv, const void* addend, void* dx, float* dg, float* part, int R, int D, int ld, hipStream_t stream);
+
+/* Rotary embedding, in place, on the first 32 dims of `heads_total` consecutive 64-wide heads per row (q | k | v of the fused
+ * projection); position = row % S; tab fp32 [S][32] = 16 cosines then 16 sines of position * 10000^(-j/16); sign -1 = backward. */
+int svsr_rotary(void* qkv, const float* tab, int R, int S, int heads_total, int ld, int sign, hipStream_t stream);
+
+/* GEGLU: u = [value | gate] bf16 [R][ldu] (halves I wide, I % 4 == 0); y [R][ldy] = dropout(value * gelu(gate)), zero for columns
+ * >= I.  Backward: du [R][ldu] from dy [R][ldy] (mask regenerated), zero for columns >= 2I.  Dropout index = r * ldy + column. */
+int svsr_geglu_fwd(const void* u, void* y, int R, int I, int ldu, int ldy, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
+int svsr_geglu_bwd(const void* dy, const void* u, void* du, int R, int I, int ldu, int ldy, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
+
+/* x0 = emb_dropout(cat(cls_token, cat(feats, word_mask[..., None], -1), 1)) (lightning.py:145-150): feats bf16 [B][S-1][F],
+ * wmask fp32 [B][S-1] (D = F + 1) or null (D = F), cls fp32 [>= D], x0 bf16 [B*S][ld].  The backward writes dfeats bf16
+ * [B][S-1][F] and adds the batch sum of row 0 into dcls (batch order fixed).  Dropout index = row * ld + column. */
+int svsr_xt_embed_fwd(const void* feats, const float* wmask, const float* cls, void* x0, int B, int S, int F, int D, int ld, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
+int svsr_xt_embed_bwd(const void* dx0, void* dfeats, float* dcls, int B, int S, int F, int D, int ld, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
+
 /* dz = dy * act'(z) when z != null: act 1 = GELU from the saved pre-activation (BertIntermediate), act 2 = ReLU from the
  * saved output (PositionwiseFeedForward; gscale = 1/(1-p) when that output went through dropout — dropped elements are
  * exactly the zeros of the saved output); db[n] += column sums (bias gradient of any nn.Linear; db may be null), via

@@ -15,7 +15,11 @@ Third-party arithmetic that is not in the reference tree:
     instantiates exactly that class in place of timm.
   * HF ``transformers.BertModel`` (unpinned; 5.15.0 in the build container) -> restated below from
     its published post-LN algorithm; the golden generator runs the real ``BertModel``.
-  * x-transformers 1.9.2 ``Encoder`` is NOT covered (not importable; parity unpinned).
+  * x-transformers 1.9.2 ``Encoder`` (``LRW/video/setup.sh``; selected by the shipped yamls) is neither vendored in the
+    reference tree nor importable offline.  ``xt_encoder`` below restates its published algorithm (pre-norm residual
+    blocks, RMSNorm, rotary embedding on the first 32 of 64 head dims, GEGLU feed-forward, stochastic layer skipping)
+    from the package's documented behaviour, anchored on the reference's call site (lightning.py:93-105,157-158).
+    PARITY UNPINNED for that branch: there is no golden vector for it; the HIP path is tested against this restatement only.
 
 Every function cites the reference lines it follows.  All maths is fp32 on CPU.
 """
@@ -129,7 +133,7 @@ class DropPlan:
         self.seed, self.p = int(seed), {"hidden": float(p_hidden), "attn": float(p_attn), "emb": float(p_emb)}
         self.sites = sites
 
-    def __call__(self, x: Tensor, site: str, kind: str = "hidden") -> Tensor:
+    def __call__(self, x: Tensor, site: str, kind: str = "hidden", pitch: int | None = None) -> Tensor:
         from syncvsr_amd.dropout import keep_mask
 
         p = self.p[kind]
@@ -139,13 +143,16 @@ class DropPlan:
             B, H, Lq, Lk = x.shape
             pitch = (Lk + 7) // 8 * 8
             m = keep_mask(self.seed, self.sites[site], p, B * H * Lq * pitch).reshape(B, H, Lq, pitch)[..., :Lk]
+        elif pitch is not None and pitch != x.shape[-1]:      # rows stored with a padded pitch: element index = row * pitch + column
+            rows = x.numel() // x.shape[-1]
+            m = keep_mask(self.seed, self.sites[site], p, rows * pitch).reshape(rows, pitch)[:, : x.shape[-1]].reshape(tuple(x.shape))
         else:
             m = keep_mask(self.seed, self.sites[site], p, x.numel()).reshape(tuple(x.shape))
         return x * torch.from_numpy(m.copy()).to(x.dtype) / (1.0 - p)
 
 
-def _dp(dp, x: Tensor, site: str, kind: str = "hidden") -> Tensor:
-    return x if dp is None else dp(x, site, kind)
+def _dp(dp, x: Tensor, site: str, kind: str = "hidden", pitch: int | None = None) -> Tensor:
+    return x if dp is None else dp(x, site, kind, pitch)
 
 
 def bert_embeddings(x: Tensor, sd: SD, eps: float, dp=None) -> Tensor:
@@ -188,6 +195,65 @@ def bert_encoder(x: Tensor, sd: SD, cfg: Any, keep: dict | None = None, dp=None)
 
 
 # --------------------------------------------------------------------------------------------
+# x-transformers encoder (lightning.py:93-105,157-158) — parity UNPINNED, see the module header
+# --------------------------------------------------------------------------------------------
+def rms_norm(x: Tensor, g: Tensor, eps: float = 1e-8) -> Tensor:
+    """x_transformers.RMSNorm: x / clamp(||x||_2 * dim^-0.5, min=eps) * g."""
+    norm = torch.linalg.vector_norm(x, dim=-1, keepdim=True) * x.size(-1) ** -0.5
+    return x / norm.clamp(min=eps) * g
+
+
+def rotary_freqs(S: int, rot: int = 32, theta: float = 10000.0) -> Tensor:
+    """x_transformers.RotaryEmbedding(dim=max(dim_head // 2, 32)): freqs[s] = cat(s * inv_freq, s * inv_freq)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, rot, 2).float() / rot))
+    f = torch.einsum("i,j->ij", torch.arange(S).float(), inv_freq)
+    return torch.cat((f, f), dim=-1)
+
+
+def apply_rotary(t: Tensor, freqs: Tensor) -> Tensor:
+    """First freqs.size(-1) dims of every head: t * cos + rotate_half(t) * sin, rotate_half((x1, x2)) = (-x2, x1)."""
+    rot = freqs.size(-1)
+    tl, tr = t[..., :rot], t[..., rot:]
+    x1, x2 = tl[..., : rot // 2], tl[..., rot // 2:]
+    tl = tl * freqs.cos() + torch.cat((-x2, x1), dim=-1) * freqs.sin()
+    return torch.cat((tl, tr), dim=-1)
+
+
+def xt_encoder(x: Tensor, sd: SD, cfg: Any, keep: dict | None = None, dp=None, skip: set | None = None) -> Tensor:
+    """AttentionLayers.forward for Encoder(dim, depth, heads, use_rmsnorm, ff_glu, rotary_pos_emb): layers alternate attention
+    ('a', even n) and feed-forward ('f', odd n) blocks, each `x = block(norm(x)) + x`; `skip` = the layer indices n that
+    layer_dropout removed this step.  Padded row pitches of the HIP library are passed to `dp` so the same masks are drawn."""
+    bert = cfg.model.bert
+    B, S, D = x.shape
+    H, dh = int(bert.heads), 64
+    E, I = H * dh, 4 * D
+    freqs = rotary_freqs(S)
+    rot_v = bool(bert.get("rotate_value", True))
+    skip = skip or set()
+    for i in range(int(bert.depth)):
+        a, f = f"encoder.layers.{2 * i}", f"encoder.layers.{2 * i + 1}"
+        if 2 * i not in skip:
+            h = rms_norm(x, sd[f"{a}.0.0.g"])
+            q, k, v = (F.linear(h, sd[f"{a}.1.to_{n}.weight"]).view(B, S, H, dh).transpose(1, 2) for n in "qkv")
+            q, k = apply_rotary(q, freqs), apply_rotary(k, freqs)
+            if rot_v:
+                v = apply_rotary(v, freqs)
+            probs = _dp(dp, torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1), f"enc.{i}.attn.probs", "attn")
+            ctx = (probs @ v).transpose(1, 2).reshape(B, S, E)
+            x = F.linear(ctx, sd[f"{a}.1.to_out.weight"]) + x
+        if 2 * i + 1 not in skip:
+            h = rms_norm(x, sd[f"{f}.0.0.g"])
+            val, gate = F.linear(h, sd[f"{f}.1.ff.0.proj.weight"], sd[f"{f}.1.ff.0.proj.bias"]).chunk(2, dim=-1)
+            y = _dp(dp, val * gelu_erf(gate), f"enc.{i}.ff.hidden", "hidden", pitch=(I + 63) // 64 * 64)
+            x = F.linear(y, sd[f"{f}.1.ff.3.weight"], sd[f"{f}.1.ff.3.bias"]) + x
+        if keep is not None:
+            keep[f"xt.{i}"] = x
+    if "encoder.final_norm.g" in sd:
+        x = rms_norm(x, sd["encoder.final_norm.g"])
+    return x
+
+
+# --------------------------------------------------------------------------------------------
 # heads + losses (lightning.py:161-191)
 # --------------------------------------------------------------------------------------------
 def cross_entropy(logits: Tensor, target: Tensor, label_smoothing: float = 0.0) -> Tensor:
@@ -211,7 +277,7 @@ def audio_dims(cfg: Any) -> tuple[int, int, int]:
 
 def forward(sd: SD, cfg: Any, videos: Tensor, audio_tokens: Tensor, labels: Tensor, word_mask: Tensor,
             training: bool = True, use_cutmix_metric: bool = False, keep: dict | None = None,
-            stats_out: dict | None = None, dp=None) -> dict[str, Tensor]:
+            stats_out: dict | None = None, dp=None, layer_skip: set | None = None) -> dict[str, Tensor]:
     """TransformerLightningModule.forward (lightning.py:133-191); dropout only through `dp` (a DropPlan replaying the
     library's masks), otherwise p = 0."""
     A, G, V = audio_dims(cfg)
@@ -222,8 +288,11 @@ def forward(sd: SD, cfg: Any, videos: Tensor, audio_tokens: Tensor, labels: Tens
         feats = torch.cat((feats, word_mask.unsqueeze(-1).to(feats.dtype)), dim=-1)
     B, T, D = feats.shape
     audio_tokens = audio_tokens[:, : T * A]                                              # :148
-    x = _dp(dp, torch.cat((sd["cls_token"].expand(B, -1, -1), feats), dim=1), "emb.in", "emb")      # :149-150
-    h = bert_encoder(x, sd, cfg, keep, dp)                                               # :152-156
+    x = _dp(dp, torch.cat((sd["cls_token"].expand(B, -1, -1), feats), dim=1), "emb.in", "emb", pitch=(D + 63) // 64 * 64)      # :149-150
+    if str(cfg.model.bert.type) == "x-transformers":
+        h = xt_encoder(x, sd, cfg, keep, dp, layer_skip)                                 # :157-158
+    else:
+        h = bert_encoder(x, sd, cfg, keep, dp)                                           # :152-156
     logits_category = F.linear(h[:, 0], sd["category_classifier.weight"], sd["category_classifier.bias"]).float()
     loss_category = cross_entropy(logits_category, labels, float(cfg.train.label_smoothing))     # :161-165
     logits_audio = F.linear(h[:, 1:], sd["audio_projection.weight"], sd["audio_projection.bias"]).float()

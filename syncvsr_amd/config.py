@@ -126,6 +126,20 @@ def default_lrw_config(**kw: Any) -> Config:
     return cfg
 
 
+def xtransformers_lrw_config(word_boundary: bool = True, **kw: Any) -> Config:
+    """The encoder the reference's shipped LRW yamls select (``LRW/video/config/bert-12l-512d_LRW_96_bf16_rrc_{WB,noWB}.yaml:17-30``):
+    ``type: x-transformers``, depth 12, RMSNorm, GEGLU feed-forward, rotary embedding, layer-drop 0.2, ff-dropout 0.3; with
+    ``use_word_boundary`` the encoder is 513 wide (lightning.py:49,145)."""
+    cfg = default_lrw_config()
+    cfg.data["use_word_boundary"] = bool(word_boundary)
+    cfg.model["bert"] = Config(
+        type="x-transformers", num_tokens=1, dim=512, depth=12, heads=8, emb_dropout=0.0, attn_dropout=0.0, layer_dropout=0.2,
+        ff_dropout=0.3, use_rmsnorm=True, ff_glu=True, rotary_pos_emb=True, num_labels=500)
+    for k, v in kw.items():
+        cfg.set_path(k.replace("__", "."), v)
+    return cfg
+
+
 def audio_codec_dims(path: str) -> tuple[str, int, int, int]:
     """(codec, audio_alignment A, vq_groups G, audio_vocab_size V) — reference lightning.py:58-67."""
     if "vq" in path:

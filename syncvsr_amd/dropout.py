@@ -41,6 +41,15 @@ def lrw_sites(layers: int) -> dict[str, int]:
     return {n: k + 1 for k, n in enumerate(names)}
 
 
+def lrw_xt_sites(depth: int) -> dict[str, int]:
+    """Sites of the `type: x-transformers` encoder: `emb_dropout_bert` (lightning.py:45,150), Attention's dropout on the
+    attention probabilities (`attn_dropout`) and FeedForward's dropout after the gate (`ff_dropout`) (lightning.py:95-105)."""
+    names = ["emb.in"]
+    for i in range(depth):
+        names += [f"enc.{i}.attn.probs", f"enc.{i}.ff.hidden"]
+    return {n: k + 1 for k, n in enumerate(names)}
+
+
 def lrs_sites(elayers: int, dlayers: int) -> dict[str, int]:
     """Stable site ids of every nn.Dropout the LRS training forward executes (transformer/embedding.py:208-217,
     encoder_layer.py:97-137, positionwise_feed_forward.py:30, attention.py:80, ctc.py:97, decoder_layer.py:91-113)."""

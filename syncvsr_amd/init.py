@@ -39,16 +39,16 @@ def resnet_block_specs() -> Iterator[tuple[str, int, int, int, bool]]:
             inplanes = planes
 
 
-def param_specs(cfg: Config) -> list[Spec]:
-    D = hidden_dim(cfg)
-    bert = cfg.model.bert
-    H = int(bert.hidden_size) + (D - int(bert.dim))
-    assert H == D, "encoder width must equal feature width (+1 with word boundary)"
-    I = int(bert.intermediate_size)
-    L = int(bert.num_hidden_layers)
-    _, A, G, V = audio_codec_dims(cfg.model.wav2vec.path)
+def pad64(n: int) -> int:
+    return (int(n) + 63) // 64 * 64
+
+
+def encoder_type(cfg: Config) -> str:
+    return str(cfg.model.bert.type)
+
+
+def _frontend_specs() -> list[Spec]:
     specs: list[Spec] = [
-        ("cls_token", (1, 1, D), "cls"),
         ("stem3d.0.weight", (64, 1, 5, 7, 7), "conv"),
         ("stem3d.1.weight", (64,), "norm_w"),
         ("stem3d.1.bias", (64,), "norm_b"),
@@ -68,35 +68,101 @@ def param_specs(cfg: Config) -> list[Spec]:
                 (f"{prefix}.downsample.1.weight", (planes,), "norm_w"),
                 (f"{prefix}.downsample.1.bias", (planes,), "norm_b"),
             ]
+    return specs
+
+
+def xt_dims(cfg: Config) -> tuple[int, int, int, int]:
+    """(D, attention inner width E = heads * 64, feed-forward inner width I = 4 D, depth) of the x-transformers encoder
+    (x_transformers defaults: dim_head 64, ff mult 4)."""
+    D = hidden_dim(cfg)
+    return D, int(cfg.model.bert.heads) * 64, 4 * D, int(cfg.model.bert.depth)
+
+
+def _xt_encoder_specs(cfg: Config) -> list[Spec]:
+    """State-dict names of x_transformers.Encoder as `AttentionLayers` registers them: `layers.{n}` = ModuleList([norms, block,
+    residual]) with n alternating attention ('a') and feed-forward ('f'); norms[0] = the pre-branch RMSNorm (`g`); Attention owns
+    bias-free to_q / to_k / to_v / to_out; FeedForward.ff = Sequential(GLU(proj), Identity, Dropout, Linear).  (Recalled from the
+    package, which is not vendored in the reference tree: parity unpinned.)"""
+    D, E, I, depth = xt_dims(cfg)
+    specs: list[Spec] = []
+    for i in range(depth):
+        a, f = f"encoder.layers.{2 * i}", f"encoder.layers.{2 * i + 1}"
+        specs += [
+            (f"{a}.0.0.g", (D,), "norm_w"),
+            (f"{a}.1.to_q.weight", (E, D), "linear_w"),
+            (f"{a}.1.to_k.weight", (E, D), "linear_w"),
+            (f"{a}.1.to_v.weight", (E, D), "linear_w"),
+            (f"{a}.1.to_out.weight", (D, E), "linear_w"),
+            (f"{f}.0.0.g", (D,), "norm_w"),
+            (f"{f}.1.ff.0.proj.weight", (2 * I, D), "linear_w"),
+            (f"{f}.1.ff.0.proj.bias", (2 * I,), f"ubias{D}"),
+            (f"{f}.1.ff.3.weight", (D, I), "linear_w"),
+            (f"{f}.1.ff.3.bias", (D,), f"ubias{I}"),
+        ]
+    if bool(cfg.model.bert.get("final_norm", False)):
+        specs.append(("encoder.final_norm.g", (D,), "norm_w"))
+    return specs
+
+
+def param_specs(cfg: Config) -> list[Spec]:
+    D = hidden_dim(cfg)
+    bert = cfg.model.bert
+    _, A, G, V = audio_codec_dims(cfg.model.wav2vec.path)
+    specs: list[Spec] = [("cls_token", (1, 1, D), "cls")] + _frontend_specs()
     specs += [
         ("audio_projection.weight", (A * G * V, D), "linear_w"),
         ("audio_projection.bias", (A * G * V,), "linear_b"),
-        ("encoder.embeddings.position_embeddings.weight", (int(bert.max_position_embeddings), D), "emb"),
-        ("encoder.embeddings.token_type_embeddings.weight", (int(bert.type_vocab_size), D), "emb"),
-        ("encoder.embeddings.LayerNorm.weight", (D,), "norm_w"),
-        ("encoder.embeddings.LayerNorm.bias", (D,), "norm_b"),
     ]
-    for i in range(L):
-        p = f"encoder.encoder.layer.{i}"
-        for nm in ("query", "key", "value"):
-            specs += [(f"{p}.attention.self.{nm}.weight", (D, D), "bert_w"), (f"{p}.attention.self.{nm}.bias", (D,), "bert_b")]
+    if encoder_type(cfg) == "x-transformers":
+        specs += _xt_encoder_specs(cfg)
+    else:
+        H = int(bert.hidden_size) + (D - int(bert.dim))
+        assert H == D, "encoder width must equal feature width (+1 with word boundary)"
+        I = int(bert.intermediate_size)
+        L = int(bert.num_hidden_layers)
         specs += [
-            (f"{p}.attention.output.dense.weight", (D, D), "bert_w"),
-            (f"{p}.attention.output.dense.bias", (D,), "bert_b"),
-            (f"{p}.attention.output.LayerNorm.weight", (D,), "norm_w"),
-            (f"{p}.attention.output.LayerNorm.bias", (D,), "norm_b"),
-            (f"{p}.intermediate.dense.weight", (I, D), "bert_w"),
-            (f"{p}.intermediate.dense.bias", (I,), "bert_b"),
-            (f"{p}.output.dense.weight", (D, I), "bert_w"),
-            (f"{p}.output.dense.bias", (D,), "bert_b"),
-            (f"{p}.output.LayerNorm.weight", (D,), "norm_w"),
-            (f"{p}.output.LayerNorm.bias", (D,), "norm_b"),
+            ("encoder.embeddings.position_embeddings.weight", (int(bert.max_position_embeddings), D), "emb"),
+            ("encoder.embeddings.token_type_embeddings.weight", (int(bert.type_vocab_size), D), "emb"),
+            ("encoder.embeddings.LayerNorm.weight", (D,), "norm_w"),
+            ("encoder.embeddings.LayerNorm.bias", (D,), "norm_b"),
         ]
+        for i in range(L):
+            p = f"encoder.encoder.layer.{i}"
+            for nm in ("query", "key", "value"):
+                specs += [(f"{p}.attention.self.{nm}.weight", (D, D), "bert_w"), (f"{p}.attention.self.{nm}.bias", (D,), "bert_b")]
+            specs += [
+                (f"{p}.attention.output.dense.weight", (D, D), "bert_w"),
+                (f"{p}.attention.output.dense.bias", (D,), "bert_b"),
+                (f"{p}.attention.output.LayerNorm.weight", (D,), "norm_w"),
+                (f"{p}.attention.output.LayerNorm.bias", (D,), "norm_b"),
+                (f"{p}.intermediate.dense.weight", (I, D), "bert_w"),
+                (f"{p}.intermediate.dense.bias", (I,), "bert_b"),
+                (f"{p}.output.dense.weight", (D, I), "bert_w"),
+                (f"{p}.output.dense.bias", (D,), "bert_b"),
+                (f"{p}.output.LayerNorm.weight", (D,), "norm_w"),
+                (f"{p}.output.LayerNorm.bias", (D,), "norm_b"),
+            ]
     specs += [
         ("category_classifier.weight", (int(bert.num_labels), D), "linear_w"),
         ("category_classifier.bias", (int(bert.num_labels),), "linear_b"),
     ]
     return specs
+
+
+def phys_shape(cfg: Config, name: str, shape: tuple[int, ...]) -> tuple[int, ...]:
+    """Shape of a tensor's storage in the flat parameter buffer.  Encoder / head dimensions that are not multiples of 64 (513 with
+    the word boundary, 2052 and 4104 in the feed-forward) are stored in rows / columns padded with zeros to the next multiple of
+    64, so the contraction kernels see aligned operands; the nn.Parameter is the [:logical] view.  Pads stay zero under training:
+    their gradients are exactly zero (zero activations times anything) and AdamW maps (p, g) = (0, 0) to 0."""
+    if encoder_type(cfg) != "x-transformers" or len(shape) > 3:
+        return tuple(shape)
+    if not (name.startswith("encoder.") or name == "cls_token" or name.startswith(("audio_projection", "category_classifier"))):
+        return tuple(shape)
+    D, E, I, _ = xt_dims(cfg)
+    wide = {D: pad64(D), I: pad64(I), 2 * I: pad64(2 * I)}
+    if name.startswith(("audio_projection", "category_classifier")):     # output features of the heads stay as they are
+        return tuple(shape[:1]) + tuple(wide.get(d, d) for d in shape[1:])
+    return tuple(wide.get(d, d) for d in shape)
 
 
 def buffer_specs(cfg: Config) -> list[Spec]:
@@ -147,6 +213,9 @@ def init_state_dict(cfg: Config, seed: int = 0, perturb_norm: bool = False) -> d
         elif kind == "linear_b":
             # fan_in of the matching weight = hidden dim
             bound = 1.0 / math.sqrt(hidden_dim(cfg))
+            t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif kind.startswith("ubias"):          # torch Linear bias: U(+-1/sqrt(fan_in)), fan_in carried in the kind
+            bound = 1.0 / math.sqrt(int(kind[5:]))
             t = (torch.rand(shape, generator=g) * 2 - 1) * bound
         elif kind in ("bert_w", "emb"):
             t = torch.randn(shape, generator=g) * 0.02

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from . import ops
 from .config import Config, audio_codec_dims
-from .init import buffer_specs, hidden_dim, init_state_dict, param_specs, resnet_block_specs
+from .init import buffer_specs, hidden_dim, init_state_dict, pad64, param_specs, phys_shape, resnet_block_specs, xt_dims
 
 BF16 = torch.bfloat16
 
@@ -107,41 +107,65 @@ class TransformerLightningModule(nn.Module):
             config = Config(config)
         self.config = config
         bert = config.model.bert
-        if bert.type != "huggingface":
-            raise NotImplementedError(
-                "only `model.bert.type: huggingface` is implemented natively; the x-transformers encoder of the shipped "
-                "yaml is a third-party dependency whose arithmetic cannot be pinned offline (SURVEY.md §8c)")
-        if config.data.use_word_boundary:
+        self.encoder_type = str(bert.type)
+        if self.encoder_type not in ("huggingface", "x-transformers"):
+            raise NotImplementedError(f"model.bert.type {bert.type!r}: the reference knows `huggingface` and `x-transformers` (lightning.py:90-105)")
+        self.use_wb = bool(config.data.use_word_boundary)
+        if self.use_wb and self.encoder_type == "huggingface":
             raise NotImplementedError(
                 "use_word_boundary needs a 513-wide encoder, which the reference's huggingface branch cannot build either "
-                "(BertConfig.hidden_size stays 512, lightning.py:92,145)")
+                "(BertConfig.hidden_size stays 512, lightning.py:92,145); use `type: x-transformers` as the shipped yaml does")
         self.is_train = False
         self.word_labels = int(bert.num_labels)
         self.lambda_audio = float(config.optim.lambda_audio)
         self.label_smoothing = float(config.train.label_smoothing)
-        self.use_wb = False
         self.codec, self.audio_alignment, self.vq_groups, self.audio_vocab_size = audio_codec_dims(config.model.wav2vec.path)
         self.dim = hidden_dim(config)
-        self.heads = int(bert.num_attention_heads)
-        self.layers = int(bert.num_hidden_layers)
-        self.inter = int(bert.intermediate_size)
-        self.ln_eps = float(bert.get("layer_norm_eps", 1e-12))
-        # Dropout.  Missing keys take the reference's defaults: emb_dropout is read directly (lightning.py:45); the other two are
-        # BertConfig(**config.model.bert) defaults, 0.1 each (lightning.py:92).  Masks are counter based (csrc/common.h): element i
-        # of site s is kept iff hash(seed, s, i) >= p * 2^32; the seed is a device word advanced once per training forward.
-        from .dropout import lrw_sites
-
-        self.emb_drop_p = float(bert.get("emb_dropout", 0.0))
-        self.drop_p = float(bert.get("hidden_dropout_prob", 0.1))
-        self.attn_drop_p = float(bert.get("attention_probs_dropout_prob", 0.1))
-        self._sites = lrw_sites(self.layers)
+        self.dim_p = pad64(self.dim)            # row pitch of the encoder's activations (pad columns are zero)
         self.dropout_seed = 0 if seed is None else int(seed)
         self._drop_word: Optional[torch.Tensor] = None
-        if self.dim % 512 or self.dim // self.heads != 64:
-            raise NotImplementedError("encoder width must be a multiple of 512 with 64-wide heads")
+        # Dropout masks are counter based (csrc/common.h): element i of site s is kept iff hash(seed, s, i) >= p * 2^32; the seed is a
+        # device word advanced once per training forward.
+        from .dropout import lrw_sites, lrw_xt_sites
+
+        self.emb_drop_p = float(bert.get("emb_dropout", 0.0))          # read directly by the module (lightning.py:45)
+        if self.encoder_type == "huggingface":
+            self.heads = int(bert.num_attention_heads)
+            self.layers = int(bert.num_hidden_layers)
+            self.inter = int(bert.intermediate_size)
+            self.ln_eps = float(bert.get("layer_norm_eps", 1e-12))
+            # missing keys take BertConfig(**config.model.bert)'s defaults, 0.1 each (lightning.py:92)
+            self.drop_p = float(bert.get("hidden_dropout_prob", 0.1))
+            self.attn_drop_p = float(bert.get("attention_probs_dropout_prob", 0.1))
+            self.layer_drop_p = 0.0
+            self._sites = lrw_sites(self.layers)
+            if self.dim % 512 or self.dim // self.heads != 64:
+                raise NotImplementedError("encoder width must be a multiple of 512 with 64-wide heads")
+        else:
+            # x_transformers.Encoder(dim, depth, heads, attn_dropout, layer_dropout, ff_dropout, use_rmsnorm, ff_glu, rotary_pos_emb)
+            # (lightning.py:95-105).  The shipped combination (RMSNorm + GEGLU + rotary) is the one built here.
+            if not (bool(bert.get("use_rmsnorm", False)) and bool(bert.get("ff_glu", False)) and bool(bert.get("rotary_pos_emb", False))):
+                raise NotImplementedError("the x-transformers encoder is implemented for use_rmsnorm = ff_glu = rotary_pos_emb = true "
+                                          "(the shipped yamls, bert-12l-512d_LRW_96_bf16_rrc_*.yaml:27-29)")
+            _, self.attn_inner, self.inter, self.layers = xt_dims(config)
+            self.heads = int(bert.heads)
+            self.inter_p, self.glu_p = pad64(self.inter), pad64(2 * self.inter)
+            self.drop_p = float(bert.get("ff_dropout", 0.0))            # FeedForward's dropout, after the gate
+            self.attn_drop_p = float(bert.get("attn_dropout", 0.0))
+            self.layer_drop_p = float(bert.get("layer_dropout", 0.0))
+            self.final_norm = bool(bert.get("final_norm", False))
+            self.rotate_value = bool(bert.get("rotate_value", True))   # x-transformers 1.x rotates q, k AND v
+            self.rms_eps = 1e-8
+            self._sites = lrw_xt_sites(self.layers)
+            import random
+
+            self._layer_rng = random.Random(self.dropout_seed)
+            self.layer_skip_override: Optional[set[int]] = None     # tests: the set of `encoder.layers.{n}` indices to skip
+            self._rot_tab: dict[tuple[int, str], torch.Tensor] = {}
 
         self._specs = param_specs(config)
         self._bspecs = buffer_specs(config)
+        self._phys = {n: phys_shape(config, n, shp) for n, shp, _ in self._specs}
         sd = init_state_dict(config, seed=0 if seed is None else seed)
         for name, shape, kind in self._specs:
             t = sd[name]
@@ -206,26 +230,37 @@ class TransformerLightningModule(nn.Module):
             return 1
         if name == "cls_token" or name.startswith("encoder.embeddings"):
             return 2
-        if name.startswith("encoder.encoder"):
+        if name.startswith(("encoder.encoder", "encoder.layers", "encoder.final_norm")):
             return 3
         return 4
 
     def _transposed_entries(self, offsets) -> list[tuple[str, int, int, int]]:
-        """(key, source offset, out features, in features) of every linear weight whose data-gradient GEMM runs."""
-        D, out = self.dim, []
-        for i in range(self.layers):
-            p = f"encoder.encoder.layer.{i}"
-            out.append((f"{p}.qkv", offsets[f"{p}.attention.self.query.weight"][0], 3 * D, D))
-            out.append((f"{p}.attention.output.dense.weight", offsets[f"{p}.attention.output.dense.weight"][0], D, D))
-            out.append((f"{p}.intermediate.dense.weight", offsets[f"{p}.intermediate.dense.weight"][0], self.inter, D))
-            out.append((f"{p}.output.dense.weight", offsets[f"{p}.output.dense.weight"][0], D, self.inter))
-            q, k, v = (offsets[f"{p}.attention.self.{x}.weight"][0] for x in ("query", "key", "value"))
-            assert k == q + D * D and v == k + D * D, "q/k/v weights must be adjacent in the flat buffer"
-            qb, kb, vb = (offsets[f"{p}.attention.self.{x}.bias"][0] for x in ("query", "key", "value"))
-            assert kb == qb + D and vb == kb + D
+        """(key, source offset, out features, in features) — storage sizes — of every linear weight whose data-gradient GEMM runs."""
+        out = []
+        if self.encoder_type == "x-transformers":
+            Dp, E = self.dim_p, self.attn_inner
+            for i in range(self.layers):
+                a, f = f"encoder.layers.{2 * i}.1", f"encoder.layers.{2 * i + 1}.1.ff"
+                q, k, v = (offsets[f"{a}.to_{x}.weight"][0] for x in "qkv")
+                assert k == q + E * Dp and v == k + E * Dp, "to_q / to_k / to_v must be adjacent in the flat buffer"
+                out.append((f"{a}.qkv", q, 3 * E, Dp))
+                out.append((f"{a}.to_out.weight", offsets[f"{a}.to_out.weight"][0], Dp, E))
+                out.append((f"{f}.0.proj.weight", offsets[f"{f}.0.proj.weight"][0], self.glu_p, Dp))
+                out.append((f"{f}.3.weight", offsets[f"{f}.3.weight"][0], Dp, self.inter_p))
+        else:
+            D = self.dim
+            for i in range(self.layers):
+                p = f"encoder.encoder.layer.{i}"
+                out.append((f"{p}.qkv", offsets[f"{p}.attention.self.query.weight"][0], 3 * D, D))
+                out.append((f"{p}.attention.output.dense.weight", offsets[f"{p}.attention.output.dense.weight"][0], D, D))
+                out.append((f"{p}.intermediate.dense.weight", offsets[f"{p}.intermediate.dense.weight"][0], self.inter, D))
+                out.append((f"{p}.output.dense.weight", offsets[f"{p}.output.dense.weight"][0], D, self.inter))
+                q, k, v = (offsets[f"{p}.attention.self.{x}.weight"][0] for x in ("query", "key", "value"))
+                assert k == q + D * D and v == k + D * D, "q/k/v weights must be adjacent in the flat buffer"
+                qb, kb, vb = (offsets[f"{p}.attention.self.{x}.bias"][0] for x in ("query", "key", "value"))
+                assert kb == qb + D and vb == kb + D
         for n in ("audio_projection.weight", "category_classifier.weight"):
-            s = offsets[n][2]
-            out.append((n, offsets[n][0], s[0], s[1]))
+            out.append((n, offsets[n][0], offsets[n][2][0], self.dim_p))
         return out
 
     def store(self) -> "_ParamStore":
@@ -253,8 +288,13 @@ class TransformerLightningModule(nn.Module):
         audio_tokens = audio_tokens[:, : T * A].contiguous()
         if audio_tokens.size(1) != T * A:
             raise ValueError(f"audio_tokens has {audio_tokens.size(1)} steps, need >= {T * A}")
+        wm = None
+        if self.use_wb:           # lightning.py:145: the word-boundary indicator becomes feature 513 of every frame
+            if word_mask.shape != (videos.size(0), T):
+                raise ValueError(f"word_mask must be [batch, frames] = {(videos.size(0), T)}, got {tuple(word_mask.shape)}")
+            wm = word_mask.to(device=videos.device, dtype=torch.float32).contiguous()
         outs = _LrwFunction.apply(self.cls_token, self, st, videos.float().contiguous(), audio_tokens, labels.contiguous(),
-                                   torch.is_grad_enabled())
+                                   torch.is_grad_enabled(), wm)
         loss_category, loss_audio, acc = outs
         loss_total = loss_category + loss_audio * self.lambda_audio
         return {
@@ -288,8 +328,10 @@ class _ParamStore:
         nodecay = [(n, s) for n, s, k in specs if len(s) < 2]
         self.offsets: dict[str, tuple[int, int, tuple[int, ...]]] = {}
         off = 0
+        phys = getattr(model, "_phys", {})
+        self.phys: dict[str, tuple[int, ...]] = {n: tuple(phys.get(n, s)) for n, s, _ in specs}
         for n, s in decay + nodecay:
-            numel = math.prod(s)
+            numel = math.prod(self.phys[n])          # storage size: rows / columns padded to 64 where the model asks for it
             off = (off + 3) // 4 * 4                    # 16-byte alignment of every tensor
             self.offsets[n] = (off, numel, tuple(s))
             off += numel
@@ -373,6 +415,9 @@ class _ParamStore:
         seg = flat[o : o + numel]
         if len(shape) == 4:   # conv weights are stored [Co][kh][kw][Ci]; the tensor keeps the logical [Co,Ci,kh,kw] shape
             return seg.view(shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2)
+        ph = self.phys[name]
+        if ph != shape:       # padded storage: the tensor is the [:logical] corner of it
+            return seg.view(ph)[tuple(slice(0, d) for d in shape)]
         return seg.view(shape)
 
     # -- accessors used by the engine -------------------------------------------------------------
@@ -593,15 +638,106 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
     return dfeats
 
 
+# ----------------------------------------------------------------------------------------------------
+# `type: x-transformers` encoder (lightning.py:93-105,157-158): pre-norm residual blocks
+#   x += to_out(attention(rotary(to_q|to_k|to_v(RMSNorm(x)))));   x += W2 . dropout(value * gelu(gate)) (+ biases), [value|gate] = W1 . RMSNorm(x)
+# with whole blocks skipped at random in training (layer_dropout).  Rows are `dim_p` wide (513 -> 576), pads zero.
+# ----------------------------------------------------------------------------------------------------
+def _xt_skips(model) -> set:
+    """Indices n of `encoder.layers.{n}` skipped this step: AttentionLayers.forward draws python's random() once per layer, in
+    order, and skips the layer when it falls below layer_dropout (training only)."""
+    if not model.training or model.layer_drop_p <= 0.0:
+        return set()
+    if model.layer_skip_override is not None:
+        return set(model.layer_skip_override)
+    return {n for n in range(2 * model.layers) if model._layer_rng.random() < model.layer_drop_p}
+
+
+def _xt_encoder_forward(model, st: _ParamStore, tape: dict, feats: torch.Tensor, wm: Optional[torch.Tensor], B: int, T: int) -> torch.Tensor:
+    D, Dp, S, H, E = model.dim, model.dim_p, T + 1, model.heads, model.attn_inner
+    I, Ip, Up = model.inter, model.inter_p, model.glu_p
+    R = B * S
+    d_in = model._d("emb.in", "emb")
+    x = ops.xt_embed_fwd(feats, wm, st.p32("cls_token"), B, S, feats.shape[-1], D, Dp, drop=d_in)
+    key = (S, str(feats.device))
+    if key not in model._rot_tab:
+        model._rot_tab[key] = ops.rotary_table(S, feats.device)
+    tab = model._rot_tab[key]
+    skip = _xt_skips(model)
+    nrot = (3 if model.rotate_value else 2) * H
+    tape["xt"] = dict(d_in=d_in, tab=tab, nrot=nrot, F=feats.shape[-1])
+    for i in range(model.layers):
+        a, f = f"encoder.layers.{2 * i}", f"encoder.layers.{2 * i + 1}"
+        if 2 * i not in skip:
+            h, inv = ops.rmsnorm_fwd(x, st.p32(f"{a}.0.0.g"), D, model.rms_eps)
+            qkv, _ = ops.linear_fwd(h, st.s16(f"{a}.1.to_q.weight", 3 * E * Dp), None, rows=R, K=Dp, N=3 * E, x_pitch=Dp)
+            ops.rotary_(qkv, tab, S, nrot, 1)
+            dpr = model._d(f"enc.{i}.attn.probs", "attn")
+            ctx, probs = ops.mha_fwd(qkv, 3 * E, qkv[:, E:], qkv[:, 2 * E:], 3 * E, B=B, H=H, Lq=S, Lk=S, drop=dpr)
+            x1, _ = ops.linear_fwd(ctx, st.s16(f"{a}.1.to_out.weight"), None, rows=R, K=E, N=Dp, x_pitch=E, addend=x)
+            tape[a] = dict(x=x, h=h, inv=inv, qkv=qkv, ctx=ctx, probs=probs, dpr=dpr)
+            x = x1
+        if 2 * i + 1 not in skip:
+            h, inv = ops.rmsnorm_fwd(x, st.p32(f"{f}.0.0.g"), D, model.rms_eps)
+            u, _ = ops.linear_fwd(h, st.s16(f"{f}.1.ff.0.proj.weight"), st.p32(f"{f}.1.ff.0.proj.bias"), rows=R, K=Dp, N=Up, x_pitch=Dp)
+            dff = model._d(f"enc.{i}.ff.hidden")
+            y = ops.geglu_fwd(u, I, Ip, drop=dff)
+            x1, _ = ops.linear_fwd(y, st.s16(f"{f}.1.ff.3.weight"), st.p32(f"{f}.1.ff.3.bias"), rows=R, K=Ip, N=Dp, x_pitch=Ip, addend=x)
+            tape[f] = dict(x=x, h=h, inv=inv, u=u, y=y, dff=dff)
+            x = x1
+    if model.final_norm:
+        h, inv = ops.rmsnorm_fwd(x, st.p32("encoder.final_norm.g"), D, model.rms_eps)
+        tape["xt"]["final"] = dict(x=x, inv=inv)
+        x = h
+    return x
+
+
+def _xt_encoder_backward(model, st: _ParamStore, tape: dict, dh: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    D, Dp, S, H, E = model.dim, model.dim_p, T + 1, model.heads, model.attn_inner
+    I, Ip, Up = model.inter, model.inter_p, model.glu_p
+    R = B * S
+    tx = tape["xt"]
+    dx = dh
+    if "final" in tx:
+        dx = ops.rmsnorm_bwd(dx, tx["final"]["x"], st.p32("encoder.final_norm.g"), tx["final"]["inv"], st.g32("encoder.final_norm.g"), D)
+    for i in reversed(range(model.layers)):
+        a, f = f"encoder.layers.{2 * i}", f"encoder.layers.{2 * i + 1}"
+        if f in tape:
+            t = tape[f]
+            _lin_wgrad(model, t["y"], dx, st.g32(f"{f}.1.ff.3.weight"), st.g32(f"{f}.1.ff.3.bias"), R, Ip, Dp, Ip, Dp)
+            dy = ops.linear_dgrad(dx, st.t16(f"{f}.1.ff.3.weight"), rows=R, N=Dp, K=Ip, dy_pitch=Dp)
+            du = ops.geglu_bwd(dy, t["u"], I, drop=t["dff"])
+            _lin_wgrad(model, t["h"], du, st.g32(f"{f}.1.ff.0.proj.weight"), st.g32(f"{f}.1.ff.0.proj.bias"), R, Dp, Up, Dp, Up)
+            dhn = ops.linear_dgrad(du, st.t16(f"{f}.1.ff.0.proj.weight"), rows=R, N=Up, K=Dp, dy_pitch=Up)
+            dx = ops.rmsnorm_bwd(dhn, t["x"], st.p32(f"{f}.0.0.g"), t["inv"], st.g32(f"{f}.0.0.g"), D, addend=dx)
+        if a in tape:
+            t = tape[a]
+            _lin_wgrad(model, t["ctx"], dx, st.g32(f"{a}.1.to_out.weight"), None, R, E, Dp, E, Dp)
+            dctx = ops.linear_dgrad(dx, st.t16(f"{a}.1.to_out.weight"), rows=R, N=Dp, K=E, dy_pitch=Dp)
+            qkv = t["qkv"]
+            dqkv = torch.empty_like(qkv)
+            ops.mha_bwd(dctx, qkv, 3 * E, qkv[:, E:], qkv[:, 2 * E:], 3 * E, t["probs"], B=B, H=H, Lq=S, Lk=S, dq=dqkv, dq_pitch=3 * E,
+                        dk=dqkv[:, E:], dv=dqkv[:, 2 * E:], dkv_pitch=3 * E, drop=t["dpr"])
+            ops.rotary_(dqkv, tx["tab"], S, tx["nrot"], -1)           # the rotation is orthogonal: its transpose is the inverse rotation
+            gq = st.grad[st.offsets[f"{a}.1.to_q.weight"][0]:][: 3 * E * Dp]
+            _lin_wgrad(model, t["h"], dqkv, gq, None, R, Dp, 3 * E, Dp, 3 * E)
+            dhn = ops.linear_dgrad(dqkv, st.t16(f"{a}.1.qkv"), rows=R, N=3 * E, K=Dp, dy_pitch=3 * E)
+            dx = ops.rmsnorm_bwd(dhn, t["x"], st.p32(f"{a}.0.0.g"), t["inv"], st.g32(f"{a}.0.0.g"), D, addend=dx)
+        _ready(model, st, f"{a}.1.to_q.weight")
+    dfeats = ops.xt_embed_bwd(dx, st.g32("cls_token"), B, S, tx["F"], D, drop=tx["d_in"])
+    _ready(model, st, "cls_token")
+    return dfeats
+
+
 class _LrwFunction(torch.autograd.Function):
     """One autograd node for the whole model: forward records a tape, backward replays it by hand and writes the
     parameter gradients straight into the flat gradient buffer (the returned input gradients are all None)."""
 
     @staticmethod
-    def forward(ctx, _anchor, model: TransformerLightningModule, st: _ParamStore, videos, audio_tokens, labels, need_grad: bool):
+    def forward(ctx, _anchor, model: TransformerLightningModule, st: _ParamStore, videos, audio_tokens, labels, need_grad: bool, word_mask=None):
         training = model.training
         B, _, T, H, W = videos.shape
-        D, S = model.dim, T + 1
+        D, S = model.dim_p, T + 1            # storage width of the encoder rows (= dim unless the word boundary makes it 513 -> 576)
         A, G, V = model.audio_alignment, model.vq_groups, model.audio_vocab_size
         if not st.shadow_fresh:          # engine.TrainStep keeps the bf16 shadows current from its optimiser kernel
             st.refresh_shadows()
@@ -609,7 +745,10 @@ class _LrwFunction(torch.autograd.Function):
             model._advance_dropout(videos.device)
         tape: dict[str, Any] = {}
         feats = _frontend_forward(model, st, tape, videos, training)
-        h = _encoder_forward(model, st, tape, feats, B, T)              # [B*S, D] bf16
+        if model.encoder_type == "x-transformers":
+            h = _xt_encoder_forward(model, st, tape, feats, word_mask, B, T)
+        else:
+            h = _encoder_forward(model, st, tape, feats, B, T)          # [B*S, D] bf16
         # word head: rows s = 0
         C = model.word_labels
         logits_c, _ = ops.linear_fwd(h, st.s16("category_classifier.weight"), st.p32("category_classifier.bias"), rows=B, K=D, N=C,
@@ -662,7 +801,10 @@ class _LrwFunction(torch.autograd.Function):
         ops.linear_dgrad(dla, st.t16("audio_projection.weight"), rows=B * T, N=NA, K=D, dy_pitch=NA, out=dh, seq=(S, 1, T))
         ops.linear_dgrad(dlc, st.t16("category_classifier.weight"), rows=B, N=C, K=D, dy_pitch=Cp, out=dh, seq=(S, 0, 1))
         _ready(model, st, "audio_projection.weight")
-        dfeats = _encoder_backward(model, st, tape, dh, B, T)
+        if model.encoder_type == "x-transformers":
+            dfeats = _xt_encoder_backward(model, st, tape, dh, B, T)
+        else:
+            dfeats = _encoder_backward(model, st, tape, dh, B, T)
         _frontend_backward(model, st, tape, dfeats)
         ctx.tape = None
-        return None, None, None, None, None, None, None
+        return None, None, None, None, None, None, None, None

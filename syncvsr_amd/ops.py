@@ -509,6 +509,63 @@ def embed_bwd_scatter(ds, dcls, dpos, dtype0, B: int, S: int, D: int, drop_in=No
     return dfeats
 
 
+# -- `type: x-transformers` encoder passes (csrc/xt.hip) ---------------------------------------------
+def rmsnorm_fwd(x, g, D: int, eps: float = 1e-8):
+    """x bf16 [R][ld] (pad columns zero) -> (y, inv [R])."""
+    R, ld = x.shape
+    y = torch.empty_like(x)
+    inv = torch.empty(R, dtype=torch.float32, device=x.device)
+    _call("svsr_rmsnorm_fwd", _p(x), _p(g), _p(y), _p(inv), R, D, ld, float(eps), _stream())
+    return y, inv
+
+
+def rmsnorm_bwd(dy, x, g, inv, dg, D: int, addend=None) -> torch.Tensor:
+    R, ld = x.shape
+    dx = torch.empty_like(x)
+    part = scratch(_query("svsr_rmsnorm_bwd_rows", R)[0] * ld)
+    _call("svsr_rmsnorm_bwd", _p(dy), _p(x), _p(g), _p(inv), _p(addend), _p(dx), _p(dg), _p(part), R, D, ld, _stream())
+    return dx
+
+
+def rotary_table(S: int, device, rot: int = 32, theta: float = 10000.0) -> torch.Tensor:
+    """fp32 [S][rot]: cos then sin of position * theta^(-2j/rot), computed with the same torch ops as x-transformers' RotaryEmbedding."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, rot, 2).float() / rot))
+    freqs = torch.einsum("i,j->ij", torch.arange(S).float(), inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).contiguous().to(device)
+
+
+def rotary_(qkv: torch.Tensor, tab: torch.Tensor, S: int, heads_total: int, sign: int = 1) -> None:
+    R, ld = qkv.shape
+    assert tab.shape == (S, 32) and tab.dtype == torch.float32
+    _call("svsr_rotary", _p(qkv), _p(tab), R, S, heads_total, ld, int(sign), _stream())
+
+
+def geglu_fwd(u: torch.Tensor, I: int, ldy: int, drop=None) -> torch.Tensor:
+    R, ldu = u.shape
+    y = torch.empty((R, ldy), dtype=BF16, device=u.device)
+    _call("svsr_geglu_fwd", _p(u), _p(y), R, I, ldu, ldy, *_drop(drop), _stream())
+    return y
+
+
+def geglu_bwd(dy: torch.Tensor, u: torch.Tensor, I: int, drop=None) -> torch.Tensor:
+    R, ldu = u.shape
+    du = torch.empty_like(u)
+    _call("svsr_geglu_bwd", _p(dy), _p(u), _p(du), R, I, ldu, dy.shape[1], *_drop(drop), _stream())
+    return du
+
+
+def xt_embed_fwd(feats, wmask, cls, B: int, S: int, F: int, D: int, ld: int, drop=None) -> torch.Tensor:
+    x0 = torch.empty((B * S, ld), dtype=BF16, device=feats.device)
+    _call("svsr_xt_embed_fwd", _p(feats), _p(wmask), _p(cls), _p(x0), B, S, F, D, ld, *_drop(drop), _stream())
+    return x0
+
+
+def xt_embed_bwd(dx0, dcls, B: int, S: int, F: int, D: int, drop=None) -> torch.Tensor:
+    dfeats = torch.empty((B * (S - 1), F), dtype=BF16, device=dx0.device)
+    _call("svsr_xt_embed_bwd", _p(dx0), _p(dfeats), _p(dcls), B, S, F, D, dx0.shape[1], *_drop(drop), _stream())
+    return dfeats
+
+
 def bias_act_bwd(dy, z, db, *, R: int, N: int, n_valid: int, ld: int, relu: bool = False, gscale: float = 1.0) -> torch.Tensor:
     """db[:n_valid] += column sums of dz, where dz = dy * act'(z) if z is given (returned) else dy; act = GELU from the
     pre-activation z, or (relu=True) ReLU from the saved output z."""

@@ -122,6 +122,43 @@ def test_param_store_layout_on_cpu():
     assert float(st.g32("audio_projection.weight").sum()) == 3.0 * p.numel()
 
 
+def test_xtransformers_word_boundary_store_is_padded_and_logical_on_cpu():
+    """`type: x-transformers` + use_word_boundary (the shipped WB yaml): 513-wide tensors live in 576-wide storage whose pads are
+    zero; parameters / state dict keep the reference modules' logical shapes; to_q/to_k/to_v are adjacent for the fused GEMM."""
+    from syncvsr_amd.config import xtransformers_lrw_config
+    from syncvsr_amd.init import init_state_dict, param_specs
+    from syncvsr_amd.model import Model, _ParamStore
+
+    cfg = xtransformers_lrw_config(True, model__bert__depth=2)
+    model = Model(cfg)
+    assert (model.dim, model.dim_p, model.inter, model.inter_p, model.glu_p) == (513, 576, 2052, 2112, 4160)
+    assert (model.drop_p, model.attn_drop_p, model.emb_drop_p, model.layer_drop_p) == (0.3, 0.0, 0.0, 0.2)
+    sd = init_state_dict(cfg, seed=7, perturb_norm=True)
+    assert sd["cls_token"][0, 0, -1] == 0.0                            # lightning.py:109-110
+    model.load_state_dict(sd, strict=True)
+    st = _ParamStore(model, torch.device("cpu"))
+    assert st.owns(model)
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), sd[n]), n
+        assert p.grad is not None and p.grad.shape == p.shape == sd[n].shape
+    q = st.offsets["encoder.layers.2.1.to_q.weight"][0]
+    assert st.offsets["encoder.layers.2.1.to_k.weight"][0] == q + 512 * 576 and st.offsets["encoder.layers.2.1.to_v.weight"][0] == q + 2 * 512 * 576
+    o, numel, shape = st.offsets["encoder.layers.1.1.ff.3.weight"]
+    assert (numel, shape, st.phys["encoder.layers.1.1.ff.3.weight"]) == (576 * 2112, (513, 2052), (576, 2112))
+    full = st.flat[o:o + numel].view(576, 2112)
+    assert torch.equal(full[:513, :2052], sd["encoder.layers.1.1.ff.3.weight"]) and not full[513:].any() and not full[:, 2052:].any()
+    assert st.t_offsets["encoder.layers.0.1.qkv"][1] == (576, 1, 1536)
+    assert st.t_offsets["encoder.layers.1.1.ff.0.proj.weight"][1] == (576, 1, 4160)
+    assert st.t_offsets["category_classifier.weight"][1] == (576, 1, 512)
+    # the no-word-boundary variant needs no padding at all
+    cfg2 = xtransformers_lrw_config(False, model__bert__depth=1)
+    m2 = Model(cfg2)
+    assert (m2.dim, m2.dim_p, m2.inter_p, m2.glu_p) == (512, 512, 2048, 4096)
+    assert all(tuple(m2._phys[n]) == tuple(shp) for n, shp, _ in param_specs(cfg2))
+    with pytest.raises(NotImplementedError):
+        Model(xtransformers_lrw_config(True, model__bert__ff_glu=False))
+
+
 def test_stride2_dgrad_tap_plan():
     """Each input-parity class of a stride-2 3x3 transposed conv uses only its own taps (1, 2, 2, 4 of the 9)."""
     k, stride, pad = 3, 2, 1
