@@ -19,7 +19,7 @@
 #include <map>
 #include <vector>
 
-#include "igemm_common.h"
+#include "common.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Launch plan (host-built, device-resident int32 words): the rows of the contraction are grouped into CLASSES of output
@@ -348,11 +348,11 @@ __global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
 // ---------------------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int NS>
 static int launch_glds(const IgemmFwdArgs& a, int gx, int gy, hipStream_t stream) {
-    const size_t lds = (size_t)NS * (BM + BN) * 64 * sizeof(bf16_t) + (size_t)BM * sizeof(long) + 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    const size_t lds = (size_t)NS * (BM + BN) * 64 * sizeof(bf16_t) + (size_t)BM * sizeof(long) + 128 + (size_t)svsr_tune_get(SVSR_TUNE_IGEMM_LDS_PAD);
+    static size_t attr_set = 0;
+    if (attr_set < lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_fwd_glds<BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        attr_set = lds;
     }
     hipLaunchKernelGGL((k_igemm_fwd_glds<BM, BN, NS>), dim3(gx, gy), dim3(256), lds, stream, a);
     return svsr_check_launch();
