@@ -261,6 +261,14 @@ int svsr_ctc_fwd(const float* logits, int ld, const int64_t* labels, int Lmax, c
 /* dlogits [B*T][ldo] bf16 = gout/B * (softmax - label occupancy) for t < ilen[b], 0 elsewhere (and for infeasible targets). */
 int svsr_ctc_grad(const float* logits, int ld, const int64_t* labels, int Lmax, const int* ilen, int B, int T, int V, const float* lse, const float* ab, const float* nll, const float* gout, void* dlogits, int ldo, hipStream_t stream);
 
+/* CTC prefix scores of beam-search extensions (espnet/nets/ctc_prefix_score.py:11-165 `CTCPrefixScoreTH.__call__`, driven by
+ * scorers/ctc.py:87-127 from LRS/video/lightning.py:237-279).  logp fp32 [T][ldp] = log-softmax of ctc_lo over the clip;
+ * r_prev fp32 [n][T][2] = (non-blank, blank) forward log-probabilities of each hypothesis' prefix; last int64 [n] = last label
+ * of each prefix; ids int64 [n][S] = candidate labels per hypothesis (null: all V labels, S = V); out_len = labels in the
+ * prefixes without <sos>.  Writes r_new fp32 [n][S][T][2] (state of every extension) and psi fp32 [n][S] (log prefix
+ * probability; eos -> total probability of the prefix, blank -> -1e10). */
+int svsr_ctc_prefix_score(const float* logp, int ldp, const float* r_prev, const int64_t* last, const int64_t* ids, float* r_new, float* psi, int T, int V, int n, int S, int out_len, int blank, int eos, hipStream_t stream);
+
 /* Decoder input: x[r] = emb[tok[r]] * scale + pe[r % L]  (torch.nn.Embedding + PositionalEncoding, decoder.py:80-84,
  * embedding.py:78-89); backward scatter-adds scale * dx into demb. */
 int svsr_embed_pos_fwd(const int64_t* tok, const float* emb, const float* pe, void* x, int R, int L, int D, float scale, hipStream_t stream);

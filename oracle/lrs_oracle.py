@@ -330,3 +330,72 @@ def forward(sd: SD, args: Any, x: Tensor, lengths: Tensor, audio_tokens: Tensor,
     loss = alpha * loss_ctc + (1 - alpha) * loss_att + float(args.audio_weight) * loss_audio
     return {"loss": loss, "loss_ctc": loss_ctc, "loss_att": loss_att, "loss_audio": loss_audio,
             "acc": th_accuracy(pred, ys_out)}
+
+
+# --------------------------------------------------------------------------------------------
+# inference scorers (transformer/decoder.py:153-220, scorers/ctc.py:87-127, ctc_prefix_score.py:11-165) — CPU checkers for
+# syncvsr_amd/lrs_infer.py; pinned by tests/golden/lrs_infer_tiny.npz (the reference's own BatchBeamSearch run)
+# --------------------------------------------------------------------------------------------
+CTC_LOGZERO = -1.0e10
+
+
+def ctc_prefix_score(logp: Tensor, r_prev: Tensor, last: Tensor, ids: Tensor | None, out_len: int, blank: int, eos: int) -> tuple[Tensor, Tensor]:
+    """logp [T, V]; r_prev [n, T, 2]; last [n]; ids [n, S] or None -> (r_new [n, S, T, 2], psi [n, S]).  Algorithm 2 of Watanabe et al.
+    as ctc_prefix_score.py:118-165 evaluates it: r_n[t] = logaddexp(r_n[t-1], phi[t-1]) + x[t], r_b[t] = logaddexp(r_n[t-1], r_b[t-1])
+    + x_blank[t], psi = logsumexp(r_n[start-1], phi[t-1] + x[t] for t >= start)."""
+    T, V = logp.shape
+    n = r_prev.shape[0]
+    if ids is None:
+        ids = torch.arange(V).unsqueeze(0).expand(n, V)
+    S = ids.shape[1]
+    x = logp[:, ids]                                   # [T, n, S]
+    xb = logp[:, blank]                                # [T]
+    r_sum = torch.logaddexp(r_prev[..., 0], r_prev[..., 1])           # [n, T]
+    same = ids == last.view(n, 1)                      # [n, S]
+    phi = torch.where(same.unsqueeze(0), r_prev[..., 1].t().unsqueeze(2), r_sum.t().unsqueeze(2))     # [T, n, S]
+    start = max(out_len, 1)
+    r = torch.full((T, 2, n, S), CTC_LOGZERO, dtype=logp.dtype)
+    if out_len == 0:
+        r[0, 0] = x[0]
+    acc = [r[start - 1, 0]]
+    for t in range(start, T):
+        r[t, 0] = torch.logaddexp(r[t - 1, 0], phi[t - 1]) + x[t]
+        r[t, 1] = torch.logaddexp(r[t - 1, 0], r[t - 1, 1]) + xb[t]
+        acc.append(phi[t - 1] + x[t])
+    psi = torch.logsumexp(torch.stack(acc), dim=0)
+    psi = torch.where(ids == eos, r_sum[:, T - 1].unsqueeze(1), psi)
+    psi = torch.where(ids == blank, torch.full_like(psi, CTC_LOGZERO), psi)
+    return r.permute(2, 3, 0, 1).contiguous(), psi
+
+
+class OracleDecoderScorer:
+    """Decoder.batch_score restated without the cache (the last row of the causal decoder is the same)."""
+
+    def __init__(self, sd: SD, args: Any):
+        self.sd, self.args = sd, args
+
+    def batch_init_state(self, x):
+        return None
+
+    def batch_score(self, ys: Tensor, states, xs: Tensor):
+        n, T = xs.shape[:2]
+        pred = decoder(ys, xs, torch.ones(n, 1, T, dtype=torch.bool), self.sd, self.args)
+        return torch.log_softmax(pred[:, -1], dim=-1), [None] * n
+
+    def select_states(self, states, prev, tok):
+        return None
+
+
+def make_oracle_ctc_scorer(sd: SD, eos: int):
+    """The product's CTCPrefixScorer host logic (full-vocabulary scatter, eos / blank rules, state selection) with the two device
+    calls replaced by this module's CPU restatements — so the CPU test exercises the shipped search + state plumbing."""
+    from syncvsr_amd.lrs_infer import CTCPrefixScorer
+
+    class _Scorer(CTCPrefixScorer):
+        def ctc_log_softmax(self, x: Tensor) -> Tensor:
+            return torch.log_softmax(_lin(x, sd, "ctc.ctc_lo"), dim=-1)
+
+        def _prefix(self, logp, r_prev, last, ids, out_len):
+            return ctc_prefix_score(logp, r_prev, last, ids, out_len, self.blank, self.eos)
+
+    return _Scorer(None, eos)

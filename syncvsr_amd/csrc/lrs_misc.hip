@@ -405,6 +405,51 @@ __global__ __launch_bounds__(256) void k_scale_bf16(const bf16_t* __restrict__ x
 
 static inline int grid1d(long n, int cap = 2048) { long b = (n + 255) / 256; if (b > cap) b = cap; if (b < 1) b = 1; return (int)b; }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// CTC prefix scores for beam search (Watanabe et al., "Hybrid CTC/attention architecture for end-to-end speech recognition",
+// Algorithm 2; the reference vectorises it in torch, espnet/nets/ctc_prefix_score.py:11-165, one launch of ~10 small kernels per
+// frame).  Here one thread owns one (hypothesis, candidate label) pair and walks the T frames of the recursion in registers:
+//   r_n[t] = logaddexp(r_n[t-1], phi[t-1]) + logp[t][c]         phi[t] = r_b_prev[t] if c == last label else logaddexp(r_n_prev[t], r_b_prev[t])
+//   r_b[t] = logaddexp(r_n[t-1], r_b[t-1]) + logp[t][blank]
+//   psi    = logsumexp(r_n[start-1], phi[t-1] + logp[t][c] for t in [start, T)),   start = max(#labels in the prefix, 1)
+// eos gets logaddexp(r_n_prev[T-1], r_b_prev[T-1]), blank gets LOGZERO.  r_new [n][S][T][2] is the state of each extension.
+// ---------------------------------------------------------------------------------------------------------------------
+#define CTC_LOGZERO (-1.0e10f)
+__device__ __forceinline__ float logaddexpf_(float a, float b) {
+    const float m = fmaxf(a, b);
+    return m + __logf(__expf(a - m) + __expf(b - m));
+}
+
+__global__ __launch_bounds__(256) void k_ctc_prefix_score(const float* __restrict__ logp, const float* __restrict__ r_prev, const long* __restrict__ last,
+                                                          const long* __restrict__ ids, float* __restrict__ r_new, float* __restrict__ psi, int T,
+                                                          int V, int ldp, int n, int S, int out_len, int blank, int eos) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * S) return;
+    const int h = idx / S, j = idx - h * S;
+    const int c = ids != nullptr ? (int)ids[(long)h * S + j] : j;
+    float* rn_out = r_new + (long)idx * T * 2;
+    const float* rp = r_prev + (long)h * T * 2;
+    const bool same = c == (int)last[h];
+    const int start = out_len > 1 ? out_len : 1;
+    for (int t = 0; t < start - 1 && t < T; ++t) { rn_out[2 * t] = CTC_LOGZERO; rn_out[2 * t + 1] = CTC_LOGZERO; }
+    float rn = (out_len == 0) ? logp[c] : CTC_LOGZERO, rb = CTC_LOGZERO;          // r[start-1]
+    if (start - 1 < T) { rn_out[2 * (start - 1)] = rn; rn_out[2 * (start - 1) + 1] = rb; }
+    float acc = rn;
+    for (int t = start; t < T; ++t) {
+        const float pn = rp[2 * (t - 1)], pb = rp[2 * (t - 1) + 1];
+        const float phi = same ? pb : logaddexpf_(pn, pb);
+        const float x = logp[(long)t * ldp + c], xb = logp[(long)t * ldp + blank];
+        acc = logaddexpf_(acc, phi + x);
+        const float nn = logaddexpf_(rn, phi) + x;
+        const float nb = logaddexpf_(rn, rb) + xb;
+        rn = nn; rb = nb;
+        rn_out[2 * t] = rn; rn_out[2 * t + 1] = rb;
+    }
+    if (c == eos) acc = logaddexpf_(rp[2 * (T - 1)], rp[2 * (T - 1) + 1]);
+    if (c == blank) acc = CTC_LOGZERO;
+    psi[idx] = acc;
+}
+
 extern "C" {
 
 int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale,
@@ -488,6 +533,15 @@ int svsr_scale_bf16(const void* x, void* y, int64_t n, float alpha, const unsign
     if (n % 8 != 0) return SVSR_ERR_ARG;
     hipLaunchKernelGGL(k_scale_bf16, dim3(grid1d(n / 8)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (long)(n / 8), alpha,
                        svsr_make_drop(drop_seed, drop_site, drop_p));
+    return svsr_check_launch();
+}
+
+int svsr_ctc_prefix_score(const float* logp, int ldp, const float* r_prev, const int64_t* last, const int64_t* ids, float* r_new, float* psi, int T,
+                          int V, int n, int S, int out_len, int blank, int eos, hipStream_t stream) {
+    if (T < 1 || V < 2 || n < 1 || S < 1 || (ids == nullptr && S != V) || ldp < V || out_len < 0 || blank < 0 || blank >= V || eos < 0 || eos >= V)
+        return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_ctc_prefix_score, dim3(grid1d((long)n * S)), dim3(256), 0, stream, logp, r_prev, (const long*)last, (const long*)ids, r_new,
+                       psi, T, V, ldp, n, S, out_len, blank, eos);
     return svsr_check_launch();
 }
 

@@ -21,7 +21,7 @@ import torch.nn as nn
 from . import ops
 from .config import Config
 from .lrs_init import LRS_ODIM, lrs_audio_dims, lrs_buffer_specs, lrs_init_state_dict, lrs_param_specs
-from .model import BF16, _SideStream, _ParamStore, _attach, _frontend_backward, _frontend_forward, _get, _bn_stats, _ready
+from .model import BF16, _Holder, _SideStream, _ParamStore, _attach, _frontend_backward, _frontend_forward, _get, _bn_stats, _ready
 
 LN_EPS = 1e-12          # transformer/layer_norm.py:19
 
@@ -42,6 +42,74 @@ class LrsTargets:
 
     def __init__(self, labels: torch.Tensor, ys_in: torch.Tensor, ys_out: torch.Tensor):
         self.labels, self.ys_in, self.ys_out = labels, ys_in, ys_out
+
+
+class _EncoderFacade(_Holder):
+    """`E2E.encoder` of the reference as a callable (transformer/encoder.py:257-289): model.encoder(xs, masks) -> (xs, masks)."""
+
+    def forward(self, xs: torch.Tensor, masks: Optional[torch.Tensor] = None, extract_resnet_feats: bool = False):
+        owner = self._owner()
+        lengths = None if masks is None else masks.reshape(masks.size(0), -1).sum(-1)
+        if extract_resnet_feats:
+            return owner.encode(xs, lengths, resnet_feats=True)
+        return owner.encode(xs, lengths), masks
+
+    def forward_one_step(self, xs: torch.Tensor, masks: Optional[torch.Tensor] = None, cache=None):
+        """encoder.py:291-318 for cache=None: (xs, masks, per-layer outputs).  Incremental re-use of a cache is not implemented —
+        the reference's own inference path never passes one (lightning.py:100-101,114-118)."""
+        if cache is not None:
+            raise NotImplementedError("Encoder.forward_one_step with a cache (streaming) is not implemented")
+        owner = self._owner()
+        lengths = None if masks is None else masks.reshape(masks.size(0), -1).sum(-1)
+        outs: list = []
+        h = owner.encode(xs, lengths, layer_outs=outs)
+        return h, masks, outs
+
+
+class _DecoderFacade(_Holder):
+    """`E2E.decoder` as the beam-search scorer of the reference (transformer/decoder.py:153-220)."""
+
+    def _scorer(self):
+        from .lrs_infer import DecoderScorer
+
+        return DecoderScorer(self._owner())
+
+    def forward_one_step(self, tgt, tgt_mask, memory, memory_mask=None, cache=None):
+        return self._scorer().forward_one_step(tgt, tgt_mask, memory, memory_mask, cache)
+
+    def score(self, ys, state, x):
+        return self._scorer().score(ys, state, x)
+
+    def batch_score(self, ys, states, xs):
+        return self._scorer().batch_score(ys, states, xs)
+
+    def init_state(self, x):
+        return None
+
+    def batch_init_state(self, x):
+        return None
+
+    def select_state(self, state, i, new_id=None):
+        return None if state is None else state[i]
+
+    def select_states(self, states, prev, tok):
+        return None
+
+
+class _CtcFacade(_Holder):
+    """`E2E.ctc` inference helpers (ctc.py:154-181) on hs_pad [B, T, adim]."""
+
+    def log_softmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
+        from .lrs_infer import CTCPrefixScorer
+
+        sc = CTCPrefixScorer(self._owner(), self._owner().eos)
+        return torch.stack([sc.ctc_log_softmax(h) for h in hs_pad])
+
+    def softmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
+        return self.log_softmax(hs_pad).exp()
+
+    def argmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
+        return self.log_softmax(hs_pad).argmax(dim=-1)
 
 
 class E2E(nn.Module):
@@ -113,6 +181,12 @@ class E2E(nn.Module):
         self._side = _SideStream()
         self.grad_ready_hook = None
         self._pos_cache: dict[tuple[str, int, str], torch.Tensor] = {}
+        import weakref
+
+        for name, cls in (("encoder", _EncoderFacade), ("decoder", _DecoderFacade), ("ctc", _CtcFacade)):
+            node = self._modules[name]
+            node.__class__ = cls
+            object.__setattr__(node, "_owner", weakref.ref(self))
 
     # ------------------------------------------------------------------------------------------------
     @staticmethod
@@ -231,7 +305,16 @@ class E2E(nn.Module):
         return LrsTargets(labels, ys_in, ys_out.contiguous())
 
     # ------------------------------------------------------------------------------------------------
-    def encode(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+    # inference surface (syncvsr_amd/lrs_infer.py): model.encoder(xs, masks), model.decoder.batch_score(...), model.ctc.log_softmax(...)
+    def scorers(self) -> dict:
+        """e2e_asr_transformer.py:182-184: dict(decoder=self.decoder, ctc=CTCPrefixScorer(self.ctc, self.eos))."""
+        from .lrs_infer import CTCPrefixScorer
+
+        return dict(decoder=self.decoder, ctc=CTCPrefixScorer(self, self.eos))
+
+    # ------------------------------------------------------------------------------------------------
+    def encode(self, x: torch.Tensor, lengths: Optional[torch.Tensor] = None, layer_outs: Optional[list] = None,
+               resnet_feats: bool = False) -> torch.Tensor:
         """`self.encoder(xs, masks)[0]` of the reference (what its inference path calls, LRS/video/lightning.py:100-101,113-116):
         x [B,T,1,H,W] -> fp32 [B,T,adim]; forward only (no autograd), honours train/eval mode for BatchNorm and dropout."""
         if x.device.type != "cuda":
@@ -243,9 +326,16 @@ class E2E(nn.Module):
         if lengths is None:
             lengths = torch.full((B,), T, dtype=torch.int32, device=x.device)
         ilen = lengths.to(device=x.device, dtype=torch.int32).contiguous()
+        tape: dict[str, Any] = {}
+        if layer_outs is not None:
+            tape["layer_outs"] = []
         with torch.no_grad():
-            h = _encoder_fwd(self, st, {}, x.float().contiguous(), ilen, self.training)[2]
-        return h.float().view(B, T, self.adim)
+            res = _encoder_fwd(self, st, tape, x.float().contiguous(), ilen, self.training)
+        if resnet_feats:                                   # Encoder.forward(extract_resnet_feats=True), encoder.py:272-273
+            return res[0].float().view(B, T, 512)
+        if layer_outs is not None:
+            layer_outs.extend(t.float().view(B, T, self.adim) for t in tape["layer_outs"])
+        return res[2].float().view(B, T, self.adim)
 
     def forward(self, x: torch.Tensor, lengths: torch.Tensor, audios: torch.Tensor, label):
         if x.device.type != "cuda":
@@ -426,6 +516,7 @@ def _decoder_fwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, memory
         x2 = _lin(st, ctx2, f"{p}.src_attn.linear_out", R, D, D, addend=x1, drop=dco)
         t["src"] = dict(x=x1, tn=t2, m=m2, r=r2, q=q, kv=kv, ctx=ctx2, probs=probs2, dpr=dcp, dao=dco)
         x = _ffn_fwd(model, st, t, "ff", x2, f"{p}.feed_forward", R, D, U, 1.0, f"{p}.norm3", f"dec.{i}.ff")
+        t["out"] = x
         tape[p] = t
     tn, m, r = _ln(st, x, "decoder.after_norm")
     V = model.odim
@@ -487,6 +578,8 @@ def _encoder_fwd(model: E2E, st: _ParamStore, tape: dict, x, ilen, training: boo
         pos16 = ops.scale_bf16(pos16, 1.0, drop=dpos)                                      # dropout(pos_emb), embedding.py:217
     for i in range(model.elayers):
         h = _encoder_layer_fwd(model, st, tape, i, h, pos16, ilen, B, T, training)
+        if "layer_outs" in tape:
+            tape["layer_outs"].append(h)
     hx = h
     h, mA, rA = _ln(st, hx, "encoder.after_norm")
     return feats, hx, h, mA, rA, pos16, dex

@@ -707,6 +707,23 @@ def ctc_grad(logits, ld: int, labels, ilen, B: int, T: int, V: int, state, gout,
     return dz
 
 
+def ctc_prefix_score(logp: torch.Tensor, r_prev: torch.Tensor, last: torch.Tensor, ids: Optional[torch.Tensor], out_len: int, blank: int,
+                     eos: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """logp fp32 [T, V], r_prev fp32 [n, T, 2], last int64 [n], ids int64 [n, S] or None (all V labels)
+    -> (r_new fp32 [n, S, T, 2], psi fp32 [n, S]).  See svsr_ctc_prefix_score."""
+    T, V = logp.shape
+    n = r_prev.shape[0]
+    assert logp.dtype == torch.float32 and logp.is_contiguous() and r_prev.dtype == torch.float32 and r_prev.shape == (n, T, 2)
+    assert r_prev.is_contiguous() and last.dtype == torch.int64 and last.numel() == n
+    assert ids is None or (ids.dtype == torch.int64 and ids.is_contiguous() and ids.shape[0] == n)
+    S = V if ids is None else ids.shape[1]
+    r_new = torch.empty((n, S, T, 2), dtype=torch.float32, device=logp.device)
+    psi = torch.empty((n, S), dtype=torch.float32, device=logp.device)
+    _call("svsr_ctc_prefix_score", _p(logp), V, _p(r_prev), _p(last), _p(ids), _p(r_new), _p(psi), T, V, n, S, int(out_len), int(blank), int(eos),
+          _stream())
+    return r_new, psi
+
+
 def embed_pos_fwd(tok, emb, pe, L: int, D: int, scale: float) -> torch.Tensor:
     R = tok.numel()
     x = torch.empty((R, D), dtype=BF16, device=emb.device)

@@ -69,6 +69,35 @@ LRS_CASES = {
 }
 
 
+# Inference (beam search) cases: (arg overrides, odim, clip frames, clip size, weight seed, data seed, head gain, eos bias, [(beam, ctc_weight)]).
+# `head gain` multiplies decoder.output_layer / ctc.ctc_lo so the random-init posteriors are peaked and the n-best order is not a
+# coin toss between near-ties.
+LRS_INFER_CASES = {
+    "lrs_infer_tiny": (dict(_LRS_TINY, dlayers=2), 41, 16, 24, 21, 191, 6.0, 2.5, [(5, 0.1), (30, 0.1), (4, 0.3)]),
+}
+
+
+def build_lrs_infer_case(name: str, load_golden: bool = True):
+    """-> (args, odim, state_dict (eval, perturbed running statistics), clip [T,1,H,W], runs [(beam, ctc_weight)], golden | None)"""
+    from syncvsr_amd.lrs_init import default_lrs_args, lrs_init_state_dict
+
+    over, odim, frames, size, wseed, dseed, gain, eos_bias, runs = LRS_INFER_CASES[name]
+    args = default_lrs_args(**over)
+    sd = lrs_init_state_dict(args, odim, seed=wseed, perturb_norm=True)
+    g = torch.Generator().manual_seed(5)
+    for k in list(sd):
+        if k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+    for k in ("decoder.output_layer.weight", "ctc.ctc_lo.weight"):
+        sd[k] = sd[k] * gain
+    sd["decoder.output_layer.bias"][odim - 1] += eos_bias      # lets hypotheses END before the length limit (end_detect path)
+    clip = torch.randn(frames, 1, size, size, generator=torch.Generator().manual_seed(dseed))
+    gold = np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False) if load_golden else None
+    return args, odim, sd, clip, runs, gold
+
+
 def build_lrs_case(name: str, load_golden: bool = True):
     """-> (args, odim, state_dict, batch, training, golden npz | None)"""
     from syncvsr_amd.lrs_init import default_lrs_args, lrs_init_state_dict, lrs_synthetic_batch

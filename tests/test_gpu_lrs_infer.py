@@ -1,0 +1,144 @@
+"""LRS inference surface on the GPU (-m gpu): `model.encoder(x, None)`, `model.decoder.batch_score`, `model.ctc.log_softmax`, the HIP
+CTC-prefix kernel and the whole beam search against (a) the reference's own outputs for the same seeded weights and clip
+(tests/golden/lrs_infer_tiny.npz) and (b) the oracle's CPU restatement.  bf16 storage / fp32 accumulation: log-probabilities agree to
+a relative L2 error of 1e-2 (max 0.1 absolute on the case's deliberately peaked posteriors); the fp32 CTC-prefix kernel agrees with the fp64 restatement to 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from golden_cases import build_lrs_infer_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("T,V,n,S", [(16, 41, 5, 7), (150, 5049, 40, 60), (37, 300, 3, None)])
+def test_ctc_prefix_kernel_matches_restatement_over_several_steps(dev, T, V, n, S):
+    from oracle import lrs_oracle as O
+    from syncvsr_amd import ops
+
+    g = torch.Generator().manual_seed(T + V)
+    logp = torch.log_softmax(2.0 * torch.randn(T, V, generator=g), dim=-1)
+    eos = V - 1
+    r_prev = torch.full((n, T, 2), O.CTC_LOGZERO)
+    r_prev[:, :, 1] = torch.cumsum(logp[:, 0], 0)
+    last = torch.full((n,), eos, dtype=torch.int64)
+    for step in range(4):
+        ids = None if S is None else torch.stack([torch.randperm(V, generator=g)[:S] for _ in range(n)])
+        if ids is not None and step > 0:
+            ids[:, 0] = last                      # make sure the "repeat the last label" branch is taken
+            ids[0, 1], ids[1, 1] = eos, 0         # and the eos / blank rules
+        r_ref, psi_ref = O.ctc_prefix_score(logp.double(), r_prev.double(), last, ids, step, 0, eos)
+        r_new, psi = ops.ctc_prefix_score(logp.to(dev), r_prev.to(dev).contiguous(), last.to(dev), None if ids is None else ids.to(dev), step, 0, eos)
+        torch.cuda.synchronize()
+        live = psi_ref > -1e9
+        assert torch.equal(live, psi.cpu() > -1e9)
+        np.testing.assert_allclose(psi.cpu().numpy()[live.numpy()], psi_ref.numpy()[live.numpy()], atol=2e-4, rtol=1e-5)
+        rl = r_ref > -1e9
+        np.testing.assert_allclose(r_new.cpu().numpy()[rl.numpy()], r_ref.numpy()[rl.numpy()], atol=5e-4, rtol=1e-5)
+        assert bool((r_new.cpu()[~rl] < -1e9).all())
+        # extend every hypothesis by one of its candidates and go on
+        j = torch.randint(1 if S is None else 2, (S or V) - 1, (n,), generator=g)
+        r_prev = r_ref[torch.arange(n), j].float().contiguous()
+        last = (j if ids is None else ids[torch.arange(n), j]).long()
+
+
+@pytest.fixture(scope="module")
+def tiny(dev):
+    from syncvsr_amd.lrs_model import E2E
+
+    args, odim, sd, clip, runs, gold = build_lrs_infer_case("lrs_infer_tiny")
+    model = E2E(odim, args)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).eval()
+    return model, odim, clip, runs, gold
+
+
+def test_encoder_decoder_ctc_entry_points_match_reference(dev, tiny):
+    model, odim, clip, runs, gold = tiny
+    enc, masks = model.encoder(clip.unsqueeze(0).to(dev), None)                       # lightning.py:115-118
+    assert masks is None and enc.shape == (1, clip.shape[0], model.adim)
+    g_enc = torch.from_numpy(gold["enc_feat"])
+    rel = float((enc[0].cpu() - g_enc).norm() / g_enc.norm())
+    assert rel <= 3e-2, rel
+    h, m2, outs = model.encoder.forward_one_step(clip.unsqueeze(0).to(dev), None)
+    assert torch.equal(h, enc) and len(outs) == model.elayers and outs[0].shape == enc.shape
+    logp = model.ctc.log_softmax(g_enc.unsqueeze(0).to(dev))[0]
+    assert float((logp.cpu() - torch.from_numpy(gold["ctc_logp"])).abs().max()) <= 5e-2        # the case multiplies ctc_lo by 6 (peaked posteriors)
+    assert torch.equal(model.ctc.argmax(g_enc.unsqueeze(0).to(dev))[0].cpu(), torch.from_numpy(gold["ctc_logp"]).argmax(-1))
+    for j in range(4):
+        ys = torch.from_numpy(gold[f"run1.dec{j}.ys"]).to(dev)
+        xs = g_enc.to(dev).unsqueeze(0).expand(ys.shape[0], -1, -1)
+        got, states = model.decoder.batch_score(ys, [None] * ys.shape[0], xs)
+        want = torch.from_numpy(gold[f"run1.dec{j}.logp"])
+        assert got.shape == want.shape and len(states) == ys.shape[0]
+        # the case multiplies the output layer by 6: log-probabilities span ~[-25, 0]; bf16 activations give 0.06 at the tails
+        assert float((got.cpu() - want).abs().max()) <= 0.1 and float((got.cpu() - want).norm() / want.norm()) <= 1e-2, \
+            (j, float((got.cpu() - want).abs().max()), float((got.cpu() - want).norm() / want.norm()))
+    one, cache = model.decoder.forward_one_step(ys[:2], None, xs[:2])
+    assert torch.equal(one, got[:2]) and len(cache) == model.dlayers and cache[0].shape == (2, ys.shape[1], model.ddim)
+    s1, _ = model.decoder.score(ys[0], None, g_enc.to(dev))
+    assert float((s1 - got[0]).abs().max()) <= 2e-2          # a different batch shape may pick different tile instantiations
+
+
+def _rescore(sd, args, odim, enc, yseq, ctcw, maxlen):
+    """Total score of one hypothesis under the oracle's fp64 scorers, accumulated along its own path (what the search adds up)."""
+    from oracle import lrs_oracle as O
+
+    dec, ctc = O.OracleDecoderScorer(sd, args), O.make_oracle_ctc_scorer(sd, odim - 1)
+    ctc.batch_init_state(enc)
+    y = torch.tensor([yseq[:1]])
+    state, tot_d, tot_c = None, 0.0, 0.0
+    for tok in yseq[1:1 + maxlen]:                      # a closing <eos> forced at the length limit is not scored
+        d, _ = dec.batch_score(y, [None], enc.unsqueeze(0))
+        c, pend = ctc.batch_score_partial(y, None, state, enc)
+        tot_d += float(d[0, tok])
+        tot_c += float(c[0, tok])
+        state = ctc.select_states(pend, torch.tensor([0]), torch.tensor([tok]))
+        y = torch.cat((y, torch.tensor([[tok]])), dim=1)
+    return (1 - ctcw) * tot_d + ctcw * tot_c, tot_d, tot_c
+
+
+def test_beam_search_on_the_gpu_finds_the_reference_hypotheses(dev, tiny):
+    """With the reference's encoder output as input: the best hypothesis equals the reference's wherever the reference's own margin
+    to its runner-up exceeds the bf16 noise (a narrow beam follows a different path under any perturbation — run 2 finds a BETTER
+    hypothesis than the reference's beam-4 search did); and for every run the scores the search reports are the true scores of the
+    hypotheses it returns (re-scored by the fp64 oracle along the same path)."""
+    from syncvsr_amd.lrs_infer import get_beam_search_decoder
+
+    model, odim, clip, runs, gold = tiny
+    args, _, sd, _, _, _ = build_lrs_infer_case("lrs_infer_tiny")
+    sd64 = {k: v.double() if v.is_floating_point() else v for k, v in sd.items()}
+    tokens = [f"t{i}" for i in range(odim)]
+    g_enc = torch.from_numpy(gold["enc_feat"])
+    for r, (beam, ctcw) in enumerate(runs):
+        nbest = get_beam_search_decoder(model, tokens, ctc_weight=ctcw, beam_size=beam)(g_enc.to(dev))
+        gy = gold[f"run{r}.yseq"]
+        want = gy[0][gy[0] >= 0].tolist()
+        gscore = gold[f"run{r}.score"]
+        print(f"run{r}: hip best {nbest[0].yseq.tolist()} {nbest[0].score:.4f} | reference {want} {gscore[0]:.4f} (2nd {gscore[1]:.4f})")
+        if gscore[0] - gscore[1] > 0.2 and beam >= 5:
+            assert nbest[0].yseq.tolist() == want, (r, nbest[0].yseq.tolist(), want)
+            assert abs(nbest[0].score - gscore[0]) <= 2e-2 * abs(gscore[0]) + 0.05
+        else:
+            assert nbest[0].score >= gscore[0] - 0.05 * abs(gscore[0])          # at least as good as what the reference found
+        for h in nbest[:3]:
+            tot, td, tc = _rescore(sd64, args, odim, g_enc.double(), h.yseq.tolist(), ctcw, g_enc.shape[0])
+            d = h.asdict()
+            assert abs(d["score"] - tot) <= 2e-2 * abs(tot) + 0.05, (r, d, tot)
+            assert abs(d["scores"]["decoder"] - td) <= 2e-2 * abs(td) + 0.05 and abs(d["scores"]["ctc"] - tc) <= 2e-2 * abs(tc) + 0.05, (r, d, td, tc)
+        assert all(nbest[i].score >= nbest[i + 1].score for i in range(len(nbest) - 1))
+        assert all(h.yseq[0] == odim - 1 and h.yseq[-1] == odim - 1 for h in nbest)
+    # the reference's test_step end to end: clip -> encoder -> beam search (lightning.py:114-123)
+    enc, _ = model.encoder(clip.unsqueeze(0).to(dev), None)
+    nbest = get_beam_search_decoder(model, tokens, ctc_weight=0.1, beam_size=30)(enc.squeeze(0))
+    gy = gold["run1.yseq"]
+    print("end to end:", nbest[0].yseq.tolist(), nbest[0].score, "reference", gy[0][gy[0] >= 0].tolist(), gold["run1.score"][0])
+    assert nbest[0].yseq.tolist() == gy[0][gy[0] >= 0].tolist()
+    assert abs(nbest[0].score - gold["run1.score"][0]) <= 0.05 * abs(gold["run1.score"][0])
