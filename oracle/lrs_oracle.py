@@ -79,21 +79,26 @@ def _lin(x: Tensor, sd: SD, p: str) -> Tensor:
 # visual front-end: backbones/conv3d_extractor.py:40-48, backbones/modules/resnet.py:90-107,163-177
 # --------------------------------------------------------------------------------------------
 def frontend(x: Tensor, sd: SD, training: bool, stats_out: dict | None = None, keep: dict | None = None) -> Tensor:
-    """x [B,T,1,H,W] -> [B,T,512].  Conv3d(5,7,7)/(1,2,2) -> BN3d -> Swish -> MaxPool(1,3,3)/(1,2,2) -> ResNet18(Swish) -> avgpool."""
-    fe = "encoder.frontend"
+    """x [B,T,1,H,W] -> [B,T,512].  Conv3d(5,7,7)/(1,2,2) -> BN3d -> act -> MaxPool(1,3,3)/(1,2,2) -> ResNet18(act) -> avgpool.
+    `conv3d` (encoder.frontend.*): Swish everywhere; `conv3d-lrw` (encoder.stem3d / encoder.resnet, encoder.py:132-139,248-255):
+    GELU stem and ReLU blocks, the word-level model's front-end."""
+    lrw = "encoder.stem3d.0.weight" in sd
+    stem, trunk = ("encoder.stem3d", "encoder.resnet") if lrw else ("encoder.frontend.frontend3D", "encoder.frontend.trunk")
+    act_stem = (lambda t: 0.5 * t * (1.0 + torch.erf(t / math.sqrt(2.0)))) if lrw else swish
+    act = torch.relu if lrw else swish
     B, T = x.shape[:2]
-    h = F.conv3d(x.transpose(1, 2), sd[f"{fe}.frontend3D.0.weight"], None, stride=(1, 2, 2), padding=(2, 3, 3))
-    h = swish(batch_norm(h, sd, f"{fe}.frontend3D.1", training, stats_out))
+    h = F.conv3d(x.transpose(1, 2), sd[f"{stem}.0.weight"], None, stride=(1, 2, 2), padding=(2, 3, 3))
+    h = act_stem(batch_norm(h, sd, f"{stem}.1", training, stats_out))
     h = F.max_pool3d(h, (1, 3, 3), (1, 2, 2), (0, 1, 1))
     h = h.transpose(1, 2).reshape(B * T, 64, h.size(3), h.size(4))
     if keep is not None:
         keep["stem_out"] = h
     for li in range(1, 5):
         for bi in range(2):
-            p = f"{fe}.trunk.layer{li}.{bi}"
+            p = f"{trunk}.layer{li}.{bi}"
             stride = 2 if (bi == 0 and li > 1) else 1
             out = F.conv2d(h, sd[f"{p}.conv1.weight"], None, stride=stride, padding=1)
-            out = swish(batch_norm(out, sd, f"{p}.bn1", training, stats_out))
+            out = act(batch_norm(out, sd, f"{p}.bn1", training, stats_out))
             out = F.conv2d(out, sd[f"{p}.conv2.weight"], None, stride=1, padding=1)
             out = batch_norm(out, sd, f"{p}.bn2", training, stats_out)
             if f"{p}.downsample.0.weight" in sd:
@@ -101,7 +106,7 @@ def frontend(x: Tensor, sd: SD, training: bool, stats_out: dict | None = None, k
                 res = batch_norm(res, sd, f"{p}.downsample.1", training, stats_out)
             else:
                 res = h
-            h = swish(out + res)
+            h = act(out + res)
     return h.mean((2, 3)).view(B, T, 512)
 
 
@@ -307,7 +312,7 @@ def forward(sd: SD, args: Any, x: Tensor, lengths: Tensor, audio_tokens: Tensor,
             stats_out: dict | None = None, keep: dict | None = None, dp: DropPlan | None = None) -> dict[str, Any]:
     """``E2E.forward`` (e2e_asr_transformer.py:187-227) with pre-computed audio tokens in the ``audios`` slot."""
     from syncvsr_amd.lrs_init import lrs_audio_dims          # parameter-free helper (codec string -> (A,G,V))
-    odim = sd["ctc.ctc_lo.weight"].size(0)
+    odim = sd["decoder.output_layer.weight"].size(0)
     B, T = x.shape[:2]
     mask = (torch.arange(T).unsqueeze(0) < lengths.view(-1, 1)).unsqueeze(-2)                 # make_non_pad_mask, [B,1,T]
     if not training:
@@ -319,7 +324,7 @@ def forward(sd: SD, args: Any, x: Tensor, lengths: Tensor, audio_tokens: Tensor,
     logits_audio = _lin(h, sd, "audio_classifier").float().unflatten(2, (-1, V))
     loss_audio = F.cross_entropy(logits_audio.flatten(0, 2), audio_tokens[:, : T * A].flatten())
     ys = [y[y != -1] for y in label.view(B, -1)]
-    loss_ctc = ctc_loss(h, lengths, ys, sd, dp)
+    loss_ctc = ctc_loss(h, lengths, ys, sd, dp) if float(args.mtlalpha) > 0.0 else torch.zeros(())     # e2e_asr_transformer.py:205-208
     ys_in, ys_out = add_sos_eos(ys, odim - 1, odim - 1)
     memory = _lin(h, sd, "proj_decoder") if "proj_decoder.weight" in sd else h               # e2e_asr_transformer.py:209-210
     pred = decoder(ys_in, memory, mask, sd, args, keep, dp)

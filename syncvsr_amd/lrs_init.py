@@ -70,18 +70,26 @@ def _ln_specs(p: str, d: int) -> list[Spec]:
     return [(f"{p}.weight", (d,), "norm_w"), (f"{p}.bias", (d,), "norm_b")]
 
 
+def lrs_frontend_names(args: Config) -> tuple[str, str]:
+    """(stem, trunk) module paths: `conv3d` = Conv3dResNet under encoder.frontend (encoder.py:130-131, backbones/conv3d_extractor.py);
+    `conv3d-lrw` = the word-level model's stem3d + resnet18 directly under the encoder (encoder.py:132-139,248-255)."""
+    if str(args.transformer_input_layer) == "conv3d-lrw":
+        return "encoder.stem3d", "encoder.resnet"
+    return "encoder.frontend.frontend3D", "encoder.frontend.trunk"
+
+
 def lrs_param_specs(args: Config, odim: int = LRS_ODIM) -> list[Spec]:
     D, Dd = int(args.adim), int(args.ddim)
     H = int(args.aheads)
     K = int(args.cnn_module_kernel)
     A, G, V = lrs_audio_dims(args)
-    fe = "encoder.frontend"
+    stem, trunk = lrs_frontend_names(args)
     specs: list[Spec] = [
-        (f"{fe}.frontend3D.0.weight", (64, 1, 5, 7, 7), "conv"),
-        (f"{fe}.frontend3D.1.weight", (64,), "norm_w"),
-        (f"{fe}.frontend3D.1.bias", (64,), "norm_b"),
+        (f"{stem}.0.weight", (64, 1, 5, 7, 7), "conv"),
+        (f"{stem}.1.weight", (64,), "norm_w"),
+        (f"{stem}.1.bias", (64,), "norm_b"),
     ]
-    for prefix, inp, planes, stride, down in _frontend_block_specs(f"{fe}.trunk"):
+    for prefix, inp, planes, stride, down in _frontend_block_specs(trunk):
         specs += [
             (f"{prefix}.conv1.weight", (planes, inp, 3, 3), "conv"),
             (f"{prefix}.bn1.weight", (planes,), "norm_w"), (f"{prefix}.bn1.bias", (planes,), "norm_b"),
@@ -124,9 +132,10 @@ def lrs_param_specs(args: Config, odim: int = LRS_ODIM) -> list[Spec]:
         for n in ("norm1", "norm2", "norm3"):
             specs += _ln_specs(f"{p}.{n}", Dd)
     specs += _ln_specs("decoder.after_norm", Dd)
-    specs += [("decoder.output_layer.weight", (odim, Dd), "linear_w"), ("decoder.output_layer.bias", (odim,), "linear_b"),
-              ("ctc.ctc_lo.weight", (odim, D), "linear_w"), ("ctc.ctc_lo.bias", (odim,), "linear_b"),
-              ("audio_classifier.weight", (A * G * V, D), "linear_w"), ("audio_classifier.bias", (A * G * V,), "linear_b")]
+    specs += [("decoder.output_layer.weight", (odim, Dd), "linear_w"), ("decoder.output_layer.bias", (odim,), "linear_b")]
+    if float(args.mtlalpha) > 0.0:             # `self.ctc` exists only then (e2e_asr_transformer.py:127-132)
+        specs += [("ctc.ctc_lo.weight", (odim, D), "linear_w"), ("ctc.ctc_lo.bias", (odim,), "linear_b")]
+    specs += [("audio_classifier.weight", (A * G * V, D), "linear_w"), ("audio_classifier.bias", (A * G * V,), "linear_b")]
     return specs
 
 
@@ -134,7 +143,8 @@ def lrs_buffer_specs(args: Config, odim: int = LRS_ODIM) -> list[Spec]:
     """BatchNorm running statistics (front-end BN3d/BN2d and each ``conv_module.norm`` BN1d)."""
     out: list[Spec] = []
     for name, shape, kind in lrs_param_specs(args, odim):
-        is_bn = kind == "norm_w" and (".bn" in name or "frontend3D.1" in name or "downsample.1" in name or "conv_module.norm" in name)
+        is_bn = kind == "norm_w" and (".bn" in name or "frontend3D.1" in name or "stem3d.1" in name or "downsample.1" in name
+                                      or "conv_module.norm" in name)
         if is_bn:
             base = name[: -len(".weight")]
             out += [(f"{base}.running_mean", shape, "bn_mean"), (f"{base}.running_var", shape, "bn_var"),
@@ -151,7 +161,7 @@ def lrs_init_state_dict(args: Config, odim: int = LRS_ODIM, seed: int = 0, pertu
     last_fan_in = 1
     for name, shape, kind in lrs_param_specs(args, odim):
         if kind == "conv":
-            if "frontend3D" in name:
+            if "frontend3D" in name or "stem3d" in name:
                 bound = 1.0 / math.sqrt(math.prod(shape[1:]))
                 t = (torch.rand(shape, generator=g) * 2 - 1) * bound
             else:

@@ -133,8 +133,8 @@ class E2E(nn.Module):
         self.length_norm = bool(args.transformer_length_normalized_loss)
         self.audio_weight = float(args.audio_weight)
         unsupported = []
-        if args.transformer_input_layer != "conv3d":
-            unsupported.append("transformer_input_layer must be conv3d")
+        if args.transformer_input_layer not in ("conv3d", "conv3d-lrw"):
+            unsupported.append("transformer_input_layer must be conv3d or conv3d-lrw (the visual front-ends, encoder.py:130-139)")
         if args.transformer_encoder_attn_layer_type != "rel_mha" or args.get("rel_pos_type", "latest") != "latest":
             unsupported.append("encoder attention must be rel_mha with rel_pos_type latest")
         if not args.macaron_style or not args.use_cnn_module:
@@ -145,8 +145,9 @@ class E2E(nn.Module):
             unsupported.append("zero_triu is not supported")
         if self.adim % 64 or self.ddim % 64 or self.adim // self.aheads != 64 or self.ddim // self.dheads != 64:
             unsupported.append("attention heads must be 64 wide")
-        if not (0.0 < self.mtlalpha < 1.0):
-            unsupported.append("mtlalpha must be in (0, 1) (both CTC and attention branches are built)")
+        if not (0.0 <= self.mtlalpha < 1.0):
+            unsupported.append("mtlalpha must be in [0, 1): with mtlalpha = 1 the reference builds no decoder (e2e_asr_transformer.py:96-109) "
+                               "and its own forward then fails at `self.decoder(...)` (:214)")
         if self.kernel % 2 == 0 or self.kernel > 31:
             unsupported.append("cnn_module_kernel must be odd and <= 31")
         if unsupported:
@@ -175,8 +176,13 @@ class E2E(nn.Module):
             _attach(self, name, sd[name], False)
         self._store: Optional[_ParamStore] = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_params_dirty())
-        self.stem_name, self.trunk_name = "encoder.frontend.frontend3D", "encoder.frontend.trunk"
-        self.stem_act = self.trunk_act = ops.ACT_SWISH           # backbones/conv3d_extractor.py:34, modules/resnet.py:76-78
+        from .lrs_init import lrs_frontend_names
+
+        self.stem_name, self.trunk_name = lrs_frontend_names(args)
+        if args.transformer_input_layer == "conv3d-lrw":         # the word-level model's front-end: GELU stem, ReLU ResNet18 (encoder.py:132-139)
+            self.stem_act, self.trunk_act = ops.ACT_GELU, ops.ACT_RELU
+        else:
+            self.stem_act = self.trunk_act = ops.ACT_SWISH       # backbones/conv3d_extractor.py:34, modules/resnet.py:76-78
         self.use_tr = True
         self._side = _SideStream()
         self.grad_ready_hook = None
@@ -184,6 +190,8 @@ class E2E(nn.Module):
         import weakref
 
         for name, cls in (("encoder", _EncoderFacade), ("decoder", _DecoderFacade), ("ctc", _CtcFacade)):
+            if name not in self._modules:          # mtlalpha = 0: no CTC branch (self.ctc = None in the reference)
+                continue
             node = self._modules[name]
             node.__class__ = cls
             object.__setattr__(node, "_owner", weakref.ref(self))
@@ -191,9 +199,9 @@ class E2E(nn.Module):
     # ------------------------------------------------------------------------------------------------
     @staticmethod
     def _fwd_rank(name: str) -> int:
-        if name.startswith("encoder.frontend.frontend3D"):
+        if name.startswith(("encoder.frontend.frontend3D", "encoder.stem3d")):
             return 0
-        if name.startswith("encoder.frontend"):
+        if name.startswith(("encoder.frontend", "encoder.resnet")):
             return 1
         if name.startswith("encoder.embed"):
             return 2
@@ -237,7 +245,8 @@ class E2E(nn.Module):
             one(f"{p}.feed_forward.w_1.weight")
             one(f"{p}.feed_forward.w_2.weight")
         for n in ("decoder.output_layer.weight", "ctc.ctc_lo.weight", "audio_classifier.weight"):
-            one(n)
+            if n in offsets:
+                one(n)
         if self.adim != self.ddim:
             one("proj_decoder.weight")
         return out
@@ -607,11 +616,15 @@ class _LrsFunction(torch.autograd.Function):
         # CTC head (ctc.py:83-151)
         Vo = model.odim
         Vp = (Vo + 63) // 64 * 64
-        dctc = model._d("ctc.in")
-        h_ctc = ops.scale_bf16(h, 1.0, drop=dctc) if dctc is not None else h                   # ctc_lo(dropout(hs_pad)), ctc.py:97
-        logits_c = ops.linear_fwd(h_ctc, st.s16("ctc.ctc_lo.weight"), st.p32("ctc.ctc_lo.bias"), rows=R, K=D, N=Vo, x_pitch=D, out_f32=True,
-                                  out_pitch=Vp)[0]
-        loss_c, ctc_state = ops.ctc_fwd(logits_c, Vp, tg.labels, ilen, B, T, Vo)
+        if model.mtlalpha > 0.0:
+            dctc = model._d("ctc.in")
+            h_ctc = ops.scale_bf16(h, 1.0, drop=dctc) if dctc is not None else h               # ctc_lo(dropout(hs_pad)), ctc.py:97
+            logits_c = ops.linear_fwd(h_ctc, st.s16("ctc.ctc_lo.weight"), st.p32("ctc.ctc_lo.bias"), rows=R, K=D, N=Vo, x_pitch=D, out_f32=True,
+                                      out_pitch=Vp)[0]
+            loss_c, ctc_state = ops.ctc_fwd(logits_c, Vp, tg.labels, ilen, B, T, Vo)
+        else:                                      # `loss_ctc = 0` (e2e_asr_transformer.py:205-208)
+            dctc = h_ctc = logits_c = ctc_state = None
+            loss_c = torch.zeros((), dtype=torch.float32, device=x.device)
         # attention decoder + label smoothing (decoder.py:122-151, label_smoothing_loss.py:41-63)
         # proj_decoder when the decoder is narrower/wider than the encoder (e2e_asr_transformer.py:93-95,209-210)
         memory = _lin(st, h, "proj_decoder", R, D, model.ddim) if model.adim != model.ddim else h
@@ -663,13 +676,14 @@ class _LrsFunction(torch.autograd.Function):
         else:
             _decoder_bwd(model, st, tape, tg, dpred, h, dh, B, T)
         # CTC and audio heads
-        dlc = ops.ctc_grad(th["logits_c"], Vp, tg.labels, th["ilen"], B, T, Vo, th["ctc_state"], g_ctc, Vp)
-        _lin_bwd(model, st, "ctc.ctc_lo", th["h_ctc"], dlc, R, D, Vo, dy_pitch=Vp, addend=dh, out=dh, drop=th["dctc"])   # dh += mask/(1-p) * (dlc W)
+        if th["logits_c"] is not None:
+            dlc = ops.ctc_grad(th["logits_c"], Vp, tg.labels, th["ilen"], B, T, Vo, th["ctc_state"], g_ctc, Vp)
+            _lin_bwd(model, st, "ctc.ctc_lo", th["h_ctc"], dlc, R, D, Vo, dy_pitch=Vp, addend=dh, out=dh, drop=th["dctc"])   # dh += mask/(1-p) * (dlc W)
         NA = A * G * V
         dla = torch.empty((R, NA), dtype=BF16, device=dev)
         ops.ce_bwd(th["logits_a"], V, th["tok"], None, R * A * G, V, 0.0, th["lse_a"], g_audio, dla, V)
         _lin_bwd(model, st, "audio_classifier", h, dla, R, D, NA, addend=dh, out=dh)
-        _ready(model, st, "ctc.ctc_lo.weight")
+        _ready(model, st, "ctc.ctc_lo.weight" if th["logits_c"] is not None else "audio_classifier.weight")
         dx = _ln_bwd(st, dh, th["hx"], "encoder.after_norm", th["mA"], th["rA"])
         for i in reversed(range(model.elayers)):
             dx = _encoder_layer_bwd(model, st, tape, i, dx, th["pos16"], B, T)

@@ -36,7 +36,12 @@ from syncvsr_amd.lrs_init import lrs_audio_dims, lrs_param_specs  # noqa: E402
 def import_reference():
     m = types.ModuleType("timm")
     m.__spec__ = importlib.machinery.ModuleSpec("timm", None)
-    m.create_model = None
+    # `transformer_input_layer: conv3d-lrw` builds timm.create_model("resnet18") (encoder.py:139); timm is not installed, so — as in
+    # make_golden_lrw.py — the topology-identical in-tree ResNet18 of the reference's LRW tree stands in for it
+    sys.path.insert(0, "/root/reference/LRW/video/src")
+    from tcn.models.resnet import BasicBlock, ResNet
+
+    m.create_model = lambda name, **k: ResNet(BasicBlock, [2, 2, 2, 2], relu_type="relu")
     sys.modules["timm"] = m
     sys.path.insert(0, REF)
     from espnet.nets.pytorch_backend.e2e_asr_transformer import E2E
@@ -71,8 +76,12 @@ def run_case(E2E, name: str) -> dict[str, np.ndarray]:
         return f
 
     enc = model.encoder
-    enc.frontend.register_forward_hook(hook("feats"))
-    enc.frontend.frontend3D.register_forward_hook(hook("stem_out5d"))
+    if hasattr(enc, "stem3d"):                 # conv3d-lrw: the features come out of a method (forward_videos), not a module
+        enc.embed.register_forward_pre_hook(lambda _m, i: keep.__setitem__("feats", i[0].detach()))
+        enc.stem3d.register_forward_hook(hook("stem_out5d"))
+    else:
+        enc.frontend.register_forward_hook(hook("feats"))
+        enc.frontend.frontend3D.register_forward_hook(hook("stem_out5d"))
     for i, layer in enumerate(enc.encoders):
         layer.register_forward_hook(hook(f"enc{i}"))
     enc.encoders[0].self_attn.register_forward_hook(hook("enc0.self_attn"))
@@ -81,7 +90,8 @@ def run_case(E2E, name: str) -> dict[str, np.ndarray]:
     for i, layer in enumerate(model.decoder.decoders):
         layer.register_forward_hook(hook(f"dec{i}"))
     model.decoder.register_forward_hook(hook("pred"))
-    model.ctc.ctc_lo.register_forward_hook(hook("ctc_logits"))
+    if model.ctc is not None:
+        model.ctc.ctc_lo.register_forward_hook(hook("ctc_logits"))
     model.audio_classifier.register_forward_hook(hook("logits_audio"))
 
     dummy_audio = torch.zeros(x.size(0), 1, 16)
@@ -96,7 +106,7 @@ def run_case(E2E, name: str) -> dict[str, np.ndarray]:
     model.zero_grad()
     if training:
         loss.backward()
-    res: dict[str, np.ndarray] = {"loss": np.float64(loss.item()), "loss_ctc": np.float64(loss_ctc.item()),
+    res: dict[str, np.ndarray] = {"loss": np.float64(loss.item()), "loss_ctc": np.float64(float(loss_ctc)),
                                   "loss_att": np.float64(loss_att.item()), "loss_audio": np.float64(loss_audio.item()),
                                   "acc": np.float64(acc)}
     keep["stem_out"] = keep.pop("stem_out5d").transpose(1, 2).flatten(0, 1)
@@ -123,7 +133,7 @@ def run_case(E2E, name: str) -> dict[str, np.ndarray]:
                 if params[n].numel() <= 4096 and (".0." in n or "after_norm" in n or "ctc" in n):
                     res[f"grad.{n}"] = params[n].grad.float().numpy()
         for n, mod in model.named_modules():
-            if isinstance(mod, nn.modules.batchnorm._BatchNorm) and (n.endswith("frontend3D.1") or "layer2.0.downsample.1" in n
+            if isinstance(mod, nn.modules.batchnorm._BatchNorm) and (n.endswith("frontend3D.1") or n.endswith("stem3d.1") or "layer2.0.downsample.1" in n
                                                                      or n.endswith("encoders.0.conv_module.norm")):
                 res[f"buf.{n}.running_mean"] = mod.running_mean.numpy().copy()
                 res[f"buf.{n}.running_var"] = mod.running_var.numpy().copy()

@@ -64,6 +64,11 @@ LRS_CASES = {
     # adim != ddim (proj_decoder, e2e_asr_transformer.py:93-95) and the length-normalised attention loss
     # the shipped 252 M-parameter config at a realistic clip length (two ragged clips padded to 150 frames)
     "lrs_full_t150": (dict(), 5049, dict(batch=2, t_max=150, size=88, label_len=(10, 30), min_len_frac=0.6), 0, 1235, False, True),
+    # transformer_input_layer conv3d-lrw: the word-level front-end (GELU stem, ReLU ResNet18) under the sentence-level encoder
+    "lrs_tiny_lrwfe": (dict(_LRS_TINY, transformer_input_layer="conv3d-lrw"), 41, dict(batch=2, t_max=9, size=24, label_len=(2, 4)), 14, 94,
+                       True, True),
+    # mtlalpha = 0: no CTC branch at all (self.ctc = None, loss_ctc = 0; e2e_asr_transformer.py:127-132,205-208)
+    "lrs_tiny_noctc": (dict(_LRS_TINY, mtlalpha=0.0), 41, dict(batch=2, t_max=9, size=24, label_len=(2, 4)), 15, 95, True, True),
     "lrs_tiny_proj": (dict(_LRS_TINY, ddim=192, dheads=3, dlayers=2, transformer_length_normalized_loss=True), 37,
                       dict(batch=3, t_max=10, size=16, label_len=(2, 5), min_len_frac=0.5), 13, 93, True, True),
 }

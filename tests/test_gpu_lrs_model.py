@@ -53,7 +53,7 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-@pytest.mark.parametrize("name,loss_tol", [("lrs_tiny", 5e-3), ("lrs_tiny_b3", 5e-3), ("lrs_tiny_proj", 5e-3), ("lrs_full_b2", 1e-3),
+@pytest.mark.parametrize("name,loss_tol", [("lrs_tiny", 5e-3), ("lrs_tiny_b3", 5e-3), ("lrs_tiny_proj", 5e-3), ("lrs_tiny_lrwfe", 5e-3), ("lrs_tiny_noctc", 5e-3), ("lrs_full_b2", 1e-3),
                                            ("lrs_full_t150", 1e-3)])
 def test_lrs_model_matches_oracle(dev, name, loss_tol):
     args, model, out, osd, ref, keep, stats, gold = _run_pair(name, dev)
@@ -74,7 +74,8 @@ def test_lrs_model_matches_oracle(dev, name, loss_tol):
         grads[n] = dict(cos=float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)), ratio=float(g.norm() / (rn + 1e-30)), ref_norm=rn)
     rows["grads"] = grads
     bufs = {}
-    for n in ("encoder.frontend.frontend3D.1.running_var", "encoder.encoders.0.conv_module.norm.running_mean",
+    stem_bn = "encoder.stem3d.1" if name == "lrs_tiny_lrwfe" else "encoder.frontend.frontend3D.1"     # conv3d-lrw front-end (encoder.py:132-139)
+    for n in (f"{stem_bn}.running_var", "encoder.encoders.0.conv_module.norm.running_mean",
               "encoder.encoders.0.conv_module.norm.running_var"):
         bufs[n] = _rel(dict(model.named_buffers())[n], stats[n])
     rows["buffers"] = bufs
@@ -87,10 +88,12 @@ def test_lrs_model_matches_oracle(dev, name, loss_tol):
     worst = sorted((v["cos"], n) for n, v in live.items())[:8]
     print("worst grad cosines:", worst)
     for k in names:
-        assert abs(rows[k]["hip"] - rows[k]["oracle"]) <= loss_tol * abs(rows[k]["oracle"]), (k, rows[k])
+        assert abs(rows[k]["hip"] - rows[k]["oracle"]) <= loss_tol * abs(rows[k]["oracle"]), (k, rows[k])      # (mtlalpha = 0: loss_ctc is exactly 0 on both sides)
         if name.startswith("lrs_full"):      # the fp32 oracle itself against the golden the reference produced (fp64) for this case
             assert abs(rows[k]["oracle"] - rows[k]["golden"]) <= 1e-4 * abs(rows[k]["golden"]), ("oracle vs reference golden", k, rows[k])
-    assert rows["rel.feats"] <= (3e-2 if name.startswith("lrs_full") else 4e-2) and rows["rel.enc_out"] <= 5e-2 and rows["rel.pred"] <= 5e-2, rows
+    # tiny 24 x 24 clips; the ReLU trunk of conv3d-lrw flips more activation masks under bf16 than the Swish trunk (measured 0.041 vs 0.03)
+    feats_tol = 3e-2 if name.startswith("lrs_full") else (5e-2 if name == "lrs_tiny_lrwfe" else 4e-2)
+    assert rows["rel.feats"] <= feats_tol and rows["rel.enc_out"] <= 5e-2 and rows["rel.pred"] <= 5e-2, rows
     for n, v in bufs.items():
         assert v <= 2e-2, (n, v)
     coss = sorted(v["cos"] for v in live.values())
