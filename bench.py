@@ -19,8 +19,10 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the HIP runtime starts: see syncvsr_amd/__init__.py
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -159,7 +161,7 @@ def main() -> None:
     ap.add_argument("--profile-steps", type=int, default=2, help="eager steps with per-launch HIP events for the roofline leg")
     ap.add_argument("--force-collective", action="store_true", help="run the RCCL path even with one rank")
     ap.add_argument("--bucket-mb", type=float, default=16.0, help="gradient all-reduce bucket size (MiB of fp32)")
-    ap.add_argument("--workload", choices=("lrw", "lrs"), default="lrw", help="lrw = BASELINE.json's headline metric (default); lrs = the "
+    ap.add_argument("--workload", choices=("lrw", "lrs", "lrw-xt"), default="lrw", help="lrw = BASELINE.json's headline metric (default); lrs = the "
                     "sentence-level E2E model (SURVEY §8 a13-a15, BASELINE configs[3]): --batch clips of up to --frames frames")
     ap.add_argument("--frames", type=int, default=150, help="LRS: padded clip length T (lengths are drawn in [0.3 T, T])")
     ap.add_argument("--dropout", type=float, default=0.1, help="LRS: dropout_rate = transformer_attn_dropout_rate (config/lrs3.yaml:20-21)")
@@ -212,7 +214,14 @@ def main() -> None:
         n_frames = int(cpu_batch[1].sum())
         label_len = cpu_batch[3].shape[-1]
     else:
-        cfg = default_lrw_config()
+        if args.workload == "lrw-xt":           # the encoder of the shipped yaml (bert-12l-512d_LRW_96_bf16_rrc_WB.yaml): x-transformers, 513 wide
+            from syncvsr_amd.config import xtransformers_lrw_config
+
+            cfg = xtransformers_lrw_config(True)
+            if use_graph:
+                raise SystemExit("layer_dropout changes the launch sequence from step to step: --graph is not available for lrw-xt")
+        else:
+            cfg = default_lrw_config()
         cfg.train.batch_size = args.batch
         model = Model(cfg, seed=0).to(dev).train()
         batch = [t.to(dev) for t in synthetic_batch(cfg, args.batch, seed=1234 + rank)]
@@ -235,6 +244,9 @@ def main() -> None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    from syncvsr_amd.engine import reduce_metrics
+
+    out = reduce_metrics(out)                        # sync_dist=True logging of the reference: rank-mean of the step's scalars
     loss = float((out[0] if lrs else out["loss_total"]).item())
     clips_per_s = args.batch * world * args.steps / elapsed
 
@@ -258,6 +270,11 @@ def main() -> None:
         "step_mfma_frac": round(clips_per_s / world * TRAIN_FLOP_PER_CLIP / MFMA_PEAK_BF16, 5),
         "final_loss": round(loss, 4),
     }
+    if args.workload == "lrw-xt":
+        result["metric"] = "lip-clips/sec training (29x88x88, x-transformers encoder + word boundary)"
+        result["config"]["workload"] = ("LRW training step with the shipped yaml's encoder: ResNet18 + 12-layer 513-d x-transformers encoder "
+                                        "(RMSNorm, rotary, GEGLU, layer-drop 0.2, ff-dropout 0.3) + vq audio head; parity of that encoder is unpinned")
+        result["step_mfma_frac"] = None
     if lrs:
         step_flops = lrs_train_flops(args.batch, args.frames, label_len)
         result["metric"] = f"lip-clips/sec training (LRS, <= {args.frames}x88x88)"
@@ -268,6 +285,14 @@ def main() -> None:
                             "padded_frames_per_s": round(clips_per_s * args.frames, 1), "valid_frames_per_step_rank0": n_frames}
         result["step_mfma_frac"] = round(step_flops * args.steps / elapsed / MFMA_PEAK_BF16, 5)
 
+    if use_dist and trainer.dp is not None:          # what the data-parallel path did in the last timed step
+        st = model.store()
+        result["collective"] = {
+            "backend": f"{dist.get_backend()} (RCCL {'.'.join(map(str, torch.cuda.nccl.version()))})", "ranks": world,
+            "all_reduce_launches_per_step": len(trainer.dp.launched), "bucket_mb": args.bucket_mb,
+            "gradient_mb_per_step": round(sum(hi - lo for lo, hi in trainer.dp.launched) * 4 / 2 ** 20, 1),
+            "buffer_broadcast_mb_per_step": round(st.bufflat.numel() * 4 / 2 ** 20, 3), "overlapped_with_backward": True,
+        }
     if rank == 0:
         # ---- roofline leg: eager steps with HIP events around every contraction launch -----------------------------
         prof = TrainStep(model, cfg, use_graph=False, always_reduce=False)

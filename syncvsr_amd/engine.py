@@ -182,6 +182,23 @@ class TrainStep:
         return {"step": int(raw[0]), "lr": float(f[2]), "grad_norm": float(f[3])}
 
 
+def reduce_metrics(metrics, process_group=None):
+    """`self.log(..., sync_dist=True)` of the reference (LRW/video/src/lightning.py:208,214; LRS/video/lightning.py:143-216): the
+    logged scalars are averaged over the ranks.  `metrics` is the dict (LRW) or tuple (LRS) of 0-d tensors a step returns; they are
+    packed into one vector so a step's logging costs ONE collective.  With no process group (or one rank) the input is returned."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return metrics
+    keys = list(metrics.keys()) if isinstance(metrics, dict) else list(range(len(metrics)))
+    vec = torch.stack([metrics[k].detach().float().reshape(()) for k in keys])
+    if dist.get_backend(process_group) == "nccl":
+        dist.all_reduce(vec, op=dist.ReduceOp.AVG, group=process_group)
+    else:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=process_group)
+        vec = vec / dist.get_world_size(process_group)
+    out = {k: vec[i] for i, k in enumerate(keys)}
+    return out if isinstance(metrics, dict) else tuple(out[k] for k in keys)
+
+
 class GradReducer:
     """Bucketed gradient all-reduce over the flat gradient buffer, overlapped with the backward pass.
 

@@ -183,7 +183,22 @@ _WORKER = textwrap.dedent("""
     model = Model(cfg)
     model._store = _ParamStore(model, torch.device("cpu"))
     st = model._store
+    # DDP construction semantics: whatever a rank holds, it starts from rank 0's parameters and BatchNorm statistics
+    st.flat.add_(float(rank)); st.bufflat.add_(float(rank))
+    mine = st.flat.clone()
     red = GradReducer(model, None, bucket_mb=8.0)
+    both = [torch.empty_like(st.flat) for _ in range(world)]
+    dist.all_gather(both, st.flat)
+    assert all(torch.equal(b, both[0]) for b in both) and (rank != 0 or torch.equal(st.flat, mine))
+    bufs = [torch.empty_like(st.bufflat) for _ in range(world)]
+    dist.all_gather(bufs, st.bufflat)
+    assert all(torch.equal(b, bufs[0]) for b in bufs)
+    # sync_dist=True logging: rank-mean of a step's scalars in one collective (dict for LRW, tuple for LRS)
+    from syncvsr_amd.engine import reduce_metrics
+    m = reduce_metrics({{"loss_total": torch.tensor(1.0 + rank), "accuracy_top1": torch.tensor(0.5 * rank)}})
+    assert abs(float(m["loss_total"]) - (1.0 + (world - 1) / 2)) < 1e-6 and abs(float(m["accuracy_top1"]) - 0.25 * (world - 1)) < 1e-6
+    t = reduce_metrics((torch.tensor(2.0 * rank), torch.tensor(3.0)))
+    assert isinstance(t, tuple) and abs(float(t[0]) - (world - 1)) < 1e-6 and float(t[1]) == 3.0
     red.begin_step()
     st.grad.copy_(torch.arange(st.numel, dtype=torch.float32) % 97 + rank)       # rank-dependent pattern
     # replay the order in which the hand-written backward reports progress
