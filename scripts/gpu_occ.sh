@@ -1,5 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
-for pad in 0 16000 30000 60000; do
-  OPB_TUNE=igemm_lds_pad=$pad python scripts/op_bench.py fwd dgrad 2>&1 | grep -E "conv3x3" | sed "s/^/pad=$pad /"
+for t in 512 640 768 1024 1536 3072; do
+  OPB_TUNE=stem_fwd_blocks=$t python scripts/op_bench.py stem 2>&1 | grep -E "stem conv fwd" | sed "s/^/blocks=$t /"
 done | tee gpurun_out/occ.log

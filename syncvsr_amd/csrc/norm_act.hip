@@ -276,11 +276,13 @@ __global__ __launch_bounds__(256) void k_stem_bn_act_pool_fwd(const bf16_t* __re
         int rl, pw, c8;
         it.decode(e, rl, pw, c8);
         const int ph = row0 + rl;
-        float best[8];
-        int bi[8];
+        // GELU and Swish both fall to a single minimum and rise from there (quasi-convex), so the maximum of act(z) over a window is
+        // attained at the window's largest or smallest z: track those two (first occurrence each) and evaluate the activation twice
+        // per channel instead of nine times — the pass was bound by the erf/exp VALU work, not by HBM.
+        float zhi[8], zlo[8];
+        int ihi[8], ilo[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; }
-        bool first = true;
+        for (int k = 0; k < 8; ++k) { zhi[k] = -INFINITY; zlo[k] = INFINITY; ihi[k] = 0; ilo[k] = 0; }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int h = 2 * ph - 1 + i;
@@ -293,11 +295,22 @@ __global__ __launch_bounds__(256) void k_stem_bn_act_pool_fwd(const bf16_t* __re
                 unpack8(*reinterpret_cast<const u32x4*>(x + (((long)n * Hc + h) * Wc + w) * C + c0), f);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float v = ACT == 2 ? swish(f[k] * sc[k] + sh[k]) : gelu_erf(f[k] * sc[k] + sh[k]);
-                    if (first || v > best[k]) { best[k] = v; bi[k] = i * 3 + j; }
+                    const float z = f[k] * sc[k] + sh[k];
+                    if (z > zhi[k]) { zhi[k] = z; ihi[k] = i * 3 + j; }
+                    if (z < zlo[k]) { zlo[k] = z; ilo[k] = i * 3 + j; }
                 }
-                first = false;
             }
+        }
+        float best[8];
+        int bi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float vh = ACT == 2 ? swish(zhi[k]) : gelu_erf(zhi[k]);
+            const float vl = ACT == 2 ? swish(zlo[k]) : gelu_erf(zlo[k]);
+            // the first maximum in window order wins (torch's max_pool: strictly-greater update)
+            const bool take_lo = vl > vh || (vl == vh && ilo[k] < ihi[k]);
+            best[k] = take_lo ? vl : vh;
+            bi[k] = take_lo ? ilo[k] : ihi[k];
         }
         const long o = (((long)n * Hp + ph) * Wp + pw) * C + c0;
         *reinterpret_cast<u32x4*>(y + o) = pack8(best);

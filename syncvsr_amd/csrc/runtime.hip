@@ -24,8 +24,9 @@ static int g_tune[SVSR_TUNE_N] = {
     /* STEM_LDS_FWD */ 0,      // LDS-tiled stem BN+act+pool forward (measured slower)
     /* STEM_LDS_BWD */ 1,      // LDS-tiled stem BN+act+pool backward (measured faster)
     /* IGEMM_LDS_PAD */ 0,     // extra dynamic LDS bytes per svsr_igemm_fwd workgroup (occupancy experiments: fewer co-resident blocks per CU)
+    /* IGEMM_BN64_BELOW */ 300, // multi-tap convolutions with fewer 128x128 tiles than this use 128x64 tiles (three workgroups per CU)
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 
