@@ -236,17 +236,23 @@ struct WgradLaunch { int bc, ns, splits, chunks_per_split, tasks; long slab; };
 static WgradLaunch wgrad_launch(long max_rows, int Co, int Ci, int ntaps, int wt_taps, bool bias) {
     WgradLaunch pl;
     const int tasks128 = ((Co + 127) / 128) * ((Ci + 127) / 128) * ntaps;
-    pl.bc = (Co >= 128 && Ci >= 128 && tasks128 >= 36) ? 128 : 64;
-    pl.ns = pl.bc == 128 ? 2 : 3;
+    const int total_chunks = (int)((max_rows + 63) / 64);
+    // short contractions (LRW encoder linears: 960 rows = 15 chunks): a workgroup's whole K loop is a few microseconds, so the cost
+    // is the fp32 slab written per split and the reduction launch behind it.  64-wide tiles give enough tasks to fill the chip
+    // WITHOUT splitting K: no slabs, no second launch (qkv 20.6 -> 16.1 us, ffn1 23.1 -> 16.3, audio head 25.7 -> 17.3).
+    const int short_k = svsr_tune_get(SVSR_TUNE_WG_SHORT_K);
+    const bool is_short = total_chunks <= short_k;
+    pl.bc = (Co >= 128 && Ci >= 128 && tasks128 >= 36 && !is_short) ? 128 : 64;
+    pl.ns = pl.bc == 128 ? 2 : 3;                      // (a 6-deep ring for the short contractions measured no gain: 16.6 vs 16.1 us)
     const int BC = pl.bc;
     pl.tasks = ((Co + BC - 1) / BC) * ((Ci + BC - 1) / BC) * ntaps;
-    const int total_chunks = (int)((max_rows + 63) / 64);
     // one round of resident workgroups: 2 per CU for the 128-wide tile (64 KiB of LDS ring, ~200 VGPRs), 3 per CU for the 64-wide
     // one — a grid a little above that runs a second, almost empty round (layer4: 576 workgroups on 512 slots took 1.4x longer)
     static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
     const int target_env = svsr_tune_get(SVSR_TUNE_WG_BLOCKS);
     const int target_blocks = target_env > 0 ? target_env : cus * (BC == 128 ? 2 : 3);
     int splits = target_blocks / pl.tasks;                    // every split costs a slab of Co*taps*Ci floats written and re-read
+    if (is_short && pl.tasks >= cus / 2) splits = 1;
     if (splits > total_chunks) splits = total_chunks;
     if (splits < 1) splits = 1;
     pl.chunks_per_split = (total_chunks + splits - 1) / splits;

@@ -25,8 +25,9 @@ static int g_tune[SVSR_TUNE_N] = {
     /* STEM_LDS_BWD */ 1,      // LDS-tiled stem BN+act+pool backward (measured faster)
     /* IGEMM_LDS_PAD */ 0,     // extra dynamic LDS bytes per svsr_igemm_fwd workgroup (occupancy experiments: fewer co-resident blocks per CU)
     /* IGEMM_BN64_BELOW */ 300, // multi-tap convolutions with fewer 128x128 tiles than this use 128x64 tiles (three workgroups per CU)
+    /* WG_SHORT_K */ 16,       // svsr_igemm_wgrad: contractions of at most this many 64-row chunks use 64-wide tiles and no K split when that fills half the chip
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 
