@@ -131,19 +131,20 @@ def cpu_baseline_lrs(lrs_args, odim: int, frames: int, budget_s: float = 20.0) -
 
 
 def pmc_traffic(kernel_label: str):
-    """HBM bytes per launch of `kernel_label` from the committed rocprofv3 PMC passes (profiles/round1_pmc_per_kernel.json:
-    FETCH_SIZE and WRITE_SIZE in KiB, separate --pmc runs).  gfx950 correction per MI355X_MICROARCH.md §HBM: FETCH_SIZE
-    reports half of the bytes of wide coalesced reads, so it is doubled.  None when no PMC record exists for the kernel."""
-    path = os.path.join(ROOT, "profiles", "round1_pmc_per_kernel.json")
+    """HBM bytes per launch of `kernel_label` from the committed rocprofv3 PMC passes (profiles/round2_pmc_per_kernel.json, made
+    by scripts/gpu_profiles_round2.sh + scripts/collect_profiles.py at the commit recorded in its __meta__: FETCH_SIZE and
+    WRITE_SIZE in KiB, separate --pmc runs).  gfx950 correction per MI355X_MICROARCH.md §HBM: FETCH_SIZE reports half of the
+    bytes of wide coalesced reads, so it is doubled.  None when no PMC record exists for the kernel."""
+    path = os.path.join(ROOT, "profiles", "round2_pmc_per_kernel.json")
     try:
         rec = json.load(open(path))
     except OSError:
         return None
     key = kernel_label.replace(",", ", ")
     for name, v in rec.items():
-        if name.replace("void ", "") == key and "FETCH_SIZE_avg_per_dispatch" in v and "WRITE_SIZE_avg_per_dispatch" in v:
+        if name != "__meta__" and name.replace("void ", "") == key and "FETCH_SIZE_avg_per_dispatch" in v and "WRITE_SIZE_avg_per_dispatch" in v:
             return {"bytes_per_launch": round((2.0 * v["FETCH_SIZE_avg_per_dispatch"] + v["WRITE_SIZE_avg_per_dispatch"]) * 1024.0),
-                    "source": "profiles/round1_pmc_per_kernel.json (rocprofv3 --pmc, FETCH_SIZE doubled for gfx950)"}
+                    "source": f"profiles/round2_pmc_per_kernel.json @ {rec.get('__meta__', {}).get('commit', '?')[:12]} (rocprofv3 --pmc, FETCH_SIZE doubled for gfx950)"}
     return None
 
 
