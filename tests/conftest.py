@@ -17,3 +17,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _tuning_overrides():
+    """SVSR_TEST_TUNE="key=value,key=value": run the suite with non-default (result-preserving) tuning knobs, e.g. to put an
+    experimental kernel variant under the same parity tests as the default one."""
+    spec = os.environ.get("SVSR_TEST_TUNE", "")
+    if spec:
+        from syncvsr_amd import ops
+
+        for kv in spec.split(","):
+            k, v = kv.split("=")
+            ops.tune(k, int(v))
+    yield
