@@ -164,6 +164,7 @@ def main() -> None:
     ap.add_argument("--bucket-mb", type=float, default=16.0, help="gradient all-reduce bucket size (MiB of fp32)")
     ap.add_argument("--workload", choices=("lrw", "lrs", "lrw-xt"), default="lrw", help="lrw = BASELINE.json's headline metric (default); lrs = the "
                     "sentence-level E2E model (SURVEY §8 a13-a15, BASELINE configs[3]): --batch clips of up to --frames frames")
+    ap.add_argument("--tune", default="", help="result-preserving tuning knobs for A/B runs, e.g. igemm_ksplit=0,wg_short_k=0 (syncvsr_amd.ops.tune)")
     ap.add_argument("--frames", type=int, default=150, help="LRS: padded clip length T (lengths are drawn in [0.3 T, T])")
     ap.add_argument("--dropout", type=float, default=0.1, help="LRS: dropout_rate = transformer_attn_dropout_rate (config/lrs3.yaml:20-21)")
     args = ap.parse_args()
@@ -190,6 +191,9 @@ def main() -> None:
     from syncvsr_amd.init import synthetic_batch
     from syncvsr_amd.model import Model
 
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        ops.tune(k, int(v))
     lrs = args.workload == "lrs"
     use_graph = args.graph and not args.no_graph     # default: eager launches + side-stream weight gradients (faster, see engine.TrainStep)
     if lrs:

@@ -1,9 +1,7 @@
 #!/bin/bash
-# A/B of tuning knobs on the op micro-benchmarks:  gpu_ab.sh "<which ops>" "<tune A>" "<tune B>" ...
+# A/B of tuning knobs on the per-op microbenchmarks: gpu_ab.sh "<op_bench sections>" "<knob=value>" "<knob=value>" ...
 mkdir -p gpurun_out
-export PYTHONUNBUFFERED=1
-which=$1; shift
+secs=$1; shift
 for t in "$@"; do
-  echo "=== OPB_TUNE=$t"
-  OPB_TUNE=$t timeout 600 python scripts/op_bench.py $which 2>&1 | grep -v amdgpu.ids
-done
+  OPB_TUNE=$t python scripts/op_bench.py $secs 2>&1 | grep -vE "^==|amdgpu.ids" | sed "s/^/$t /"
+done | tee gpurun_out/ab.log

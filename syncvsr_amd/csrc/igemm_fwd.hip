@@ -61,9 +61,11 @@ __device__ unsigned g_zero_page[64];     // 256 zero bytes: DMA source for rows 
 // ---------------------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&acc)[TM][TN], unsigned char* smem_raw, const long* sRow,
-                                               int wm0, int wn0, int n0) {
+                                               int wm0, int wn0, int n0, int tid, bool active) {
+    // tid: 0..255 inside the group of four waves that owns the tile; `active` is false for the waves of a second K group, which only
+    // take part in the barriers
     constexpr int WN = BN / 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     // per-channel statistics from the fp32 accumulators (rows outside M carry exact zeros)
     float st_s[TN], st_q[TN];
     if (p.stats != nullptr) {
@@ -80,15 +82,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
     }
     // accumulators -> LDS fp32 [BM][BN] (the tile buffers are dead: the caller has passed a barrier after its last read)
     float* sOut = reinterpret_cast<float*>(smem_raw);
+    if (active) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                sOut[row * BN + wn0 + j * 32 + (lane & 31)] = acc[i][j][r];
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    sOut[row * BN + wn0 + j * 32 + (lane & 31)] = acc[i][j][r];
+                }
+    }
     __syncthreads();
     const bool vec_pitch = (p.out_pitch & 7) == 0;
     constexpr int CV = BN / 8;
@@ -101,7 +105,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
 #pragma unroll
         for (int k = 0; k < 8; ++k) bias8[k] = (p.bias != nullptr && nb + k < p.Co) ? p.bias[nb + k] : 0.f;
     }
-    for (int task = tid; task < BM * CV; task += 256) {
+    for (int task = active ? tid : BM * CV; task < BM * CV; task += 256) {
         const int r = task / CV, c8 = task - r * CV;
         const long off = sRow[r];
         const int n = n0 + c8 * 8;
@@ -167,12 +171,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
         float* red = reinterpret_cast<float*>(smem_raw);   // [4 waves][WN][2]
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            if (lane < 32) {
+            if (active && lane < 32) {
                 red[(wave * WN + j * 32 + lane) * 2 + 0] = st_s[j];
                 red[(wave * WN + j * 32 + lane) * 2 + 1] = st_q[j];
             }
         __syncthreads();
-        for (int c = tid; c < BN; c += 256) {
+        for (int c = active ? tid : BN; c < BN; c += 256) {
             const int wcol = c / WN, cc = c - wcol * WN;      // waves (0,wcol) and (1,wcol) own this column
             const float s = red[((0 * 2 + wcol) * WN + cc) * 2 + 0] + red[((1 * 2 + wcol) * WN + cc) * 2 + 0];
             const float q = red[((0 * 2 + wcol) * WN + cc) * 2 + 1] + red[((1 * 2 + wcol) * WN + cc) * 2 + 1];
@@ -229,19 +233,24 @@ __device__ __forceinline__ void split_row(int m, int P, float inv_p, int& n, int
     if (j < 0) { n--; j += P; } else if (j >= P) { n++; j -= P; }
 }
 
-template <int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
+// KG = 2: in-workgroup split of the contraction.  Two groups of four waves work on the SAME output tile, each with its own LDS ring
+// over one half of the K steps; the second group's accumulators are added to the first's through LDS (always in that order) before
+// the epilogue.  For launches with far fewer tiles than CUs and a long K (the encoder's 960-row linears with 512 outputs: 120
+// tiles, 24-40 K steps) this halves the serial K loop of the few workgroups there are.
+template <int BM, int BN, int NS, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
     constexpr int BK = 64;
     static_assert(NS >= 2 && (BM / 32 + BN / 32) * (NS - 2) <= 63, "vmcnt immediate is 6 bits");
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, S_ELEMS = A_ELEMS + B_ELEMS;
     constexpr int AR = BM / 32, BR = BN / 32, LPT = AR + BR;     // DMA instructions per thread per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* sStage = reinterpret_cast<bf16_t*>(smem_raw);                 // [NS][A | B]
-    long* sRow = reinterpret_cast<long*>(sStage + NS * S_ELEMS);
+    const int grp = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    bf16_t* sStage = reinterpret_cast<bf16_t*>(smem_raw) + grp * NS * S_ELEMS;      // this group's ring [NS][A | B]
+    long* sRow = reinterpret_cast<long*>(reinterpret_cast<bf16_t*>(smem_raw) + KG * NS * S_ELEMS);
     int* sTap = reinterpret_cast<int*>(sRow + BM);                        // delta[9], tw[9]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
     const int n0 = blockIdx.y * BN;
     const int slot = tid & 7, r0 = tid >> 3;                 // lane writes LDS chunk `slot` of row r0 + 32*i ...
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
     const int m0 = ((int)blockIdx.x - cw[3]) * BM;
     const int Mc = p.Nimg * P;
     const float inv_p = 1.0f / (float)P;
-    if (tid < 18) sTap[tid] = cw[4 + tid];
+    if (tid < 18) sTap[tid] = cw[4 + tid];                 // (both K groups write the same values)
 
     // Everything that depends on the row is hoisted out of the K loop: a pointer to the row's centre pixel (rows beyond the
     // class read the zero page for every tap).  A K step then costs one 64-bit add per DMA.
@@ -293,8 +302,14 @@ __global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
     }
     __syncthreads();
 
-    const int KT = ntaps * (p.Ci / BK);
-    int t_next = 0, c_next = 0;
+    const int KT_all = ntaps * (p.Ci / BK);
+    // K steps of this group: [k_begin, k_begin + KT); the loop below runs KT_loop iterations in every group so that the groups
+    // meet at the same barriers (a group that is one step short idles through its last iteration)
+    const int KT_loop = (KT_all + KG - 1) / KG;
+    const int k_begin = grp * KT_loop;
+    const int KT = KT_all - k_begin < KT_loop ? (KT_all - k_begin > 0 ? KT_all - k_begin : 0) : KT_loop;
+    const int spt = p.Ci / BK;                                           // K steps per tap
+    int t_next = k_begin / spt, c_next = (k_begin - (k_begin / spt) * spt) * BK;
     auto stage = [&](int buf) {
         const int tw = sTap[9 + t_next];
         const int c0 = c_next;
@@ -330,31 +345,57 @@ __global__ __launch_bounds__(256) void k_igemm_fwd_glds(const IgemmFwdArgs p) {
     for (int s = 0; s < NS - 1; ++s)
         if (s < KT) stage(s);
     int buf = 0;
-    for (int it = 0; it < KT; ++it) {
+    for (int it = 0; it < KT_loop; ++it) {
         // tile `it` has landed once at most min(NS-2, tiles left) later tiles' DMAs are still outstanding (vmcnt retires in
         // order); the barrier makes every wave's part visible and proves everybody is done reading the buffer the next
         // stage() overwrites.
-        const int later = KT - 1 - it < NS - 2 ? KT - 1 - it : NS - 2;
+        int later = KT - 1 - it < NS - 2 ? KT - 1 - it : NS - 2;
+        if (later < 0) later = 0;
         wait_tiles_barrier<LPT, NS - 2>(later);
         if (it + NS - 1 < KT) stage(buf >= 1 ? buf - 1 : NS - 1);   // == (it + NS - 1) % NS
-        const bf16_t* cA = sStage + buf * S_ELEMS;
-        igemm_mma_tile<BM, BN, TM, TN>(cA, cA + A_ELEMS, acc, wm0, wn0, lane);
+        if (KG == 1 || it < KT) {
+            const bf16_t* cA = sStage + buf * S_ELEMS;
+            igemm_mma_tile<BM, BN, TM, TN>(cA, cA + A_ELEMS, acc, wm0, wn0, lane);
+        }
         buf = buf + 1 == NS ? 0 : buf + 1;
     }
     __syncthreads();
-    igemm_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, sRow, wm0, wn0, n0);
+    if constexpr (KG == 2) {
+        // group 1 -> LDS (its own, now dead, ring) -> group 0: acc0 + acc1, one fixed order
+        float* sX = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem_raw) + NS * S_ELEMS);      // [TM*TN*16][256]
+        static_assert((size_t)TM * TN * 16 * 256 * sizeof(float) <= (size_t)NS * S_ELEMS * sizeof(bf16_t), "exchange buffer fits the ring");
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sX[((i * TN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += sX[((i * TN + j) * 16 + r) * 256 + tid];
+        }
+        __syncthreads();
+    }
+    igemm_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, sRow, wm0, wn0, n0, tid, grp == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int KG = 1>
 static int launch_glds(const IgemmFwdArgs& a, int gx, int gy, hipStream_t stream) {
-    const size_t lds = (size_t)NS * (BM + BN) * 64 * sizeof(bf16_t) + (size_t)BM * sizeof(long) + 128 + (size_t)svsr_tune_get(SVSR_TUNE_IGEMM_LDS_PAD);
+    const size_t lds = (size_t)KG * NS * (BM + BN) * 64 * sizeof(bf16_t) + (size_t)BM * sizeof(long) + 128 + (size_t)svsr_tune_get(SVSR_TUNE_IGEMM_LDS_PAD);
     static size_t attr_set = 0;
     if (attr_set < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_fwd_glds<BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_fwd_glds<BM, BN, NS, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = lds;
     }
-    hipLaunchKernelGGL((k_igemm_fwd_glds<BM, BN, NS>), dim3(gx, gy), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((k_igemm_fwd_glds<BM, BN, NS, KG>), dim3(gx, gy), dim3(256 * KG), lds, stream, a);
     return svsr_check_launch();
 }
 
@@ -529,6 +570,10 @@ extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* o
     a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
     const int bm = meta[0], bn = meta[1], ns = meta[2], gx = meta[3], gy = (Co + bn - 1) / bn;
     if (gx < 1) return SVSR_ERR_ARG;
+    // few tiles, long contraction: split K inside the workgroup (see k_igemm_fwd_glds, KG = 2)
+    if (bm == 64 && bn == 64 && svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT) && (long)gx * gy <= svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT) &&
+        (long)meta[6] * (Ci / 64) >= 12)
+        return launch_glds<64, 64, 4, 2>(a, gx, gy, stream);
 #define SVSR_IGEMM_CASE(BM_, BN_, NS_) if (bm == BM_ && bn == BN_ && ns == NS_) return launch_glds<BM_, BN_, NS_>(a, gx, gy, stream)
     SVSR_IGEMM_CASE(128, 128, 2);
     SVSR_IGEMM_CASE(128, 64, 2);
