@@ -141,8 +141,9 @@ def pmc_traffic(kernel_label: str):
     except OSError:
         return None
     key = kernel_label.replace(",", ", ")
+    keys = {key, key[:-1] + ", 1>"}          # k_igemm_fwd_glds carries a defaulted fourth template argument (K groups) in the profiler's name
     for name, v in rec.items():
-        if name != "__meta__" and name.replace("void ", "") == key and "FETCH_SIZE_avg_per_dispatch" in v and "WRITE_SIZE_avg_per_dispatch" in v:
+        if name != "__meta__" and name.replace("void ", "") in keys and "FETCH_SIZE_avg_per_dispatch" in v and "WRITE_SIZE_avg_per_dispatch" in v:
             return {"bytes_per_launch": round((2.0 * v["FETCH_SIZE_avg_per_dispatch"] + v["WRITE_SIZE_avg_per_dispatch"]) * 1024.0),
                     "source": f"profiles/round2_pmc_per_kernel.json @ {rec.get('__meta__', {}).get('commit', '?')[:12]} (rocprofv3 --pmc, FETCH_SIZE doubled for gfx950)"}
     return None
@@ -158,7 +159,7 @@ def main() -> None:
     ap.add_argument("--graph", action="store_true", help="capture the whole step into one HIP graph and replay it (measured slower than the "
                                                          "eager default, whose weight-gradient launches overlap on a side stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU-baseline leg (default: the workload's own per-GPU batch; ~4 s per step on 32 threads)")
     ap.add_argument("--profile-steps", type=int, default=2, help="eager steps with per-launch HIP events for the roofline leg")
     ap.add_argument("--force-collective", action="store_true", help="run the RCCL path even with one rank")
     ap.add_argument("--bucket-mb", type=float, default=16.0, help="gradient all-reduce bucket size (MiB of fp32)")
