@@ -223,3 +223,37 @@ def test_lrs_encode_api(dev):
     np_ref = gold["full.enc_out"] if "full.enc_out" in gold.files else None
     if np_ref is not None:
         assert _rel(h, torch.from_numpy(np_ref)) <= 5e-2
+
+
+def test_lrs_longest_clip_full_width(dev):
+    """BASELINE.json configs[3] names clips of up to 400 frames: the shipped 252 M-parameter model on ONE 400-frame clip (the longest
+    the recipe admits, the attention kernels' 13 row tiles per head) against the fp32 oracle — forward losses to north_star's 1e-3,
+    encoder output and the gradients of both ends of the network."""
+    from oracle import lrs_oracle as O
+    from syncvsr_amd.lrs_init import LRS_ODIM, default_lrs_args, lrs_init_state_dict, lrs_synthetic_batch
+    from syncvsr_amd.lrs_model import E2E
+
+    args = default_lrs_args(dropout_rate=0.0, transformer_attn_dropout_rate=0.0)
+    sd = lrs_init_state_dict(args, LRS_ODIM, seed=3)
+    x, lengths, tokens, label = lrs_synthetic_batch(args, 1, 400, odim=LRS_ODIM, size=88, seed=77, label_len=(60, 60))
+    model = E2E(LRS_ODIM, args)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).train()
+    out = model(x.to(dev), lengths.to(dev), tokens.to(dev), label.to(dev))
+    out[0].backward()
+    torch.cuda.synchronize()
+    watch = ("encoder.frontend.trunk.layer1.0.conv1.weight", "encoder.encoders.0.self_attn.linear_q.weight", "encoder.encoders.11.feed_forward.w_2.weight",
+             "decoder.decoders.5.src_attn.linear_k.weight", "ctc.ctc_lo.weight", "audio_classifier.weight")
+    osd = {k: (v.clone().requires_grad_(True) if k in watch else v) for k, v in sd.items()}
+    keep = {}
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref = O.forward(osd, args, x, lengths, tokens, label, training=True, keep=keep)
+    ref["loss"].backward()
+    for i, k in enumerate(("loss", "loss_ctc", "loss_att", "loss_audio")):
+        assert abs(out[i].item() - ref[k].item()) <= 1e-3 * abs(ref[k].item()), (k, out[i].item(), ref[k].item())
+    assert _rel(model._last["enc_out"], keep["enc_out"]) <= 4e-2
+    params = dict(model.named_parameters())
+    for n in watch:
+        g, r = params[n].grad.detach().float().cpu().flatten(), osd[n].grad.flatten()
+        cos = float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30))
+        assert cos >= 0.97 and 0.93 <= float(g.norm() / r.norm()) <= 1.07, (n, cos, float(g.norm() / r.norm()))
