@@ -159,7 +159,9 @@ class TrainStep:
         st.shadow_fresh = True
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # thread-local capture mode: with a process group alive, the collective backend's watchdog thread polls HIP events at any
+        # moment, which the default (global) mode turns into "operation not permitted when stream is capturing" and an abort
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
             self._out = self._step_impl(*self._static)
 
     # -- checkpoint / resume -------------------------------------------------------------------------
