@@ -324,7 +324,14 @@ def main() -> None:
                                    "launches": v["launches"] // max(1, args.profile_steps)} for k, v in sorted(rows.items())},
             }
             if not args.no_cpu_baseline and world == 1:
-                result["cpu_baseline"] = cpu_baseline_lrs(lrs_args, LRS_ODIM, 32) if lrs else cpu_baseline(cfg, args.cpu_batch)
+                if lrs:
+                    result["cpu_baseline"] = cpu_baseline_lrs(lrs_args, LRS_ODIM, 32)
+                else:       # the CPU port at the workload's own batch (the reported value) and at batch 2
+                    result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_batch, budget_s=14.0)
+                    if args.cpu_batch != 2:
+                        small = cpu_baseline(cfg, 2, budget_s=5.0)
+                        result["cpu_baseline"]["batch2_value"] = round(small["value"], 3)
+                        result["cpu_baseline"]["sample"] += "; batch 2: " + small["sample"]
         try:        # RCCL prints its version banner through C stdio, which is flushed at exit: push it out first so the JSON line is last
             import ctypes
             ctypes.CDLL(None).fflush(None)
