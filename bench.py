@@ -165,6 +165,8 @@ def main() -> None:
     ap.add_argument("--bucket-mb", type=float, default=16.0, help="gradient all-reduce bucket size (MiB of fp32)")
     ap.add_argument("--workload", choices=("lrw", "lrs", "lrw-xt"), default="lrw", help="lrw = BASELINE.json's headline metric (default); lrs = the "
                     "sentence-level E2E model (SURVEY §8 a13-a15, BASELINE configs[3]): --batch clips of up to --frames frames")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the multi-rank control "
+                    "flow on a box with one GPU, together with SVSR_BENCH_ONE_DEVICE=1)")
     ap.add_argument("--tune", default="", help="result-preserving tuning knobs for A/B runs, e.g. igemm_ksplit=0,wg_short_k=0 (syncvsr_amd.ops.tune)")
     ap.add_argument("--frames", type=int, default=150, help="LRS: padded clip length T (lengths are drawn in [0.3 T, T])")
     ap.add_argument("--dropout", type=float, default=0.1, help="LRS: dropout_rate = transformer_attn_dropout_rate (config/lrs3.yaml:20-21)")
@@ -177,6 +179,8 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("SVSR_BENCH_ONE_DEVICE") == "1":       # test aid: every rank on GPU 0 (not a measurement)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_collective
@@ -184,7 +188,10 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from syncvsr_amd import ops
     from syncvsr_amd.config import default_lrw_config
@@ -294,16 +301,15 @@ def main() -> None:
     if use_dist and trainer.dp is not None:          # what the data-parallel path did in the last timed step
         st = model.store()
         result["collective"] = {
-            "backend": f"{dist.get_backend()} (RCCL {'.'.join(map(str, torch.cuda.nccl.version()))})", "ranks": world,
+            "backend": (f"nccl (RCCL {'.'.join(map(str, torch.cuda.nccl.version()))})" if dist.get_backend() == "nccl" else dist.get_backend()),
+            "ranks": world,
             "all_reduce_launches_per_step": len(trainer.dp.launched), "bucket_mb": args.bucket_mb,
             "gradient_mb_per_step": round(sum(hi - lo for lo, hi in trainer.dp.launched) * 4 / 2 ** 20, 1),
             "buffer_broadcast_mb_per_step": round(st.bufflat.numel() * 4 / 2 ** 20, 3), "overlapped_with_backward": True,
         }
     if rank == 0:
         # ---- roofline leg: eager steps with HIP events around every contraction launch -----------------------------
-        prof = TrainStep(model, cfg, use_graph=False, always_reduce=False)
-        prof.dp = None
-        model.grad_ready_hook = None
+        prof = TrainStep(model, cfg, use_graph=False, data_parallel=False)      # rank 0 alone: must not issue a collective
         model._side.enabled = model._side.enabled_small = False        # time every kernel alone, not overlapped with a side-stream neighbour
         if True:
             prof._step_impl(*batch)

@@ -44,7 +44,7 @@ class TrainStep:
     optionally one HIP graph per step."""
 
     def __init__(self, model, config: Optional[Config] = None, process_group=None,
-                 use_graph: bool = False, bucket_mb: float = 32.0, always_reduce: bool = False):
+                 use_graph: bool = False, bucket_mb: float = 32.0, always_reduce: bool = False, data_parallel: bool = True):
         self.model = model
         self.is_lrw = isinstance(model, TransformerLightningModule)
         if self.is_lrw:            # LRW/video/config/*.yaml: optim.optimizer / optim.scheduler / train.gradient_clip_val
@@ -69,7 +69,11 @@ class TrainStep:
         self.total_steps = int(sch.get("num_training_steps", 0) or 0)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # always_reduce: run the collective path even for a 1-rank group (exercises RCCL + graph capture on one GPU)
-        self.dp = GradReducer(model, process_group, bucket_mb, always_reduce) if (self.world > 1 or always_reduce) else None
+        # data_parallel=False: a purely local step even inside an initialised process group (no collective is ever issued — e.g. the
+        # single-rank profiling leg of bench.py, which the other ranks do not take part in)
+        self.dp = GradReducer(model, process_group, bucket_mb, always_reduce) if data_parallel and (self.world > 1 or always_reduce) else None
+        if not data_parallel:
+            model.grad_ready_hook = None
         self.use_graph = use_graph
         if use_graph and getattr(model, "layer_drop_p", 0.0) > 0.0:
             raise NotImplementedError("layer_dropout skips whole encoder blocks at random: the launch sequence differs from step to "
