@@ -163,6 +163,7 @@ def main() -> None:
     ap.add_argument("--profile-steps", type=int, default=2, help="eager steps with per-launch HIP events for the roofline leg")
     ap.add_argument("--force-collective", action="store_true", help="run the RCCL path even with one rank")
     ap.add_argument("--bucket-mb", type=float, default=16.0, help="gradient all-reduce bucket size (MiB of fp32)")
+    ap.add_argument("--grad-comm", choices=("fp32", "bf16"), default="fp32", help="wire format of the gradient buckets (fp32 = DDP's; bf16 halves the bytes)")
     ap.add_argument("--workload", choices=("lrw", "lrs", "lrw-xt"), default="lrw", help="lrw = BASELINE.json's headline metric (default); lrs = the "
                     "sentence-level E2E model (SURVEY §8 a13-a15, BASELINE configs[3]): --batch clips of up to --frames frames")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the multi-rank control "
@@ -238,7 +239,8 @@ def main() -> None:
         cfg.train.batch_size = args.batch
         model = Model(cfg, seed=0).to(dev).train()
         batch = [t.to(dev) for t in synthetic_batch(cfg, args.batch, seed=1234 + rank)]
-    trainer = TrainStep(model, cfg, use_graph=use_graph, always_reduce=args.force_collective, bucket_mb=args.bucket_mb)
+    trainer = TrainStep(model, cfg, use_graph=use_graph, always_reduce=args.force_collective, bucket_mb=args.bucket_mb,
+                        grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32)
 
     def barrier():
         if use_dist:
@@ -303,7 +305,7 @@ def main() -> None:
         result["collective"] = {
             "backend": (f"nccl (RCCL {'.'.join(map(str, torch.cuda.nccl.version()))})" if dist.get_backend() == "nccl" else dist.get_backend()),
             "ranks": world,
-            "all_reduce_launches_per_step": len(trainer.dp.launched), "bucket_mb": args.bucket_mb,
+            "all_reduce_launches_per_step": len(trainer.dp.launched), "bucket_mb": args.bucket_mb, "wire_dtype": args.grad_comm,
             "gradient_mb_per_step": round(sum(hi - lo for lo, hi in trainer.dp.launched) * 4 / 2 ** 20, 1),
             "buffer_broadcast_mb_per_step": round(st.bufflat.numel() * 4 / 2 ** 20, 3), "overlapped_with_backward": True,
         }

@@ -44,7 +44,8 @@ class TrainStep:
     optionally one HIP graph per step."""
 
     def __init__(self, model, config: Optional[Config] = None, process_group=None,
-                 use_graph: bool = False, bucket_mb: float = 32.0, always_reduce: bool = False, data_parallel: bool = True):
+                 use_graph: bool = False, bucket_mb: float = 32.0, always_reduce: bool = False, data_parallel: bool = True,
+                 grad_comm_dtype: torch.dtype = torch.float32):
         self.model = model
         self.is_lrw = isinstance(model, TransformerLightningModule)
         if self.is_lrw:            # LRW/video/config/*.yaml: optim.optimizer / optim.scheduler / train.gradient_clip_val
@@ -71,7 +72,7 @@ class TrainStep:
         # always_reduce: run the collective path even for a 1-rank group (exercises RCCL + graph capture on one GPU)
         # data_parallel=False: a purely local step even inside an initialised process group (no collective is ever issued — e.g. the
         # single-rank profiling leg of bench.py, which the other ranks do not take part in)
-        self.dp = GradReducer(model, process_group, bucket_mb, always_reduce) if data_parallel and (self.world > 1 or always_reduce) else None
+        self.dp = GradReducer(model, process_group, bucket_mb, always_reduce, grad_comm_dtype) if data_parallel and (self.world > 1 or always_reduce) else None
         if not data_parallel:
             model.grad_ready_hook = None
         self.use_graph = use_graph
@@ -213,8 +214,14 @@ class GradReducer:
     complete and reduced on a side stream.  `on_ready(0)` (end of backward) flushes the rest plus the 1-D tail.
     """
 
-    def __init__(self, model, process_group=None, bucket_mb: float = 32.0, always: bool = False):
+    def __init__(self, model, process_group=None, bucket_mb: float = 32.0, always: bool = False, comm_dtype: torch.dtype = torch.float32):
         self.model = model
+        # comm_dtype=torch.bfloat16: buckets cross the links as bf16 (half the bytes; SURVEY §8e) and come back into the fp32 gradient
+        # buffer — an opt-in deviation from DDP's fp32 all-reduce, for when the step is short enough for the collective to show
+        if comm_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("comm_dtype must be torch.float32 or torch.bfloat16")
+        self.comm_dtype = comm_dtype
+        self._comm_buf: Optional[torch.Tensor] = None
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.always = always and dist.is_initialized()
@@ -268,11 +275,20 @@ class GradReducer:
             if side is not None and side.stream is not None and (side.enabled or side.enabled_small):
                 self.comm_stream.wait_stream(side.stream)                 # ... and, for weight gradients, on the model's side stream
             with torch.cuda.stream(self.comm_stream):
-                if backend == "nccl":
-                    dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group)
+                if self.comm_dtype == torch.bfloat16:
+                    if self._comm_buf is None or self._comm_buf.numel() < seg.numel():      # on the comm stream, used only there
+                        self._comm_buf = torch.empty(max(seg.numel(), self.bucket_elems), dtype=torch.bfloat16, device=seg.device)
+                    wire = self._comm_buf[: seg.numel()]
+                    wire.copy_(seg)
                 else:
-                    dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
-                    seg.div_(self.world)
+                    wire = seg
+                if backend == "nccl":
+                    dist.all_reduce(wire, op=dist.ReduceOp.AVG, group=self.group)
+                else:
+                    dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group)
+                    wire.div_(self.world)
+                if wire is not seg:
+                    seg.copy_(wire)
         else:
             dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
             seg.div_(self.world)
