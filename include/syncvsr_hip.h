@@ -95,6 +95,14 @@ int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, float* dbias, co
 int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W);
 int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, const int* dy, const int* dx, const int* tw, hipStream_t stream);
 
+/* svsr_conv3x3_res: conv3x3, stride 1, pad 1 for 128 / 256 input channels (layer2 / layer3 of the trunk, resnet.py:8-10,59-72) forward and,
+ * with the transposed weights and mirrored taps, its input-gradient: the 128-pixel activation tile (+ a halo of W+1 pixels) stays in
+ * LDS across the nine taps, only weight tiles stream (igemm_fwd.hip k_conv3x3_res).  in bf16 [Nimg][H][W][Ci]; wt bf16 [Co][9][Ci];
+ * out bf16 [Nimg][H][W][Co] (+ addend, which may alias out); tap t reads pixel (y+dy[t], x+dx[t]) with weight tap tw[t] (HOST arrays
+ * of 9 ints); stats [rows][2][Co] with rows = svsr_conv3x3_res_stat_rows(Nimg, H, W) or null. */
+int svsr_conv3x3_res_stat_rows(int Nimg, int H, int W);
+int svsr_conv3x3_res(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, int Ci, int Co, const int* dy, const int* dx, const int* tw, hipStream_t stream);
+
 /* svsr_conv3x3_wgrad: weight gradient of a 3x3 / stride-1 / pad-1 Conv2d (resnet.py:8-10) with all nine taps sharing one
  * pass over x [Nimg][H][W][Ci] and dy [Nimg][H][W][Co] (zero-padded coordinates, wgrad3x3.hip).  dw fp32 [Co][9][Ci] is
  * ACCUMULATED; split-K slabs go through `part` (size from svsr_conv3x3_wgrad_plan) and are added in a fixed order.
