@@ -406,9 +406,10 @@ struct ResArgs {
 template <int CI>
 __device__ __forceinline__ int res_a_off(int row, int chunk) { return row * CI + ((chunk ^ (row & 15)) << 3); }
 
-template <int CI>
+template <int CI, int BK, int NS>
 __global__ __launch_bounds__(256) void k_conv3x3_res(const ResArgs q) {
-    constexpr int BM = 128, BN = 128, BK = 64, NS = 2, KC = CI / BK;
+    constexpr int BM = 128, BN = 128, KC = CI / BK;
+    constexpr int BCPR = BK / 8, BRPP = 256 / BCPR, BR = BN / BRPP;      // weight tile: chunks per row, rows per pass, DMA instructions per thread
     constexpr int TM = 2, TN = 2, WM = 64, WN = 64;
     constexpr int B_ELEMS = BN * BK;
     constexpr int CPR = CI / 8, RPP = 256 / CPR;            // 16-byte chunks per activation row; rows per staging pass
@@ -457,26 +458,27 @@ __global__ __launch_bounds__(256) void k_conv3x3_res(const ResArgs q) {
     }
 
     // ---- weight tiles through the ring -----------------------------------------------------------------------------------
-    const int slotb = tid & 7, r0b = tid >> 3;
-    const int cswb = slotb ^ ((r0b >> 1) & 7);
-    const int wrowb = __builtin_amdgcn_readfirstlane(wave) * 8;
-    const bf16_t* b_ptr[4];
+    const int slotb = tid % BCPR, r0b = tid / BCPR;
+    const int cswb = slotb ^ (BK == 64 ? ((r0b >> 1) & 7) : ((r0b >> 2) & 3));
+    const int wrowb = __builtin_amdgcn_readfirstlane(wave) * (64 / BCPR);
+    const bf16_t* b_ptr[BR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + r0b + 32 * i;
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + r0b + BRPP * i;
         b_ptr[i] = n < p.Co ? p.wt + (long)n * 9 * CI + cswb * 8 : nullptr;
     }
     const bf16_t* zero_b = reinterpret_cast<const bf16_t*>(g_zero_page) + slotb * 8;
     constexpr int KT = 9 * KC;
-    auto stage = [&](int it, int buf) {
-        const int t = it / KC, kc = it - t * KC;
-        const long off = (long)q.tw[t] * CI + kc * BK;
-        bf16_t* dst = sB + buf * B_ELEMS + wrowb * 64;
+    // (taps are walked with COMPILE-TIME indices below: a kernel-argument array indexed with a run-time value lives in scratch memory,
+    // and one scratch load per K step costs more than the step's MFMAs)
+    auto stage = [&](int tw_t, int kc, int buf) {
+        const long off = (long)tw_t * CI + kc * BK;
+        bf16_t* dst = sB + buf * B_ELEMS + wrowb * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < BR; ++i) {
             const bf16_t* src = b_ptr[i] != nullptr ? b_ptr[i] + off : zero_b;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + i * 32 * 64), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + i * BRPP * BK), 16, 0, 0);
         }
     };
 
@@ -488,28 +490,34 @@ __global__ __launch_bounds__(256) void k_conv3x3_res(const ResArgs q) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    stage(0, 0);
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0) stage(q.tw[s0 / KC], s0 % KC, s0);
+#pragma unroll
     for (int it = 0; it < KT; ++it) {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");        // tile `it` (and, the first time, the activation tile) landed
-        if (it + 1 < KT) stage(it + 1, (it + 1) & 1);
-        const int t = it / KC, kc = it - t * KC;
-        const bf16_t* cB = sB + (it & 1) * B_ELEMS;
+        // weight tile `it` (and, the first time, the activation tile in front of it) has landed once at most min(NS-2, tiles left) later
+        // tiles are still in flight; the barrier also frees the ring slot the next stage() overwrites
+        constexpr int dummy = 0; (void)dummy;
+        const int later = KT - 1 - it < NS - 2 ? KT - 1 - it : NS - 2;
+        wait_tiles_barrier<BR, NS - 2>(later);
+        if (it + NS - 1 < KT) stage(q.tw[(it + NS - 1) / KC], (it + NS - 1) % KC, (it + NS - 1) % NS);
+        const int t = it / KC, kc = it % KC;                      // compile-time after unrolling
+        const bf16_t* cB = sB + (it % NS) * B_ELEMS;
         const int sh = halo + q.shift[t];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             const int ch = ks * 2 + (lane >> 5);
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = wm0 + i * 32 + (lane & 31) + sh;
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(sA + res_a_off<CI>(row, kc * 8 + ch));
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(sA + res_a_off<CI>(row, kc * (BK / 8) + ch));
                 const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                 fa[i] = ((vmask[i] >> t) & 1u) ? v : z;
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + j * 32 + (lane & 31);
-                fb[j] = *reinterpret_cast<const bf16x8*>(cB + LDS_SWZ(row, ch));
+                fb[j] = *reinterpret_cast<const bf16x8*>(cB + (BK == 64 ? LDS_SWZ(row, ch) : row * 32 + ((ch ^ ((row >> 2) & 3)) << 3)));
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -715,17 +723,23 @@ extern "C" int svsr_conv3x3_res(const void* in, const void* wt, void* out, const
     }
     const int halo = W + 1, rpp = 256 / (Ci / 8);
     const int arows = (128 + 2 * halo + rpp - 1) / rpp * rpp;
+    const int deep = svsr_tune_get(SVSR_TUNE_RES_DEEP) && Ci == 128;       // 32-deep weight tiles, 4-deep ring (three in flight) in the same 32 KiB
     size_t lds = (size_t)arows * Ci * sizeof(bf16_t) + 2 * 128 * 64 * sizeof(bf16_t) + 128 * sizeof(long) + 128;
     if (lds < (size_t)128 * 128 * sizeof(float) + 128 * sizeof(long)) return SVSR_ERR_ARG;      // the fp32 epilogue staging re-uses the tiles
     if (lds > 160 * 1024) return SVSR_ERR_ARG;
     const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Co + 127) / 128));
     static size_t set128 = 0, set256 = 0;
     if (Ci == 128) {
-        if (set128 < lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_res<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set128 = lds; }
-        hipLaunchKernelGGL(k_conv3x3_res<128>, grid, dim3(256), lds, stream, q);
+        if (set128 < lds) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_res<128, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_res<128, 32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            set128 = lds;
+        }
+        if (deep) hipLaunchKernelGGL((k_conv3x3_res<128, 32, 4>), grid, dim3(256), lds, stream, q);
+        else hipLaunchKernelGGL((k_conv3x3_res<128, 64, 2>), grid, dim3(256), lds, stream, q);
     } else {
-        if (set256 < lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_res<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set256 = lds; }
-        hipLaunchKernelGGL(k_conv3x3_res<256>, grid, dim3(256), lds, stream, q);
+        if (set256 < lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_res<256, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set256 = lds; }
+        hipLaunchKernelGGL((k_conv3x3_res<256, 64, 2>), grid, dim3(256), lds, stream, q);
     }
     return svsr_check_launch();
 }
