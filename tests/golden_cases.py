@@ -79,6 +79,8 @@ LRS_CASES = {
 # coin toss between near-ties.
 LRS_INFER_CASES = {
     "lrs_infer_tiny": (dict(_LRS_TINY, dlayers=2), 41, 16, 24, 21, 191, 6.0, 2.5, [(5, 0.1), (30, 0.1), (4, 0.3)]),
+    # the shipped model and the reference's own search settings (beam 40, CTC weight 0.1, 5,049 units: pre-beam of 60 candidates per hypothesis)
+    "lrs_infer_full": (dict(), 5049, 36, 88, 22, 192, 8.0, 4.0, [(40, 0.1)]),
 }
 
 

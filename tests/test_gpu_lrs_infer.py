@@ -142,3 +142,40 @@ def test_beam_search_on_the_gpu_finds_the_reference_hypotheses(dev, tiny):
     print("end to end:", nbest[0].yseq.tolist(), nbest[0].score, "reference", gy[0][gy[0] >= 0].tolist(), gold["run1.score"][0])
     assert nbest[0].yseq.tolist() == gy[0][gy[0] >= 0].tolist()
     assert abs(nbest[0].score - gold["run1.score"][0]) <= 0.05 * abs(gold["run1.score"][0])
+
+
+def test_shipped_model_with_the_reference_search_settings(dev):
+    """The 252 M-parameter model, 5,049 output units, beam 40, CTC weight 0.1 (lightning.py:237-279 defaults): pre-beam of 60 candidates per
+    hypothesis, 36 frames.  Against the reference's own run (tests/golden/lrs_infer_full.npz): CTC posteriors, the decoder's first two
+    scoring calls, and a search result that is at least as good as the reference's and whose reported scores equal the fp64 re-scoring of
+    the returned hypothesis."""
+    from syncvsr_amd.lrs_infer import get_beam_search_decoder
+    from syncvsr_amd.lrs_model import E2E
+
+    args, odim, sd, clip, runs, gold = build_lrs_infer_case("lrs_infer_full")
+    model = E2E(odim, args)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).eval()
+    g_enc = torch.from_numpy(gold["enc_feat"])
+    enc, _ = model.encoder(clip.unsqueeze(0).to(dev), None)
+    assert float((enc[0].cpu() - g_enc).norm() / g_enc.norm()) <= 3e-2
+    lp = model.ctc.log_softmax(g_enc.unsqueeze(0).to(dev))[0].cpu()
+    assert int((lp.argmax(-1) == torch.from_numpy(gold["ctc_logp_argmax"])).sum()) >= g_enc.shape[0] - 2        # near-ties may flip under bf16
+    assert float((lp.max(-1).values - torch.from_numpy(gold["ctc_logp_max"])).abs().max()) <= 0.1
+    for j in range(2):
+        ys = torch.from_numpy(gold[f"run0.dec{j}.ys"]).to(dev)
+        xs = g_enc.to(dev).unsqueeze(0).expand(ys.shape[0], -1, -1)
+        got, _ = model.decoder.batch_score(ys, [None] * ys.shape[0], xs)
+        want = torch.from_numpy(gold[f"run0.dec{j}.logp"])
+        got = got[: want.shape[0]].cpu()
+        assert float((got - want).norm() / want.norm()) <= 1e-2, (j, float((got - want).norm() / want.norm()))
+    beam, ctcw = runs[0]
+    nbest = get_beam_search_decoder(model, [f"t{i}" for i in range(odim)], ctc_weight=ctcw, beam_size=beam)(g_enc.to(dev))
+    gs = gold["run0.score"]
+    print(f"hip best {nbest[0].score:.4f} ({len(nbest[0].yseq)} tokens) | reference {gs[0]:.4f} (2nd {gs[1]:.4f}); ended {len(nbest)} vs {int(gold['run0.n_ended'])}")
+    assert nbest[0].score >= gs[0] - 0.02 * abs(gs[0])
+    sd64 = {k: v.double() if v.is_floating_point() else v for k, v in sd.items()}
+    tot, td, tc = _rescore(sd64, args, odim, g_enc.double(), nbest[0].yseq.tolist(), ctcw, g_enc.shape[0])
+    d = nbest[0].asdict()
+    assert abs(d["score"] - tot) <= 2e-2 * abs(tot) + 0.05, (d["score"], tot)
+    assert abs(d["scores"]["decoder"] - td) <= 2e-2 * abs(td) + 0.05 and abs(d["scores"]["ctc"] - tc) <= 2e-2 * abs(tc) + 0.05
