@@ -50,6 +50,7 @@ struct IgemmFwdArgs {
     int act, out_f32;          // act: 0 none, 1 GELU(erf) (pre-activation kept in out_pre), 2 ReLU
     float alpha;               // out = alpha * dropout(act(acc + bias)) + addend
     DropArgs drop;             // drop.seed == nullptr: no dropout
+    int epi_batched;           // epilogue: request all rows' operands before using the first (tuning knob "epi_batched", default on)
 };
 
 __device__ unsigned g_zero_page[64];     // 256 zero bytes: DMA source for rows outside the grid
@@ -105,6 +106,67 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
 #pragma unroll
         for (int k = 0; k < 8; ++k) bias8[k] = (p.bias != nullptr && nb + k < p.Co) ? p.bias[nb + k] : 0.f;
     }
+    // A thread keeps its 8-column group and walks rows rbase, rbase + RSTEP, ...  When the whole group is inside Co (the usual case) the
+    // row offsets, the staged accumulators and the addend pieces of ALL its rows are requested before the first one is used: the
+    // loop form paid one LDS round trip — and, with an addend, one global round trip — per row, which was most of the epilogue.
+    constexpr int ITERS = BM * CV / 256, RSTEP = 256 / CV;
+    static_assert(BM * CV % 256 == 0, "whole rows per pass");
+    const int c8 = tid % CV, rbase = tid / CV, n = n0 + c8 * 8;
+    if (active && vec_pitch && n + 8 <= p.Co && p.epi_batched) {
+        long offs[ITERS];
+        f32x4 lo[ITERS], hi[ITERS];
+        u32x4 add8[ITERS];
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int r = rbase + RSTEP * i;
+            offs[i] = sRow[r];
+            lo[i] = *reinterpret_cast<const f32x4*>(sOut + r * BN + c8 * 8);
+            hi[i] = *reinterpret_cast<const f32x4*>(sOut + r * BN + c8 * 8 + 4);
+        }
+        if (p.addend != nullptr) {
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i)
+                add8[i] = *reinterpret_cast<const u32x4*>(p.addend + (offs[i] >= 0 ? offs[i] : 0) + n);
+        }
+        const unsigned key = p.drop.seed != nullptr ? drop_key(p.drop) : 0u;
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const long off = offs[i];
+            if (off < 0) continue;
+            float v[8] = {lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2], hi[i][3]};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += bias8[k];
+            if (p.act == 1) {
+                if (p.out_pre != nullptr) *reinterpret_cast<u32x4*>(p.out_pre + off + n) = pack8(v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (p.drop.seed != nullptr) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = drop_keep(key, p.drop.thresh, (unsigned)(off + n + k)) ? v[k] * p.drop.scale : 0.f;
+            }
+            if (p.alpha != 1.f) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= p.alpha;
+            }
+            if (p.addend != nullptr) {
+                float a8[8];
+                unpack8(add8[i], a8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += a8[k];
+            }
+            if (p.out_f32) {
+                float* o = reinterpret_cast<float*>(p.out) + off + n;
+                *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+                *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + off + n) = pack8(v);
+            }
+        }
+    } else
     for (int task = active ? tid : BM * CV; task < BM * CV; task += 256) {
         const int r = task / CV, c8 = task - r * CV;
         const long off = sRow[r];
@@ -716,6 +778,7 @@ extern "C" int svsr_conv3x3_res(const void* in, const void* wt, void* out, const
     a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = out; a.out_pre = nullptr; a.bias = nullptr; a.addend = (const bf16_t*)addend;
     a.stats = stats; a.plan = nullptr; a.Nimg = Nimg; a.in_pix = H * W; a.Ci = Ci; a.in_pitch = Ci; a.Co = Co; a.out_pix = H * W; a.out_pitch = Co;
     a.wt_taps = 9; a.act = 0; a.out_f32 = 0; a.alpha = 1.f; a.drop = svsr_make_drop(nullptr, 0, 0.f);
+    a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED);
     q.H = H; q.W = W; q.M = (int)M;
     for (int t = 0; t < 9; ++t) {
         if (dy[t] < -1 || dy[t] > 1 || dx[t] < -1 || dx[t] > 1 || tw[t] < 0 || tw[t] > 8) return SVSR_ERR_ARG;
@@ -758,6 +821,7 @@ extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* o
     a.Nimg = Nimg; a.in_pix = in_pix; a.Ci = Ci; a.in_pitch = in_pitch; a.Co = Co; a.out_pix = out_pix; a.out_pitch = out_pitch;
     a.wt_taps = wt_taps; a.act = act; a.out_f32 = out_f32; a.alpha = alpha;
     a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
+    a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED);
     const int bm = meta[0], bn = meta[1], ns = meta[2], gx = meta[3], gy = (Co + bn - 1) / bn;
     if (gx < 1) return SVSR_ERR_ARG;
     // few tiles, long contraction: split K inside the workgroup (see k_igemm_fwd_glds, KG = 2)
