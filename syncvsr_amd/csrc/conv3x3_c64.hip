@@ -29,6 +29,11 @@ struct Conv64Args {
     int Nimg, H, W, WP, Q, Qtot, total_chunks;
     float inv_q, inv_wp;
     int dy[9], dx[9], tw[9];
+    // BatchNorm-backward fusion (see svsr_conv3x3_c64_dgrad_bn): out = g = (y > 0 ? result : 0), stats = sums of {g, g * (x - mean) * rstd}
+    const bf16_t* bnb_y;
+    const bf16_t* bnb_x;
+    const float* bnb_mean;
+    const float* bnb_rstd;
 };
 
 __device__ unsigned g_c64_zero_page[64];
@@ -86,6 +91,12 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
     float st_s[8], st_q[8];         // channels slot*8 .. +7 of the rows this thread stores, summed over its chunks
 #pragma unroll
     for (int k = 0; k < 8; ++k) { st_s[k] = 0.f; st_q[k] = 0.f; }
+    const bool bnb = p.bnb_x != nullptr;
+    float mu[8], rs[8];
+    if (bnb) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { mu[k] = p.bnb_mean[slot * 8 + k]; rs[k] = p.bnb_rstd[slot * 8 + k]; }
+    }
     int c = blockIdx.x, buf = 0;
     if (c < p.total_chunks) stage(c, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // weights + first tile
@@ -151,6 +162,37 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
 #pragma unroll
             for (int i = 0; i < 4; ++i) add[i] = *reinterpret_cast<const u32x4*>(p.addend + (long)(pixv[i] >= 0 ? pixv[i] : 0) * 64 + slot * 8);
         }
+        if (bnb) {
+            u32x4 y8[4], x8[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long o = (long)(pixv[i] >= 0 ? pixv[i] : 0) * 64 + slot * 8;
+                y8[i] = *reinterpret_cast<const u32x4*>(p.bnb_y + o);
+                x8[i] = *reinterpret_cast<const u32x4*>(p.bnb_x + o);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (pixv[i] < 0) continue;
+                float a[8], yv[8], xv[8];
+                unpack8(piece[i], a);
+                unpack8(y8[i], yv);
+                unpack8(x8[i], xv);
+                if (p.addend != nullptr) {
+                    float b[8];
+                    unpack8(add[i], b);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a[k] = bf2f(f2bf(a[k] + b[k]));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    a[k] = yv[k] > 0.f ? a[k] : 0.f;
+                    st_s[k] += a[k];
+                    st_q[k] += a[k] * (xv[k] - mu[k]) * rs[k];
+                }
+                *reinterpret_cast<u32x4*>(p.out + (long)pixv[i] * 64 + slot * 8) = pack8(a);
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (pixv[i] < 0) continue;
@@ -197,11 +239,13 @@ extern "C" int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W) {
     return c64_grid(((long)Nimg * (H + 2) * (W + 2) + C64_CH - 1) / C64_CH);
 }
 
-extern "C" int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
-                                const int* dy, const int* dx, const int* tw, hipStream_t stream) {
+static int c64_run(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
+                   const int* dy, const int* dx, const int* tw, const void* bnb_y, const void* bnb_x, const float* bnb_mean,
+                   const float* bnb_rstd, hipStream_t stream) {
     if (W + 2 > (C64_XR - C64_CH) / 2 - 1 || H < 1 || W < 1 || Nimg < 1) return SVSR_ERR_ARG;
     Conv64Args a;
     a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = (bf16_t*)out; a.addend = (const bf16_t*)addend; a.stats = stats;
+    a.bnb_y = (const bf16_t*)bnb_y; a.bnb_x = (const bf16_t*)bnb_x; a.bnb_mean = bnb_mean; a.bnb_rstd = bnb_rstd;
     a.Nimg = Nimg; a.H = H; a.W = W; a.WP = W + 2; a.Q = (H + 2) * (W + 2);
     const long qtot = (long)Nimg * a.Q;
     if (qtot >= (1L << 24) || (long)Nimg * H * W >= (1L << 25)) return SVSR_ERR_ARG;
@@ -218,4 +262,20 @@ extern "C" int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const
     const int grid = c64_grid(a.total_chunks);
     hipLaunchKernelGGL(k_conv3x3_c64, dim3(grid), dim3(C64_THREADS), lds, stream, a);
     return svsr_check_launch();
+}
+
+extern "C" int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
+                                const int* dy, const int* dx, const int* tw, hipStream_t stream) {
+    return c64_run(in, wt, out, addend, stats, Nimg, H, W, dy, dx, tw, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+/* svsr_conv3x3_c64_dgrad_bn: the data gradient of a 64 -> 64 convolution whose result is the gradient of a BatchNorm + ReLU output
+ * y = relu(bn(x) [+ residual]) (reference tcn/models/resnet.py:59-72 backward).  Stores g = (y > 0 ? result [+ addend] : 0) and writes
+ * per workgroup the column sums of g and g * (x - mean) * rstd into stats[svsr_conv3x3_c64_stat_rows][2][64]: the first pass of the
+ * BatchNorm backward, taken while the tile is in registers (svsr_bn_bwd_from_stats finishes it).  addend may alias out. */
+extern "C" int svsr_conv3x3_c64_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
+                                         const int* dy, const int* dx, const int* tw, const void* y, const void* x, const float* mean,
+                                         const float* rstd, hipStream_t stream) {
+    if (y == nullptr || x == nullptr || mean == nullptr || rstd == nullptr || stats == nullptr) return SVSR_ERR_ARG;
+    return c64_run(in, wt, out, addend, stats, Nimg, H, W, dy, dx, tw, y, x, mean, rstd, stream);
 }

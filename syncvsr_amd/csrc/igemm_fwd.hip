@@ -51,6 +51,12 @@ struct IgemmFwdArgs {
     float alpha;               // out = alpha * dropout(act(acc + bias)) + addend
     DropArgs drop;             // drop.seed == nullptr: no dropout
     int epi_batched;           // epilogue: request all rows' operands before using the first (tuning knob "epi_batched", default on)
+    // BatchNorm-backward fusion (data-gradient launches whose result is the gradient of a BatchNorm+ReLU output y = relu(bn(x) [+ res])):
+    // out = g = (y > 0 ? result : 0) and stats rows = this tile's column sums of {g, g * (x - mean) * rstd}   (bnb_x == nullptr: off)
+    const bf16_t* bnb_y;
+    const bf16_t* bnb_x;
+    const float* bnb_mean;
+    const float* bnb_rstd;
 };
 
 __device__ unsigned g_zero_page[64];     // 256 zero bytes: DMA source for rows outside the grid
@@ -69,7 +75,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
     const int lane = tid & 63, wave = tid >> 6;
     // per-channel statistics from the fp32 accumulators (rows outside M carry exact zeros)
     float st_s[TN], st_q[TN];
-    if (p.stats != nullptr) {
+    const bool bnb = p.bnb_x != nullptr;
+    if (p.stats != nullptr && !bnb) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float s = 0.f, q = 0.f;
@@ -112,7 +119,60 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
     constexpr int ITERS = BM * CV / 256, RSTEP = 256 / CV;
     static_assert(BM * CV % 256 == 0, "whole rows per pass");
     const int c8 = tid % CV, rbase = tid / CV, n = n0 + c8 * 8;
-    if (active && vec_pitch && n + 8 <= p.Co && p.epi_batched) {
+    float bs1[8], bs2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { bs1[k] = 0.f; bs2[k] = 0.f; }
+    if (bnb) {
+        // data-gradient launch feeding a BatchNorm+ReLU backward (host: vec_pitch, Co % 8 == 0, no bias / activation / dropout, bf16 out):
+        // rows in batches of BROWS, operands of a batch requested together (the registers of the full-tile batch below would not fit twice)
+        constexpr int BROWS = ITERS >= 8 ? 4 : (ITERS >= 2 ? 2 : 1);
+        float mu[8], rs[8];
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { mu[k] = p.bnb_mean[n + k]; rs[k] = p.bnb_rstd[n + k]; }
+        }
+        for (int i0 = 0; i0 < (active ? ITERS : 0); i0 += BROWS) {
+            long offs[BROWS];
+            f32x4 lo[BROWS], hi[BROWS];
+            u32x4 add8[BROWS], y8[BROWS], x8[BROWS];
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) {
+                const int r = rbase + RSTEP * (i0 + i);
+                offs[i] = sRow[r];
+                lo[i] = *reinterpret_cast<const f32x4*>(sOut + r * BN + c8 * 8);
+                hi[i] = *reinterpret_cast<const f32x4*>(sOut + r * BN + c8 * 8 + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) {
+                const long o = (offs[i] >= 0 ? offs[i] : 0) + n;
+                y8[i] = *reinterpret_cast<const u32x4*>(p.bnb_y + o);
+                x8[i] = *reinterpret_cast<const u32x4*>(p.bnb_x + o);
+                if (p.addend != nullptr) add8[i] = *reinterpret_cast<const u32x4*>(p.addend + o);
+            }
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) {
+                if (offs[i] < 0) continue;
+                float v[8] = {lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2], hi[i][3]};
+                float yv[8], xv[8];
+                unpack8(y8[i], yv);
+                unpack8(x8[i], xv);
+                if (p.addend != nullptr) {
+                    float a8[8];
+                    unpack8(add8[i], a8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += a8[k];
+                }
+                // sums over the values the apply pass reads back (rounded to bf16): mean(g) is then the mean of what it is subtracted from
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k] = yv[k] > 0.f ? bf2f(f2bf(v[k])) : 0.f;
+                    bs1[k] += v[k];
+                    bs2[k] += v[k] * (xv[k] - mu[k]) * rs[k];
+                }
+                *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + offs[i] + n) = pack8(v);
+            }
+        }
+    } else if (active && vec_pitch && n + 8 <= p.Co && p.epi_batched) {
         long offs[ITERS];
         f32x4 lo[ITERS], hi[ITERS];
         u32x4 add8[ITERS];
@@ -228,7 +288,22 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
             }
         }
     }
-    if (p.stats != nullptr) {
+    if (bnb) {
+        // threads rbase * CV + c8 share the column group c8: their sums are added through LDS in the order of rbase
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);   // [256][16]
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { red[tid * 16 + k] = bs1[k]; red[tid * 16 + 8 + k] = bs2[k]; }
+        }
+        __syncthreads();
+        for (int c = active ? tid : 2 * BN; c < 2 * BN; c += 256) {
+            const int which = c / BN, cc = c - which * BN;
+            float s = 0.f;
+            for (int rb = 0; rb < RSTEP; ++rb) s += red[(rb * CV + (cc >> 3)) * 16 + which * 8 + (cc & 7)];
+            if (n0 + cc < p.Co) p.stats[((long)blockIdx.x * 2 + which) * p.Co + n0 + cc] = s;
+        }
+    } else if (p.stats != nullptr) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem_raw);   // [4 waves][WN][2]
 #pragma unroll
@@ -779,6 +854,7 @@ extern "C" int svsr_conv3x3_res(const void* in, const void* wt, void* out, const
     a.stats = stats; a.plan = nullptr; a.Nimg = Nimg; a.in_pix = H * W; a.Ci = Ci; a.in_pitch = Ci; a.Co = Co; a.out_pix = H * W; a.out_pitch = Co;
     a.wt_taps = 9; a.act = 0; a.out_f32 = 0; a.alpha = 1.f; a.drop = svsr_make_drop(nullptr, 0, 0.f);
     a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED);
+    a.bnb_y = nullptr; a.bnb_x = nullptr; a.bnb_mean = nullptr; a.bnb_rstd = nullptr;
     q.H = H; q.W = W; q.M = (int)M;
     for (int t = 0; t < 9; ++t) {
         if (dy[t] < -1 || dy[t] > 1 || dx[t] < -1 || dx[t] > 1 || tw[t] < 0 || tw[t] > 8) return SVSR_ERR_ARG;
@@ -808,10 +884,11 @@ extern "C" int svsr_conv3x3_res(const void* in, const void* wt, void* out, const
 }
 
 /* svsr_igemm_fwd: runs a plan.  plan_dev = device copy of the words, meta = the host meta[8] svsr_*_plan returned with them. */
-extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend,
-                              float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co,
-                              int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed,
-                              unsigned drop_site, float drop_p, hipStream_t stream) {
+static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend,
+                         float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co,
+                         int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed,
+                         unsigned drop_site, float drop_p, const void* bnb_y, const void* bnb_x, const float* bnb_mean,
+                         const float* bnb_rstd, hipStream_t stream) {
     if (plan_dev == nullptr || meta == nullptr || Ci % 64 != 0 || Ci <= 0 || Co <= 0 || in_pitch % 8 != 0 || Nimg <= 0 || wt_taps < 1)
         return SVSR_ERR_ARG;
     if (act != 0 && (addend != nullptr || alpha != 1.f)) return SVSR_ERR_ARG;     // the activation is applied before alpha / addend
@@ -822,10 +899,11 @@ extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* o
     a.wt_taps = wt_taps; a.act = act; a.out_f32 = out_f32; a.alpha = alpha;
     a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
     a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED);
+    a.bnb_y = (const bf16_t*)bnb_y; a.bnb_x = (const bf16_t*)bnb_x; a.bnb_mean = bnb_mean; a.bnb_rstd = bnb_rstd;
     const int bm = meta[0], bn = meta[1], ns = meta[2], gx = meta[3], gy = (Co + bn - 1) / bn;
     if (gx < 1) return SVSR_ERR_ARG;
     // few tiles, long contraction: split K inside the workgroup (see k_igemm_fwd_glds, KG = 2)
-    if (bm == 64 && bn == 64 && svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT) && (long)gx * gy <= svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT) &&
+    if (bnb_x == nullptr && bm == 64 && bn == 64 && svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT) && (long)gx * gy <= svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT) &&
         (long)meta[6] * (Ci / 64) >= 12)
         return launch_glds<64, 64, 4, 2>(a, gx, gy, stream);
 #define SVSR_IGEMM_CASE(BM_, BN_, NS_) if (bm == BM_ && bn == BN_ && ns == NS_) return launch_glds<BM_, BN_, NS_>(a, gx, gy, stream)
@@ -836,4 +914,26 @@ extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* o
     SVSR_IGEMM_CASE(64, 64, 3);
 #undef SVSR_IGEMM_CASE
     return SVSR_ERR_ARG;
+}
+
+extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend,
+                              float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co,
+                              int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed,
+                              unsigned drop_site, float drop_p, hipStream_t stream) {
+    return igemm_fwd_run(in, wt, out, out_pre, bias, addend, stats, plan_dev, meta, Nimg, in_pix, Ci, in_pitch, Co, out_pix, out_pitch,
+                         wt_taps, act, out_f32, alpha, drop_seed, drop_site, drop_p, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+/* svsr_igemm_dgrad_bn: a data-gradient plan (every target pixel visited exactly once: svsr_conv_plan mode 1) whose result dL/dy is the
+ * gradient of a BatchNorm + ReLU output y = relu(bn(x) [+ residual]) with the geometry of `out` (reference tcn/models/resnet.py:59-72
+ * backward).  The launch stores g = (y > 0 ? dL/dy [+ addend] : 0) instead of dL/dy and writes, per row tile, the column sums of g and of
+ * g * (x - mean) * rstd into stats[meta[3]][2][Co] — the first pass of the BatchNorm backward, taken while the tile is in registers;
+ * svsr_bn_bwd_from_stats finishes it.  addend may alias out. */
+extern "C" int svsr_igemm_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, const int* plan_dev,
+                                   const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch,
+                                   int wt_taps, const void* y, const void* x, const float* mean, const float* rstd, hipStream_t stream) {
+    if (y == nullptr || x == nullptr || mean == nullptr || rstd == nullptr || stats == nullptr || Co % 8 != 0 || out_pitch % 8 != 0)
+        return SVSR_ERR_ARG;
+    return igemm_fwd_run(in, wt, out, nullptr, nullptr, addend, stats, plan_dev, meta, Nimg, in_pix, Ci, in_pitch, Co, out_pix, out_pitch,
+                         wt_taps, 0, 0, 1.0f, nullptr, 0, 0.f, y, x, mean, rstd, stream);
 }

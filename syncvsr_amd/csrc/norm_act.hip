@@ -704,6 +704,19 @@ int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* m
     return svsr_check_launch();
 }
 
+/* svsr_bn_bwd_from_stats: second half of a BatchNorm backward whose first pass was taken by the producing data-gradient launch
+ * (svsr_igemm_dgrad_bn / svsr_conv3x3_c64_dgrad_bn): g = the masked gradient that launch stored, stats = its nrows x [2][C] partial sums
+ * of {g, g * xhat}.  Adds the rows in a fixed order (dgamma += , dbeta +=, coef) and writes dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)). */
+int svsr_bn_bwd_from_stats(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma, const float* stats,
+                           int nrows, float* coef, float* dgamma, float* dbeta, void* dx, int64_t npix, int C, hipStream_t stream) {
+    if (!chan_ok_any(C) || nrows < 1 || npix < 1 || g == nullptr || x == nullptr || stats == nullptr || dx == nullptr) return SVSR_ERR_ARG;
+    const long nvec = npix * (C / 8);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, stats, nrows, C, (float)npix, gamma, rstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(k_bn_act_bwd_apply<0>, dim3(ew_grid_for(nvec, C)), dim3(256), 0, stream, (const bf16_t*)g, (const bf16_t*)nullptr,
+                       (const bf16_t*)x, mean, rstd, coef, (bf16_t*)dx, (bf16_t*)nullptr, nvec, C, gamma, (const float*)nullptr, (const bf16_t*)nullptr);
+    return svsr_check_launch();
+}
+
 int svsr_stem_bn_act_pool_fwd(const void* x, void* y, void* amax, const float* mean, const float* rstd, const float* gamma,
                               const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, hipStream_t stream) {
     if (!chan_ok(C) || (act != SVSR_ACT_GELU && act != SVSR_ACT_SWISH)) return SVSR_ERR_ARG;

@@ -512,31 +512,56 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
     use_tr = model.use_tr
     act = model.trunk_act
     dx = ops.avgpool_bwd(dfeats, tape["trunk_out_shape"])
-    for prefix, inp, planes, stride, down in reversed(list(_trunk_blocks(model))):
+    # ReLU trunk: the launch that produces the gradient of a BatchNorm+ReLU output also masks it and takes the first pass of that
+    # BatchNorm's backward in its epilogue (ops.conv2d_dgrad_bn); dx_stats != None means dx already is that masked gradient.
+    fused = act == 1 and ops.BN_BWD_FUSED
+    dx_stats = None
+    blocks = list(_trunk_blocks(model))
+    for bi in range(len(blocks) - 1, -1, -1):
+        prefix, inp, planes, stride, down = blocks[bi]
         t2 = tape[f"{prefix}.conv2"]
         ws2 = st.bn[t2["bn"]]
-        dc2, dres = ops.bn_act_bwd(dx, t2["y"], t2["c"], t2["mean"], t2["rstd"], st.p32(f"{t2['bn']}.weight"), ws2["coef"],
-                                   st.g32(f"{t2['bn']}.weight"), st.g32(f"{t2['bn']}.bias"), act, True,
-                                   beta=st.p32(f"{t2['bn']}.bias"), res=t2["res"])
+        if dx_stats is not None:
+            dres = dx
+            dc2 = ops.bn_bwd_from_stats(dx, t2["c"], t2["mean"], t2["rstd"], st.p32(f"{t2['bn']}.weight"), dx_stats, ws2["coef"],
+                                        st.g32(f"{t2['bn']}.weight"), st.g32(f"{t2['bn']}.bias"))
+        else:
+            dc2, dres = ops.bn_act_bwd(dx, t2["y"], t2["c"], t2["mean"], t2["rstd"], st.p32(f"{t2['bn']}.weight"), ws2["coef"],
+                                       st.g32(f"{t2['bn']}.weight"), st.g32(f"{t2['bn']}.bias"), act, True,
+                                       beta=st.p32(f"{t2['bn']}.bias"), res=t2["res"])
         _conv_wgrad(model, st, f"{prefix}.conv2", t2, dc2, use_tr)
-        do1 = ops.conv2d_dgrad(dc2, st.t16(f"{prefix}.conv2.weight").view(planes, 3, 3, planes), 3, 1, 1, t2["x"].shape[1:3])
         t1 = tape[f"{prefix}.conv1"]
         ws1 = st.bn[t1["bn"]]
-        dc1, _ = ops.bn_act_bwd(do1, t1["y"], t1["c"], t1["mean"], t1["rstd"], st.p32(f"{t1['bn']}.weight"), ws1["coef"],
-                                st.g32(f"{t1['bn']}.weight"), st.g32(f"{t1['bn']}.bias"), act, False, beta=st.p32(f"{t1['bn']}.bias"))
+        w2t = st.t16(f"{prefix}.conv2.weight").view(planes, 3, 3, planes)
+        if fused:
+            g1, st1 = ops.conv2d_dgrad_bn(dc2, w2t, 3, 1, 1, t2["x"].shape[1:3], None, t1["y"], t1["c"], t1["mean"], t1["rstd"])
+            dc1 = ops.bn_bwd_from_stats(g1, t1["c"], t1["mean"], t1["rstd"], st.p32(f"{t1['bn']}.weight"), st1, ws1["coef"],
+                                        st.g32(f"{t1['bn']}.weight"), st.g32(f"{t1['bn']}.bias"))
+        else:
+            do1 = ops.conv2d_dgrad(dc2, w2t, 3, 1, 1, t2["x"].shape[1:3])
+            dc1, _ = ops.bn_act_bwd(do1, t1["y"], t1["c"], t1["mean"], t1["rstd"], st.p32(f"{t1['bn']}.weight"), ws1["coef"],
+                                    st.g32(f"{t1['bn']}.weight"), st.g32(f"{t1['bn']}.bias"), act, False, beta=st.p32(f"{t1['bn']}.bias"))
         _conv_wgrad(model, st, f"{prefix}.conv1", t1, dc1, use_tr)
         in_hw = t1["x"].shape[1:3]
         w1t = st.t16(f"{prefix}.conv1.weight").view(inp, 3, 3, planes)
+        tp = tape[f"{blocks[bi - 1][0]}.conv2"] if fused and bi > 0 else None       # the block below: its output is this block's input
         if down:
             td = tape[f"{prefix}.downsample.0"]
             wsd = st.bn[td["bn"]]
             dcd, _ = ops.bn_act_bwd(dres, None, td["c"], td["mean"], td["rstd"], st.p32(f"{td['bn']}.weight"), wsd["coef"],
                                     st.g32(f"{td['bn']}.weight"), st.g32(f"{td['bn']}.bias"), 0, False)
             _conv_wgrad(model, st, f"{prefix}.downsample.0", td, dcd, use_tr)
-            dxa = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw)
-            dx = ops.conv2d_dgrad(dcd, st.t16(f"{prefix}.downsample.0.weight").view(inp, 1, 1, planes), 1, stride, 0, in_hw, addend=dxa)
+            wdt = st.t16(f"{prefix}.downsample.0.weight").view(inp, 1, 1, planes)
+            if tp is not None:
+                dxd = ops.conv2d_dgrad(dcd, wdt, 1, stride, 0, in_hw)
+                dx, dx_stats = ops.conv2d_dgrad_bn(dc1, w1t, 3, stride, 1, in_hw, dxd, tp["y"], tp["c"], tp["mean"], tp["rstd"])
+            else:
+                dxa = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw)
+                dx, dx_stats = ops.conv2d_dgrad(dcd, wdt, 1, stride, 0, in_hw, addend=dxa), None
+        elif tp is not None:
+            dx, dx_stats = ops.conv2d_dgrad_bn(dc1, w1t, 3, stride, 1, in_hw, dres, tp["y"], tp["c"], tp["mean"], tp["rstd"])
         else:
-            dx = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw, addend=dres)
+            dx, dx_stats = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw, addend=dres), None
         _ready(model, st, f"{prefix}.conv1.weight")
     ts = tape["stem"]
     sc, sb = model.stem_name + ".0", model.stem_name + ".1"

@@ -87,7 +87,12 @@ def _query(name: str, *args) -> tuple:
 
 
 def tune(key: str, value: int) -> None:
-    """Result-preserving tuning knob of the library (svsr_tune); invalidates cached plans."""
+    """Result-preserving tuning knob of the library (svsr_tune); invalidates cached plans.  `bn_bwd_fused` is a host-side choice
+    (which launches the trunk backward issues), kept in this module."""
+    if key == "bn_bwd_fused":
+        global BN_BWD_FUSED
+        BN_BWD_FUSED = bool(value)
+        return
     rc = _lib.load().svsr_tune(key.encode(), int(value))
     if rc != 0:
         _lib.check(rc, f"svsr_tune({key})")
@@ -335,6 +340,45 @@ def conv2d_dgrad(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad:
         return dx
     igemm_fwd(conv_plan(1 if addend is None else 2, N, H, W, Ci, k, stride, pad), dy, w16t, dx, Nimg=N, in_pix=Ho * Wo, Ci=Co, in_pitch=Co, Co=Ci, out_pix=H * W,
               out_pitch=Ci, wt_taps=k * k, addend=addend, flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
+    return dx
+
+
+BN_BWD_FUSED = True    # ReLU trunk: first pass of the BatchNorm backward inside the producing data-gradient launch (False: separate pass)
+
+
+def conv2d_dgrad_bn(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad: int, in_hw: tuple[int, int],
+                    addend: Optional[torch.Tensor], y: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor):
+    """conv2d_dgrad whose result is the gradient of y = relu(bn(x) [+ residual]) (y, x shaped like the result): the launch stores
+    g = (y > 0) * (dgrad + addend) instead and takes the first pass of that BatchNorm's backward in its epilogue.
+    -> (g, (stats, rows)) for bn_bwd_from_stats.  In place when addend is given."""
+    N, Ho, Wo, Co = dy.shape
+    Ci = w16t.shape[0]
+    H, W = in_hw
+    if y.shape != (N, H, W, Ci) or x.shape != y.shape or not (y.is_contiguous() and x.is_contiguous()):
+        raise ValueError("conv2d_dgrad_bn: y / x must be contiguous tensors with the geometry of the result")
+    g = torch.empty((N, H, W, Ci), dtype=BF16, device=dy.device) if addend is None else addend
+    if stride == 1 and _c64_ok(Ci, Co, k, stride, pad, W):
+        taps = tuple((pad - kh, pad - kw, kh * k + kw) for kh in range(k) for kw in range(k))
+        tdy, tdx, tw = zip(*taps)
+        rows = _query("svsr_conv3x3_c64_stat_rows", N, H, W)[0]
+        stats = scratch(rows * 2 * 64)
+        _call("svsr_conv3x3_c64_dgrad_bn", _p(dy), _p(w16t), _p(g), _p(addend), _p(stats), N, H, W, _ints(tdy), _ints(tdx), _ints(tw),
+              _p(y), _p(x), _p(mean), _p(rstd), _stream(), label="k_conv3x3_c64", flops=2.0 * N * H * W * 64 * 64 * 9)
+        return g, (stats, rows)
+    plan = conv_plan(1, N, H, W, Ci, k, stride, pad)        # mode 1: every pixel of the result is visited once
+    stats = scratch(plan.tiles * 2 * Ci)
+    _call("svsr_igemm_dgrad_bn", _p(dy), _p(w16t), _p(g), _p(addend), _p(stats), plan.words.data_ptr(), plan.meta, N, Ho * Wo, Co, Co, Ci,
+          H * W, Ci, k * k, _p(y), _p(x), _p(mean), _p(rstd), _stream(), label=plan.label, flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
+    return g, (stats, plan.tiles)
+
+
+def bn_bwd_from_stats(g, x, mean, rstd, gamma, stats, coef, dgamma, dbeta) -> torch.Tensor:
+    """Second half of the BatchNorm backward after conv2d_dgrad_bn: -> dx (gradient of the BatchNorm input x)."""
+    part, rows = stats
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    _call("svsr_bn_bwd_from_stats", _p(g), _p(x), _p(mean), _p(rstd), _p(gamma), _p(part), rows, _p(coef), _p(dgamma), _p(dbeta), _p(dx),
+          x.numel() // C, C, _stream())
     return dx
 
 

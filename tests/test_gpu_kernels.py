@@ -279,6 +279,80 @@ def test_bn_act(dev, C, act, use_res):
         check(dres, rf.grad, "bn.dres")
 
 
+DGRAD_BN_CASES = [
+    # N, H, W, Ci, Co, k, stride, pad, addend          (H, W, Ci: geometry of the RESULT = the BatchNorm output being differentiated)
+    (40, 22, 22, 64, 64, 3, 1, 1, True),       # persistent 64 -> 64 kernel, several chunks per workgroup
+    (3, 11, 11, 64, 64, 3, 1, 1, False),       # the same kernel with fewer chunks than workgroups
+    (70, 11, 11, 128, 128, 3, 1, 1, True),     # 128x128 tiles
+    (70, 11, 11, 128, 128, 3, 1, 1, False),
+    (9, 12, 12, 64, 128, 3, 2, 1, True),       # stride-2 data gradient: four parity classes in one launch
+    (150, 6, 6, 256, 256, 3, 1, 1, True),      # 128x64 tiles (few tiles)
+    (5, 3, 3, 512, 512, 3, 1, 1, False),       # 64x64 tiles
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_BN_CASES)
+def test_conv_dgrad_with_bn_backward_epilogue(dev, case):
+    """svsr_igemm_dgrad_bn / svsr_conv3x3_c64_dgrad_bn + svsr_bn_bwd_from_stats == data gradient, then BatchNorm+ReLU backward
+    (torch fp32), and the masked gradient is bit-identical to the one the separate passes produce."""
+    from syncvsr_amd import ops
+
+    N, H, W, Ci, Co, k, s, p, use_add = case
+    Ho, Wo = ops.conv_out_size(H, k, s, p), ops.conv_out_size(W, k, s, p)
+    dy = rnd((N, Ho, Wo, Co), 3)
+    w = rnd((Co, k, k, Ci), 4, 1.0 / math.sqrt(k * k * Co))
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    add = rnd((N, H, W, Ci), 5) if use_add else None
+    xb = rnd((N, H, W, Ci), 6, 2.0) + 0.3                  # the BatchNorm input whose output the result differentiates
+    res = rnd((N, H, W, Ci), 7) if use_add else None       # residual branch of that output (only its effect on the mask matters)
+    g_ = torch.Generator().manual_seed(8)
+    gamma = 1 + 0.2 * torch.randn(Ci, generator=g_)
+    beta = 0.2 * torch.randn(Ci, generator=g_)
+    xs = torch.zeros(N, Ci, H, W, requires_grad=True)
+    F.conv2d(xs, w.float().permute(0, 3, 1, 2), stride=s, padding=p).backward(nchw(dy.float()))
+    dout = nhwc(xs.grad) + (add.float() if use_add else 0.0)
+    xf = xb.float().requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yref, mean, var = _bn_ref(xf, gm, bt, None if res is None else res.float(), 1)
+    mean, var = mean.detach(), var.detach()
+    ybf = yref.detach().to(BF)
+    # reference backward with the mask of the bf16 output the kernels see, and the gradient rounded as the launch stores it
+    gref = torch.where(ybf.float() > 0, dout.to(BF).float(), torch.zeros(()))
+    rstd = torch.rsqrt(var + 1e-5)
+    xhat = (xb.float() - mean) * rstd
+    cnt = N * H * W
+    s1, s2 = gref.sum((0, 1, 2)), (gref * xhat).sum((0, 1, 2))
+    dxb_ref = gamma * rstd * (gref - s1 / cnt - xhat * s2 / cnt)
+
+    m, r = mean.to(dev), rstd.to(dev)
+    g, stats = ops.conv2d_dgrad_bn(dy.to(dev), wt.to(dev), k, s, p, (H, W), None if add is None else add.to(dev).clone(), ybf.to(dev),
+                                   xb.to(dev), m, r)
+    check(g, gref, "dgrad_bn.g")
+    sums = stat_sums(stats, Ci)
+    check(sums[0], s1, "dgrad_bn.sum_g", 1e-2, 6e-3)
+    check(sums[1], s2, "dgrad_bn.sum_g_xhat", 1e-2, 6e-3)
+    coef = torch.empty(3 * Ci, device=dev)
+    dg = torch.zeros(Ci, device=dev); db = torch.zeros(Ci, device=dev)
+    dxb = ops.bn_bwd_from_stats(g, xb.to(dev), m, r, gamma.to(dev), stats, coef, dg, db)
+    check(dxb, dxb_ref, "dgrad_bn.dx", 2e-2, 8e-3)
+    check(dg, s2, "dgrad_bn.dgamma", 1e-2, 6e-3)
+    check(db, s1, "dgrad_bn.dbeta", 1e-2, 6e-3)
+    # the separate passes on the same inputs: same masked gradient bit for bit, same BatchNorm input gradient up to summation order
+    do = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), k, s, p, (H, W), addend=None if add is None else add.to(dev).clone())
+    dg2 = torch.zeros(Ci, device=dev); db2 = torch.zeros(Ci, device=dev)
+    dxb2, dres2 = ops.bn_act_bwd(do, ybf.to(dev), xb.to(dev), m, r, gamma.to(dev), coef, dg2, db2, 1, True)
+    if s == 1 and Ci == 64 or ops.conv_plan(1, N, H, W, Ci, k, s, p).bm == 128:
+        assert torch.equal(g, dres2), "masked gradient differs from the separate pass"
+    else:       # few 64x64 tiles: the plain launch splits K inside the workgroup (another summation order), the fused one does not
+        check(g, dres2.float().cpu(), "dgrad_bn.g vs separate passes", 1e-2, 3e-3)
+    check(dxb, dxb2.float().cpu(), "dgrad_bn.dx vs separate passes", 1e-2, 3e-3)
+    check(dg, dg2.cpu(), "dgrad_bn.dgamma vs separate passes", 1e-3, 1e-3)
+    # reproducible
+    g3, stats3 = ops.conv2d_dgrad_bn(dy.to(dev), wt.to(dev), k, s, p, (H, W), None if add is None else add.to(dev).clone(), ybf.to(dev),
+                                     xb.to(dev), m, r)
+    assert torch.equal(g3, g) and torch.equal(stat_sums(stats3, Ci), sums)
+
+
 @pytest.mark.parametrize("Hc,Wc", [(12, 12), (11, 9), (44, 44)])
 def test_stem_bn_gelu_pool(dev, Hc, Wc):
     from syncvsr_amd import ops
