@@ -574,6 +574,70 @@ __global__ __launch_bounds__(256) void k_stem_bwd_lds(const bf16_t* __restrict__
     if (!APPLY) reduce_to_row(sred, s1, s2, cv, C, slots);
 }
 
+
+// Reduce pass of the stem backward in GATHER form (C = 64).  sum g and sum g*xhat only need g at the window WINNERS: per pooled output
+// and channel, g = dpool * act'(bn(x[winner])), four times fewer activation-derivative evaluations than the element-centric pass
+// above (which evaluates it for every conv element although ~3/4 of them win no window) and no window-membership compares — that
+// pass was VALU-bound at 1.7 TB/s.  A workgroup owns STEM_GP pooled rows of one frame: the 2*STEM_GP+1 conv rows under them are
+// copied to LDS by DMA (16-byte pieces XOR-swizzled by pixel pair so that the per-channel 2-byte reads of lanes with equal channel
+// group spread over the banks), then every thread walks pooled 8-channel vectors and reads its eight winners.
+#define STEM_GP 4
+__device__ unsigned g_stem_zero_page[64];
+template <int ACT>
+__global__ __launch_bounds__(256) void k_stem_bwd_reduce_gather(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ amax,
+                                                                const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ slots, int Hc, int Wc,
+                                                                int Hp, int Wp) {
+    constexpr int C = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_stem[];
+    bf16_t* sX = reinterpret_cast<bf16_t*>(smem_stem);            // [2*STEM_GP+1][Wc] pixels x 8 pieces of 8 channels, piece index swizzled
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.y, p0 = blockIdx.x * STEM_GP, h_lo = 2 * p0 - 1;
+    const int npix = (2 * STEM_GP + 1) * Wc, total = npix * 8;
+    for (int e0 = 0; e0 < total; e0 += 256) {
+        const int e = e0 + tid, q = e >> 3, slot = e & 7;
+        const int r = q / Wc, h = h_lo + r;
+        const bf16_t* src = (e < total && h >= 0 && h < Hc)
+                                ? x + (((long)n * Hc + h) * Wc + (q - r * Wc)) * C + ((slot ^ ((q >> 1) & 7)) << 3)
+                                : reinterpret_cast<const bf16_t*>(g_stem_zero_page) + slot * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sX + (size_t)(e0 + wave * 64) * 8), 16, 0, 0);
+    }
+    const int c8 = tid & 7, c0 = c8 * 8;
+    float mu[8], rs[8], ga[8], be[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k]; ga[k] = gamma[c0 + k]; be[k] = beta[c0 + k]; s1[k] = 0.f; s2[k] = 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int pcv = Wp * 8;
+    for (int v = tid; v < STEM_GP * pcv; v += 256) {           // 256 % 8 == 0: a thread keeps its channel group
+        const int pr = v / pcv, pw = (v - pr * pcv) >> 3, ph = p0 + pr;
+        if (ph >= Hp) break;
+        const long o = (((long)n * Hp + ph) * Wp + pw) * C + c0;
+        float d[8];
+        unpack8(*reinterpret_cast<const u32x4*>(dpool + o), d);
+        const uint2 am = *reinterpret_cast<const uint2*>(amax + o);
+        const int qbase = (2 * pr) * Wc + 2 * pw - 1;          // tile-local pixel of window position (0,0): row 2*ph-1 - h_lo = 2*pr
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = (int)(((k < 4 ? am.x : am.y) >> (8 * (k & 3))) & 0xffu);
+            const int i = (idx * 11) >> 5, j = idx - 3 * i;
+            const int q = qbase + i * Wc + j;
+            const float xv = bf2f(sX[q * C + (((c8 ^ ((q >> 1) & 7))) << 3) + k]);
+            const float xh = (xv - mu[k]) * rs[k];
+            const float z = ga[k] * xh + be[k];
+            const float g = d[k] * (ACT == 2 ? swish_grad(z) : gelu_erf_grad(z));
+            s1[k] += g;
+            s2[k] += g * xh;
+        }
+    }
+    __syncthreads();                                              // the tile is dead: its first 16 KiB become the reduction buffer
+    reduce_to_row(reinterpret_cast<float*>(smem_stem), s1, s2, 8, C, slots);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // global spatial mean  [N][HW][C] -> [N][C]  and its backward
 // ---------------------------------------------------------------------------------------------------------
@@ -752,12 +816,18 @@ int svsr_stem_bn_act_pool_fwd(const void* x, void* y, void* amax, const float* m
 }
 
 static inline bool stem_bwd_uses_lds(int Wp, int C) { return stem_lds_bwd() && (size_t)(STEM_BR / 2 + 1) * Wp * C * 3 <= 60 * 1024; }
+// gather-form reduce pass (k_stem_bwd_reduce_gather): tuning value 2, 64 channels, tile of 2*STEM_GP+1 conv rows within 64 KiB
+static inline size_t stem_gather_lds(int Wc) { const size_t t = (size_t)(((2 * STEM_GP + 1) * Wc * 8 + 255) / 256 * 256) * 16; return t > 16384 ? t : 16384; }
+static inline bool stem_bwd_gathers(int Wc, int Wp, int C) {
+    return svsr_tune_get(SVSR_TUNE_STEM_LDS_BWD) >= 2 && C == 64 && stem_bwd_uses_lds(Wp, C) && stem_gather_lds(Wc) <= 64 * 1024;
+}
 
 /* rows of [2][C] partials svsr_stem_bn_act_pool_bwd needs in its workspace for this shape */
 int svsr_stem_bn_act_pool_bwd_rows(int N, int Hc, int Wc, int C) {
     StemRowIter it;
     if (!chan_ok(C) || !stem_iter(it, C, Wc, Hc) || N < 1) return 0;
-    const int Wp = (Wc - 1) / 2 + 1;
+    const int Wp = (Wc - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1;
+    if (stem_bwd_gathers(Wc, Wp, C)) return N * ((Hp + STEM_GP - 1) / STEM_GP);
     return N * (stem_bwd_uses_lds(Wp, C) ? (Hc + STEM_BR - 1) / STEM_BR : (Hc + it.rpb - 1) / it.rpb);
 }
 
@@ -773,7 +843,17 @@ int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x
         const dim3 g2((Hc + STEM_BR - 1) / STEM_BR, N);
 #define SVSR_STEM_BWD(A, AP) hipLaunchKernelGGL((k_stem_bwd_lds<A, AP>), g2, dim3(256), lds_b, stream, (const bf16_t*)dpool, (const unsigned char*)amax, \
                        (const bf16_t*)x, mean, rstd, gamma, beta, coef, (bf16_t*)dx, slots, Hc, Wc, Hp, Wp, C)
-        if (act == SVSR_ACT_SWISH) SVSR_STEM_BWD(2, false); else SVSR_STEM_BWD(1, false);
+        if (stem_bwd_gathers(Wc, Wp, C)) {
+            if (Hp != (Hc - 1) / 2 + 1) return SVSR_ERR_ARG;
+            const dim3 gg((Hp + STEM_GP - 1) / STEM_GP, N);
+            const size_t lds_g = stem_gather_lds(Wc);
+            if (act == SVSR_ACT_SWISH)
+                hipLaunchKernelGGL(k_stem_bwd_reduce_gather<2>, gg, dim3(256), lds_g, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
+                                   (const bf16_t*)x, mean, rstd, gamma, beta, slots, Hc, Wc, Hp, Wp);
+            else
+                hipLaunchKernelGGL(k_stem_bwd_reduce_gather<1>, gg, dim3(256), lds_g, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
+                                   (const bf16_t*)x, mean, rstd, gamma, beta, slots, Hc, Wc, Hp, Wp);
+        } else if (act == SVSR_ACT_SWISH) SVSR_STEM_BWD(2, false); else SVSR_STEM_BWD(1, false);
         hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
                            dgamma, dbeta, coef);
         if (act == SVSR_ACT_SWISH) SVSR_STEM_BWD(2, true); else SVSR_STEM_BWD(1, true);

@@ -22,7 +22,7 @@ static int g_tune[SVSR_TUNE_N] = {
     /* W3_BLOCKS    */ 512,    // target workgroups of svsr_conv3x3_wgrad: one round at 2 per CU (swept 192..768 with slab epilogues: 110 / 92 / 81 / 74 / 98 us)
     /* LN_RPB       */ 16,     // rows per workgroup of svsr_add_ln_bwd
     /* STEM_LDS_FWD */ 0,      // LDS-tiled stem BN+act+pool forward (measured slower)
-    /* STEM_LDS_BWD */ 1,      // LDS-tiled stem BN+act+pool backward (measured faster)
+    /* STEM_LDS_BWD */ 2,      // stem BN+act+pool backward: 0 plain, 1 LDS-tiled passes, 2 LDS-tiled apply pass + gather-form reduce pass (fastest)
     /* IGEMM_LDS_PAD */ 0,     // extra dynamic LDS bytes per svsr_igemm_fwd workgroup (occupancy experiments: fewer co-resident blocks per CU)
     /* IGEMM_BN64_BELOW */ 300, // multi-tap convolutions with fewer 128x128 tiles than this use 128x64 tiles (three workgroups per CU)
     /* WG_SHORT_K */ 16,       // svsr_igemm_wgrad: contractions of at most this many 64-row chunks use 64-wide tiles and no K split when that fills half the chip
