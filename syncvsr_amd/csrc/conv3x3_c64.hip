@@ -34,6 +34,8 @@ struct Conv64Args {
     const bf16_t* bnb_x;
     const float* bnb_mean;
     const float* bnb_rstd;
+    const float* bnb_gamma;     // bnb_y == nullptr: mask recomputed as bn(x) > 0 (forward's own expression), y not read
+    const float* bnb_beta;
 };
 
 __device__ unsigned g_c64_zero_page[64];
@@ -92,10 +94,16 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
 #pragma unroll
     for (int k = 0; k < 8; ++k) { st_s[k] = 0.f; st_q[k] = 0.f; }
     const bool bnb = p.bnb_x != nullptr;
-    float mu[8], rs[8];
-    if (bnb) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { mu[k] = p.bnb_mean[slot * 8 + k]; rs[k] = p.bnb_rstd[slot * 8 + k]; }
+    const bool from_x = p.bnb_y == nullptr;
+    // per-channel constants of the fused BatchNorm backward live in LDS, not in registers: the MFMA loop below already uses ~240 VGPRs
+    // and 32 more, live across the persistent loop, spilled to scratch (90 instead of 74 us per launch)
+    float* sC = reinterpret_cast<float*>(sPix + 2 * C64_CH);        // [4][64]: mean, rstd, gamma*rstd, beta - mean*gamma*rstd
+    if (bnb && tid < 64) {
+        const float m = p.bnb_mean[tid], r = p.bnb_rstd[tid];
+        sC[tid] = m; sC[64 + tid] = r;
+        const float c = from_x ? p.bnb_gamma[tid] * r : 0.f;
+        sC[128 + tid] = c;
+        sC[192 + tid] = from_x ? __builtin_fmaf(-m, c, p.bnb_beta[tid]) : 0.f;
     }
     int c = blockIdx.x, buf = 0;
     if (c < p.total_chunks) stage(c, 0);
@@ -167,16 +175,29 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const long o = (long)(pixv[i] >= 0 ? pixv[i] : 0) * 64 + slot * 8;
-                y8[i] = *reinterpret_cast<const u32x4*>(p.bnb_y + o);
                 x8[i] = *reinterpret_cast<const u32x4*>(p.bnb_x + o);
+                if (!from_x) y8[i] = *reinterpret_cast<const u32x4*>(p.bnb_y + o);
+            }
+            float mu[8], rs[8], sc[8], sh[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 m4 = *reinterpret_cast<const f32x4*>(sC + slot * 8 + 4 * h), r4 = *reinterpret_cast<const f32x4*>(sC + 64 + slot * 8 + 4 * h);
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(sC + 128 + slot * 8 + 4 * h), h4 = *reinterpret_cast<const f32x4*>(sC + 192 + slot * 8 + 4 * h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { mu[4 * h + k] = m4[k]; rs[4 * h + k] = r4[k]; sc[4 * h + k] = c4[k]; sh[4 * h + k] = h4[k]; }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (pixv[i] < 0) continue;
                 float a[8], yv[8], xv[8];
                 unpack8(piece[i], a);
-                unpack8(y8[i], yv);
                 unpack8(x8[i], xv);
+                if (from_x) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) yv[k] = __builtin_fmaf(xv[k], sc[k], sh[k]);
+                } else {
+                    unpack8(y8[i], yv);
+                }
                 if (p.addend != nullptr) {
                     float b[8];
                     unpack8(add[i], b);
@@ -241,11 +262,12 @@ extern "C" int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W) {
 
 static int c64_run(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
                    const int* dy, const int* dx, const int* tw, const void* bnb_y, const void* bnb_x, const float* bnb_mean,
-                   const float* bnb_rstd, hipStream_t stream) {
+                   const float* bnb_rstd, const float* bnb_gamma, const float* bnb_beta, hipStream_t stream) {
     if (W + 2 > (C64_XR - C64_CH) / 2 - 1 || H < 1 || W < 1 || Nimg < 1) return SVSR_ERR_ARG;
     Conv64Args a;
     a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = (bf16_t*)out; a.addend = (const bf16_t*)addend; a.stats = stats;
     a.bnb_y = (const bf16_t*)bnb_y; a.bnb_x = (const bf16_t*)bnb_x; a.bnb_mean = bnb_mean; a.bnb_rstd = bnb_rstd;
+    a.bnb_gamma = bnb_gamma; a.bnb_beta = bnb_beta;
     a.Nimg = Nimg; a.H = H; a.W = W; a.WP = W + 2; a.Q = (H + 2) * (W + 2);
     const long qtot = (long)Nimg * a.Q;
     if (qtot >= (1L << 24) || (long)Nimg * H * W >= (1L << 25)) return SVSR_ERR_ARG;
@@ -253,7 +275,7 @@ static int c64_run(const void* in, const void* wt, void* out, const void* addend
     a.total_chunks = (a.Qtot + C64_CH - 1) / C64_CH;
     a.inv_q = 1.0f / (float)a.Q; a.inv_wp = 1.0f / (float)a.WP;
     for (int i = 0; i < 9; ++i) { a.dy[i] = dy[i]; a.dx[i] = dx[i]; a.tw[i] = tw[i]; }
-    const size_t lds = (size_t)(C64_LDS_W + 2 * C64_LDS_A) * sizeof(bf16_t) + 2 * C64_CH * sizeof(int);
+    const size_t lds = (size_t)(C64_LDS_W + 2 * C64_LDS_A) * sizeof(bf16_t) + 2 * C64_CH * sizeof(int) + 4 * 64 * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -266,16 +288,18 @@ static int c64_run(const void* in, const void* wt, void* out, const void* addend
 
 extern "C" int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
                                 const int* dy, const int* dx, const int* tw, hipStream_t stream) {
-    return c64_run(in, wt, out, addend, stats, Nimg, H, W, dy, dx, tw, nullptr, nullptr, nullptr, nullptr, stream);
+    return c64_run(in, wt, out, addend, stats, Nimg, H, W, dy, dx, tw, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 /* svsr_conv3x3_c64_dgrad_bn: the data gradient of a 64 -> 64 convolution whose result is the gradient of a BatchNorm + ReLU output
  * y = relu(bn(x) [+ residual]) (reference tcn/models/resnet.py:59-72 backward).  Stores g = (y > 0 ? result [+ addend] : 0) and writes
  * per workgroup the column sums of g and g * (x - mean) * rstd into stats[svsr_conv3x3_c64_stat_rows][2][64]: the first pass of the
- * BatchNorm backward, taken while the tile is in registers (svsr_bn_bwd_from_stats finishes it).  addend may alias out. */
+ * BatchNorm backward, taken while the tile is in registers (svsr_bn_bwd_from_stats finishes it).  addend may alias out.
+ * y == nullptr (output without residual branch): mask = bn(x) > 0 recomputed with gamma / beta, y is not read. */
 extern "C" int svsr_conv3x3_c64_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
                                          const int* dy, const int* dx, const int* tw, const void* y, const void* x, const float* mean,
-                                         const float* rstd, hipStream_t stream) {
-    if (y == nullptr || x == nullptr || mean == nullptr || rstd == nullptr || stats == nullptr) return SVSR_ERR_ARG;
-    return c64_run(in, wt, out, addend, stats, Nimg, H, W, dy, dx, tw, y, x, mean, rstd, stream);
+                                         const float* rstd, const float* gamma, const float* beta, hipStream_t stream) {
+    if (x == nullptr || mean == nullptr || rstd == nullptr || stats == nullptr) return SVSR_ERR_ARG;
+    if (y == nullptr && (gamma == nullptr || beta == nullptr)) return SVSR_ERR_ARG;
+    return c64_run(in, wt, out, addend, stats, Nimg, H, W, dy, dx, tw, y, x, mean, rstd, gamma, beta, stream);
 }

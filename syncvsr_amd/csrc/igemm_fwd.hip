@@ -57,6 +57,8 @@ struct IgemmFwdArgs {
     const bf16_t* bnb_x;
     const float* bnb_mean;
     const float* bnb_rstd;
+    const float* bnb_gamma;    // with bnb_y == nullptr (no residual branch): the mask is recomputed as bn(x) > 0 with the forward's own
+    const float* bnb_beta;     // expression (norm_act.hip k_bn_act_fwd) instead of being read from y
 };
 
 __device__ unsigned g_zero_page[64];     // 256 zero bytes: DMA source for rows outside the grid
@@ -124,38 +126,44 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
     for (int k = 0; k < 8; ++k) { bs1[k] = 0.f; bs2[k] = 0.f; }
     if (bnb) {
         // data-gradient launch feeding a BatchNorm+ReLU backward (host: vec_pitch, Co % 8 == 0, no bias / activation / dropout, bf16 out):
-        // rows in batches of BROWS, operands of a batch requested together (the registers of the full-tile batch below would not fit twice)
-        constexpr int BROWS = ITERS >= 8 ? 4 : (ITERS >= 2 ? 2 : 1);
+        // the global operands (y, x, addend pieces) of ALL rows are requested before the first is used — one round trip per tile —
+        // while the staged accumulators are read from LDS row by row (the full-tile batch of the path below plus these would not fit)
         float mu[8], rs[8];
         if (active) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) { mu[k] = p.bnb_mean[n + k]; rs[k] = p.bnb_rstd[n + k]; }
-        }
-        for (int i0 = 0; i0 < (active ? ITERS : 0); i0 += BROWS) {
-            long offs[BROWS];
-            f32x4 lo[BROWS], hi[BROWS];
-            u32x4 add8[BROWS], y8[BROWS], x8[BROWS];
+            const bool from_x = p.bnb_y == nullptr;
+            float sc[8], sh[8];
+            if (from_x) {
 #pragma unroll
-            for (int i = 0; i < BROWS; ++i) {
-                const int r = rbase + RSTEP * (i0 + i);
-                offs[i] = sRow[r];
-                lo[i] = *reinterpret_cast<const f32x4*>(sOut + r * BN + c8 * 8);
-                hi[i] = *reinterpret_cast<const f32x4*>(sOut + r * BN + c8 * 8 + 4);
+                for (int k = 0; k < 8; ++k) { sc[k] = p.bnb_gamma[n + k] * rs[k]; sh[k] = __builtin_fmaf(-mu[k], sc[k], p.bnb_beta[n + k]); }
             }
+            long offs[ITERS];
+            u32x4 add8[ITERS], y8[ITERS], x8[ITERS];
 #pragma unroll
-            for (int i = 0; i < BROWS; ++i) {
+            for (int i = 0; i < ITERS; ++i) offs[i] = sRow[rbase + RSTEP * i];
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) {
                 const long o = (offs[i] >= 0 ? offs[i] : 0) + n;
-                y8[i] = *reinterpret_cast<const u32x4*>(p.bnb_y + o);
                 x8[i] = *reinterpret_cast<const u32x4*>(p.bnb_x + o);
+                if (!from_x) y8[i] = *reinterpret_cast<const u32x4*>(p.bnb_y + o);
                 if (p.addend != nullptr) add8[i] = *reinterpret_cast<const u32x4*>(p.addend + o);
             }
 #pragma unroll
-            for (int i = 0; i < BROWS; ++i) {
+            for (int i = 0; i < ITERS; ++i) {
                 if (offs[i] < 0) continue;
-                float v[8] = {lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2], hi[i][3]};
+                const int r = rbase + RSTEP * i;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(sOut + r * BN + c8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(sOut + r * BN + c8 * 8 + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 float yv[8], xv[8];
-                unpack8(y8[i], yv);
                 unpack8(x8[i], xv);
+                if (from_x) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) yv[k] = __builtin_fmaf(xv[k], sc[k], sh[k]);
+                } else {
+                    unpack8(y8[i], yv);
+                }
                 if (p.addend != nullptr) {
                     float a8[8];
                     unpack8(add8[i], a8);
@@ -854,7 +862,7 @@ extern "C" int svsr_conv3x3_res(const void* in, const void* wt, void* out, const
     a.stats = stats; a.plan = nullptr; a.Nimg = Nimg; a.in_pix = H * W; a.Ci = Ci; a.in_pitch = Ci; a.Co = Co; a.out_pix = H * W; a.out_pitch = Co;
     a.wt_taps = 9; a.act = 0; a.out_f32 = 0; a.alpha = 1.f; a.drop = svsr_make_drop(nullptr, 0, 0.f);
     a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED);
-    a.bnb_y = nullptr; a.bnb_x = nullptr; a.bnb_mean = nullptr; a.bnb_rstd = nullptr;
+    a.bnb_y = nullptr; a.bnb_x = nullptr; a.bnb_mean = nullptr; a.bnb_rstd = nullptr; a.bnb_gamma = nullptr; a.bnb_beta = nullptr;
     q.H = H; q.W = W; q.M = (int)M;
     for (int t = 0; t < 9; ++t) {
         if (dy[t] < -1 || dy[t] > 1 || dx[t] < -1 || dx[t] > 1 || tw[t] < 0 || tw[t] > 8) return SVSR_ERR_ARG;
@@ -888,7 +896,7 @@ static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pr
                          float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co,
                          int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed,
                          unsigned drop_site, float drop_p, const void* bnb_y, const void* bnb_x, const float* bnb_mean,
-                         const float* bnb_rstd, hipStream_t stream) {
+                         const float* bnb_rstd, const float* bnb_gamma, const float* bnb_beta, hipStream_t stream) {
     if (plan_dev == nullptr || meta == nullptr || Ci % 64 != 0 || Ci <= 0 || Co <= 0 || in_pitch % 8 != 0 || Nimg <= 0 || wt_taps < 1)
         return SVSR_ERR_ARG;
     if (act != 0 && (addend != nullptr || alpha != 1.f)) return SVSR_ERR_ARG;     // the activation is applied before alpha / addend
@@ -900,6 +908,7 @@ static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pr
     a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
     a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED);
     a.bnb_y = (const bf16_t*)bnb_y; a.bnb_x = (const bf16_t*)bnb_x; a.bnb_mean = bnb_mean; a.bnb_rstd = bnb_rstd;
+    a.bnb_gamma = bnb_gamma; a.bnb_beta = bnb_beta;
     const int bm = meta[0], bn = meta[1], ns = meta[2], gx = meta[3], gy = (Co + bn - 1) / bn;
     if (gx < 1) return SVSR_ERR_ARG;
     // few tiles, long contraction: split K inside the workgroup (see k_igemm_fwd_glds, KG = 2)
@@ -921,19 +930,21 @@ extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* o
                               int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed,
                               unsigned drop_site, float drop_p, hipStream_t stream) {
     return igemm_fwd_run(in, wt, out, out_pre, bias, addend, stats, plan_dev, meta, Nimg, in_pix, Ci, in_pitch, Co, out_pix, out_pitch,
-                         wt_taps, act, out_f32, alpha, drop_seed, drop_site, drop_p, nullptr, nullptr, nullptr, nullptr, stream);
+                         wt_taps, act, out_f32, alpha, drop_seed, drop_site, drop_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 /* svsr_igemm_dgrad_bn: a data-gradient plan (every target pixel visited exactly once: svsr_conv_plan mode 1) whose result dL/dy is the
  * gradient of a BatchNorm + ReLU output y = relu(bn(x) [+ residual]) with the geometry of `out` (reference tcn/models/resnet.py:59-72
  * backward).  The launch stores g = (y > 0 ? dL/dy [+ addend] : 0) instead of dL/dy and writes, per row tile, the column sums of g and of
  * g * (x - mean) * rstd into stats[meta[3]][2][Co] — the first pass of the BatchNorm backward, taken while the tile is in registers;
- * svsr_bn_bwd_from_stats finishes it.  addend may alias out. */
+ * svsr_bn_bwd_from_stats finishes it.  addend may alias out.  y == nullptr (only for an output WITHOUT residual branch): the mask is
+ * recomputed from x as bn(x) > 0 with gamma / beta, in the forward pass's own arithmetic, and y is not read. */
 extern "C" int svsr_igemm_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, const int* plan_dev,
                                    const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch,
-                                   int wt_taps, const void* y, const void* x, const float* mean, const float* rstd, hipStream_t stream) {
-    if (y == nullptr || x == nullptr || mean == nullptr || rstd == nullptr || stats == nullptr || Co % 8 != 0 || out_pitch % 8 != 0)
-        return SVSR_ERR_ARG;
+                                   int wt_taps, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, hipStream_t stream) {
+    if (x == nullptr || mean == nullptr || rstd == nullptr || stats == nullptr || Co % 8 != 0 || out_pitch % 8 != 0) return SVSR_ERR_ARG;
+    if (y == nullptr && (gamma == nullptr || beta == nullptr)) return SVSR_ERR_ARG;
     return igemm_fwd_run(in, wt, out, nullptr, nullptr, addend, stats, plan_dev, meta, Nimg, in_pix, Ci, in_pitch, Co, out_pix, out_pitch,
-                         wt_taps, 0, 0, 1.0f, nullptr, 0, 0.f, y, x, mean, rstd, stream);
+                         wt_taps, 0, 0, 1.0f, nullptr, 0, 0.f, y, x, mean, rstd, gamma, beta, stream);
 }

@@ -87,13 +87,14 @@ __global__ __launch_bounds__(256) void k_bn_act_fwd(const bf16_t* __restrict__ x
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         sc[k] = gamma[c0 + k] * rstd[c0 + k];
-        sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k];
+        sh[k] = __builtin_fmaf(-mean[c0 + k], sc[k], beta[c0 + k]);
     }
     for (; idx < nvec; idx += stride) {
         float f[8];
         unpack8(reinterpret_cast<const u32x4*>(x)[idx], f);
+        // (explicit fused multiply-adds: the data-gradient epilogues that recompute the ReLU mask as bn(x) > 0 use the same two)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) f[k] = f[k] * sc[k] + sh[k];
+        for (int k = 0; k < 8; ++k) f[k] = __builtin_fmaf(f[k], sc[k], sh[k]);
         if (res != nullptr) {
             float r[8];
             unpack8(reinterpret_cast<const u32x4*>(res)[idx], r);

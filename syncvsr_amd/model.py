@@ -534,7 +534,9 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
         ws1 = st.bn[t1["bn"]]
         w2t = st.t16(f"{prefix}.conv2.weight").view(planes, 3, 3, planes)
         if fused:
-            g1, st1 = ops.conv2d_dgrad_bn(dc2, w2t, 3, 1, 1, t2["x"].shape[1:3], None, t1["y"], t1["c"], t1["mean"], t1["rstd"])
+            # bn1 has no residual branch: the mask is recomputed from its input (y is not read)
+            g1, st1 = ops.conv2d_dgrad_bn(dc2, w2t, 3, 1, 1, t2["x"].shape[1:3], None, None, t1["c"], t1["mean"], t1["rstd"],
+                                          st.p32(f"{t1['bn']}.weight"), st.p32(f"{t1['bn']}.bias"))
             dc1 = ops.bn_bwd_from_stats(g1, t1["c"], t1["mean"], t1["rstd"], st.p32(f"{t1['bn']}.weight"), st1, ws1["coef"],
                                         st.g32(f"{t1['bn']}.weight"), st.g32(f"{t1['bn']}.bias"))
         else:

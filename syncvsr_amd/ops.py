@@ -347,15 +347,19 @@ BN_BWD_FUSED = True    # ReLU trunk: first pass of the BatchNorm backward inside
 
 
 def conv2d_dgrad_bn(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad: int, in_hw: tuple[int, int],
-                    addend: Optional[torch.Tensor], y: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor):
+                    addend: Optional[torch.Tensor], y: Optional[torch.Tensor], x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
+                    gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None):
     """conv2d_dgrad whose result is the gradient of y = relu(bn(x) [+ residual]) (y, x shaped like the result): the launch stores
     g = (y > 0) * (dgrad + addend) instead and takes the first pass of that BatchNorm's backward in its epilogue.
+    y=None (no residual branch): the mask is recomputed from x, gamma, beta and y is not read.
     -> (g, (stats, rows)) for bn_bwd_from_stats.  In place when addend is given."""
     N, Ho, Wo, Co = dy.shape
     Ci = w16t.shape[0]
     H, W = in_hw
-    if y.shape != (N, H, W, Ci) or x.shape != y.shape or not (y.is_contiguous() and x.is_contiguous()):
+    if x.shape != (N, H, W, Ci) or not x.is_contiguous() or (y is not None and (y.shape != x.shape or not y.is_contiguous())):
         raise ValueError("conv2d_dgrad_bn: y / x must be contiguous tensors with the geometry of the result")
+    if y is None and (gamma is None or beta is None):
+        raise ValueError("conv2d_dgrad_bn: y=None needs gamma and beta")
     g = torch.empty((N, H, W, Ci), dtype=BF16, device=dy.device) if addend is None else addend
     if stride == 1 and _c64_ok(Ci, Co, k, stride, pad, W):
         taps = tuple((pad - kh, pad - kw, kh * k + kw) for kh in range(k) for kw in range(k))
@@ -363,12 +367,12 @@ def conv2d_dgrad_bn(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, p
         rows = _query("svsr_conv3x3_c64_stat_rows", N, H, W)[0]
         stats = scratch(rows * 2 * 64)
         _call("svsr_conv3x3_c64_dgrad_bn", _p(dy), _p(w16t), _p(g), _p(addend), _p(stats), N, H, W, _ints(tdy), _ints(tdx), _ints(tw),
-              _p(y), _p(x), _p(mean), _p(rstd), _stream(), label="k_conv3x3_c64", flops=2.0 * N * H * W * 64 * 64 * 9)
+              _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _stream(), label="k_conv3x3_c64", flops=2.0 * N * H * W * 64 * 64 * 9)
         return g, (stats, rows)
     plan = conv_plan(1, N, H, W, Ci, k, stride, pad)        # mode 1: every pixel of the result is visited once
     stats = scratch(plan.tiles * 2 * Ci)
     _call("svsr_igemm_dgrad_bn", _p(dy), _p(w16t), _p(g), _p(addend), _p(stats), plan.words.data_ptr(), plan.meta, N, Ho * Wo, Co, Co, Ci,
-          H * W, Ci, k * k, _p(y), _p(x), _p(mean), _p(rstd), _stream(), label=plan.label, flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
+          H * W, Ci, k * k, _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _stream(), label=plan.label, flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
     return g, (stats, plan.tiles)
 
 

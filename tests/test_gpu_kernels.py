@@ -315,7 +315,11 @@ def test_conv_dgrad_with_bn_backward_epilogue(dev, case):
     gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     yref, mean, var = _bn_ref(xf, gm, bt, None if res is None else res.float(), 1)
     mean, var = mean.detach(), var.detach()
-    ybf = yref.detach().to(BF)
+    # the forward output the backward sees is the HIP forward's (its ReLU mask is what the mask-from-x variant must reproduce bit for bit)
+    y_dev = ops.bn_act_fwd(xb.to(dev), None if res is None else res.to(dev), mean.to(dev), torch.rsqrt(var + 1e-5).to(dev),
+                           gamma.to(dev), beta.to(dev), 1)
+    check(y_dev, yref.detach(), "bn_act_fwd")
+    ybf = y_dev.cpu()
     # reference backward with the mask of the bf16 output the kernels see, and the gradient rounded as the launch stores it
     gref = torch.where(ybf.float() > 0, dout.to(BF).float(), torch.zeros(()))
     rstd = torch.rsqrt(var + 1e-5)
@@ -347,6 +351,9 @@ def test_conv_dgrad_with_bn_backward_epilogue(dev, case):
         check(g, dres2.float().cpu(), "dgrad_bn.g vs separate passes", 1e-2, 3e-3)
     check(dxb, dxb2.float().cpu(), "dgrad_bn.dx vs separate passes", 1e-2, 3e-3)
     check(dg, dg2.cpu(), "dgrad_bn.dgamma vs separate passes", 1e-3, 1e-3)
+    if res is None:     # no residual branch: the mask recomputed from x equals the mask read from y
+        gx, statsx = ops.conv2d_dgrad_bn(dy.to(dev), wt.to(dev), k, s, p, (H, W), None, None, xb.to(dev), m, r, gamma.to(dev), beta.to(dev))
+        assert torch.equal(gx, g) and torch.equal(stat_sums(statsx, Ci), sums), "mask recomputed from x differs from the stored one"
     # reproducible
     g3, stats3 = ops.conv2d_dgrad_bn(dy.to(dev), wt.to(dev), k, s, p, (H, W), None if add is None else add.to(dev).clone(), ybf.to(dev),
                                      xb.to(dev), m, r)
