@@ -367,12 +367,12 @@ def conv2d_dgrad_bn(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, p
         rows = _query("svsr_conv3x3_c64_stat_rows", N, H, W)[0]
         stats = scratch(rows * 2 * 64)
         _call("svsr_conv3x3_c64_dgrad_bn", _p(dy), _p(w16t), _p(g), _p(addend), _p(stats), N, H, W, _ints(tdy), _ints(tdx), _ints(tw),
-              _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _stream(), label="k_conv3x3_c64", flops=2.0 * N * H * W * 64 * 64 * 9)
+              _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _stream(), label="k_conv3x3_c64+bn", flops=2.0 * N * H * W * 64 * 64 * 9)
         return g, (stats, rows)
     plan = conv_plan(1, N, H, W, Ci, k, stride, pad)        # mode 1: every pixel of the result is visited once
     stats = scratch(plan.tiles * 2 * Ci)
     _call("svsr_igemm_dgrad_bn", _p(dy), _p(w16t), _p(g), _p(addend), _p(stats), plan.words.data_ptr(), plan.meta, N, Ho * Wo, Co, Co, Ci,
-          H * W, Ci, k * k, _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _stream(), label=plan.label, flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
+          H * W, Ci, k * k, _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _stream(), label=plan.label + "+bn", flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
     return g, (stats, plan.tiles)
 
 

@@ -223,3 +223,70 @@ def test_stem_at_benchmark_batch(dev):
     dw2 = torch.zeros_like(dw)
     ops.stem_conv_wgrad(vid.to(dev), dy.to(dev), dw2, use_tr=True)
     assert torch.equal(dw, dw2), "stem wgrad is not reproducible"
+
+
+# the data-gradient launches of the B = 32 step that carry the first pass of a BatchNorm backward in their epilogue (ReLU trunk):
+# every 3x3 data gradient; the expected instantiation is the one bench.py lists as "<kernel>+bn"
+EXPECT_DGRAD_BN = {
+    "layer1.conv": "k_conv3x3_c64",
+    "layer2.conv": "k_igemm_fwd_glds<128,128,2>",
+    "layer3.conv": "k_igemm_fwd_glds<128,128,2>",
+    "layer3.0.conv1": "k_igemm_fwd_glds<128,128,2>",
+    "layer4.0.conv1": "k_igemm_fwd_glds<128,128,2>",
+    "layer4.conv": "k_igemm_fwd_glds<128,64,2>",
+}
+
+
+@pytest.mark.parametrize("name", [n for n in TRUNK if TRUNK[n][4] == 3])
+@pytest.mark.parametrize("residual", [False, True])
+def test_trunk_dgrad_with_bn_backward_epilogue_at_928_frames(dev, name, residual):
+    """ops.conv2d_dgrad_bn + bn_bwd_from_stats at the benchmark's shapes == data gradient, then BatchNorm+ReLU backward in fp32."""
+    from syncvsr_amd import ops
+
+    H, W, Ci, Co, k, s, p = TRUNK[name]
+    N = N_FRAMES
+    Ho, Wo = ops.conv_out_size(H, k, s, p), ops.conv_out_size(W, k, s, p)
+    dy = rnd((N, Ho, Wo, Co), 3)
+    w2 = rnd((Co, k, k, Ci), 4, 1.0 / math.sqrt(k * k * Co))
+    wt = w2.permute(3, 1, 2, 0).contiguous()
+    xs = torch.zeros(N, Ci, H, W, requires_grad=True)
+    F.conv2d(xs, w2.float().permute(0, 3, 1, 2), stride=s, padding=p).backward(nchw(dy.float()))
+    add = rnd((N, H, W, Ci), 5) if residual else None
+    dout = nhwc(xs.grad) + (add.float() if residual else 0.0)
+    xb = rnd((N, H, W, Ci), 6, 2.0) + 0.3
+    res = rnd((N, H, W, Ci), 7) if residual else None
+    g_ = torch.Generator().manual_seed(8)
+    gamma = 1 + 0.2 * torch.randn(Ci, generator=g_)
+    beta = 0.2 * torch.randn(Ci, generator=g_)
+    xf = xb.float()
+    mean, var = xf.mean((0, 1, 2)), xf.var((0, 1, 2), unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    m, r = mean.to(dev), rstd.to(dev)
+    y_dev = ops.bn_act_fwd(xb.to(dev), None if res is None else res.to(dev), m, r, gamma.to(dev), beta.to(dev), 1)
+    mask = y_dev.float().cpu() > 0
+    gref = torch.where(mask, dout.to(BF).float(), torch.zeros(()))
+    xhat = (xf - mean) * rstd
+    cnt = N * H * W
+    s1, s2 = gref.sum((0, 1, 2)), (gref * xhat).sum((0, 1, 2))
+    dxb_ref = gamma * rstd * (gref - s1 / cnt - xhat * s2 / cnt)
+    # residual outputs read the mask from y; residual-free ones recompute it from x (as the model's backward does)
+    g, stats = ops.conv2d_dgrad_bn(dy.to(dev), wt.to(dev), k, s, p, (H, W), None if add is None else add.to(dev).clone(),
+                                   y_dev if residual else None, xb.to(dev), m, r, gamma.to(dev), beta.to(dev))
+    label = "k_conv3x3_c64" if (s == 1 and ops._c64_ok(Ci, Co, k, s, p, W)) else ops.conv_plan(1, N, H, W, Ci, k, s, p).label
+    _SEEN[f"{name}.dgrad+bn"] = label
+    if name in EXPECT_DGRAD_BN:
+        assert label == EXPECT_DGRAD_BN[name], label
+    check(g, gref, f"{name}.dgrad_bn.g")
+    buf, rows = stats
+    sums = buf[: rows * 2 * Ci].view(rows, 2, Ci).double().sum(0).float().cpu()
+    check(sums[0], s1, f"{name}.dgrad_bn.sum_g", 1e-2, 6e-3)
+    check(sums[1], s2, f"{name}.dgrad_bn.sum_g_xhat", 1e-2, 6e-3)
+    coef = torch.empty(3 * Ci, device=dev)
+    dg = torch.zeros(Ci, device=dev); db = torch.zeros(Ci, device=dev)
+    dxb = ops.bn_bwd_from_stats(g, xb.to(dev), m, r, gamma.to(dev), stats, coef, dg, db)
+    check(dxb, dxb_ref, f"{name}.dgrad_bn.dx", 2e-2, 8e-3)
+    check(dg, s2, f"{name}.dgrad_bn.dgamma", 1e-2, 6e-3)
+    check(db, s1, f"{name}.dgrad_bn.dbeta", 1e-2, 6e-3)
+    g2, stats2 = ops.conv2d_dgrad_bn(dy.to(dev), wt.to(dev), k, s, p, (H, W), None if add is None else add.to(dev).clone(),
+                                     y_dev if residual else None, xb.to(dev), m, r, gamma.to(dev), beta.to(dev))
+    assert torch.equal(g2, g) and torch.equal(stats2[0][: rows * 2 * Ci], buf[: rows * 2 * Ci]), f"{name}: not reproducible"
