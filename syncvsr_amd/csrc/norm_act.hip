@@ -509,16 +509,17 @@ __global__ __launch_bounds__(256) void k_stem_bwd_lds(const bf16_t* __restrict__
     const int pcv = Wp * cv;
     for (int e = threadIdx.x; e < PROWS * pcv; e += 256) {
         const int pr = e / pcv, rem = e - pr * pcv, pw = rem / cv, ph = p_lo + pr;
-        u32x4 d{0u, 0u, 0u, 0u};
-        uint2 m = make_uint2(0xffffffffu, 0xffffffffu);
-        if (ph < Hp) {
-            const long o = (((long)n * Hp + ph) * Wp + pw) * C + c0;
-            d = *reinterpret_cast<const u32x4*>(dpool + o);
-            m = *reinterpret_cast<const uint2*>(amax + o);
-        }
+        // (compiler vector types and no branch: a conditionally assigned u32x4 STRUCT is kept in scratch memory)
+        typedef __attribute__((ext_vector_type(4))) unsigned v4u;
+        typedef __attribute__((ext_vector_type(2))) unsigned v2u;
+        const bool ok = ph < Hp;
+        const long o = ok ? (((long)n * Hp + ph) * Wp + pw) * C + c0 : 0;
+        v4u d = *reinterpret_cast<const v4u*>(dpool + o);
+        v2u m = *reinterpret_cast<const v2u*>(amax + o);
+        if (!ok) { d = v4u{0u, 0u, 0u, 0u}; m = v2u{0xffffffffu, 0xffffffffu}; }
         const int so = (pr * Wp + pw) * C + c0;
-        *reinterpret_cast<u32x4*>(sD + so) = d;
-        *reinterpret_cast<uint2*>(sM + so) = m;
+        *reinterpret_cast<v4u*>(sD + so) = d;
+        *reinterpret_cast<v2u*>(sM + so) = m;
     }
     float mu[8], rs[8], ga[8], be[8], k0[8], k1[8], k2[8], s1[8], s2[8];
 #pragma unroll

@@ -164,6 +164,9 @@ struct StemWgradArgs {
     int use_tr;
 };
 
+typedef __attribute__((ext_vector_type(4))) unsigned v4u;
+__device__ unsigned g_stem_zero[4];     // 16 zero bytes: source of predicated-off tile loads
+
 template <bool USE_TR>
 __device__ __forceinline__ bf16x8 stem_frag_T(const bf16_t* tile, int ch0, int pos0, int lane) {
     bf16x8 f;
@@ -212,7 +215,6 @@ __global__ __launch_bounds__(256) void k_stem_conv_wgrad(const StemWgradArgs p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
     for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
         const int f = tile / p.groups_per_frame, gi = tile - f * p.groups_per_frame;
         const int b = f / p.T, t = f - b * p.T;
@@ -226,10 +228,11 @@ __global__ __launch_bounds__(256) void k_stem_conv_wgrad(const StemWgradArgs p) 
         for (int e = tid; e < SW_RB * p.WoP * 8; e += 256) {
             const int pos = e >> 3, ch = e & 7;
             const int yl = pos / p.WoP, x = pos - yl * p.WoP;
-            u32x4 v = zero4;
-            if (yl < rb && x < p.Wo)
-                v = *reinterpret_cast<const u32x4*>(p.dy + (((long)f * p.Ho + y0 + yl) * p.Wo + x) * STEM_C + ch * 8);
-            *reinterpret_cast<u32x4*>(sDY + pos * SW_DPITCH + ch * 8) = v;
+            // (no branch around the load and a compiler vector type: a conditionally assigned u32x4 STRUCT went through scratch memory)
+            const bool ok = yl < rb && x < p.Wo;
+            const v4u v = *reinterpret_cast<const v4u*>(ok ? p.dy + (((long)f * p.Ho + y0 + yl) * p.Wo + x) * STEM_C + ch * 8
+                                                           : reinterpret_cast<const bf16_t*>(g_stem_zero));
+            *reinterpret_cast<v4u*>(sDY + pos * SW_DPITCH + ch * 8) = v;
         }
         // input rows, de-interleaved: padded column cp = col + 4 -> plane cp&1, index cp>>1
         for (int rr = tid >> 5; rr < 5 * nrows; rr += 8) {
@@ -277,13 +280,12 @@ __global__ __launch_bounds__(256) void k_stem_conv_wgrad(const StemWgradArgs p) 
                     const unsigned* src = reinterpret_cast<const unsigned*>(sIn + (a & ~1));
                     const unsigned sh = (a & 1) * 16;
                     const unsigned d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3], d4 = src[4];
-                    union { bf16x8 v; unsigned u[4]; } fr;
-                    fr.u[0] = __builtin_amdgcn_alignbit(d1, d0, sh);
-                    fr.u[1] = __builtin_amdgcn_alignbit(d2, d1, sh);
-                    fr.u[2] = __builtin_amdgcn_alignbit(d3, d2, sh);
-                    fr.u[3] = __builtin_amdgcn_alignbit(d4, d3, sh);
-                    if (!kvalid[q]) { fr.u[0] = 0; fr.u[1] = 0; fr.u[2] = 0; fr.u[3] = 0; }
-                    fb[q] = fr.v;
+                    u32x4 fr;          // (a plain struct of four registers: a union with an array went through scratch memory)
+                    fr.x = kvalid[q] ? __builtin_amdgcn_alignbit(d1, d0, sh) : 0u;
+                    fr.y = kvalid[q] ? __builtin_amdgcn_alignbit(d2, d1, sh) : 0u;
+                    fr.z = kvalid[q] ? __builtin_amdgcn_alignbit(d3, d2, sh) : 0u;
+                    fr.w = kvalid[q] ? __builtin_amdgcn_alignbit(d4, d3, sh) : 0u;
+                    fb[q] = __builtin_bit_cast(bf16x8, fr);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -292,6 +294,143 @@ __global__ __launch_bounds__(256) void k_stem_conv_wgrad(const StemWgradArgs p) 
                         acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[q], acc[i][q], 0, 0, 0);
             }
         }
+    }
+    // D[row = channel][col = tap] -> this workgroup's slab (plain stores; the slabs are added in a fixed order afterwards)
+    float* dst = p.part + (long)blockIdx.x * (STEM_C * 245);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = (wave * 2 + q) * 32 + (lane & 31);
+        if (k >= 245) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                dst[c * 245 + k] = acc[i][q][r];
+            }
+    }
+}
+
+template <bool USE_TR>
+__global__ __launch_bounds__(256) void k_stem_conv_wgrad_pipe(const StemWgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sDY = reinterpret_cast<bf16_t*>(smem_raw);                 // [SW_RB*WoP][SW_DPITCH]
+    bf16_t* sIn = sDY + SW_RB * p.WoP * SW_DPITCH;                     // [5][2*SW_RB+5][2][PW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nrows = 2 * SW_RB + 5;
+    const int kg = lane >> 5;
+
+    // this lane's two taps (B-fragment columns): k = (wave*2 + q)*32 + (lane&31)
+    int kbase[2];
+    bool kvalid[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = (wave * 2 + q) * 32 + (lane & 31);
+        kvalid[q] = k < 245;
+        const int kk = kvalid[q] ? k : 0;
+        const int kt = kk / 49, kh = (kk % 49) / 7, kw = kk % 7;
+        const int plane = (kw + 1) & 1, off = (kw + 1) >> 1;      // padded column 2x+kw+1 -> plane, index x + off
+        kbase[q] = ((kt * nrows + kh) * 2 + plane) * p.PW + off + kg * 8;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Tile operands travel global -> registers -> LDS, and the registers of the NEXT tile are requested before this tile's MFMA
+    // block: the first version loaded and stored piece by piece (one global round trip per loop iteration, ~15 per tile), which
+    // made a tile cost 13 us for 0.7 us of MFMA work.  Host guarantees: SW_RB*WoP*8 <= NDY*256, W % 4 == 0, PW / 2 <= 32.
+    constexpr int NDY = 8, NIN = (5 * (2 * SW_RB + 5) + 7) / 8;
+    v4u dyv[NDY];            // (compiler vector types: arrays of the u32x4 / float4 STRUCTS were kept in scratch memory)
+    f32x4 inv[NIN];
+    const int dy_total = SW_RB * p.WoP * 8;
+    const int l32 = tid & 31, rr0 = tid >> 5;
+    const int nd = p.PW >> 1, last = (p.W >> 2) + 1;       // dwords per plane; data dwords [1, last)
+    // one loop iteration = { stash the registers of `tile` into LDS, request the registers of the next tile, contract `tile` }; the
+    // first iteration (tile < 0) only requests
+    for (int tile = (int)blockIdx.x - (int)gridDim.x;; tile += gridDim.x) {
+        const int nxt = tile + (int)gridDim.x;
+        int rb = 0;
+        if (tile >= 0) {
+            const int gi = tile % p.groups_per_frame;
+            rb = p.Ho - gi * SW_RB;
+            if (rb > SW_RB) rb = SW_RB;
+            __syncthreads();                 // everybody is done reading the previous tile
+#pragma unroll
+            for (int i = 0; i < NDY; ++i) {
+                const int e = tid + 256 * i, pos = e >> 3, ch = e & 7;
+                if (e < dy_total) *reinterpret_cast<v4u*>(sDY + pos * SW_DPITCH + ch * 8) = dyv[i];
+            }
+            // input rows, de-interleaved: pixels 4v..4v+3 -> even plane dword (x0, x2), odd plane dword (x1, x3) at dword v + 1
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                const int rr = rr0 + 8 * i;
+                if (rr < 5 * nrows && l32 < nd) {
+                    bf16_t* dst = sIn + (long)rr * 2 * p.PW;
+                    reinterpret_cast<unsigned*>(dst)[l32] = pack2bf(inv[i][0], inv[i][2]);
+                    reinterpret_cast<unsigned*>(dst + p.PW)[l32] = pack2bf(inv[i][1], inv[i][3]);
+                }
+            }
+            __syncthreads();
+        }
+        if (nxt < p.total_tiles) {
+            const int f = nxt / p.groups_per_frame, gi = nxt - f * p.groups_per_frame;
+            const int b = f / p.T, t = f - b * p.T;
+            const int y0 = gi * SW_RB;
+            int rbn = p.Ho - y0;
+            if (rbn > SW_RB) rbn = SW_RB;
+            const int row_base = 2 * y0 - 3;
+#pragma unroll
+            for (int i = 0; i < NDY; ++i) {
+                const int e = tid + 256 * i, pos = e >> 3, ch = e & 7;
+                const int yl = pos / p.WoP, x = pos - yl * p.WoP;
+                const bool ok = e < dy_total && yl < rbn && x < p.Wo;       // (no branch: the register arrays must not end up in scratch)
+                dyv[i] = *reinterpret_cast<const v4u*>(ok ? p.dy + (((long)f * p.Ho + y0 + yl) * p.Wo + x) * STEM_C + ch * 8
+                                                            : reinterpret_cast<const bf16_t*>(g_stem_zero));
+            }
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                const int rr = rr0 + 8 * i;
+                const int kt = rr / nrows, r = rr - kt * nrows;
+                const int tt = t + kt - 2, iy = row_base + r;
+                const bool ok = rr < 5 * nrows && tt >= 0 && tt < p.T && iy >= 0 && iy < p.H && l32 >= 1 && l32 < last;
+                inv[i] = *reinterpret_cast<const f32x4*>(ok ? p.vid + (((long)b * p.T + tt) * p.H + iy) * p.W + 4 * (l32 - 1)
+                                                             : reinterpret_cast<const float*>(g_stem_zero));
+            }
+        }
+        if (tile < 0) continue;
+
+        for (int yl = 0; yl < rb; ++yl) {
+            for (int xs = 0; xs < p.WoP; xs += 16) {
+                const int pos0 = yl * p.WoP + xs;
+                bf16x8 fa[2], fb[2];
+                fa[0] = stem_frag_T<USE_TR>(sDY, 0, pos0, lane);
+                fa[1] = stem_frag_T<USE_TR>(sDY, 32, pos0, lane);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int a = kbase[q] + (2 * yl) * 2 * p.PW + xs;      // element address of x = xs + kg*8 for this tap
+                    const unsigned* src = reinterpret_cast<const unsigned*>(sIn + (a & ~1));
+                    const unsigned sh = (a & 1) * 16;
+                    const unsigned d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3], d4 = src[4];
+                    u32x4 fr;          // (a plain struct of four registers: a union with an array went through scratch memory)
+                    fr.x = kvalid[q] ? __builtin_amdgcn_alignbit(d1, d0, sh) : 0u;
+                    fr.y = kvalid[q] ? __builtin_amdgcn_alignbit(d2, d1, sh) : 0u;
+                    fr.z = kvalid[q] ? __builtin_amdgcn_alignbit(d3, d2, sh) : 0u;
+                    fr.w = kvalid[q] ? __builtin_amdgcn_alignbit(d4, d3, sh) : 0u;
+                    fb[q] = __builtin_bit_cast(bf16x8, fr);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[q], acc[i][q], 0, 0, 0);
+            }
+        }
+        if (nxt >= p.total_tiles) break;
     }
     // D[row = channel][col = tap] -> this workgroup's slab (plain stores; the slabs are added in a fixed order afterwards)
     float* dst = p.part + (long)blockIdx.x * (STEM_C * 245);
@@ -380,7 +519,16 @@ int svsr_stem_conv_wgrad(const float* vid, const void* dy, float* dw, int B, int
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set[use_tr ? 1 : 0] = lds;
     }
-    if (use_tr) hipLaunchKernelGGL(k_stem_conv_wgrad<true>, dim3(grid), dim3(256), lds, stream, a);
+    // the register-pipelined kernel covers the shapes whose tile pieces fit its fixed prefetch registers (88 x 88 clips do)
+    const bool pipe = use_tr && (W & 3) == 0 && a.PW / 2 <= 32 && SW_RB * a.WoP * 8 <= 8 * 256 && svsr_tune_get(SVSR_TUNE_STEM_WG_PIPE);
+    if (pipe) {
+        static size_t lds_pipe = 0;
+        if (lds > lds_pipe) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem_conv_wgrad_pipe<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            lds_pipe = lds;
+        }
+        hipLaunchKernelGGL(k_stem_conv_wgrad_pipe<true>, dim3(grid), dim3(256), lds, stream, a);
+    } else if (use_tr) hipLaunchKernelGGL(k_stem_conv_wgrad<true>, dim3(grid), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(k_stem_conv_wgrad<false>, dim3(grid), dim3(256), lds, stream, a);
     const int rc = svsr_check_launch();
     if (rc != SVSR_OK) return rc;
