@@ -402,7 +402,10 @@ __global__ __launch_bounds__(256) void k_stem_conv_wgrad_pipe(const StemWgradArg
                                                              : reinterpret_cast<const float*>(g_stem_zero));
             }
         }
-        if (tile < 0) continue;
+        if (tile < 0) {
+            if (nxt >= p.total_tiles) break;      // (a workgroup without any tile: the host never launches one)
+            continue;
+        }
 
         for (int yl = 0; yl < rb; ++yl) {
             for (int xs = 0; xs < p.WoP; xs += 16) {
