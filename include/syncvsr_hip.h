@@ -129,7 +129,8 @@ int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H
  * vid fp32 [B][1][T][H][W]; w fp32 [64][1][5][7][7]; out bf16 [B*T][H/2][W/2][64]; stats [rows][2][64] with rows =
  * svsr_stem_conv_fwd_stat_rows(B, T, H, W). */
 int svsr_stem_conv_fwd_stat_rows(int B, int T, int H, int W);
-int svsr_stem_conv_fwd(const float* vid, const float* w, void* out, float* stats, int B, int T, int H, int W, hipStream_t stream);
+int64_t svsr_stem_conv_fwd_ws_bytes(int B, int T, int H, int W);
+int svsr_stem_conv_fwd(const float* vid, const float* w, void* out, float* stats, int B, int T, int H, int W, void* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* weight gradient of the stem conv (autograd of lightning.py:50); dw fp32 [64][245] accumulated (per-workgroup slabs in
  * `part`, size from svsr_stem_conv_wgrad_plan, added in a fixed order). */

@@ -29,14 +29,18 @@ def parse_header(path: str = HEADER) -> dict[str, list[tuple[str, str]]]:
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out: dict[str, list[tuple[str, str]]] = {}
-    for m in re.finditer(r"\bint\s+(svsr_\w+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"\b(int|int64_t)\s+(svsr_\w+)\s*\(([^)]*)\)\s*;", text):
         args = []
-        for a in m.group(2).split(","):
+        for a in m.group(3).split(","):
             a = " ".join(a.split())
             mm = re.match(r"(.+?)\s*(\w+)$", a)
             args.append((mm.group(1).strip(), mm.group(2)))
-        out[m.group(1)] = args
+        out[m.group(2)] = args
+        _RESTYPE[m.group(2)] = m.group(1)
     return out
+
+
+_RESTYPE: dict[str, str] = {}
 
 
 def _ctype(ctype: str):
@@ -54,7 +58,7 @@ def load() -> ctypes.CDLL:
     lib = ctypes.CDLL(LIB_PATH)
     for name, args in parse_header().items():
         fn = getattr(lib, name)
-        fn.restype = ctypes.c_int
+        fn.restype = _CTYPES[_RESTYPE.get(name, "int")]
         fn.argtypes = [_ctype(t) for t, _ in args]
     return lib
 

@@ -30,8 +30,9 @@ static int g_tune[SVSR_TUNE_N] = {
     /* RES_DEEP */ 0,          // svsr_conv3x3_res at 128 channels: 32-deep weight tiles in a 4-deep ring (three in flight) instead of 64-deep / 2-deep
     /* EPI_BATCHED */ 1,       // svsr_igemm_fwd epilogue: all rows' staged accumulators / addend pieces requested before the first is used
     /* STEM_WG_PIPE */ 1,      // svsr_stem_conv_wgrad: next tile's operands prefetched into registers during the MFMA block
+    /* STEM_FWD_DMA */ 1,      // svsr_stem_conv_fwd: bf16 prep pass + LDS-DMA tile fills (0: direct fp32 -> LDS path)
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 

@@ -10,6 +10,8 @@
 #define STEM_KROWS 36          // 35 (kt,kh) rows + 1 zero row
 #define STEM_WPITCH 296        // 288 + 8 pad: 592-byte rows -> conflict-free ds_read_b128 of B fragments
 
+typedef __attribute__((ext_vector_type(4))) unsigned v4u;
+
 struct StemFwdArgs {
     const float* vid;   // [B][T][H][W] fp32 (C = 1)
     const float* w;     // [64][5][7][7] fp32
@@ -143,6 +145,151 @@ __global__ __launch_bounds__(256) void k_stem_conv_fwd(const StemFwdArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The same convolution fed by LDS-DMA (the path 88 x 88 clips take).  k_stem_conv_fwd above converts fp32 pixels and weights to bf16 on
+// its way into LDS with one dependent global round trip per row (9 per tile) and per weight element (72 per workgroup): measured,
+// 106 us of its 233 us were the input fill and 60 us the weight fill, for 70 us of MFMA work.  Here a prep pass (k_stem_prep, ~12 us)
+// writes the clip once as bf16 rows in exactly the LDS layout — [3 zeros | W pixels | 5 zeros], pitch W + 8 — and the weights in the
+// padded K layout [64][296]; tile rows and weights then go global -> LDS as verbatim 16-byte DMA copies.
+// ------------------------------------------------------------------------------------------------------------
+#define STEM_W_CHUNKS (STEM_C * STEM_WPITCH / 8)               // 2368 16-byte pieces
+static_assert(STEM_W_CHUNKS % 64 == 0, "the weight DMA covers whole waves");
+
+__device__ unsigned g_stem_zero_row[64];     // 256 zero bytes: DMA source of rows outside the clip
+
+__global__ __launch_bounds__(256) void k_stem_prep(const float* __restrict__ vid, const float* __restrict__ w, bf16_t* __restrict__ vid16,
+                                                   bf16_t* __restrict__ wpack, long rows, int W, int vid_blocks) {
+    if ((int)blockIdx.x >= vid_blocks) {        // weights: k = (kt*7+kh)*8 + kw, zero where kw = 7 or the row is the 36th
+        const int e = (blockIdx.x - vid_blocks) * 256 + threadIdx.x;
+        if (e < STEM_C * STEM_WPITCH) {
+            const int c = e / STEM_WPITCH, k = e - c * STEM_WPITCH, r = k >> 3, kw = k & 7;
+            wpack[e] = f2bf((r < 35 && kw < 7) ? w[c * 245 + r * 7 + kw] : 0.f);
+        }
+        return;
+    }
+    const int cpr = (W + 8) >> 3;               // 16-byte pieces per output row
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows * cpr) return;
+    const long row = e / cpr;
+    const int ch = (int)(e - row * cpr);
+    const float* src = vid + row * W;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int ix = ch * 8 + k - 3;
+        v[k] = (ix >= 0 && ix < W) ? src[ix] : 0.f;
+    }
+    *reinterpret_cast<u32x4*>(vid16 + row * (W + 8) + ch * 8) = pack8(v);
+}
+
+__global__ __launch_bounds__(256) void k_stem_conv_fwd_dma(const StemFwdArgs p, const bf16_t* __restrict__ vid16, const bf16_t* __restrict__ wpack) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);                 // [64][STEM_WPITCH] (+ pad to whole DMA waves)
+    bf16_t* sIn = sW + STEM_W_CHUNKS * 8;                             // [5 * nrows][WP], rows packed with this tile's own row count (+ pad to a whole wave)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HoWo = p.Ho * p.Wo;
+    const int WP = p.W + 8, cpr = WP >> 3;
+    const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_stem_zero_row) + (lane & 7) * 8;
+
+    for (int e0 = 0; e0 + wave * 64 < STEM_W_CHUNKS; e0 += 256) {       // (wave-uniform bound: a DMA instruction moves 64 pieces)
+        const int e = e0 + tid;
+        const bf16_t* src = wpack + (long)e * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sW + (size_t)(e0 + wave * 64) * 8), 16, 0, 0);
+    }
+
+    float st_s[2] = {0.f, 0.f}, st_q[2] = {0.f, 0.f};   // this lane's channel (jt*32 + lane&31), over the rows this lane holds
+
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+        const int f = tile / p.tiles_per_frame, tp = tile - f * p.tiles_per_frame;
+        const int b = f / p.T, t = f - b * p.T;
+        const int p0 = tp * 128;
+        int plast = p0 + 127;
+        if (plast > HoWo - 1) plast = HoWo - 1;
+        const int y0 = p0 / p.Wo, y1 = plast / p.Wo;
+        const int nrows = 2 * (y1 - y0) + 7;
+        const int row_base = 2 * y0 - 3;
+
+        __syncthreads();   // previous tile's reads of sIn are complete
+        const int chunks = 5 * nrows * cpr;
+        for (int e0 = 0; e0 + wave * 64 < chunks; e0 += 256) {
+            const int e = e0 + tid;
+            const int rr = e / cpr, ch = e - rr * cpr;
+            const int kt = rr / nrows, r = rr - kt * nrows;
+            const int tt = t + kt - 2, iy = row_base + r;
+            const bool ok = e < chunks && tt >= 0 && tt < p.T && iy >= 0 && iy < p.H;
+            const bf16_t* src = ok ? vid16 + (((long)b * p.T + tt) * p.H + iy) * WP + ch * 8 : zero_src;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sIn + (size_t)(e0 + wave * 64) * 8), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (also the weights, the first time)
+        __syncthreads();
+
+        int pp = p0 + wave * 32 + (lane & 31);
+        if (pp > HoWo - 1) pp = HoWo - 1;          // clamp: rows beyond the frame are masked at the store
+        const int y = pp / p.Wo, x = pp - y * p.Wo;
+        const int abase = (2 * (y - y0)) * WP + 2 * x;
+        const int kg = lane >> 5;
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+
+#pragma unroll
+        for (int ks = 0; ks < STEM_KROWS / 2; ++ks) {
+            const int re = 2 * ks, ro = (2 * ks + 1 < 35) ? 2 * ks + 1 : 34;   // the zero row reads row 34's (finite) pixels
+            const int kte = re / 7, khe = re % 7, kto = ro / 7, kho = ro % 7;
+            const int kt = kg ? kto : kte, kh = kg ? kho : khe;
+            const unsigned* src = reinterpret_cast<const unsigned*>(sIn + (kt * nrows + kh) * WP + abase);
+            v4u fa4;
+            fa4[0] = src[0]; fa4[1] = src[1]; fa4[2] = src[2]; fa4[3] = src[3];
+            const bf16x8 fa = __builtin_bit_cast(bf16x8, fa4);
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + (jt * 32 + (lane & 31)) * STEM_WPITCH + ks * 16 + kg * 8);
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[jt], 0, 0, 0);
+            }
+        }
+
+        bf16_t* obase = p.out + (long)f * HoWo * STEM_C;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int c = jt * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int po = p0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (po < HoWo) {
+                    const float v = acc[jt][r];
+                    obase[(long)po * STEM_C + c] = f2bf(v);
+                    st_s[jt] += v;
+                    st_q[jt] += v * v;
+                }
+            }
+        }
+    }
+    if (p.stats != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // a workgroup without a tile still has its weight DMA in flight
+        __syncthreads();
+        float* sred = reinterpret_cast<float*>(smem_raw);          // [4 waves][2][64]
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const float s = st_s[jt] + __shfl_xor(st_s[jt], 32, 64);
+            const float q = st_q[jt] + __shfl_xor(st_q[jt], 32, 64);
+            if (lane < 32) {
+                sred[(wave * 2 + 0) * STEM_C + jt * 32 + lane] = s;
+                sred[(wave * 2 + 1) * STEM_C + jt * 32 + lane] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * STEM_C) {
+            const int which = tid >> 6, c = tid & 63;
+            const float v = ((sred[(0 * 2 + which) * STEM_C + c] + sred[(1 * 2 + which) * STEM_C + c]) + sred[(2 * 2 + which) * STEM_C + c]) +
+                            sred[(3 * 2 + which) * STEM_C + c];
+            p.stats[((long)blockIdx.x * 2 + which) * STEM_C + c] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // weight gradient  dW[c][kt][kh][kw] += sum_{b,t,y,x} dY[b,t,y,x,c] * in[b, t+kt-2, 2y+kh-3, 2x+kw-3]
 // MFMA view: D[c][k] += sum_m dY^T[c][m] * P[m][k] with m running along x inside one output row.  A fragments
 // (8 consecutive positions of one channel) come from the position-major dY tile via ds_read_b64_tr_b16; B fragments
@@ -164,7 +311,6 @@ struct StemWgradArgs {
     int use_tr;
 };
 
-typedef __attribute__((ext_vector_type(4))) unsigned v4u;
 __device__ unsigned g_stem_zero[4];     // 16 zero bytes: source of predicated-off tile loads
 
 template <bool USE_TR>
@@ -461,7 +607,14 @@ static int stem_fwd_grid(int B, int T, int H, int W) {
 /* rows of [2][64] BatchNorm partials svsr_stem_conv_fwd writes for this shape (= its persistent workgroups) */
 int svsr_stem_conv_fwd_stat_rows(int B, int T, int H, int W) { return (B < 1 || T < 1 || H < 8 || W < 8) ? 0 : stem_fwd_grid(B, T, H, W); }
 
-int svsr_stem_conv_fwd(const float* vid, const float* w, void* out, float* stats, int B, int T, int H, int W, hipStream_t stream) {
+/* bytes of the workspace the DMA-fed forward path wants (0: this shape takes the direct path and needs none) */
+int64_t svsr_stem_conv_fwd_ws_bytes(int B, int T, int H, int W) {
+    if ((H & 1) || (W & 7) || H < 8 || W < 8 || B < 1 || T < 1 || !svsr_tune_get(SVSR_TUNE_STEM_FWD_DMA)) return 0;
+    return ((int64_t)B * T * H * (W + 8) + (int64_t)STEM_W_CHUNKS * 8) * 2;
+}
+
+int svsr_stem_conv_fwd(const float* vid, const float* w, void* out, float* stats, int B, int T, int H, int W, void* ws, int64_t ws_bytes,
+                       hipStream_t stream) {
     if ((H & 1) || (W & 1) || H < 8 || W < 8) return SVSR_ERR_ARG;
     StemFwdArgs a;
     a.vid = vid; a.w = w; a.out = (bf16_t*)out; a.stats = stats;
@@ -480,6 +633,23 @@ int svsr_stem_conv_fwd(const float* vid, const float* w, void* out, float* stats
         lds_set = lds;
     }
     const int grid = stem_fwd_grid(B, T, H, W);
+    const int64_t need = svsr_stem_conv_fwd_ws_bytes(B, T, H, W);
+    if (ws != nullptr && need > 0 && ws_bytes >= need) {
+        bf16_t* vid16 = (bf16_t*)ws;
+        bf16_t* wpack = vid16 + (int64_t)B * T * H * (W + 8);
+        const long rows = (long)B * T * H;
+        const int vid_blocks = (int)((rows * ((W + 8) / 8) + 255) / 256), w_blocks = (STEM_C * STEM_WPITCH + 255) / 256;
+        hipLaunchKernelGGL(k_stem_prep, dim3(vid_blocks + w_blocks), dim3(256), 0, stream, vid, w, vid16, wpack, rows, W, vid_blocks);
+        const size_t lds_d = (size_t)STEM_W_CHUNKS * 16 + ((size_t)5 * a.rows_in_max * ((W + 8) / 8) + 63) / 64 * 64 * 16;
+        if (lds_d > 160 * 1024) return SVSR_ERR_ARG;
+        static size_t lds_dma = 0;
+        if (lds_d > lds_dma) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem_conv_fwd_dma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
+            lds_dma = lds_d;
+        }
+        hipLaunchKernelGGL(k_stem_conv_fwd_dma, dim3(grid), dim3(256), lds_d, stream, a, (const bf16_t*)vid16, (const bf16_t*)wpack);
+        return svsr_check_launch();
+    }
     hipLaunchKernelGGL(k_stem_conv_fwd, dim3(grid), dim3(256), lds, stream, a);
     return svsr_check_launch();
 }

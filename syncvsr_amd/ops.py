@@ -71,7 +71,7 @@ def _query(name: str, *args) -> tuple:
     if hit is not None:
         return hit
     fn = getattr(_lib.load(), name)
-    if name.endswith("_rows"):
+    if name.endswith("_rows") or name.endswith("_bytes"):
         out = (int(fn(*args)),)
     else:
         nout = {"svsr_conv3x3_wgrad_plan": (1, 1),
@@ -456,6 +456,9 @@ def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, rows: i
 # --------------------------------------------------------------------------------------------------
 # stem
 # --------------------------------------------------------------------------------------------------
+_STEM_WS: dict = {}
+
+
 def stem_conv_fwd(videos: torch.Tensor, w: torch.Tensor, want_stats: bool = False):
     """-> (out [B*T,H/2,W/2,64] bf16, BatchNorm partials (buffer, rows) or None)"""
     B, C, T, H, W = videos.shape
@@ -466,7 +469,13 @@ def stem_conv_fwd(videos: torch.Tensor, w: torch.Tensor, want_stats: bool = Fals
         rows = _query("svsr_stem_conv_fwd_stat_rows", B, T, H, W)[0]
         stats = scratch(rows * 2 * 64)
         st = (stats, rows)
-    _call("svsr_stem_conv_fwd", _p(videos), _p(w), _p(out), _p(stats), B, T, H, W, _stream(),
+    nws = _query("svsr_stem_conv_fwd_ws_bytes", B, T, H, W)[0]
+    ws = None
+    if nws:         # bf16 copy of the clip + packed weights for the DMA-fed kernel (a per-shape buffer: `stats` lives in the shared scratch)
+        ws = _STEM_WS.get((B, T, H, W, videos.device))
+        if ws is None or ws.numel() < nws:
+            ws = _STEM_WS[(B, T, H, W, videos.device)] = torch.empty(nws, dtype=torch.uint8, device=videos.device)
+    _call("svsr_stem_conv_fwd", _p(videos), _p(w), _p(out), _p(stats), B, T, H, W, _p(ws), nws, _stream(),
           label="k_stem_conv_fwd", flops=2.0 * B * T * (H // 2) * (W // 2) * 64 * 245)
     return out, st
 
