@@ -254,18 +254,31 @@ __global__ __launch_bounds__(256) void k_bias_act_bwd(const bf16_t* __restrict__
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
     if (v < cv) {
-        for (int r = r0 + rl; r < r1; r += 8) {
-            float g[8];
-            unpack8(*reinterpret_cast<const u32x4*>(dy + (long)r * ld + v * 8), g);
+        // two rows per trip, all four loads requested before the first is used (one row per trip left a thread with a chain of
+        // dependent global round trips: 15 us for 960 x 2,048 values)
+        for (int r = r0 + rl; r < r1; r += 16) {
+            const int rb = r + 8 < r1 ? r + 8 : r;          // (clamped: the second row's result is dropped when it is out of range)
+            const bool hb = r + 8 < r1;
+            const u32x4 ga = *reinterpret_cast<const u32x4*>(dy + (long)r * ld + v * 8);
+            const u32x4 gb = *reinterpret_cast<const u32x4*>(dy + (long)rb * ld + v * 8);
+            float g0[8], g1[8];
             if (z != nullptr) {
-                float zz[8];
-                unpack8(*reinterpret_cast<const u32x4*>(z + (long)r * ld + v * 8), zz);
+                const u32x4 za = *reinterpret_cast<const u32x4*>(z + (long)r * ld + v * 8);
+                const u32x4 zb = *reinterpret_cast<const u32x4*>(z + (long)rb * ld + v * 8);
+                float z0[8], z1[8];
+                unpack8(ga, g0); unpack8(gb, g1); unpack8(za, z0); unpack8(zb, z1);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) g[k] = act == 2 ? (zz[k] > 0.f ? g[k] * gscale : 0.f) : g[k] * gelu_erf_grad(zz[k]) * gscale;
-                *reinterpret_cast<u32x4*>(dz + (long)r * ld + v * 8) = pack8(g);
+                for (int k = 0; k < 8; ++k) {
+                    g0[k] = act == 2 ? (z0[k] > 0.f ? g0[k] * gscale : 0.f) : g0[k] * gelu_erf_grad(z0[k]) * gscale;
+                    g1[k] = act == 2 ? (z1[k] > 0.f ? g1[k] * gscale : 0.f) : g1[k] * gelu_erf_grad(z1[k]) * gscale;
+                }
+                *reinterpret_cast<u32x4*>(dz + (long)r * ld + v * 8) = pack8(g0);
+                if (hb) *reinterpret_cast<u32x4*>(dz + (long)rb * ld + v * 8) = pack8(g1);
+            } else {
+                unpack8(ga, g0); unpack8(gb, g1);
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] += g[k];
+            for (int k = 0; k < 8; ++k) acc[k] = (acc[k] + g0[k]) + (hb ? g1[k] : 0.f);
         }
     }
     if (db == nullptr) return;
@@ -347,7 +360,7 @@ int svsr_embed_bwd_scatter(const void* ds, void* dfeats, float* dcls, float* dpo
 static void bias_bwd_grid(int R, int N, int& col_blocks, int& splits, int& rpb) {
     const int cv = N / 8;
     col_blocks = (cv + 31) / 32;
-    splits = (R + 63) / 64;                                  // ~64 rows (8 per thread) per block ...
+    splits = (R + 15) / 16;                                  // 16 rows (2 per thread) per block: 480 workgroups at 960 x 2,048 ...
     while (splits > 1 && col_blocks * splits > 2048) splits = (splits + 1) / 2;
     rpb = (R + splits - 1) / splits;
     splits = (R + rpb - 1) / rpb;

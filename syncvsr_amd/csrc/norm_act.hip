@@ -22,7 +22,17 @@ __device__ __forceinline__ void bn_rows_sum(const float* __restrict__ part, int 
     double a = 0.0, b = 0.0;
     if (live) {
         int r = rl;
-        for (; r + 3 * BNF_RL < nrows; r += 4 * BNF_RL) {           // four independent row pairs in flight, added in row order
+        for (; r + 7 * BNF_RL < nrows; r += 8 * BNF_RL) {           // eight independent row pairs in flight (one round trip for up to 512 rows), added in row order
+            float av[8], bv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                av[k] = part[((long)(r + k * BNF_RL) * 2 + 0) * C + c];
+                bv[k] = part[((long)(r + k * BNF_RL) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a += (double)av[k]; b += (double)bv[k]; }
+        }
+        for (; r + 3 * BNF_RL < nrows; r += 4 * BNF_RL) {           // four
             const float a0 = part[((long)r * 2 + 0) * C + c], b0 = part[((long)r * 2 + 1) * C + c];
             const float a1 = part[((long)(r + BNF_RL) * 2 + 0) * C + c], b1 = part[((long)(r + BNF_RL) * 2 + 1) * C + c];
             const float a2 = part[((long)(r + 2 * BNF_RL) * 2 + 0) * C + c], b2 = part[((long)(r + 2 * BNF_RL) * 2 + 1) * C + c];

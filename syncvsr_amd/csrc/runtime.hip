@@ -20,7 +20,7 @@ static int g_tune[SVSR_TUNE_N] = {
     /* IGEMM_M128   */ 8192,   // rows from which 128-row tiles are used
     /* WG_BLOCKS    */ 0,      // target workgroups of svsr_igemm_wgrad (0: built-in per tile size)
     /* W3_BLOCKS    */ 512,    // target workgroups of svsr_conv3x3_wgrad: one round at 2 per CU (swept 192..768 with slab epilogues: 110 / 92 / 81 / 74 / 98 us)
-    /* LN_RPB       */ 16,     // rows per workgroup of svsr_add_ln_bwd
+    /* LN_RPB       */ 4,      // rows per workgroup of svsr_add_ln_bwd (one per wave: 16 -> 4 measured 6.00 -> 5.97 ms per LRW step)
     /* STEM_LDS_FWD */ 0,      // LDS-tiled stem BN+act+pool forward (measured slower)
     /* STEM_LDS_BWD */ 2,      // stem BN+act+pool backward: 0 plain, 1 LDS-tiled passes, 2 LDS-tiled apply pass + gather-form reduce pass (fastest)
     /* IGEMM_LDS_PAD */ 0,     // extra dynamic LDS bytes per svsr_igemm_fwd workgroup (occupancy experiments: fewer co-resident blocks per CU)
@@ -60,7 +60,14 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ ws, in
     if (live) {
         const float* src = ws + c;
         int r = rl;
-        for (; r + 3 * RL < nrows; r += 4 * RL) {      // four independent loads in flight, added in row order
+        for (; r + 7 * RL < nrows; r += 8 * RL) {      // eight independent loads in flight, added in row order
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = src[(long)(r + k * RL) * ld];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += t[k];
+        }
+        for (; r + 3 * RL < nrows; r += 4 * RL) {      // four
             const float a = src[(long)r * ld], b = src[(long)(r + RL) * ld], d = src[(long)(r + 2 * RL) * ld], e = src[(long)(r + 3 * RL) * ld];
             acc = (((acc + a) + b) + d) + e;
         }
