@@ -708,7 +708,10 @@ static IgemmFwdPlan igemm_fwd_plan(long M, int Co, int max_taps) {
     }
     // few-tile convolutions (LRW layer4: 66 x 4 tiles of 128x128 = about one workgroup per CU): 128x64 tiles with a 2-deep ring
     // fit three workgroups per CU and measure 82 -> 77 us; with more tiles the 128x128 shape wins (layer2 61 vs 66 us)
-    if (bm == 128 && Co > 64 && max_taps > 1 && ((M + 127) / 128) * ((Co + 127) / 128) < svsr_tune_get(SVSR_TUNE_IGEMM_BN64_BELOW)) { pl.bm = 128; pl.bn = 64; pl.ns = 2; }
+    // single-tap launches (linears) too small for 128x128 tiles but with many rows (LRS: 2,400 x 768-wide outputs): 128x64 tiles, 3-deep ring
+    const int lin_rows = svsr_tune_get(SVSR_TUNE_IGEMM_LIN_BN64);
+    if (bm == 64 && forced == 0 && Co > 64 && max_taps == 1 && lin_rows > 0 && M >= lin_rows) { pl.bm = 128; pl.bn = 64; pl.ns = 3; }
+    else if (bm == 128 && Co > 64 && max_taps > 1 && ((M + 127) / 128) * ((Co + 127) / 128) < svsr_tune_get(SVSR_TUNE_IGEMM_BN64_BELOW)) { pl.bm = 128; pl.bn = 64; pl.ns = 2; }
     else if (bm == 128 && Co <= 64) { pl.bm = 128; pl.bn = 64; pl.ns = 3; }
     else if (bm == 128) { pl.bm = 128; pl.bn = 128; pl.ns = 2; }
     else { pl.bm = 64; pl.bn = 64; pl.ns = 0; }

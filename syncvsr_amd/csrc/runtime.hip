@@ -31,8 +31,9 @@ static int g_tune[SVSR_TUNE_N] = {
     /* EPI_BATCHED */ 1,       // svsr_igemm_fwd epilogue: all rows' staged accumulators / addend pieces requested before the first is used
     /* STEM_WG_PIPE */ 1,      // svsr_stem_conv_wgrad: next tile's operands prefetched into registers during the MFMA block
     /* STEM_FWD_DMA */ 1,      // svsr_stem_conv_fwd: bf16 prep pass + LDS-DMA tile fills (0: direct fp32 -> LDS path)
+    /* IGEMM_LIN_BN64 */ 2048, // svsr_igemm_fwd: linears that would get 64x64 tiles use 128x64 tiles from this many rows on (0: never; LRS 768-wide outputs at 2,400 rows: 29.6 -> 29.1 ms per step)
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 

@@ -170,6 +170,8 @@ def test_linear_fwd_dgrad_wgrad_at_benchmark_rows(dev, rows, K, N, gelu, bias):
     Np = (N + 7) // 8 * 8
     out, pre = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), rows=rows, K=K, N=N, x_pitch=K, out_pitch=Np, gelu=gelu)
     _SEEN[f"linear {rows}x{K}->{N}.fwd"] = ops.rows_plan(rows, 1, 0, 0, N).label
+    if rows == 2400 and N == 768:       # many rows, too few 128x128 tiles: the 128x64 shape (LRS 768-wide outputs)
+        assert _SEEN[f"linear {rows}x{K}->{N}.fwd"] == "k_igemm_fwd_glds<128,64,3>"
     if gelu:
         check(pre[:, :N], ref, "linear.pre")
         check(out[:, :N], F.gelu(ref), "linear.gelu")
