@@ -33,6 +33,8 @@ def parse_header(path: str = HEADER) -> dict[str, list[tuple[str, str]]]:
         args = []
         for a in m.group(3).split(","):
             a = " ".join(a.split())
+            if a in ("void", ""):
+                continue
             mm = re.match(r"(.+?)\s*(\w+)$", a)
             args.append((mm.group(1).strip(), mm.group(2)))
         out[m.group(2)] = args
