@@ -102,11 +102,13 @@ int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* adde
  * of g and of g * (x - mean) * rstd into stats[rows][2][Co] (rows = meta[3] of the plan, resp. svsr_conv3x3_c64_stat_rows).
  * y == NULL (allowed only when y has no residual branch): the mask is recomputed from x as bn(x) > 0 with gamma / beta in the forward
  * pass's own arithmetic (svsr_bn_act_fwd) and y is not read; otherwise gamma / beta may be NULL.
+ * act = 1: ReLU as described.  act = 2: Swish (LRS trunk, Conformer convolution module): g = dL/dy * swish'(bn(x) + r), where `y` is the
+ * residual INPUT r of the output (NULL: none) and gamma / beta are required.
  * svsr_igemm_dgrad_bn needs a plan that visits every target pixel once (svsr_conv_plan mode 1), Co % 8 == 0, out_pitch % 8 == 0.
  * svsr_bn_bwd_from_stats then adds the rows in a fixed order (dgamma +=, dbeta +=, coef[3][C] scratch) and writes
  * dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)). */
-int svsr_igemm_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, hipStream_t stream);
-int svsr_conv3x3_c64_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, const int* dy, const int* dx, const int* tw, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, hipStream_t stream);
+int svsr_igemm_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, hipStream_t stream);
+int svsr_conv3x3_c64_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, const int* dy, const int* dx, const int* tw, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, hipStream_t stream);
 int svsr_bn_bwd_from_stats(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma, const float* stats, int nrows, float* coef, float* dgamma, float* dbeta, void* dx, int64_t npix, int C, hipStream_t stream);
 
 /* svsr_conv3x3_res: conv3x3, stride 1, pad 1 for 128 / 256 input channels (layer2 / layer3 of the trunk, resnet.py:8-10,59-72) forward and,

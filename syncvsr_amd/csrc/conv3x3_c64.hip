@@ -36,6 +36,7 @@ struct Conv64Args {
     const float* bnb_rstd;
     const float* bnb_gamma;     // bnb_y == nullptr: mask recomputed as bn(x) > 0 (forward's own expression), y not read
     const float* bnb_beta;
+    int bnb_act;                // 1 ReLU, 2 Swish (bnb_y = the residual input or null; see svsr_igemm_dgrad_bn)
 };
 
 __device__ unsigned g_c64_zero_page[64];
@@ -54,6 +55,9 @@ __device__ __forceinline__ int c64_pixel(const Conv64Args& p, int q) {
     return (n * p.H + (yp - 1)) * p.W + (xp - 1);
 }
 
+// SWISH: the Swish variant of the BatchNorm-backward epilogue (LRS trunk) is its own instantiation — compiled into the ReLU / plain kernel
+// its temporaries push the 255-register MFMA loop over the limit and spill.
+template <bool SWISH>
 __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);                // [9*64 rows][64]
@@ -101,9 +105,10 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
     if (bnb && tid < 64) {
         const float m = p.bnb_mean[tid], r = p.bnb_rstd[tid];
         sC[tid] = m; sC[64 + tid] = r;
-        const float c = from_x ? p.bnb_gamma[tid] * r : 0.f;
+        const bool affine = from_x || SWISH;
+        const float c = affine ? p.bnb_gamma[tid] * r : 0.f;
         sC[128 + tid] = c;
-        sC[192 + tid] = from_x ? __builtin_fmaf(-m, c, p.bnb_beta[tid]) : 0.f;
+        sC[192 + tid] = affine ? __builtin_fmaf(-m, c, p.bnb_beta[tid]) : 0.f;
     }
     int c = blockIdx.x, buf = 0;
     if (c < p.total_chunks) stage(c, 0);
@@ -178,18 +183,19 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
                 x8[i] = *reinterpret_cast<const u32x4*>(p.bnb_x + o);
                 if (!from_x) y8[i] = *reinterpret_cast<const u32x4*>(p.bnb_y + o);
             }
-            float mu[8], rs[8], sc[8], sh[8];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f32x4 m4 = *reinterpret_cast<const f32x4*>(sC + slot * 8 + 4 * h), r4 = *reinterpret_cast<const f32x4*>(sC + 64 + slot * 8 + 4 * h);
-                const f32x4 c4 = *reinterpret_cast<const f32x4*>(sC + 128 + slot * 8 + 4 * h), h4 = *reinterpret_cast<const f32x4*>(sC + 192 + slot * 8 + 4 * h);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { mu[4 * h + k] = m4[k]; rs[4 * h + k] = r4[k]; sc[4 * h + k] = c4[k]; sh[4 * h + k] = h4[k]; }
-            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (pixv[i] < 0) continue;
                 float a[8], yv[8], xv[8];
+                // (the per-channel constants are re-read from LDS for every row: held across the four rows they cost 32 registers and spilled)
+                float mu[8], rs[8], sc[8], sh[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 m4 = *reinterpret_cast<const f32x4*>(sC + slot * 8 + 4 * h), r4 = *reinterpret_cast<const f32x4*>(sC + 64 + slot * 8 + 4 * h);
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(sC + 128 + slot * 8 + 4 * h), h4 = *reinterpret_cast<const f32x4*>(sC + 192 + slot * 8 + 4 * h);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { mu[4 * h + k] = m4[k]; rs[4 * h + k] = r4[k]; sc[4 * h + k] = c4[k]; sh[4 * h + k] = h4[k]; }
+                }
                 unpack8(piece[i], a);
                 unpack8(x8[i], xv);
                 if (from_x) {
@@ -204,11 +210,21 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
 #pragma unroll
                     for (int k = 0; k < 8; ++k) a[k] = bf2f(f2bf(a[k] + b[k]));
                 }
+                if (SWISH) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    a[k] = yv[k] > 0.f ? a[k] : 0.f;
-                    st_s[k] += a[k];
-                    st_q[k] += a[k] * (xv[k] - mu[k]) * rs[k];
+                    for (int k = 0; k < 8; ++k) {
+                        const float z = from_x ? yv[k] : __builtin_fmaf(xv[k], sc[k], sh[k]) + yv[k];     // (from_x: yv already is bn(x))
+                        a[k] = bf2f(f2bf(a[k] * swish_grad(z)));
+                        st_s[k] += a[k];
+                        st_q[k] += a[k] * (xv[k] - mu[k]) * rs[k];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        a[k] = yv[k] > 0.f ? a[k] : 0.f;
+                        st_s[k] += a[k];
+                        st_q[k] += a[k] * (xv[k] - mu[k]) * rs[k];
+                    }
                 }
                 *reinterpret_cast<u32x4*>(p.out + (long)pixv[i] * 64 + slot * 8) = pack8(a);
             }
@@ -262,12 +278,12 @@ extern "C" int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W) {
 
 static int c64_run(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
                    const int* dy, const int* dx, const int* tw, const void* bnb_y, const void* bnb_x, const float* bnb_mean,
-                   const float* bnb_rstd, const float* bnb_gamma, const float* bnb_beta, hipStream_t stream) {
+                   const float* bnb_rstd, const float* bnb_gamma, const float* bnb_beta, int bnb_act, hipStream_t stream) {
     if (W + 2 > (C64_XR - C64_CH) / 2 - 1 || H < 1 || W < 1 || Nimg < 1) return SVSR_ERR_ARG;
     Conv64Args a;
     a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = (bf16_t*)out; a.addend = (const bf16_t*)addend; a.stats = stats;
     a.bnb_y = (const bf16_t*)bnb_y; a.bnb_x = (const bf16_t*)bnb_x; a.bnb_mean = bnb_mean; a.bnb_rstd = bnb_rstd;
-    a.bnb_gamma = bnb_gamma; a.bnb_beta = bnb_beta;
+    a.bnb_gamma = bnb_gamma; a.bnb_beta = bnb_beta; a.bnb_act = bnb_act;
     a.Nimg = Nimg; a.H = H; a.W = W; a.WP = W + 2; a.Q = (H + 2) * (W + 2);
     const long qtot = (long)Nimg * a.Q;
     if (qtot >= (1L << 24) || (long)Nimg * H * W >= (1L << 25)) return SVSR_ERR_ARG;
@@ -278,17 +294,19 @@ static int c64_run(const void* in, const void* wt, void* out, const void* addend
     const size_t lds = (size_t)(C64_LDS_W + 2 * C64_LDS_A) * sizeof(bf16_t) + 2 * C64_CH * sizeof(int) + 4 * 64 * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const int grid = c64_grid(a.total_chunks);
-    hipLaunchKernelGGL(k_conv3x3_c64, dim3(grid), dim3(C64_THREADS), lds, stream, a);
+    if (bnb_x != nullptr && bnb_act == 2) hipLaunchKernelGGL(k_conv3x3_c64<true>, dim3(grid), dim3(C64_THREADS), lds, stream, a);
+    else hipLaunchKernelGGL(k_conv3x3_c64<false>, dim3(grid), dim3(C64_THREADS), lds, stream, a);
     return svsr_check_launch();
 }
 
 extern "C" int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
                                 const int* dy, const int* dx, const int* tw, hipStream_t stream) {
-    return c64_run(in, wt, out, addend, stats, Nimg, H, W, dy, dx, tw, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+    return c64_run(in, wt, out, addend, stats, Nimg, H, W, dy, dx, tw, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 /* svsr_conv3x3_c64_dgrad_bn: the data gradient of a 64 -> 64 convolution whose result is the gradient of a BatchNorm + ReLU output
@@ -298,8 +316,8 @@ extern "C" int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const
  * y == nullptr (output without residual branch): mask = bn(x) > 0 recomputed with gamma / beta, y is not read. */
 extern "C" int svsr_conv3x3_c64_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
                                          const int* dy, const int* dx, const int* tw, const void* y, const void* x, const float* mean,
-                                         const float* rstd, const float* gamma, const float* beta, hipStream_t stream) {
-    if (x == nullptr || mean == nullptr || rstd == nullptr || stats == nullptr) return SVSR_ERR_ARG;
-    if (y == nullptr && (gamma == nullptr || beta == nullptr)) return SVSR_ERR_ARG;
-    return c64_run(in, wt, out, addend, stats, Nimg, H, W, dy, dx, tw, y, x, mean, rstd, gamma, beta, stream);
+                                         const float* rstd, const float* gamma, const float* beta, int act, hipStream_t stream) {
+    if (x == nullptr || mean == nullptr || rstd == nullptr || stats == nullptr || (act != 1 && act != 2)) return SVSR_ERR_ARG;
+    if ((y == nullptr || act == 2) && (gamma == nullptr || beta == nullptr)) return SVSR_ERR_ARG;
+    return c64_run(in, wt, out, addend, stats, Nimg, H, W, dy, dx, tw, y, x, mean, rstd, gamma, beta, act, stream);
 }

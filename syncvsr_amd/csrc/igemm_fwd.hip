@@ -59,6 +59,7 @@ struct IgemmFwdArgs {
     const float* bnb_rstd;
     const float* bnb_gamma;    // with bnb_y == nullptr (no residual branch): the mask is recomputed as bn(x) > 0 with the forward's own
     const float* bnb_beta;     // expression (norm_act.hip k_bn_act_fwd) instead of being read from y
+    int bnb_act;               // 1 ReLU (bnb_y = the output y, or null), 2 Swish: g = result * swish'(bn(x) + r), bnb_y = the residual input r or null
 };
 
 __device__ unsigned g_zero_page[64];     // 256 zero bytes: DMA source for rows outside the grid
@@ -132,9 +133,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
         if (active) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) { mu[k] = p.bnb_mean[n + k]; rs[k] = p.bnb_rstd[n + k]; }
-            const bool from_x = p.bnb_y == nullptr;
+            const bool from_x = p.bnb_y == nullptr, swish_act = p.bnb_act == 2;
             float sc[8], sh[8];
-            if (from_x) {
+            if (from_x || swish_act) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { sc[k] = p.bnb_gamma[n + k] * rs[k]; sh[k] = __builtin_fmaf(-mu[k], sc[k], p.bnb_beta[n + k]); }
             }
@@ -171,11 +172,21 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
                     for (int k = 0; k < 8; ++k) v[k] += a8[k];
                 }
                 // sums over the values the apply pass reads back (rounded to bf16): mean(g) is then the mean of what it is subtracted from
+                if (swish_act) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    v[k] = yv[k] > 0.f ? bf2f(f2bf(v[k])) : 0.f;
-                    bs1[k] += v[k];
-                    bs2[k] += v[k] * (xv[k] - mu[k]) * rs[k];
+                    for (int k = 0; k < 8; ++k) {
+                        const float z = __builtin_fmaf(xv[k], sc[k], sh[k]) + (from_x ? 0.f : yv[k]);       // yv: the residual input here
+                        v[k] = bf2f(f2bf(bf2f(f2bf(v[k])) * swish_grad(z)));
+                        bs1[k] += v[k];
+                        bs2[k] += v[k] * (xv[k] - mu[k]) * rs[k];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        v[k] = yv[k] > 0.f ? bf2f(f2bf(v[k])) : 0.f;
+                        bs1[k] += v[k];
+                        bs2[k] += v[k] * (xv[k] - mu[k]) * rs[k];
+                    }
                 }
                 *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + offs[i] + n) = pack8(v);
             }
@@ -865,7 +876,7 @@ extern "C" int svsr_conv3x3_res(const void* in, const void* wt, void* out, const
     a.stats = stats; a.plan = nullptr; a.Nimg = Nimg; a.in_pix = H * W; a.Ci = Ci; a.in_pitch = Ci; a.Co = Co; a.out_pix = H * W; a.out_pitch = Co;
     a.wt_taps = 9; a.act = 0; a.out_f32 = 0; a.alpha = 1.f; a.drop = svsr_make_drop(nullptr, 0, 0.f);
     a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED);
-    a.bnb_y = nullptr; a.bnb_x = nullptr; a.bnb_mean = nullptr; a.bnb_rstd = nullptr; a.bnb_gamma = nullptr; a.bnb_beta = nullptr;
+    a.bnb_y = nullptr; a.bnb_x = nullptr; a.bnb_mean = nullptr; a.bnb_rstd = nullptr; a.bnb_gamma = nullptr; a.bnb_beta = nullptr; a.bnb_act = 0;
     q.H = H; q.W = W; q.M = (int)M;
     for (int t = 0; t < 9; ++t) {
         if (dy[t] < -1 || dy[t] > 1 || dx[t] < -1 || dx[t] > 1 || tw[t] < 0 || tw[t] > 8) return SVSR_ERR_ARG;
@@ -899,7 +910,7 @@ static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pr
                          float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co,
                          int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed,
                          unsigned drop_site, float drop_p, const void* bnb_y, const void* bnb_x, const float* bnb_mean,
-                         const float* bnb_rstd, const float* bnb_gamma, const float* bnb_beta, hipStream_t stream) {
+                         const float* bnb_rstd, const float* bnb_gamma, const float* bnb_beta, int bnb_act, hipStream_t stream) {
     if (plan_dev == nullptr || meta == nullptr || Ci % 64 != 0 || Ci <= 0 || Co <= 0 || in_pitch % 8 != 0 || Nimg <= 0 || wt_taps < 1)
         return SVSR_ERR_ARG;
     if (act != 0 && (addend != nullptr || alpha != 1.f)) return SVSR_ERR_ARG;     // the activation is applied before alpha / addend
@@ -911,7 +922,7 @@ static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pr
     a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
     a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED);
     a.bnb_y = (const bf16_t*)bnb_y; a.bnb_x = (const bf16_t*)bnb_x; a.bnb_mean = bnb_mean; a.bnb_rstd = bnb_rstd;
-    a.bnb_gamma = bnb_gamma; a.bnb_beta = bnb_beta;
+    a.bnb_gamma = bnb_gamma; a.bnb_beta = bnb_beta; a.bnb_act = bnb_act;
     const int bm = meta[0], bn = meta[1], ns = meta[2], gx = meta[3], gy = (Co + bn - 1) / bn;
     if (gx < 1) return SVSR_ERR_ARG;
     // few tiles, long contraction: split K inside the workgroup (see k_igemm_fwd_glds, KG = 2)
@@ -933,7 +944,7 @@ extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* o
                               int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed,
                               unsigned drop_site, float drop_p, hipStream_t stream) {
     return igemm_fwd_run(in, wt, out, out_pre, bias, addend, stats, plan_dev, meta, Nimg, in_pix, Ci, in_pitch, Co, out_pix, out_pitch,
-                         wt_taps, act, out_f32, alpha, drop_seed, drop_site, drop_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                         wt_taps, act, out_f32, alpha, drop_seed, drop_site, drop_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 /* svsr_igemm_dgrad_bn: a data-gradient plan (every target pixel visited exactly once: svsr_conv_plan mode 1) whose result dL/dy is the
@@ -941,13 +952,16 @@ extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* o
  * backward).  The launch stores g = (y > 0 ? dL/dy [+ addend] : 0) instead of dL/dy and writes, per row tile, the column sums of g and of
  * g * (x - mean) * rstd into stats[meta[3]][2][Co] — the first pass of the BatchNorm backward, taken while the tile is in registers;
  * svsr_bn_bwd_from_stats finishes it.  addend may alias out.  y == nullptr (only for an output WITHOUT residual branch): the mask is
- * recomputed from x as bn(x) > 0 with gamma / beta, in the forward pass's own arithmetic, and y is not read. */
+ * recomputed from x as bn(x) > 0 with gamma / beta, in the forward pass's own arithmetic, and y is not read.
+ * act = 2 (Swish, the LRS trunk and Conformer convolution module): g = dL/dy * swish'(bn(x) + r) with `y` = the residual INPUT r of the
+ * output (null: none); gamma / beta are required. */
 extern "C" int svsr_igemm_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, const int* plan_dev,
                                    const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch,
                                    int wt_taps, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma,
-                                   const float* beta, hipStream_t stream) {
+                                   const float* beta, int act, hipStream_t stream) {
     if (x == nullptr || mean == nullptr || rstd == nullptr || stats == nullptr || Co % 8 != 0 || out_pitch % 8 != 0) return SVSR_ERR_ARG;
-    if (y == nullptr && (gamma == nullptr || beta == nullptr)) return SVSR_ERR_ARG;
+    if (act != 1 && act != 2) return SVSR_ERR_ARG;
+    if ((y == nullptr || act == 2) && (gamma == nullptr || beta == nullptr)) return SVSR_ERR_ARG;
     return igemm_fwd_run(in, wt, out, nullptr, nullptr, addend, stats, plan_dev, meta, Nimg, in_pix, Ci, in_pitch, Co, out_pix, out_pitch,
-                         wt_taps, 0, 0, 1.0f, nullptr, 0, 0.f, y, x, mean, rstd, gamma, beta, stream);
+                         wt_taps, 0, 0, 1.0f, nullptr, 0, 0.f, y, x, mean, rstd, gamma, beta, act, stream);
 }

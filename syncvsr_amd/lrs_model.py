@@ -471,10 +471,20 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
     # convolution module
     tc = t["conv"]
     cm, bn = f"{p}.conv_module", f"{p}.conv_module.norm"
-    dy = _lin_bwd(model, st, f"{cm}.pointwise_cov2", tc["y"], _branch_grad(dx3, 1.0, tc["dco"]), R, D, D)
     ws = st.bn[bn]
-    dc, _ = ops.bn_act_bwd(dy, tc["y"], tc["c"], tc["mean"], tc["rstd"], st.p32(f"{bn}.weight"), ws["coef"], st.g32(f"{bn}.weight"),
-                           st.g32(f"{bn}.bias"), ops.ACT_SWISH, False, beta=st.p32(f"{bn}.bias"))
+    if ops.BN_BWD_FUSED:
+        # the data gradient of pointwise_conv2 is the gradient of swish(bn(c)): its launch multiplies by swish' and takes the
+        # BatchNorm backward's first pass in its epilogue (ops.linear_dgrad_bn)
+        dyo = _branch_grad(dx3, 1.0, tc["dco"])
+        _lin_bwd(model, st, f"{cm}.pointwise_cov2", tc["y"], dyo, R, D, D, need_dx=False)
+        g, gst = ops.linear_dgrad_bn(dyo, st.t16(f"{cm}.pointwise_cov2.weight"), rows=R, N=D, K=D, dy_pitch=D, x=tc["c"], mean=tc["mean"],
+                                     rstd=tc["rstd"], gamma=st.p32(f"{bn}.weight"), beta=st.p32(f"{bn}.bias"), act=ops.ACT_SWISH)
+        dc = ops.bn_bwd_from_stats(g, tc["c"], tc["mean"], tc["rstd"], st.p32(f"{bn}.weight"), gst, ws["coef"], st.g32(f"{bn}.weight"),
+                                   st.g32(f"{bn}.bias"))
+    else:
+        dy = _lin_bwd(model, st, f"{cm}.pointwise_cov2", tc["y"], _branch_grad(dx3, 1.0, tc["dco"]), R, D, D)
+        dc, _ = ops.bn_act_bwd(dy, tc["y"], tc["c"], tc["mean"], tc["rstd"], st.p32(f"{bn}.weight"), ws["coef"], st.g32(f"{bn}.weight"),
+                               st.g32(f"{bn}.bias"), ops.ACT_SWISH, False, beta=st.p32(f"{bn}.bias"))
     du = ops.glu_dwconv_bwd(dc, tc["u"], st.p32(f"{cm}.depthwise_conv.weight"), st.g32(f"{cm}.depthwise_conv.weight"),
                             st.g32(f"{cm}.depthwise_conv.bias"), B, T, D, K)
     dt3 = _lin_bwd(model, st, f"{cm}.pointwise_cov1", tc["tn"], du, R, D, 2 * D)

@@ -514,7 +514,7 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
     dx = ops.avgpool_bwd(dfeats, tape["trunk_out_shape"])
     # ReLU trunk: the launch that produces the gradient of a BatchNorm+ReLU output also masks it and takes the first pass of that
     # BatchNorm's backward in its epilogue (ops.conv2d_dgrad_bn); dx_stats != None means dx already is that masked gradient.
-    fused = act == 1 and ops.BN_BWD_FUSED
+    fused = act in (1, 2) and ops.BN_BWD_FUSED       # 1 ReLU (LRW), 2 Swish (LRS): the epilogue masks / multiplies by swish'
     dx_stats = None
     blocks = list(_trunk_blocks(model))
     for bi in range(len(blocks) - 1, -1, -1):
@@ -534,9 +534,9 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
         ws1 = st.bn[t1["bn"]]
         w2t = st.t16(f"{prefix}.conv2.weight").view(planes, 3, 3, planes)
         if fused:
-            # bn1 has no residual branch: the mask is recomputed from its input (y is not read)
+            # bn1 has no residual branch: the mask / pre-activation is recomputed from its input (y is not read)
             g1, st1 = ops.conv2d_dgrad_bn(dc2, w2t, 3, 1, 1, t2["x"].shape[1:3], None, None, t1["c"], t1["mean"], t1["rstd"],
-                                          st.p32(f"{t1['bn']}.weight"), st.p32(f"{t1['bn']}.bias"))
+                                          st.p32(f"{t1['bn']}.weight"), st.p32(f"{t1['bn']}.bias"), act)
             dc1 = ops.bn_bwd_from_stats(g1, t1["c"], t1["mean"], t1["rstd"], st.p32(f"{t1['bn']}.weight"), st1, ws1["coef"],
                                         st.g32(f"{t1['bn']}.weight"), st.g32(f"{t1['bn']}.bias"))
         else:
@@ -547,6 +547,9 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
         in_hw = t1["x"].shape[1:3]
         w1t = st.t16(f"{prefix}.conv1.weight").view(inp, 3, 3, planes)
         tp = tape[f"{blocks[bi - 1][0]}.conv2"] if fused and bi > 0 else None       # the block below: its output is this block's input
+        if tp is not None:      # what the epilogue needs of that output: ReLU its value (the mask), Swish its residual input
+            tp_aux = tp["y"] if act == 1 else tp["res"]
+            tp_gb = (st.p32(f"{tp['bn']}.weight"), st.p32(f"{tp['bn']}.bias"), act)
         if down:
             td = tape[f"{prefix}.downsample.0"]
             wsd = st.bn[td["bn"]]
@@ -556,12 +559,12 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
             wdt = st.t16(f"{prefix}.downsample.0.weight").view(inp, 1, 1, planes)
             if tp is not None:
                 dxd = ops.conv2d_dgrad(dcd, wdt, 1, stride, 0, in_hw)
-                dx, dx_stats = ops.conv2d_dgrad_bn(dc1, w1t, 3, stride, 1, in_hw, dxd, tp["y"], tp["c"], tp["mean"], tp["rstd"])
+                dx, dx_stats = ops.conv2d_dgrad_bn(dc1, w1t, 3, stride, 1, in_hw, dxd, tp_aux, tp["c"], tp["mean"], tp["rstd"], *tp_gb)
             else:
                 dxa = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw)
                 dx, dx_stats = ops.conv2d_dgrad(dcd, wdt, 1, stride, 0, in_hw, addend=dxa), None
         elif tp is not None:
-            dx, dx_stats = ops.conv2d_dgrad_bn(dc1, w1t, 3, stride, 1, in_hw, dres, tp["y"], tp["c"], tp["mean"], tp["rstd"])
+            dx, dx_stats = ops.conv2d_dgrad_bn(dc1, w1t, 3, stride, 1, in_hw, dres, tp_aux, tp["c"], tp["mean"], tp["rstd"], *tp_gb)
         else:
             dx, dx_stats = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw, addend=dres), None
         _ready(model, st, f"{prefix}.conv1.weight")

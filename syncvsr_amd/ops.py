@@ -348,18 +348,19 @@ BN_BWD_FUSED = True    # ReLU trunk: first pass of the BatchNorm backward inside
 
 def conv2d_dgrad_bn(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad: int, in_hw: tuple[int, int],
                     addend: Optional[torch.Tensor], y: Optional[torch.Tensor], x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
-                    gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None):
+                    gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None, act: int = 1):
     """conv2d_dgrad whose result is the gradient of y = relu(bn(x) [+ residual]) (y, x shaped like the result): the launch stores
     g = (y > 0) * (dgrad + addend) instead and takes the first pass of that BatchNorm's backward in its epilogue.
     y=None (no residual branch): the mask is recomputed from x, gamma, beta and y is not read.
+    act=2 (Swish): g = (dgrad + addend) * swish'(bn(x) + r) where `y` is the residual INPUT r (or None); gamma / beta required.
     -> (g, (stats, rows)) for bn_bwd_from_stats.  In place when addend is given."""
     N, Ho, Wo, Co = dy.shape
     Ci = w16t.shape[0]
     H, W = in_hw
     if x.shape != (N, H, W, Ci) or not x.is_contiguous() or (y is not None and (y.shape != x.shape or not y.is_contiguous())):
         raise ValueError("conv2d_dgrad_bn: y / x must be contiguous tensors with the geometry of the result")
-    if y is None and (gamma is None or beta is None):
-        raise ValueError("conv2d_dgrad_bn: y=None needs gamma and beta")
+    if (y is None or act == 2) and (gamma is None or beta is None):
+        raise ValueError("conv2d_dgrad_bn: y=None / act=2 need gamma and beta")
     g = torch.empty((N, H, W, Ci), dtype=BF16, device=dy.device) if addend is None else addend
     if stride == 1 and _c64_ok(Ci, Co, k, stride, pad, W):
         taps = tuple((pad - kh, pad - kw, kh * k + kw) for kh in range(k) for kw in range(k))
@@ -367,12 +368,12 @@ def conv2d_dgrad_bn(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, p
         rows = _query("svsr_conv3x3_c64_stat_rows", N, H, W)[0]
         stats = scratch(rows * 2 * 64)
         _call("svsr_conv3x3_c64_dgrad_bn", _p(dy), _p(w16t), _p(g), _p(addend), _p(stats), N, H, W, _ints(tdy), _ints(tdx), _ints(tw),
-              _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _stream(), label="k_conv3x3_c64+bn", flops=2.0 * N * H * W * 64 * 64 * 9)
+              _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), act, _stream(), label="k_conv3x3_c64+bn", flops=2.0 * N * H * W * 64 * 64 * 9)
         return g, (stats, rows)
     plan = conv_plan(1, N, H, W, Ci, k, stride, pad)        # mode 1: every pixel of the result is visited once
     stats = scratch(plan.tiles * 2 * Ci)
     _call("svsr_igemm_dgrad_bn", _p(dy), _p(w16t), _p(g), _p(addend), _p(stats), plan.words.data_ptr(), plan.meta, N, Ho * Wo, Co, Co, Ci,
-          H * W, Ci, k * k, _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _stream(), label=plan.label + "+bn", flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
+          H * W, Ci, k * k, _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), act, _stream(), label=plan.label + "+bn", flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
     return g, (stats, plan.tiles)
 
 
@@ -439,6 +440,22 @@ def linear_dgrad(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, K: 
     igemm_fwd(plan, dy, w16t, out, Ci=Np, in_pitch=dy_pitch, Co=K, out_pitch=K, addend=addend, alpha=alpha, drop=drop,
               flops=2.0 * rows * N * K, **geo)
     return out
+
+
+def linear_dgrad_bn(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, K: int, dy_pitch: int, x: torch.Tensor, mean: torch.Tensor,
+                    rstd: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, act: int):
+    """linear_dgrad whose result is the gradient of act(bn(x)) (x [rows, K], no residual branch): the launch stores
+    g = dgrad * act'(bn(x)) instead and takes the first pass of that BatchNorm's backward in its epilogue (see conv2d_dgrad_bn).
+    -> (g, (stats, rows)) for bn_bwd_from_stats."""
+    Np = w16t.shape[-1]
+    if x.shape != (rows, K) or not x.is_contiguous():
+        raise ValueError("linear_dgrad_bn: x must be a contiguous [rows, K] tensor")
+    g = torch.empty((rows, K), dtype=BF16, device=dy.device)
+    plan = rows_plan(rows, 1, 0, 0, K)
+    stats = scratch(plan.tiles * 2 * K)
+    _call("svsr_igemm_dgrad_bn", _p(dy), _p(w16t), _p(g), None, _p(stats), plan.words.data_ptr(), plan.meta, rows, 1, Np, dy_pitch, K,
+          1, K, 1, None, _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), act, _stream(), label=plan.label + "+bn", flops=2.0 * rows * N * K)
+    return g, (stats, plan.tiles)
 
 
 def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, rows: int, K: int, N: int, x_pitch: int, dy_pitch: int,

@@ -360,6 +360,97 @@ def test_conv_dgrad_with_bn_backward_epilogue(dev, case):
     assert torch.equal(g3, g) and torch.equal(stat_sums(stats3, Ci), sums)
 
 
+@pytest.mark.parametrize("case", [DGRAD_BN_CASES[0], DGRAD_BN_CASES[1], DGRAD_BN_CASES[2], DGRAD_BN_CASES[3], DGRAD_BN_CASES[5]])
+def test_conv_dgrad_with_swish_bn_backward_epilogue(dev, case):
+    """The Swish variant (LRS trunk): g = (dgrad + addend) * swish'(bn(x) + residual), sums of g and g * xhat, then the apply pass ==
+    data gradient followed by BatchNorm+Swish backward in fp32; and == the separate passes up to one bf16 rounding of g."""
+    from syncvsr_amd import ops
+
+    N, H, W, Ci, Co, k, s, p, use_add = case
+    Ho, Wo = ops.conv_out_size(H, k, s, p), ops.conv_out_size(W, k, s, p)
+    dy = rnd((N, Ho, Wo, Co), 3)
+    w = rnd((Co, k, k, Ci), 4, 1.0 / math.sqrt(k * k * Co))
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    add = rnd((N, H, W, Ci), 5) if use_add else None
+    xb = rnd((N, H, W, Ci), 6, 2.0) + 0.3
+    res = rnd((N, H, W, Ci), 7) if use_add else None
+    g_ = torch.Generator().manual_seed(8)
+    gamma = 1 + 0.2 * torch.randn(Ci, generator=g_)
+    beta = 0.2 * torch.randn(Ci, generator=g_)
+    xs = torch.zeros(N, Ci, H, W, requires_grad=True)
+    F.conv2d(xs, w.float().permute(0, 3, 1, 2), stride=s, padding=p).backward(nchw(dy.float()))
+    dout = (nhwc(xs.grad) + (add.float() if use_add else 0.0)).to(BF).float()
+    xf = xb.float()
+    mean, var = xf.mean((0, 1, 2)), xf.var((0, 1, 2), unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    xhat = (xf - mean) * rstd
+    z = (xhat * gamma + beta + (res.float() if res is not None else 0.0)).requires_grad_(True)
+    (z * torch.sigmoid(z)).sum().backward()
+    gref = dout * z.grad
+    cnt = N * H * W
+    s1, s2 = gref.sum((0, 1, 2)), (gref * xhat).sum((0, 1, 2))
+    dxb_ref = gamma * rstd * (gref - s1 / cnt - xhat * s2 / cnt)
+    m, r = mean.to(dev), rstd.to(dev)
+    g, stats = ops.conv2d_dgrad_bn(dy.to(dev), wt.to(dev), k, s, p, (H, W), None if add is None else add.to(dev).clone(),
+                                   None if res is None else res.to(dev), xb.to(dev), m, r, gamma.to(dev), beta.to(dev), act=2)
+    check(g, gref, "dgrad_bn_swish.g", 2e-2, 8e-3)
+    sums = stat_sums(stats, Ci)
+    check(sums[0], s1, "dgrad_bn_swish.sum_g", 1e-2, 6e-3)
+    check(sums[1], s2, "dgrad_bn_swish.sum_g_xhat", 1e-2, 6e-3)
+    coef = torch.empty(3 * Ci, device=dev)
+    dg = torch.zeros(Ci, device=dev); db = torch.zeros(Ci, device=dev)
+    dxb = ops.bn_bwd_from_stats(g, xb.to(dev), m, r, gamma.to(dev), stats, coef, dg, db)
+    check(dxb, dxb_ref, "dgrad_bn_swish.dx", 2e-2, 8e-3)
+    check(dg, s2, "dgrad_bn_swish.dgamma", 1e-2, 6e-3)
+    check(db, s1, "dgrad_bn_swish.dbeta", 1e-2, 6e-3)
+    # the separate passes on the same inputs
+    do = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), k, s, p, (H, W), addend=None if add is None else add.to(dev).clone())
+    y_dev = ops.bn_act_fwd(xb.to(dev), None if res is None else res.to(dev), m, r, gamma.to(dev), beta.to(dev), 2)
+    dg2 = torch.zeros(Ci, device=dev); db2 = torch.zeros(Ci, device=dev)
+    dxb2, dres2 = ops.bn_act_bwd(do, y_dev, xb.to(dev), m, r, gamma.to(dev), coef, dg2, db2, 2, True, beta=beta.to(dev),
+                                 res=None if res is None else res.to(dev))
+    check(g, dres2.float().cpu(), "dgrad_bn_swish.g vs separate passes", 1e-2, 4e-3)
+    check(dxb, dxb2.float().cpu(), "dgrad_bn_swish.dx vs separate passes", 1.5e-2, 5e-3)
+    check(dg, dg2.cpu(), "dgrad_bn_swish.dgamma vs separate passes", 3e-3, 3e-3)
+    g3, stats3 = ops.conv2d_dgrad_bn(dy.to(dev), wt.to(dev), k, s, p, (H, W), None if add is None else add.to(dev).clone(),
+                                     None if res is None else res.to(dev), xb.to(dev), m, r, gamma.to(dev), beta.to(dev), act=2)
+    assert torch.equal(g3, g) and torch.equal(stat_sums(stats3, Ci), sums)
+
+
+def test_linear_dgrad_with_swish_bn_backward_epilogue(dev):
+    """ops.linear_dgrad_bn (Conformer convolution module: pointwise_conv2's data gradient -> BatchNorm1d + Swish backward)."""
+    from syncvsr_amd import ops
+
+    R, D = 2400, 768
+    dy = rnd((R, D), 3)
+    w = rnd((D, D), 4, 1.0 / math.sqrt(D))            # [N out][K in]
+    wt = w.t().contiguous().view(D, 1, D)             # transposed shadow [K][1][N]
+    xb = rnd((R, D), 6, 2.0) + 0.3
+    g_ = torch.Generator().manual_seed(8)
+    gamma = 1 + 0.2 * torch.randn(D, generator=g_)
+    beta = 0.2 * torch.randn(D, generator=g_)
+    dout = (dy.float() @ w.float()).to(BF).float()
+    xf = xb.float()
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    xhat = (xf - mean) * rstd
+    z = (xhat * gamma + beta).requires_grad_(True)
+    (z * torch.sigmoid(z)).sum().backward()
+    gref = dout * z.grad
+    s1, s2 = gref.sum(0), (gref * xhat).sum(0)
+    dxb_ref = gamma * rstd * (gref - s1 / R - xhat * s2 / R)
+    m, r = mean.to(dev), rstd.to(dev)
+    g, stats = ops.linear_dgrad_bn(dy.to(dev), wt.to(dev), rows=R, N=D, K=D, dy_pitch=D, x=xb.to(dev), mean=m, rstd=r,
+                                   gamma=gamma.to(dev), beta=beta.to(dev), act=2)
+    check(g, gref, "linear_dgrad_bn.g", 2e-2, 8e-3)
+    coef = torch.empty(3 * D, device=dev)
+    dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev)
+    dxb = ops.bn_bwd_from_stats(g, xb.to(dev), m, r, gamma.to(dev), stats, coef, dg, db)
+    check(dxb, dxb_ref, "linear_dgrad_bn.dx", 2e-2, 8e-3)
+    check(dg, s2, "linear_dgrad_bn.dgamma", 1e-2, 6e-3)
+    check(db, s1, "linear_dgrad_bn.dbeta", 1e-2, 6e-3)
+
+
 @pytest.mark.parametrize("Hc,Wc", [(12, 12), (11, 9), (44, 44)])
 def test_stem_bn_gelu_pool(dev, Hc, Wc):
     from syncvsr_amd import ops
