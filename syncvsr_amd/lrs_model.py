@@ -628,10 +628,21 @@ class _LrsFunction(torch.autograd.Function):
         Vp = (Vo + 63) // 64 * 64
         if model.mtlalpha > 0.0:
             dctc = model._d("ctc.in")
-            h_ctc = ops.scale_bf16(h, 1.0, drop=dctc) if dctc is not None else h               # ctc_lo(dropout(hs_pad)), ctc.py:97
-            logits_c = ops.linear_fwd(h_ctc, st.s16("ctc.ctc_lo.weight"), st.p32("ctc.ctc_lo.bias"), rows=R, K=D, N=Vo, x_pitch=D, out_f32=True,
-                                      out_pitch=Vp)[0]
-            loss_c, ctc_state = ops.ctc_fwd(logits_c, Vp, tg.labels, ilen, B, T, Vo)
+            box: dict[str, Any] = {}
+
+            def ctc_branch():
+                hc = ops.scale_bf16(h, 1.0, drop=dctc) if dctc is not None else h               # ctc_lo(dropout(hs_pad)), ctc.py:97
+                lc = ops.linear_fwd(hc, st.s16("ctc.ctc_lo.weight"), st.p32("ctc.ctc_lo.bias"), rows=R, K=D, N=Vo, x_pitch=D, out_f32=True,
+                                    out_pitch=Vp)[0]
+                box["h_ctc"], box["logits_c"] = hc, lc
+                box["loss_c"], box["ctc_state"] = ops.ctc_fwd(lc, Vp, tg.labels, ilen, B, T, Vo)
+
+            # the CTC branch (its lattice is T sequential steps: ~300 us of latency, not of work) runs on the side stream next to the
+            # attention decoder's forward; both only read the encoder output.  Joined below, before anything uses its results.
+            if ops.CTC_SIDE:
+                model._side.run(ctc_branch, h, small=True)
+            else:
+                ctc_branch()
         else:                                      # `loss_ctc = 0` (e2e_asr_transformer.py:205-208)
             dctc = h_ctc = logits_c = ctc_state = None
             loss_c = torch.zeros((), dtype=torch.float32, device=x.device)
@@ -647,6 +658,10 @@ class _LrsFunction(torch.autograd.Function):
         loss_att, lse_p, counts = ops.ls_loss_fwd(pred, Vp, tgt, B * L, Vo, model.lsm_weight, inv_denom)
         if model.length_norm:
             loss_att = loss_att / counts[1]
+        if model.mtlalpha > 0.0:
+            if ops.CTC_SIDE:
+                model._side.join()
+            h_ctc, logits_c, loss_c, ctc_state = box["h_ctc"], box["logits_c"], box["loss_c"], box["ctc_state"]
         model._last = dict(feats=feats, enc_out=h, pred=pred, logits_audio=logits_a, logits_ctc=logits_c)
         if need_grad:
             tape["head"] = dict(hx=hx, h=h, mA=mA, rA=rA, logits_a=logits_a, lse_a=lse_a, tok=tok, logits_c=logits_c, ctc_state=ctc_state,

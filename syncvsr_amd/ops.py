@@ -93,6 +93,10 @@ def tune(key: str, value: int) -> None:
         global BN_BWD_FUSED
         BN_BWD_FUSED = bool(value)
         return
+    if key == "ctc_side":
+        global CTC_SIDE
+        CTC_SIDE = bool(value)
+        return
     rc = _lib.load().svsr_tune(key.encode(), int(value))
     if rc != 0:
         _lib.check(rc, f"svsr_tune({key})")
@@ -343,6 +347,7 @@ def conv2d_dgrad(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad:
     return dx
 
 
+CTC_SIDE = True         # LRS: the CTC branch of the forward on the model's side stream, beside the attention decoder (tuning knob "ctc_side")
 BN_BWD_FUSED = True    # ReLU trunk: first pass of the BatchNorm backward inside the producing data-gradient launch (False: separate pass)
 
 
