@@ -314,18 +314,38 @@ __global__ __launch_bounds__(256) void k_embed_pos_fwd(const long* __restrict__ 
     }
 }
 
-// Rows of a repeated token are added in increasing row order by the threads of its FIRST occurrence (no atomics).
+// Rows of a repeated token are added in increasing row order by the workgroup of its FIRST occurrence (no floating-point atomics).
+// One workgroup per row: its threads look for an earlier occurrence together, mark the later ones in an LDS bit mask and then walk the
+// set bits in increasing order, one column per thread.  (The first version let every (row, column) thread scan all rows by itself:
+// R dependent loads per element, 211 us for 1,600 x 768.)
+#define EMB_MAX_ROWS 16384
 __global__ __launch_bounds__(256) void k_embed_pos_bwd(const long* __restrict__ tok, const bf16_t* __restrict__ dx, float* __restrict__ demb,
                                                        int R, int D, float scale) {
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)R * D; idx += (long)gridDim.x * 256) {
-        const int r = (int)(idx / D), c = (int)(idx - (long)r * D);
-        const long tk = tok[r];
-        bool first = true;
-        for (int r2 = 0; r2 < r; ++r2) first = first && tok[r2] != tk;
-        if (!first) continue;
+    __shared__ unsigned s_bits[EMB_MAX_ROWS / 32];
+    __shared__ int s_dup;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const long tk = tok[r];
+    const int nwords = (R + 31) >> 5;
+    if (tid == 0) s_dup = 0;
+    for (int w = tid; w < nwords; w += 256) s_bits[w] = 0u;
+    __syncthreads();
+    for (int r2 = tid; r2 < R; r2 += 256) {
+        if (tok[r2] != tk) continue;
+        if (r2 < r) s_dup = 1;                                   // (every writer writes the same value)
+        else atomicOr(&s_bits[r2 >> 5], 1u << (r2 & 31));
+    }
+    __syncthreads();
+    if (s_dup) return;
+    for (int c = tid; c < D; c += 256) {
         float acc = 0.f;
-        for (int r2 = r; r2 < R; ++r2)
-            if (tok[r2] == tk) acc += bf2f(dx[(long)r2 * D + c]) * scale;
+        for (int w = r >> 5; w < nwords; ++w) {
+            unsigned m = s_bits[w];
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1;
+                acc += bf2f(dx[(long)(w * 32 + b) * D + c]) * scale;
+            }
+        }
         demb[tk * D + c] += acc;
     }
 }
@@ -507,7 +527,8 @@ int svsr_embed_pos_fwd(const int64_t* tok, const float* emb, const float* pe, vo
 }
 
 int svsr_embed_pos_bwd(const int64_t* tok, const void* dx, float* demb, int R, int D, float scale, hipStream_t stream) {
-    hipLaunchKernelGGL(k_embed_pos_bwd, dim3(grid1d((long)R * D)), dim3(256), 0, stream, (const long*)tok, (const bf16_t*)dx, demb, R, D, scale);
+    if (R < 1 || R > EMB_MAX_ROWS || D < 1) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_embed_pos_bwd, dim3(R), dim3(256), 0, stream, (const long*)tok, (const bf16_t*)dx, demb, R, D, scale);
     return svsr_check_launch();
 }
 

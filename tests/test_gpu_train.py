@@ -198,12 +198,8 @@ def test_training_steps_are_bit_reproducible_at_batch_32(use_graph):
     assert torch.isfinite(a[0]).all() and float(a[0][2]) < float(a[0][1])
 
 
-def test_rccl_single_rank_collective_path_equals_plain_step():
-    """The data-parallel path on ONE rank: RCCL (torch.distributed backend "nccl") all-reduces every gradient bucket on the comm
-    stream while the backward still runs, parameters and BatchNorm buffers are broadcast from rank 0 — eager and captured into
-    a HIP graph.  With a single rank every collective is the identity, so the results must EQUAL the plain step bit for bit."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+def _rccl_single_rank_case():
+    """Body of test_rccl_single_rank_collective_path_equals_plain_step (runs in a process of its own)."""
     import os
 
     import torch.distributed as dist
@@ -249,6 +245,34 @@ def test_rccl_single_rank_collective_path_equals_plain_step():
     for name, got in (("eager+RCCL", eager), ("graph+RCCL", graph)):
         for what, x, y in zip(("losses", "parameters", "running statistics"), got, plain):
             assert torch.equal(x, y), f"{name}: {what} differ from the plain step"
+    print("RCCL_CASE_OK")
+
+
+def test_rccl_single_rank_collective_path_equals_plain_step():
+    """The data-parallel path on ONE rank: RCCL (torch.distributed backend "nccl") all-reduces every gradient bucket on the comm
+    stream while the backward still runs, parameters and BatchNorm buffers are broadcast from rank 0 — eager and captured into
+    a HIP graph.  With a single rank every collective is the identity, so the results must EQUAL the plain step bit for bit.
+
+    Runs in a process of its own: torch's ProcessGroupNCCL watchdog thread has (once in ~40 runs, and only after other tests had
+    captured graphs in the same process) aborted the interpreter with hipErrorCapturedEvent while polling its events next to a HIP
+    graph capture — an abort here must not take the rest of the suite with it.  One retry for exactly that signature."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = "import sys; sys.path.insert(0, %r); import test_gpu_train as t; t._rccl_single_rank_case()" % here
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(here), os.environ.get("PYTHONPATH", "")]))
+    for attempt in range(2):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(here))
+        if r.returncode == 0 and "RCCL_CASE_OK" in r.stdout:
+            return
+        watchdog_abort = r.returncode in (-6, 134) and "watchdog" in r.stderr and "apturing" in r.stderr
+        if not (watchdog_abort and attempt == 0):
+            break
+    raise AssertionError(f"RCCL single-rank case failed (exit {r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}")
 
 
 def test_checkpoint_resume_lrs():
