@@ -557,12 +557,13 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
                                     st.g32(f"{td['bn']}.weight"), st.g32(f"{td['bn']}.bias"), 0, False)
             _conv_wgrad(model, st, f"{prefix}.downsample.0", td, dcd, use_tr)
             wdt = st.t16(f"{prefix}.downsample.0.weight").view(inp, 1, 1, planes)
+            # the 1x1 branch first (pixels its stride skips are written as zeros), the 3x3 branch adds to it: the launch that completes
+            # the block's input gradient is the one with the taps that reach every pixel
+            dxd = ops.conv2d_dgrad(dcd, wdt, 1, stride, 0, in_hw)
             if tp is not None:
-                dxd = ops.conv2d_dgrad(dcd, wdt, 1, stride, 0, in_hw)
                 dx, dx_stats = ops.conv2d_dgrad_bn(dc1, w1t, 3, stride, 1, in_hw, dxd, tp_aux, tp["c"], tp["mean"], tp["rstd"], *tp_gb)
             else:
-                dxa = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw)
-                dx, dx_stats = ops.conv2d_dgrad(dcd, wdt, 1, stride, 0, in_hw, addend=dxa), None
+                dx, dx_stats = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw, addend=dxd), None
         elif tp is not None:
             dx, dx_stats = ops.conv2d_dgrad_bn(dc1, w1t, 3, stride, 1, in_hw, dres, tp_aux, tp["c"], tp["mean"], tp["rstd"], *tp_gb)
         else:
