@@ -228,7 +228,13 @@ class GradReducer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.always = always and dist.is_initialized()
         self.bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
+        # the bucket at the bottom of the buffer (stem, layer1: final only when the backward ends) is the one collective nothing can
+        # hide: bucket edges are anchored so that it holds at most 4 MB, whatever is left over goes to the FIRST bucket (top of the
+        # buffer, ready earliest)
+        self.last_elems = min(self.bucket_elems, 1 << 20)
         self._buffers_pending = False
+        self._st = None
+        self._backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self.top = 0
         self.launched: list[tuple[int, int]] = []
@@ -260,7 +266,7 @@ class GradReducer:
             dist.broadcast(st.bufflat, src=src, group=self.group)
 
     def begin_step(self) -> None:
-        st = self.model.store()
+        st = self._st = self.model.store()         # (store() re-validates ~300 tensors: once per step, not once per hook call)
         self.top = st.decay_end
         self.launched = []
         if self.comm_stream is None and st.flat.is_cuda:
@@ -273,11 +279,11 @@ class GradReducer:
         if hi <= lo:
             return
         self.launched.append((lo, hi))
-        st = self.model.store()
+        st = self._st if self._st is not None else self.model.store()
         seg = st.grad[lo:hi]
         if self.world == 1 and not self.always:
             return
-        backend = dist.get_backend(self.group)
+        backend = self._backend
         if seg.is_cuda:
             self.comm_stream.wait_stream(torch.cuda.current_stream())     # the segment's producers are enqueued there ...
             side = getattr(self.model, "_side", None)
@@ -303,25 +309,28 @@ class GradReducer:
             seg.div_(self.world)
 
     def on_ready(self, lo: int) -> None:
-        st = self.model.store()
+        st = self._st if self._st is not None else self.model.store()
         if lo == 0:
             self._reduce(0, self.top)
             self.top = 0
             self._reduce(st.decay_end, st.numel)
             return
-        while self.top - lo >= self.bucket_elems:
-            self._reduce(self.top - self.bucket_elems, self.top)
-            self.top -= self.bucket_elems
+        while self.top > self.last_elems:
+            edge = self.last_elems + (self.top - 1 - self.last_elems) // self.bucket_elems * self.bucket_elems     # lower edge of the top bucket
+            if edge < lo:
+                break
+            self._reduce(edge, self.top)
+            self.top = edge
 
     def finish(self) -> None:
         if (self.world > 1 or self.always) and self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
             # DDP re-broadcasts the buffers before every forward; here the collective is enqueued right after the backward's
             # BatchNorm updates on the comm stream, where it overlaps the optimiser and the host's enqueue of the next step
-            st = self.model.store()
+            st = self._st if self._st is not None else self.model.store()
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self._broadcast_buffers(st)
             self._buffers_pending = True
         elif self.world > 1 or self.always:
-            self._broadcast_buffers(self.model.store())
+            self._broadcast_buffers(self._st if self._st is not None else self.model.store())

@@ -327,6 +327,7 @@ class _ParamStore:
         decay = sorted([(n, s) for n, s, k in specs if len(s) >= 2], key=lambda e: fwd_rank(e[0]))   # stable
         nodecay = [(n, s) for n, s, k in specs if len(s) < 2]
         self.offsets: dict[str, tuple[int, int, tuple[int, ...]]] = {}
+        self._vc: dict = {}        # cached views of the flat buffers (p32 / g32 / s16 / t16)
         off = 0
         phys = getattr(model, "_phys", {})
         self.phys: dict[str, tuple[int, ...]] = {n: tuple(phys.get(n, s)) for n, s, _ in specs}
@@ -421,21 +422,34 @@ class _ParamStore:
         return seg.view(shape)
 
     # -- accessors used by the engine -------------------------------------------------------------
+    # (the views are cached: the flat buffers are never reallocated, and building ~400 tensor views per step was 0.3 ms of host time)
     def p32(self, name: str) -> torch.Tensor:
-        o, n, _ = self.offsets[name]
-        return self.flat[o : o + n]
+        v = self._vc.get(("p", name))
+        if v is None:
+            o, n, _ = self.offsets[name]
+            v = self._vc[("p", name)] = self.flat[o : o + n]
+        return v
 
     def g32(self, name: str) -> torch.Tensor:
-        o, n, _ = self.offsets[name]
-        return self.grad[o : o + n]
+        v = self._vc.get(("g", name))
+        if v is None:
+            o, n, _ = self.offsets[name]
+            v = self._vc[("g", name)] = self.grad[o : o + n]
+        return v
 
     def s16(self, name: str, numel: Optional[int] = None) -> torch.Tensor:
-        o, n, _ = self.offsets[name]
-        return self.w16[o : o + (numel or n)]
+        v = self._vc.get(("s", name, numel))
+        if v is None:
+            o, n, _ = self.offsets[name]
+            v = self._vc[("s", name, numel)] = self.w16[o : o + (numel or n)]
+        return v
 
     def t16(self, key: str) -> torch.Tensor:
-        o, (Bd, T, Apad) = self.t_offsets[key]
-        return self.w16t[o : o + Bd * T * Apad].view(Bd, T, Apad)
+        v = self._vc.get(("t", key))
+        if v is None:
+            o, (Bd, T, Apad) = self.t_offsets[key]
+            v = self._vc[("t", key)] = self.w16t[o : o + Bd * T * Apad].view(Bd, T, Apad)
+        return v
 
     def span(self, name: str, numel: Optional[int] = None) -> tuple[int, int]:
         o, n, _ = self.offsets[name]

@@ -217,6 +217,7 @@ _WORKER = textwrap.dedent("""
         assert lo == pos, (lo, pos)
         pos = hi
     assert pos == st.numel and len(covered) >= 3
+    assert covered[0] == (0, min(1 << 20, covered[0][1])), "the bucket reduced after the backward holds at most 4 MB"
     dist.barrier(); dist.destroy_process_group()
     print("ok", rank)
 """)
