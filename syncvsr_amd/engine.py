@@ -147,6 +147,7 @@ class TrainStep:
         return self._out
 
     def _capture(self, *batch) -> None:
+        ops.PLAN_CACHE_PINNED = True       # the captured launches reference the plans' device words
         self._static = [t.clone() for t in batch]
         # warm-up on a side stream (allocator pools, hipFuncSetAttribute, lazy module loads), state restored afterwards
         st = self.model.store()

@@ -61,7 +61,19 @@ def scratch(nfloats: int) -> torch.Tensor:
     return t
 
 
-_PLAN_CACHE: dict = {}
+class _BoundedCache(dict):
+    """Per-shape launch plans and shape queries.  Variable-length batches (LRS without the length buckets) meet a new shape almost every
+    step: beyond PLAN_CACHE_MAX entries the cache starts over, so host and device memory stay bounded (a plan costs ~50 us to rebuild)."""
+
+    def __setitem__(self, key, value):
+        if len(self) >= PLAN_CACHE_MAX and not PLAN_CACHE_PINNED:
+            self.clear()
+        super().__setitem__(key, value)
+
+
+PLAN_CACHE_MAX = 20000
+PLAN_CACHE_PINNED = False       # set once a HIP graph has captured launches: their plans' device words must stay alive
+_PLAN_CACHE: dict = _BoundedCache()
 
 
 def _query(name: str, *args) -> tuple:
@@ -493,10 +505,11 @@ def stem_conv_fwd(videos: torch.Tensor, w: torch.Tensor, want_stats: bool = Fals
         st = (stats, rows)
     nws = _query("svsr_stem_conv_fwd_ws_bytes", B, T, H, W)[0]
     ws = None
-    if nws:         # bf16 copy of the clip + packed weights for the DMA-fed kernel (a per-shape buffer: `stats` lives in the shared scratch)
-        ws = _STEM_WS.get((B, T, H, W, videos.device))
+    if nws:         # bf16 copy of the clip + packed weights for the DMA-fed kernel: one grow-only buffer per device and stream (`stats`
+        key = (videos.device, _stream())        # lives in the shared scratch; variable-length LRS batches must not pile up one buffer per shape)
+        ws = _STEM_WS.get(key)
         if ws is None or ws.numel() < nws:
-            ws = _STEM_WS[(B, T, H, W, videos.device)] = torch.empty(nws, dtype=torch.uint8, device=videos.device)
+            ws = _STEM_WS[key] = torch.empty(nws, dtype=torch.uint8, device=videos.device)
     _call("svsr_stem_conv_fwd", _p(videos), _p(w), _p(out), _p(stats), B, T, H, W, _p(ws), nws, _stream(),
           label="k_stem_conv_fwd", flops=2.0 * B * T * (H // 2) * (W // 2) * 64 * 245)
     return out, st
