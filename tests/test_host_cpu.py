@@ -282,3 +282,33 @@ def test_lrs_host_logic():
     a, b = keep_mask(5, sites["enc.0.ff.out"], 0.1, 100000), keep_mask(5, sites["enc.0.ff.out"], 0.1, 100000)
     c = keep_mask(5, sites["enc.1.ff.out"], 0.1, 100000)
     assert (a == b).all() and abs(a.mean() - 0.9) < 5e-3 and abs((a == c).mean() - 0.82) < 1e-2
+
+
+def test_plan_cache_is_bounded_for_variable_shapes(monkeypatch):
+    """ops._PLAN_CACHE (per-shape launch plans / shape queries): variable-length batches meet new shapes for ever — the cache starts over
+    at PLAN_CACHE_MAX entries, except once a HIP graph has captured launches that reference the plans' device words."""
+    from syncvsr_amd import ops
+
+    cache = ops._BoundedCache()
+    monkeypatch.setattr(ops, "PLAN_CACHE_MAX", 5)
+    monkeypatch.setattr(ops, "PLAN_CACHE_PINNED", False)
+    for i in range(5):
+        cache[i] = i
+    assert len(cache) == 5
+    cache[5] = 5                      # the sixth shape: start over
+    assert list(cache) == [5]
+    monkeypatch.setattr(ops, "PLAN_CACHE_PINNED", True)
+    for i in range(10, 20):
+        cache[i] = i
+    assert len(cache) == 11           # pinned: nothing is dropped
+
+
+def test_header_parser_handles_every_declaration_form():
+    """_lib.parse_header: int and int64_t return types, (void) parameter lists, pointer / scalar argument kinds."""
+    from syncvsr_amd import _lib
+
+    h = _lib.parse_header()
+    assert "svsr_stem_conv_fwd_ws_bytes" in h and _lib._RESTYPE["svsr_stem_conv_fwd_ws_bytes"] == "int64_t"
+    assert _lib._RESTYPE["svsr_igemm_fwd"] == "int"
+    assert [t for t, _ in h["svsr_tune"]] == ["const char*", "int"]
+    assert all(name.startswith("svsr_") for name in h) and len(h) >= 69
