@@ -10,9 +10,10 @@
 
 // ---------------------------------------------------------------------------------------------------------------------
 // GLU + depthwise conv.  u [B*T][2D] bf16 (value | gate), w [D][K] fp32, bias [D] -> c [B*T][D] bf16, BN partial sums.
-// block = (64-frame tile, 64-channel group, batch item); the gated input (tile + halo) is staged in LDS as fp32.
+// block = (DW_TT-frame tile, 64-channel group, batch item); the gated input (tile + halo) is staged in LDS as fp32.
 // ---------------------------------------------------------------------------------------------------------------------
-#define DW_TT 64
+#define DW_TT 32                 // frames per workgroup tile (64 left each thread a serial loop of 16 frames x 31 taps and 576 workgroups)
+#define DW_FPT (DW_TT / 4)       // frames per thread: four wave-quarters of a tile
 #define DW_MAXK 31
 
 __device__ __forceinline__ void dw_stage_glu(float* sG, const bf16_t* __restrict__ u, int b, int T, int D, int t_lo, int rows, int c0) {
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void k_glu_dwconv_fwd(const bf16_t* __restrict
     for (int k = 0; k < DW_MAXK; ++k) wk[k] = k < K ? w[(long)(c0 + ch) * K + k] : 0.f;
     const float bs = bias[c0 + ch];
     float s1 = 0.f, s2 = 0.f;
-    for (int tl = tq * 16; tl < tq * 16 + 16; ++tl) {
+    for (int tl = tq * DW_FPT; tl < tq * DW_FPT + DW_FPT; ++tl) {
         const int t = t0 + tl;
         if (t >= T) break;
         float acc = bs;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void k_glu_dwconv_fwd(const bf16_t* __restrict
         if (threadIdx.x < 128) {
             const int which = threadIdx.x >> 6;
             const float v = ((sRed[0][which][ch] + sRed[1][which][ch]) + sRed[2][which][ch]) + sRed[3][which][ch];
-            const long row = (long)blockIdx.z * gridDim.x + blockIdx.x;      // one row of partials per (clip, 64-frame tile)
+            const long row = (long)blockIdx.z * gridDim.x + blockIdx.x;      // one row of partials per (clip, DW_TT-frame tile)
             stats[(row * 2 + which) * D + c0 + ch] = v;
         }
     }
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(256) void k_glu_dwconv_fwd(const bf16_t* __restrict
 // backward: dc [B*T][D] -> du [B*T][2D]; per-block partial dw/dbias into part[split][D*(K+1)] (reduced by k_dw_reduce)
 __global__ __launch_bounds__(256) void k_glu_dwconv_bwd(const bf16_t* __restrict__ dc, const bf16_t* __restrict__ u, const float* __restrict__ w,
                                                         bf16_t* __restrict__ du, float* __restrict__ part, int B, int T, int D, int K, int ntt) {
-    __shared__ float sAll[2 * (DW_TT + DW_MAXK - 1) * 64];
+    constexpr int STAGE_F = 2 * (DW_TT + DW_MAXK - 1) * 64, RED_F = 4 * (DW_MAXK + 1) * 64;       // staging (g, dc) / final reduction
+    __shared__ float sAll[STAGE_F > RED_F ? STAGE_F : RED_F];
     float* sG = sAll;
     float* sDC = sAll + (DW_TT + DW_MAXK - 1) * 64;
     const int pad = (K - 1) / 2;
@@ -100,9 +102,21 @@ __global__ __launch_bounds__(256) void k_glu_dwconv_bwd(const bf16_t* __restrict
             for (int k = 0; k < 8; ++k) sDC[r * 64 + c8 * 8 + k] = g[k];
         }
         __syncthreads();
-        for (int tl = tq * 16; tl < tq * 16 + 16; ++tl) {
+        // this thread's DW_FPT (value, gate) pairs of u, requested together ahead of the frame loop: loaded inside it, every frame paid its
+        // own dependent global round trip (78 us per layer for 12 MB of traffic)
+        unsigned short ua[DW_FPT], ug[DW_FPT];
+#pragma unroll
+        for (int i = 0; i < DW_FPT; ++i) {
+            const int t = t0 + tq * DW_FPT + i;
+            const long o = ((long)b * T + (t < T ? t : T - 1)) * (2 * D) + c0 + ch;
+            ua[i] = u[o];
+            ug[i] = u[o + D];
+        }
+#pragma unroll
+        for (int i = 0; i < DW_FPT; ++i) {
+            const int tl = tq * DW_FPT + i;
             const int t = t0 + tl;
-            if (t >= T) break;
+            if (t >= T) continue;
             // c[t] = sum_k g[t+k-pad] w[k]  =>  dg[t] = sum_k dc[t-k+pad] w[k];  dw[k] += dc[t] g[t+k-pad]
             const float dct = sDC[(tl + pad) * 64 + ch];
             float dg = 0.f;
@@ -114,14 +128,14 @@ __global__ __launch_bounds__(256) void k_glu_dwconv_bwd(const bf16_t* __restrict
                 }
             dbs += dct;
             const long o = ((long)b * T + t) * (2 * D) + c0 + ch;
-            const float av = bf2f(u[o]), sg = sigmoid_fast(bf2f(u[o + D]));
+            const float av = bf2f(ua[i]), sg = sigmoid_fast(bf2f(ug[i]));
             du[o] = f2bf(dg * sg);
             du[o + D] = f2bf(dg * av * sg * (1.f - sg));
         }
     }
     // reduce the four frame-quarters of the block through LDS, then one plain store per (channel, tap)
     __syncthreads();
-    float* sR = sAll;    // [4][K+1][64] <= 32 KB of the 47 KB staging area
+    float* sR = sAll;    // [4][K+1][64]
 #pragma unroll
     for (int k = 0; k < DW_MAXK; ++k)
         if (k < K) sR[(tq * (K + 1) + k) * 64 + ch] = dwk[k];
@@ -140,7 +154,15 @@ __global__ void k_dw_reduce(const float* __restrict__ part, int nsplit, int D, i
     const int n = D * (K + 1);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int p = 0; p < nsplit; ++p) s += part[(long)p * n + i];
+        int p = 0;
+        for (; p + 8 <= nsplit; p += 8) {            // eight loads in flight, added in split order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(long)(p + k) * n + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; p < nsplit; ++p) s += part[(long)p * n + i];
         if (i < D * K) dw[i] += s;
         else dbias[i - D * K] += s;
     }
@@ -475,7 +497,7 @@ extern "C" {
 int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale,
                      hipStream_t stream);
 
-/* rows of [2][D] BatchNorm1d partials svsr_glu_dwconv_fwd writes (one per clip and 64-frame tile) */
+/* rows of [2][D] BatchNorm1d partials svsr_glu_dwconv_fwd writes (one per clip and DW_TT-frame tile) */
 int svsr_glu_dwconv_fwd_stat_rows(int B, int T) { return (B < 1 || T < 1) ? 0 : B * ((T + DW_TT - 1) / DW_TT); }
 
 int svsr_glu_dwconv_fwd(const void* u, const float* w, const float* bias, void* c, float* stats, int B, int T, int D, int K, hipStream_t stream) {

@@ -800,7 +800,7 @@ def glu_dwconv_fwd(u, w, bias, want_stats: bool, B: int, T: int, D: int, K: int)
     return c, st
 
 
-DW_SPLITS = 16
+DW_SPLITS = 96        # workgroups per 64-channel block of svsr_glu_dwconv_bwd: one (clip, 32-frame tile) each at B = 16, T <= 192 (16 splits left a quarter of the CUs idle with several tiles in a row each)
 
 
 def glu_dwconv_bwd(dc, u, w, dw, dbias, B: int, T: int, D: int, K: int) -> torch.Tensor:
