@@ -247,6 +247,8 @@ int svsr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, 
  * table: device array of {int64 src_off, dst_off; int32 A, T, Bd, Apad} (elements). */
 int svsr_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
 int svsr_transpose_cast_multi(const float* src, void* dst, const void* table, int n_entries, hipStream_t stream);
+/* the same from the bf16 shadow (src16: bf16 copy of the parameter buffer, same offsets): half the bytes read, identical result */
+int svsr_transpose_bf16_multi(const void* src16, void* dst, const void* table, int n_entries, hipStream_t stream);
 int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream);
 
 /* Device-side input pipeline (reference LRW/video/src/data.py:150,157-171: x/255 -> RandomHorizontalFlip ->

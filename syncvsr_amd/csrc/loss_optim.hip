@@ -239,6 +239,47 @@ __global__ __launch_bounds__(256) void k_transpose_cast_multi(const float* __res
     }
 }
 
+// the same from the bf16 shadow (same layout as the fp32 buffer, refreshed by the optimiser kernel just before): half the bytes read,
+// identical result.  64 (A) x 64 (Bd) tiles: a thread reads two neighbouring Bd elements as one dword and writes two neighbouring A
+// elements as one dword.
+__global__ __launch_bounds__(256) void k_transpose_bf16_multi(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                              const TransEntry* __restrict__ table) {
+    __shared__ bf16_t tile[64][66];
+    const TransEntry e = table[blockIdx.y];
+    const int ta = (e.A + 63) / 64, tb = (e.Bd + 63) / 64;
+    const int ntiles = e.T * ta * tb;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 pairs x 8 rows
+    const bool pair_src = (e.Bd & 1) == 0 && (e.src_off & 1) == 0, pair_dst = (e.Apad & 1) == 0 && (e.dst_off & 1) == 0;
+    for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+        const int t = tile_id / (ta * tb);
+        const int rem = tile_id - t * (ta * tb);
+        const int a0 = (rem / tb) * 64, b0 = (rem % tb) * 64;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int a = a0 + ty + 8 * i, bd = b0 + 2 * tx;
+            bf16_t v0 = 0, v1 = 0;
+            if (a < e.A) {
+                const bf16_t* p = src + e.src_off + ((long)a * e.T + t) * e.Bd + bd;
+                if (pair_src && bd + 1 < e.Bd) { const unsigned u = *reinterpret_cast<const unsigned*>(p); v0 = (bf16_t)(u & 0xffffu); v1 = (bf16_t)(u >> 16); }
+                else { if (bd < e.Bd) v0 = p[0]; if (bd + 1 < e.Bd) v1 = p[1]; }
+            }
+            tile[ty + 8 * i][2 * tx] = v0;
+            tile[ty + 8 * i][2 * tx + 1] = v1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int bd = b0 + ty + 8 * i, a = a0 + 2 * tx;
+            if (bd >= e.Bd || a >= e.A) continue;
+            bf16_t* q = dst + e.dst_off + ((long)bd * e.T + t) * e.Apad + a;
+            const bf16_t v0 = tile[2 * tx][ty + 8 * i], v1 = tile[2 * tx + 1][ty + 8 * i];
+            if (pair_dst && a + 1 < e.A) *reinterpret_cast<unsigned*>(q) = (unsigned)v0 | ((unsigned)v1 << 16);
+            else { q[0] = v0; if (a + 1 < e.A) q[1] = v1; }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void k_fill_f32(float* p, long n, float v) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
 }
@@ -345,6 +386,13 @@ int svsr_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {
 int svsr_transpose_cast_multi(const float* src, void* dst, const void* table, int n_entries, hipStream_t stream) {
     if (n_entries < 1) return SVSR_OK;
     hipLaunchKernelGGL(k_transpose_cast_multi, dim3(128, n_entries), dim3(256), 0, stream, src, (bf16_t*)dst, (const TransEntry*)table);
+    return svsr_check_launch();
+}
+
+/* the same refresh from the bf16 shadow of the parameters (same offsets as the fp32 buffer): half the bytes read, identical result */
+int svsr_transpose_bf16_multi(const void* src16, void* dst, const void* table, int n_entries, hipStream_t stream) {
+    if (n_entries < 1) return SVSR_OK;
+    hipLaunchKernelGGL(k_transpose_bf16_multi, dim3(128, n_entries), dim3(256), 0, stream, (const bf16_t*)src16, (bf16_t*)dst, (const TransEntry*)table);
     return svsr_check_launch();
 }
 

@@ -122,7 +122,7 @@ class TrainStep:
         ops.grad_sumsq(st.grad, self.opt_state)
         ops.adamw_step(st.flat, st.grad, self.m, self.v, st.w16, st.decay_end, self.lr, self.betas, self.eps, self.weight_decay,
                        self.max_norm, self.warmup, self.total_steps, self.opt_state)
-        ops.transpose_cast_multi(st.flat, st.w16t, st.table, st.n_entries)
+        ops.transpose_shadows(st.flat, st.w16, st.w16t, st.table, st.n_entries)
         st.shadow_fresh = True
         if trace:
             torch.cuda.nvtx.range_pop()

@@ -457,7 +457,7 @@ class _ParamStore:
 
     def refresh_shadows(self) -> None:
         ops.cast_bf16(self.flat, self.w16)
-        ops.transpose_cast_multi(self.flat, self.w16t, self.table, self.n_entries)
+        ops.transpose_shadows(self.flat, self.w16, self.w16t, self.table, self.n_entries)
 
     def zero_grad(self) -> None:
         self.grad.zero_()

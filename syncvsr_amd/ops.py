@@ -101,6 +101,10 @@ def _query(name: str, *args) -> tuple:
 def tune(key: str, value: int) -> None:
     """Result-preserving tuning knob of the library (svsr_tune); invalidates cached plans.  `bn_bwd_fused` is a host-side choice
     (which launches the trunk backward issues), kept in this module."""
+    if key == "transpose_from_bf16":
+        global TRANSPOSE_FROM_BF16
+        TRANSPOSE_FROM_BF16 = bool(value)
+        return
     if key == "bn_bwd_fused":
         global BN_BWD_FUSED
         BN_BWD_FUSED = bool(value)
@@ -750,6 +754,17 @@ def cast_bf16(src: torch.Tensor, dst: torch.Tensor) -> None:
 
 def transpose_cast_multi(src, dst, table: torch.Tensor, n_entries: int) -> None:
     _call("svsr_transpose_cast_multi", _p(src), _p(dst), _p(table), n_entries, _stream())
+
+
+TRANSPOSE_FROM_BF16 = True      # tuning knob "transpose_from_bf16": refresh the transposed shadows from the bf16 shadow (half the bytes read)
+
+
+def transpose_shadows(flat, w16, dst, table: torch.Tensor, n_entries: int) -> None:
+    """Transposed bf16 shadows of the 2-D weights from the (fresh) bf16 shadow w16, or from the fp32 buffer: identical results."""
+    if TRANSPOSE_FROM_BF16:
+        _call("svsr_transpose_bf16_multi", _p(w16), _p(dst), _p(table), n_entries, _stream())
+    else:
+        transpose_cast_multi(flat, dst, table, n_entries)
 
 
 # --------------------------------------------------------------------------------------------------
