@@ -158,6 +158,9 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
     ap.add_argument("--graph", action="store_true", help="capture the whole step into one HIP graph and replay it (measured slower than the "
                                                          "eager default, whose weight-gradient launches overlap on a side stream)")
+    ap.add_argument("--enqueue", choices=("native", "eager"), default="native", help="native (default): the step's launch list is recorded once "
+                    "and re-issued by one library call per step (csrc/steplist.hip) — the same eager launches on the same streams without the "
+                    "per-launch Python cost; eager: every launch from Python (LRS and lrw-xt always run eager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU-baseline leg (default: the workload's own per-GPU batch; ~4 s per step on 32 threads)")
     ap.add_argument("--profile-steps", type=int, default=2, help="eager steps with per-launch HIP events for the roofline leg")
@@ -239,8 +242,9 @@ def main() -> None:
         cfg.train.batch_size = args.batch
         model = Model(cfg, seed=0).to(dev).train()
         batch = [t.to(dev) for t in synthetic_batch(cfg, args.batch, seed=1234 + rank)]
+    native = args.enqueue == "native" and args.workload == "lrw" and not use_graph
     trainer = TrainStep(model, cfg, use_graph=use_graph, always_reduce=args.force_collective, bucket_mb=args.bucket_mb,
-                        grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32)
+                        grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32, native=native)
 
     def barrier():
         if use_dist:
@@ -251,8 +255,10 @@ def main() -> None:
         out = trainer.step(*batch)
     barrier()
     t0 = time.perf_counter()
+    trainer.host_ms.clear()
     for _ in range(args.steps):
         out = trainer.step(*batch)
+    host_ms = sorted(trainer.host_ms)
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist and world > 1:
@@ -281,7 +287,9 @@ def main() -> None:
         "config": {"workload": "LRW training step (fwd+bwd+allreduce+clip+AdamW), ResNet18 + 6-layer 512-d encoder + vq audio-token CE "
                                "head, random-init weights, N(0,1) clips 29x88x88, uniform tokens/labels",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                   "hip_graph": use_graph},
+                   "hip_graph": use_graph, "enqueue": "hip_graph" if use_graph else ("native step list" if native else "eager (python)")},
+        # host time of one step's enqueue (median over the timed steps, this rank): below ms_per_step the GPU is the limit
+        "host_enqueue_ms": round(host_ms[len(host_ms) // 2], 4) if host_ms else None,
         "step_mfma_frac": round(clips_per_s / world * TRAIN_FLOP_PER_CLIP / MFMA_PEAK_BF16, 5),
         "final_loss": round(loss, 4),
     }

@@ -250,6 +250,11 @@ int svsr_transpose_cast_multi(const float* src, void* dst, const void* table, in
 /* the same from the bf16 shadow (src16: bf16 copy of the parameter buffer, same offsets): half the bytes read, identical result */
 int svsr_transpose_bf16_multi(const void* src16, void* dst, const void* table, int n_entries, hipStream_t stream);
 int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream);
+/* scalars on the device, so that a step never depends on a host value: *word += delta (the dropout seed word, advanced once per
+ * training forward: lightning.py:150 draws fresh masks every step);  *out = *a + wb * *b  (loss_total = loss_category +
+ * lambda_audio * loss_audio, lightning.py:187). */
+int svsr_word_add(int* word, int delta, hipStream_t stream);
+int svsr_lincomb2(const float* a, const float* b, float wb, float* out, hipStream_t stream);
 
 /* Device-side input pipeline (reference LRW/video/src/data.py:150,157-171: x/255 -> RandomHorizontalFlip ->
  * RandomResizedCrop | CenterCrop -> Normalize(0.421, 0.165)): stored uint8 clips [B][T][Hs][Ws] -> fp32 model input
@@ -316,6 +321,29 @@ int svsr_ls_loss_bwd(const float* logits, int ld, const int64_t* target, int R, 
  * scaled by 1/(1-p).  The backward passes regenerate the mask from (seed, site); drop_seed is a device word the caller
  * advances once per step.  drop_seed == null or p == 0 disables it. */
 int svsr_scale_bf16(const void* x, void* y, int64_t n, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
+
+/* ---- native step enqueuer (steplist.hip; host code, launches nothing of its own) -----------------------------------
+ * Stands where the reference's per-step host loop stands (pl.Trainer.fit -> training_step, LRW/video/src/train.py:23-45,
+ * lightning.py:194-202): ONE host call per optimisation step instead of one per launch.  A list records, once, the launch
+ * sequence of a training step: CALL = one stream-taking entry point of this header with its arguments frozen (arguments are
+ * passed as 64-bit slots: integers sign-extended, floats as the bits of a double, pointers as they are), WAIT = `waiter`
+ * waits for everything enqueued so far on `signaller`, MEMSET = hipMemsetAsync, BREAK = segment boundary (the host may issue
+ * a collective between two segments).  svsr_steplist_run(list, k, &failed) re-issues segment k (k < 0: every segment) on the
+ * recorded streams and returns 0 or the first failing call's code with its op index in *failed.  Every buffer a recorded call
+ * points to (device and host) must stay alive and in place while the list exists.  svsr_steplist_knows(name): 1 if the
+ * entry point can be recorded.  svsr_stream_wait / svsr_memset_async are the eager twins of WAIT / MEMSET. */
+void* svsr_steplist_create(void);
+int svsr_steplist_destroy(void* list);
+int svsr_steplist_knows(const char* name);
+int svsr_steplist_push_call(void* list, const char* name, const int64_t* slots, int nslots);
+int svsr_steplist_push_wait(void* list, hipStream_t waiter, hipStream_t signaller);
+int svsr_steplist_push_memset(void* list, void* ptr, int value, int64_t bytes, hipStream_t stream);
+int svsr_steplist_push_break(void* list);
+int svsr_steplist_segments(void* list);
+int64_t svsr_steplist_size(void* list);
+int svsr_steplist_run(void* list, int segment, int* failed);
+int svsr_stream_wait(hipStream_t waiter, hipStream_t signaller);
+int svsr_memset_async(void* ptr, int value, int64_t bytes, hipStream_t stream);
 
 #ifdef __cplusplus
 }

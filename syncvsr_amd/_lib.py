@@ -29,7 +29,7 @@ def parse_header(path: str = HEADER) -> dict[str, list[tuple[str, str]]]:
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out: dict[str, list[tuple[str, str]]] = {}
-    for m in re.finditer(r"\b(int|int64_t)\s+(svsr_\w+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"\b(int|int64_t|void\*)\s+(svsr_\w+)\s*\(([^)]*)\)\s*;", text):
         args = []
         for a in m.group(3).split(","):
             a = " ".join(a.split())
@@ -60,7 +60,7 @@ def load() -> ctypes.CDLL:
     lib = ctypes.CDLL(LIB_PATH)
     for name, args in parse_header().items():
         fn = getattr(lib, name)
-        fn.restype = _CTYPES[_RESTYPE.get(name, "int")]
+        fn.restype = _ctype(_RESTYPE.get(name, "int"))
         fn.argtypes = [_ctype(t) for t, _ in args]
     return lib
 

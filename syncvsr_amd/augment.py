@@ -118,7 +118,8 @@ class DeviceClipPipeline:
     five integers per clip, and the uint8 clips cross PCIe at a quarter of the fp32 size.
 
     train=True:  RandomHorizontalFlip(0.5) and, with use_rrc, RandomResizedCrop(size, scale=(0.6, 1.0), ratio=(3/4, 4/3)) with
-                 torchvision's rejection sampling (10 tries, then the central fallback); without use_rrc the whole frame is resized.
+                 torchvision's rejection sampling (10 tries, then the central fallback); without use_rrc the frame passes through
+                 at its stored size (nn.Identity, data.py:160).
     train=False: CenterCrop(size) (or Resize with use_val_resize).
     The draws come from a numpy generator (torchvision, whose RNG order the reference follows, is not available to pin them);
     the resize is bilinear without antialias."""
@@ -147,9 +148,15 @@ class DeviceClipPipeline:
                     if 0 < w <= Ws and 0 < h <= Hs:
                         out[b, :4] = (self.rng.integers(0, Hs - h + 1), self.rng.integers(0, Ws - w + 1), h, w)
                         break
-                else:       # torchvision's fallback: the central crop with the nearest admissible ratio
-                    ratio = Ws / Hs
-                    w, h = (Ws, int(round(Ws / (4 / 3)))) if ratio > 4 / 3 else ((int(round(Hs * 3 / 4)), Hs) if ratio < 3 / 4 else (Ws, Hs))
+                else:       # torchvision's fallback (RandomResizedCrop.get_params): the central crop with the nearest admissible ratio
+                    in_ratio = Ws / Hs
+                    if in_ratio < 3 / 4:
+                        w, h = Ws, int(round(Ws / (3 / 4)))
+                    elif in_ratio > 4 / 3:
+                        h = Hs
+                        w = int(round(h * (4 / 3)))
+                    else:
+                        w, h = Ws, Hs
                     out[b, :4] = ((Hs - h) // 2, (Ws - w) // 2, h, w)
             elif (self.train and not self.use_rrc) or (not self.train and self.use_val_resize):
                 out[b, :4] = (0, 0, Hs, Ws)
@@ -164,4 +171,10 @@ class DeviceClipPipeline:
         B, T, Hs, Ws = frames_u8.shape
         if params is None:
             params = self.draw(B, Hs, Ws)
-        return ops.clip_prep(frames_u8.contiguous(), params.to(frames_u8.device, non_blocking=True), self.size, self.size, self.mean, self.std)
+        if params.device.type == "cpu":         # (device-resident windows are clamped into the frame by the kernel instead)
+            top, left, h, w = (params[:, i] for i in range(4))
+            if bool(((top < 0) | (left < 0) | (h < 1) | (w < 1) | (top + h > Hs) | (left + w > Ws)).any()):
+                raise ValueError("crop window outside the stored frame")
+        identity = self.train and not self.use_rrc          # nn.Identity: output size = stored size
+        H, W = (Hs, Ws) if identity else (self.size, self.size)
+        return ops.clip_prep(frames_u8.contiguous(), params.to(frames_u8.device, non_blocking=True), H, W, self.mean, self.std)

@@ -284,6 +284,9 @@ __global__ void k_fill_f32(float* p, long n, float v) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
 }
 
+__global__ void k_word_add(int* w, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) w[0] += delta; }
+__global__ void k_lincomb2(const float* a, const float* b, float wb, float* out) { if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = a[0] + wb * b[0]; }
+
 __global__ __launch_bounds__(256) void k_video_cast(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = f2bf(src[i]);
 }
@@ -305,7 +308,13 @@ __global__ __launch_bounds__(256) void k_clip_prep(const unsigned char* __restri
         const int y = (int)(r % H);
         r /= H;
         const int t = (int)(r % T), b = (int)(r / T);
-        const int top = params[b * 5 + 0], left = params[b * 5 + 1], ch = params[b * 5 + 2], cw = params[b * 5 + 3], flip = params[b * 5 + 4];
+        int top = params[b * 5 + 0], left = params[b * 5 + 1], ch = params[b * 5 + 2], cw = params[b * 5 + 3];
+        const int flip = params[b * 5 + 4];
+        // the window is clamped into the stored frame: no read outside it whatever the host drew
+        top = top < 0 ? 0 : (top > Hs - 1 ? Hs - 1 : top);
+        left = left < 0 ? 0 : (left > Ws - 1 ? Ws - 1 : left);
+        ch = ch < 1 ? 1 : (ch > Hs - top ? Hs - top : ch);
+        cw = cw < 1 ? 1 : (cw > Ws - left ? Ws - left : cw);
         const int xo = flip ? W - 1 - x : x;
         // source coordinates inside the window (pixel centres), clamped to the window like torch's upsample_bilinear2d
         float fy = ((float)y + 0.5f) * ((float)ch / (float)H) - 0.5f;
@@ -408,6 +417,18 @@ int svsr_clip_prep(const void* src_u8, const int* params, float* dst, int B, int
 
 int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream) {
     hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(n)), dim3(256), 0, stream, p, (long)n, v);
+    return svsr_check_launch();
+}
+
+int svsr_word_add(int* word, int delta, hipStream_t stream) {
+    if (word == nullptr) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_word_add, dim3(1), dim3(64), 0, stream, word, delta);
+    return svsr_check_launch();
+}
+
+int svsr_lincomb2(const float* a, const float* b, float wb, float* out, hipStream_t stream) {
+    if (a == nullptr || b == nullptr || out == nullptr) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_lincomb2, dim3(1), dim3(64), 0, stream, a, b, wb, out);
     return svsr_check_launch();
 }
 

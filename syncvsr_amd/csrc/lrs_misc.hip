@@ -583,7 +583,10 @@ int svsr_ctc_prefix_score(const float* logp, int ldp, const float* r_prev, const
                           int V, int n, int S, int out_len, int blank, int eos, hipStream_t stream) {
     if (T < 1 || V < 2 || n < 1 || S < 1 || (ids == nullptr && S != V) || ldp < V || out_len < 0 || blank < 0 || blank >= V || eos < 0 || eos >= V)
         return SVSR_ERR_ARG;
-    hipLaunchKernelGGL(k_ctc_prefix_score, dim3(grid1d((long)n * S)), dim3(256), 0, stream, logp, r_prev, (const long*)last, (const long*)ids, r_new,
+    // one thread per (hypothesis, candidate), no grid-stride loop in the kernel: the grid covers every pair (full-vocabulary scoring at a
+    // wide beam exceeds the 2048-block cap of grid1d)
+    if (((long)n * S + 255) / 256 > 0x7fffffffL) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_ctc_prefix_score, dim3((unsigned)(((long)n * S + 255) / 256)), dim3(256), 0, stream, logp, r_prev, (const long*)last, (const long*)ids, r_new,
                        psi, T, V, ldp, n, S, out_len, blank, eos);
     return svsr_check_launch();
 }

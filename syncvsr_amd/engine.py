@@ -47,7 +47,11 @@ class TrainStep:
 
     def __init__(self, model, config: Optional[Config] = None, process_group=None,
                  use_graph: bool = False, bucket_mb: float = 32.0, always_reduce: bool = False, data_parallel: bool = True,
-                 grad_comm_dtype: torch.dtype = torch.float32):
+                 grad_comm_dtype: torch.dtype = torch.float32, native: bool = False):
+        """native=True: the launch sequence of the first step is recorded into a native step list (csrc/steplist.hip) and every
+        later step re-issues it with one library call per segment — eager launches on the same streams (the weight-gradient side
+        stream keeps overlapping, which a captured HIP graph loses) without the per-launch host cost of the Python loop.  Batch
+        shapes are fixed by the first call, as with use_graph."""
         self.model = model
         self.is_lrw = isinstance(model, TransformerLightningModule)
         if self.is_lrw:            # LRW/video/config/*.yaml: optim.optimizer / optim.scheduler / train.gradient_clip_val
@@ -78,6 +82,15 @@ class TrainStep:
         if not data_parallel:
             model.grad_ready_hook = None
         self.use_graph = use_graph
+        self.native = bool(native)
+        if self.native and use_graph:
+            raise ValueError("native=True and use_graph=True are two ways of replaying a step: pick one")
+        if self.native and not self.is_lrw:
+            raise NotImplementedError("native=True is implemented for the LRW model (the LRS forward prepares its targets with torch ops)")
+        if self.native and getattr(model, "layer_drop_p", 0.0) > 0.0:
+            raise NotImplementedError("layer_dropout changes the launch sequence from step to step: it cannot be replayed from a recorded list")
+        self._rec: Optional[ops.StepRecorder] = None
+        self.host_ms: list[float] = []          # host time of the last steps' enqueue (bench.py reports the median)
         if use_graph and getattr(model, "layer_drop_p", 0.0) > 0.0:
             raise NotImplementedError("layer_dropout skips whole encoder blocks at random: the launch sequence differs from step to "
                                       "step and cannot be replayed from one captured HIP graph (use use_graph=False)")
@@ -130,11 +143,81 @@ class TrainStep:
             return {k: v.detach() for k, v in out.items()}
         return tuple(v.detach() for v in out)
 
+    # -- native step list ----------------------------------------------------------------------------
+    def _direct_impl(self, *batch):
+        """_step_impl without autograd or torch kernels: every device operation is a library call (recordable)."""
+        model = self.model
+        st = model.store()
+        out = model.train_step_direct(*batch)
+        if self.dp is not None:
+            ops.host_callback(self.dp.finish)
+        ops.grad_sumsq(st.grad, self.opt_state)
+        ops.adamw_step(st.flat, st.grad, self.m, self.v, st.w16, st.decay_end, self.lr, self.betas, self.eps, self.weight_decay,
+                       self.max_norm, self.warmup, self.total_steps, self.opt_state)
+        ops.transpose_shadows(st.flat, st.w16, st.w16t, st.table, st.n_entries)
+        st.shadow_fresh = True
+        return out
+
+    def _native_step(self, *batch):
+        model = self.model
+        if self._rec is None:
+            if not model.training:
+                raise RuntimeError("TrainStep(native=True) records a TRAINING step: call model.train() first")
+            prepped = model.prepare_batch(*batch)
+            self._static = [t.clone() if torch.is_tensor(t) else t for t in prepped]
+            st = model.store()
+            if not st.shadow_fresh:
+                st.refresh_shadows()
+                st.shadow_fresh = True
+            if self.dp is not None:
+                self.dp.begin_step()
+            if model._side.stream is None:
+                model._side.stream = torch.cuda.Stream()
+            if getattr(model, "_drop_word", None) is None and (model.drop_p > 0.0 or model.attn_drop_p > 0.0 or model.emb_drop_p > 0.0):
+                model._advance_dropout(self._static[0].device)      # creates the seed word outside the recorded region ...
+                ops.word_add(model._drop_word, -1)                   # ... and leaves its value where the first forward expects it
+            rec = ops.StepRecorder()
+            with ops.recording(rec):
+                out = self._direct_impl(*self._static)
+            self._rec = rec
+            self._out = {k: v.detach() for k, v in out.items()}
+            self._main_stream = rec.main_stream
+            return self._out
+        for dst, src in zip(self._static, batch):
+            if not torch.is_tensor(dst):
+                continue
+            if dst.shape[0] != src.shape[0] or dst.shape[2:] != src.shape[2:]:
+                raise ValueError("a recorded TrainStep needs fixed batch shapes (pad to the recorded size or use native=False)")
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src if src.dim() != 2 or src.shape[1] == dst.shape[1] else src[:, : dst.shape[1]], non_blocking=True)
+        if ops._stream() != self._main_stream:
+            raise RuntimeError("a recorded TrainStep must be replayed on the stream it was recorded on")
+        if self.dp is not None:
+            self.dp.begin_step()
+        self._rec.run()
+        return self._out
+
     def step(self, *batch):
         """One optimisation step; returns the model's outputs (LRW: the dict of five scalars; LRS: the 5-tuple).
-        With use_graph the batch shapes are fixed by the first call (later batches are copied into the captured buffers)."""
+        With use_graph / native the batch shapes are fixed by the first call (later batches are copied into the static buffers)."""
+        if self.native:
+            import time as _time
+
+            t0 = _time.perf_counter()
+            out = self._native_step(*batch)
+            self.host_ms.append((_time.perf_counter() - t0) * 1e3)
+            if len(self.host_ms) > 256:
+                del self.host_ms[:128]
+            return out
         if not self.use_graph:
-            return self._step_impl(*batch)
+            import time as _time
+
+            t0 = _time.perf_counter()
+            out = self._step_impl(*batch)
+            self.host_ms.append((_time.perf_counter() - t0) * 1e3)
+            if len(self.host_ms) > 256:
+                del self.host_ms[:128]
+            return out
         if self._graph is None:
             self._capture(*batch)
         else:
@@ -176,7 +259,15 @@ class TrainStep:
     def state_dict(self) -> dict[str, torch.Tensor]:
         """Optimiser state for checkpointing (what Lightning stores next to the model's state_dict): AdamW moments as flat
         fp32 vectors in the parameter store's order, and the 16-byte device state {step, -, lr, grad-norm}."""
-        return {"exp_avg": self.m.detach().clone(), "exp_avg_sq": self.v.detach().clone(), "opt_state": self.opt_state.detach().clone()}
+        sd = {"exp_avg": self.m.detach().clone(), "exp_avg_sq": self.v.detach().clone(), "opt_state": self.opt_state.detach().clone()}
+        if hasattr(self.model, "rng_state"):        # dropout seed word + layer-drop generator: a resumed run draws the same masks / skips
+            import pickle
+
+            rs = self.model.rng_state()
+            sd["dropout_word"] = torch.tensor([rs["dropout_word"]], dtype=torch.int64)
+            if "layer_rng" in rs:
+                sd["layer_rng"] = torch.frombuffer(bytearray(pickle.dumps(rs["layer_rng"])), dtype=torch.uint8).clone()
+        return sd
 
     def load_state_dict(self, sd: dict[str, torch.Tensor]) -> None:
         if sd["exp_avg"].numel() != self.m.numel():
@@ -184,6 +275,13 @@ class TrainStep:
         self.m.copy_(sd["exp_avg"])
         self.v.copy_(sd["exp_avg_sq"])
         self.opt_state[:4].copy_(sd["opt_state"][:4])
+        if "dropout_word" in sd and hasattr(self.model, "load_rng_state"):
+            import pickle
+
+            rs = {"dropout_word": int(sd["dropout_word"].reshape(-1)[0])}
+            if "layer_rng" in sd:
+                rs["layer_rng"] = pickle.loads(bytes(sd["layer_rng"].cpu().numpy().tobytes()))
+            self.model.load_rng_state(rs)
 
     # -- introspection ------------------------------------------------------------------------------
     def state(self) -> dict[str, float]:
@@ -233,7 +331,6 @@ class GradReducer:
         # hide: bucket edges are anchored so that it holds at most 4 MB, whatever is left over goes to the FIRST bucket (top of the
         # buffer, ready earliest)
         self.last_elems = min(self.bucket_elems, 1 << 20)
-        self._buffers_pending = False
         self._st = None
         self._backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self.comm_stream: Optional[torch.cuda.Stream] = None
@@ -272,9 +369,6 @@ class GradReducer:
         self.launched = []
         if self.comm_stream is None and st.flat.is_cuda:
             self.comm_stream = torch.cuda.Stream(device=st.flat.device)
-        if (self.world > 1 or self.always) and st.flat.is_cuda and self._buffers_pending:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)     # last step's buffer broadcast precedes this forward's BN updates
-            self._buffers_pending = False
 
     def _reduce(self, lo: int, hi: int) -> None:
         if hi <= lo:
@@ -324,14 +418,15 @@ class GradReducer:
             self.top = edge
 
     def finish(self) -> None:
+        """Joins the bucket all-reduces.  DDP re-broadcasts the buffers before every forward; here rank 0's BatchNorm running
+        statistics (a few KB in one flat vector) follow the buckets on the comm stream and the ONE join below covers both, so
+        nothing is left un-joined when the step ends: a captured HIP graph has no dangling branch, and an eval forward or a
+        state_dict() read right after the step sees the broadcast values."""
         if (self.world > 1 or self.always) and self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
-            # DDP re-broadcasts the buffers before every forward; here the collective is enqueued right after the backward's
-            # BatchNorm updates on the comm stream, where it overlaps the optimiser and the host's enqueue of the next step
             st = self._st if self._st is not None else self.model.store()
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self._broadcast_buffers(st)
-            self._buffers_pending = True
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
         elif self.world > 1 or self.always:
             self._broadcast_buffers(self._st if self._st is not None else self.model.store())

@@ -56,7 +56,7 @@ class _SideStream:
             return
         if self.stream is None:
             self.stream = torch.cuda.Stream()
-        self.stream.wait_stream(torch.cuda.current_stream())
+        ops.stream_wait(self.stream, torch.cuda.current_stream())
         # launches go to the side stream through ops.STREAM_OVERRIDE (they allocate nothing on the device), which is
         # much cheaper on the host than entering a torch.cuda.stream() context per weight-gradient launch
         ops.STREAM_OVERRIDE = self.stream.cuda_stream
@@ -70,7 +70,7 @@ class _SideStream:
     def join(self) -> None:
         self.flush()
         if self.stream is not None and (self.enabled or self.enabled_small):
-            torch.cuda.current_stream().wait_stream(self.stream)
+            ops.stream_wait(torch.cuda.current_stream(), self.stream)
         self.keep.clear()
 
 
@@ -204,11 +204,29 @@ class TransformerLightningModule(nn.Module):
     def _advance_dropout(self, dev: torch.device) -> None:
         if self._drop_word is None or self._drop_word.device != dev:
             self._drop_word = torch.tensor([self.dropout_seed], dtype=torch.int32, device=dev)
-        self._drop_word.add_(1)                   # a device op: graph replays keep drawing fresh masks
+        ops.word_add(self._drop_word, 1)          # a device op: graph / step-list replays keep drawing fresh masks
 
     def reseed_dropout(self, seed: int) -> None:
         self.dropout_seed = int(seed)
         self._drop_word = None
+        if hasattr(self, "_layer_rng"):          # the layer-drop draws follow the seed too (per-rank / per-run reseeding)
+            self._layer_rng.seed(self.dropout_seed)
+
+    def rng_state(self) -> dict:
+        """Everything random about the next training forward, for bit-exact resume: the dropout seed word (the device counter the
+        masks are hashed from) and the python generator behind layer_dropout.  engine.TrainStep.state_dict stores it."""
+        word = self.dropout_seed if self._drop_word is None else int(self._drop_word.item())
+        out = {"dropout_word": word}
+        if hasattr(self, "_layer_rng"):
+            out["layer_rng"] = self._layer_rng.getstate()
+        return out
+
+    def load_rng_state(self, state: dict) -> None:
+        self.dropout_seed = int(state["dropout_word"])
+        if self._drop_word is not None:
+            self._drop_word.fill_(self.dropout_seed)
+        if "layer_rng" in state and hasattr(self, "_layer_rng"):
+            self._layer_rng.setstate(state["layer_rng"])
 
     def _d(self, site: str, kind: str = "hidden"):
         """(seed word, site id, p) for ops.*(drop=...) or None when dropout is off (eval mode / p = 0)."""
@@ -304,6 +322,47 @@ class TransformerLightningModule(nn.Module):
             "accuracy_top1": acc[0],
             "accuracy_top5": acc[1],
         }
+
+
+    # ------------------------------------------------------------------------------------------------
+    def prepare_batch(self, videos, audio_tokens, labels, word_mask):
+        """The input conversions of forward(), done ahead of it: what engine.TrainStep keeps as the static inputs of a recorded step
+        (inside the recorded region every one of them must be a no-op, so that no torch kernel is needed at replay)."""
+        T = videos.size(2)
+        A = self.audio_alignment
+        if audio_tokens.size(1) < T * A:
+            raise ValueError(f"audio_tokens has {audio_tokens.size(1)} steps, need >= {T * A}")
+        hard = labels.dtype in (torch.int64, torch.int32)
+        wm = word_mask
+        if self.use_wb:
+            if word_mask.shape != (videos.size(0), T):
+                raise ValueError(f"word_mask must be [batch, frames] = {(videos.size(0), T)}, got {tuple(word_mask.shape)}")
+            wm = word_mask.to(device=videos.device, dtype=torch.float32).contiguous()
+        return (videos.float().contiguous(), audio_tokens[:, : T * A].contiguous(), (labels.long() if hard else labels.float()).contiguous(), wm)
+
+    def train_step_direct(self, videos, audio_tokens, labels, word_mask) -> dict[str, torch.Tensor]:
+        """forward + backward of loss_total WITHOUT autograd: the same tape functions `forward()` + `loss_total.backward()` run,
+        called directly, with loss_total and the two loss weights formed on the device.  Inputs as prepare_batch returns them.
+        Every device operation in here is a library call, so the whole step can be recorded into a native step list."""
+        if videos.device.type != "cuda":
+            raise RuntimeError("syncvsr_amd runs on an MI355X HIP device only; there is no CPU fallback (use oracle/ for checking)")
+        st = self.store()
+        dev = videos.device
+        if getattr(self, "_g_one", None) is None or self._g_one.device != dev:
+            self._g_one = torch.ones((), dtype=torch.float32, device=dev)
+            self._g_lam = torch.full((), self.lambda_audio, dtype=torch.float32, device=dev)
+
+        class _Ctx:
+            def mark_non_differentiable(self, *a):
+                pass
+
+        ctx = _Ctx()
+        loss_category, loss_audio, acc = _LrwFunction.forward(ctx, self.cls_token, self, st, videos, audio_tokens, labels, True,
+                                                              word_mask if self.use_wb else None)
+        loss_total = ops.lincomb2(loss_category, loss_audio, self.lambda_audio)
+        _LrwFunction.backward(ctx, self._g_one, self._g_lam, None)
+        return {"loss_total": loss_total, "loss_category": loss_category, "loss_audio": loss_audio, "accuracy_top1": acc[0],
+                "accuracy_top5": acc[1]}
 
 
 Model = TransformerLightningModule
@@ -460,7 +519,7 @@ class _ParamStore:
         ops.transpose_shadows(self.flat, self.w16, self.w16t, self.table, self.n_entries)
 
     def zero_grad(self) -> None:
-        self.grad.zero_()
+        ops.memset(self.grad, 0)
 
     def rebind_grads(self) -> None:
         for n, p in self._params.items():
@@ -608,7 +667,8 @@ def _ready(model, st: "_ParamStore", name: Optional[str]) -> None:
     region is final (backward walks the flat buffer from its end to its start); None = all gradients final."""
     if model.grad_ready_hook is not None:     # (the reducer's comm stream waits for the side stream itself: engine.GradReducer._reduce)
         model._side.flush()
-        model.grad_ready_hook(0 if name is None else st.offsets[name][0])
+        hook, lo = model.grad_ready_hook, (0 if name is None else st.offsets[name][0])
+        ops.host_callback(lambda: hook(lo))   # a host-side step (collective): a segment boundary of a recorded step list
 
 
 def _encoder_forward(model: TransformerLightningModule, st: _ParamStore, tape: dict, feats: torch.Tensor, B: int, T: int) -> torch.Tensor:
@@ -835,7 +895,7 @@ class _LrwFunction(torch.autograd.Function):
         Cp = (C + 63) // 64 * 64
         dla = torch.empty((B * T, NA), dtype=BF16, device=dev)
         ops.ce_bwd(th["logits_a"], V, th["tok"], None, B * T * A * G, V, 0.0, th["lse_a"], g_audio, dla, V)
-        dlc = torch.zeros((B, Cp), dtype=BF16, device=dev)
+        dlc = ops.zeros((B, Cp), BF16, dev)
         ops.ce_bwd(th["logits_c"], C, th["lab_idx"], th["lab_prob"], B, C, model.label_smoothing, th["lse_c"], g_cat, dlc, Cp)
         h = th["h"]
         ops.linear_wgrad(h, dla, st.g32("audio_projection.weight"), rows=B * T, K=D, N=NA, x_pitch=D, dy_pitch=NA, seq=(S, 1, T), use_tr=use_tr,

@@ -6,7 +6,9 @@ libsyncvsr_hip.so on the current HIP stream.  Tensors are NHWC bf16 activations 
 from __future__ import annotations
 
 import ctypes
-from typing import Optional, Sequence
+import struct
+from contextlib import contextmanager
+from typing import Callable, Optional, Sequence
 
 import torch
 
@@ -67,13 +69,23 @@ class _BoundedCache(dict):
 
     def __setitem__(self, key, value):
         if len(self) >= PLAN_CACHE_MAX and not PLAN_CACHE_PINNED:
-            self.clear()
+            self.retire()
         super().__setitem__(key, value)
+
+    def retire(self) -> None:
+        """Starts over.  The evicted plans stay alive for one more generation (or for ever once a graph / step list holds their
+        device words): a weight-gradient launch on the side stream may still be reading them, and the caching allocator would hand
+        their memory to the next allocation on the main stream."""
+        global _PLAN_RETIRED
+        old = list(self.values())
+        _PLAN_RETIRED = (_PLAN_RETIRED + old) if PLAN_CACHE_PINNED else old
+        self.clear()
 
 
 PLAN_CACHE_MAX = 20000
 PLAN_CACHE_PINNED = False       # set once a HIP graph has captured launches: their plans' device words must stay alive
-_PLAN_CACHE: dict = _BoundedCache()
+_PLAN_RETIRED: list = []
+_PLAN_CACHE: _BoundedCache = _BoundedCache()
 
 
 def _query(name: str, *args) -> tuple:
@@ -116,7 +128,7 @@ def tune(key: str, value: int) -> None:
     rc = _lib.load().svsr_tune(key.encode(), int(value))
     if rc != 0:
         _lib.check(rc, f"svsr_tune({key})")
-    _PLAN_CACHE.clear()
+    _PLAN_CACHE.retire()          # plans are rebuilt with the new knob; the old ones stay alive for whoever still points at them
 
 
 _INT_ARRAYS: dict = {}
@@ -152,6 +164,176 @@ def stop_event_timing() -> dict[str, dict[str, float]]:
     return out
 
 
+# --------------------------------------------------------------------------------------------------
+# native step enqueuer (csrc/steplist.hip): every launch of one training step is recorded once and re-issued by ONE library
+# call per step (engine.TrainStep(native=True))
+# --------------------------------------------------------------------------------------------------
+class StepRecorder:
+    """While active (`with ops.recording(rec)`), every library launch, cross-stream wait and memset issued through this module is
+    executed AND appended to a native step list; `host_callback` ends a segment, so that host-side work (a collective) can sit
+    between two segments of the replay.  The recorder keeps everything the list points to alive: the tensors allocated during the
+    recorded step (their storage is re-used by every replay, exactly as a captured HIP graph would) and the host-side arrays."""
+
+    def __init__(self) -> None:
+        self.lib = _lib.load()
+        self.handle = self.lib.svsr_steplist_create()
+        self.keep: list = []
+        self.callbacks: dict[int, list[Callable[[], None]]] = {}      # segment index -> host calls that follow it
+        self.main_stream: Optional[int] = None
+        self.closed = False
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.svsr_steplist_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def call(self, name: str, args: tuple) -> None:
+        fn = getattr(self.lib, name)
+        n = len(args)
+        slots = (ctypes.c_int64 * n)()
+        for i, (a, t) in enumerate(zip(args, fn.argtypes)):
+            if t is ctypes.c_float:
+                slots[i] = struct.unpack("<q", struct.pack("<d", float(a)))[0]
+            elif t is ctypes.c_void_p:
+                if a is None:
+                    slots[i] = 0
+                elif isinstance(a, int):
+                    slots[i] = a
+                else:                       # a ctypes array (plan meta record, tap table): host memory the launch reads
+                    slots[i] = ctypes.addressof(a)
+                    self.keep.append(a)
+            else:
+                slots[i] = int(a)
+        rc = self.lib.svsr_steplist_push_call(self.handle, name.encode(), slots, n)
+        if rc != 0:
+            raise _lib.SvsrError(f"{name} cannot be recorded into a step list (code {rc}): not a stream launch of include/syncvsr_hip.h?")
+
+    def wait(self, waiter: int, signaller: int) -> None:
+        _lib.check(self.lib.svsr_steplist_push_wait(self.handle, waiter, signaller), "svsr_steplist_push_wait")
+
+    def memset(self, ptr: int, value: int, nbytes: int, stream: int) -> None:
+        _lib.check(self.lib.svsr_steplist_push_memset(self.handle, ptr, value, nbytes, stream), "svsr_steplist_push_memset")
+
+    def add_callback(self, fn: Callable[[], None]) -> None:
+        seg = self.lib.svsr_steplist_push_break(self.handle)
+        if seg < 1:
+            _lib.check(-seg if seg < 0 else 1001, "svsr_steplist_push_break")
+        self.callbacks.setdefault(seg - 1, []).append(fn)
+
+    @property
+    def segments(self) -> int:
+        return int(self.lib.svsr_steplist_segments(self.handle))
+
+    @property
+    def size(self) -> int:
+        return int(self.lib.svsr_steplist_size(self.handle))
+
+    def run(self) -> None:
+        """Re-issues the recorded step: segment by segment, each followed by its host callbacks."""
+        failed = ctypes.c_int(-1)
+        run, h, cbs = self.lib.svsr_steplist_run, self.handle, self.callbacks
+        if len(cbs) == 0:
+            rc = run(h, -1, ctypes.byref(failed))
+            if rc != 0:
+                _lib.check(rc, f"svsr_steplist_run (op {failed.value})")
+            return
+        for k in range(self.segments):
+            rc = run(h, k, ctypes.byref(failed))
+            if rc != 0:
+                _lib.check(rc, f"svsr_steplist_run (op {failed.value})")
+            for fn in cbs.get(k, ()):
+                fn()
+
+
+_REC: Optional[StepRecorder] = None
+_ALLOC_KEEP = ("empty", "empty_like")
+_ALLOC_FORBID = ("zeros", "zeros_like", "ones", "ones_like", "full", "full_like")      # would launch a torch kernel the list does not hold
+
+
+@contextmanager
+def recording(rec: StepRecorder):
+    """Everything launched through this module inside the block is also appended to `rec`.  torch.empty / torch.empty_like results
+    are kept alive by the recorder (the replay re-uses their storage); torch.zeros & co. raise — use ops.zeros, whose fill is
+    recorded.  Launch plans are pinned (their device words are referenced by the list)."""
+    global _REC, PLAN_CACHE_PINNED
+    if _REC is not None or _TIMING is not None:
+        raise RuntimeError("nested recording / recording while per-launch event timing is on")
+    saved = {n: getattr(torch, n) for n in _ALLOC_KEEP + _ALLOC_FORBID}
+
+    def keeper(fn):
+        def w(*a, **k):
+            t = fn(*a, **k)
+            rec.keep.append(t)
+            return t
+        return w
+
+    def forbid(name):
+        def w(*a, **k):
+            raise RuntimeError(f"torch.{name} inside a recorded step launches a kernel the native step list does not hold (use ops.zeros)")
+        return w
+
+    for n in _ALLOC_KEEP:
+        setattr(torch, n, keeper(saved[n]))
+    for n in _ALLOC_FORBID:
+        setattr(torch, n, forbid(n))
+    _REC = rec
+    rec.main_stream = _stream()
+    PLAN_CACHE_PINNED = True
+    try:
+        yield rec
+    finally:
+        _REC = None
+        for n, f in saved.items():
+            setattr(torch, n, f)
+        rec.closed = True
+
+
+def host_callback(fn: Callable[[], None]) -> None:
+    """Runs fn() now; inside a recorded step it also closes the current segment and is called again after that segment in
+    every replay (collectives and their stream joins: engine.GradReducer)."""
+    fn()
+    if _REC is not None:
+        _REC.add_callback(fn)
+
+
+def stream_wait(waiter: torch.cuda.Stream, signaller: torch.cuda.Stream) -> None:
+    """`waiter` waits for everything enqueued so far on `signaller`.  Eager: torch's own event path; recorded steps: the library's."""
+    if _REC is None:
+        waiter.wait_stream(signaller)
+        return
+    w, s = waiter.cuda_stream, signaller.cuda_stream
+    _lib.check(_lib.load().svsr_stream_wait(w, s), "svsr_stream_wait")
+    _REC.wait(w, s)
+
+
+def memset(t: torch.Tensor, value: int = 0) -> None:
+    """hipMemsetAsync over a contiguous tensor on the current stream."""
+    nbytes, stream = t.numel() * t.element_size(), _stream()
+    _lib.check(_lib.load().svsr_memset_async(t.data_ptr(), value, nbytes, stream), "svsr_memset_async")
+    if _REC is not None:
+        _REC.memset(t.data_ptr(), value, nbytes, stream)
+
+
+def zeros(shape, dtype, device) -> torch.Tensor:
+    t = torch.empty(shape, dtype=dtype, device=device)
+    memset(t, 0)
+    return t
+
+
+def word_add(word: torch.Tensor, delta: int) -> None:
+    _call("svsr_word_add", _p(word), int(delta), _stream())
+
+
+def lincomb2(a: torch.Tensor, b: torch.Tensor, wb: float) -> torch.Tensor:
+    """0-d fp32: a + wb * b, on the device."""
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    _call("svsr_lincomb2", _p(a), _p(b), float(wb), _p(out), _stream())
+    return out
+
+
 def _call(name: str, *args, label: Optional[str] = None, flops: float = 0.0, nbytes: float = 0.0) -> None:
     timing = _TIMING
     if timing is not None:
@@ -163,6 +345,8 @@ def _call(name: str, *args, label: Optional[str] = None, flops: float = 0.0, nby
         timing.setdefault(label or name, []).append((s, e, flops, nbytes))
     if rc != 0:
         _lib.check(rc, name)
+    if _REC is not None:
+        _REC.call(name, args)
 
 
 class Plan:
@@ -513,6 +697,8 @@ def stem_conv_fwd(videos: torch.Tensor, w: torch.Tensor, want_stats: bool = Fals
         key = (videos.device, _stream())        # lives in the shared scratch; variable-length LRS batches must not pile up one buffer per shape)
         ws = _STEM_WS.get(key)
         if ws is None or ws.numel() < nws:
+            if ws is not None:
+                _SCRATCH_KEEP.append(ws)      # a captured graph / recorded step list may still hold its address
             ws = _STEM_WS[key] = torch.empty(nws, dtype=torch.uint8, device=videos.device)
     _call("svsr_stem_conv_fwd", _p(videos), _p(w), _p(out), _p(stats), B, T, H, W, _p(ws), nws, _stream(),
           label="k_stem_conv_fwd", flops=2.0 * B * T * (H // 2) * (W // 2) * 64 * 245)

@@ -311,3 +311,81 @@ def test_checkpoint_resume_lrs():
     assert ts3.state()["step"] == 4
     for a, b in zip(first + resumed, ref):
         assert abs(a - b) <= 2e-4 * abs(b), (first + resumed, ref)
+
+
+@pytest.mark.parametrize("case", ["lrw_tiny", "lrw_full_b2"])
+def test_native_step_list_equals_eager_steps(case):
+    """engine.TrainStep(native=True): the first step is recorded into a native step list (csrc/steplist.hip: every launch with its
+    stream, the cross-stream waits, the memsets), later steps re-issue it with one library call.  The launches are the same launches
+    on the same streams, so losses, parameters, running statistics and optimiser state must EQUAL the eager steps' bit for bit —
+    with dropout on (the seed word advances on the device: a missed launch would repeat a mask) and the side stream in use."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from syncvsr_amd.engine import TrainStep
+    from syncvsr_amd.model import Model
+
+    dev = torch.device("cuda:0")
+    cfg, sd, batch, training, gold = build_case(case)
+    cfg.optim.scheduler.num_warmup_steps = 1
+    cfg.model.bert.hidden_dropout_prob = 0.1
+    cfg.model.bert.attention_probs_dropout_prob = 0.1
+    gb = [t.to(dev) for t in batch]
+
+    def run(native):
+        model = Model(cfg, seed=3)
+        model.load_state_dict(sd)
+        model.to(dev).train()
+        ts = TrainStep(model, cfg, native=native)
+        outs = [{k: v.clone() for k, v in ts.step(*gb).items()} for _ in range(4)]
+        torch.cuda.synchronize()
+        st = model.store()
+        return outs, st.flat.clone(), st.bufflat.clone(), ts.opt_state.clone(), ts
+
+    eager, native = run(False), run(True)
+    assert native[4]._rec is not None and native[4]._rec.size > 100, "the step was not recorded"
+    for i, (a, b) in enumerate(zip(eager[0], native[0])):
+        for k in a:
+            assert torch.equal(a[k], b[k]), f"step {i}: {k} eager {a[k].item()} native {b[k].item()}"
+    for what, x, y in zip(("parameters", "running statistics", "optimiser state"), eager[1:4], native[1:4]):
+        assert torch.equal(x, y), f"{what}: {int((x != y).sum())} elements differ between eager and native steps"
+    losses = [o["loss_total"].item() for o in native[0]]
+    assert len(set(losses)) == 4, f"the replayed steps must keep training (and drawing fresh dropout masks): {losses}"
+    # a new batch of the same shape is copied into the static inputs
+    ts = native[4]
+    nb = [t.clone() for t in gb]
+    nb[0] = nb[0] * 0.5
+    out = ts.step(*nb)
+    assert torch.isfinite(out["loss_total"]).item()
+    with pytest.raises(ValueError):
+        ts.step(nb[0][:1], nb[1][:1], nb[2][:1], nb[3][:1])
+
+
+def test_checkpoint_resume_lrw_with_dropout():
+    """TrainStep.state_dict() carries the dropout seed word: a resumed LRW run draws the masks the uninterrupted run draws."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from syncvsr_amd.engine import TrainStep
+    from syncvsr_amd.model import Model
+
+    dev = torch.device("cuda:0")
+    cfg, sd, batch, training, gold = build_case("lrw_tiny")
+    cfg.optim.scheduler.num_warmup_steps = 1
+    cfg.model.bert.hidden_dropout_prob = 0.2
+    gb = [t.to(dev) for t in batch]
+
+    def fresh(state):
+        m = Model(cfg, seed=5)
+        m.load_state_dict(state)
+        m.to(dev).train()
+        return m, TrainStep(m, cfg)
+
+    m1, ts1 = fresh(sd)
+    ref = [ts1.step(*gb)["loss_total"].item() for _ in range(4)]
+    m2, ts2 = fresh(sd)
+    first = [ts2.step(*gb)["loss_total"].item() for _ in range(2)]
+    ckpt_model = {k: v.detach().cpu().clone() for k, v in m2.state_dict().items()}
+    ckpt_opt = {k: v.cpu() for k, v in ts2.state_dict().items()}
+    m3, ts3 = fresh(ckpt_model)
+    ts3.load_state_dict({k: v.to(dev) for k, v in ckpt_opt.items()})
+    resumed = [ts3.step(*gb)["loss_total"].item() for _ in range(2)]
+    assert first + resumed == ref, (first + resumed, ref)

@@ -312,3 +312,41 @@ def test_header_parser_handles_every_declaration_form():
     assert _lib._RESTYPE["svsr_igemm_fwd"] == "int"
     assert [t for t, _ in h["svsr_tune"]] == ["const char*", "int"]
     assert all(name.startswith("svsr_") for name in h) and len(h) >= 69
+
+
+def test_step_list_registry_covers_every_stream_entry_point():
+    """csrc/steplist.hip re-issues recorded launches through a table of entry points: every function of include/syncvsr_hip.h that
+    takes a hipStream_t (except the step-list / stream plumbing itself) must be in it, or a recorded step would refuse the launch."""
+    from syncvsr_amd import _lib
+
+    lib = _lib.load()
+    hdr = _lib.parse_header()
+    plumbing = {"svsr_stream_wait", "svsr_memset_async"}
+    launches = [n for n, a in hdr.items() if a and a[-1][0] == "hipStream_t" and not n.startswith("svsr_steplist") and n not in plumbing]
+    assert len(launches) >= 50
+    missing = [n for n in launches if not lib.svsr_steplist_knows(n.encode())]
+    assert not missing, missing
+    assert not lib.svsr_steplist_knows(b"svsr_conv_plan")            # host-side query, not a launch
+
+
+def test_step_list_segments_and_argument_checks():
+    """Host logic of the step list without a GPU: segment bookkeeping, arity check, unknown names."""
+    import ctypes
+
+    from syncvsr_amd import _lib
+
+    lib = _lib.load()
+    h = lib.svsr_steplist_create()
+    try:
+        assert lib.svsr_steplist_segments(h) == 1 and lib.svsr_steplist_size(h) == 0
+        slots = (ctypes.c_int64 * 3)(0, 1, 0)
+        assert lib.svsr_steplist_push_call(h, b"svsr_word_add", slots, 3) == 0
+        assert lib.svsr_steplist_push_call(h, b"svsr_word_add", slots, 2) == 1001          # wrong arity
+        assert lib.svsr_steplist_push_call(h, b"svsr_no_such_entry", slots, 3) == 1001
+        assert lib.svsr_steplist_push_break(h) == 1
+        assert lib.svsr_steplist_segments(h) == 2 and lib.svsr_steplist_size(h) == 1
+        failed = ctypes.c_int(-1)
+        assert lib.svsr_steplist_run(h, 5, ctypes.byref(failed)) == 1001                   # no such segment
+        assert lib.svsr_steplist_run(h, 1, ctypes.byref(failed)) == 0                      # empty segment: nothing to issue
+    finally:
+        assert lib.svsr_steplist_destroy(h) == 0
