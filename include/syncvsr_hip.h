@@ -40,11 +40,13 @@ extern "C" {
 /* ---- plumbing (runtime.hip) ------------------------------------------------------------------------------------
  * svsr_tune: sets a result-preserving tuning knob ("igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd",
  * "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe",
- * "stem_fwd_dma", "igemm_lin_bn64": tile shapes, split counts, kernel-variant switches — documented at the table in runtime.hip;
+ * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger": tile shapes, split counts, kernel-variant switches — documented at the table in runtime.hip;
  * never read from the environment); unknown key -> SVSR_ERR_ARG.
  * svsr_colsum_rows: out[c] (+)= scale * sum_{r<nrows} ws[r*ld + c], rows added in a fixed order; columns [0,n0) go to out0,
  * [n0,n0+n1) to out1 (may be null when n1 = 0); accumulate != 0 adds to the existing values. */
 int svsr_tune(const char* key, int value);
+/* debug aid of scripts/probes: the per-phase time stamps (s_memtime) of the last launch made with the knob "p8_trace" set */
+int svsr_debug_p8_trace(int64_t* out1024);
 int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale, hipStream_t stream);
 
 /* ---- implicit-GEMM contractions (igemm_fwd.hip) -------------------------------------------------------------------

@@ -39,20 +39,91 @@ BN_MOMENTUM = 0.1
 
 
 # --------------------------------------------------------------------------------------------
+# bf16-storage emulation (`emu=True`): the SAME restatement with every tensor the HIP path keeps in bf16 rounded to bf16 at the
+# point where that path stores it — activations in the forward pass, their gradients in the backward pass — and the MFMA
+# kernels' weight operands taken from the bf16 shadow.  Arithmetic stays fp32 (as the kernels' accumulators and BatchNorm /
+# LayerNorm statistics are).  The reference itself trains under bf16 autocast (config `precision: bf16`), so neither mode is
+# "the" reference result; this one isolates what the fp32 comparison cannot: whether the HIP kernels compute the right
+# function of the rounded values (ReLU masks, pooling winners and BatchNorm sums then agree instead of flipping at random).
+# --------------------------------------------------------------------------------------------
+class _RoundBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _st(x: Tensor, emu: bool) -> Tensor:
+    """A tensor the HIP path stores in bf16 (value and gradient)."""
+    return _RoundBf16.apply(x) if emu else x
+
+
+class _BnEmu(torch.autograd.Function):
+    """Training-mode BatchNorm as the HIP path evaluates it around a bf16-stored input: statistics from the convolution's fp32
+    accumulators `c32`, normalisation of its bf16 copy, and a backward pass that forms
+        dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat))
+    in fp32 and stores THAT in bf16 (norm_act.hip k_bn_act_bwd_apply) — one rounding of the whole expression, where composing
+    autograd nodes would round the direct term only.  The difference is zero-mean noise per element, but a weight gradient sums
+    it against the block input, and where that input has a large common component (the stem's GELU output feeding layer1) the
+    sum has nothing else left: measured cosine 0.9946 -> 0.9999 on resnet.layer1.0.conv1.weight."""
+
+    @staticmethod
+    def forward(ctx, c32, w, b):
+        dims = [d for d in range(c32.dim()) if d != 1]
+        shape = [1, -1] + [1] * (c32.dim() - 2)
+        mean = c32.mean(dims)
+        rstd = torch.rsqrt(c32.var(dims, unbiased=False) + BN_EPS)
+        xhat = (c32.bfloat16().float() - mean.view(shape)) * rstd.view(shape)
+        ctx.save_for_backward(xhat, rstd, w)
+        ctx.dims, ctx.shape = dims, shape
+        return xhat * w.view(shape) + b.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        xhat, rstd, w = ctx.saved_tensors
+        dims, shape = ctx.dims, ctx.shape
+        sg, sgx = g.sum(dims), (g * xhat).sum(dims)
+        n = g.numel() // g.size(1)
+        dx = (w * rstd).view(shape) * (g - (sg / n).view(shape) - xhat * (sgx / n).view(shape))
+        return dx.bfloat16().float(), sgx, sg
+
+
+def _w16(w: Tensor, emu: bool) -> Tensor:
+    """The bf16 shadow of a weight the MFMA kernels read; its gradient reaches the fp32 master unrounded."""
+    return w.bfloat16().float() if emu else w
+
+
+# --------------------------------------------------------------------------------------------
 # primitives
 # --------------------------------------------------------------------------------------------
-def batch_norm(x: Tensor, sd: SD, prefix: str, training: bool, stats_out: dict | None = None) -> Tensor:
+def batch_norm(x: Tensor, sd: SD, prefix: str, training: bool, stats_out: dict | None = None, x_stats: Tensor | None = None) -> Tensor:
     """BatchNorm{2d,3d} over all non-channel dims (channel = dim 1).  SURVEY App. A.1.
 
     training: biased batch variance for normalisation; running stats updated with momentum 0.1 and the
-    *unbiased* variance.  eval: running statistics.
+    *unbiased* variance.  eval: running statistics.  x_stats (bf16-storage emulation, training): the convolution's fp32
+    accumulators — the batch statistics are taken from them while their bf16-rounded copy is what gets normalised (_BnEmu; `x` is
+    then only the eval-mode input).
     """
     w, b = sd[f"{prefix}.weight"], sd[f"{prefix}.bias"]
     dims = [d for d in range(x.dim()) if d != 1]
     shape = [1, -1] + [1] * (x.dim() - 2)
+    if training and x_stats is not None:
+        if stats_out is not None:
+            with torch.no_grad():
+                n = x_stats.numel() // x_stats.size(1)
+                mean, var = x_stats.mean(dims), x_stats.var(dims, unbiased=False)
+                rm, rv = sd[f"{prefix}.running_mean"], sd[f"{prefix}.running_var"]
+                stats_out[f"{prefix}.running_mean"] = (1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean
+                stats_out[f"{prefix}.running_var"] = (1 - BN_MOMENTUM) * rv + BN_MOMENTUM * var * n / max(n - 1, 1)
+                stats_out[f"{prefix}.num_batches_tracked"] = sd[f"{prefix}.num_batches_tracked"] + 1
+        return _BnEmu.apply(x_stats, w, b)
     if training:
-        mean = x.mean(dims)
-        var = x.var(dims, unbiased=False)
+        xs = x
+        mean = xs.mean(dims)
+        var = xs.var(dims, unbiased=False)
         if stats_out is not None:
             n = x.numel() // x.size(1)
             rm, rv = sd[f"{prefix}.running_mean"], sd[f"{prefix}.running_var"]
@@ -79,44 +150,57 @@ def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
 # --------------------------------------------------------------------------------------------
 # visual front-end  (lightning.py:49-55, 112-119)
 # --------------------------------------------------------------------------------------------
-def stem3d(videos: Tensor, sd: SD, training: bool, stats_out: dict | None = None, keep: dict | None = None) -> Tensor:
-    """Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) -> BatchNorm3d -> GELU -> MaxPool3d((1,3,3),(1,2,2),(0,1,1))."""
-    x = F.conv3d(videos, sd["stem3d.0.weight"], None, stride=(1, 2, 2), padding=(2, 3, 3))
+def stem3d(videos: Tensor, sd: SD, training: bool, stats_out: dict | None = None, keep: dict | None = None, emu: bool = False) -> Tensor:
+    """Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) -> BatchNorm3d -> GELU -> MaxPool3d((1,3,3),(1,2,2),(0,1,1)).
+    emu: clip and weights enter the MFMA contraction as bf16; the conv output and the pooled output are stored in bf16."""
+    c32 = F.conv3d(videos.bfloat16().float() if emu else videos, _w16(sd["stem3d.0.weight"], emu), None, stride=(1, 2, 2), padding=(2, 3, 3))
+    x = _st(c32, emu)
     if keep is not None:
         keep["stem_conv"] = x
-    x = batch_norm(x, sd, "stem3d.1", training, stats_out)
+    x = batch_norm(x, sd, "stem3d.1", training, stats_out, x_stats=c32 if emu else None)
     x = gelu_erf(x)
     x = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
-    return x
+    return _st(x, emu)
 
 
-def basic_block(x: Tensor, sd: SD, prefix: str, stride: int, training: bool, stats_out: dict | None = None) -> Tensor:
-    """tcn/models/resnet.py:59-72 with relu_type='relu' (== timm BasicBlock)."""
-    out = F.conv2d(x, sd[f"{prefix}.conv1.weight"], None, stride=stride, padding=1)
-    out = torch.relu(batch_norm(out, sd, f"{prefix}.bn1", training, stats_out))
-    out = F.conv2d(out, sd[f"{prefix}.conv2.weight"], None, stride=1, padding=1)
-    out = batch_norm(out, sd, f"{prefix}.bn2", training, stats_out)
+def basic_block(x: Tensor, sd: SD, prefix: str, stride: int, training: bool, stats_out: dict | None = None, emu: bool = False,
+                keep: dict | None = None) -> Tensor:
+    """tcn/models/resnet.py:59-72 with relu_type='relu' (== timm BasicBlock).
+    emu: each convolution output (pre-BatchNorm, statistics from its fp32 accumulators) and each BatchNorm(+ReLU) output is a bf16 tensor."""
+    c32 = F.conv2d(x, _w16(sd[f"{prefix}.conv1.weight"], emu), None, stride=stride, padding=1)
+    out = _st(torch.relu(batch_norm(_st(c32, emu), sd, f"{prefix}.bn1", training, stats_out, x_stats=c32 if emu else None)), emu)
+    if keep is not None:
+        keep[f"{prefix}.conv1.c"], keep[f"{prefix}.bn1.y"] = c32, out
+    c32 = F.conv2d(out, _w16(sd[f"{prefix}.conv2.weight"], emu), None, stride=1, padding=1)
+    if keep is not None:
+        keep[f"{prefix}.conv2.c"] = c32
+    out = batch_norm(_st(c32, emu), sd, f"{prefix}.bn2", training, stats_out, x_stats=c32 if emu else None)
     if f"{prefix}.downsample.0.weight" in sd:
-        res = F.conv2d(x, sd[f"{prefix}.downsample.0.weight"], None, stride=stride)
-        res = batch_norm(res, sd, f"{prefix}.downsample.1", training, stats_out)
+        c32 = F.conv2d(x, _w16(sd[f"{prefix}.downsample.0.weight"], emu), None, stride=stride)
+        res = _st(batch_norm(_st(c32, emu), sd, f"{prefix}.downsample.1", training, stats_out, x_stats=c32 if emu else None), emu)
     else:
         res = x
-    return torch.relu(out + res)
+    z = out + res
+    if keep is not None:
+        keep[f"{prefix}.z"] = z           # pre-activation of the block's output
+    return _st(torch.relu(z), emu)
 
 
-def forward_videos(videos: Tensor, sd: SD, training: bool, stats_out: dict | None = None, keep: dict | None = None) -> Tensor:
+def forward_videos(videos: Tensor, sd: SD, training: bool, stats_out: dict | None = None, keep: dict | None = None, emu: bool = False) -> Tensor:
     """lightning.py:112-119: stem -> (B*T) frames -> layer1..4 -> spatial mean -> [B,T,512]."""
     B = videos.size(0)
-    h = stem3d(videos, sd, training, stats_out, keep).transpose(1, 2).flatten(0, 1)
+    h = stem3d(videos, sd, training, stats_out, keep, emu).transpose(1, 2).flatten(0, 1)
     if keep is not None:
         keep["stem_out"] = h
     for li in range(1, 5):
         for bi in range(2):
             stride = 2 if (bi == 0 and li > 1) else 1
-            h = basic_block(h, sd, f"resnet.layer{li}.{bi}", stride, training, stats_out)
+            h = basic_block(h, sd, f"resnet.layer{li}.{bi}", stride, training, stats_out, emu, keep)
+            if keep is not None:
+                keep[f"resnet.layer{li}.{bi}.out"] = h
         if keep is not None:
             keep[f"layer{li}"] = h
-    return h.mean((2, 3)).unflatten(0, (B, -1))
+    return _st(h.mean((2, 3)), emu).unflatten(0, (B, -1))
 
 
 # --------------------------------------------------------------------------------------------
@@ -155,42 +239,42 @@ def _dp(dp, x: Tensor, site: str, kind: str = "hidden", pitch: int | None = None
     return x if dp is None else dp(x, site, kind, pitch)
 
 
-def bert_embeddings(x: Tensor, sd: SD, eps: float, dp=None) -> Tensor:
+def bert_embeddings(x: Tensor, sd: SD, eps: float, dp=None, emu: bool = False) -> Tensor:
     S = x.size(1)
-    e = x + sd["encoder.embeddings.position_embeddings.weight"][:S] + sd["encoder.embeddings.token_type_embeddings.weight"][0]
-    return _dp(dp, layer_norm(e, sd["encoder.embeddings.LayerNorm.weight"], sd["encoder.embeddings.LayerNorm.bias"], eps), "emb.out")
+    e = _st(x + sd["encoder.embeddings.position_embeddings.weight"][:S] + sd["encoder.embeddings.token_type_embeddings.weight"][0], emu)
+    return _st(_dp(dp, layer_norm(e, sd["encoder.embeddings.LayerNorm.weight"], sd["encoder.embeddings.LayerNorm.bias"], eps), "emb.out"), emu)
 
 
-def bert_layer(x: Tensor, sd: SD, p: str, heads: int, eps: float, keep: dict | None = None, dp=None, i: int = 0) -> Tensor:
+def bert_layer(x: Tensor, sd: SD, p: str, heads: int, eps: float, keep: dict | None = None, dp=None, i: int = 0, emu: bool = False) -> Tensor:
     B, S, D = x.shape
     dh = D // heads
 
     def lin(t: Tensor, name: str) -> Tensor:
-        return F.linear(t, sd[f"{p}.{name}.weight"], sd[f"{p}.{name}.bias"])
+        return F.linear(t, _w16(sd[f"{p}.{name}.weight"], emu), sd[f"{p}.{name}.bias"])
 
-    q = lin(x, "attention.self.query").view(B, S, heads, dh).transpose(1, 2)
-    k = lin(x, "attention.self.key").view(B, S, heads, dh).transpose(1, 2)
-    v = lin(x, "attention.self.value").view(B, S, heads, dh).transpose(1, 2)
+    q = _st(lin(x, "attention.self.query"), emu).view(B, S, heads, dh).transpose(1, 2)
+    k = _st(lin(x, "attention.self.key"), emu).view(B, S, heads, dh).transpose(1, 2)
+    v = _st(lin(x, "attention.self.value"), emu).view(B, S, heads, dh).transpose(1, 2)
     scores = q @ k.transpose(-1, -2) / math.sqrt(dh)
-    probs = _dp(dp, torch.softmax(scores, dim=-1), f"enc.{i}.attn.probs", "attn")
-    ctx = (probs @ v).transpose(1, 2).reshape(B, S, D)
+    probs = _dp(dp, _st(torch.softmax(scores, dim=-1), emu), f"enc.{i}.attn.probs", "attn")
+    ctx = _st((probs @ v).transpose(1, 2).reshape(B, S, D), emu)
     if keep is not None:
         keep[f"{p}.ctx"] = ctx
-    x = layer_norm(_dp(dp, lin(ctx, "attention.output.dense"), f"enc.{i}.attn.out") + x, sd[f"{p}.attention.output.LayerNorm.weight"],
-                   sd[f"{p}.attention.output.LayerNorm.bias"], eps)
-    h = gelu_erf(lin(x, "intermediate.dense"))
-    x = layer_norm(_dp(dp, lin(h, "output.dense"), f"enc.{i}.ff.out") + x, sd[f"{p}.output.LayerNorm.weight"], sd[f"{p}.output.LayerNorm.bias"], eps)
+    x = _st(layer_norm(_st(_dp(dp, lin(ctx, "attention.output.dense"), f"enc.{i}.attn.out"), emu) + x, sd[f"{p}.attention.output.LayerNorm.weight"],
+                       sd[f"{p}.attention.output.LayerNorm.bias"], eps), emu)
+    h = _st(gelu_erf(_st(lin(x, "intermediate.dense"), emu)), emu)
+    x = _st(layer_norm(_st(_dp(dp, lin(h, "output.dense"), f"enc.{i}.ff.out"), emu) + x, sd[f"{p}.output.LayerNorm.weight"], sd[f"{p}.output.LayerNorm.bias"], eps), emu)
     return x
 
 
-def bert_encoder(x: Tensor, sd: SD, cfg: Any, keep: dict | None = None, dp=None) -> Tensor:
+def bert_encoder(x: Tensor, sd: SD, cfg: Any, keep: dict | None = None, dp=None, emu: bool = False) -> Tensor:
     bert = cfg.model.bert
     eps = float(bert.get("layer_norm_eps", 1e-12))
-    x = bert_embeddings(x, sd, eps, dp)
+    x = bert_embeddings(x, sd, eps, dp, emu)
     if keep is not None:
         keep["emb"] = x
     for i in range(int(bert.num_hidden_layers)):
-        x = bert_layer(x, sd, f"encoder.encoder.layer.{i}", int(bert.num_attention_heads), eps, keep, dp, i)
+        x = bert_layer(x, sd, f"encoder.encoder.layer.{i}", int(bert.num_attention_heads), eps, keep, dp, i, emu)
     return x
 
 
@@ -277,11 +361,13 @@ def audio_dims(cfg: Any) -> tuple[int, int, int]:
 
 def forward(sd: SD, cfg: Any, videos: Tensor, audio_tokens: Tensor, labels: Tensor, word_mask: Tensor,
             training: bool = True, use_cutmix_metric: bool = False, keep: dict | None = None,
-            stats_out: dict | None = None, dp=None, layer_skip: set | None = None) -> dict[str, Tensor]:
+            stats_out: dict | None = None, dp=None, layer_skip: set | None = None, emu: bool = False) -> dict[str, Tensor]:
     """TransformerLightningModule.forward (lightning.py:133-191); dropout only through `dp` (a DropPlan replaying the
-    library's masks), otherwise p = 0."""
+    library's masks), otherwise p = 0.  emu: bf16-storage emulation (see _RoundBf16; `type: huggingface` encoder only)."""
     A, G, V = audio_dims(cfg)
-    feats = forward_videos(videos, sd, training, stats_out, keep)                      # :136
+    if emu and str(cfg.model.bert.type) == "x-transformers":
+        raise NotImplementedError("bf16-storage emulation covers the huggingface branch")
+    feats = forward_videos(videos, sd, training, stats_out, keep, emu)                 # :136
     if keep is not None:
         keep["feats"] = feats
     if cfg.data.use_word_boundary:                                                       # :145
@@ -292,10 +378,10 @@ def forward(sd: SD, cfg: Any, videos: Tensor, audio_tokens: Tensor, labels: Tens
     if str(cfg.model.bert.type) == "x-transformers":
         h = xt_encoder(x, sd, cfg, keep, dp, layer_skip)                                 # :157-158
     else:
-        h = bert_encoder(x, sd, cfg, keep, dp)                                           # :152-156
-    logits_category = F.linear(h[:, 0], sd["category_classifier.weight"], sd["category_classifier.bias"]).float()
+        h = bert_encoder(x, sd, cfg, keep, dp, emu)                                      # :152-156
+    logits_category = F.linear(h[:, 0], _w16(sd["category_classifier.weight"], emu), sd["category_classifier.bias"]).float()
     loss_category = cross_entropy(logits_category, labels, float(cfg.train.label_smoothing))     # :161-165
-    logits_audio = F.linear(h[:, 1:], sd["audio_projection.weight"], sd["audio_projection.bias"]).float()
+    logits_audio = _st(F.linear(h[:, 1:], _w16(sd["audio_projection.weight"], emu), sd["audio_projection.bias"]).float(), emu)
     logits_audio = logits_audio.reshape(B, T, A * G, V)                                  # :168-170
     loss_audio = cross_entropy(logits_audio.reshape(-1, V), audio_tokens.flatten())      # :171
     loss_total = loss_category + loss_audio * float(cfg.optim.lambda_audio)              # :174

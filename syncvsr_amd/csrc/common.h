@@ -16,20 +16,22 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // Result-preserving tuning knobs (runtime.hip): a process-wide table set through svsr_tune(); the library never reads the
 // environment.
 enum { SVSR_TUNE_IGEMM_TILE = 0, SVSR_TUNE_IGEMM_M128, SVSR_TUNE_WG_BLOCKS, SVSR_TUNE_W3_BLOCKS, SVSR_TUNE_LN_RPB,
-       SVSR_TUNE_STEM_LDS_FWD, SVSR_TUNE_STEM_LDS_BWD, SVSR_TUNE_IGEMM_LDS_PAD, SVSR_TUNE_IGEMM_BN64_BELOW, SVSR_TUNE_WG_SHORT_K, SVSR_TUNE_IGEMM_KSPLIT, SVSR_TUNE_RES_DEEP, SVSR_TUNE_EPI_BATCHED, SVSR_TUNE_STEM_WG_PIPE, SVSR_TUNE_STEM_FWD_DMA, SVSR_TUNE_IGEMM_LIN_BN64, SVSR_TUNE_N };
+       SVSR_TUNE_STEM_LDS_FWD, SVSR_TUNE_STEM_LDS_BWD, SVSR_TUNE_IGEMM_LDS_PAD, SVSR_TUNE_IGEMM_BN64_BELOW, SVSR_TUNE_WG_SHORT_K, SVSR_TUNE_IGEMM_KSPLIT, SVSR_TUNE_RES_DEEP, SVSR_TUNE_EPI_BATCHED, SVSR_TUNE_STEM_WG_PIPE, SVSR_TUNE_STEM_FWD_DMA, SVSR_TUNE_IGEMM_LIN_BN64, SVSR_TUNE_P8, SVSR_TUNE_P8_GRID, SVSR_TUNE_P8_MIN_ITEMS, SVSR_TUNE_P8_TRACE, SVSR_TUNE_P8_PH, SVSR_TUNE_P8_STAGGER, SVSR_TUNE_N };
 int svsr_tune_get(int id);
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((unsigned)u) << 16); }
 
-// round-to-nearest-even, NaN preserved (matches torch's float -> bfloat16 cast)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// float -> bfloat16, round-to-nearest-even (torch's cast): ONE v_cvt_pk_bf16_f32 per pair on gfx950.  (The integer formulation
+// u += 0x7fff + lsb with its NaN test cost ~7 VALU operations per element: the output passes of the contraction epilogues and of the
+// BatchNorm / stem kernels were VALU-bound on it.  Results are identical for every non-NaN input; NaNs stay NaNs.)
+typedef __bf16 svsr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float svsr_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    const svsr_f32x2 v = {lo, hi};
+    const svsr_bf16x2 b = __builtin_convertvector(v, svsr_bf16x2);
+    return __builtin_bit_cast(unsigned, b);
 }
-
-__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 // Standard-normal CDF Phi(x) and e = exp(-x^2/2) for the exact (erf) GELU of nn.GELU().
 // erfc(z) = t*(a1 + t*(a2 + t*(a3 + t*(a4 + t*a5)))) * exp(-z^2), t = 1/(1 + p*z), z >= 0   (Abramowitz & Stegun 7.1.26,

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "common.h"
+#include "igemm_fwd.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Launch plan (host-built, device-resident int32 words): the rows of the contraction are grouped into CLASSES of output
@@ -36,35 +37,8 @@
 #define PLAN_CLS_WORDS 24
 #define PLAN_HDR_WORDS 2
 
-struct IgemmFwdArgs {
-    const bf16_t* in;
-    const bf16_t* wt;      // [Co][wt_taps][Ci]
-    void* out;             // bf16 or f32 pixels
-    bf16_t* out_pre;       // optional pre-activation copy (GELU epilogue)
-    const float* bias;     // optional [Co]
-    const bf16_t* addend;  // optional bf16 pixels with the geometry of `out`, added before the activation
-    float* stats;          // optional BatchNorm partials [gridDim.x][2][Co]: row blockIdx.x = this M tile's column sums / sums of squares
-    const int* plan;       // device copy of the plan words
-    int Nimg, in_pix, Ci, in_pitch;      // images, pixels per source image, contraction channels per tap (multiple of 64), source pitch
-    int Co, out_pix, out_pitch, wt_taps; // output channels, pixels per target image, target pitch, taps physically present in wt
-    int act, out_f32;          // act: 0 none, 1 GELU(erf) (pre-activation kept in out_pre), 2 ReLU
-    float alpha;               // out = alpha * dropout(act(acc + bias)) + addend
-    DropArgs drop;             // drop.seed == nullptr: no dropout
-    int epi_batched;           // epilogue: request all rows' operands before using the first (tuning knob "epi_batched", default on)
-    // BatchNorm-backward fusion (data-gradient launches whose result is the gradient of a BatchNorm+ReLU output y = relu(bn(x) [+ res])):
-    // out = g = (y > 0 ? result : 0) and stats rows = this tile's column sums of {g, g * (x - mean) * rstd}   (bnb_x == nullptr: off)
-    const bf16_t* bnb_y;
-    const bf16_t* bnb_x;
-    const float* bnb_mean;
-    const float* bnb_rstd;
-    const float* bnb_gamma;    // with bnb_y == nullptr (no residual branch): the mask is recomputed as bn(x) > 0 with the forward's own
-    const float* bnb_beta;     // expression (norm_act.hip k_bn_act_fwd) instead of being read from y
-    int bnb_act;               // 1 ReLU (bnb_y = the output y, or null), 2 Swish: g = result * swish'(bn(x) + r), bnb_y = the residual input r or null
-};
-
 __device__ unsigned g_zero_page[64];     // 256 zero bytes: DMA source for rows outside the grid
 
-#define LDS_SWZ(row, chunk) ((row) * 64 + ((((chunk) ^ (((row) >> 1) & 7))) << 3))
 
 // ---------------------------------------------------------------------------------------------------------------------
 // shared epilogue
@@ -735,12 +709,60 @@ static IgemmFwdPlan igemm_fwd_plan(long M, int Co, int max_taps) {
 struct PlanClass { int ntaps; int delta[9], tw[9]; std::vector<int> pos; };     // pos: (src, dst) pairs
 
 // meta: {bm, bn, ns, tiles (= grid.x = BatchNorm partial rows), grid.y, classes, max taps of a class, total rows / 2^0 (low 31 bits)}
-static int plan_emit(std::vector<PlanClass>& cls, int Nimg, int Co, int* words, int cap_words, int* meta) {
+// p8 format (igemm_fwd.h): per 256-row M tile a descriptor and a row table of global pixel indices, tiles in class order
+static int plan_emit_p8(const std::vector<PlanClass>& cls, int Nimg, int Co, int in_pix, int out_pix, int* words, int cap_words, int* meta, long M, int max_taps) {
+    long tiles_m = 0;
+    for (const PlanClass& c : cls) tiles_m += ((long)Nimg * (long)(c.pos.size() / 2) + P8_BM - 1) / P8_BM;
+    const int gy = Co / P8_BN;
+    const long nwords = P8_HDR_WORDS + tiles_m * (P8_DESC_WORDS + 2 * P8_BM);
+    if (nwords > 0x7fffffffL || (long)Nimg * in_pix >= (1L << 31) || (long)Nimg * out_pix >= (1L << 31)) return -SVSR_ERR_ARG;
+    if (words != nullptr) {
+        if (cap_words < nwords) return -SVSR_ERR_ARG;
+        const int off_desc = P8_HDR_WORDS, off_rows = P8_HDR_WORDS + (int)tiles_m * P8_DESC_WORDS;
+        words[0] = P8_MAGIC; words[1] = (int)tiles_m; words[2] = gy; words[3] = off_desc; words[4] = off_rows;
+        words[5] = (int)((tiles_m + 7) / 8 * 8 * gy); words[6] = 0; words[7] = 0;
+        long t = 0;
+        for (const PlanClass& c : cls) {
+            const long P = (long)(c.pos.size() / 2), Mc = (long)Nimg * P;
+            for (long m0 = 0; m0 < Mc; m0 += P8_BM, ++t) {
+                int* d = words + off_desc + t * P8_DESC_WORDS;
+                for (int k = 0; k < P8_DESC_WORDS; ++k) d[k] = 0;
+                d[0] = c.ntaps; d[1] = (int)(Mc - m0 < P8_BM ? Mc - m0 : P8_BM);
+                for (int k = 0; k < c.ntaps; ++k) { d[2 + k] = c.delta[k]; d[11 + k] = c.tw[k]; }
+                int* rt = words + off_rows + t * 2 * P8_BM;
+                for (int rr = 0; rr < P8_BM; ++rr) {
+                    const long m = m0 + rr;
+                    if (m < Mc) {
+                        const long n = m / P, j = m - n * P;
+                        rt[2 * rr] = (int)(n * in_pix + c.pos[2 * j]);
+                        rt[2 * rr + 1] = (int)(n * out_pix + c.pos[2 * j + 1]);
+                    } else { rt[2 * rr] = rt[0]; rt[2 * rr + 1] = -1; }       // a readable source (the tile's first row); no target
+                }
+            }
+        }
+    }
+    if (meta != nullptr) {
+        meta[0] = P8_BM; meta[1] = P8_BN; meta[2] = 3; meta[3] = (int)tiles_m; meta[4] = gy; meta[5] = (int)cls.size(); meta[6] = max_taps;
+        meta[7] = (int)(M & 0x7fffffff);
+    }
+    return (int)nwords;
+}
+
+// p8_pix: {source pixels per image, target pixels per image} when the caller's shape qualifies for the persistent kernel, else null
+static int plan_emit(std::vector<PlanClass>& cls, int Nimg, int Co, int* words, int cap_words, int* meta, const int* p8_pix = nullptr) {
     std::stable_sort(cls.begin(), cls.end(), [](const PlanClass& a, const PlanClass& b) { return a.ntaps > b.ntaps; });
     long M = 0;
     int max_taps = 0;
     for (const PlanClass& c : cls) { M += (long)Nimg * (long)(c.pos.size() / 2); if (c.ntaps > max_taps) max_taps = c.ntaps; }
     if (M >= (1L << 24) * 64 || cls.empty()) return -SVSR_ERR_ARG;
+    if (p8_pix != nullptr && svsr_tune_get(SVSR_TUNE_P8) && Co % P8_BN == 0) {
+        long tiles_m = 0;
+        int min_taps = 9;
+        for (const PlanClass& c : cls) { tiles_m += ((long)Nimg * (long)(c.pos.size() / 2) + P8_BM - 1) / P8_BM; if (c.ntaps < min_taps) min_taps = c.ntaps; }
+        // (the kernel's pipeline needs >= 4 K tiles per tile: every class of a padded 3x3 convolution has >= 4 taps)
+        if (min_taps >= 4 && tiles_m * (Co / P8_BN) >= svsr_tune_get(SVSR_TUNE_P8_MIN_ITEMS))
+            return plan_emit_p8(cls, Nimg, Co, p8_pix[0], p8_pix[1], words, cap_words, meta, M, max_taps);
+    }
     const IgemmFwdPlan pl = igemm_fwd_plan(M, Co, max_taps);
     const int ncls = (int)cls.size();
     int nwords = PLAN_HDR_WORDS + ncls * PLAN_CLS_WORDS;
@@ -842,7 +864,10 @@ extern "C" int svsr_conv_plan(int mode, int Nimg, int H, int W, int Co_out, int 
                 add(key, ca * Wo + cb, y * W + x);
             }
     }
-    return plan_emit(cls, Nimg, Co_out, words, cap_words, meta);
+    // stride-1 3x3 / pad 1 (forward and data gradient alike: same map size on both sides): candidates for the persistent kernel
+    const int p8_pix[2] = {mode == 0 ? H * W : Ho * Wo, mode == 0 ? Ho * Wo : H * W};
+    const bool p8_ok = k == 3 && stride == 1 && pad == 1 && H >= 2 && W >= 2;
+    return plan_emit(cls, Nimg, Co_out, words, cap_words, meta, p8_ok ? p8_pix : nullptr);
 }
 
 /* svsr_rows_plan (host): plan of a dense layer over rows grouped in Nimg sequences: row (n, j), j < P, reads source row
@@ -925,6 +950,7 @@ static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pr
     a.bnb_gamma = bnb_gamma; a.bnb_beta = bnb_beta; a.bnb_act = bnb_act;
     const int bm = meta[0], bn = meta[1], ns = meta[2], gx = meta[3], gy = (Co + bn - 1) / bn;
     if (gx < 1) return SVSR_ERR_ARG;
+    if (bm == P8_BM) return igemm_p8_launch(a, meta, stream);
     // few tiles, long contraction: split K inside the workgroup (see k_igemm_fwd_glds, KG = 2)
     if (bnb_x == nullptr && bm == 64 && bn == 64 && svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT) && (long)gx * gy <= svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT) &&
         (long)meta[6] * (Ci / 64) >= 12)

