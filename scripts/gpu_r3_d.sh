@@ -1,3 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r3d
-timeout 1500 python scripts/probes/emu_parity.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3d/emu.log
+timeout 600 python scripts/probes/native_debug.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r3d/native_debug.log

@@ -285,7 +285,15 @@ __global__ void k_fill_f32(float* p, long n, float v) {
 }
 
 __global__ void k_word_add(int* w, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) w[0] += delta; }
-__global__ void k_lincomb2(const float* a, const float* b, float wb, float* out) { if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = __fadd_rn(a[0], __fmul_rn(wb, b[0]));   /* two roundings, as torch's mul + add */ }
+__global__ void k_lincomb2(const float* a, const float* b, float wb, float* out) {
+    // two roundings, as torch's `a + b * w` (a mul kernel, then an add kernel): no fused multiply-add here
+    // (the build's -ffp-contract=fast disregards contraction pragmas: the product goes through an opaque register instead)
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float t = wb * b[0];
+        asm volatile("" : "+v"(t));
+        out[0] = a[0] + t;
+    }
+}
 
 __global__ __launch_bounds__(256) void k_video_cast(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = f2bf(src[i]);
