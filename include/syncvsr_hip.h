@@ -33,6 +33,12 @@ typedef void* hipStream_t;
 #define SVSR_OK 0
 #define SVSR_ERR_ARG 1001
 
+/* one problem of svsr_igemm_wgrad_group: the arguments of a svsr_igemm_wgrad call (device pointers; meta = the HOST meta[8] of the plan) */
+typedef struct svsr_wgrad_problem {
+    const void* x; const void* dy; float* dw; float* dbias; const int* plan_dev; const int* meta;
+    int Nimg; int in_pix; int Ci; int in_pitch; int Co; int out_pix; int out_pitch; int wt_taps;
+} svsr_wgrad_problem;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -90,6 +96,13 @@ int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, con
 int svsr_wgrad_plan(int Nimg, int H, int W, int Ci, int Co, int k, int stride, int pad, int* words, int cap_words, int* meta, int64_t* part_floats);
 int svsr_wgrad_rows_plan(int Nimg, int P, int src0, int dst0, int Ci, int Co, int has_bias, int* words, int cap_words, int* meta, int64_t* part_floats);
 int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, float* dbias, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, float* part, int64_t part_floats, hipStream_t stream);
+/* svsr_igemm_wgrad_group: n independent svsr_igemm_wgrad problems in ONE launch — the weight gradients of the encoder's and the heads'
+ * nn.Linear layers (reference lightning.py:82,92,107: 26 short contractions of a backward pass; as launches of their own each is 7-17 us
+ * of latency for ~1 us of work).  Every problem must carry a plan without K split on 64-wide tiles (meta[0..2] = {64, 3, 1}); anything
+ * else returns SVSR_ERR_ARG.  table_dev: caller-owned device buffer of >= svsr_igemm_wgrad_group_bytes(n) bytes.  Results are identical
+ * to n separate svsr_igemm_wgrad calls (same workgroup code, one writer per element). */
+int64_t svsr_igemm_wgrad_group_bytes(int n);
+int svsr_igemm_wgrad_group(const svsr_wgrad_problem* problems, int n, void* table_dev, int64_t table_bytes, hipStream_t stream);
 
 /* svsr_conv3x3_c64: conv3x3(64, 64), stride 1, pad 1 (layer1 of the trunk, resnet.py:8-10,36,53) forward and, with the
  * transposed weights and mirrored taps, its input-gradient; persistent workgroups, weights resident in LDS

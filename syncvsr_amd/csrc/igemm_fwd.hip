@@ -388,7 +388,11 @@ __global__ __launch_bounds__(256 * KG) void k_igemm_fwd_glds(const IgemmFwdArgs 
     const int wrow = __builtin_amdgcn_readfirstlane(wave) * 8;   // first row of this wave's 8-row group
 
     // this block's class (wave-uniform scalar loads; tile_begin is ascending)
-    const int ncls = p.plan[0];
+    // words[0] = classes | identity << 16: identity = the one class maps row m to source row m and target row m (a plain dense layer):
+    // no position table to fetch — one dependent global round trip less in front of the first DMA of these latency-bound launches
+    const int hdr0 = p.plan[0];
+    const int ncls = hdr0 & 0xffff;
+    const bool identity = (hdr0 >> 16) != 0;
     int cls = 0;
     for (int c = 1; c < ncls; ++c)
         if ((int)blockIdx.x >= p.plan[PLAN_HDR_WORDS + c * PLAN_CLS_WORDS + 3]) cls = c;
@@ -409,9 +413,13 @@ __global__ __launch_bounds__(256 * KG) void k_igemm_fwd_glds(const IgemmFwdArgs 
     for (int i = 0; i < AR; ++i) {
         const int m = m0 + r0 + 32 * i;
         const bool ok = m < Mc;
-        int n, j;
-        split_row(ok ? m : 0, P, inv_p, n, j);
-        a_ptr[i] = p.in + ((long)n * p.in_pix + pos[2 * j]) * p.in_pitch + csw * 8;
+        if (identity) {
+            a_ptr[i] = p.in + (long)(ok ? m : 0) * p.in_pix * p.in_pitch + csw * 8;
+        } else {
+            int n, j;
+            split_row(ok ? m : 0, P, inv_p, n, j);
+            a_ptr[i] = p.in + ((long)n * p.in_pix + pos[2 * j]) * p.in_pitch + csw * 8;
+        }
         a_ok |= (ok ? 1u : 0u) << i;
     }
     const bf16_t* b_ptr[BR];
@@ -424,9 +432,13 @@ __global__ __launch_bounds__(256 * KG) void k_igemm_fwd_glds(const IgemmFwdArgs 
         const int m = m0 + r;
         long off = -1;
         if (m < Mc) {
-            int n, j;
-            split_row(m, P, inv_p, n, j);
-            off = ((long)n * p.out_pix + pos[2 * j + 1]) * p.out_pitch;
+            if (identity) {
+                off = (long)m * p.out_pix * p.out_pitch;
+            } else {
+                int n, j;
+                split_row(m, P, inv_p, n, j);
+                off = ((long)n * p.out_pix + pos[2 * j + 1]) * p.out_pitch;
+            }
         }
         sRow[r] = off;
     }
@@ -879,7 +891,9 @@ extern "C" int svsr_rows_plan(int Nimg, int P, int src0, int dst0, int Co_out, i
     cls[0].ntaps = 1; cls[0].delta[0] = 0; cls[0].tw[0] = 0;
     cls[0].pos.reserve(2 * (size_t)P);
     for (int j = 0; j < P; ++j) { cls[0].pos.push_back(src0 + j); cls[0].pos.push_back(dst0 + j); }
-    return plan_emit(cls, Nimg, Co_out, words, cap_words, meta);
+    const int n = plan_emit(cls, Nimg, Co_out, words, cap_words, meta);
+    if (n > 0 && words != nullptr && P == 1 && src0 == 0 && dst0 == 0) words[0] |= 1 << 16;      // identity rows: see k_igemm_fwd_glds
+    return n;
 }
 
 /* rows of [2][Co] BatchNorm partials svsr_conv3x3_res writes (one per 128-pixel tile) */

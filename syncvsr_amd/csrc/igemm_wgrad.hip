@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "common.h"
+#include "../../include/syncvsr_hip.h"
 
 #define WPLAN_HDR 2           // words[0] = taps, words[1] = word offset of the position table
 #define WPLAN_TAP_WORDS 4     // per tap: { P, pos_off (pairs), tw, 0 }
@@ -78,7 +79,7 @@ __device__ __forceinline__ void wg_wait_tiles_barrier(int later) {
 }
 
 template <int BC, int NS, bool BIAS>
-__device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_raw) {
+__device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_raw, const int split_idx, const int task_idx) {
     constexpr int T_ELEMS = 64 * BC;                 // one operand tile
     constexpr int S_ELEMS = 2 * T_ELEMS;             // stage = dY tile | X tile
     constexpr int RPI = 1024 / (BC * 2);             // rows per DMA instruction (1 KiB): 4 (BC 128) or 8 (BC 64)
@@ -93,7 +94,7 @@ __device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int co_tiles = (p.Co + BC - 1) / BC, ci_tiles = (p.Ci + BC - 1) / BC;
-    int rest = blockIdx.y;
+    int rest = task_idx;
     const int cot = rest % co_tiles; rest /= co_tiles;
     const int cit = rest % ci_tiles; rest /= ci_tiles;
     const int t = rest;
@@ -106,7 +107,7 @@ __device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_
     const int Mt = p.Nimg * P;                       // rows of this tap (0 for a tap no position reaches)
     const float inv_p = P > 0 ? 1.0f / (float)P : 0.f;
     const int total_chunks = (Mt + 63) / 64;
-    const int c_begin = blockIdx.x * p.chunks_per_split;
+    const int c_begin = split_idx * p.chunks_per_split;
     int c_end = c_begin + p.chunks_per_split;
     if (c_end > total_chunks) c_end = total_chunks;
     const int KT = c_end > c_begin ? c_end - c_begin : 0;
@@ -192,7 +193,7 @@ __device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_
     }
     // D[row = co][col = ci]: one writer per element — slab `blockIdx.x` (plain store) or, without a split, dW itself
     const bool direct = p.splits <= 1;
-    float* dst = direct ? p.dw : p.part + (long)blockIdx.x * p.slab;
+    float* dst = direct ? p.dw : p.part + (long)split_idx * p.slab;
 #pragma unroll
     for (int j = 0; j < TT; ++j) {
         const int ci = ci0 + wci + j * 32 + (lane & 31);
@@ -209,7 +210,7 @@ __device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_
             }
     }
     if (BIAS && wci == 0 && (lane & 31) == 0) {      // every column of accb holds the same sums: lanes 0 and 32 own 16 rows each
-        float* dbd = direct ? p.db : p.part + (long)blockIdx.x * p.slab + (long)p.Co * p.wt_taps * p.Ci;
+        float* dbd = direct ? p.db : p.part + (long)split_idx * p.slab + (long)p.Co * p.wt_taps * p.Ci;
 #pragma unroll
         for (int i = 0; i < TT; ++i)
 #pragma unroll
@@ -226,8 +227,28 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad(const WgradArgs p) {
     // the workgroups of ci tile 0 / tap 0 also produce the bias gradient: a scalar (blockIdx) branch between two instantiations
     const int co_tiles = (p.Co + BC - 1) / BC, ci_tiles = (p.Ci + BC - 1) / BC;
     const int rest = (int)blockIdx.y / co_tiles;
-    if (p.db != nullptr && rest % ci_tiles == 0 && rest / ci_tiles == 0) wg_body<BC, NS, true>(p, smem_raw);
-    else wg_body<BC, NS, false>(p, smem_raw);
+    if (p.db != nullptr && rest % ci_tiles == 0 && rest / ci_tiles == 0) wg_body<BC, NS, true>(p, smem_raw, blockIdx.x, blockIdx.y);
+    else wg_body<BC, NS, false>(p, smem_raw, blockIdx.x, blockIdx.y);
+}
+
+// GROUPED launch: one grid over the tiles of several independent weight-gradient problems (the encoder's and the heads' linear layers:
+// 26 contractions of 15 K chunks each, 7-17 us apiece as launches of their own — latency, not work).  table[i] = the problem's arguments
+// and the first tile it owns; every workgroup finds its problem with a scan over the (wave-uniform) table and runs the ordinary body.
+// No K split inside a group (splits = 1: each tile adds its result to dW directly, one writer per element), so nothing needs a slab.
+struct WgradGroupEntry { WgradArgs a; int tile_begin; int pad_; };
+
+template <int BC, int NS>
+__global__ __launch_bounds__(256) void k_igemm_wgrad_group(const WgradGroupEntry* __restrict__ table, int n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int idx = 0;
+    for (int i = 1; i < n; ++i)
+        if ((int)blockIdx.x >= table[i].tile_begin) idx = i;
+    const WgradArgs p = table[idx].a;
+    const int task = (int)blockIdx.x - table[idx].tile_begin;
+    const int co_tiles = (p.Co + BC - 1) / BC, ci_tiles = (p.Ci + BC - 1) / BC;
+    const int rest = task / co_tiles;
+    if (p.db != nullptr && rest % ci_tiles == 0 && rest / ci_tiles == 0) wg_body<BC, NS, true>(p, smem_raw, 0, task);
+    else wg_body<BC, NS, false>(p, smem_raw, 0, task);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
@@ -372,6 +393,47 @@ int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, float* dbias, co
     if (rc != SVSR_OK || a.splits <= 1) return rc;
     const int64_t n = (int64_t)Co * wt_taps * Ci;
     return svsr_colsum_rows(part, a.splits, a.slab, dw, n, dbias, dbias != nullptr ? Co : 0, 1, 1.0f, stream);
+}
+
+/* svsr_igemm_wgrad_group: n independent svsr_igemm_wgrad problems (each described like a call of its own: plan_dev + meta of
+ * svsr_wgrad_*plan) in ONE launch.  Every problem must have a plan without K split on 64-wide tiles (meta = {64, 3, 1, ...}: the short
+ * contractions this exists for) — anything else returns SVSR_ERR_ARG and the caller launches it alone.  table_dev: caller-owned device
+ * buffer of at least svsr_igemm_wgrad_group_bytes(n) bytes (the problem table is copied there on `stream` ahead of the kernel). */
+int64_t svsr_igemm_wgrad_group_bytes(int n) { return n < 1 ? 0 : (int64_t)n * (int64_t)sizeof(WgradGroupEntry); }
+
+int svsr_igemm_wgrad_group(const svsr_wgrad_problem* problems, int n, void* table_dev, int64_t table_bytes, hipStream_t stream) {
+    if (problems == nullptr || n < 1 || n > 256 || table_dev == nullptr || table_bytes < svsr_igemm_wgrad_group_bytes(n)) return SVSR_ERR_ARG;
+    std::vector<WgradGroupEntry> tab((size_t)n);
+    int tiles = 0, maxP = 1;
+    for (int i = 0; i < n; ++i) {
+        const svsr_wgrad_problem& q = problems[i];
+        if (q.plan_dev == nullptr || q.meta == nullptr || q.Ci < 1 || q.Co < 1 || q.in_pitch % 8 != 0 || q.out_pitch % 8 != 0 || q.Ci % 8 != 0 || q.Nimg < 1 ||
+            q.x == nullptr || q.dy == nullptr || q.dw == nullptr)
+            return SVSR_ERR_ARG;
+        if (q.meta[0] != 64 || q.meta[1] != 3 || q.meta[2] != 1) return SVSR_ERR_ARG;
+        WgradArgs& a = tab[i].a;
+        a.x = (const bf16_t*)q.x; a.dy = (const bf16_t*)q.dy; a.dw = q.dw; a.db = q.dbias; a.part = nullptr; a.plan = q.plan_dev;
+        a.splits = 1; a.chunks_per_split = q.meta[3];
+        a.slab = (long)q.Co * q.wt_taps * q.Ci + (q.dbias != nullptr ? q.Co : 0);
+        a.Nimg = q.Nimg; a.in_pix = q.in_pix; a.Ci = q.Ci; a.in_pitch = q.in_pitch; a.Co = q.Co; a.out_pix = q.out_pix; a.out_pitch = q.out_pitch;
+        a.wt_taps = q.wt_taps;
+        tab[i].tile_begin = tiles; tab[i].pad_ = 0;
+        tiles += q.meta[4];
+        if (q.meta[6] > maxP) maxP = q.meta[6];
+    }
+    // (pageable source: the runtime stages it before returning, so `tab` may go out of scope)
+    hipError_t e = hipMemcpyAsync(table_dev, tab.data(), (size_t)n * sizeof(WgradGroupEntry), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+    constexpr int BC = 64, NS = 3;
+    const size_t lds_max = (size_t)NS * 2 * 64 * BC * sizeof(bf16_t) + (size_t)WG_MAXP * 2 * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_wgrad_group<BC, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        attr_set = true;
+    }
+    const size_t lds = (size_t)NS * 2 * 64 * BC * sizeof(bf16_t) + (((size_t)maxP * 2 * sizeof(int) + 127) & ~(size_t)127);
+    hipLaunchKernelGGL((k_igemm_wgrad_group<BC, NS>), dim3(tiles), dim3(256), lds, stream, (const WgradGroupEntry*)table_dev, n);
+    return svsr_check_launch();
 }
 
 }  // extern "C"

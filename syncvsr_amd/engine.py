@@ -333,6 +333,8 @@ class GradReducer:
         # buffer, ready earliest)
         self.last_elems = min(self.bucket_elems, 1 << 20)
         self._st = None
+        self.measure = False                  # bench.py: time the join in finish() with HIP events (the collective time the step is exposed to)
+        self._join_events: list = []
         self._backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self.top = 0
@@ -356,6 +358,16 @@ class GradReducer:
                 if not b.is_floating_point():
                     dist.broadcast(b, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
             st.shadow_fresh = False          # the bf16 shadows follow the broadcast weights at the next forward
+
+    def exposed_ms(self) -> Optional[float]:
+        """Median time the main stream sat at the join of finish() (measure=True): what the step pays for collectives the backward
+        did not hide.  Synchronises the device."""
+        if not self._join_events:
+            return None
+        torch.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) for a, b in self._join_events)
+        self._join_events.clear()
+        return t[len(t) // 2]
 
     def _broadcast_buffers(self, st) -> None:
         """broadcast_buffers=True of DDP: the BatchNorm running statistics of every rank follow rank 0's — one collective over
@@ -428,6 +440,12 @@ class GradReducer:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self._broadcast_buffers(st)
+            if self.measure:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+            if self.measure:
+                e1.record()
+                self._join_events.append((e0, e1))
         elif self.world > 1 or self.always:
             self._broadcast_buffers(self._st if self._st is not None else self.model.store())

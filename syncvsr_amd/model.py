@@ -660,14 +660,38 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
     _ready(model, st, None)
 
 
+_ABLATE = os.environ.get("SVSR_ABLATE", "")       # timing experiments only (results wrong): "conv_wgrad", "lin_wgrad" skip those launches
+
+
 def _conv_wgrad(model, st: "_ParamStore", conv: str, t: dict, dc: torch.Tensor, use_tr: bool) -> None:
+    if "conv_wgrad" in _ABLATE:
+        return
     model._side.run(lambda: ops.conv2d_wgrad(t["x"], dc, st.g32(f"{conv}.weight"), t["k"], t["stride"], t["pad"], use_tr), dc)
 
 
 def _lin_wgrad(model, x, dy, gw, gb, rows: int, K: int, N: int, x_pitch: int, dy_pitch: int) -> None:
     """Weight (+ bias) gradient of an encoder linear layer, handed to the side stream (a function call, so that the deferred
     launch sees THIS layer's tensors and not the loop variables of a later one)."""
+    if "lin_wgrad" in _ABLATE:
+        return
+    group = getattr(model, "_wg_group", None)
+    if group is not None:          # collected: one grouped launch at the end of the encoder's backward (_flush_lin_wgrads)
+        group.append(dict(x=x, dy=dy, dw=gw, db=gb, rows=rows, K=K, N=N, x_pitch=x_pitch, dy_pitch=dy_pitch))
+        return
     model._side.run(lambda: ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=x_pitch, dy_pitch=dy_pitch, db=gb), x, dy, small=True)
+
+
+def _flush_lin_wgrads(model) -> None:
+    """The collected linear weight gradients of this backward pass as one launch (ops.linear_wgrad_group), on the side stream when
+    the trunk's weight gradients go there: nothing downstream reads them before the optimiser."""
+    group, model._wg_group = model._wg_group, None
+    if not group:
+        return
+    keep = [t for q in group for t in (q["x"], q["dy"])]
+    if model._side.enabled:
+        model._side.run(lambda: ops.linear_wgrad_group(group), *keep)
+    else:
+        ops.linear_wgrad_group(group)
 
 
 def _ready(model, st: "_ParamStore", name: Optional[str]) -> None:
@@ -739,7 +763,12 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
         gqb = st.grad[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
         _lin_wgrad(model, t["x"], dqkv, gq, gqb, R, D, 3 * D, D, 3 * D)
         dx = ops.linear_dgrad(dqkv, st.t16(f"{p}.qkv"), rows=R, N=3 * D, K=D, dy_pitch=3 * D, addend=ds1)
-        _ready(model, st, f"{p}.attention.self.query.weight")
+        if getattr(model, "_wg_group", None) is None:
+            _ready(model, st, f"{p}.attention.self.query.weight")
+    if getattr(model, "_wg_group", None) is not None:
+        # every linear weight gradient of the encoder and the heads in one launch; their flat-buffer range is final from here
+        _flush_lin_wgrads(model)
+        _ready(model, st, "encoder.encoder.layer.0.attention.self.query.weight")
     te = tape["emb"]
     if te["d_out"] is not None:
         dx = ops.scale_bf16(dx, 1.0, drop=te["d_out"])
@@ -906,14 +935,21 @@ class _LrwFunction(torch.autograd.Function):
         dlc = ops.zeros((B, Cp), BF16, dev)
         ops.ce_bwd(th["logits_c"], C, th["lab_idx"], th["lab_prob"], B, C, model.label_smoothing, th["lse_c"], g_cat, dlc, Cp)
         h = th["h"]
-        ops.linear_wgrad(h, dla, st.g32("audio_projection.weight"), rows=B * T, K=D, N=NA, x_pitch=D, dy_pitch=NA, seq=(S, 1, T), use_tr=use_tr,
-                         db=st.g32("audio_projection.bias"))
-        ops.linear_wgrad(h, dlc, st.g32("category_classifier.weight"), rows=B, K=D, N=C, x_pitch=D, dy_pitch=Cp, seq=(S, 0, 1), use_tr=use_tr,
-                         db=st.g32("category_classifier.bias"))
+        grouped = ops.WGRAD_GROUP and model.encoder_type == "huggingface"
+        model._wg_group = [] if grouped else None
+        heads = (dict(x=h, dy=dla, dw=st.g32("audio_projection.weight"), rows=B * T, K=D, N=NA, x_pitch=D, dy_pitch=NA, seq=(S, 1, T), db=st.g32("audio_projection.bias")),
+                 dict(x=h, dy=dlc, dw=st.g32("category_classifier.weight"), rows=B, K=D, N=C, x_pitch=D, dy_pitch=Cp, seq=(S, 0, 1), db=st.g32("category_classifier.bias")))
+        for q in heads:
+            if grouped:
+                model._wg_group.append(q)
+            else:
+                ops.linear_wgrad(q["x"], q["dy"], q["dw"], rows=q["rows"], K=q["K"], N=q["N"], x_pitch=q["x_pitch"], dy_pitch=q["dy_pitch"], seq=q["seq"],
+                                 use_tr=use_tr, db=q["db"])
         dh = torch.empty((B * S, D), dtype=BF16, device=dev)
         ops.linear_dgrad(dla, st.t16("audio_projection.weight"), rows=B * T, N=NA, K=D, dy_pitch=NA, out=dh, seq=(S, 1, T))
         ops.linear_dgrad(dlc, st.t16("category_classifier.weight"), rows=B, N=C, K=D, dy_pitch=Cp, out=dh, seq=(S, 0, 1))
-        _ready(model, st, "audio_projection.weight")
+        if not grouped:
+            _ready(model, st, "audio_projection.weight")
         if model.encoder_type == "x-transformers":
             dfeats = _xt_encoder_backward(model, st, tape, dh, B, T)
         else:

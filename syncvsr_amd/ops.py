@@ -448,6 +448,42 @@ def igemm_wgrad(plan: WPlan, x: torch.Tensor, dyp: torch.Tensor, dw: torch.Tenso
           out_pitch, wt_taps, _p(part), plan.part_floats, _stream(), label=plan.label, flops=flops)
 
 
+class _WgradProblem(ctypes.Structure):
+    """svsr_wgrad_problem of include/syncvsr_hip.h"""
+    _fields_ = [("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("dbias", ctypes.c_void_p), ("plan_dev", ctypes.c_void_p),
+                ("meta", ctypes.c_void_p), ("Nimg", ctypes.c_int), ("in_pix", ctypes.c_int), ("Ci", ctypes.c_int), ("in_pitch", ctypes.c_int),
+                ("Co", ctypes.c_int), ("out_pix", ctypes.c_int), ("out_pitch", ctypes.c_int), ("wt_taps", ctypes.c_int)]
+
+
+WGRAD_GROUP = True      # the encoder's / heads' linear weight gradients of a backward pass in ONE launch (False: one launch each)
+
+
+def linear_wgrad_group(problems: Sequence[dict]) -> None:
+    """problems: keyword arguments of linear_wgrad calls (x, dy, dw, rows, K, N, x_pitch, dy_pitch, seq, db).  Those whose plan has no K
+    split on 64-wide tiles go out as one svsr_igemm_wgrad_group launch; the others (none at the LRW shapes) as launches of their own."""
+    grouped, keep = [], []
+    for q in problems:
+        rows, K, N, seq, db = q["rows"], q["K"], q["N"], q.get("seq"), q.get("db")
+        if seq is None:
+            plan, geo = wgrad_rows_plan(rows, 1, 0, 0, K, N, db is not None), (rows, 1, 1)
+        else:
+            S, s0, n = seq
+            plan, geo = wgrad_rows_plan(rows // n, n, s0, 0, K, N, db is not None), (rows // n, S, n)
+        if not (WGRAD_GROUP and plan.bc == 64 and int(plan.meta[1]) == 3 and plan.splits == 1):
+            linear_wgrad(q["x"], q["dy"], q["dw"], rows=rows, K=K, N=N, x_pitch=q["x_pitch"], dy_pitch=q["dy_pitch"], seq=seq, db=db)
+            continue
+        grouped.append(_WgradProblem(_p(q["x"]), _p(q["dy"]), _p(q["dw"]), _p(db), plan.words.data_ptr(), ctypes.addressof(plan.meta),
+                                     geo[0], geo[1], K, q["x_pitch"], N, geo[2], q["dy_pitch"], 1))
+        keep.append(plan)
+    if not grouped:
+        return
+    arr = (_WgradProblem * len(grouped))(*grouped)
+    nbytes = int(_lib.load().svsr_igemm_wgrad_group_bytes(len(grouped)))
+    table = torch.empty(nbytes, dtype=torch.uint8, device=problems[0]["x"].device)
+    flops = sum(2.0 * q["rows"] * q["K"] * q["N"] for q in problems)
+    _call("svsr_igemm_wgrad_group", arr, len(grouped), _p(table), nbytes, _stream(), label="k_igemm_wgrad_group<64,3>", flops=flops)
+
+
 def conv_out_size(n: int, k: int, stride: int, pad: int) -> int:
     return (n + 2 * pad - k) // stride + 1
 

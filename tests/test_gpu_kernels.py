@@ -620,3 +620,45 @@ def test_adamw_clip_schedule(dev):
     check(shadow, ref, "adamw.shadow", 8e-3, 4e-3)
     st = state.cpu()
     assert int(st[0]) == 3
+
+
+def test_grouped_linear_weight_gradients_equal_separate_launches(dev):
+    """svsr_igemm_wgrad_group: the encoder's / heads' nn.Linear weight gradients of a backward pass as ONE launch (reference
+    lightning.py:82,92,107 via autograd).  Same workgroup code, one writer per element: the results must EQUAL those of separate
+    svsr_igemm_wgrad launches bit for bit, bias gradients and sequence-sliced rows (the two heads) included."""
+    from syncvsr_amd import ops
+
+    g = torch.Generator().manual_seed(7)
+    B, S, D = 4, 30, 512
+
+    def mk(shape, scale=1.0):
+        return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+    R = B * S
+    shapes = [dict(rows=R, K=D, N=3 * D, bias=True), dict(rows=R, K=D, N=D, bias=True), dict(rows=R, K=D, N=2048, bias=False),
+              dict(rows=R, K=2048, N=D, bias=True), dict(rows=B * (S - 1), K=D, N=1280, bias=True, seq=(S, 1, S - 1)),
+              dict(rows=B, K=D, N=500, bias=True, seq=(S, 0, 1), dy_pitch=512)]
+    problems, singles = [], []
+    for sh in shapes:
+        x = mk((R, sh["K"]))
+        dyp = sh.get("dy_pitch", sh["N"])
+        dy = mk((sh["rows"], dyp), 0.1)
+        if dyp != sh["N"]:
+            dy[:, sh["N"]:] = 0
+        for store in (problems, singles):
+            dw = torch.zeros((sh["N"], sh["K"]), dtype=torch.float32, device=dev)
+            db = torch.zeros(sh["N"], dtype=torch.float32, device=dev) if sh["bias"] else None
+            store.append(dict(x=x, dy=dy, dw=dw, db=db, rows=sh["rows"], K=sh["K"], N=sh["N"], x_pitch=sh["K"], dy_pitch=dyp, seq=sh.get("seq")))
+    ops.linear_wgrad_group(problems)
+    for q in singles:
+        ops.linear_wgrad(q["x"], q["dy"], q["dw"], rows=q["rows"], K=q["K"], N=q["N"], x_pitch=q["x_pitch"], dy_pitch=q["dy_pitch"], seq=q["seq"], db=q["db"])
+    torch.cuda.synchronize()
+    for a, b, sh in zip(problems, singles, shapes):
+        assert torch.equal(a["dw"], b["dw"]), sh
+        assert float(a["dw"].abs().max()) > 0
+        if sh["bias"]:
+            assert torch.equal(a["db"], b["db"]), sh
+    # and against torch on the first problem
+    q = problems[0]
+    ref = q["dy"].float().t() @ q["x"].float()
+    assert ((q["dw"] - ref).norm() / ref.norm()).item() < 2e-3
