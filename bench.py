@@ -151,22 +151,32 @@ def cpu_baseline_lrs(lrs_args, odim: int, frames: int, budget_s: float = 20.0) -
 
 
 def pmc_traffic(kernel_label: str):
-    """HBM bytes per launch of `kernel_label` from the committed rocprofv3 PMC passes (profiles/round2_pmc_per_kernel.json, made
-    by scripts/gpu_profiles_round2.sh + scripts/collect_profiles.py at the commit recorded in its __meta__: FETCH_SIZE and
-    WRITE_SIZE in KiB, separate --pmc runs).  gfx950 correction per MI355X_MICROARCH.md §HBM: FETCH_SIZE reports half of the
-    bytes of wide coalesced reads, so it is doubled.  None when no PMC record exists for the kernel."""
-    path = os.path.join(ROOT, "profiles", "round2_pmc_per_kernel.json")
+    """HBM bytes per launch of `kernel_label` from the committed rocprofv3 PMC passes (profiles/round3_pmc_per_kernel.json, made
+    by scripts/gpu_profiles_round3.sh + scripts/collect_profiles.py at the commit recorded in its __meta__: FETCH_SIZE and
+    WRITE_SIZE in KiB, separate --pmc runs).  gfx950 correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE reports half of the
+    bytes of wide coalesced reads, so it is doubled.  None when no PMC record exists for the kernel.  The bench label
+    k_igemm_p8<256,128,3> covers the profiler's instantiations k_igemm_p8<0|1, PH, false> (plain / BatchNorm-backward epilogue): their
+    launch-weighted mean."""
+    path = os.path.join(ROOT, "profiles", "round3_pmc_per_kernel.json")
     try:
         rec = json.load(open(path))
     except OSError:
         return None
     key = kernel_label.replace(",", ", ")
     keys = {key, key[:-1] + ", 1>"}          # k_igemm_fwd_glds carries a defaulted fourth template argument (K groups) in the profiler's name
+    tot_b = tot_n = 0.0
     for name, v in rec.items():
-        if name != "__meta__" and name.replace("void ", "") in keys and "FETCH_SIZE_avg_per_dispatch" in v and "WRITE_SIZE_avg_per_dispatch" in v:
-            return {"bytes_per_launch": round((2.0 * v["FETCH_SIZE_avg_per_dispatch"] + v["WRITE_SIZE_avg_per_dispatch"]) * 1024.0),
-                    "source": f"profiles/round2_pmc_per_kernel.json @ {rec.get('__meta__', {}).get('commit', '?')[:12]} (rocprofv3 --pmc, FETCH_SIZE doubled for gfx950)"}
-    return None
+        if name == "__meta__" or "FETCH_SIZE_avg_per_dispatch" not in v or "WRITE_SIZE_avg_per_dispatch" not in v:
+            continue
+        plain = name.replace("void ", "")
+        if plain in keys or (kernel_label.startswith("k_igemm_p8<") and plain.startswith("k_igemm_p8<")):
+            n = float(v.get("dispatches_FETCH_SIZE", 1))
+            tot_b += n * (2.0 * v["FETCH_SIZE_avg_per_dispatch"] + v["WRITE_SIZE_avg_per_dispatch"]) * 1024.0
+            tot_n += n
+    if tot_n == 0:
+        return None
+    return {"bytes_per_launch": round(tot_b / tot_n),
+            "source": f"profiles/round3_pmc_per_kernel.json @ {rec.get('__meta__', {}).get('commit', '?')[:12]} (rocprofv3 --pmc, FETCH_SIZE doubled for gfx950)"}
 
 
 def build_lrs(args, dev, world: int, rank: int):

@@ -81,6 +81,7 @@ int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_
  *   per-channel BatchNorm partial sums stats[tiles][2][Co] (plain stores; reduced by svsr_bn_finalize). */
 int svsr_conv_plan(int mode, int Nimg, int H, int W, int Co_out, int k, int stride, int pad, int* words, int cap_words, int* meta);
 int svsr_rows_plan(int Nimg, int P, int src0, int dst0, int Co_out, int* words, int cap_words, int* meta);
+int svsr_igemm_fwd_kgroups(const int* meta, int Ci, int Co, int bn_epilogue);   /* host query: 2 when the launch splits K over two wave groups (k_igemm_fwd_glds<64,64,4,2>) */
 int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 
 /* svsr_igemm_wgrad replaces: the weight-gradient of the same Conv2d / Linear layers (torch autograd).

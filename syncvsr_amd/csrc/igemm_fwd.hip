@@ -944,6 +944,16 @@ extern "C" int svsr_conv3x3_res(const void* in, const void* wt, void* out, const
     return svsr_check_launch();
 }
 
+/* K groups of the instantiation svsr_igemm_fwd / svsr_igemm_dgrad_bn will launch for this plan: 2 = k_igemm_fwd_glds<64,64,4,2> (the
+ * contraction split over two wave groups of one workgroup: few 64x64 tiles, >= 12 K steps), else 1.  Host-side query (bench.py labels
+ * its per-kernel table with it, so the table's names are the profiler's). */
+extern "C" int svsr_igemm_fwd_kgroups(const int* meta, int Ci, int Co, int bn_epilogue) {
+    if (meta == nullptr || Ci < 64) return 1;
+    const int bm = meta[0], bn = meta[1], gx = meta[3], gy = (Co + bn - 1) / bn;
+    const int ks = svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT);
+    return (!bn_epilogue && bm == 64 && bn == 64 && ks && (long)gx * gy <= ks && (long)meta[6] * (Ci / 64) >= 12) ? 2 : 1;
+}
+
 /* svsr_igemm_fwd: runs a plan.  plan_dev = device copy of the words, meta = the host meta[8] svsr_*_plan returned with them. */
 static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend,
                          float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co,
@@ -966,9 +976,7 @@ static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pr
     if (gx < 1) return SVSR_ERR_ARG;
     if (bm == P8_BM) return igemm_p8_launch(a, meta, stream);
     // few tiles, long contraction: split K inside the workgroup (see k_igemm_fwd_glds, KG = 2)
-    if (bnb_x == nullptr && bm == 64 && bn == 64 && svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT) && (long)gx * gy <= svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT) &&
-        (long)meta[6] * (Ci / 64) >= 12)
-        return launch_glds<64, 64, 4, 2>(a, gx, gy, stream);
+    if (svsr_igemm_fwd_kgroups(meta, Ci, Co, bnb_x != nullptr) == 2) return launch_glds<64, 64, 4, 2>(a, gx, gy, stream);
 #define SVSR_IGEMM_CASE(BM_, BN_, NS_) if (bm == BM_ && bn == BN_ && ns == NS_) return launch_glds<BM_, BN_, NS_>(a, gx, gy, stream)
     SVSR_IGEMM_CASE(128, 128, 2);
     SVSR_IGEMM_CASE(128, 64, 2);

@@ -325,6 +325,23 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0t + wn * 64 + j * 32 + c4 * 4;      // first of this lane's four channels
+                // the global operands of this 32-column half of the wave tile (addend, x, y: 8 bytes per row and fragment) are requested
+                // HERE, before the first is used: with LDS-DMA pieces of the next tile in flight hipcc turns every wait for an ordinary
+                // load into vmcnt(0), so per-fragment requests would cost one full round trip each
+                uint2 add_all[2][4], x_all[2][4], y_all[2][4];
+                if (p.addend != nullptr || EPI == 1) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const long o = (offs[i][k] >= 0 ? offs[i][k] : 0) + n;
+                            if (p.addend != nullptr) add_all[i][k] = *reinterpret_cast<const uint2*>(p.addend + o);
+                            if (EPI == 1) {
+                                x_all[i][k] = *reinterpret_cast<const uint2*>(p.bnb_x + o);
+                                if (!from_x) y_all[i][k] = *reinterpret_cast<const uint2*>(p.bnb_y + o);
+                            }
+                        }
+                }
                 float mu[4], rs[4], sc[4], sh[4];
                 if (EPI == 1) {
 #pragma unroll
@@ -337,17 +354,9 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     if (TRACE && ablate == 1) continue;
-                    // global operands of the four rows first (one round trip), then the fragment through the patch
-                    uint2 add4[4], x4[4], y4[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const long o = (offs[i][k] >= 0 ? offs[i][k] : 0) + n;
-                        if (p.addend != nullptr) add4[k] = *reinterpret_cast<const uint2*>(p.addend + o);
-                        if (EPI == 1) {
-                            x4[k] = *reinterpret_cast<const uint2*>(p.bnb_x + o);
-                            if (!from_x) y4[k] = *reinterpret_cast<const uint2*>(p.bnb_y + o);
-                        }
-                    }
+                    const uint2 (&add4)[4] = add_all[i];
+                    const uint2 (&x4)[4] = x_all[i];
+                    const uint2 (&y4)[4] = y_all[i];
                     if (!TRACE || ablate != 7)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) sW[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][e];

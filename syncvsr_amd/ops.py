@@ -435,9 +435,12 @@ def igemm_fwd(plan: Plan, inp: torch.Tensor, wt: torch.Tensor, out: torch.Tensor
     if want_stats:
         stats = scratch(plan.tiles * 2 * Co)
         st = (stats, plan.tiles)
+    label = plan.label
+    if _TIMING is not None and plan.bm == 64 and int(_lib.load().svsr_igemm_fwd_kgroups(plan.meta, Ci, Co, 0)) == 2:
+        label = label[:-1] + ",2>"          # the in-workgroup K-split instantiation: the profiler's k_igemm_fwd_glds<64, 64, 4, 2>
     _call("svsr_igemm_fwd", _p(inp), _p(wt), _p(out), _p(out_pre), _p(bias), _p(addend), _p(stats), plan.words.data_ptr(), plan.meta,
           Nimg, in_pix, Ci, in_pitch, Co, out_pix, out_pitch, wt_taps, 1 if gelu else (2 if relu else 0), int(out_f32), float(alpha),
-          *_drop(drop), _stream(), label=plan.label, flops=flops)
+          *_drop(drop), _stream(), label=label, flops=flops)
     return st
 
 

@@ -257,3 +257,55 @@ def test_lrs_longest_clip_full_width(dev):
         g, r = params[n].grad.detach().float().cpu().flatten(), osd[n].grad.flatten()
         cos = float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30))
         assert cos >= 0.97 and 0.93 <= float(g.norm() / r.norm()) <= 1.07, (n, cos, float(g.norm() / r.norm()))
+
+
+def test_lrs_bench_shape_matches_oracle(dev):
+    """Whole-model LRS parity at the shape bench.py's LRS leg times (BASELINE configs[3]): the shipped 252 M-parameter config
+    (LRS/video/config/lrs3.yaml:14-39), 16 clips of ONE length bucket padded to 160 frames, built by the benchmark's own batch builder
+    (syncvsr_amd.lrs_data.LengthBucketBatchSampler over the reference's length histogram), dropout off so the two sides see the same
+    function.  Losses to 1e-3, features / logits and every live gradient against the fp32 oracle with the bounds of the lrs_full cases."""
+    import numpy as np
+
+    from oracle import lrs_oracle as O
+    from syncvsr_amd.lrs_data import LengthBucketBatchSampler, reference_length_histogram
+    from syncvsr_amd.lrs_init import LRS_ODIM, default_lrs_args, lrs_init_state_dict, lrs_synthetic_batch
+    from syncvsr_amd.lrs_model import E2E
+
+    args = default_lrs_args(dropout_rate=0.0, transformer_attn_dropout_rate=0.0)
+    pool = reference_length_histogram(4096, seed=7) * 150 // 155
+    sampler = LengthBucketBatchSampler(pool, 16, 1, 0, width=16, seed=11)
+    idx = max(range(len(sampler)), key=lambda i: sampler.padded_frames()[i])
+    frames = sampler.padded_frames()[idx]
+    assert frames == 160, frames
+    x, lengths, tokens, label = lrs_synthetic_batch(args, 16, frames, seed=1234, lengths=pool[list(sampler)[idx]])
+    sd = lrs_init_state_dict(args, LRS_ODIM, seed=0)
+    model = E2E(LRS_ODIM, args)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).train()
+    out = model(x.to(dev), lengths.to(dev), tokens.to(dev), label.to(dev))
+    out[0].backward()
+    torch.cuda.synchronize()
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    keep = {}
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    ref = O.forward(osd, args, x, lengths, tokens, label, training=True, keep=keep)
+    ref["loss"].backward()
+    names = ("loss", "loss_ctc", "loss_att", "loss_audio")
+    rows = {k: (out[i].item(), ref[k].item()) for i, k in enumerate(names)}
+    print("losses (hip, oracle):", rows)
+    for k, (a, b) in rows.items():
+        assert abs(a - b) <= 1e-3 * abs(b), (k, a, b)
+    last = model._last
+    rel = {"feats": _rel(last["feats"], keep["feats"]), "enc_out": _rel(last["enc_out"], keep["enc_out"]), "pred": _rel(last["pred"][:, :model.odim], keep["pred"])}
+    print("relative L2:", rel)
+    assert rel["feats"] <= 3e-2 and rel["enc_out"] <= 5e-2 and rel["pred"] <= 5e-2, rel
+    grads = []
+    gmax = max(osd[n].grad.norm().item() for n, _ in model.named_parameters())
+    for n, p in model.named_parameters():
+        g, r = p.grad.detach().float().cpu().flatten(), osd[n].grad.flatten()
+        if r.norm().item() > 1e-6 * gmax:
+            grads.append((float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)), float(g.norm() / r.norm()), n))
+    grads.sort()
+    print("worst gradient cosines:", grads[:5], "median", grads[len(grads) // 2][0], "ratio range", min(g[1] for g in grads), max(g[1] for g in grads))
+    assert grads[len(grads) // 2][0] >= 0.995 and grads[0][0] >= 0.97, (grads[:3], grads[len(grads) // 2])
+    assert all(0.95 <= r <= 1.05 for _, r, _ in grads), sorted(grads, key=lambda t: -abs(t[1] - 1))[:3]

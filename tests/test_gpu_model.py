@@ -286,12 +286,27 @@ def test_lrw_other_shapes(dev, B, T, size):
     torch.cuda.synchronize()
     keep = {}
     torch.set_num_threads(min(32, os.cpu_count() or 8))
-    ref = O.forward(sd, cfg, *batch, training=True, keep=keep)
+    with torch.no_grad():
+        ref = O.forward(sd, cfg, *batch, training=True, keep=keep)
+    # fp32 reference: small batches put as few as 343 values into a BatchNorm channel, so one flipped bf16 rounding moves the statistics
+    loss_tol = 1e-3 if size == 96 else 2e-2          # the 96 x 96 crop of the shipped yaml is held to north_star's bound
     for k in ("loss_total", "loss_category", "loss_audio"):
-        assert abs(out[k].item() - ref[k].item()) <= 2e-2 * abs(ref[k].item()), (k, out[k].item(), ref[k].item())
+        assert abs(out[k].item() - ref[k].item()) <= loss_tol * abs(ref[k].item()), (k, out[k].item(), ref[k].item())
     a, b = model._last["feats"].float().cpu().flatten(), keep["feats"].flatten()
     assert float((a - b).norm() / b.norm()) <= 4e-2
+    # gradients against the bf16-storage emulation of the oracle (same rounding points as the HIP path)
+    trunk, other = _emu_grad_stats(cfg, sd, batch, model)
+    print(f"B={B} T={T} {size}x{size}: loss hip {out['loss_total'].item():.5f} fp32 {ref['loss_total'].item():.5f} | trunk cos min {trunk[0][0]:.4f} median "
+          f"{trunk[len(trunk) // 2][0]:.4f} ratio [{min(r for _, r, _ in trunk):.3f}, {max(r for _, r, _ in trunk):.3f}] | encoder/heads cos min {other[0][0]:.4f} "
+          f"ratio [{min(r for _, r, _ in other):.3f}, {max(r for _, r, _ in other):.3f}]")
+    assert trunk[0][0] >= GRAD_BOUNDS[size][0] and trunk[len(trunk) // 2][0] >= GRAD_BOUNDS[size][1], (trunk[:3], trunk[len(trunk) // 2])
+    assert other[0][0] >= GRAD_BOUNDS[size][2], other[:3]
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+# (trunk min cosine, trunk median cosine, encoder/heads min cosine) against the emulation, by crop size: set from the measured values
+# printed above with a margin for run-to-run rounding flips (the deeper check is tests/test_gpu_blockwise.py)
+GRAD_BOUNDS = {88: (0.90, 0.95, 0.997), 96: (0.90, 0.95, 0.997), 40: (0.92, 0.955, 0.997), 64: (0.92, 0.955, 0.997)}      # measured: 0.926-0.950 / 0.966-0.973 / 0.9985-0.9987
 
 
 def test_fused_batchnorm_backward_equals_separate_passes(dev):
