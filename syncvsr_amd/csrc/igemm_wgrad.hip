@@ -21,6 +21,7 @@
 // single split the tile is added to dW directly (one writer per element).  The bias gradient of an nn.Linear (column sums of dY)
 // comes out of the same staged dY tiles through one extra MFMA per step against a fragment of ones.
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -106,7 +107,16 @@ __device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_
     for (int i = tid; i < 2 * P; i += 256) sPos[i] = pos[i];
     const int Mt = p.Nimg * P;                       // rows of this tap (0 for a tap no position reaches)
     const float inv_p = P > 0 ? 1.0f / (float)P : 0.f;
-    const int total_chunks = (Mt + 63) / 64;
+    // Row enumeration (plan flag, words[0] bit 16).  Row-major: chunk c = rows c*64.. of the list (image n, position j) with j fastest:
+    // every lane divides its row index and looks its position up (LDS) for every DMA piece — ~300 instructions and four dependent LDS
+    // round trips per chunk in front of 16 MFMAs.  IMAGE-BLOCK major (plans with >= 64 images, every dense layer): chunk c = position
+    // j = c / cpp of the 64 images nb*64.. (cpp = ceil(Nimg / 64) blocks per position): position and block are wave-uniform, a lane's
+    // row is image nb*64 + rt — its address is a scalar base (block, position, tile channel) plus a per-lane constant, so a piece is
+    // `global_load_lds_dwordx4 v_off, s[base]` with no vector arithmetic at all; only a position's last block (images past Nimg read
+    // the zero page) and tiles that overhang Co / Ci take the path with per-lane selects.
+    const bool imgmajor = ((p.plan[0] >> 16) & 1) != 0;
+    const int cpp = (p.Nimg + 63) >> 6;
+    const int total_chunks = imgmajor ? P * cpp : (Mt + 63) / 64;
     const int c_begin = split_idx * p.chunks_per_split;
     int c_end = c_begin + p.chunks_per_split;
     if (c_end > total_chunks) c_end = total_chunks;
@@ -119,7 +129,62 @@ __device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_
     const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * RPI;        // instruction i of wave w covers rows (i*4 + w)*RPI ..
     __syncthreads();
 
-    auto stage = [&](int c, int buf) {
+    // image-block mode: per-lane constants of every piece, and the stream position (position sj, image block snb) of the next chunk to stage
+    unsigned offY[AR], offX[AR];
+    bool chY[AR], chX[AR];
+    int rtv[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int rt = i * 4 * RPI + wrow0 + lrow;
+        const int f = U == 4 ? (rt & 3) : ((rt >> 1) & 1);
+        const int gpiece = (((lpiece >> 2) ^ f) << 2) | (lpiece & 3);
+        rtv[i] = rt;
+        chY[i] = co0 + gpiece * 8 < p.Co;
+        chX[i] = ci0 + gpiece * 8 < p.Ci;
+        offY[i] = ((unsigned)rt * (unsigned)p.out_pix * (unsigned)p.out_pitch + (unsigned)(gpiece * 8)) * 2u;
+        offX[i] = ((unsigned)rt * (unsigned)p.in_pix * (unsigned)p.in_pitch + (unsigned)(gpiece * 8)) * 2u;
+    }
+    const bool full_tile = co0 + BC <= p.Co && ci0 + BC <= p.Ci;
+    int sj = 0, snb = 0, xp_cur = 0, yp_cur = 0, xp_nxt = 0, yp_nxt = 0;
+    if (imgmajor && KT > 0) {
+        sj = c_begin / cpp; snb = c_begin - sj * cpp;
+        xp_cur = pos[2 * sj]; yp_cur = pos[2 * sj + 1];
+        if (sj + 1 < P) { xp_nxt = pos[2 * sj + 2]; yp_nxt = pos[2 * sj + 3]; }
+    }
+    auto stage_img = [&](int buf) {
+        bf16_t* dstY = sStage + buf * S_ELEMS;
+        bf16_t* dstX = dstY + T_ELEMS;
+        const char* ybase = reinterpret_cast<const char*>(p.dy) + (((long)(snb * 64) * p.out_pix + yp_cur) * p.out_pitch + co0) * 2;
+        const char* xbase = reinterpret_cast<const char*>(p.x) + (((long)(snb * 64) * p.in_pix + xp_cur) * p.in_pitch + ci0) * 2;
+        const bool tail = snb * 64 + 64 > p.Nimg;
+        if (full_tile && !tail) {
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ybase + offY[i]),
+                                                 (__attribute__((address_space(3))) void*)(dstY + (i * 4 * RPI + wrow0) * BC), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xbase + offX[i]),
+                                                 (__attribute__((address_space(3))) void*)(dstX + (i * 4 * RPI + wrow0) * BC), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bool ok = snb * 64 + rtv[i] < p.Nimg;
+                const void* sy = (ok && chY[i]) ? (const void*)(ybase + offY[i]) : (const void*)zero_src;
+                const void* sx = (ok && chX[i]) ? (const void*)(xbase + offX[i]) : (const void*)zero_src;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sy,
+                                                 (__attribute__((address_space(3))) void*)(dstY + (i * 4 * RPI + wrow0) * BC), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
+                                                 (__attribute__((address_space(3))) void*)(dstX + (i * 4 * RPI + wrow0) * BC), 16, 0, 0);
+            }
+        }
+        // advance the stream: next block of this position, or block 0 of the next position (whose offsets were requested a position ago)
+        if (++snb == cpp) {
+            snb = 0; ++sj;
+            xp_cur = xp_nxt; yp_cur = yp_nxt;
+            if (sj + 1 < P) { xp_nxt = pos[2 * sj + 2]; yp_nxt = pos[2 * sj + 3]; }
+        }
+    };
+    auto stage_row = [&](int c, int buf) {
         bf16_t* dstY = sStage + buf * S_ELEMS;
         bf16_t* dstX = dstY + T_ELEMS;
 #pragma unroll
@@ -142,6 +207,9 @@ __device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
                                              (__attribute__((address_space(3))) void*)(dstX + (i * 4 * RPI + wrow0) * BC), 16, 0, 0);
         }
+    };
+    auto stage = [&](int c, int buf) {           // (chunks are staged in increasing order, one call each: stage_img keeps the position itself)
+        if (imgmajor) stage_img(buf); else stage_row(c, buf);
     };
 
     f32x16 acc[TT][TT], accb[BIAS ? TT : 1];
@@ -237,6 +305,18 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad(const WgradArgs p) {
 // No K split inside a group (splits = 1: each tile adds its result to dW directly, one writer per element), so nothing needs a slab.
 struct WgradGroupEntry { WgradArgs a; int tile_begin; int pad_; };
 
+// The table reaches the device as kernel arguments of a writer kernel (16 entries a launch), not as a host-to-device copy: a launch is
+// captured into a HIP graph (and re-issued by the native step list) with its arguments by value, a copy node would keep a pointer
+// into host memory that is gone by the time the graph replays.
+constexpr int WG_TABLE_CHUNK = 16;
+struct WgradGroupChunk { WgradGroupEntry e[WG_TABLE_CHUNK]; };
+static_assert(sizeof(WgradGroupEntry) % 8 == 0 && sizeof(WgradGroupChunk) <= 3584, "a chunk travels in the kernel-argument segment");
+
+__global__ __launch_bounds__(256) void k_wgrad_group_table(const WgradGroupChunk c, int words, long long* __restrict__ dst) {
+    const long long* src = reinterpret_cast<const long long*>(&c);
+    for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+}
+
 template <int BC, int NS>
 __global__ __launch_bounds__(256) void k_igemm_wgrad_group(const WgradGroupEntry* __restrict__ table, int n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -254,10 +334,13 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad_group(const WgradGroupEntry
 // ---- host side -------------------------------------------------------------------------------------------------------
 struct WgradLaunch { int bc, ns, splits, chunks_per_split, tasks; long slab; };
 
-static WgradLaunch wgrad_launch(long max_rows, int Co, int Ci, int ntaps, int wt_taps, bool bias) {
+// image-block row enumeration (see wg_body): from 64 images on (a partial block of fewer would be mostly padding)
+static bool wgrad_imgmajor(int Nimg) { return Nimg >= 64 && svsr_tune_get(SVSR_TUNE_WG_IMGMAJOR) != 0; }
+
+static WgradLaunch wgrad_launch(long total_chunks_l, int Co, int Ci, int ntaps, int wt_taps, bool bias) {
     WgradLaunch pl;
     const int tasks128 = ((Co + 127) / 128) * ((Ci + 127) / 128) * ntaps;
-    const int total_chunks = (int)((max_rows + 63) / 64);
+    const int total_chunks = (int)total_chunks_l;
     // short contractions (LRW encoder linears: 960 rows = 15 chunks): a workgroup's whole K loop is a few microseconds, so the cost
     // is the fp32 slab written per split and the reduction launch behind it.  64-wide tiles give enough tasks to fill the chip
     // WITHOUT splitting K: no slabs, no second launch (qkv 20.6 -> 16.1 us, ffn1 23.1 -> 16.3, audio head 25.7 -> 17.3).
@@ -296,10 +379,12 @@ static int wplan_emit(const std::vector<std::vector<int>>& taps_pos, const std::
     long maxP = 0;
     for (const auto& v : taps_pos) { nwords += (int)v.size(); if ((long)v.size() / 2 > maxP) maxP = (long)v.size() / 2; }
     if (maxP < 1 || maxP > WG_MAXP || (long)Nimg * maxP >= (1L << 24)) return -SVSR_ERR_ARG;
-    const WgradLaunch pl = wgrad_launch((long)Nimg * maxP, Co, Ci, ntaps, wt_taps, has_bias != 0);
+    const bool im = wgrad_imgmajor(Nimg);
+    const long chunks = im ? maxP * (long)((Nimg + 63) / 64) : ((long)Nimg * maxP + 63) / 64;
+    const WgradLaunch pl = wgrad_launch(chunks, Co, Ci, ntaps, wt_taps, has_bias != 0);
     if (words != nullptr) {
         if (cap_words < nwords) return -SVSR_ERR_ARG;
-        words[0] = ntaps; words[1] = pos_word0;
+        words[0] = ntaps | ((im ? 1 : 0) << 16); words[1] = pos_word0;
         int pos_off = 0;
         for (int t = 0; t < ntaps; ++t) {
             int* w = words + WPLAN_HDR + t * WPLAN_TAP_WORDS;
@@ -398,12 +483,12 @@ int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, float* dbias, co
 /* svsr_igemm_wgrad_group: n independent svsr_igemm_wgrad problems (each described like a call of its own: plan_dev + meta of
  * svsr_wgrad_*plan) in ONE launch.  Every problem must have a plan without K split on 64-wide tiles (meta = {64, 3, 1, ...}: the short
  * contractions this exists for) — anything else returns SVSR_ERR_ARG and the caller launches it alone.  table_dev: caller-owned device
- * buffer of at least svsr_igemm_wgrad_group_bytes(n) bytes (the problem table is copied there on `stream` ahead of the kernel). */
+ * buffer of at least svsr_igemm_wgrad_group_bytes(n) bytes (the problem table is written there on `stream`, by a kernel that carries it as arguments, ahead of the contraction: graph- and replay-safe). */
 int64_t svsr_igemm_wgrad_group_bytes(int n) { return n < 1 ? 0 : (int64_t)n * (int64_t)sizeof(WgradGroupEntry); }
 
 int svsr_igemm_wgrad_group(const svsr_wgrad_problem* problems, int n, void* table_dev, int64_t table_bytes, hipStream_t stream) {
     if (problems == nullptr || n < 1 || n > 256 || table_dev == nullptr || table_bytes < svsr_igemm_wgrad_group_bytes(n)) return SVSR_ERR_ARG;
-    std::vector<WgradGroupEntry> tab((size_t)n);
+    std::vector<WgradGroupEntry> tab((size_t)((n + WG_TABLE_CHUNK - 1) / WG_TABLE_CHUNK) * WG_TABLE_CHUNK);
     int tiles = 0, maxP = 1;
     for (int i = 0; i < n; ++i) {
         const svsr_wgrad_problem& q = problems[i];
@@ -421,9 +506,13 @@ int svsr_igemm_wgrad_group(const svsr_wgrad_problem* problems, int n, void* tabl
         tiles += q.meta[4];
         if (q.meta[6] > maxP) maxP = q.meta[6];
     }
-    // (pageable source: the runtime stages it before returning, so `tab` may go out of scope)
-    hipError_t e = hipMemcpyAsync(table_dev, tab.data(), (size_t)n * sizeof(WgradGroupEntry), hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return (int)e;
+    for (int i0 = 0; i0 < n; i0 += WG_TABLE_CHUNK) {
+        const int cnt = n - i0 < WG_TABLE_CHUNK ? n - i0 : WG_TABLE_CHUNK;
+        WgradGroupChunk chunk;
+        std::memcpy(&chunk, &tab[(size_t)i0], sizeof(chunk));
+        hipLaunchKernelGGL(k_wgrad_group_table, dim3(1), dim3(256), 0, stream, chunk, (int)(cnt * sizeof(WgradGroupEntry) / 8),
+                           reinterpret_cast<long long*>(static_cast<WgradGroupEntry*>(table_dev) + i0));
+    }
     constexpr int BC = 64, NS = 3;
     const size_t lds_max = (size_t)NS * 2 * 64 * BC * sizeof(bf16_t) + (size_t)WG_MAXP * 2 * sizeof(int);
     static bool attr_set = false;

@@ -383,7 +383,8 @@ class GradReducer:
         if self.comm_stream is None and st.flat.is_cuda:
             self.comm_stream = torch.cuda.Stream(device=st.flat.device)
 
-    def _reduce(self, lo: int, hi: int) -> None:
+    def _reduce(self, lo: int, hi: int, fence: bool = True) -> None:
+        """fence=False: the comm stream already waits for this segment's producers (an earlier bucket of the same on_ready call)."""
         if hi <= lo:
             return
         self.launched.append((lo, hi))
@@ -393,10 +394,11 @@ class GradReducer:
             return
         backend = self._backend
         if seg.is_cuda:
-            self.comm_stream.wait_stream(torch.cuda.current_stream())     # the segment's producers are enqueued there ...
-            side = getattr(self.model, "_side", None)
-            if side is not None and side.stream is not None and (side.enabled or side.enabled_small):
-                self.comm_stream.wait_stream(side.stream)                 # ... and, for weight gradients, on the model's side stream
+            if fence:
+                self.comm_stream.wait_stream(torch.cuda.current_stream())     # the segment's producers are enqueued there ...
+                side = getattr(self.model, "_side", None)
+                if side is not None and side.stream is not None and (side.enabled or side.enabled_small):
+                    self.comm_stream.wait_stream(side.stream)                 # ... and, for weight gradients, on the model's side stream
             with torch.cuda.stream(self.comm_stream):
                 if self.comm_dtype == torch.bfloat16:
                     if self._comm_buf is None or self._comm_buf.numel() < seg.numel():      # on the comm stream, used only there
@@ -418,17 +420,21 @@ class GradReducer:
 
     def on_ready(self, lo: int) -> None:
         st = self._st if self._st is not None else self.model.store()
+        # one fence per call: every bucket launched here waits for the same producers (all enqueued by now), the later ones follow
+        # the first in comm-stream order
         if lo == 0:
             self._reduce(0, self.top)
+            fenced = self.top > 0
             self.top = 0
-            self._reduce(st.decay_end, st.numel)
+            self._reduce(st.decay_end, st.numel, fence=not fenced)
             return
+        fence = True
         while self.top > self.last_elems:
             edge = self.last_elems + (self.top - 1 - self.last_elems) // self.bucket_elems * self.bucket_elems     # lower edge of the top bucket
             if edge < lo:
                 break
-            self._reduce(edge, self.top)
-            self.top = edge
+            self._reduce(edge, self.top, fence)
+            self.top, fence = edge, False
 
     def finish(self) -> None:
         """Joins the bucket all-reduces.  DDP re-broadcasts the buffers before every forward; here rank 0's BatchNorm running

@@ -662,3 +662,71 @@ def test_grouped_linear_weight_gradients_equal_separate_launches(dev):
     q = problems[0]
     ref = q["dy"].float().t() @ q["x"].float()
     assert ((q["dw"] - ref).norm() / ref.norm()).item() < 2e-3
+
+
+@pytest.mark.parametrize("imgmajor", [1, 0])
+@pytest.mark.parametrize("case", [(70, 6, 6, 72, 40, 3, 1, 1), (130, 5, 7, 64, 136, 3, 2, 1), (64, 4, 4, 128, 128, 1, 2, 0), (200, 3, 3, 136, 72, 3, 1, 1)])
+def test_conv_wgrad_image_block_enumeration(dev, case, imgmajor):
+    """svsr_igemm_wgrad's two row enumerations (plan word 0 bit 16; tune key wg_imgmajor): with >= 64 images a 64-row chunk is one
+    output position of 64 consecutive images (wave-uniform DMA bases).  Cases: a last block with 6 / 2 / 8 images only, exactly one
+    block, stride 2, a 1x1 stride-2 projection, channel counts that overhang the 64/128-wide tile (zero-page selects)."""
+    from syncvsr_amd import ops
+
+    N, H, W, Ci, Co, k, s, p = case
+    Ho, Wo = ops.conv_out_size(H, k, s, p), ops.conv_out_size(W, k, s, p)
+    x = rnd((N, H, W, Ci), 16)
+    dy = rnd((N, Ho, Wo, Co), 17, 0.25)
+    ws = torch.zeros(Co, Ci, k, k, requires_grad=True)
+    F.conv2d(nchw(x.float()), ws, stride=s, padding=p).backward(nchw(dy.float()))
+    ops.tune("wg_imgmajor", imgmajor)
+    try:
+        plan = ops.wgrad_conv_plan(N, H, W, Ci, Co, k, s, p)
+        assert (int(plan.words[0].item()) >> 16) & 1 == imgmajor
+        dw = torch.zeros(Co, k, k, Ci, device=dev)
+        ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw, k, s, p, use_tr=False)
+        dw2 = torch.zeros(Co, k, k, Ci, device=dev)
+        ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw2, k, s, p, use_tr=False)
+        torch.cuda.synchronize()
+    finally:
+        ops.tune("wg_imgmajor", 1)
+    assert torch.equal(dw, dw2)
+    check(dw, ws.grad.permute(0, 2, 3, 1), f"conv_wgrad imgmajor={imgmajor}", 3e-3, 2e-3)
+
+
+def test_grouped_weight_gradients_replay_from_a_hip_graph(dev):
+    """svsr_igemm_wgrad_group inside a captured HIP graph: the problem table travels as kernel arguments (by value in the graph's
+    nodes), so a replay long after the host-side problem list is gone still computes the same thing — 20 problems = two table
+    chunks.  (A host-to-device copy node of the table kept a pointer into freed host memory: the replay aborted.)"""
+    from syncvsr_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    R, K, N = 928, 512, 2048
+    xs = [(torch.randn((R, K), generator=g)).to(torch.bfloat16).to(dev) for _ in range(20)]
+    dys = [(torch.randn((R, N), generator=g) * 0.1).to(torch.bfloat16).to(dev) for _ in range(20)]
+    dws = [torch.zeros((N, K), dtype=torch.float32, device=dev) for _ in range(20)]
+    dbs = [torch.zeros(N, dtype=torch.float32, device=dev) for _ in range(20)]
+
+    def problems():
+        return [dict(x=x, dy=dy, dw=dw, db=db, rows=R, K=K, N=N, x_pitch=K, dy_pitch=N) for x, dy, dw, db in zip(xs, dys, dws, dbs)]
+
+    plan = ops.wgrad_rows_plan(R, 1, 0, 0, K, N, True)
+    assert plan.bc == 64 and plan.splits == 1 and int(plan.meta[1]) == 3, "the case must take the grouped launch"
+    ops.linear_wgrad_group(problems())           # eager (also builds the plans outside the capture)
+    torch.cuda.synchronize()
+    want = [(dw.clone(), db.clone()) for dw, db in zip(dws, dbs)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            ops.linear_wgrad_group(problems())
+    torch.cuda.current_stream().wait_stream(side)
+    junk = [bytearray(1 << 16) for _ in range(64)]          # churn the host heap
+    del junk
+    for t in dws + dbs:
+        t.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for (dw, db), (wdw, wdb) in zip(zip(dws, dbs), want):
+        assert torch.equal(dw, wdw) and torch.equal(db, wdb)
+    assert float(dws[0].abs().max()) > 0
