@@ -76,10 +76,18 @@ class LengthBonus:
 
 
 class DecoderScorer:
-    """The attention decoder as a full-vocabulary scorer (transformer/decoder.py:153-220)."""
+    """The attention decoder as a full-vocabulary scorer (transformer/decoder.py:153-220), incremental like the reference's
+    `forward_one_step(..., cache)` (decoder.py:153-186 + decoder_layer.py:67-103): a step computes ONE new row per hypothesis.
+
+    State / cache: one tensor per decoder layer, [n, L, 3*ddim] = (layer output | self-attention key | self-attention value) of the
+    L positions scored so far — a list of per-layer [n, L, .] tensors exactly like the reference's cache, so generic scorer plumbing
+    (stack / index by hypothesis) works on it unchanged.  The reference caches the layer outputs only and re-projects keys and
+    values of the whole prefix every step; keeping them too makes a step O(L) in the attention alone.  The source-attention keys /
+    values of `memory` (recomputed per step in the reference, decoder_layer.py:106-113) are projected once per clip and layer."""
 
     def __init__(self, model):
         self.model = model
+        self._mem = None          # (memory tensor, version, per-layer [T, 2D] of ONE row when all rows alias it | None, {n: [per-layer [n*T, 2D]]})
 
     # -- ScorerInterface / BatchScorerInterface ---------------------------------------------------
     def init_state(self, x):
@@ -89,15 +97,39 @@ class DecoderScorer:
         return None
 
     def select_state(self, state, i, new_id=None):
-        return None if state is None else state[i]
+        return None if state is None else [c[i] for c in state]
 
     def select_states(self, states, prev, tok):
-        return None
+        return None if states is None else tuple(c[prev] for c in states)
+
+    # -- source-attention keys / values -----------------------------------------------------------
+    def _memory_kv(self, st, memory: torch.Tensor, n: int, T: int):
+        m = self.model
+        D = m.ddim
+        c = self._mem
+        same = (c is not None and c["ptr"] == memory.data_ptr() and c["ver"] == memory._version and c["T"] == T and c["stride"] == memory.stride()
+                and c["base"] is memory._base)
+        if not same:
+            c = self._mem = dict(ptr=memory.data_ptr(), ver=memory._version, T=T, stride=memory.stride(), base=memory._base, keep=memory, row=None, by_n={})
+        if n in c["by_n"]:
+            return c["by_n"][n]
+        aliased = n > 1 and memory.stride(0) == 0           # x.unsqueeze(0).expand(n, T, D): every hypothesis attends to the same clip
+        if aliased or n == 1:
+            if c["row"] is None:
+                mem = memory[0].to(BF16).contiguous()
+                c["row"] = [_lin_kv(st, mem, f"decoder.decoders.{i}.src_attn.linear_k", T, D) for i in range(m.dlayers)]
+            kv = [r.unsqueeze(0).expand(n, T, 2 * D).reshape(n * T, 2 * D).contiguous() if n > 1 else r for r in c["row"]]
+        else:
+            mem = memory.to(BF16).reshape(n * T, D).contiguous()
+            kv = [_lin_kv(st, mem, f"decoder.decoders.{i}.src_attn.linear_k", n * T, D) for i in range(m.dlayers)]
+        c["by_n"] = {n: kv}                                  # (the beam only shrinks or stays: one width at a time is enough)
+        return kv
 
     def forward_one_step(self, tgt: torch.Tensor, tgt_mask, memory: torch.Tensor, memory_mask=None, cache=None):
-        """tgt int64 [n, L], memory [n, T, ddim] -> (log-probabilities of the next token [n, odim], per-layer outputs [n, L, ddim]).
-        `tgt_mask` is the causal mask by construction (decoder.py:189,216) and `cache` is accepted for interface compatibility:
-        the prefix is recomputed (causal self-attention makes the cached and the recomputed last row identical)."""
+        """tgt int64 [n, L], memory [n, T, ddim], cache: None or per-layer [n, L-1, 3*ddim] from the previous step ->
+        (log-probabilities of the next token [n, odim], new cache: per-layer [n, L, 3*ddim]).  `tgt_mask` is the causal mask by
+        construction (decoder.py:189,216).  Without a cache the whole prefix is computed (and the cache built); with one, only
+        position L-1."""
         from .lrs_model import LrsTargets, _decoder_fwd
 
         m = self.model
@@ -109,29 +141,80 @@ class DecoderScorer:
         st = m.store()
         if not st.shadow_fresh:
             st.refresh_shadows()
+            self._mem = None                         # projected with the old weights
         n, L = tgt.shape
-        T = memory.size(1)
-        tg = LrsTargets(None, tgt.contiguous(), None)
-        mem = memory.to(BF16).reshape(n * T, m.ddim).contiguous()
+        T, D = memory.size(1), m.ddim
         if memory_mask is not None:
             ilen = memory_mask.reshape(n, -1).sum(-1).to(torch.int32).contiguous()
         else:
             ilen = torch.full((n,), T, dtype=torch.int32, device=memory.device)
-        tape: dict[str, Any] = {}
+        if cache is not None and (len(cache) != m.dlayers or any(c is None for c in cache)):
+            cache = None
+        if cache is not None and (cache[0].shape[0] != n or cache[0].shape[1] != L - 1 or cache[0].shape[2] != 3 * D):
+            raise ValueError(f"cache entries are {tuple(cache[0].shape)}, expected ({n}, {L - 1}, {3 * D}): the cache must come from the "
+                             "previous forward_one_step call for the same hypotheses")
         with torch.no_grad():
-            pred = _decoder_fwd(m, st, tape, tg, mem, ilen, n, T)                    # fp32 [n * L, odim padded to 64]
-        logits = pred.view(n, L, -1)[:, -1, : m.odim]
-        new_cache = [tape[f"decoder.decoders.{i}"]["out"].view(n, L, m.ddim) for i in range(m.dlayers)] if "decoder.decoders.0" in tape and \
-            "out" in tape["decoder.decoders.0"] else None
+            if cache is None or L == 1:
+                tg = LrsTargets(None, tgt.contiguous(), None)
+                mem = memory.to(BF16).reshape(n * T, D).contiguous()
+                tape: dict[str, Any] = {}
+                pred = _decoder_fwd(m, st, tape, tg, mem, ilen, n, T)                # fp32 [n * L, odim padded to 64]
+                logits = pred.view(n, L, -1)[:, -1, : m.odim]
+                new_cache = tuple(torch.cat((tape[f"decoder.decoders.{i}"]["out"].view(n, L, D),
+                                             tape[f"decoder.decoders.{i}"]["self"]["qkv"].view(n, L, 3 * D)[:, :, D:]), dim=2) for i in range(m.dlayers))
+            else:
+                logits, new_cache = self._step_cached(st, tgt, memory, ilen, cache, n, L, T)
         return torch.log_softmax(logits.float(), dim=-1), new_cache
 
+    def _step_cached(self, st, tgt, memory, ilen, cache, n: int, L: int, T: int):
+        """Position L-1 of every hypothesis on top of `cache` (decoder_layer.py:67-127 with tgt_q = tgt[:, -1:])."""
+        from .lrs_model import _ffn_fwd, _lin, _ln
+
+        m = self.model
+        D, U, H = m.ddim, m.dunits, m.dheads
+        memkv = self._memory_kv(st, memory, n, T)
+        pe = m._pos_table("abs", L, memory.device)
+        x = ops.embed_pos_fwd(tgt[:, -1:].contiguous(), st.p32("decoder.embed.0.weight"), pe[L - 1 : L].contiguous(), 1, D, math.sqrt(D))   # [n, D]
+        new_cache = []
+        for i in range(m.dlayers):
+            p = f"decoder.decoders.{i}"
+            c = cache[i]
+            t1, _, _ = _ln(st, x, f"{p}.norm1")
+            qkv = _lin(st, t1, f"{p}.self_attn.linear_q", n, D, 3 * D)                                     # this position's q | k | v
+            kv = torch.cat((c[:, :, D:], qkv[:, D:].unsqueeze(1)), dim=1).view(n * L, 2 * D)               # keys / values 0..L-1
+            ctx, _ = ops.mha_fwd(qkv, 3 * D, kv, kv[:, D:], 2 * D, B=n, H=H, Lq=1, Lk=L)                     # the last query sees every key
+            x1 = _lin(st, ctx, f"{p}.self_attn.linear_out", n, D, D, addend=x)
+            t2, _, _ = _ln(st, x1, f"{p}.norm2")
+            q = _lin(st, t2, f"{p}.src_attn.linear_q", n, D, D)
+            ctx2, _ = ops.mha_fwd(q, D, memkv[i], memkv[i][:, D:], 2 * D, B=n, H=H, Lq=1, Lk=T, klen=ilen)
+            x2 = _lin(st, ctx2, f"{p}.src_attn.linear_out", n, D, D, addend=x1)
+            x = _ffn_fwd(m, st, {}, "ff", x2, f"{p}.feed_forward", n, D, U, 1.0, f"{p}.norm3", f"dec.{i}.ff")
+            new_cache.append(torch.cat((c, torch.cat((x, qkv[:, D:]), dim=1).unsqueeze(1)), dim=1))
+        tn, _, _ = _ln(st, x, "decoder.after_norm")
+        V = m.odim
+        Vp = (V + 63) // 64 * 64
+        pred = ops.linear_fwd(tn, st.s16("decoder.output_layer.weight"), st.p32("decoder.output_layer.bias"), rows=n, K=D, N=V, x_pitch=D,
+                              out_f32=True, out_pitch=Vp)[0]
+        return pred[:, :V], tuple(new_cache)
+
     def score(self, ys: torch.Tensor, state, x: torch.Tensor):
-        logp, _ = self.forward_one_step(ys.unsqueeze(0), None, x.unsqueeze(0), cache=state)
-        return logp.squeeze(0), None
+        logp, cache = self.forward_one_step(ys.unsqueeze(0), None, x.unsqueeze(0), cache=None if state is None else [c.unsqueeze(0) for c in state])
+        return logp.squeeze(0), [c.squeeze(0) for c in cache]
 
     def batch_score(self, ys: torch.Tensor, states, xs: torch.Tensor):
-        logp, _ = self.forward_one_step(ys, None, xs)
-        return logp, [None] * ys.shape[0]
+        """states: None (first step) or the batched cache (per-layer [n, L-1, 3*ddim], as select_states returns it); a list of
+        per-hypothesis states (the reference's calling convention, batch_beam_search.py) is stacked first."""
+        if isinstance(states, list) and states and isinstance(states[0], (list, tuple)):
+            states = [torch.stack([s[i] for s in states]) for i in range(len(states[0]))]
+        elif isinstance(states, list):                      # [None] * n
+            states = None
+        return self.forward_one_step(ys, None, xs, cache=states)
+
+
+def _lin_kv(st, mem, name: str, rows: int, D: int):
+    from .lrs_model import _lin
+
+    return _lin(st, mem, name, rows, D, 2 * D)
 
 
 class CTCPrefixScorer:

@@ -72,7 +72,10 @@ class _DecoderFacade(_Holder):
     def _scorer(self):
         from .lrs_infer import DecoderScorer
 
-        return DecoderScorer(self._owner())
+        sc = self.__dict__.get("_sc")
+        if sc is None or sc.model is not self._owner():
+            sc = self.__dict__["_sc"] = DecoderScorer(self._owner())         # kept: it owns the per-clip source key / value projections
+        return sc
 
     def forward_one_step(self, tgt, tgt_mask, memory, memory_mask=None, cache=None):
         return self._scorer().forward_one_step(tgt, tgt_mask, memory, memory_mask, cache)
@@ -90,10 +93,10 @@ class _DecoderFacade(_Holder):
         return None
 
     def select_state(self, state, i, new_id=None):
-        return None if state is None else state[i]
+        return self._scorer().select_state(state, i, new_id)
 
     def select_states(self, states, prev, tok):
-        return None
+        return self._scorer().select_states(states, prev, tok)
 
 
 class _CtcFacade(_Holder):

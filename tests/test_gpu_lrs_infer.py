@@ -77,14 +77,56 @@ def test_encoder_decoder_ctc_entry_points_match_reference(dev, tiny):
         xs = g_enc.to(dev).unsqueeze(0).expand(ys.shape[0], -1, -1)
         got, states = model.decoder.batch_score(ys, [None] * ys.shape[0], xs)
         want = torch.from_numpy(gold[f"run1.dec{j}.logp"])
-        assert got.shape == want.shape and len(states) == ys.shape[0]
+        assert got.shape == want.shape and len(states) == model.dlayers and states[0].shape == (ys.shape[0], ys.shape[1], 3 * model.ddim)
         # the case multiplies the output layer by 6: log-probabilities span ~[-25, 0]; bf16 activations give 0.06 at the tails
         assert float((got.cpu() - want).abs().max()) <= 0.1 and float((got.cpu() - want).norm() / want.norm()) <= 1e-2, \
             (j, float((got.cpu() - want).abs().max()), float((got.cpu() - want).norm() / want.norm()))
     one, cache = model.decoder.forward_one_step(ys[:2], None, xs[:2])
-    assert torch.equal(one, got[:2]) and len(cache) == model.dlayers and cache[0].shape == (2, ys.shape[1], model.ddim)
+    assert torch.equal(one, got[:2]) and len(cache) == model.dlayers and cache[0].shape == (2, ys.shape[1], 3 * model.ddim)
     s1, _ = model.decoder.score(ys[0], None, g_enc.to(dev))
     assert float((s1 - got[0]).abs().max()) <= 2e-2          # a different batch shape may pick different tile instantiations
+
+
+def test_decoder_cache_steps_equal_prefix_recomputation(dev, tiny):
+    """`forward_one_step(..., cache)` (transformer/decoder.py:153-186, decoder_layer.py:67-103: only the last position is computed,
+    the earlier rows come from the cache) against recomputing the whole prefix at every length: same next-token log-probabilities
+    and the same per-layer outputs, through a hypothesis re-ordering (select_states) and a shrinking beam, with the clip shared by
+    all hypotheses (expanded memory: source keys / values projected once) and with distinct memories per row."""
+    model, odim, clip, runs, gold = tiny
+    g = torch.Generator().manual_seed(5)
+    enc = torch.from_numpy(gold["enc_feat"]).to(dev)
+    T, D = enc.shape
+    other = (enc + 0.3 * torch.randn(enc.shape, generator=g).to(dev))
+    for shared in (True, False):
+        n = 5
+        xs = enc.unsqueeze(0).expand(n, T, D) if shared else torch.stack([enc if b % 2 == 0 else other * (1 + 0.1 * b) for b in range(n)])
+        ys = torch.full((n, 1), odim - 1, dtype=torch.int64, device=dev)
+        states = None
+        for step in range(7):
+            logp, states = model.decoder.batch_score(ys, states, xs)
+            full, full_cache = model.decoder.forward_one_step(ys, None, xs, cache=None)
+            assert logp.shape == (n, odim) and states[0].shape == (n, ys.shape[1], 3 * D)
+            err = float((logp - full).abs().max())
+            assert err <= 3e-2, (shared, step, err)
+            for c, f in zip(states, full_cache):
+                rel = float((c.float() - f.float()).norm() / f.float().norm())
+                assert rel <= 1e-2, (shared, step, rel)
+            # next tokens: the argmax for some rows, random for others; then re-order / drop hypotheses like the beam search does
+            tok = torch.where(torch.arange(n, device=dev) % 2 == 0, logp.argmax(-1), torch.randint(0, odim - 1, (n,), generator=g).to(dev))
+            prev = torch.randperm(n, generator=g).to(dev)
+            if step == 3:
+                prev = prev[:3]
+            ys = torch.cat((ys[prev], tok[prev].unsqueeze(1)), dim=1)
+            states = model.decoder.select_states(states, prev, tok[prev])
+            xs = xs[prev] if not shared else enc.unsqueeze(0).expand(prev.numel(), T, D)
+            n = prev.numel()
+    # the single-hypothesis interface carries the same cache
+    s, st1 = model.decoder.score(ys[0, :1], None, enc)
+    s2, st2 = model.decoder.score(ys[0, :2], st1, enc)
+    ref2, _ = model.decoder.forward_one_step(ys[:1, :2], None, enc.unsqueeze(0))
+    assert float((s2 - ref2[0]).abs().max()) <= 3e-2 and st2[0].shape == (2, 3 * D)
+    with pytest.raises(ValueError):
+        model.decoder.forward_one_step(ys[:2], None, enc.unsqueeze(0).expand(2, T, D), cache=[c[:2, :1] for c in states])
 
 
 def _rescore(sd, args, odim, enc, yseq, ctcw, maxlen):
