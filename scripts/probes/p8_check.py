@@ -51,7 +51,9 @@ def run(N, H, C, reps=30):
         g2, gst2 = ops.conv2d_dgrad_bn(dy, w, 3, 1, 1, (H, H), None, None, xb, mean, rstd, gamma, beta, 1)
         gs2 = gst2[0][: gst2[1] * 2 * C].view(gst2[1], 2, C).sum(0).clone()
         t_b = timeit(lambda: ops.conv2d_dgrad_bn(dy, w, 3, 1, 1, (H, H), None, None, xb, mean, rstd, gamma, beta, 1), reps)
-        res[mode] = dict(out=out.clone(), stats=stats, dx=dx.clone(), g=g.clone(), gs=gs, g2=g2.clone(), gs2=gs2, label=pl.label, t=(t_f, t_d, t_b))
+        scratch_add2 = add.clone()
+        t_b2 = timeit(lambda: ops.conv2d_dgrad_bn(dy, w, 3, 1, 1, (H, H), scratch_add2, yb, xb, mean, rstd, gamma, beta, 1), reps)
+        res[mode] = dict(out=out.clone(), stats=stats, dx=dx.clone(), g=g.clone(), gs=gs, g2=g2.clone(), gs2=gs2, label=pl.label, t=(t_f, t_d, t_b, t_b2))
     a, b = res[0], res[1]
     ok = True
     for k in ("out", "dx", "g", "g2"):
@@ -70,8 +72,8 @@ def run(N, H, C, reps=30):
     s1 = s1[0][: s1[1] * 2 * C].clone()
     o2, s2 = ops.conv2d_fwd(x, w, 3, 1, 1, want_stats=True)
     rep = torch.equal(o1, o2) and torch.equal(s1, s2[0][: s2[1] * 2 * C])
-    print(f"N={N} {H}x{H} C={C}: {'OK' if ok else 'FAIL'} reproducible={rep} | {a['label']} fwd/dgrad+add/dgrad+bn us {a['t'][0]:.1f} {a['t'][1]:.1f} {a['t'][2]:.1f} "
-          f"({flops / a['t'][0] / 1e6:.0f} TF) | {b['label']} {b['t'][0]:.1f} {b['t'][1]:.1f} {b['t'][2]:.1f} ({flops / b['t'][0] / 1e6:.0f} TF)")
+    print(f"N={N} {H}x{H} C={C}: {'OK' if ok else 'FAIL'} reproducible={rep} | {a['label']} fwd/dgrad+add/dgrad+bn(x)/dgrad+bn(y,add) us {a['t'][0]:.1f} {a['t'][1]:.1f} {a['t'][2]:.1f} {a['t'][3]:.1f} "
+          f"({flops / a['t'][0] / 1e6:.0f} TF) | {b['label']} {b['t'][0]:.1f} {b['t'][1]:.1f} {b['t'][2]:.1f} {b['t'][3]:.1f} ({flops / b['t'][0] / 1e6:.0f} TF)")
     return ok and rep
 
 

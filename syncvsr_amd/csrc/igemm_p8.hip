@@ -304,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                     st_q[j] = q + __shfl_xor(q, 32, 64);
                 }
             }
-            const bool from_x = p.bnb_y == nullptr, swish_act = p.bnb_act == 2;
+            const bool from_x = p.bnb_y == nullptr, swish_act = p.bnb_act == 2, has_add = p.addend != nullptr;
             float bs1[2][4], bs2[2][4];
             if (EPI == 1) {
 #pragma unroll
@@ -313,13 +313,13 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                     for (int k = 0; k < 4; ++k) { bs1[j][k] = 0.f; bs2[j][k] = 0.f; }
             }
             // target offsets of this lane's rows: fragment i, read k -> row wm*64 + i*32 + rq + 8k
-            long offs[2][4];
+            int offs[2][4];          // elements (the launcher bounds rows * out_pitch below 2^31)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int dstpix = rowtab[(wm * 64 + i * 32 + rq + 8 * k) * 2 + 1];
-                    offs[i][k] = dstpix >= 0 ? (long)dstpix * p.out_pitch : -1;
+                    offs[i][k] = dstpix >= 0 ? dstpix * p.out_pitch : -1;
                 }
             P8_WAIT_LGKM0();
 #pragma unroll
@@ -329,13 +329,13 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                 // HERE, before the first is used: with LDS-DMA pieces of the next tile in flight hipcc turns every wait for an ordinary
                 // load into vmcnt(0), so per-fragment requests would cost one full round trip each
                 uint2 add_all[2][4], x_all[2][4], y_all[2][4];
-                if (p.addend != nullptr || EPI == 1) {
+                if (has_add || EPI == 1) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const long o = (offs[i][k] >= 0 ? offs[i][k] : 0) + n;
-                            if (p.addend != nullptr) add_all[i][k] = *reinterpret_cast<const uint2*>(p.addend + o);
+                            const long o = (long)((offs[i][k] >= 0 ? offs[i][k] : 0) + n);
+                            if (has_add) add_all[i][k] = *reinterpret_cast<const uint2*>(p.addend + o);
                             if (EPI == 1) {
                                 x_all[i][k] = *reinterpret_cast<const uint2*>(p.bnb_x + o);
                                 if (!from_x) y_all[i][k] = *reinterpret_cast<const uint2*>(p.bnb_y + o);
@@ -350,6 +350,24 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { sc[k] = p.bnb_gamma[n + k] * rs[k]; sh[k] = __builtin_fmaf(-mu[k], sc[k], p.bnb_beta[n + k]); }
                     }
+                }
+                // ARRIVAL POINT of the operands: a first use in straight-line code.  hipcc tracks outstanding loads per control-flow path
+                // and, with LDS-DMA in flight, waits with vmcnt(0); left to find the first use inside a row's divergent `if (live)` it
+                // re-waits in EVERY row, and on gfx950 vmcnt(0) also waits for the previous row's store.
+                if (has_add) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(add_all[i][k].x), "+v"(add_all[i][k].y));
+                }
+                if (EPI == 1) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            asm volatile("" : "+v"(x_all[i][k].x), "+v"(x_all[i][k].y));
+                            if (!from_x) asm volatile("" : "+v"(y_all[i][k].x), "+v"(y_all[i][k].y));
+                        }
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -367,11 +385,15 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                     P8_WAIT_LGKM0();
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        if (offs[i][k] < 0) continue;
+                        // (no early exit for a padding row: a divergent skip in front of the first use of the hoisted operands makes hipcc
+                        // re-wait vmcnt(0) in every row, and on gfx950 that counter includes the previous row's STORE — one store round
+                        // trip per row, 6 us per tile.  Padding rows compute on row 0's operands and are masked out of sums and stores.)
+                        const bool live = offs[i][k] >= 0;
                         float v[4] = {rowv[k][0], rowv[k][1], rowv[k][2], rowv[k][3]};
-                        if (p.addend != nullptr) {
-                            v[0] += __uint_as_float(add4[k].x << 16); v[1] += __uint_as_float(add4[k].x & 0xffff0000u);
-                            v[2] += __uint_as_float(add4[k].y << 16); v[3] += __uint_as_float(add4[k].y & 0xffff0000u);
+                        {   // (selects, not a branch: a uniform branch in every row has the same effect on hipcc's waits as the early exit)
+                            const unsigned ax = has_add ? add4[k].x : 0u, ay = has_add ? add4[k].y : 0u;
+                            v[0] += __uint_as_float(ax << 16); v[1] += __uint_as_float(ax & 0xffff0000u);
+                            v[2] += __uint_as_float(ay << 16); v[3] += __uint_as_float(ay & 0xffff0000u);
                         }
                         if (EPI == 1) {
                             const float xv[4] = {__uint_as_float(x4[k].x << 16), __uint_as_float(x4[k].x & 0xffff0000u),
@@ -389,14 +411,14 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) {
                                     const float z = __builtin_fmaf(xv[c], sc[c], sh[c]) + (from_x ? 0.f : yv[c]);
-                                    v[c] = bf2f(f2bf(bf2f(f2bf(v[c])) * swish_grad(z)));
+                                    v[c] = live ? bf2f(f2bf(bf2f(f2bf(v[c])) * swish_grad(z))) : 0.f;
                                     bs1[j][c] += v[c];
                                     bs2[j][c] += v[c] * (xv[c] - mu[c]) * rs[c];
                                 }
                             } else {
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) {
-                                    v[c] = yv[c] > 0.f ? bf2f(f2bf(v[c])) : 0.f;
+                                    v[c] = (live && yv[c] > 0.f) ? bf2f(f2bf(v[c])) : 0.f;
                                     bs1[j][c] += v[c];
                                     bs2[j][c] += v[c] * (xv[c] - mu[c]) * rs[c];
                                 }
@@ -404,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                         }
                         uint2 o2;
                         o2.x = pack2bf(v[0], v[1]); o2.y = pack2bf(v[2], v[3]);
-                        if (!TRACE || ablate != 6) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + offs[i][k] + n) = o2;
+                        if (live && (!TRACE || ablate != 6)) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long)(offs[i][k] + n)) = o2;
                     }
                 }
             }
@@ -466,6 +488,7 @@ int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) 
     if (a.Co % BN != 0 || a.out_pitch % 8 != 0 || a.Ci % BK != 0) return SVSR_ERR_ARG;
     // per-lane addresses are 32-bit byte offsets from the tensor bases
     if ((long)a.Nimg * a.in_pix * a.in_pitch * 2 >= (1L << 32) || (long)a.Co * a.wt_taps * a.Ci * 2 >= (1L << 32)) return SVSR_ERR_ARG;
+    if ((long)a.Nimg * a.out_pix * a.out_pitch >= (1L << 31)) return SVSR_ERR_ARG;          // the epilogue's row offsets are 32-bit element counts
     static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
     const int tiles_m = meta[3], gy = a.Co / BN;
     const int items = (tiles_m + 7) / 8 * 8 * gy;
