@@ -46,13 +46,14 @@ extern "C" {
 /* ---- plumbing (runtime.hip) ------------------------------------------------------------------------------------
  * svsr_tune: sets a result-preserving tuning knob ("igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd",
  * "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe",
- * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor": tile shapes, split counts, kernel-variant switches — documented at the table in runtime.hip;
+ * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased": tile shapes, split counts, kernel-variant switches — documented at the table in runtime.hip;
  * never read from the environment); unknown key -> SVSR_ERR_ARG.
  * svsr_colsum_rows: out[c] (+)= scale * sum_{r<nrows} ws[r*ld + c], rows added in a fixed order; columns [0,n0) go to out0,
  * [n0,n0+n1) to out1 (may be null when n1 = 0); accumulate != 0 adds to the existing values. */
 int svsr_tune(const char* key, int value);
 /* debug aid of scripts/probes: the per-phase time stamps (s_memtime) of the last launch made with the knob "p8_trace" set */
 int svsr_debug_p8_trace(int64_t* out1024);
+int svsr_debug_c64_trace(int64_t* out512);      /* the same for svsr_conv3x3_c64 (tune p8_trace = 9): [phase][wave group][8 stamps] of workgroup 0 */
 int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale, hipStream_t stream);
 
 /* ---- implicit-GEMM contractions (igemm_fwd.hip) -------------------------------------------------------------------
@@ -111,7 +112,13 @@ int svsr_igemm_wgrad_group(const svsr_wgrad_problem* problems, int n, void* tabl
  * weight tap tw[t] (HOST arrays of 9 ints); out = conv (+ addend); stats [rows][2][64] with rows =
  * svsr_conv3x3_c64_stat_rows(Nimg, H, W) (one per persistent workgroup).  Requires W <= 29. */
 int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W);
-int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, const int* dy, const int* dx, const int* tw, hipStream_t stream);
+/* pixtab (both launches below): device copy of svsr_conv3x3_c64_pixtab's table for (Nimg, H, W) — pixel index or -1 per padded
+ * coordinate — or null.  With the table AND the tuning knob "c64_dephased" set, launches without the BatchNorm-backward epilogue take
+ * the de-phased kernel (two wave groups half a period apart: one contracts a chunk while the other drains the previous one and
+ * fetches the next; an experiment at parity with the default lock-step kernel).  Outputs are identical bit for bit, the BatchNorm
+ * partial sums are added in a different (fixed) order.  svsr_conv3x3_c64_pixtab(..., out = null) returns the entry count. */
+int64_t svsr_conv3x3_c64_pixtab(int Nimg, int H, int W, int* out, int64_t cap);
+int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, const int* dy, const int* dx, const int* tw, const int* pixtab, hipStream_t stream);
 
 /* Data-gradient launches with the FIRST PASS OF THE BATCHNORM BACKWARD in their epilogue (replaces the separate reduce pass of
  * svsr_bn_act_bwd for the ReLU trunk; reference backward of tcn/models/resnet.py:59-72 = autograd of bn -> relu).  The launch computes
@@ -126,7 +133,7 @@ int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* adde
  * svsr_bn_bwd_from_stats then adds the rows in a fixed order (dgamma +=, dbeta +=, coef[3][C] scratch) and writes
  * dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)). */
 int svsr_igemm_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, hipStream_t stream);
-int svsr_conv3x3_c64_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, const int* dy, const int* dx, const int* tw, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, hipStream_t stream);
+int svsr_conv3x3_c64_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, const int* dy, const int* dx, const int* tw, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, const int* pixtab, hipStream_t stream);
 int svsr_bn_bwd_from_stats(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma, const float* stats, int nrows, float* coef, float* dgamma, float* dbeta, void* dx, int64_t npix, int C, hipStream_t stream);
 
 /* svsr_conv3x3_res: conv3x3, stride 1, pad 1 for 128 / 256 input channels (layer2 / layer3 of the trunk, resnet.py:8-10,59-72) forward and,

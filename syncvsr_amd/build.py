@@ -32,11 +32,17 @@ def sources() -> list[str]:
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def headers() -> list[str]:
+    """Every header a source may include: csrc/*.h and the public C ABI (steplist.hip derives its call thunks from its declarations)."""
+    pub = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(pub, "*.h"))
+
+
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h"))
+    deps = sources() + headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -46,7 +52,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     cc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
     srcs = sources()
-    hdr_t = max([os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h"))] + [0.0])
+    hdr_t = max([os.path.getmtime(h) for h in headers()] + [0.0])
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")

@@ -39,8 +39,9 @@ static int g_tune[SVSR_TUNE_N] = {
     /* P8_PH */ 1,             // phases per K tile of the persistent kernel: 1 (16 MFMAs between barriers) or 2 (8)
     /* P8_STAGGER */ 1,        // its two wave groups run their phases one barrier apart (0: in lock step)
     /* WG_IMGMAJOR */ 1,       // svsr_igemm_wgrad plans with >= 64 images enumerate rows by (position, block of 64 images): wave-uniform DMA bases (0: row-major)
+    /* C64_DEPHASED */ 0,      // experiment: svsr_conv3x3_c64 (plain epilogue) with two wave groups half a period apart — one contracts a chunk while the other drains and fetches; at parity with the lock-step kernel (0)
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 

@@ -520,6 +520,26 @@ def _conv_taps(k: int, pad: int) -> tuple:
 C64_CONV = True        # persistent weights-in-LDS kernel for conv3x3(64, 64) stride 1 (False: generic implicit GEMM)
 
 
+_C64_TABS: dict = {}
+
+
+def c64_pixtab(N: int, H: int, W: int, device) -> torch.Tensor:
+    """Device copy of svsr_conv3x3_c64_pixtab(N, H, W) (padded coordinate -> pixel index or -1), cached per shape like a launch plan."""
+    key = (N, H, W, str(device))
+    t = _C64_TABS.get(key)
+    if t is None:
+        lib = _lib.load()
+        n = int(lib.svsr_conv3x3_c64_pixtab(N, H, W, None, 0))
+        if n <= 0:
+            raise _lib.SvsrError(f"svsr_conv3x3_c64_pixtab({N}, {H}, {W}) failed ({n})")
+        host = torch.empty(n, dtype=torch.int32)
+        got = int(lib.svsr_conv3x3_c64_pixtab(N, H, W, host.data_ptr(), n))
+        if got != n:
+            raise _lib.SvsrError(f"svsr_conv3x3_c64_pixtab wrote {got} of {n} entries")
+        t = _C64_TABS[key] = host.to(device)
+    return t
+
+
 def _c64_ok(Ci: int, Co: int, k: int, stride: int, pad: int, W: int) -> bool:
     return C64_CONV and Ci == 64 and Co == 64 and k == 3 and stride == 1 and pad == 1 and W <= 29
 
@@ -533,7 +553,7 @@ def conv3x3_c64(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, addend: Op
         rows = _query("svsr_conv3x3_c64_stat_rows", N, H, W)[0]
         stats = scratch(rows * 2 * 64)
         st = (stats, rows)
-    _call("svsr_conv3x3_c64", _p(x), _p(wt), _p(out), _p(addend), _p(stats), N, H, W, _ints(dy), _ints(dx), _ints(tw), _stream(),
+    _call("svsr_conv3x3_c64", _p(x), _p(wt), _p(out), _p(addend), _p(stats), N, H, W, _ints(dy), _ints(dx), _ints(tw), _p(c64_pixtab(N, H, W, x.device)), _stream(),
           label="k_conv3x3_c64", flops=2.0 * N * H * W * 64 * 64 * 9)
     return st
 
@@ -612,7 +632,7 @@ def conv2d_dgrad_bn(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, p
         rows = _query("svsr_conv3x3_c64_stat_rows", N, H, W)[0]
         stats = scratch(rows * 2 * 64)
         _call("svsr_conv3x3_c64_dgrad_bn", _p(dy), _p(w16t), _p(g), _p(addend), _p(stats), N, H, W, _ints(tdy), _ints(tdx), _ints(tw),
-              _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), act, _stream(), label="k_conv3x3_c64+bn", flops=2.0 * N * H * W * 64 * 64 * 9)
+              _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), act, _p(c64_pixtab(N, H, W, dy.device)), _stream(), label="k_conv3x3_c64+bn", flops=2.0 * N * H * W * 64 * 64 * 9)
         return g, (stats, rows)
     plan = conv_plan(1, N, H, W, Ci, k, stride, pad)        # mode 1: every pixel of the result is visited once
     stats = scratch(plan.tiles * 2 * Ci)

@@ -730,3 +730,33 @@ def test_grouped_weight_gradients_replay_from_a_hip_graph(dev):
     for (dw, db), (wdw, wdb) in zip(zip(dws, dbs), want):
         assert torch.equal(dw, wdw) and torch.equal(db, wdb)
     assert float(dws[0].abs().max()) > 0
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7), (16, 22, 22), (70, 11, 29)])
+def test_conv3x3_c64_dephased_kernel_equals_lock_step(dev, shape):
+    """svsr_conv3x3_c64 with the pixel table and the knob c64_dephased (an experiment, off by default): two wave groups half a period
+    apart.  Same MFMA instruction and accumulation order as the lock-step kernel: forward and data-gradient(+addend) outputs are
+    EQUAL bit for bit; the BatchNorm partial sums agree to rounding (added in another fixed order) and are reproducible."""
+    from syncvsr_amd import ops
+
+    N, H, W = shape
+    x = rnd((N, H, W, 64), 31).to(dev)
+    w = rnd((64, 3, 3, 64), 32, 0.05).to(dev)
+    dy = rnd((N, H, W, 64), 33).to(dev)
+    add = rnd((N, H, W, 64), 34).to(dev)
+    got = {}
+    try:
+        for mode in (0, 1):
+            ops.tune("c64_dephased", mode)
+            out, st = ops.conv2d_fwd(x, w, 3, 1, 1, want_stats=True)
+            stats = st[0][: st[1] * 128].view(st[1], 2, 64).sum(0).clone()
+            out2, st2 = ops.conv2d_fwd(x, w, 3, 1, 1, want_stats=True)
+            assert torch.equal(out, out2) and torch.equal(st[0][: st[1] * 128], st2[0][: st2[1] * 128])
+            dx = ops.conv2d_dgrad(dy, w, 3, 1, 1, (H, W), addend=add.clone())
+            got[mode] = (out.clone(), stats, dx.clone())
+    finally:
+        ops.tune("c64_dephased", 0)
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][2], got[1][2])
+    assert float((got[0][1] - got[1][1]).abs().max() / got[0][1].abs().max()) <= 1e-5
+    ref = F.conv2d(nchw(x.float().cpu()), w.float().cpu().permute(0, 3, 1, 2), stride=1, padding=1)
+    check(got[1][0], nhwc(ref), "c64 de-phased fwd")

@@ -350,3 +350,30 @@ def test_step_list_segments_and_argument_checks():
         assert lib.svsr_steplist_run(h, 1, ctypes.byref(failed)) == 0                      # empty segment: nothing to issue
     finally:
         assert lib.svsr_steplist_destroy(h) == 0
+
+
+def test_c64_pixel_table_matches_the_padded_grid():
+    """svsr_conv3x3_c64_pixtab: entry PAD + q = pixel of padded coordinate q ((H+2) x (W+2) grid per image) or -1 (host function, no GPU)."""
+    import ctypes
+
+    from syncvsr_amd import _lib
+
+    lib = _lib.load()
+    N, H, W = 3, 4, 5
+    n = int(lib.svsr_conv3x3_c64_pixtab(N, H, W, None, 0))
+    buf = (ctypes.c_int * n)()
+    assert int(lib.svsr_conv3x3_c64_pixtab(N, H, W, buf, n)) == n
+    assert int(lib.svsr_conv3x3_c64_pixtab(N, H, W, buf, n - 1)) < 0
+    tab = list(buf)
+    pad = 64
+    Q = (H + 2) * (W + 2)
+    assert all(v == -1 for v in tab[:pad]) and n >= pad + N * Q
+    seen = []
+    for q in range(N * Q):
+        img, rem = divmod(q, Q)
+        yp, xp = divmod(rem, W + 2)
+        want = (img * H + yp - 1) * W + xp - 1 if 1 <= yp <= H and 1 <= xp <= W else -1
+        assert tab[pad + q] == want
+        if want >= 0:
+            seen.append(want)
+    assert seen == list(range(N * H * W)) and all(v == -1 for v in tab[pad + N * Q:])
