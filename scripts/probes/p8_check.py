@@ -131,6 +131,29 @@ if __name__ == "__main__":
                 print(f"ph {ph} {names[ab]:32s}: layer2 {t2:.1f} us  layer3 {t3:.1f} us")
         ops.tune("p8_trace", 0)
         sys.exit(0)
+    if "--order" in sys.argv:
+        ops.tune("p8", 1)
+        for (N, H, C) in ((928, 11, 128), (928, 6, 256), (928, 22, 128)):
+            x = (torch.randn(N, H, H, C, device=dev) * 0.5).to(BF16); w = (torch.randn(C, 3, 3, C, device=dev) * 0.05).to(BF16)
+            dy = (torch.randn(N, H, H, C, device=dev) * 0.5).to(BF16); add = (torch.randn(N, H, H, C, device=dev) * 0.5).to(BF16)
+            xb = torch.randn(N, H, H, C, device=dev).to(BF16); yb = torch.relu(torch.randn(N, H, H, C, device=dev)).to(BF16)
+            mean, rstd = torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5
+            gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
+            ref = None
+            for stg in (1, 3, 1, 3):
+                ops.tune("p8_stagger", stg)
+                sa = add.clone()
+                g, gst = ops.conv2d_dgrad_bn(dy, w, 3, 1, 1, (H, H), add.clone(), yb, xb, mean, rstd, gamma, beta, 1)
+                key = (g.clone(), gst[0][: gst[1] * 2 * C].clone())
+                if ref is None:
+                    ref = key
+                same = torch.equal(ref[0], key[0]) and torch.equal(ref[1], key[1])
+                t_f = timeit(lambda: ops.conv2d_fwd(x, w, 3, 1, 1, want_stats=True), 30)
+                t_b = timeit(lambda: ops.conv2d_dgrad_bn(dy, w, 3, 1, 1, (H, H), None, None, xb, mean, rstd, gamma, beta, 1), 30)
+                t_b2 = timeit(lambda: ops.conv2d_dgrad_bn(dy, w, 3, 1, 1, (H, H), sa, yb, xb, mean, rstd, gamma, beta, 1), 30)
+                print(f"N={N} {H}x{H} C={C} p8_stagger={stg}: fwd {t_f:.1f}  bn(x) {t_b:.1f}  bn(y,add) {t_b2:.1f} us  identical={same}")
+        ops.tune("p8_stagger", 1)
+        sys.exit(0)
     if "--sweep" in sys.argv:
         x2 = (torch.randn(928, 11, 11, 128, device=dev) * 0.5).to(BF16); w2 = (torch.randn(128, 3, 3, 128, device=dev) * 0.05).to(BF16)
         x3 = (torch.randn(928, 6, 6, 256, device=dev) * 0.5).to(BF16); w3 = (torch.randn(256, 3, 3, 256, device=dev) * 0.05).to(BF16)

@@ -58,7 +58,10 @@ struct TileCtx {
 
 // work item r of workgroup w: rounds alternate direction, so the workgroups that drew the longest tiles of one round draw the
 // shortest of the next (tiles are ordered by decreasing tap count)
-__device__ __forceinline__ bool p8_item(int gy, int items, int w, int G, int r, int& m_tile, int& n0) {
+// rev > 0 (= this workgroup's round count): the rounds are walked last to first — half the workgroups start with their SHORT tile, so
+// the first epilogues of a launch (an HBM burst when they coincide) do not all fall at the same moment
+__device__ __forceinline__ bool p8_item(int gy, int items, int w, int G, int r, int& m_tile, int& n0, int rev = 0) {
+    if (rev > 0) { if (r >= rev) return false; r = rev - 1 - r; }
     const int q = r * G + ((r & 1) ? G - 1 - w : w);
     if (q >= items) return false;
     const int grp = q / (8 * gy), rem = q - grp * 8 * gy;
@@ -67,10 +70,10 @@ __device__ __forceinline__ bool p8_item(int gy, int items, int w, int G, int r, 
     return true;          // (m_tile may be a hole >= tiles_m: the caller skips it)
 }
 
-__device__ __forceinline__ bool p8_next_item(int tiles_m, int gy, int items, int w, int G, int& r, int& m_tile, int& n0) {
+__device__ __forceinline__ bool p8_next_item(int tiles_m, int gy, int items, int w, int G, int& r, int& m_tile, int& n0, int rev = 0) {
     for (;;) {
         ++r;
-        if (!p8_item(gy, items, w, G, r, m_tile, n0)) return false;
+        if (!p8_item(gy, items, w, G, r, m_tile, n0, rev)) return false;
         if (m_tile < tiles_m) return true;
     }
 }
@@ -135,8 +138,13 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
     };
 
     // ---- first item of this workgroup ---------------------------------------------------------------------------------------
+    int rev = 0;
+    if ((stagger & 2) && (w & 1)) {
+        int mt, nn;
+        while (p8_item(gy, items, w, G, rev, mt, nn)) ++rev;      // rounds of this workgroup
+    }
     int r = -1, m_tile = 0, n0 = 0;
-    if (!p8_next_item(tiles_m, gy, items, w, G, r, m_tile, n0)) return;
+    if (!p8_next_item(tiles_m, gy, items, w, G, r, m_tile, n0, rev)) return;
     int par = 0;
     meta_dma(m_tile, par);
     P8_SYNC_ALL();
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
     for (;;) {
         // ---- the following item (its meta data is requested during K tile 0, its pointers are built at K tile 2) ----------
         int r2 = r, m2 = 0, n2 = 0;
-        const bool has_next = p8_next_item(tiles_m, gy, items, w, G, r2, m2, n2);
+        const bool has_next = p8_next_item(tiles_m, gy, items, w, G, r2, m2, n2, rev);
         if (!has_next) dummy_ctx(nxt);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                 if (lane == 0 && PH == 1) sTrace[((kt * 2 + 1) * 2 + wn) * 4 + k] = t;
             }
         };
-        if (stagger && wn == 1) P8_BARRIER();             // stagger: group 1 runs one barrier behind group 0
+        if ((stagger & 1) && wn == 1) P8_BARRIER();             // stagger: group 1 runs one barrier behind group 0
         const int KT = cur.KT;
         for (int kt = 0; kt < KT; ++kt) {
             if (kt == 2 && has_next) make_ctx(nxt, m2, n2, par ^ 1);
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
             stream_advance();
             stg = stg == 2 ? 0 : stg + 1;
         }
-        if (stagger && wn == 0) P8_BARRIER();             // the groups meet again
+        if ((stagger & 1) && wn == 0) P8_BARRIER();             // the groups meet again
         if (TRACE && ablate == 9 && blockIdx.x == 0 && r == 0) {
             P8_SYNC_ALL();
             for (int i = tid; i < 1024; i += 512) g_p8_trace[i] = sTrace[i];
@@ -495,7 +503,7 @@ int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) 
     int G = items < cus ? items : cus;
     const int forced = svsr_tune_get(SVSR_TUNE_P8_GRID);
     if (forced > 0 && forced < G) G = forced;
-    const int ph = svsr_tune_get(SVSR_TUNE_P8_PH) == 2 ? 2 : 1, stagger = svsr_tune_get(SVSR_TUNE_P8_STAGGER) ? 1 : 0;
+    const int ph = svsr_tune_get(SVSR_TUNE_P8_PH) == 2 ? 2 : 1, stagger = svsr_tune_get(SVSR_TUNE_P8_STAGGER) & 3;      // bit 0: wave groups one barrier apart, bit 1: odd workgroups walk their rounds backwards
 #define P8_LAUNCH(...) do { static bool set_ = false; \
         if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_p8<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); set_ = true; } \
         hipLaunchKernelGGL((k_igemm_p8<__VA_ARGS__>), dim3(G), dim3(512), LDS_BYTES, stream, a, stagger, svsr_tune_get(SVSR_TUNE_P8_TRACE)); } while (0)
