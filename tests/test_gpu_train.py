@@ -231,6 +231,7 @@ def _rccl_single_rank_case():
     try:
         eager = run(always_reduce=True, bucket_mb=8.0)
         graph = run(always_reduce=True, bucket_mb=8.0, use_graph=True)
+        native = run(always_reduce=True, bucket_mb=8.0, native=True)          # bench.py's default enqueue path: recorded list + collectives
         wire16 = run(always_reduce=True, bucket_mb=8.0, grad_comm_dtype=torch.bfloat16)
     finally:
         dist.destroy_process_group()
@@ -242,7 +243,8 @@ def _rccl_single_rank_case():
     assert len(eager[3]) >= 4, "the backward must have peeled several buckets off the gradient buffer"
     covered = sorted(eager[3])
     assert covered[0][0] == 0 and all(a[1] == b[0] or b[0] >= a[1] for a, b in zip(covered, covered[1:]))
-    for name, got in (("eager+RCCL", eager), ("graph+RCCL", graph)):
+    assert len(native[3]) == len(eager[3]), "the replayed step must issue the same buckets"
+    for name, got in (("eager+RCCL", eager), ("graph+RCCL", graph), ("native+RCCL", native)):
         for what, x, y in zip(("losses", "parameters", "running statistics"), got, plain):
             assert torch.equal(x, y), f"{name}: {what} differ from the plain step"
     print("RCCL_CASE_OK")
