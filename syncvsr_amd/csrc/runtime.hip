@@ -19,7 +19,7 @@ static int g_tune[SVSR_TUNE_N] = {
     /* IGEMM_TILE   */ 0,      // 0 auto, 64 / 128: force the M tile of svsr_igemm_fwd
     /* IGEMM_M128   */ 8192,   // rows from which 128-row tiles are used
     /* WG_BLOCKS    */ 0,      // target workgroups of svsr_igemm_wgrad (0: built-in per tile size)
-    /* W3_BLOCKS    */ 288,    // target workgroups of svsr_conv3x3_wgrad.  Alone the launch is fastest at one round of 2 per CU (512: 61 us, 288: 73 us), but it runs on the side stream under the backward chain, and with about one workgroup per CU it leaves the main stream's launches their share: step 5.62 -> 5.55 ms (swept 224..512)
+    /* W3_BLOCKS    */ 448,    // target workgroups of svsr_conv3x3_wgrad.  Alone the launch is fastest at one round of 2 per CU (512: 61 us, 448: 64, 288: 73), but it runs on the side stream under the backward chain and a smaller grid leaves the main stream's launches their share: step 5.62 -> 5.60 ms at 448, 5.55 at 288 (swept 224..512; 448 keeps the launch itself near its best)
     /* LN_RPB       */ 4,      // rows per workgroup of svsr_add_ln_bwd (one per wave: 16 -> 4 measured 6.00 -> 5.97 ms per LRW step)
     /* STEM_LDS_FWD */ 0,      // LDS-tiled stem BN+act+pool forward (measured slower)
     /* STEM_LDS_BWD */ 2,      // stem BN+act+pool backward: 0 plain, 1 LDS-tiled passes, 2 LDS-tiled apply pass + gather-form reduce pass (fastest)
