@@ -502,7 +502,7 @@ int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) 
     const int items = (tiles_m + 7) / 8 * 8 * gy;
     int G = items < cus ? items : cus;
     const int forced = svsr_tune_get(SVSR_TUNE_P8_GRID);
-    if (forced > 0 && forced < G) G = forced;
+    if (forced > 0) G = forced < items ? forced : items;          // (above the CU count: one tile per workgroup, handed out by the dispatcher)
     const int ph = svsr_tune_get(SVSR_TUNE_P8_PH) == 2 ? 2 : 1, stagger = svsr_tune_get(SVSR_TUNE_P8_STAGGER) & 3;      // bit 0: wave groups one barrier apart, bit 1: odd workgroups walk their rounds backwards
 #define P8_LAUNCH(...) do { static bool set_ = false; \
         if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_p8<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); set_ = true; } \
