@@ -187,12 +187,16 @@ int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* m
 /* stem3d[1..3]: BatchNorm3d -> activation -> MaxPool3d((1,3,3),(1,2,2),(0,1,1)) fused; act 1 = exact nn.GELU()
  * (LRW lightning.py:51-53), act 2 = Swish (LRS backbones/conv3d_extractor.py:30-36).
  * x [N][Hc][Wc][C] -> y [N][Hp][Wp][C], amax uint8 [N][Hp][Wp][C] = window-local argmax (first max wins). */
-int svsr_stem_bn_act_pool_fwd(const void* x, void* y, void* amax, const float* mean, const float* rstd, const float* gamma, const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, hipStream_t stream);
+int svsr_stem_bn_act_pool_fwd(const void* x, void* y, void* amax, const float* mean, const float* rstd, const float* gamma, const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, void* xwin, hipStream_t stream);
 
 /* backward of the fused stem pass: dx = gradient of the stem conv output; slots: workspace of
  * svsr_stem_bn_act_pool_bwd_rows(N, Hc, Wc, C) rows of [2][C] floats. */
 int svsr_stem_bn_act_pool_bwd_rows(int N, int Hc, int Wc, int C);
-int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* slots, float* coef, float* dgamma, float* dbeta, void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, hipStream_t stream);
+/* xwin (forward: optional output, backward: optional input), gpool (backward: optional workspace), both bf16 [N][Hp][Wp][C] like y:
+ * the convolution output at every window's arg-max, kept by the forward so that the backward's reduce pass streams pooled-size tensors
+ * (one activation derivative per pooled output, g = dpool * act' written to gpool) instead of gathering from the 4x larger
+ * convolution output, and its apply pass evaluates no activation derivative at all.  Null: the gather form. */
+int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, float* slots, float* coef, float* dgamma, float* dbeta, void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, const void* xwin, void* gpool, hipStream_t stream);
 
 /* hidden.mean((2,3)) (lightning.py:118) and its backward: [N][HW][C] <-> [N][C]. */
 int svsr_avgpool_fwd(const void* x, void* y, int64_t N, int HW, int C, hipStream_t stream);

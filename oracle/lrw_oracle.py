@@ -56,6 +56,18 @@ class _RoundBf16(torch.autograd.Function):
         return g.bfloat16().float()
 
 
+class _RoundGradBf16(torch.autograd.Function):
+    """Identity whose GRADIENT is rounded to bf16: a point where only the HIP path's backward stores a bf16 tensor."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
 def _st(x: Tensor, emu: bool) -> Tensor:
     """A tensor the HIP path stores in bf16 (value and gradient)."""
     return _RoundBf16.apply(x) if emu else x
@@ -158,6 +170,10 @@ def stem3d(videos: Tensor, sd: SD, training: bool, stats_out: dict | None = None
     if keep is not None:
         keep["stem_conv"] = x
     x = batch_norm(x, sd, "stem3d.1", training, stats_out, x_stats=c32 if emu else None)
+    if emu:
+        # the HIP backward keeps g = dpool * gelu'(z) per pooled output in bf16 between its reduce and apply passes (norm_act.hip
+        # k_stem_bwd_reduce_win) — as the reference's own bf16 autocast does with the GELU's input gradient
+        x = _RoundGradBf16.apply(x)
     x = gelu_erf(x)
     x = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
     return _st(x, emu)

@@ -272,15 +272,20 @@ struct StemRowIter {
 
 template <int ACT>
 __global__ __launch_bounds__(256) void k_stem_bn_act_pool_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
-                                                               unsigned char* __restrict__ amax,
+                                                               unsigned char* __restrict__ amax, bf16_t* __restrict__ xwin,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                int N, int Hc, int Wc, int Hp, int Wp, int C, StemRowIter it) {
     const int n = blockIdx.y, row0 = blockIdx.x * it.rpb;
     const int c0 = (threadIdx.x & (it.cv - 1)) * 8;            // 256 % cv == 0: a thread keeps its channel group
-    float sc[8], sh[8];
+    float sc[8], sh[8], rsc[8];
+    bool any_zero_scale = false;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { sc[k] = gamma[c0 + k] * rstd[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k]; }
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = gamma[c0 + k] * rstd[c0 + k]; sh[k] = beta[c0 + k] - mean[c0 + k] * sc[k];
+        rsc[k] = sc[k] != 0.f ? 1.0f / sc[k] : 0.f;
+        any_zero_scale |= sc[k] == 0.f;
+    }
     int rows = Hp - row0; if (rows > it.rpb) rows = it.rpb;
     const int items = rows * (Wp << it.cshift);
     for (int e = threadIdx.x; e < items; e += 256) {
@@ -290,7 +295,9 @@ __global__ __launch_bounds__(256) void k_stem_bn_act_pool_fwd(const bf16_t* __re
         // GELU and Swish both fall to a single minimum and rise from there (quasi-convex), so the maximum of act(z) over a window is
         // attained at the window's largest or smallest z: track those two (first occurrence each) and evaluate the activation twice
         // per channel instead of nine times — the pass was bound by the erf/exp VALU work, not by HBM.
-        float zhi[8], zlo[8];
+        // (A fast path for windows whose largest z is >= 0 — the maximum is then there, one activation per channel — measured SLOWER,
+        // 192 vs 150 us: with 8 channels x 64 lanes some lane of nearly every wave has an all-negative window, so both paths run.)
+        float zhi[8], zlo[8], zw[8];
         int ihi[8], ilo[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { zhi[k] = -INFINITY; zlo[k] = INFINITY; ihi[k] = 0; ilo[k] = 0; }
@@ -322,6 +329,7 @@ __global__ __launch_bounds__(256) void k_stem_bn_act_pool_fwd(const bf16_t* __re
             const bool take_lo = vl > vh || (vl == vh && ilo[k] < ihi[k]);
             best[k] = take_lo ? vl : vh;
             bi[k] = take_lo ? ilo[k] : ihi[k];
+            zw[k] = take_lo ? zlo[k] : zhi[k];
         }
         const long o = (((long)n * Hp + ph) * Wp + pw) * C + c0;
         *reinterpret_cast<u32x4*>(y + o) = pack8(best);
@@ -329,6 +337,23 @@ __global__ __launch_bounds__(256) void k_stem_bn_act_pool_fwd(const bf16_t* __re
 #pragma unroll
         for (int k = 0; k < 4; ++k) { lo |= (unsigned)bi[k] << (8 * k); hi |= (unsigned)bi[k + 4] << (8 * k); }
         *reinterpret_cast<uint2*>(amax + o) = make_uint2(lo, hi);
+        if (xwin != nullptr) {
+            // the winner's convolution output, for the backward's reduce pass (svsr_stem_bn_act_pool_bwd with xwin): recovered from its
+            // z = x * sc + sh — x is a bf16 value, the few fp32 ulps of the round trip vanish in the rounding back to bf16 — or read
+            // again where a channel's scale is exactly zero
+            float xw[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xw[k] = (zw[k] - sh[k]) * rsc[k];
+            if (any_zero_scale) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (sc[k] == 0.f) {
+                        const int i = (bi[k] * 11) >> 5, j = bi[k] - 3 * i;
+                        xw[k] = bf2f(x[(((long)n * Hc + (2 * ph - 1 + i)) * Wc + (2 * pw - 1 + j)) * C + c0 + k]);
+                    }
+            }
+            *reinterpret_cast<u32x4*>(xwin + o) = pack8(xw);
+        }
     }
 }
 
@@ -502,7 +527,9 @@ __global__ __launch_bounds__(256) void k_stem_fwd_lds(const bf16_t* __restrict__
     }
 }
 
-template <int ACT, bool APPLY>
+// GP: `dpool` already is g = dpool * act'(z of the window's winner) (written by k_stem_bwd_reduce_win): no activation derivative here —
+// evaluated per convolution element it was 4 of the pass's ~6 G vector operations
+template <int ACT, bool APPLY, bool GP = false>
 __global__ __launch_bounds__(256) void k_stem_bwd_lds(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ amax,
                                                       const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -570,8 +597,11 @@ __global__ __launch_bounds__(256) void k_stem_bwd_lds(const bf16_t* __restrict__
         float g[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float z = ga[k] * xh[k] + be[k];
-            g[k] = acc[k] * (ACT == 2 ? swish_grad(z) : gelu_erf_grad(z));
+            if (GP) g[k] = acc[k];
+            else {
+                const float z = ga[k] * xh[k] + be[k];
+                g[k] = acc[k] * (ACT == 2 ? swish_grad(z) : gelu_erf_grad(z));
+            }
         }
         if (APPLY) {
             float ov[8];
@@ -595,6 +625,45 @@ __global__ __launch_bounds__(256) void k_stem_bwd_lds(const bf16_t* __restrict__
 // group spread over the banks), then every thread walks pooled 8-channel vectors and reads its eight winners.
 #define STEM_GP 4
 __device__ unsigned g_stem_zero_page[64];
+// Reduce pass of the stem's BatchNorm backward from the winners the FORWARD kept (xwin = convolution output at every window's
+// arg-max): per pooled output one activation derivative, g = dpool * act'(z), written out (bf16) for the apply pass, and the sums of g
+// and g * xhat over the values the apply pass will read back.  Streams 3 x 57 MB at B = 32 instead of re-reading the 230 MB
+// convolution output through LDS tiles (k_stem_bwd_reduce_gather).  Same grid and partial rows as the gather form.
+template <int ACT>
+__global__ __launch_bounds__(256) void k_stem_bwd_reduce_win(const bf16_t* __restrict__ dpool, const bf16_t* __restrict__ xwin,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              bf16_t* __restrict__ gpool, float* __restrict__ slots, int Hp, int Wp) {
+    constexpr int C = 64;
+    __shared__ float sred[256 * 16];
+    const int tid = threadIdx.x, n = blockIdx.y, p0 = blockIdx.x * STEM_GP;
+    const int c0 = (tid & 7) * 8;
+    float mu[8], rs[8], ga[8], be[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k]; ga[k] = gamma[c0 + k]; be[k] = beta[c0 + k]; s1[k] = 0.f; s2[k] = 0.f;
+    }
+    int rows = Hp - p0; if (rows > STEM_GP) rows = STEM_GP;
+    const int pcv = Wp * 8;
+    for (int v = tid; v < rows * pcv; v += 256) {               // 256 % 8 == 0: a thread keeps its channel group
+        const int pr = v / pcv, pw = (v - pr * pcv) >> 3;
+        const long o = (((long)n * Hp + p0 + pr) * Wp + pw) * C + c0;
+        float d[8], xv[8], g[8];
+        unpack8(*reinterpret_cast<const u32x4*>(dpool + o), d);
+        unpack8(*reinterpret_cast<const u32x4*>(xwin + o), xv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float xh = (xv[k] - mu[k]) * rs[k];
+            const float z = ga[k] * xh + be[k];
+            g[k] = bf2f(f2bf(d[k] * (ACT == 2 ? swish_grad(z) : gelu_erf_grad(z))));
+            s1[k] += g[k];
+            s2[k] += g[k] * xh;
+        }
+        *reinterpret_cast<u32x4*>(gpool + o) = pack8(g);
+    }
+    reduce_to_row(sred, s1, s2, 8, C, slots);
+}
+
 template <int ACT>
 __global__ __launch_bounds__(256) void k_stem_bwd_reduce_gather(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ amax,
                                                                 const bf16_t* __restrict__ x, const float* __restrict__ mean,
@@ -794,11 +863,11 @@ int svsr_bn_bwd_from_stats(const void* g, const void* x, const float* mean, cons
 }
 
 int svsr_stem_bn_act_pool_fwd(const void* x, void* y, void* amax, const float* mean, const float* rstd, const float* gamma,
-                              const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, hipStream_t stream) {
+                              const float* beta, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, void* xwin, hipStream_t stream) {
     if (!chan_ok(C) || (act != SVSR_ACT_GELU && act != SVSR_ACT_SWISH)) return SVSR_ERR_ARG;
     StemRowIter it;
     if (!stem_iter(it, C, Wp, Hp)) return SVSR_ERR_ARG;
-    if (stem_lds_fwd()) {
+    if (stem_lds_fwd() && xwin == nullptr) {
         const size_t lds = (size_t)(2 * STEM_PR + 1) * Wc * C * sizeof(float);
         if (lds <= 150 * 1024) {
             static bool attr = false;
@@ -819,10 +888,10 @@ int svsr_stem_bn_act_pool_fwd(const void* x, void* y, void* amax, const float* m
     }
     const dim3 grid((Hp + it.rpb - 1) / it.rpb, N);
     if (act == SVSR_ACT_SWISH)
-        hipLaunchKernelGGL(k_stem_bn_act_pool_fwd<2>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (unsigned char*)amax, mean,
+        hipLaunchKernelGGL(k_stem_bn_act_pool_fwd<2>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (unsigned char*)amax, (bf16_t*)xwin, mean,
                            rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, it);
     else
-        hipLaunchKernelGGL(k_stem_bn_act_pool_fwd<1>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (unsigned char*)amax, mean,
+        hipLaunchKernelGGL(k_stem_bn_act_pool_fwd<1>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, (unsigned char*)amax, (bf16_t*)xwin, mean,
                            rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, it);
     return svsr_check_launch();
 }
@@ -845,7 +914,7 @@ int svsr_stem_bn_act_pool_bwd_rows(int N, int Hc, int Wc, int C) {
 
 int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x, const float* mean, const float* rstd,
                               const float* gamma, const float* beta, float* slots, float* coef, float* dgamma, float* dbeta,
-                              void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, hipStream_t stream) {
+                              void* dx, int N, int Hc, int Wc, int Hp, int Wp, int C, int act, const void* xwin, void* gpool, hipStream_t stream) {
     if (!chan_ok(C) || (act != SVSR_ACT_GELU && act != SVSR_ACT_SWISH)) return SVSR_ERR_ARG;
     StemRowIter it;
     if (!stem_iter(it, C, Wc, Hc)) return SVSR_ERR_ARG;
@@ -855,6 +924,26 @@ int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x
         const dim3 g2((Hc + STEM_BR - 1) / STEM_BR, N);
 #define SVSR_STEM_BWD(A, AP) hipLaunchKernelGGL((k_stem_bwd_lds<A, AP>), g2, dim3(256), lds_b, stream, (const bf16_t*)dpool, (const unsigned char*)amax, \
                        (const bf16_t*)x, mean, rstd, gamma, beta, coef, (bf16_t*)dx, slots, Hc, Wc, Hp, Wp, C)
+        if (stem_bwd_gathers(Wc, Wp, C) && xwin != nullptr && gpool != nullptr) {
+            // winners kept by the forward: reduce pass over pooled outputs only, apply pass without activation derivatives
+            if (Hp != (Hc - 1) / 2 + 1) return SVSR_ERR_ARG;
+            const dim3 gg((Hp + STEM_GP - 1) / STEM_GP, N);
+            if (act == SVSR_ACT_SWISH)
+                hipLaunchKernelGGL(k_stem_bwd_reduce_win<2>, gg, dim3(256), 0, stream, (const bf16_t*)dpool, (const bf16_t*)xwin, mean, rstd, gamma, beta,
+                                   (bf16_t*)gpool, slots, Hp, Wp);
+            else
+                hipLaunchKernelGGL(k_stem_bwd_reduce_win<1>, gg, dim3(256), 0, stream, (const bf16_t*)dpool, (const bf16_t*)xwin, mean, rstd, gamma, beta,
+                                   (bf16_t*)gpool, slots, Hp, Wp);
+            hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
+                               dgamma, dbeta, coef);
+            if (act == SVSR_ACT_SWISH)
+                hipLaunchKernelGGL((k_stem_bwd_lds<2, true, true>), g2, dim3(256), lds_b, stream, (const bf16_t*)gpool, (const unsigned char*)amax, (const bf16_t*)x,
+                                   mean, rstd, gamma, beta, coef, (bf16_t*)dx, slots, Hc, Wc, Hp, Wp, C);
+            else
+                hipLaunchKernelGGL((k_stem_bwd_lds<1, true, true>), g2, dim3(256), lds_b, stream, (const bf16_t*)gpool, (const unsigned char*)amax, (const bf16_t*)x,
+                                   mean, rstd, gamma, beta, coef, (bf16_t*)dx, slots, Hc, Wc, Hp, Wp, C);
+            return svsr_check_launch();
+        }
         if (stem_bwd_gathers(Wc, Wp, C)) {
             if (Hp != (Hc - 1) / 2 + 1) return SVSR_ERR_ARG;
             const dim3 gg((Hp + STEM_GP - 1) / STEM_GP, N);

@@ -570,8 +570,11 @@ def _frontend_forward(model, st: "_ParamStore", tape: dict, videos: torch.Tensor
     sc, sb, act = model.stem_name + ".0", model.stem_name + ".1", model.trunk_act
     c, stats = ops.stem_conv_fwd(videos, st.p32(f"{sc}.weight"), want_stats=training)
     mean, rstd = _bn_stats(st, sb, training, c.numel() // 64, stats)
-    x, amax = ops.stem_bn_gelu_pool_fwd(c, mean, rstd, st.p32(f"{sb}.weight"), st.p32(f"{sb}.bias"), model.stem_act)
-    tape["stem"] = dict(videos=videos, c=c, amax=amax, mean=mean, rstd=rstd, pooled_shape=tuple(x.shape))
+    if training and ops.STEM_KEEP_WINNERS:
+        x, amax, xwin = ops.stem_bn_gelu_pool_fwd(c, mean, rstd, st.p32(f"{sb}.weight"), st.p32(f"{sb}.bias"), model.stem_act, want_win=True)
+    else:
+        (x, amax), xwin = ops.stem_bn_gelu_pool_fwd(c, mean, rstd, st.p32(f"{sb}.weight"), st.p32(f"{sb}.bias"), model.stem_act), None
+    tape["stem"] = dict(videos=videos, c=c, amax=amax, xwin=xwin, mean=mean, rstd=rstd, pooled_shape=tuple(x.shape))
     for prefix, inp, planes, stride, down in _trunk_blocks(model):
         xin = x
         o1 = _conv_bn(st, tape, xin, f"{prefix}.conv1", f"{prefix}.bn1", 3, stride, 1, training, None, act)
@@ -654,7 +657,7 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
     sc, sb = model.stem_name + ".0", model.stem_name + ".1"
     ws = st.bn[sb]
     dconv = ops.stem_bn_gelu_pool_bwd(dx, ts["amax"], ts["c"], ts["mean"], ts["rstd"], st.p32(f"{sb}.weight"), st.p32(f"{sb}.bias"),
-                                      ws["coef"], st.g32(f"{sb}.weight"), st.g32(f"{sb}.bias"), model.stem_act)
+                                      ws["coef"], st.g32(f"{sb}.weight"), st.g32(f"{sb}.bias"), model.stem_act, xwin=ts.get("xwin"))
     ops.stem_conv_wgrad(ts["videos"], dconv, st.g32(f"{sc}.weight"), use_tr)
     model._side.join()
     _ready(model, st, None)

@@ -6,6 +6,7 @@ libsyncvsr_hip.so on the current HIP stream.  Tensors are NHWC bf16 activations 
 from __future__ import annotations
 
 import ctypes
+import os
 import struct
 from contextlib import contextmanager
 from typing import Callable, Optional, Sequence
@@ -120,6 +121,10 @@ def tune(key: str, value: int) -> None:
     if key == "bn_bwd_fused":
         global BN_BWD_FUSED
         BN_BWD_FUSED = bool(value)
+        return
+    if key == "stem_keep_winners":
+        global STEM_KEEP_WINNERS
+        STEM_KEEP_WINNERS = bool(value)
         return
     if key == "ctc_side":
         global CTC_SIDE
@@ -774,22 +779,29 @@ def stem_conv_wgrad(videos: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, us
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SWISH = 0, 1, 1, 2     # ReLU/GELU share code 1: ReLU in the BN passes, GELU in the stem pass
 
 
-def stem_bn_gelu_pool_fwd(x: torch.Tensor, mean, rstd, gamma, beta, act: int = ACT_GELU) -> tuple[torch.Tensor, torch.Tensor]:
+STEM_KEEP_WINNERS = os.environ.get("SVSR_STEM_KEEP_WINNERS", "1") != "0"     # the stem's forward keeps the convolution output at every pooling window's arg-max for its backward
+
+
+def stem_bn_gelu_pool_fwd(x: torch.Tensor, mean, rstd, gamma, beta, act: int = ACT_GELU, want_win: bool = False):
+    """-> (y, amax) or, with want_win, (y, amax, xwin): xwin = the convolution output at every window's arg-max, for
+    stem_bn_gelu_pool_bwd(xwin=...) (reduce pass over pooled-size tensors, apply pass without activation derivatives)."""
     N, Hc, Wc, C = x.shape
     Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
     y = torch.empty((N, Hp, Wp, C), dtype=BF16, device=x.device)
     amax = torch.empty((N, Hp, Wp, C), dtype=torch.uint8, device=x.device)
-    _call("svsr_stem_bn_act_pool_fwd", _p(x), _p(y), _p(amax), _p(mean), _p(rstd), _p(gamma), _p(beta), N, Hc, Wc, Hp, Wp, C, act, _stream())
-    return y, amax
+    xwin = torch.empty((N, Hp, Wp, C), dtype=BF16, device=x.device) if want_win else None
+    _call("svsr_stem_bn_act_pool_fwd", _p(x), _p(y), _p(amax), _p(mean), _p(rstd), _p(gamma), _p(beta), N, Hc, Wc, Hp, Wp, C, act, _p(xwin), _stream())
+    return (y, amax, xwin) if want_win else (y, amax)
 
 
-def stem_bn_gelu_pool_bwd(dpool, amax, x, mean, rstd, gamma, beta, coef, dgamma, dbeta, act: int = ACT_GELU) -> torch.Tensor:
+def stem_bn_gelu_pool_bwd(dpool, amax, x, mean, rstd, gamma, beta, coef, dgamma, dbeta, act: int = ACT_GELU, xwin=None) -> torch.Tensor:
     N, Hc, Wc, C = x.shape
     _, Hp, Wp, _ = dpool.shape
     dx = torch.empty_like(x)
     slots = scratch(_query("svsr_stem_bn_act_pool_bwd_rows", N, Hc, Wc, C)[0] * 2 * C)
+    gpool = torch.empty_like(dpool) if xwin is not None else None
     _call("svsr_stem_bn_act_pool_bwd", _p(dpool), _p(amax), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slots), _p(coef),
-          _p(dgamma), _p(dbeta), _p(dx), N, Hc, Wc, Hp, Wp, C, act, _stream())
+          _p(dgamma), _p(dbeta), _p(dx), N, Hc, Wc, Hp, Wp, C, act, _p(xwin), _p(gpool), _stream())
     return dx
 
 

@@ -91,7 +91,11 @@ def test_front_end_backward_block_by_block(case):
     up = _nchw(rec["stem"][0])                                                        # [B*T, 64, 22, 22]
     pooled.backward(up.unflatten(0, (B, T)).transpose(1, 2).contiguous())
     for n in ("stem3d.0.weight", "stem3d.1.weight", "stem3d.1.bias"):
-        check(n, hip_grad[n], osd[n].grad)
+        # BatchNorm parameters of the stem: sums of g = dpool * gelu'(z) over 450 k positions per channel that cancel to a few per cent
+        # of their terms; g is a bf16 tensor between the backward's two passes (as under the reference's bf16 autocast), the HIP
+        # path rounds it per pooled output and the oracle per convolution element — two realisations of the same rounding noise,
+        # 0.2 % of the sums' norm at B = 32
+        check(n, hip_grad[n], osd[n].grad, ratio_tol=ratio_band if n == "stem3d.0.weight" else max(ratio_band, 0.005))
     worst.sort()
     print("lowest cosines:", [(round(c, 5), round(r, 4), n) for c, r, n in worst[:6]])
     print("largest norm deviations:", [(round(c, 5), round(r, 4), n) for c, r, n in sorted(worst, key=lambda w: -abs(w[1] - 1.0))[:6]])

@@ -482,6 +482,23 @@ def test_stem_bn_gelu_pool(dev, Hc, Wc):
     assert ((got - ref_dx).norm() / ref_dx.norm()).item() <= 3e-2
     check(dg, gm.grad, "stem.dgamma", 1e-2, 6e-3)
     check(db, bt.grad, "stem.dbeta", 1e-2, 6e-3)
+    # the same through the winners the forward keeps (xwin: the convolution output at every window's arg-max; reduce pass over pooled
+    # outputs, apply pass without activation derivatives): same outputs, and xwin IS the bf16 value at the arg-max
+    y2, amax2, xwin = ops.stem_bn_gelu_pool_fwd(x.to(dev), m, r, gamma.to(dev), beta.to(dev), want_win=True)
+    assert torch.equal(y2, y) and torch.equal(amax2, amax)
+    Hp, Wp = y.shape[1], y.shape[2]
+    xpad = F.pad(nchw(x.float()), (1, 1, 1, 1))
+    win = F.unfold(xpad, 3, stride=2).view(N, C, 9, Hp, Wp)                     # [N, C, 9, Hp, Wp]
+    want_win = torch.gather(win, 2, nchw(amax.cpu().long()).unsqueeze(2)).squeeze(2)
+    assert torch.equal(nchw(xwin.float().cpu()), want_win), "xwin must be the stored convolution output at the arg-max"
+    dg2 = torch.zeros(C, device=dev); db2 = torch.zeros(C, device=dev)
+    dx2 = ops.stem_bn_gelu_pool_bwd(dpool.to(dev), amax, x.to(dev), m, r, gamma.to(dev), beta.to(dev), coef, dg2, db2, xwin=xwin)
+    got2 = dx2.float().cpu()
+    assert ((got2 - got).norm() / got.norm()).item() <= 4e-3, "winner form vs gather form (g rounded to bf16 once more)"
+    bad2 = ((got2 - ref_dx).abs() > 2e-2 * ref_dx.abs().max()).sum().item()
+    assert bad2 <= max(4, 1e-3 * ref_dx.numel()) and ((got2 - ref_dx).norm() / ref_dx.norm()).item() <= 3e-2
+    check(dg2, gm.grad, "stem.dgamma (winners)", 1e-2, 6e-3)
+    check(db2, bt.grad, "stem.dbeta (winners)", 1e-2, 6e-3)
 
 
 def test_avgpool(dev):
