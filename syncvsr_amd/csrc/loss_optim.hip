@@ -249,6 +249,40 @@ __global__ __launch_bounds__(256) void k_transpose_bf16_multi(const bf16_t* __re
     const int ta = (e.A + 63) / 64, tb = (e.Bd + 63) / 64;
     const int ntiles = e.T * ta * tb;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 pairs x 8 rows
+    if ((e.Bd & 7) == 0 && (e.Apad & 7) == 0 && (e.src_off & 7) == 0 && (e.dst_off & 7) == 0) {
+        // 16-byte global accesses (every trunk / encoder weight): a thread loads two 8-element row pieces, the tile turns in LDS
+        // (4-byte writes, 2-byte column reads), and it stores two 8-element pieces of transposed rows.  4-byte accesses ran the
+        // refresh at 2.4 TB/s.
+        const int vx = threadIdx.x & 7, vy = threadIdx.x >> 3;    // 8 pieces x 32 rows
+        for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+            const int t = tile_id / (ta * tb);
+            const int rem = tile_id - t * (ta * tb);
+            const int a0 = (rem / tb) * 64, b0 = (rem % tb) * 64;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int a = a0 + vy + 32 * i, bd = b0 + 8 * vx;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (a < e.A && bd < e.Bd) v = *reinterpret_cast<const u32x4*>(src + e.src_off + ((long)a * e.T + t) * e.Bd + bd);
+                unsigned* row = reinterpret_cast<unsigned*>(&tile[vy + 32 * i][8 * vx]);
+                row[0] = v.x; row[1] = v.y; row[2] = v.z; row[3] = v.w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int bd = b0 + vy + 32 * i, a = a0 + 8 * vx;
+                if (bd < e.Bd && a < e.Apad) {
+                    unsigned w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        w[k] = (unsigned)tile[8 * vx + 2 * k][vy + 32 * i] | ((unsigned)tile[8 * vx + 2 * k + 1][vy + 32 * i] << 16);
+                    u32x4 o; o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+                    *reinterpret_cast<u32x4*>(dst + e.dst_off + ((long)bd * e.T + t) * e.Apad + a) = o;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const bool pair_src = (e.Bd & 1) == 0 && (e.src_off & 1) == 0, pair_dst = (e.Apad & 1) == 0 && (e.dst_off & 1) == 0;
     for (int tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
         const int t = tile_id / (ta * tb);
