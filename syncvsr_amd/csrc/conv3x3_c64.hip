@@ -83,13 +83,23 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
                                          (__attribute__((address_space(3))) void*)(sW + (wrow + 64 * i) * 64), 16, 0, 0);
     }
 
+    // source pixels of the five rows this thread stages: from the table (svsr_conv3x3_c64_pixtab; the entries of a chunk are requested
+    // one chunk ahead, pixn) — computing them costs two divisions by reciprocal with fix-ups per row, ~500 instructions per chunk
+    // and thread in front of 72 MFMAs per wave — or, without a table, by that arithmetic
+    const bool tab = p.pixtab != nullptr;
+    int pixn[5];
+    auto table_rows = [&](int c) {
+        const int* t = p.pixtab + C64_TAB_PAD + c * C64_CH - halo + r0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) pixn[i] = t[64 * i];
+    };
     auto stage = [&](int c, int buf) {
         const int q0 = c * C64_CH;
         bf16_t* dst = sA + buf * C64_LDS_A + wrow * 64;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int rr = r0 + 64 * i;
-            const int pix = c64_pixel(p, q0 - halo + rr);
+            const int pix = tab ? pixn[i] : c64_pixel(p, q0 - halo + rr);
             const bf16_t* src = pix >= 0 ? p.in + (long)pix * 64 + csw * 8 : zero_src;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + i * 64 * 64), 16, 0, 0);
@@ -115,13 +125,16 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
         sC[192 + tid] = affine ? __builtin_fmaf(-m, c, p.bnb_beta[tid]) : 0.f;
     }
     int c = blockIdx.x, buf = 0;
+    if (tab && c < p.total_chunks) table_rows(c);
     if (c < p.total_chunks) stage(c, 0);
+    if (tab && c + (int)gridDim.x < p.total_chunks) table_rows(c + gridDim.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // weights + first tile
     for (; c < p.total_chunks; c += gridDim.x, buf ^= 1) {
         // every wave's part of this chunk's tile has landed (each waited before arriving here), and everybody is done with
         // the previous chunk's tile / staging, which the next DMA overwrites
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (c + (int)gridDim.x < p.total_chunks) stage(c + gridDim.x, buf ^ 1);
+        if (tab && c + 2 * (int)gridDim.x < p.total_chunks) table_rows(c + 2 * gridDim.x);
         const bf16_t* cA = sA + buf * C64_LDS_A;
 
         f32x16 acc[2];              // D[row = output channel j*32 + ..][col = position]: 4 consecutive channels per lane
