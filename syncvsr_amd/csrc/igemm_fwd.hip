@@ -877,8 +877,11 @@ extern "C" int svsr_conv_plan(int mode, int Nimg, int H, int W, int Co_out, int 
             }
     }
     // stride-1 3x3 / pad 1 (forward and data gradient alike: same map size on both sides): candidates for the persistent kernel
+    // (tune key p8 = 3: stride 1 only)
     const int p8_pix[2] = {mode == 0 ? H * W : Ho * Wo, mode == 0 ? Ho * Wo : H * W};
-    const bool p8_ok = k == 3 && stride == 1 && pad == 1 && H >= 2 && W >= 2;
+    // (and the FORWARD of the stride-2 3x3 convolutions that open layer2-4: the same tap classes over a quarter of the positions; their data
+    // gradients have parity classes of one or two taps, too short for the kernel's pipeline)
+    const bool p8_ok = k == 3 && pad == 1 && H >= 2 && W >= 2 && (stride == 1 || (stride == 2 && mode == 0 && svsr_tune_get(SVSR_TUNE_P8) >= 1 && svsr_tune_get(SVSR_TUNE_P8) != 3));
     return plan_emit(cls, Nimg, Co_out, words, cap_words, meta, p8_ok ? p8_pix : nullptr);
 }
 

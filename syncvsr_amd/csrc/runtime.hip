@@ -32,7 +32,7 @@ static int g_tune[SVSR_TUNE_N] = {
     /* STEM_WG_PIPE */ 1,      // svsr_stem_conv_wgrad: next tile's operands prefetched into registers during the MFMA block
     /* STEM_FWD_DMA */ 1,      // svsr_stem_conv_fwd: bf16 prep pass + LDS-DMA tile fills (0: direct fp32 -> LDS path)
     /* IGEMM_LIN_BN64 */ 2048, // svsr_igemm_fwd: linears that would get 64x64 tiles use 128x64 tiles from this many rows on (0: never; LRS 768-wide outputs at 2,400 rows: 29.6 -> 29.1 ms per step)
-    /* P8 */ 1,                // stride-1 3x3 convolution plans with Co % 128 == 0 and enough tiles use the persistent 8-wave 256x128 kernel (igemm_p8.hip)
+    /* P8 */ 1,                // stride-1 3x3 convolution plans with Co % 128 == 0 and enough tiles use the persistent 8-wave 256x128 kernel (igemm_p8.hip) — also the forward of the stride-2 3x3 convolutions (3: stride 1 only)
     /* P8_GRID */ 0,           // workgroups of that kernel (0: one per CU)
     /* P8_MIN_ITEMS */ 200,    // ... from this many 256x128 tiles on (fewer leave CUs idle for the whole launch)
     /* P8_TRACE */ 0,          // debug: the instrumented instantiation (per-phase time stamps of workgroup 0, svsr_debug_p8_trace)
