@@ -722,10 +722,10 @@ struct PlanClass { int ntaps; int delta[9], tw[9]; std::vector<int> pos; };     
 
 // meta: {bm, bn, ns, tiles (= grid.x = BatchNorm partial rows), grid.y, classes, max taps of a class, total rows / 2^0 (low 31 bits)}
 // p8 format (igemm_fwd.h): per 256-row M tile a descriptor and a row table of global pixel indices, tiles in class order
-static int plan_emit_p8(const std::vector<PlanClass>& cls, int Nimg, int Co, int in_pix, int out_pix, int* words, int cap_words, int* meta, long M, int max_taps) {
+static int plan_emit_p8(const std::vector<PlanClass>& cls, int Nimg, int Co, int in_pix, int out_pix, int* words, int cap_words, int* meta, long M, int max_taps, int bn) {
     long tiles_m = 0;
     for (const PlanClass& c : cls) tiles_m += ((long)Nimg * (long)(c.pos.size() / 2) + P8_BM - 1) / P8_BM;
-    const int gy = Co / P8_BN;
+    const int gy = Co / bn;
     const long nwords = P8_HDR_WORDS + tiles_m * (P8_DESC_WORDS + 2 * P8_BM);
     if (nwords > 0x7fffffffL || (long)Nimg * in_pix >= (1L << 31) || (long)Nimg * out_pix >= (1L << 31)) return -SVSR_ERR_ARG;
     if (words != nullptr) {
@@ -754,7 +754,7 @@ static int plan_emit_p8(const std::vector<PlanClass>& cls, int Nimg, int Co, int
         }
     }
     if (meta != nullptr) {
-        meta[0] = P8_BM; meta[1] = P8_BN; meta[2] = 3; meta[3] = (int)tiles_m; meta[4] = gy; meta[5] = (int)cls.size(); meta[6] = max_taps;
+        meta[0] = P8_BM; meta[1] = bn; meta[2] = 3; meta[3] = (int)tiles_m; meta[4] = gy; meta[5] = (int)cls.size(); meta[6] = max_taps;
         meta[7] = (int)(M & 0x7fffffff);
     }
     return (int)nwords;
@@ -767,13 +767,17 @@ static int plan_emit(std::vector<PlanClass>& cls, int Nimg, int Co, int* words, 
     int max_taps = 0;
     for (const PlanClass& c : cls) { M += (long)Nimg * (long)(c.pos.size() / 2); if (c.ntaps > max_taps) max_taps = c.ntaps; }
     if (M >= (1L << 24) * 64 || cls.empty()) return -SVSR_ERR_ARG;
-    if (p8_pix != nullptr && svsr_tune_get(SVSR_TUNE_P8) && Co % P8_BN == 0) {
+    if (p8_pix != nullptr && svsr_tune_get(SVSR_TUNE_P8) && Co % 64 == 0) {
         long tiles_m = 0;
         int min_taps = 9;
         for (const PlanClass& c : cls) { tiles_m += ((long)Nimg * (long)(c.pos.size() / 2) + P8_BM - 1) / P8_BM; if (c.ntaps < min_taps) min_taps = c.ntaps; }
         // (the kernel's pipeline needs >= 4 K tiles per tile: every class of a padded 3x3 convolution has >= 4 taps)
-        if (min_taps >= 4 && tiles_m * (Co / P8_BN) >= svsr_tune_get(SVSR_TUNE_P8_MIN_ITEMS))
-            return plan_emit_p8(cls, Nimg, Co, p8_pix[0], p8_pix[1], words, cap_words, meta, M, max_taps);
+        const int min_items = svsr_tune_get(SVSR_TUNE_P8_MIN_ITEMS);
+        if (min_taps >= 4 && Co % P8_BN == 0 && tiles_m * (Co / P8_BN) >= min_items)
+            return plan_emit_p8(cls, Nimg, Co, p8_pix[0], p8_pix[1], words, cap_words, meta, M, max_taps, P8_BN);
+        // too few 256 x 128 items to give every CU one (layer4: 33 row tiles x 4): 256 x 64 tiles (tune key p8_bn64)
+        if (min_taps >= 4 && Co >= 128 && tiles_m * (Co / 64) >= min_items && svsr_tune_get(SVSR_TUNE_P8_BN64))
+            return plan_emit_p8(cls, Nimg, Co, p8_pix[0], p8_pix[1], words, cap_words, meta, M, max_taps, 64);
     }
     const IgemmFwdPlan pl = igemm_fwd_plan(M, Co, max_taps);
     const int ncls = (int)cls.size();

@@ -60,20 +60,20 @@ struct TileCtx {
 // shortest of the next (tiles are ordered by decreasing tap count)
 // rev > 0 (= this workgroup's round count): the rounds are walked last to first — half the workgroups start with their SHORT tile, so
 // the first epilogues of a launch (an HBM burst when they coincide) do not all fall at the same moment
-__device__ __forceinline__ bool p8_item(int gy, int items, int w, int G, int r, int& m_tile, int& n0, int rev = 0) {
+__device__ __forceinline__ bool p8_item(int gy, int items, int w, int G, int r, int& m_tile, int& n0, int rev = 0, int bn = BN) {
     if (rev > 0) { if (r >= rev) return false; r = rev - 1 - r; }
     const int q = r * G + ((r & 1) ? G - 1 - w : w);
     if (q >= items) return false;
     const int grp = q / (8 * gy), rem = q - grp * 8 * gy;
     m_tile = grp * 8 + (rem & 7);
-    n0 = (rem >> 3) * BN;
+    n0 = (rem >> 3) * bn;
     return true;          // (m_tile may be a hole >= tiles_m: the caller skips it)
 }
 
-__device__ __forceinline__ bool p8_next_item(int tiles_m, int gy, int items, int w, int G, int& r, int& m_tile, int& n0, int rev = 0) {
+__device__ __forceinline__ bool p8_next_item(int tiles_m, int gy, int items, int w, int G, int& r, int& m_tile, int& n0, int rev = 0, int bn = BN) {
     for (;;) {
         ++r;
-        if (!p8_item(gy, items, w, G, r, m_tile, n0, rev)) return false;
+        if (!p8_item(gy, items, w, G, r, m_tile, n0, rev, bn)) return false;
         if (m_tile < tiles_m) return true;
     }
 }
@@ -86,8 +86,12 @@ __device__ __forceinline__ bool p8_next_item(int tiles_m, int gy, int items, int
 __device__ unsigned long long g_p8_trace[1024];
 
 // PH: phases per K tile (2: the 32-deep halves, 8 MFMAs between barriers; 1: the whole K tile, 16 MFMAs between barriers)
-template <int EPI, int PH = 2, bool TRACE = false>
+// NJ: 32-column blocks of a wave's tile — 2: the 256 x 128 tile (wave tile 64 x 64); 1: a 256 x 64 tile (wave tile 64 x 32) for launches whose
+// 128-wide items would leave half the CUs idle (layer4: 33 row tiles x 512 channels = 132 items of 128 columns, 264 of 64)
+template <int EPI, int PH = 2, bool TRACE = false, int NJ = 2>
 __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int stagger, int ablate) {
+    constexpr int BNT = 64 * NJ, NPIECE = 4 + NJ;          // tile columns; DMA pieces per thread and K tile
+    static_assert(NJ == 2 || PH == 1, "the 64-column tile has five pieces per K tile: one phase");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
     int* sRowTab = reinterpret_cast<int*>(smem + ROWTAB_OFF);
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
         for (int i = 0; i < 4; ++i)       // (rows past the end of a class repeat the tile's first row: always a readable pixel; their results are dropped)
             c.a_off[i] = ((unsigned)sRowTab[par * 512 + (rr + 64 * i) * 2] * (unsigned)p.in_pitch + csw * 8) * 2u;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) c.b_off[i] = ((unsigned)(n0 + rr + 64 * i) * (unsigned)(p.wt_taps * p.Ci) + csw * 8) * 2u;
+        for (int i = 0; i < NJ; ++i) c.b_off[i] = ((unsigned)(n0 + rr + 64 * i) * (unsigned)(p.wt_taps * p.Ci) + csw * 8) * 2u;
     };
     auto dummy_ctx = [&](TileCtx& c) {                    // past the last tile: the staging stream keeps its rhythm on a harmless source
         c.m_tile = -1; c.n0 = 0; c.desc = 0; c.KT = 1 << 30;
@@ -141,10 +145,10 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
     int rev = 0;
     if ((stagger & 2) && (w & 1)) {
         int mt, nn;
-        while (p8_item(gy, items, w, G, rev, mt, nn)) ++rev;      // rounds of this workgroup
+        while (p8_item(gy, items, w, G, rev, mt, nn, 0, BNT)) ++rev;      // rounds of this workgroup
     }
     int r = -1, m_tile = 0, n0 = 0;
-    if (!p8_next_item(tiles_m, gy, items, w, G, r, m_tile, n0, rev)) return;
+    if (!p8_next_item(tiles_m, gy, items, w, G, r, m_tile, n0, rev, BNT)) return;
     int par = 0;
     meta_dma(m_tile, par);
     P8_SYNC_ALL();
@@ -170,23 +174,23 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
         for (int s = 0; s < 2; ++s) {
             const char *abase, *bbase;
             stream_bases(abase, bbase);
-            stage_pieces(str, abase, bbase, ring + s * S_ELEMS, std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{});
+            stage_pieces(str, abase, bbase, ring + s * S_ELEMS, std::integral_constant<int, 0>{}, std::integral_constant<int, NPIECE>{});
             stream_advance();
         }
-        P8_WAIT_VM(6);
+        P8_WAIT_VM(NPIECE);
         P8_BARRIER();
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
     for (;;) {
         // ---- the following item (its meta data is requested during K tile 0, its pointers are built at K tile 2) ----------
         int r2 = r, m2 = 0, n2 = 0;
-        const bool has_next = p8_next_item(tiles_m, gy, items, w, G, r2, m2, n2, rev);
+        const bool has_next = p8_next_item(tiles_m, gy, items, w, G, r2, m2, n2, rev, BNT);
         if (!has_next) dummy_ctx(nxt);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
@@ -210,11 +214,11 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
             const bf16_t* cB = cA + A_ELEMS;
             const int tgt = stg == 0 ? 2 : stg - 1;       // == (stg + 2) % 3
             bf16_t* dst = ring + tgt * S_ELEMS;
-            constexpr int KF = 4 / PH, NP = 6 / PH;        // 16-deep fragments and DMA pieces per phase
-            bf16x8 fa[KF][2], fb[KF][2];
+            constexpr int KF = 4 / PH, NP = NPIECE / PH;   // 16-deep fragments and DMA pieces per phase
+            bf16x8 fa[KF][2], fb[KF][NJ];
             if (TRACE) {
 #pragma unroll
-                for (int kf = 0; kf < KF; ++kf) { fa[kf][0] = fa[kf][1] = fb[kf][0] = fb[kf][1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+                for (int kf = 0; kf < KF; ++kf) { fa[kf][0] = fa[kf][1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; for (int j = 0; j < NJ; ++j) fb[kf][j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
             }
 #pragma unroll
             for (int h = 0; h < PH; ++h) {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                 if (kt == 0 && h == 0) P8_WAIT_VM(0);
                 if (!TRACE || ablate != 3) {
                     if (h == 0) stage_pieces(str, abase, bbase, dst, std::integral_constant<int, 0>{}, std::integral_constant<int, NP>{});
-                    else stage_pieces(str, abase, bbase, dst, std::integral_constant<int, NP>{}, std::integral_constant<int, 6>{});
+                    else stage_pieces(str, abase, bbase, dst, std::integral_constant<int, NP>{}, std::integral_constant<int, NPIECE>{});
                 }
                 if (!TRACE || ablate != 4)
 #pragma unroll
@@ -234,12 +238,12 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 #pragma unroll
                     for (int i = 0; i < 2; ++i) fa[kf][i] = *reinterpret_cast<const bf16x8*>(cA + LDS_SWZ(wm * 64 + i * 32 + (lane & 31), ch));
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) fb[kf][j] = *reinterpret_cast<const bf16x8*>(cB + LDS_SWZ(wn * 64 + j * 32 + (lane & 31), ch));
+                    for (int j = 0; j < NJ; ++j) fb[kf][j] = *reinterpret_cast<const bf16x8*>(cB + LDS_SWZ(wn * 32 * NJ + j * 32 + (lane & 31), ch));
                 }
                 if (h == PH - 1) {
                     // K tile kt + 1 has landed once only K tile kt + 2's six pieces (and, at kt = 0, the two meta pieces) are outstanding
                     if (kt == 0) { if (has_next) meta_dma(m2, par ^ 1); }
-                    else P8_WAIT_VM(6);
+                    else P8_WAIT_VM(NPIECE);
                 }
                 P8_WAIT_LGKM0();
                 stamp(kt, h, 1);
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < NJ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kf][i], fb[kf][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -286,12 +290,12 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
             const int* rowtab = sRowTab + par * 512;
             const int n0t = cur.n0;
             const int c4 = lane & 7, rq = lane >> 3;      // this lane's four channels of a fragment, its row (+ 8 k) of a fragment
-            float st_s[2], st_q[2];
+            float st_s[NJ], st_q[NJ];
             if (EPI == 0 && p.stats != nullptr) {
                 // rows past the end of the class carry the first row's data, not zeros: a partial tile (wave-uniform test) masks them
                 const int valid = __builtin_amdgcn_readlane(cur.desc, 1);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     float s = 0.f, q = 0.f;
                     if (valid >= BM) {
 #pragma unroll
@@ -313,10 +317,10 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                 }
             }
             const bool from_x = p.bnb_y == nullptr, swish_act = p.bnb_act == 2, has_add = p.addend != nullptr;
-            float bs1[2][4], bs2[2][4];
+            float bs1[NJ][4], bs2[NJ][4];
             if (EPI == 1) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { bs1[j][k] = 0.f; bs2[j][k] = 0.f; }
             }
@@ -331,8 +335,8 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                 }
             P8_WAIT_LGKM0();
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0t + wn * 64 + j * 32 + c4 * 4;      // first of this lane's four channels
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0t + wn * 32 * NJ + j * 32 + c4 * 4;      // first of this lane's four channels
                 // the global operands of this 32-column half of the wave tile (addend, x, y: 8 bytes per row and fragment) are requested
                 // HERE, before the first is used: with LDS-DMA pieces of the next tile in flight hipcc turns every wait for an ordinary
                 // load into vmcnt(0), so per-fragment requests would cost one full round trip each
@@ -444,13 +448,13 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                 P8_SYNC_LDS();                               // every wave is done with its patch
                 float* red = reinterpret_cast<float*>(ring + idle * S_ELEMS);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { red[(wave * 64 + lane) * 16 + j * 4 + k] = bs1[j][k]; red[(wave * 64 + lane) * 16 + 8 + j * 4 + k] = bs2[j][k]; }
                 P8_SYNC_LDS();
-                if (tid < 2 * BN) {
-                    const int which = tid / BN, cc = tid - which * BN;       // cc = wn*64 + j*32 + c4*4 + k
-                    const int g = cc >> 6, j = (cc >> 5) & 1, c4r = (cc >> 2) & 7, k = cc & 3;
+                if (tid < 2 * BNT) {
+                    const int which = tid / BNT, cc = tid - which * BNT;     // cc = wn*32*NJ + j*32 + c4*4 + k
+                    const int g = cc / (32 * NJ), j = (cc >> 5) % NJ, c4r = (cc >> 2) & 7, k = cc & 3;
                     float s = 0.f;
                     for (int m = 0; m < 4; ++m)
                         for (int q = 0; q < 8; ++q) s += red[((g * 4 + m) * 64 + q * 8 + c4r) * 16 + which * 8 + j * 4 + k];
@@ -459,14 +463,14 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
             } else if (p.stats != nullptr) {
                 // sRed: [8 waves][64 columns][2]; waves (wm, wn), wm = 0..3, own the columns of wn: added in the order of wm
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     if (lane < 32) {
                         sRed[(wave * 64 + j * 32 + lane) * 2 + 0] = st_s[j];
                         sRed[(wave * 64 + j * 32 + lane) * 2 + 1] = st_q[j];
                     }
                 P8_SYNC_LDS();
-                if (tid < BN) {
-                    const int g = tid >> 6, cc = tid & 63;
+                if (tid < BNT) {
+                    const int g = tid / (32 * NJ), cc = tid % (32 * NJ);
                     float s = 0.f, q = 0.f;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) { s += sRed[((g * 4 + m) * 64 + cc) * 2 + 0]; q += sRed[((g * 4 + m) * 64 + cc) * 2 + 1]; }
@@ -493,12 +497,13 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) {
     // meta: {256, 128, 3, M tiles, gy, classes, max taps, rows}; the epilogues this kernel has: (+addend | BatchNorm-backward), BatchNorm partials
     if (a.bias != nullptr || a.act != 0 || a.out_f32 || a.out_pre != nullptr || a.alpha != 1.f || a.drop.seed != nullptr) return SVSR_ERR_ARG;
-    if (a.Co % BN != 0 || a.out_pitch % 8 != 0 || a.Ci % BK != 0) return SVSR_ERR_ARG;
+    const int bn = meta[1];                     // 128, or 64 (plans whose 128-wide items would not fill the chip)
+    if ((bn != BN && bn != 64) || a.Co % bn != 0 || a.out_pitch % 8 != 0 || a.Ci % BK != 0) return SVSR_ERR_ARG;
     // per-lane addresses are 32-bit byte offsets from the tensor bases
     if ((long)a.Nimg * a.in_pix * a.in_pitch * 2 >= (1L << 32) || (long)a.Co * a.wt_taps * a.Ci * 2 >= (1L << 32)) return SVSR_ERR_ARG;
     if ((long)a.Nimg * a.out_pix * a.out_pitch >= (1L << 31)) return SVSR_ERR_ARG;          // the epilogue's row offsets are 32-bit element counts
     static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
-    const int tiles_m = meta[3], gy = a.Co / BN;
+    const int tiles_m = meta[3], gy = a.Co / bn;
     const int items = (tiles_m + 7) / 8 * 8 * gy;
     int G = items < cus ? items : cus;
     const int forced = svsr_tune_get(SVSR_TUNE_P8_GRID);
@@ -507,7 +512,8 @@ int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) 
 #define P8_LAUNCH(...) do { static bool set_ = false; \
         if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_p8<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); set_ = true; } \
         hipLaunchKernelGGL((k_igemm_p8<__VA_ARGS__>), dim3(G), dim3(512), LDS_BYTES, stream, a, stagger, svsr_tune_get(SVSR_TUNE_P8_TRACE)); } while (0)
-    if (svsr_tune_get(SVSR_TUNE_P8_TRACE) && a.bnb_x == nullptr) { if (ph == 2) P8_LAUNCH(0, 2, true); else P8_LAUNCH(0, 1, true); }
+    if (bn == 64) { if (a.bnb_x != nullptr) P8_LAUNCH(1, 1, false, 1); else P8_LAUNCH(0, 1, false, 1); }
+    else if (svsr_tune_get(SVSR_TUNE_P8_TRACE) && a.bnb_x == nullptr) { if (ph == 2) P8_LAUNCH(0, 2, true); else P8_LAUNCH(0, 1, true); }
     else if (a.bnb_x != nullptr) { if (ph == 2) P8_LAUNCH(1, 2, false); else P8_LAUNCH(1, 1, false); }
     else { if (ph == 2) P8_LAUNCH(0, 2, false); else P8_LAUNCH(0, 1, false); }
 #undef P8_LAUNCH

@@ -40,8 +40,9 @@ static int g_tune[SVSR_TUNE_N] = {
     /* P8_STAGGER */ 3,        // bit 0: its two wave groups run their phases one barrier apart; bit 1: odd workgroups walk their rounds last to first (their first epilogue falls elsewhere than the even ones')
     /* WG_IMGMAJOR */ 1,       // svsr_igemm_wgrad plans with >= 64 images enumerate rows by (position, block of 64 images): wave-uniform DMA bases (0: row-major)
     /* C64_DEPHASED */ 0,      // experiment: svsr_conv3x3_c64 (plain epilogue) with two wave groups half a period apart — one contracts a chunk while the other drains and fetches; at parity with the lock-step kernel (0)
+    /* P8_BN64 */ 1,           // 3x3 plans with too few 256 x 128 items for one per CU use 256 x 64 tiles of the persistent kernel (layer4); 0: the 4-wave kernel
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased", "p8_bn64"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 

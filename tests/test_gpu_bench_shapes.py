@@ -78,7 +78,7 @@ TRUNK = {
 EXPECT_FWD = {
     "layer2.conv": "k_igemm_p8<256,128,3>",          # the persistent 8-wave kernel (csrc/igemm_p8.hip)
     "layer3.conv": "k_igemm_p8<256,128,3>",
-    "layer4.conv": "k_igemm_fwd_glds<128,64,2>",      # too few 256x128 tiles for it: stays on the 4-wave kernel
+    "layer4.conv": "k_igemm_p8<256,64,3>",            # 132 items of 256 x 128 would leave half the CUs idle: 264 of 256 x 64
 }
 
 
@@ -141,7 +141,7 @@ def test_trunk_conv_fwd_dgrad_wgrad_at_928_frames(dev, name):
 
 def test_benchmark_instantiations_cover_the_big_tiles(dev):
     """The B = 32 shapes must select the tiles bench.py reports: layer2/3 stride-1 3x3 forward and data-gradient on the persistent
-    8-wave kernel (256x128 tiles) — also the stride-2 forward launches that open layer2/3 —, the other stride-2 / 1x1 launches on <128,128,2>, layer4 on <128,64,2>, the generic weight gradient on
+    8-wave kernel (256x128 tiles) — also the stride-2 forward launches that open layer2/3 —, the other stride-2 / 1x1 launches on <128,128,2>, layer4 on its 256x64 tiles, the generic weight gradient on
     128-wide tiles."""
     from syncvsr_amd import ops
 
@@ -150,8 +150,8 @@ def test_benchmark_instantiations_cover_the_big_tiles(dev):
     assert ops.conv_plan(2, N_FRAMES, 6, 6, 256, 3, 1, 1).label == "k_igemm_p8<256,128,3>"
     assert ops.conv_plan(0, N_FRAMES, 11, 11, 256, 3, 2, 1).label == "k_igemm_p8<256,128,3>"            # stride-2 FORWARD: the same tap classes
     assert "p8" not in ops.conv_plan(2, N_FRAMES, 11, 11, 128, 3, 2, 1).label      # its data gradient: parity classes of 1-2 taps, too short
-    assert "p8" not in ops.conv_plan(0, N_FRAMES, 6, 6, 512, 3, 2, 1).label        # layer4.0.conv1: 132 items of 256 x 128, too few
-    assert ops.conv_plan(0, N_FRAMES, 3, 3, 512, 3, 1, 1).label == "k_igemm_fwd_glds<128,64,2>"
+    assert ops.conv_plan(0, N_FRAMES, 6, 6, 512, 3, 2, 1).label == "k_igemm_p8<256,64,3>"       # layer4.0.conv1 forward: 264 items of 256 x 64
+    assert ops.conv_plan(0, N_FRAMES, 3, 3, 512, 3, 1, 1).label == "k_igemm_p8<256,64,3>"
     assert ops.wgrad_conv_plan(N_FRAMES, 6, 6, 256, 256, 3, 1, 1).bc == 128
     assert ops.wgrad_conv_plan(N_FRAMES, 3, 3, 512, 512, 3, 1, 1).bc == 128
 
@@ -240,7 +240,7 @@ EXPECT_DGRAD_BN = {
     "layer3.conv": "k_igemm_p8<256,128,3>",
     "layer3.0.conv1": "k_igemm_fwd_glds<128,128,2>",
     "layer4.0.conv1": "k_igemm_fwd_glds<128,128,2>",
-    "layer4.conv": "k_igemm_fwd_glds<128,64,2>",
+    "layer4.conv": "k_igemm_p8<256,64,3>",
 }
 
 
