@@ -279,6 +279,8 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=150, help="LRS: padded clip length T (lengths are drawn in [0.3 T, T])")
     ap.add_argument("--lrs-steps", type=int, default=8, help="timed steps of the LRS leg attached to the default line")
     ap.add_argument("--no-lrs-leg", action="store_true", help="skip the LRS leg of the default (LRW, one GPU) run")
+    ap.add_argument("--ablate", default="", help="TIMING EXPERIMENTS ONLY (gradients wrong, the line is marked invalid): comma list of conv_wgrad, lin_wgrad — "
+                    "those launches are skipped (how much of the step do they cost?)")
     ap.add_argument("--dropout", type=float, default=0.1, help="LRS: dropout_rate = transformer_attn_dropout_rate (config/lrs3.yaml:20-21)")
     args = ap.parse_args()
     if args.workload == "lrs" and args.batch == 32 and "--batch" not in sys.argv:
@@ -310,6 +312,10 @@ def main() -> None:
     from syncvsr_amd.init import synthetic_batch
     from syncvsr_amd.model import Model
 
+    if args.ablate:
+        import syncvsr_amd.model as _m
+
+        _m._ABLATE = frozenset(filter(None, args.ablate.split(",")))
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         ops.tune(k, int(v))
@@ -382,6 +388,8 @@ def main() -> None:
         "step_mfma_frac": round(clips_per_s / world * TRAIN_FLOP_PER_CLIP / MFMA_PEAK_BF16, 5),
         "final_loss": round(loss, 4),
     }
+    if args.ablate:
+        result["INVALID_ablated"] = sorted(filter(None, args.ablate.split(",")))
     if args.workload == "lrw-xt":
         result["metric"] = "lip-clips/sec training (29x88x88, x-transformers encoder + word boundary)"
         result["config"]["workload"] = ("LRW training step with the shipped yaml's encoder: ResNet18 + 12-layer 513-d x-transformers encoder "

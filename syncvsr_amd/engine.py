@@ -40,6 +40,29 @@ def lrs_train_config(**kw) -> Config:
     return cfg
 
 
+def _rng_state_to_tensor(state) -> torch.Tensor:
+    """random.Random.getstate() = (version, 625 words, gauss_next or None) as an int64 vector
+    [version, 625 words, has_gauss, gauss bits]: plain numbers, nothing a checkpoint reader has to unpickle."""
+    import struct
+
+    version, words, gauss = state
+    if len(words) != 625:
+        raise ValueError("unexpected random.Random state layout")
+    bits = 0 if gauss is None else struct.unpack("<q", struct.pack("<d", float(gauss)))[0]
+    return torch.tensor([int(version), *[int(w) for w in words], 0 if gauss is None else 1, bits], dtype=torch.int64)
+
+
+def _rng_state_from_tensor(t: torch.Tensor):
+    import struct
+
+    if t.dtype != torch.int64 or t.numel() != 628:
+        raise ValueError("layer_rng in this checkpoint is not the int64[628] generator state TrainStep.state_dict writes "
+                         "(pickled states of older checkpoints are refused)")
+    v = [int(x) for x in t.cpu().tolist()]
+    gauss = struct.unpack("<d", struct.pack("<q", v[627]))[0] if v[626] else None
+    return (v[0], tuple(v[1:626]), gauss)
+
+
 class TrainStep:
     """forward + backward + (all-reduce) + clip + AdamW for the LRW model (`TransformerLightningModule`; its step takes
     (videos, audio_tokens, labels, word_mask)) or the LRS model (`lrs_model.E2E`; (x, lengths, audio_tokens, label));
@@ -137,6 +160,7 @@ class TrainStep:
                        self.max_norm, self.warmup, self.total_steps, self.opt_state)
         ops.transpose_shadows(st.flat, st.w16, st.w16t, st.table, st.n_entries)
         st.shadow_fresh = True
+        st.generation += 1
         if trace:
             torch.cuda.nvtx.range_pop()
         if self.is_lrw:
@@ -156,6 +180,7 @@ class TrainStep:
                        self.max_norm, self.warmup, self.total_steps, self.opt_state)
         ops.transpose_shadows(st.flat, st.w16, st.w16t, st.table, st.n_entries)
         st.shadow_fresh = True
+        st.generation += 1
         return out
 
     def _native_step(self, *batch):
@@ -196,6 +221,7 @@ class TrainStep:
         if self.dp is not None:
             self.dp.begin_step()
         self._rec.run()
+        model._store.generation += 1
         return self._out
 
     def step(self, *batch):
@@ -228,6 +254,7 @@ class TrainStep:
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src, non_blocking=True)
         self._graph.replay()
+        self.model._store.generation += 1
         return self._out
 
     def _capture(self, *batch) -> None:
@@ -262,12 +289,10 @@ class TrainStep:
         fp32 vectors in the parameter store's order, and the 16-byte device state {step, -, lr, grad-norm}."""
         sd = {"exp_avg": self.m.detach().clone(), "exp_avg_sq": self.v.detach().clone(), "opt_state": self.opt_state.detach().clone()}
         if hasattr(self.model, "rng_state"):        # dropout seed word + layer-drop generator: a resumed run draws the same masks / skips
-            import pickle
-
             rs = self.model.rng_state()
             sd["dropout_word"] = torch.tensor([rs["dropout_word"]], dtype=torch.int64)
             if "layer_rng" in rs:
-                sd["layer_rng"] = torch.frombuffer(bytearray(pickle.dumps(rs["layer_rng"])), dtype=torch.uint8).clone()
+                sd["layer_rng"] = _rng_state_to_tensor(rs["layer_rng"])
         return sd
 
     def load_state_dict(self, sd: dict[str, torch.Tensor]) -> None:
@@ -277,11 +302,9 @@ class TrainStep:
         self.v.copy_(sd["exp_avg_sq"])
         self.opt_state[:4].copy_(sd["opt_state"][:4])
         if "dropout_word" in sd and hasattr(self.model, "load_rng_state"):
-            import pickle
-
             rs = {"dropout_word": int(sd["dropout_word"].reshape(-1)[0])}
             if "layer_rng" in sd:
-                rs["layer_rng"] = pickle.loads(bytes(sd["layer_rng"].cpu().numpy().tobytes()))
+                rs["layer_rng"] = _rng_state_from_tensor(sd["layer_rng"])
             self.model.load_rng_state(rs)
 
     # -- introspection ------------------------------------------------------------------------------

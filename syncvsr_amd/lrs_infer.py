@@ -107,10 +107,15 @@ class DecoderScorer:
         m = self.model
         D = m.ddim
         c = self._mem
-        same = (c is not None and c["ptr"] == memory.data_ptr() and c["ver"] == memory._version and c["T"] == T and c["stride"] == memory.stride()
+        try:                       # inference tensors (torch.inference_mode) carry no version counter: identity + weights generation decide alone
+            ver = memory._version
+        except RuntimeError:
+            ver = -1
+        gen = getattr(st, "generation", 0)          # bumped by every optimiser step / shadow refresh: cached keys / values follow the weights
+        same = (c is not None and c["ptr"] == memory.data_ptr() and c["ver"] == ver and c["gen"] == gen and c["T"] == T and c["stride"] == memory.stride()
                 and c["base"] is memory._base)
         if not same:
-            c = self._mem = dict(ptr=memory.data_ptr(), ver=memory._version, T=T, stride=memory.stride(), base=memory._base, keep=memory, row=None, by_n={})
+            c = self._mem = dict(ptr=memory.data_ptr(), ver=ver, gen=gen, T=T, stride=memory.stride(), base=memory._base, keep=memory, row=None, by_n={})
         if n in c["by_n"]:
             return c["by_n"][n]
         aliased = n > 1 and memory.stride(0) == 0           # x.unsqueeze(0).expand(n, T, D): every hypothesis attends to the same clip

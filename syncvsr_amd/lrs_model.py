@@ -277,7 +277,8 @@ class E2E(nn.Module):
 
     def reseed_dropout(self, seed: int) -> None:
         self.dropout_seed = int(seed)
-        self._drop_word = None
+        if self._drop_word is not None:          # in place: a captured graph holds this word's address
+            self._drop_word.fill_(self.dropout_seed)
 
     def _d(self, site: str, attn: bool = False):
         """(seed word, site id, p) for ops.*(drop=...) or None when dropout is off (eval mode / p = 0)."""

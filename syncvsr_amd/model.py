@@ -208,7 +208,8 @@ class TransformerLightningModule(nn.Module):
 
     def reseed_dropout(self, seed: int) -> None:
         self.dropout_seed = int(seed)
-        self._drop_word = None
+        if self._drop_word is not None:          # in place: a captured graph / recorded step list holds this word's address
+            self._drop_word.fill_(self.dropout_seed)
         if hasattr(self, "_layer_rng"):          # the layer-drop draws follow the seed too (per-rank / per-run reseeding)
             self._layer_rng.seed(self.dropout_seed)
 
@@ -465,6 +466,7 @@ class _ParamStore:
                     rstd=torch.empty(C, dtype=torch.float32, device=device),
                 )
         self.shadow_fresh = False     # True only while an optimiser that writes the shadows itself owns the step loop
+        self.generation = 0           # counts weight updates (optimiser steps, shadow refreshes): caches derived from the weights key on it
 
     def owns(self, model) -> bool:
         lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * 4
@@ -518,6 +520,7 @@ class _ParamStore:
         return o, o + (numel or n)
 
     def refresh_shadows(self) -> None:
+        self.generation += 1
         ops.cast_bf16(self.flat, self.w16)
         ops.transpose_shadows(self.flat, self.w16, self.w16t, self.table, self.n_entries)
 
@@ -663,7 +666,9 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
     _ready(model, st, None)
 
 
-_ABLATE = os.environ.get("SVSR_ABLATE", "")       # timing experiments only (results wrong): "conv_wgrad", "lin_wgrad" skip those launches
+# Timing experiments only (results WRONG): a probe script may set this to {"conv_wgrad"} / {"lin_wgrad"} to skip those launches.
+# Deliberately not an environment switch: nothing outside an explicit assignment in a probe can turn gradients off.
+_ABLATE: frozenset = frozenset()
 
 
 def _conv_wgrad(model, st: "_ParamStore", conv: str, t: dict, dc: torch.Tensor, use_tr: bool) -> None:

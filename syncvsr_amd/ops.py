@@ -466,6 +466,23 @@ class _WgradProblem(ctypes.Structure):
 WGRAD_GROUP = True      # the encoder's / heads' linear weight gradients of a backward pass in ONE launch (False: one launch each)
 
 
+_WG_TABLES: dict = {}
+
+
+def _group_table(nbytes: int, device) -> torch.Tensor:
+    """Problem table of a grouped launch: one grow-only buffer per (device, stream the launch goes to).  The launch may run on the
+    model's side stream (STREAM_OVERRIDE) while this function's allocations belong to torch's current stream: a tensor made here and
+    dropped on return could be handed to the next main-stream allocation while the side stream still reads it.  In-stream order makes
+    re-use by the next grouped launch on the same stream safe (its table writer runs behind this launch's contraction)."""
+    key = (str(device), _stream())
+    t = _WG_TABLES.get(key)
+    if t is None or t.numel() < nbytes:
+        if t is not None:
+            _SCRATCH_KEEP.append(t)          # a captured graph / recorded step list / pending launch may still hold its address
+        t = _WG_TABLES[key] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+    return t
+
+
 def linear_wgrad_group(problems: Sequence[dict]) -> None:
     """problems: keyword arguments of linear_wgrad calls (x, dy, dw, rows, K, N, x_pitch, dy_pitch, seq, db).  Those whose plan has no K
     split on 64-wide tiles go out as one svsr_igemm_wgrad_group launch; the others (none at the LRW shapes) as launches of their own."""
@@ -487,7 +504,7 @@ def linear_wgrad_group(problems: Sequence[dict]) -> None:
         return
     arr = (_WgradProblem * len(grouped))(*grouped)
     nbytes = int(_lib.load().svsr_igemm_wgrad_group_bytes(len(grouped)))
-    table = torch.empty(nbytes, dtype=torch.uint8, device=problems[0]["x"].device)
+    table = _group_table(nbytes, problems[0]["x"].device)
     flops = sum(2.0 * q["rows"] * q["K"] * q["N"] for q in problems)
     _call("svsr_igemm_wgrad_group", arr, len(grouped), _p(table), nbytes, _stream(), label="k_igemm_wgrad_group<64,3>", flops=flops)
 
