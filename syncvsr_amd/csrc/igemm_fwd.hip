@@ -714,6 +714,7 @@ static IgemmFwdPlan igemm_fwd_plan(long M, int Co, int max_taps) {
     else { pl.bm = 64; pl.bn = 64; pl.ns = 0; }
     pl.gy = (Co + pl.bn - 1) / pl.bn;
     if (pl.ns == 0) pl.ns = ((M + pl.bm - 1) / pl.bm) * pl.gy <= (long)cus * 5 / 2 ? 4 : 3;
+    if (pl.bm == 64 && pl.bn == 64 && (svsr_tune_get(SVSR_TUNE_IGEMM_NS64) == 6 || svsr_tune_get(SVSR_TUNE_IGEMM_NS64) == 8)) pl.ns = svsr_tune_get(SVSR_TUNE_IGEMM_NS64);
     return pl;
 }
 
@@ -990,6 +991,8 @@ static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pr
     SVSR_IGEMM_CASE(128, 64, 3);
     SVSR_IGEMM_CASE(64, 64, 4);
     SVSR_IGEMM_CASE(64, 64, 3);
+    SVSR_IGEMM_CASE(64, 64, 6);
+    SVSR_IGEMM_CASE(64, 64, 8);
 #undef SVSR_IGEMM_CASE
     return SVSR_ERR_ARG;
 }

@@ -79,8 +79,14 @@ __device__ __forceinline__ void wg_wait_tiles_barrier(int later) {
     }
 }
 
+// frag_dst != null (unit-list launches): the workgroup's tile goes out in the MFMA FRAGMENT layout — float4 group
+// g = (((wave * TT + i) * TT + j) * 4 + rq) * 64 + lane holds accumulator registers rq*4 .. rq*4+3 of fragment (i, j) — as 16-byte
+// stores of 1 KiB per wave-instruction (16 per wave and 128 x 128 tile instead of 64 dword stores of two 128-byte rows each); followed by
+// the BC bias sums when BIAS.  k_wgrad_unit_reduce adds a task's partial tiles in slot order and scatters the sum into dW once.
+// unit_begin / unit_count >= 0 replace the (split_idx, chunks_per_split) range.
 template <int BC, int NS, bool BIAS>
-__device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_raw, const int split_idx, const int task_idx) {
+__device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_raw, const int split_idx, const int task_idx,
+                                        float* frag_dst = nullptr, const int unit_begin = -1, const int unit_count = 0) {
     constexpr int T_ELEMS = 64 * BC;                 // one operand tile
     constexpr int S_ELEMS = 2 * T_ELEMS;             // stage = dY tile | X tile
     constexpr int RPI = 1024 / (BC * 2);             // rows per DMA instruction (1 KiB): 4 (BC 128) or 8 (BC 64)
@@ -117,8 +123,8 @@ __device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_
     const bool imgmajor = ((p.plan[0] >> 16) & 1) != 0;
     const int cpp = (p.Nimg + 63) >> 6;
     const int total_chunks = imgmajor ? P * cpp : (Mt + 63) / 64;
-    const int c_begin = split_idx * p.chunks_per_split;
-    int c_end = c_begin + p.chunks_per_split;
+    const int c_begin = unit_begin >= 0 ? unit_begin : split_idx * p.chunks_per_split;
+    int c_end = unit_begin >= 0 ? unit_begin + unit_count : c_begin + p.chunks_per_split;
     if (c_end > total_chunks) c_end = total_chunks;
     const int KT = c_end > c_begin ? c_end - c_begin : 0;
 
@@ -259,6 +265,27 @@ __device__ __forceinline__ void wg_body(const WgradArgs& p, unsigned char* smem_
         }
         buf = buf + 1 == NS ? 0 : buf + 1;
     }
+    if (frag_dst != nullptr) {
+        f32x4* d4 = reinterpret_cast<f32x4*>(frag_dst);
+#pragma unroll
+        for (int i = 0; i < TT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    f32x4 v;
+                    v[0] = acc[i][j][rq * 4 + 0]; v[1] = acc[i][j][rq * 4 + 1]; v[2] = acc[i][j][rq * 4 + 2]; v[3] = acc[i][j][rq * 4 + 3];
+                    d4[(((wave * TT + i) * TT + j) * 4 + rq) * 64 + lane] = v;
+                }
+        if (BIAS && wci == 0 && (lane & 31) == 0) {
+            float* dbd = frag_dst + BC * BC;
+#pragma unroll
+            for (int i = 0; i < TT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dbd[wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = accb[i][r];
+        }
+        return;
+    }
     // D[row = co][col = ci]: one writer per element — slab `blockIdx.x` (plain store) or, without a split, dW itself
     const bool direct = p.splits <= 1;
     float* dst = direct ? p.dw : p.part + (long)split_idx * p.slab;
@@ -331,6 +358,108 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad_group(const WgradGroupEntry
     else wg_body<BC, NS, false>(p, smem_raw, 0, task);
 }
 
+// UNIT-LIST launch (plan format 2): the grid is a host-built list of work units {task, first chunk, chunks, slab slot} of nearly equal
+// length.  The (split, task) grid above gives every tap the split count of the LONGEST tap: on a 3 x 3 map (layer4) the taps have 9 / 6 / 4
+// positions, so a third of the workgroups ran 45 chunks while the rest ran 15 or none — the launch lasted twice its mean.  Here a task of L
+// chunks is cut into round(L / target) units, tiles leave in fragment layout (above) and one reduce launch sums each task's slots.
+// Unit words: {task, chunk_begin, chunk_count, slot (-1: the task's only unit adds to dW directly)}.
+#define WUNIT_WORDS 4
+struct WgradUnitArgs { WgradArgs a; const int* units; long tile_stride; };
+
+template <int BC, int NS>
+__device__ __forceinline__ void wg_unit(const WgradArgs& p, const int* __restrict__ u, long tile_stride, unsigned char* smem_raw) {
+    const int task = u[0], cb = u[1], cn = u[2], slot = u[3];
+    const int co_tiles = (p.Co + BC - 1) / BC, ci_tiles = (p.Ci + BC - 1) / BC;
+    const int rest = task / co_tiles;
+    float* dst = slot >= 0 ? p.part + (long)slot * tile_stride : nullptr;
+    if (p.db != nullptr && rest % ci_tiles == 0 && rest / ci_tiles == 0) wg_body<BC, NS, true>(p, smem_raw, 0, task, dst, cb, cn);
+    else wg_body<BC, NS, false>(p, smem_raw, 0, task, dst, cb, cn);
+}
+
+template <int BC, int NS>
+__global__ __launch_bounds__(256) void k_igemm_wgrad_units(const WgradUnitArgs q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    wg_unit<BC, NS>(q.a, q.units + (long)blockIdx.x * WUNIT_WORDS, q.tile_stride, smem_raw);
+}
+
+// several unit-list problems (the convolutions of a ResNet layer) in ONE launch: entry i owns blocks [unit_begin_i, unit_begin_{i+1})
+struct WgradMultiEntry { WgradArgs a; const int* units; long tile_stride; int unit_begin; int pad_; };
+constexpr int WG_MULTI_CHUNK = 16;
+struct WgradMultiChunk { WgradMultiEntry e[WG_MULTI_CHUNK]; };
+static_assert(sizeof(WgradMultiEntry) % 8 == 0 && sizeof(WgradMultiChunk) <= 3584, "a chunk travels in the kernel-argument segment");
+
+__global__ __launch_bounds__(256) void k_wgrad_multi_table(const WgradMultiChunk c, int words, long long* __restrict__ dst) {
+    const long long* src = reinterpret_cast<const long long*>(&c);
+    for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+}
+
+template <int BC, int NS>
+__global__ __launch_bounds__(256) void k_igemm_wgrad_multi(const WgradMultiEntry* __restrict__ table, int n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int idx = 0;
+    for (int i = 1; i < n; ++i)
+        if ((int)blockIdx.x >= table[i].unit_begin) idx = i;
+    const WgradArgs p = table[idx].a;
+    wg_unit<BC, NS>(p, table[idx].units + (long)((int)blockIdx.x - table[idx].unit_begin) * WUNIT_WORDS, table[idx].tile_stride, smem_raw);
+}
+
+// dW[co][tw][ci] += sum over a task's slots (in slot order) of its partial tiles; db likewise.  Task words: {slot_begin, slots}.
+// grid (BC*BC/4/64 (+1 for the bias row), tasks); a thread owns one float4 group of the fragment layout and one of four slot lanes.
+struct WgradReduceArgs {
+    const float* part; float* dw; float* db; const int* plan; const int* tasktab;
+    long tile_stride; int Co, Ci, wt_taps, co_tiles, ci_tiles;
+};
+
+// Block = 64 float4 groups x 4 slot lanes: lane sl adds slots sl, sl + 4, ... in increasing order (two loads in flight), the four lane
+// sums are added in lane order — a fixed association, and a task with a hundred slots (the 1 x 1 convolutions: two tasks, K split 200
+// ways) is not one thread's chain of a hundred dependent round trips.
+template <int BC>
+__global__ __launch_bounds__(256) void k_wgrad_unit_reduce(const WgradReduceArgs q) {
+    constexpr int TT = BC / 64, WT = BC / 2, GB = BC * BC / 4 / 64;       // GB: blocks of 64 groups per tile
+    __shared__ f32x4 sred[4][64];
+    const int task = blockIdx.y, blk = blockIdx.x;
+    const int s0 = q.tasktab[2 * task], ns = q.tasktab[2 * task + 1];
+    if (ns <= 0) return;                                // (a task whose single unit wrote dW itself)
+    int rest = task;
+    const int cot = rest % q.co_tiles; rest /= q.co_tiles;
+    const int cit = rest % q.ci_tiles; rest /= q.ci_tiles;
+    const int tw = q.plan[WPLAN_HDR + rest * WPLAN_TAP_WORDS + 2];
+    const float* src = q.part + (long)s0 * q.tile_stride;
+    if (blk == GB) {                                    // the bias sums of this task's column tile (tasks of ci tile 0 / tap 0 only)
+        if (q.db == nullptr || cit != 0 || rest != 0) return;
+        for (int c = threadIdx.x; c < BC; c += 256) {
+            float a = 0.f;
+            for (int s = 0; s < ns; ++s) a += src[(long)s * q.tile_stride + BC * BC + c];
+            if (cot * BC + c < q.Co) q.db[cot * BC + c] += a;
+        }
+        return;
+    }
+    const int gl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int g = blk * 64 + gl;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    int s = sl;
+    for (; s + 4 < ns; s += 8) {
+        const f32x4 v0 = reinterpret_cast<const f32x4*>(src + (long)s * q.tile_stride)[g];
+        const f32x4 v1 = reinterpret_cast<const f32x4*>(src + (long)(s + 4) * q.tile_stride)[g];
+        a = (a + v0) + v1;
+    }
+    for (; s < ns; s += 4) a = a + reinterpret_cast<const f32x4*>(src + (long)s * q.tile_stride)[g];
+    sred[sl][gl] = a;
+    __syncthreads();
+    if (sl != 0) return;
+    a = ((sred[0][gl] + sred[1][gl]) + sred[2][gl]) + sred[3][gl];
+    const int lane = g & 63, rq = (g >> 6) & 3, fj = (g >> 8) % TT, fi = (g >> 8) / TT % TT, wave = (g >> 8) / (TT * TT);
+    const int ci = cit * BC + (wave & 1) * WT + fj * 32 + (lane & 31);
+    const int co = cot * BC + (wave >> 1) * WT + fi * 32 + 8 * rq + 4 * (lane >> 5);
+    if (ci >= q.Ci) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (co + k < q.Co) {
+            float* d = q.dw + ((long)(co + k) * q.wt_taps + tw) * q.Ci + ci;
+            *d += a[k];
+        }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 struct WgradLaunch { int bc, ns, splits, chunks_per_split, tasks; long slab; };
 
@@ -370,7 +499,60 @@ static WgradLaunch wgrad_launch(long total_chunks_l, int Co, int Ci, int ntaps, 
     return pl;
 }
 
+// Unit list of a plan (format 2): tasks in index order (tap, ci tile, co tile), a task of L chunks cut into n = ceil(L / U) units of
+// floor / ceil(L / n) chunks, U the smallest unit length that keeps the number of units within `rounds` full rounds of resident
+// workgroups (a grid a little above a round runs an almost empty extra round: layer4's 576 workgroups on 512 slots took 1.4x longer).
+struct WgradUnits { std::vector<int> units, tasktab; int slots = 0; };
+
+static WgradUnits wgrad_units(const std::vector<long>& tap_chunks, int co_tiles, int ci_tiles, int bc) {
+    static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+    const int target_env = svsr_tune_get(SVSR_TUNE_WG_BLOCKS);
+    const long resident = target_env > 0 ? target_env : (long)cus * (bc == 128 ? 2 : 3);
+    const int umax = svsr_tune_get(SVSR_TUNE_WG_UNIT_MAX) > 0 ? svsr_tune_get(SVSR_TUNE_WG_UNIT_MAX) : 48;
+    const int umin = svsr_tune_get(SVSR_TUNE_WG_UNIT_MIN) > 0 ? svsr_tune_get(SVSR_TUNE_WG_UNIT_MIN) : 8;
+    const int tiles = co_tiles * ci_tiles;
+    long total = 0, longest = 0;
+    for (long L : tap_chunks) { total += L * tiles; if (L > longest) longest = L; }
+    long rounds = (total + resident * umax - 1) / (resident * umax);
+    if (rounds < 1) rounds = 1;
+    long U = (total + resident * rounds - 1) / (resident * rounds);
+    if (U < umin) U = umin;
+    for (;; ++U) {
+        long n = 0;
+        for (long L : tap_chunks) n += ((L + U - 1) / U) * tiles;
+        if (n <= resident * rounds || U >= longest) break;
+    }
+    WgradUnits w;
+    const int ntaps = (int)tap_chunks.size();
+    w.tasktab.assign((size_t)2 * ntaps * tiles, 0);
+    for (int t = 0; t < ntaps; ++t) {
+        const long L = tap_chunks[t];
+        const int n = (int)((L + U - 1) / U);
+        for (int tile = 0; tile < tiles; ++tile) {
+            const int task = t * tiles + tile;         // == (t * ci_tiles + cit) * co_tiles + cot
+            if (n > 1) { w.tasktab[2 * task] = w.slots; w.tasktab[2 * task + 1] = n; }
+            long c = 0;
+            for (int k = 0; k < n; ++k) {
+                const long len = L / n + (k < L % n ? 1 : 0);
+                w.units.push_back(task); w.units.push_back((int)c); w.units.push_back((int)len); w.units.push_back(n > 1 ? w.slots++ : -1);
+                c += len;
+            }
+        }
+    }
+    // long units first: the dispatcher hands workgroups out in index order, the short ones fill the tail of the round
+    const int nu = (int)(w.units.size() / WUNIT_WORDS);
+    std::vector<int> order(nu);
+    for (int i = 0; i < nu; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return w.units[a * WUNIT_WORDS + 2] > w.units[b * WUNIT_WORDS + 2]; });
+    std::vector<int> sorted((size_t)nu * WUNIT_WORDS);
+    for (int i = 0; i < nu; ++i) std::copy(w.units.begin() + order[i] * WUNIT_WORDS, w.units.begin() + (order[i] + 1) * WUNIT_WORDS, sorted.begin() + i * WUNIT_WORDS);
+    w.units.swap(sorted);
+    return w;
+}
+
 // meta: {tile edge, ring depth, K splits, chunks per split, tasks, taps, max positions of a tap, 0}
+// format 2 (unit list; meta[7] > 0): {tile edge, ring depth, slab slots, units, tasks, taps, max positions, word offset of the unit table};
+// the task table {first slot, slots} x tasks follows the units.
 static int wplan_emit(const std::vector<std::vector<int>>& taps_pos, const std::vector<int>& tws, int Nimg, int Co, int Ci, int wt_taps,
                       int has_bias, int* words, int cap_words, int* meta, int64_t* part_floats) {
     const int ntaps = (int)taps_pos.size();
@@ -382,8 +564,22 @@ static int wplan_emit(const std::vector<std::vector<int>>& taps_pos, const std::
     const bool im = wgrad_imgmajor(Nimg);
     const long chunks = im ? maxP * (long)((Nimg + 63) / 64) : ((long)Nimg * maxP + 63) / 64;
     const WgradLaunch pl = wgrad_launch(chunks, Co, Ci, ntaps, wt_taps, has_bias != 0);
+    // unit lists for the long contractions (the short ones — LRW's 960-row linears — have no K split to balance and ride the grouped launch)
+    const bool use_units = svsr_tune_get(SVSR_TUNE_WG_UNITS) != 0 && chunks > svsr_tune_get(SVSR_TUNE_WG_SHORT_K);
+    WgradUnits wu;
+    const int units_word0 = nwords;
+    if (use_units) {
+        std::vector<long> tap_chunks;
+        for (const auto& v : taps_pos) { const long P = (long)v.size() / 2; tap_chunks.push_back(im ? P * (long)((Nimg + 63) / 64) : ((long)Nimg * P + 63) / 64); }
+        wu = wgrad_units(tap_chunks, (Co + pl.bc - 1) / pl.bc, (Ci + pl.bc - 1) / pl.bc, pl.bc);
+        nwords += (int)wu.units.size() + (int)wu.tasktab.size();
+    }
     if (words != nullptr) {
         if (cap_words < nwords) return -SVSR_ERR_ARG;
+        if (use_units) {
+            std::copy(wu.units.begin(), wu.units.end(), words + units_word0);
+            std::copy(wu.tasktab.begin(), wu.tasktab.end(), words + units_word0 + wu.units.size());
+        }
         words[0] = ntaps | ((im ? 1 : 0) << 16); words[1] = pos_word0;
         int pos_off = 0;
         for (int t = 0; t < ntaps; ++t) {
@@ -397,8 +593,12 @@ static int wplan_emit(const std::vector<std::vector<int>>& taps_pos, const std::
     if (meta != nullptr) {
         meta[0] = pl.bc; meta[1] = pl.ns; meta[2] = pl.splits; meta[3] = pl.chunks_per_split; meta[4] = pl.tasks; meta[5] = ntaps;
         meta[6] = (int)maxP; meta[7] = 0;
+        if (use_units) { meta[2] = wu.slots; meta[3] = (int)(wu.units.size() / WUNIT_WORDS); meta[7] = units_word0; }
     }
-    if (part_floats != nullptr) *part_floats = pl.splits > 1 ? (int64_t)pl.splits * pl.slab : 0;
+    if (part_floats != nullptr) {
+        *part_floats = pl.splits > 1 ? (int64_t)pl.splits * pl.slab : 0;
+        if (use_units) *part_floats = (int64_t)wu.slots * ((int64_t)pl.bc * pl.bc + (has_bias ? pl.bc : 0));
+    }
     return nwords;
 }
 
@@ -412,6 +612,34 @@ static int launch_wgrad(const WgradArgs& a, int tasks, int maxP, hipStream_t str
     }
     const size_t lds = (size_t)NS * 2 * 64 * BC * sizeof(bf16_t) + (((size_t)maxP * 2 * sizeof(int) + 127) & ~(size_t)127);
     hipLaunchKernelGGL((k_igemm_wgrad<BC, NS>), dim3(a.splits, tasks), dim3(256), lds, stream, a);
+    return svsr_check_launch();
+}
+
+template <int BC, int NS>
+static int launch_wgrad_units(const WgradArgs& a, const int* plan_dev, const int* meta, hipStream_t stream) {
+    const int slots = meta[2], n_units = meta[3], tasks = meta[4], maxP = meta[6];
+    WgradUnitArgs q;
+    q.a = a; q.a.splits = 1;
+    q.units = plan_dev + meta[7];
+    q.tile_stride = (long)BC * BC + (a.db != nullptr ? BC : 0);
+    if (n_units > 0) {
+        const size_t lds_max = (size_t)NS * 2 * 64 * BC * sizeof(bf16_t) + (size_t)WG_MAXP * 2 * sizeof(int);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_wgrad_units<BC, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+            attr_set = true;
+        }
+        const size_t lds = (size_t)NS * 2 * 64 * BC * sizeof(bf16_t) + (((size_t)maxP * 2 * sizeof(int) + 127) & ~(size_t)127);
+        hipLaunchKernelGGL((k_igemm_wgrad_units<BC, NS>), dim3(n_units), dim3(256), lds, stream, q);
+        const int rc = svsr_check_launch();
+        if (rc != SVSR_OK) return rc;
+    }
+    if (slots <= 0) return SVSR_OK;
+    WgradReduceArgs r;
+    r.part = a.part; r.dw = a.dw; r.db = a.db; r.plan = plan_dev; r.tasktab = plan_dev + meta[7] + n_units * WUNIT_WORDS;
+    r.tile_stride = q.tile_stride; r.Co = a.Co; r.Ci = a.Ci; r.wt_taps = a.wt_taps;
+    r.co_tiles = (a.Co + BC - 1) / BC; r.ci_tiles = (a.Ci + BC - 1) / BC;
+    hipLaunchKernelGGL((k_wgrad_unit_reduce<BC>), dim3(BC * BC / 256 + (a.db != nullptr ? 1 : 0), tasks), dim3(256), 0, stream, r);
     return svsr_check_launch();
 }
 
@@ -469,8 +697,15 @@ int svsr_igemm_wgrad(const void* x, const void* dyp, float* dw, float* dbias, co
     a.splits = meta[2]; a.chunks_per_split = meta[3];
     a.slab = (long)Co * wt_taps * Ci + (dbias != nullptr ? Co : 0);
     a.Nimg = Nimg; a.in_pix = in_pix; a.Ci = Ci; a.in_pitch = in_pitch; a.Co = Co; a.out_pix = out_pix; a.out_pitch = out_pitch; a.wt_taps = wt_taps;
-    if (a.splits > 1 && (part == nullptr || part_floats < (int64_t)a.splits * a.slab)) return SVSR_ERR_ARG;
     const int bc = meta[0], ns = meta[1], tasks = meta[4], maxP = meta[6];
+    if (meta[7] > 0) {          // unit-list plan
+        const int64_t need = (int64_t)meta[2] * ((int64_t)bc * bc + (dbias != nullptr ? bc : 0));
+        if (meta[2] > 0 && (part == nullptr || part_floats < need)) return SVSR_ERR_ARG;
+        if (bc == 128 && ns == 2) return launch_wgrad_units<128, 2>(a, plan_dev, meta, stream);
+        if (bc == 64 && ns == 3) return launch_wgrad_units<64, 3>(a, plan_dev, meta, stream);
+        return SVSR_ERR_ARG;
+    }
+    if (a.splits > 1 && (part == nullptr || part_floats < (int64_t)a.splits * a.slab)) return SVSR_ERR_ARG;
     int rc;
     if (bc == 128 && ns == 2) rc = launch_wgrad<128, 2>(a, tasks, maxP, stream);
     else if (bc == 64 && ns == 3) rc = launch_wgrad<64, 3>(a, tasks, maxP, stream);

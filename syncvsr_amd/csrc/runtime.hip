@@ -41,8 +41,12 @@ static int g_tune[SVSR_TUNE_N] = {
     /* WG_IMGMAJOR */ 1,       // svsr_igemm_wgrad plans with >= 64 images enumerate rows by (position, block of 64 images): wave-uniform DMA bases (0: row-major)
     /* C64_DEPHASED */ 0,      // experiment: svsr_conv3x3_c64 (plain epilogue) with two wave groups half a period apart — one contracts a chunk while the other drains and fetches; at parity with the lock-step kernel (0)
     /* P8_BN64 */ 1,           // 3x3 plans with too few 256 x 128 items for one per CU use 256 x 64 tiles of the persistent kernel (layer4); 0: the 4-wave kernel
+    /* IGEMM_NS64 */ 0,        // ring depth of the 64x64 tiles of svsr_igemm_fwd: 0 auto (3 / 4), or 6 / 8
+    /* WG_UNITS */ 1,          // svsr_igemm_wgrad plans of long contractions as balanced unit lists (format 2); 0: (K split, task) grids
+    /* WG_UNIT_MAX */ 48,      // ... longest unit in 64-row chunks before the list takes a further round of workgroups
+    /* WG_UNIT_MIN */ 8,       // ... shortest unit worth a slab tile of its own
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased", "p8_bn64"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 

@@ -689,6 +689,9 @@ def _lin_wgrad(model, x, dy, gw, gb, rows: int, K: int, N: int, x_pitch: int, dy
     model._side.run(lambda: ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=x_pitch, dy_pitch=dy_pitch, db=gb), x, dy, small=True)
 
 
+WG_GROUP_LAYERS = int(os.environ.get("SVSR_WG_GROUP_LAYERS", "1"))      # encoder layers per grouped weight-gradient launch (0: one launch for the whole encoder)
+
+
 def _flush_lin_wgrads(model) -> None:
     """The collected linear weight gradients of this backward pass as one launch (ops.linear_wgrad_group), on the side stream when
     the trunk's weight gradients go there: nothing downstream reads them before the optimiser."""
@@ -773,8 +776,14 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
         dx = ops.linear_dgrad(dqkv, st.t16(f"{p}.qkv"), rows=R, N=3 * D, K=D, dy_pitch=3 * D, addend=ds1)
         if getattr(model, "_wg_group", None) is None:
             _ready(model, st, f"{p}.attention.self.query.weight")
+        elif WG_GROUP_LAYERS > 0 and (model.layers - i) % WG_GROUP_LAYERS == 0 and i > 0:
+            # the weight gradients collected so far as one launch on the side stream NOW: the encoder's backward is a chain of small
+            # launches that leaves most of the chip idle, while a single launch at its end competes with the trunk's backward
+            _flush_lin_wgrads(model)
+            model._wg_group = []
+            _ready(model, st, f"{p}.attention.self.query.weight")
     if getattr(model, "_wg_group", None) is not None:
-        # every linear weight gradient of the encoder and the heads in one launch; their flat-buffer range is final from here
+        # the remaining linear weight gradients of the encoder (and the heads) in one launch; their flat-buffer range is final from here
         _flush_lin_wgrads(model)
         _ready(model, st, "encoder.encoder.layer.0.attention.self.query.weight")
     te = tape["emb"]
