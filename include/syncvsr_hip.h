@@ -39,6 +39,19 @@ typedef struct svsr_wgrad_problem {
     int Nimg; int in_pix; int Ci; int in_pitch; int Co; int out_pix; int out_pitch; int wt_taps;
 } svsr_wgrad_problem;
 
+/* one encoder layer of svsr_enc_fwd: DEVICE pointers.  Weights: the bf16 shadows [out][in] of query|key|value (adjacent: [1536][512]),
+ * attention.output.dense [512][512], intermediate.dense [2048][512], output.dense [512][2048]; biases and LayerNorm parameters fp32.
+ * Written by the launch (what the backward reads): qkv bf16 [R][1536], probs bf16 [B*8][S][ldp = ceil8(S)], ctx / ao / x1 / f / xout bf16
+ * [R][512], z / hg bf16 [R][2048], LayerNorm statistics m1 r1 m2 r2 fp32 [R].  site_*: dropout sites of the attention probabilities,
+ * BertSelfOutput's and BertOutput's dropout. */
+typedef struct svsr_enc_layer {
+    const void* wqkv; const void* wo; const void* w1; const void* w2;
+    const float* bqkv; const float* bo; const float* b1; const float* b2; const float* g1; const float* be1; const float* g2; const float* be2;
+    void* qkv; void* probs; void* ctx; void* ao; void* x1; void* z; void* hg; void* f; void* xout;
+    float* m1; float* r1; float* m2; float* r2;
+    unsigned site_probs; unsigned site_ao; unsigned site_fo; unsigned pad_;
+} svsr_enc_layer;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -280,6 +293,20 @@ int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream);
 /* scalars on the device, so that a step never depends on a host value: *word += delta (the dropout seed word, advanced once per
  * training forward: lightning.py:150 draws fresh masks every step);  *out = *a + wb * *b  (loss_total = loss_category +
  * lambda_audio * loss_audio, lightning.py:187). */
+/* ---- fused encoder forward (enc_fused.hip) -----------------------------------------------------------------------
+ * svsr_enc_fwd replaces the forward of `n_layers` (<= 8 per call) consecutive HF BertLayers of the word-level model's encoder
+ * (reference LRW/video/src/lightning.py:92,152-156: BertSelfAttention, BertSelfOutput, BertIntermediate, BertOutput) for width 512,
+ * 8 heads of 64, FFN 2048 and sequences of S <= 32 rows: ONE launch per 32 sequences instead of seven per layer.  Eight workgroups
+ * per sequence (one per head / column eighth) exchange ctx, ao, hg and f through memory between arrival counters (write-through
+ * stores, relaxed agent-scope counter, L1-bypassing loads; all eight must be resident together, which the 32-sequence launches
+ * guarantee on 256 CUs).  x0 bf16 [B*S][512]; `layers`: HOST array of records (copied by value into the launch); every tensor a
+ * layer writes has the contents the unfused launches (svsr_igemm_fwd, svsr_mha_fwd, svsr_add_ln_fwd) give it, dropout masks included.
+ * ws: svsr_enc_fwd_ws_bytes(B) bytes of device workspace (arrival counters, zeroed here; word B = error flag, non-zero if a bounded
+ * wait gave up; the layer records). */
+int64_t svsr_enc_fwd_ws_bytes(int B);
+int svsr_debug_enc_trace(int64_t* out, int n);     /* debug: out == null arms s_memtime stamps of workgroup 0 at the phase boundaries of the next launches; else copies n stamps out */
+int svsr_enc_fwd(const void* x0, const svsr_enc_layer* layers, int n_layers, int B, int S, float ln_eps, const unsigned* drop_seed, float p_hidden, float p_attn, void* ws, int64_t ws_bytes, hipStream_t stream);
+
 int svsr_word_add(int* word, int delta, hipStream_t stream);
 int svsr_lincomb2(const float* a, const float* b, float wb, float* out, hipStream_t stream);
 

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd(const bf16_t* __restrict__ a
         for (int i = 0; i < LN_MAXV; ++i)
             if ((i * 64 + lane) * 8 < D)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
+                for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q = __builtin_fmaf(d, d, q); }      // (explicit: csrc/enc_fused.hip repeats this arithmetic bit for bit)
         const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_add_ln_fwd(const bf16_t* __restrict__ a
                 const int c0 = (i * 64 + lane) * 8;
                 float o[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = (v[i][k] - mu) * rs * gamma[c0 + k] + beta[c0 + k];
+                for (int k = 0; k < 8; ++k) o[k] = __builtin_fmaf((v[i][k] - mu) * rs, gamma[c0 + k], beta[c0 + k]);
                 reinterpret_cast<u32x4*>(y)[((long)row * D + c0) >> 3] = pack8(o);
             }
         }

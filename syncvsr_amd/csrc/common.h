@@ -38,13 +38,19 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f
 // |error| <= 1.5e-7 — three decimal orders below bf16 resolution); evaluated on |x| and mirrored, so the negative tail has
 // no 1 - erf cancellation.  ~15 VALU ops (v_rcp_f32 + v_exp_f32) instead of libdevice erff's ~45: the stem's
 // BatchNorm+GELU+pool passes were VALU-bound on erff, not HBM-bound.
+// (every multiply-add spelled out: the same source inlined into two kernels must round the same way — under -ffp-contract=fast the
+// compiler otherwise picks its own contractions per call site, and csrc/enc_fused.hip is tested bit for bit against the launch chain)
 __device__ __forceinline__ void normal_cdf_exp(float x, float& cdf, float& ex) {
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    ex = __expf(-z * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 0.5f * poly * ex;
-    cdf = x >= 0.f ? 1.0f - e : e;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    ex = __expf(-(z * z));
+    float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    poly = __builtin_fmaf(t, poly, 1.421413741f);
+    poly = __builtin_fmaf(t, poly, -0.284496736f);
+    poly = __builtin_fmaf(t, poly, 0.254829592f);
+    const float hp = 0.5f * (t * poly);
+    const float e = hp * ex;
+    cdf = x >= 0.f ? __builtin_fmaf(-hp, ex, 1.0f) : e;      // (1 - e as ONE explicit fma: left to the compiler it is contracted in some call sites only)
 }
 __device__ __forceinline__ float gelu_erf(float x) {
     float cdf, ex;
@@ -55,7 +61,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     // d/dx [x * Phi(x)] = Phi(x) + x * phi(x),  phi(x) = exp(-x^2/2) / sqrt(2 pi)
     float cdf, ex;
     normal_cdf_exp(x, cdf, ex);
-    return cdf + x * 0.39894228040143267794f * ex;
+    return __builtin_fmaf(x * 0.39894228040143267794f, ex, cdf);
 }
 
 // Swish / SiLU (LRS front-end and Conformer convolution module: transformer/convolution.py:78-83)
@@ -82,15 +88,36 @@ __device__ __forceinline__ unsigned svsr_mix(unsigned h) {
 __device__ __forceinline__ unsigned drop_key(const DropArgs& d) { return svsr_mix(d.seed[0] * 0x9E3779B9u + d.site * 0x7F4A7C15u + 0x165667B1u); }
 __device__ __forceinline__ bool drop_keep(unsigned key, unsigned thresh, unsigned idx) { return svsr_mix(idx * 2654435761u + key) >= thresh; }
 
+// 64-lane all-reduce without LDS-crossbar permutes where the ISA offers a cheaper path (a ds_bpermute butterfly costs ~55 cycles a step in a
+// dependent chain: the LayerNorm of eight rows in csrc/enc_fused.hip spent 5,300 cycles in 96 of them): DPP quad permutes (partners
+// l^1, l^2), row_half_mirror and row_mirror (the quads / octets already hold equal values, so l <-> 7-l and l <-> 15-l pair the same groups
+// as l^4 and l^8), ds_swizzle for l^16 and v_permlane32_swap for l^32.  Every lane ends with the same bits; the association is
+// ((((pairs) quads) octets) rows) halves — fixed, whatever the launch.
+__device__ __forceinline__ float dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_half_mirror(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_mirror(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_ror8(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true)); }
+__device__ __forceinline__ float swz_xor16(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); }
+__device__ __forceinline__ float swz_lane0_of_32(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x0000)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_xor1(v);
+    v += dpp_xor2(v);
+    v += dpp_half_mirror(v);
+    v += dpp_mirror(v);
+    v += swz_xor16(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);      // {lower half's value, upper half's value} in every lane
+    return __int_as_float(r[0]) + __int_as_float(r[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_xor1(v));
+    v = fmaxf(v, dpp_xor2(v));
+    v = fmaxf(v, dpp_half_mirror(v));
+    v = fmaxf(v, dpp_mirror(v));
+    v = fmaxf(v, swz_xor16(v));
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return fmaxf(__int_as_float(r[0]), __int_as_float(r[1]));
 }
 
 // 16-byte vector of 8 bf16 as 4 dwords

@@ -1,0 +1,696 @@
+// Fused forward of the 512-wide HF-BERT encoder layers (gfx950): ALL layers of the encoder in ONE launch.
+//
+// Replaces, for the word-level model's `type: huggingface` encoder (reference LRW/video/src/lightning.py:92,152-156 -> HF
+// BertLayer: BertSelfAttention, BertSelfOutput, BertIntermediate, BertOutput), the chain of seven launches per layer
+// (qkv GEMM, attention, output GEMM, add+LayerNorm, GELU GEMM, output GEMM, add+LayerNorm).  At 960 rows that chain is pure
+// latency: 42 launches of 5-15 us for 36 GFLOP, with the chip almost idle.
+//
+// Rows of different sequences never meet inside an encoder layer, so a sequence (S <= 32 rows) is an independent pipeline through
+// all layers.  A CLUSTER of H = 8 workgroups owns one sequence; workgroup h of the cluster owns head h and the h-th eighth of the
+// columns of every GEMM of the layer:
+//   P1  q_h | k_h | v_h = X W_qkv[h]^T (+bias) -> qkv;  S = q k^T / 8, softmax -> probs;  ctx_h = dropout(P) v      (no exchange)
+//   P2  ao[:, h] = dropout(ctx W_o[h]^T + b)                                   needs every head's ctx      -> cluster barrier 1
+//   P3  x1 = LN(ao + X) (every workgroup, redundantly);  z_h = x1 W_1[h]^T + b, hg_h = gelu(z_h)           -> cluster barrier 2
+//   P4  f[:, h] = dropout(hg W_2[h]^T + b)                                      needs all of hg             -> cluster barrier 3
+//   P5  X' = LN(f + x1) (redundantly) = the next layer's input                                             -> cluster barrier 4
+// The activations a layer keeps for the backward (qkv, probs, ctx, ao, x1, z, hg, f, X', LayerNorm statistics) are written exactly
+// where the unfused path writes them, with the same arithmetic (bf16 rounding points, dropout element indices, LayerNorm in fp32
+// with one wave per row), so the hand-written backward and the parity tests are unchanged.
+//
+// Exchange between the workgroups of a cluster follows the placement-independent recipe of the programming guide (section 6,
+// guideline 16): payload written with write-through (sc1) stores, every storing wave drains its stores, ONE lane bumps the
+// cluster's arrival counter with a relaxed agent-scope atomic; consumers poll that one word (relaxed, with s_sleep) and read the
+// payload with sc1 loads (LDS-DMA with the sc1 bit for GEMM operands).  Counters are zeroed by a memset node in front of the launch
+// and count monotonically through the 4 x layers barriers of a launch; spins are bounded (the error word is set and the launch
+// finishes with garbage instead of hanging).  Weights are read-only and stream through a 3-deep LDS ring by LDS-DMA.
+// Grid: 8 workgroups per sequence, all of which must be resident together: at most 32 sequences per launch (256 CUs); the host
+// splits larger batches into several launches (sequences are independent).
+#include <string.h>
+
+#include "common.h"
+#include "../../include/syncvsr_hip.h"
+
+namespace {
+
+constexpr int ED = 512, EH = 8, EI = 2048, TR = 32;            // width, heads (= workgroups per cluster), FFN width, rows per tile
+constexpr int IH = EI / EH;                                    // FFN1 columns per workgroup
+#define EF_SWZ(row, chunk) ((row) * 64 + (((chunk) ^ (((row) >> 1) & 7)) << 3))       // [rows][64 k] bf16 block, 16-byte chunks XOR-swizzled
+
+// LDS map (bytes): the A operand with the whole K = 512 resident (also attention scratch and epilogue staging) + a 4-deep ring of 32 KiB
+// slots (three tiles = 96 KiB in flight: the weight stream is bound by bytes in flight / L2 latency, ~55 GB/s per CU with two)
+constexpr int BUFA = 0;                         // bf16 [8 kb][32][64] (32 KiB)
+constexpr int RING = 32768;
+constexpr int SLOT = 32768, NSLOT = 4;
+constexpr int LDS_TOTAL = RING + NSLOT * SLOT;  // 160 KiB
+static_assert(LDS_TOTAL <= 160 * 1024, "one workgroup per CU");
+
+struct EncArgs {
+    const bf16_t* x0;            // [R][512] input of the first layer
+    const svsr_enc_layer* Ls;    // DEVICE copy of the layer records (a kernel-argument array indexed with a run-time value would be moved to scratch)
+    int layers, S, seq0, nseq;   // sequences seq0 .. seq0 + nseq - 1 of the batch
+    float eps;
+    const unsigned* seed; unsigned th_hidden, th_attn; float sc_hidden, sc_attn;
+    unsigned* cnt;               // [nseq] arrival counters (zero at launch)
+    unsigned* err;               // set to 1 when a bounded spin gave up
+    unsigned long long* trace;   // debug (svsr_debug_enc_trace): s_memtime stamps of workgroup 0 at the phase boundaries, or null
+};
+
+__device__ __forceinline__ void glds16(const void* src, void* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+__device__ __forceinline__ void glds16_sc1(const void* src, void* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 16);
+}
+// 16 bytes of exchanged payload: write-through stores / L1-bypassing loads (two 8-byte relaxed agent-scope accesses each)
+__device__ __forceinline__ void st16_sc1(bf16_t* p, const u32x4& v) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    __hip_atomic_store(q, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, ((unsigned long long)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u32x4 ld16_sc1(const bf16_t* p) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u32x4 v; v.x = (unsigned)a; v.y = (unsigned)(a >> 32); v.z = (unsigned)b; v.w = (unsigned)(b >> 32);
+    return v;
+}
+
+#define EF_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define EF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// arrival: every wave's payload stores have left (write-through), then one lane counts the workgroup in
+__device__ __forceinline__ void cluster_signal(unsigned* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (the same when weight tiles of the next phase are already in flight: vmcnt(0) waits for them too — the price of one counter for loads and stores)
+__device__ __forceinline__ void cluster_signal_keep_dma(unsigned* cnt) { cluster_signal(cnt); }
+__device__ __forceinline__ void cluster_wait(unsigned* cnt, unsigned target, unsigned* err) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 20)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const bf16_t* blk, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(blk + EF_SWZ(row, chunk));
+}
+
+// eight rows of 512 columns per wave (lane owns columns lane*8 .. +7 of each): y = LayerNorm(a + r) * gamma + beta with the arithmetic of
+// k_add_ln_fwd (bert.hip) — the eight rows' shuffle reductions are interleaved, each row's own order of additions is unchanged
+__device__ __forceinline__ void ln8(const u32x4 (&ra)[8], const u32x4 (&rr)[8], const float* gamma, const float* beta, int lane, float eps,
+                                    u32x4 (&out)[8], float (&mu)[8], float (&rs)[8]) {
+    float v[8][8], s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float fa[8], fr[8];
+        unpack8(ra[i], fa);
+        unpack8(rr[i], fr);
+        s[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[i][k] = fa[k] + fr[k]; s[i] += v[i][k]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = wave_sum(s[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mu[i] = s[i] / (float)ED;
+        s[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu[i]; s[i] = __builtin_fmaf(d, d, s[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = wave_sum(s[i]);
+    float g8[8], b8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { g8[k] = gamma[lane * 8 + k]; b8[k] = beta[lane * 8 + k]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        rs[i] = rsqrtf(s[i] / (float)ED + eps);
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = __builtin_fmaf((v[i][k] - mu[i]) * rs[i], g8[k], b8[k]);
+        out[i] = pack8(o);
+    }
+}
+
+// accumulator block (32 x 32, MFMA layout) -> fp32 [32][pitch] staging at column col0
+__device__ __forceinline__ void acc_to_stage(const f32x16& a, float* st, int pitch, int col0, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * pitch + col0 + (lane & 31)] = a[r];
+}
+
+}  // namespace
+
+// Accumulation order = the launch chain's (tests/test_gpu_enc_fused.py compares bit for bit): every output element of the qkv, attention-output
+// and intermediate GEMMs is ONE accumulator walking k upwards (k_igemm_fwd_glds<64,64,4,1>), the output GEMM (K = 2048) is two halves of
+// K in two accumulators added at the end (k_igemm_fwd_glds<64,64,4,2>), softmax sums and the P.V contraction follow k_mha_fwd4.
+__global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* bufA = reinterpret_cast<bf16_t*>(smem + BUFA);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // cluster / head of this workgroup: with a multiple of 8 sequences the 8 workgroups of a cluster share blockIdx % 8 (observed to be
+    // the XCD: the exchanged tensors stay in one L2's neighbourhood; with a HEAD per XCD instead — weights L2-resident — the weight
+    // stream was no faster, it is bound by the CU's LDS-DMA path at ~20 B/clk, and every exchange slower: 458 vs 319 us).  Speed only.
+    int c, h;
+    {
+        const int i = blockIdx.x;
+        if ((p.nseq & 7) == 0) { const int j = i >> 3; h = j & 7; c = (i & 7) + 8 * (j >> 3); }
+        else { c = i >> 3; h = i & 7; }
+    }
+    const int S = p.S;
+    const long row0 = (long)(p.seq0 + c) * S;                       // first row of this sequence
+    const int bh = (p.seq0 + c) * EH + h;
+    unsigned* cnt = p.cnt + c;
+    unsigned arrivals = 0;                                          // barrier target so far
+    int tix = 0;
+    auto stamp = [&]() {
+        if (p.trace != nullptr && blockIdx.x == 0 && tid == 0 && tix < 500) p.trace[tix] = __builtin_amdgcn_s_memtime();
+        ++tix;
+    };
+    int fix = 0;
+    auto fstamp = [&](int l_) {          // fine-grained stamps of layer 1 only, at p.trace[200 ..]
+        if (p.trace != nullptr && blockIdx.x == 0 && tid == 0 && l_ == 1 && fix < 60) p.trace[200 + fix++] = __builtin_amdgcn_s_memtime();
+    };
+    stamp();
+    const int slot8 = tid & 7, r32 = tid >> 3;                      // DMA: lane writes 16-byte chunk slot8 of row r32 (+ 32 i) ...
+    const int csw = slot8 ^ ((r32 >> 1) & 7);                       // ... which holds global chunk csw (swizzle on the source)
+    const int rsrc = r32 < S ? r32 : S - 1;                         // padding rows of the tile repeat the last row (results never stored)
+    const bool drop_on = p.seed != nullptr;
+    auto ring = [&](int slot) { return reinterpret_cast<bf16_t*>(smem + RING + slot * SLOT); };
+
+    // ---- layer input X -> bufA (A layout) ---------------------------------------------------------------------------------
+    {
+        const bf16_t* src = p.x0 + (row0 + rsrc) * ED + csw * 8;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) glds16(src + kb * 64, bufA + kb * 2048 + wave * 8 * 64);
+    }
+
+    for (int l = 0; l < p.layers; ++l) {
+        const svsr_enc_layer L = p.Ls[l];
+        const bf16_t* xin = l == 0 ? p.x0 : reinterpret_cast<const bf16_t*>(p.Ls[l - 1].xout);
+        const unsigned key_pr = drop_on ? svsr_mix(p.seed[0] * 0x9E3779B9u + L.site_probs * 0x7F4A7C15u + 0x165667B1u) : 0u;
+        const unsigned key_ao = drop_on ? svsr_mix(p.seed[0] * 0x9E3779B9u + L.site_ao * 0x7F4A7C15u + 0x165667B1u) : 0u;
+        const unsigned key_fo = drop_on ? svsr_mix(p.seed[0] * 0x9E3779B9u + L.site_fo * 0x7F4A7C15u + 0x165667B1u) : 0u;
+
+        // =========================== P1: q | k | v of head h, attention =====================================================
+        {
+            const bf16_t* W = reinterpret_cast<const bf16_t*>(L.wqkv);
+            // B tile of step s: rows {q, k, v} x 64 of head h, k-chunk s: 6 DMA pieces per thread
+            auto stageB = [&](int s, int slot) {
+                bf16_t* dst = ring(slot);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const long wrow = (long)(i >> 1) * ED + h * 64 + (i & 1) * 32 + r32;
+                    glds16(W + wrow * ED + s * 64 + csw * 8, dst + (i * 32 + wave * 8) * 64);
+                }
+            };
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            // (the queue may still hold the previous layer's stores: counted waits below must only ever see DMA pieces behind them)
+            if (l > 0) { EF_WAIT_VM(0); EF_BARRIER(); }      // ... and every wave has read its rows of f / x1 out of slots 0 and 1 (P5)
+            stageB(0, 0); stageB(1, 1); stageB(2, 2);
+            for (int s = 0; s < 8; ++s) {
+                if (s < 6) EF_WAIT_VM(12); else if (s == 6) EF_WAIT_VM(6); else EF_WAIT_VM(0);
+                EF_BARRIER();
+                if (s + 3 < 8) stageB(s + 3, (s + 3) & 3);
+                if (wave < 3) {
+                    const bf16_t* B = ring(s & 3) + wave * 64 * 64;
+                    const bf16_t* A = bufA + s * 2048;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int ch = ks * 2 + (lane >> 5);
+                        const bf16x8 fa = lds_frag(A, lane & 31, ch);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, lds_frag(B, j * 32 + (lane & 31), ch), acc[j], 0, 0, 0);
+                    }
+                }
+            }
+            stamp();                                         // [1] P1 GEMM done
+            __syncthreads();                                 // everybody is done with X in bufA and with the ring
+            // ring slot 0: fp32 staging [3][32][64]; bufA: attention operands
+            float* stage = reinterpret_cast<float*>(ring(0));
+            bf16_t* Qa = bufA;                               // [32][64] A layout
+            bf16_t* Kb = bufA + 2048;                        // [32 keys][64] B layout
+            bf16_t* Vt = bufA + 4096;                        // [64 d][64: keys 0..31] B layout of V^T
+            bf16_t* Pa = bufA + 8192;                        // [32][64: keys 0..31] A layout of dropout(P)
+            if (wave < 3) {
+                float* st = stage + wave * 2048;
+                acc_to_stage(acc[0], st, 64, 0, lane);
+                acc_to_stage(acc[1], st, 64, 32, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const float* bias = L.bqkv + wave * ED + h * 64;
+                const int c8 = lane & 7;
+                float b8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) b8[k] = bias[c8 * 8 + k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = (lane >> 3) + 8 * i;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(st + row * 64 + c8 * 8), hi = *reinterpret_cast<const f32x4*>(st + row * 64 + c8 * 8 + 4);
+                    float v[8] = {lo[0] + b8[0], lo[1] + b8[1], lo[2] + b8[2], lo[3] + b8[3], hi[0] + b8[4], hi[1] + b8[5], hi[2] + b8[6], hi[3] + b8[7]};
+                    const u32x4 pk = pack8(v);
+                    if (row < S) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(L.qkv) + (row0 + row) * (3 * ED) + wave * ED + h * 64 + c8 * 8) = pk;
+                    if (wave == 0) *reinterpret_cast<u32x4*>(Qa + EF_SWZ(row, c8)) = pk;
+                    else if (wave == 1) *reinterpret_cast<u32x4*>(Kb + EF_SWZ(row, c8)) = pk;
+                    else {
+                        const unsigned w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) Vt[EF_SWZ(c8 * 8 + e, row >> 3) + (row & 7)] = (bf16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                    }
+                }
+            }
+            // the next phase's first weight tiles (slots 1..3; slot 0 holds the staging): requested before the attention runs
+            const bf16_t* Wo = reinterpret_cast<const bf16_t*>(L.wo) + (long)(h * 64) * ED;
+            auto stageWo = [&](int s, int slot) {      // 64 rows x 256 k (4 chunks of 64): 8 DMA pieces per thread
+                bf16_t* dst = ring(slot);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int sub = i >> 1, row = (i & 1) * 32 + r32;
+                    glds16(Wo + (long)row * ED + s * 256 + sub * 64 + csw * 8, dst + sub * 4096 + ((i & 1) * 32 + wave * 8) * 64);
+                }
+            };
+            fstamp(l);                                       // f0: qkv epilogue done
+            stageWo(0, 1); stageWo(1, 2);
+            fstamp(l);                                       // f1: Wo issued
+            EF_BARRIER();                                    // (LDS visibility only: the weight tiles stay in flight across it)
+            {   // scores of the whole 32 x 32 block on every wave (four MFMAs); wave w finishes rows 8w .. 8w+7 (accumulator registers 4w .. 4w+3)
+                f32x16 sc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ch = ks * 2 + (lane >> 5);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Qa, lane & 31, ch), lds_frag(Kb, lane & 31, ch), sc, 0, 0, 0);
+                }
+                fstamp(l);                                   // f2: scores done
+                const int j = lane & 31;
+                const int ldp = (S + 7) & ~7;
+                float sv[4], e[4], sum[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x = sc[0];
+                    // (accumulator register 4*wave + q, selected with compile-time indices)
+                    if (wave == 0) x = sc[q]; else if (wave == 1) x = sc[4 + q]; else if (wave == 2) x = sc[8 + q]; else x = sc[12 + q];
+                    sv[q] = j < S ? x * 0.125f : -INFINITY;
+                }
+                // row maximum over the 32 lanes of a half (any tree: a maximum is exact), then the row sum in k_mha_fwd4's order: eight partial
+                // sums ((e[p] + e[p+8]) + e[p+16]) + e[p+24] — valid in lanes 0..7 of each half — a butterfly over the eight (its l^4 step pairs
+                // quads of equal values: row_half_mirror pairs the same quads), broadcast from lane 0 of the half
+                float m[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x = sv[q];
+                    x = fmaxf(x, dpp_xor1(x)); x = fmaxf(x, dpp_xor2(x)); x = fmaxf(x, dpp_half_mirror(x)); x = fmaxf(x, dpp_mirror(x));
+                    m[q] = fmaxf(x, swz_xor16(x));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = __expf(sv[q] - m[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float u = swz_xor16(e[q]);
+                    float a = ((e[q] + dpp_ror8(e[q])) + u) + dpp_ror8(u);
+                    a += dpp_xor1(a);
+                    a += dpp_xor2(a);
+                    a += dpp_half_mirror(a);
+                    sum[q] = swz_lane0_of_32(a);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 8 * wave + q + 4 * (lane >> 5);
+                    const float inv = sum[q] > 0.f ? 1.f / sum[q] : 0.f;
+                    float pr = (j < S && inv > 0.f) ? e[q] * inv : 0.f;
+                    const long idx = ((long)bh * S + i) * ldp + j;
+                    if (i < S && j < ldp) reinterpret_cast<bf16_t*>(L.probs)[idx] = f2bf(pr);
+                    if (drop_on) pr = drop_keep(key_pr, p.th_attn, (unsigned)idx) ? pr * p.sc_attn : 0.f;
+                    Pa[EF_SWZ(i, j >> 3) + (j & 7)] = f2bf(pr);
+                }
+                fstamp(l);                                   // f3: softmax + stores done
+            }
+            EF_BARRIER();
+            fstamp(l);                                       // f4: barrier
+            if (wave < 2) {       // ctx[:, wave*32 ..] = P' V: one accumulator per 16-key slice, added at the end (k_mha_fwd4's two k-slice waves)
+                f32x16 c0, c1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Pa, lane & 31, lane >> 5), lds_frag(Vt, wave * 32 + (lane & 31), lane >> 5), c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Pa, lane & 31, 2 + (lane >> 5)), lds_frag(Vt, wave * 32 + (lane & 31), 2 + (lane >> 5)), c1, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c0[r] += c1[r];
+                float* st = stage + wave * 1024;                                         // [32][32] per wave (the q / k staging is consumed)
+                acc_to_stage(c0, st, 32, 0, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int c4 = lane & 3;                                                  // 8 columns each: 4 groups per 32-column row
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = (lane >> 2) + 16 * i;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(st + row * 32 + c4 * 8), hi = *reinterpret_cast<const f32x4*>(st + row * 32 + c4 * 8 + 4);
+                    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (row < S) st16_sc1(reinterpret_cast<bf16_t*>(L.ctx) + (row0 + row) * ED + h * 64 + wave * 32 + c4 * 8, pack8(v));
+                }
+            }
+            stamp();                                         // [2] attention done
+            cluster_signal(cnt);
+            stamp();                                         // [3] signalled
+        }
+
+        // =========================== P2: ao[:, h*64 ..] = dropout(ctx W_o^T + b) =============================================
+        {
+            arrivals += EH;
+            cluster_wait(cnt, arrivals, p.err);
+            stamp();                                         // [4] barrier 1 passed
+            {   // every head's ctx -> bufA
+                const bf16_t* src = reinterpret_cast<const bf16_t*>(L.ctx) + (row0 + rsrc) * ED + csw * 8;
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) glds16_sc1(src + kb * 64, bufA + kb * 2048 + wave * 8 * 64);
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            EF_WAIT_VM(0);
+            EF_BARRIER();
+            // the next phase's first weight tiles (W_1: 256 rows x 64 k per step) into the free slots 3 and 0
+            const bf16_t* W1 = reinterpret_cast<const bf16_t*>(L.w1) + (long)(h * IH) * ED;
+            auto stageW1 = [&](int s, int slot) {
+                bf16_t* dst = ring(slot);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) glds16(W1 + (long)(i * 32 + r32) * ED + s * 64 + csw * 8, dst + (i * 32 + wave * 8) * 64);
+            };
+            stageW1(0, 3); stageW1(1, 0);
+            if (wave < 2) {       // one accumulator per 32-column block walks k upwards
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16_t* B = ring(1 + s);
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            const int ch = ks * 2 + (lane >> 5);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(bufA + (s * 4 + sub) * 2048, lane & 31, ch),
+                                                                           lds_frag(B + sub * 4096, wave * 32 + (lane & 31), ch), acc, 0, 0, 0);
+                        }
+                }
+            }
+            EF_BARRIER();                                    // ctx in bufA is consumed: bufA becomes the fp32 staging [32][64]
+            float* stage = reinterpret_cast<float*>(bufA);
+            if (wave < 2) acc_to_stage(acc, stage, 64, wave * 32, lane);
+            EF_BARRIER();
+            {   // all 256 threads: row tid / 8, eight columns: bias, dropout, write-through store
+                const int row = tid >> 3, c8 = tid & 7, n = h * 64 + c8 * 8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + row * 64 + c8 * 8), hi = *reinterpret_cast<const f32x4*>(stage + row * 64 + c8 * 8 + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const long off = (row0 + row) * ED + n;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k] += L.bo[n + k];
+                    if (drop_on) v[k] = drop_keep(key_ao, p.th_hidden, (unsigned)(off + k)) ? v[k] * p.sc_hidden : 0.f;
+                }
+                if (row < S) st16_sc1(reinterpret_cast<bf16_t*>(L.ao) + off, pack8(v));
+            }
+            stamp();                                         // [5] P2 done
+            cluster_signal_keep_dma(cnt);
+        }
+
+        // =========================== P3: x1 = LN(ao + X);  z_h | hg_h = gelu(x1 W_1^T + b) ===================================
+        {
+            const bf16_t* W1 = reinterpret_cast<const bf16_t*>(L.w1) + (long)(h * IH) * ED;
+            auto stageW1 = [&](int s, int slot) {
+                bf16_t* dst = ring(slot);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) glds16(W1 + (long)(i * 32 + r32) * ED + s * 64 + csw * 8, dst + (i * 32 + wave * 8) * 64);
+            };
+            arrivals += EH;
+            cluster_wait(cnt, arrivals, p.err);
+            stamp();                                         // [6] barrier 2 passed
+            // LayerNorm of rows wave*8 .. +7 (lane owns 8 columns of each) -> bufA (A layout); this workgroup's column slice -> x1.
+            // ao and X arrive by LDS-DMA (sc1) in slots 1 and 2 (free: W_o is consumed; W_1's first tiles sit in 3 and 0): one round trip
+            {
+                const bf16_t* sa = reinterpret_cast<const bf16_t*>(L.ao) + (row0 + rsrc) * ED + csw * 8;
+                const bf16_t* sx = xin + (row0 + rsrc) * ED + csw * 8;
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) {
+                    glds16_sc1(sa + kb * 64, ring(1) + kb * 2048 + wave * 8 * 64);
+                    glds16_sc1(sx + kb * 64, ring(2) + kb * 2048 + wave * 8 * 64);
+                }
+                fstamp(l);                                   // f5: LN1 DMA issued
+                EF_WAIT_VM(0);
+                EF_BARRIER();
+                fstamp(l);                                   // f6: LN1 DMA landed
+                u32x4 ra[8], rr[8], o8[8];
+                float mu[8], rs[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = wave * 8 + i;
+                    ra[i] = *reinterpret_cast<const u32x4*>(ring(1) + (lane >> 3) * 2048 + EF_SWZ(row, lane & 7));
+                    rr[i] = *reinterpret_cast<const u32x4*>(ring(2) + (lane >> 3) * 2048 + EF_SWZ(row, lane & 7));
+                }
+                ln8(ra, rr, L.g1, L.be1, lane, p.eps, o8, mu, rs);
+                fstamp(l);                                   // f7: ln8 done
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = wave * 8 + i;
+                    *reinterpret_cast<u32x4*>(bufA + (lane >> 3) * 2048 + EF_SWZ(row, lane & 7)) = o8[i];
+                    if (row < S) {
+                        if ((lane >> 3) == h) st16_sc1(reinterpret_cast<bf16_t*>(L.x1) + (row0 + row) * ED + lane * 8, o8[i]);
+                        if (h == 0 && lane == 0) { L.m1[row0 + row] = mu[i]; L.r1[row0 + row] = rs[i]; }
+                    }
+                }
+            }
+            stamp();                                         // [7] LN1 done
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            EF_WAIT_VM(0);                                   // tiles 0 and 1 (requested in P2) and this phase's own stores
+            EF_BARRIER();                                    // every wave has read its rows of ao / X out of slots 1 and 2
+            stageW1(2, 1);
+            for (int s = 0; s < 8; ++s) {                    // tile s lives in slot (s + 3) & 3
+                if (s == 0) {} else if (s < 6) EF_WAIT_VM(16); else if (s == 6) EF_WAIT_VM(8); else EF_WAIT_VM(0);
+                EF_BARRIER();
+                if (s + 3 < 8) stageW1(s + 3, (s + 6) & 3);
+                const bf16_t* B = ring((s + 3) & 3) + wave * 64 * 64;
+                const bf16_t* A = bufA + s * 2048;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ch = ks * 2 + (lane >> 5);
+                    const bf16x8 fa = lds_frag(A, lane & 31, ch);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, lds_frag(B, j * 32 + (lane & 31), ch), acc[j], 0, 0, 0);
+                }
+            }
+            __syncthreads();                                 // x1 in bufA and the ring are consumed
+            // the next phase's weight half-tiles (W_2) do not depend on the other workgroups: requested before the epilogue
+            const bf16_t* W2 = reinterpret_cast<const bf16_t*>(L.w2) + (long)(h * 64) * EI;
+            auto stageW2 = [&](int s, int slot) {           // chunks s (K group 0) and 16 + s (K group 1): 64 rows x 64 k each, 4 pieces per thread
+                bf16_t* dst = ring(slot);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int g = i >> 1, row = (i & 1) * 32 + r32;
+                    glds16(W2 + (long)row * EI + (g * 16 + s) * 64 + csw * 8, dst + g * 4096 + ((i & 1) * 32 + wave * 8) * 64);
+                }
+            };
+            stageW2(0, 0); stageW2(1, 1); stageW2(2, 2);
+            {
+                float* st = reinterpret_cast<float*>(bufA) + wave * 2048;               // fp32 [4][32][64] = 32 KiB = all of bufA
+                acc_to_stage(acc[0], st, 64, 0, lane);
+                acc_to_stage(acc[1], st, 64, 32, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int c8 = lane & 7, n = h * IH + wave * 64 + c8 * 8;
+                float b8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) b8[k] = L.b1[n + k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = (lane >> 3) + 8 * i;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(st + row * 64 + c8 * 8), hi = *reinterpret_cast<const f32x4*>(st + row * 64 + c8 * 8 + 4);
+                    float v[8] = {lo[0] + b8[0], lo[1] + b8[1], lo[2] + b8[2], lo[3] + b8[3], hi[0] + b8[4], hi[1] + b8[5], hi[2] + b8[6], hi[3] + b8[7]};
+                    const long off = (row0 + row) * EI + n;
+                    if (row < S) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(L.z) + off) = pack8(v);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+                    if (row < S) st16_sc1(reinterpret_cast<bf16_t*>(L.hg) + off, pack8(v));
+                }
+            }
+            stamp();                                         // [8] P3 done
+            cluster_signal_keep_dma(cnt);
+        }
+
+        // =========================== P4: f[:, h*64 ..] = dropout(hg W_2^T + b) ==============================================
+        {
+            const bf16_t* W2 = reinterpret_cast<const bf16_t*>(L.w2) + (long)(h * 64) * EI;
+            const bf16_t* HG = reinterpret_cast<const bf16_t*>(L.hg) + (row0 + rsrc) * EI + csw * 8;
+            auto stageW2 = [&](int s, int slot) {
+                bf16_t* dst = ring(slot);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int g = i >> 1, row = (i & 1) * 32 + r32;
+                    glds16(W2 + (long)row * EI + (g * 16 + s) * 64 + csw * 8, dst + g * 4096 + ((i & 1) * 32 + wave * 8) * 64);
+                }
+            };
+            auto stageHG = [&](int s, int slot) {           // hg rows, chunks s and 16 + s: 2 pieces per thread (sc1)
+                bf16_t* dst = ring(slot) + 8192;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) glds16_sc1(HG + (g * 16 + s) * 64, dst + g * 2048 + wave * 8 * 64);
+            };
+            arrivals += EH;
+            cluster_wait(cnt, arrivals, p.err);
+            stamp();                                         // [9] barrier 3 passed
+            EF_WAIT_VM(0);                                   // the three prefetched weight half-tiles (and this wave's own stores)
+            stageHG(0, 0); stageHG(1, 1); stageHG(2, 2);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int g = wave >> 1, jb = wave & 1;          // K group, 32-column block
+            for (int s = 0; s < 16; ++s) {
+                // outstanding behind tile s: s = 0: the hg pieces of tiles 1, 2 (4); s = 1: hg of tile 2 + tile 3 (8); then tiles s+1, s+2 (12); the tail drains
+                if (s == 0) EF_WAIT_VM(4); else if (s == 1) EF_WAIT_VM(8); else if (s < 14) EF_WAIT_VM(12); else if (s == 14) EF_WAIT_VM(6); else EF_WAIT_VM(0);
+                EF_BARRIER();
+                if (s + 3 < 16) { stageW2(s + 3, (s + 3) & 3); stageHG(s + 3, (s + 3) & 3); }
+                const bf16_t* T = ring(s & 3);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ch = ks * 2 + (lane >> 5);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(T + 8192 + g * 2048, lane & 31, ch), lds_frag(T + g * 4096, jb * 32 + (lane & 31), ch), acc, 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            float* stage = reinterpret_cast<float*>(bufA);   // fp32 [2 K groups][32][64]
+            acc_to_stage(acc, stage + g * 2048, 64, jb * 32, lane);
+            __syncthreads();
+            {
+                const int row = tid >> 3, c8 = tid & 7, n = h * 64 + c8 * 8;
+                const f32x4 lo0 = *reinterpret_cast<const f32x4*>(stage + row * 64 + c8 * 8), hi0 = *reinterpret_cast<const f32x4*>(stage + row * 64 + c8 * 8 + 4);
+                const f32x4 lo1 = *reinterpret_cast<const f32x4*>(stage + 2048 + row * 64 + c8 * 8), hi1 = *reinterpret_cast<const f32x4*>(stage + 2048 + row * 64 + c8 * 8 + 4);
+                float v[8] = {lo0[0] + lo1[0], lo0[1] + lo1[1], lo0[2] + lo1[2], lo0[3] + lo1[3], hi0[0] + hi1[0], hi0[1] + hi1[1], hi0[2] + hi1[2], hi0[3] + hi1[3]};
+                const long off = (row0 + row) * ED + n;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k] += L.b2[n + k];
+                    if (drop_on) v[k] = drop_keep(key_fo, p.th_hidden, (unsigned)(off + k)) ? v[k] * p.sc_hidden : 0.f;
+                }
+                if (row < S) st16_sc1(reinterpret_cast<bf16_t*>(L.f) + off, pack8(v));
+            }
+            stamp();                                         // [10] P4 done
+            cluster_signal(cnt);
+        }
+
+        // =========================== P5: X' = LN(f + x1) -> bufA, column slice -> xout =======================================
+        {
+            arrivals += EH;
+            cluster_wait(cnt, arrivals, p.err);
+            stamp();                                         // [11] barrier 4 passed
+            {   // f and x1 by LDS-DMA (sc1) into slots 0 and 1 (the whole ring is idle here)
+                const bf16_t* sa = reinterpret_cast<const bf16_t*>(L.f) + (row0 + rsrc) * ED + csw * 8;
+                const bf16_t* sx = reinterpret_cast<const bf16_t*>(L.x1) + (row0 + rsrc) * ED + csw * 8;
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) {
+                    glds16_sc1(sa + kb * 64, ring(0) + kb * 2048 + wave * 8 * 64);
+                    glds16_sc1(sx + kb * 64, ring(1) + kb * 2048 + wave * 8 * 64);
+                }
+                EF_WAIT_VM(0);
+                EF_BARRIER();
+            }
+            u32x4 ra[8], rr[8], o8[8];
+            float mu[8], rs[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = wave * 8 + i;
+                ra[i] = *reinterpret_cast<const u32x4*>(ring(0) + (lane >> 3) * 2048 + EF_SWZ(row, lane & 7));
+                rr[i] = *reinterpret_cast<const u32x4*>(ring(1) + (lane >> 3) * 2048 + EF_SWZ(row, lane & 7));
+            }
+            ln8(ra, rr, L.g2, L.be2, lane, p.eps, o8, mu, rs);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = wave * 8 + i;
+                *reinterpret_cast<u32x4*>(bufA + (lane >> 3) * 2048 + EF_SWZ(row, lane & 7)) = o8[i];
+                if (row < S) {
+                    if ((lane >> 3) == h) st16_sc1(reinterpret_cast<bf16_t*>(L.xout) + (row0 + row) * ED + lane * 8, o8[i]);
+                    if (h == 0 && lane == 0) { L.m2[row0 + row] = mu[i]; L.r2[row0 + row] = rs[i]; }
+                }
+            }
+            stamp();                                         // [12] LN2 done
+            // No barrier here: X' (write-through) is read by the other workgroups only in the next layer's P3, two barriers away, and
+            // every tensor of this layer that they may still be reading (f, x1) is never written again.
+        }
+    }
+}
+
+struct EncTable { svsr_enc_layer L[8]; };
+static_assert(sizeof(EncTable) <= 3584, "the layer records travel in the kernel-argument segment");
+
+// the layer records reach the device as the arguments of this writer kernel (no host pointer survives the call: graph- and replay-safe)
+__global__ __launch_bounds__(256) void k_enc_table(const EncTable t, int words, long long* __restrict__ dst) {
+    const long long* src = reinterpret_cast<const long long*>(&t);
+    for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+}
+
+static unsigned long long* g_enc_trace = nullptr;
+
+extern "C" {
+
+/* debug aid of scripts/probes: the next svsr_enc_fwd launches stamp s_memtime of workgroup 0 at their phase boundaries (1 + 12 per layer);
+ * svsr_debug_enc_trace(out, n) synchronises and copies the first n stamps out, then switches tracing off */
+int svsr_debug_enc_trace(int64_t* out, int n) {
+    if (out == nullptr) {
+        if (g_enc_trace == nullptr && hipMalloc(reinterpret_cast<void**>(&g_enc_trace), 512 * sizeof(unsigned long long)) != hipSuccess) return SVSR_ERR_LAUNCH;
+        return (int)hipMemset(g_enc_trace, 0, 512 * sizeof(unsigned long long));
+    }
+    if (g_enc_trace == nullptr || n < 1 || n > 512) return SVSR_ERR_ARG;
+    (void)hipDeviceSynchronize();
+    const int rc = (int)hipMemcpy(out, g_enc_trace, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(g_enc_trace); g_enc_trace = nullptr;
+    return rc;
+}
+
+/* bytes of the device workspace svsr_enc_fwd needs for B sequences: arrival counters, error word, layer records */
+int64_t svsr_enc_fwd_ws_bytes(int B) { return B < 1 ? 0 : (int64_t)(((B + 1) * 4 + 255) / 256 * 256) + (int64_t)sizeof(EncTable); }
+
+/* svsr_enc_fwd: forward of `n_layers` consecutive HF-BERT encoder layers (width 512, 8 heads of 64, FFN 2048, sequences of S <= 32
+ * rows) in one launch per 32 sequences.  x0 bf16 [B*S][512]: the first layer's input; layers: HOST array of n_layers records (device
+ * pointers of the weights' bf16 shadows, fp32 biases / LayerNorm parameters and of the tensors the layer writes: the same tensors, with
+ * the same contents, as the unfused launches svsr_igemm_fwd / svsr_mha_fwd / svsr_add_ln_fwd produce).  drop_seed null: no dropout.
+ * ws: device workspace of svsr_enc_fwd_ws_bytes(B) bytes (counters are zeroed here with a memset on `stream`; word B is the error flag:
+ * non-zero after the launch if a bounded wait gave up). */
+int svsr_enc_fwd(const void* x0, const svsr_enc_layer* layers, int n_layers, int B, int S, float ln_eps, const unsigned* drop_seed,
+                 float p_hidden, float p_attn, void* ws, int64_t ws_bytes, hipStream_t stream) {
+    if (x0 == nullptr || layers == nullptr || n_layers < 1 || n_layers > 8 || B < 1 || S < 1 || S > TR || ws == nullptr || ws_bytes < svsr_enc_fwd_ws_bytes(B))
+        return SVSR_ERR_ARG;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_enc_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); attr = true; }
+    unsigned* cnt = static_cast<unsigned*>(ws);
+    const size_t cnt_bytes = (size_t)(((B + 1) * 4 + 255) / 256 * 256);
+    hipError_t e = hipMemsetAsync(cnt, 0, cnt_bytes, stream);
+    if (e != hipSuccess) return (int)e;
+    EncTable t;
+    memset(&t, 0, sizeof t);
+    for (int l = 0; l < n_layers; ++l) t.L[l] = layers[l];
+    svsr_enc_layer* tab_dev = reinterpret_cast<svsr_enc_layer*>(static_cast<char*>(ws) + cnt_bytes);
+    hipLaunchKernelGGL(k_enc_table, dim3(1), dim3(256), 0, stream, t, (int)(sizeof(EncTable) / 8), reinterpret_cast<long long*>(tab_dev));
+    EncArgs a;
+    a.x0 = (const bf16_t*)x0; a.Ls = tab_dev;
+    a.layers = n_layers; a.S = S; a.eps = ln_eps;
+    const DropArgs dh = svsr_make_drop(drop_seed, 0, p_hidden), da = svsr_make_drop(drop_seed, 0, p_attn);
+    a.seed = (dh.seed != nullptr || da.seed != nullptr) ? drop_seed : nullptr;
+    a.th_hidden = dh.thresh; a.sc_hidden = dh.scale; a.th_attn = da.thresh; a.sc_attn = da.scale;
+    a.err = cnt + B;
+    a.trace = g_enc_trace;
+    for (int s0 = 0; s0 < B; s0 += 32) {          // all workgroups of a launch must be resident together: 8 per sequence on 256 CUs
+        a.seq0 = s0; a.nseq = B - s0 < 32 ? B - s0 : 32; a.cnt = cnt + s0;
+        hipLaunchKernelGGL(k_enc_fwd, dim3(a.nseq * EH), dim3(256), LDS_TOTAL, stream, a);
+    }
+    return svsr_check_launch();
+}
+
+}  // extern "C"

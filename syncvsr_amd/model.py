@@ -723,6 +723,8 @@ def _encoder_forward(model: TransformerLightningModule, st: _ParamStore, tape: d
     s0, x, mean0, rstd0 = ops.embed_ln_fwd(feats, st.p32("cls_token"), pos, type0, st.p32("encoder.embeddings.LayerNorm.weight"),
                                            st.p32("encoder.embeddings.LayerNorm.bias"), B, S, D, model.ln_eps, drop_in=d_in, drop_out=d_out)
     tape["emb"] = dict(sum=s0, mean=mean0, rstd=rstd0, d_in=d_in, d_out=d_out)
+    if ops.enc_fused_ok(D, H, model.inter, S):
+        return _encoder_forward_fused(model, st, tape, x, B, S)
     for i in range(model.layers):
         p = f"encoder.encoder.layer.{i}"
         wqkv = st.s16(f"{p}.attention.self.query.weight", 3 * D * D)
@@ -741,6 +743,44 @@ def _encoder_forward(model: TransformerLightningModule, st: _ParamStore, tape: d
         tape[p] = dict(x=x, qkv=qkv, ctx=ctx, probs=probs, ao=ao, x1=x1, m1=m1, r1=r1, z=z, hg=hg, f=f, m2=m2, r2=r2, dpr=dpr, dao=dao, dfo=dfo)
         x = x2
     return x
+
+
+def _encoder_forward_fused(model: TransformerLightningModule, st: _ParamStore, tape: dict, x: torch.Tensor, B: int, S: int) -> torch.Tensor:
+    """All encoder layers in one launch (ops.enc_fwd, csrc/enc_fused.hip); fills the same tape entries as the per-layer path."""
+    D, H, I, Lc = model.dim, model.heads, model.inter, model.layers
+    R = B * S
+    dev = x.device
+    ldp = ops.probs_pitch(S)
+    # one allocation per tensor kind for all layers
+    qkv = torch.empty((Lc, R, 3 * D), dtype=BF16, device=dev)
+    probs = torch.empty((Lc, B * H, S, ldp), dtype=BF16, device=dev)
+    act = torch.empty((5, Lc, R, D), dtype=BF16, device=dev)               # ctx, ao, x1, f, xout
+    zz = torch.empty((2, Lc, R, I), dtype=BF16, device=dev)                # z, hg
+    stat = torch.empty((4, Lc, R), dtype=torch.float32, device=dev)        # m1, r1, m2, r2
+    training = model.training
+    recs = []
+    xin = x
+    for i in range(Lc):
+        p = f"encoder.encoder.layer.{i}"
+        dpr, dao, dfo = model._d(f"enc.{i}.attn.probs", "attn"), model._d(f"enc.{i}.attn.out"), model._d(f"enc.{i}.ff.out")
+        rec = dict(
+            wqkv=st.s16(f"{p}.attention.self.query.weight", 3 * D * D), wo=st.s16(f"{p}.attention.output.dense.weight"),
+            w1=st.s16(f"{p}.intermediate.dense.weight"), w2=st.s16(f"{p}.output.dense.weight"),
+            bqkv=st.flat[st.offsets[f"{p}.attention.self.query.bias"][0]:][: 3 * D], bo=st.p32(f"{p}.attention.output.dense.bias"),
+            b1=st.p32(f"{p}.intermediate.dense.bias"), b2=st.p32(f"{p}.output.dense.bias"),
+            g1=st.p32(f"{p}.attention.output.LayerNorm.weight"), be1=st.p32(f"{p}.attention.output.LayerNorm.bias"),
+            g2=st.p32(f"{p}.output.LayerNorm.weight"), be2=st.p32(f"{p}.output.LayerNorm.bias"),
+            qkv=qkv[i], probs=probs[i], ctx=act[0, i], ao=act[1, i], x1=act[2, i], z=zz[0, i], hg=zz[1, i], f=act[3, i], xout=act[4, i],
+            m1=stat[0, i], r1=stat[1, i], m2=stat[2, i], r2=stat[3, i],
+            site_probs=model._sites[f"enc.{i}.attn.probs"], site_ao=model._sites[f"enc.{i}.attn.out"], site_fo=model._sites[f"enc.{i}.ff.out"])
+        recs.append(rec)
+        tape[p] = dict(x=xin, qkv=rec["qkv"], ctx=rec["ctx"], probs=rec["probs"], ao=rec["ao"], x1=rec["x1"], m1=rec["m1"], r1=rec["r1"], z=rec["z"],
+                       hg=rec["hg"], f=rec["f"], m2=rec["m2"], r2=rec["r2"], dpr=dpr, dao=dao, dfo=dfo)
+        xin = rec["xout"]
+    on = training and (model.drop_p > 0.0 or model.attn_drop_p > 0.0)
+    ops.enc_fwd(x, recs, B, S, model.ln_eps, model._drop_word if on else None, model.drop_p if training else 0.0,
+                model.attn_drop_p if training else 0.0)
+    return xin
 
 
 def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: dict, dh: torch.Tensor, B: int, T: int) -> torch.Tensor:

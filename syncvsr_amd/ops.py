@@ -910,6 +910,46 @@ def embed_bwd_scatter(ds, dcls, dpos, dtype0, B: int, S: int, D: int, drop_in=No
     return dfeats
 
 
+# -- fused forward of the HF-BERT encoder layers (csrc/enc_fused.hip) ---------------------------------
+class _EncLayer(ctypes.Structure):
+    """svsr_enc_layer of include/syncvsr_hip.h"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("wqkv", "wo", "w1", "w2", "bqkv", "bo", "b1", "b2", "g1", "be1", "g2", "be2",
+                                               "qkv", "probs", "ctx", "ao", "x1", "z", "hg", "f", "xout", "m1", "r1", "m2", "r2")] + \
+               [("site_probs", ctypes.c_uint), ("site_ao", ctypes.c_uint), ("site_fo", ctypes.c_uint), ("pad_", ctypes.c_uint)]
+
+
+ENC_FUSED = os.environ.get("SVSR_ENC_FUSED", "1") != "0"     # the whole encoder forward as one launch (False: seven launches per layer)
+_ENC_WS: dict = {}
+
+
+def enc_fused_ok(D: int, H: int, inter: int, S: int) -> bool:
+    return ENC_FUSED and D == 512 and H == 8 and inter == 2048 and 1 <= S <= 32
+
+
+def enc_fwd(x0: torch.Tensor, layers: Sequence[dict], B: int, S: int, eps: float, seed: Optional[torch.Tensor], p_hidden: float, p_attn: float) -> None:
+    """layers: per layer a dict of tensors under the field names of svsr_enc_layer (+ site_probs / site_ao / site_fo ints).
+    Up to 8 layers per launch; deeper encoders take several (the last output of one call is the input of the next)."""
+    dev = x0.device
+    nbytes = int(_lib.load().svsr_enc_fwd_ws_bytes(B))
+    key = (str(dev), _stream())
+    ws = _ENC_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _SCRATCH_KEEP.append(ws)
+        ws = _ENC_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    x = x0
+    for i0 in range(0, len(layers), 8):
+        chunk = layers[i0: i0 + 8]
+        arr = (_EncLayer * len(chunk))()
+        for rec, q in zip(arr, chunk):
+            for name, _ in _EncLayer._fields_[:25]:
+                setattr(rec, name, q[name].data_ptr())
+            rec.site_probs, rec.site_ao, rec.site_fo, rec.pad_ = int(q["site_probs"]), int(q["site_ao"]), int(q["site_fo"]), 0
+        _call("svsr_enc_fwd", _p(x), arr, len(chunk), B, S, float(eps), _p(seed), float(p_hidden), float(p_attn), _p(ws), nbytes, _stream(),
+              label="k_enc_fwd", flops=float(len(chunk)) * 2.0 * B * S * (4 * 512 * 512 + 2 * 512 * 2048) + float(len(chunk)) * 4.0 * B * 8 * S * S * 64)
+        x = chunk[-1]["xout"]
+
+
 # -- `type: x-transformers` encoder passes (csrc/xt.hip) ---------------------------------------------
 def rmsnorm_fwd(x, g, D: int, eps: float = 1e-8):
     """x bf16 [R][ld] (pad columns zero) -> (y, inv [R])."""
