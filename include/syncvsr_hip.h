@@ -163,6 +163,11 @@ int svsr_conv3x3_res(const void* in, const void* wt, void* out, const void* adde
  * Requires Ci, Co multiples of 64 and W <= 29; other shapes go through svsr_igemm_wgrad. */
 int svsr_conv3x3_wgrad_plan(int Nimg, int H, int W, int Ci, int Co, int* splits, int64_t* part_floats);
 int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Ci, int Co, float* part, int64_t part_floats, hipStream_t stream);
+/* n <= 4 such weight gradients of one geometry in ONE launch (the stride-1 convolutions of a ResNet layer, once all their output
+ * gradients exist): the launch's workgroups are divided among them, so each writes 1/n of the split-K
+ * slabs of a launch of its own.  xs / dys / dws: HOST arrays of n device pointers; part: svsr_conv3x3_wgrad_multi_floats(...) floats. */
+int64_t svsr_conv3x3_wgrad_multi_floats(int n, int Nimg, int H, int W, int Ci, int Co);
+int svsr_conv3x3_wgrad_multi(const void* const* xs, const void* const* dys, float* const* dws, int n, int Nimg, int H, int W, int Ci, int Co, float* part, int64_t part_floats, hipStream_t stream);
 
 /* ---- 3-D stem (stem.hip) --------------------------------------------------------------------------------------
  * svsr_stem_conv_fwd replaces stem3d[0] = nn.Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3),bias=False) (lightning.py:50).
@@ -223,6 +228,10 @@ int svsr_avgpool_bwd(const void* dy, void* dx, int64_t N, int HW, int C, hipStre
 int svsr_add_ln_fwd(const void* a, const void* r, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int R, int D, float eps, hipStream_t stream);
 int svsr_add_ln_bwd_rows(int R);
 int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd, void* ds, float* dgamma, float* dbeta, int R, int D, const void* addend, float* part, hipStream_t stream);
+/* svsr_add_ln_bwd / svsr_bias_act_bwd WITHOUT their fixed-order reduction: the partial rows stay in `part` (a buffer of the caller's that must live until
+ * it has added them with svsr_colsum_rows on a stream of its choice — parameter-gradient sums the backward chain never waits for) */
+int svsr_add_ln_bwd_partials(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd, void* ds, int R, int D, const void* addend, float* part, hipStream_t stream);
+int svsr_bias_act_bwd_partials(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, float gscale, float* part, hipStream_t stream);
 
 /* BertEmbeddings on inputs_embeds = emb_dropout(cat(cls_token, feats)) (lightning.py:149-156):
  * y = dropout_out(LN(dropout_in(e) + pos[s] + type[0])); dropout_in = the module's emb_dropout (site_in, p_in), dropout_out =

@@ -324,15 +324,22 @@ int svsr_add_ln_bwd_rows(int R) { return ln_bwd_grid(R); }
 int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale,
                      hipStream_t stream);
 
-int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd,
-                    void* ds, float* dgamma, float* dbeta, int R, int D, const void* addend, float* part, hipStream_t stream) {
+/* the launch without its reduction: part [svsr_add_ln_bwd_rows(R)][2 * D] is left for the caller to add with svsr_colsum_rows(part, rows, 2 * D,
+ * dgamma, D, dbeta, D, 1, 1.0f, any stream) — a parameter-gradient sum nothing in the backward chain waits for */
+int svsr_add_ln_bwd_partials(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd,
+                             void* ds, int R, int D, const void* addend, float* part, hipStream_t stream) {
     if (D % 8 != 0 || D > 512 * LN_MAXV || part == nullptr) return SVSR_ERR_ARG;
     const int grid = ln_bwd_grid(R);
     hipLaunchKernelGGL(k_add_ln_bwd, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), stream, (const bf16_t*)dy, (const bf16_t*)a, (const bf16_t*)r, gamma,
                        mean, rstd, (bf16_t*)ds, part, R, D, (const bf16_t*)addend);
-    const int rc = svsr_check_launch();
+    return svsr_check_launch();
+}
+
+int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd,
+                    void* ds, float* dgamma, float* dbeta, int R, int D, const void* addend, float* part, hipStream_t stream) {
+    const int rc = svsr_add_ln_bwd_partials(dy, a, r, gamma, mean, rstd, ds, R, D, addend, part, stream);
     if (rc != SVSR_OK) return rc;
-    return svsr_colsum_rows(part, grid, 2 * D, dgamma, D, dbeta, D, 1, 1.0f, stream);
+    return svsr_colsum_rows(part, ln_bwd_grid(R), 2 * D, dgamma, D, dbeta, D, 1, 1.0f, stream);
 }
 
 int svsr_embed_ln_fwd(const void* feats, const float* cls, const float* pos, const float* type0, const float* gamma,
@@ -374,17 +381,25 @@ int svsr_bias_act_bwd_rows(int R, int N) {
     return sp > 1 ? sp : 0;
 }
 
-int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, float gscale,
-                      float* part, hipStream_t stream) {
+/* the launch without its reduction (only when svsr_bias_act_bwd_rows(R, N) > 0, i.e. the grid has several row slabs): part [rows][N] is left
+ * for the caller to add with svsr_colsum_rows(part, rows, N, db, n_valid, null, 0, 1, 1.0f, any stream) */
+int svsr_bias_act_bwd_partials(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, float gscale,
+                               float* part, hipStream_t stream) {
     if (N % 8 != 0 || ld % 8 != 0) return SVSR_ERR_ARG;
     int col_blocks, splits, rpb;
     bias_bwd_grid(R, N, col_blocks, splits, rpb);
     if (db != nullptr && splits > 1 && part == nullptr) return SVSR_ERR_ARG;
     hipLaunchKernelGGL(k_bias_act_bwd, dim3(col_blocks, splits), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)z,
                        (bf16_t*)dz, db, part, R, N, n_valid, ld, rpb, act, gscale);
-    const int rc = svsr_check_launch();
-    if (rc != SVSR_OK || db == nullptr || splits <= 1) return rc;
-    return svsr_colsum_rows(part, splits, N, db, n_valid, nullptr, 0, 1, 1.0f, stream);
+    return svsr_check_launch();
+}
+
+int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, float gscale,
+                      float* part, hipStream_t stream) {
+    const int rc = svsr_bias_act_bwd_partials(dy, z, dz, db, R, N, n_valid, ld, act, gscale, part, stream);
+    const int rows = svsr_bias_act_bwd_rows(R, N);
+    if (rc != SVSR_OK || db == nullptr || rows <= 0) return rc;
+    return svsr_colsum_rows(part, rows, N, db, n_valid, nullptr, 0, 1, 1.0f, stream);
 }
 
 }  // extern "C"

@@ -33,6 +33,17 @@ struct Wgrad3Args {
     int chunks_per_block, total_chunks;
 };
 
+// Slab format: a workgroup's nine 64 x 64 tiles leave in MFMA FRAGMENT layout — float4 group ((tap * 4 + wave) * 4 + rq) * 64 + lane holds
+// accumulator registers rq*4 .. rq*4+3 — as 36 16-byte stores per lane (1 KiB per wave-instruction) instead of 144 dword stores of two
+// 128-byte rows each; k_wgrad3_reduce adds a task's slabs in split order (64 float4 groups x 4 slot lanes per block) and scatters the sum
+// into dW once.  Up to four convolutions of the same geometry can share a launch (blockIdx.z): the launch's workgroups are divided among
+// them, so each writes 1/n of the slabs of a launch of its own (svsr_conv3x3_wgrad_multi).
+// (Measured and dropped: ONE 8-wave workgroup per CU whose two 4-wave groups take alternate chunks one barrier apart, accumulators merged
+// through LDS — half the slabs, but 94 vs 78 us per launch: a group's wait for its next chunk's rows, 2-3 us from HBM, stalls the shared
+// barrier for both groups, while two independent workgroups hide each other's waits.)
+struct Wgrad3Multi { const bf16_t* x[4]; const bf16_t* dy[4]; float* dw[4]; };
+#define W3_TILE_FLOATS (9 * 64 * 64)
+
 __device__ __forceinline__ bf16x8 w3_frag_T(const bf16_t* tile, int ch0, int pos0, int lane) {
     // MFMA 32x32x16 fragment: lane l <- channel ch0 + (l&31), positions pos0 + (l>>5)*8 .. +7, via two transpose reads
     const int gq = lane >> 4, s = lane & 15;
@@ -58,7 +69,7 @@ __device__ __forceinline__ long w3_pixel(const Wgrad3Args& p, int q) {
     return ((long)n * p.H + (yp - 1)) * p.W + (xp - 1);
 }
 
-__global__ __launch_bounds__(256, 2) void k_wgrad3x3_halo(const Wgrad3Args p) {
+__global__ __launch_bounds__(256, 2) void k_wgrad3x3_halo(const Wgrad3Args p, const Wgrad3Multi m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sY = reinterpret_cast<bf16_t*>(smem_raw);            // [128][PITCH]
     bf16_t* sX = sY + W3_CH * W3_PITCH;                          // [XR][PITCH]
@@ -68,6 +79,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_halo(const Wgrad3Args p) {
     const int co0 = cot * 64, ci0 = cit * 64;
     const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
     const int chunk = tid & 7, r0 = tid >> 3;
+    const bf16_t* gx = m.x[blockIdx.z];
+    const bf16_t* gy = m.dy[blockIdx.z];
 
     f32x16 acc[9];
 #pragma unroll
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_halo(const Wgrad3Args p) {
         for (int i = 0; i < 4; ++i) {
             const long pix = w3_pixel(p, q0 + r0 + 32 * i);
             const bool ok = pix >= 0;
-            vy[i] = *reinterpret_cast<const u32x4*>(p.dy + (ok ? pix * p.Co + co0 + chunk * 8 : 0));
+            vy[i] = *reinterpret_cast<const u32x4*>(gy + (ok ? pix * p.Co + co0 + chunk * 8 : 0));
             ld_ok |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_halo(const Wgrad3Args p) {
             const int rr = r0 + 32 * i;
             const long pix = rr < p.XR ? w3_pixel(p, q0 - (p.WP + 1) + rr) : -1;
             const bool ok = pix >= 0;
-            vx[i] = *reinterpret_cast<const u32x4*>(p.x + (ok ? pix * p.Ci + ci0 + chunk * 8 : 0));
+            vx[i] = *reinterpret_cast<const u32x4*>(gx + (ok ? pix * p.Ci + ci0 + chunk * 8 : 0));
             ld_ok |= (ok ? 1u : 0u) << (8 + i);
         }
     };
@@ -136,29 +149,68 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_halo(const Wgrad3Args p) {
                 }
         }
     }
-    // D[row = co][col = ci]
+    if (p.splits > 1) {
+        f32x4* dst = reinterpret_cast<f32x4*>(p.part + (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * W3_TILE_FLOATS);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                dst[((t * 4 + wave) * 4 + rq) * 64 + lane] = f32x4{acc[t][rq * 4], acc[t][rq * 4 + 1], acc[t][rq * 4 + 2], acc[t][rq * 4 + 3]};
+        return;
+    }
+    // single split: D[row = co][col = ci] added to dW directly (one writer per element)
     const int ci = ci0 + wci + (lane & 31);
-    const bool direct = p.splits <= 1;
-    float* dst = direct ? p.dw : p.part + (long)blockIdx.x * ((long)p.Co * 9 * p.Ci);
+    float* dwp = m.dw[blockIdx.z];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float* d = dst + ((long)co * 9 + t) * p.Ci + ci;
-            *d = direct ? *d + acc[t][r] : acc[t][r];
+            float* d = dwp + ((long)co * 9 + t) * p.Ci + ci;
+            *d += acc[t][r];
         }
+}
+
+// dW[co][t][ci] += sum over the splits (in split order) of a task's tiles.  grid (9 * 16 blocks of 64 float4 groups, tasks, problems)
+__global__ __launch_bounds__(256) void k_wgrad3_reduce(const float* __restrict__ part, const Wgrad3Multi m, int splits, int Ci, int ci_tiles) {
+    __shared__ f32x4 sred[4][64];
+    const int gl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int g = blockIdx.x * 64 + gl;
+    const float* src = part + ((long)blockIdx.z * gridDim.y + blockIdx.y) * splits * W3_TILE_FLOATS;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    int s = sl;
+    for (; s + 4 < splits; s += 8) {
+        const f32x4 v0 = reinterpret_cast<const f32x4*>(src + (long)s * W3_TILE_FLOATS)[g];
+        const f32x4 v1 = reinterpret_cast<const f32x4*>(src + (long)(s + 4) * W3_TILE_FLOATS)[g];
+        a = (a + v0) + v1;
+    }
+    for (; s < splits; s += 4) a = a + reinterpret_cast<const f32x4*>(src + (long)s * W3_TILE_FLOATS)[g];
+    sred[sl][gl] = a;
+    __syncthreads();
+    if (sl != 0) return;
+    a = ((sred[0][gl] + sred[1][gl]) + sred[2][gl]) + sred[3][gl];
+    const int lane = g & 63, rq = (g >> 6) & 3, wave = (g >> 8) & 3, t = g >> 10;
+    const int cot = blockIdx.y / ci_tiles, cit = blockIdx.y - cot * ci_tiles;
+    const int ci = cit * 64 + (wave & 1) * 32 + (lane & 31);
+    const int co = cot * 64 + (wave >> 1) * 32 + 8 * rq + 4 * (lane >> 5);
+    float* dw = m.dw[blockIdx.z];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float* d = dw + ((long)(co + k) * 9 + t) * Ci + ci;
+        *d += a[k];
+    }
 }
 
 struct W3Plan { int splits, chunks_per_block, total_chunks, tasks; };
 
-static W3Plan w3_plan(int Nimg, int H, int W, int Ci, int Co) {
+static W3Plan w3_plan(int Nimg, int H, int W, int Ci, int Co, int nprob = 1) {
     W3Plan pl;
     const long qtot = (long)Nimg * (H + 2) * (W + 2);
     pl.total_chunks = (int)((qtot + W3_CH - 1) / W3_CH);
     pl.tasks = (Co / 64) * (Ci / 64);
-    const int target_blocks = svsr_tune_get(SVSR_TUNE_W3_BLOCKS);      // one round of 2 workgroups per CU
-    int splits = ((target_blocks > 0 ? target_blocks : 512) + pl.tasks - 1) / pl.tasks;   // every split costs a slab written and re-read
+    int target_blocks = svsr_tune_get(SVSR_TUNE_W3_BLOCKS);      // one round of 2 workgroups per CU, shared by the problems of the launch
+    target_blocks = (target_blocks > 0 ? target_blocks : 512) / (nprob > 0 ? nprob : 1);
+    int splits = (target_blocks + pl.tasks - 1) / pl.tasks;       // every split costs a slab written and re-read
     if (splits > pl.total_chunks) splits = pl.total_chunks;
     if (splits < 1) splits = 1;
     pl.chunks_per_block = (pl.total_chunks + splits - 1) / splits;
@@ -166,23 +218,27 @@ static W3Plan w3_plan(int Nimg, int H, int W, int Ci, int Co) {
     return pl;
 }
 
-/* workspace (floats) svsr_conv3x3_wgrad needs for this shape: splits * Co*9*Ci (0 when a single split writes dW directly) */
+/* workspace (floats) svsr_conv3x3_wgrad needs for this shape */
 extern "C" int svsr_conv3x3_wgrad_plan(int Nimg, int H, int W, int Ci, int Co, int* splits, int64_t* part_floats) {
     if (Ci % 64 || Co % 64 || Ci <= 0 || Co <= 0 || H < 1 || W < 1 || Nimg < 1) return SVSR_ERR_ARG;
     const W3Plan pl = w3_plan(Nimg, H, W, Ci, Co);
     if (splits) *splits = pl.splits;
-    if (part_floats) *part_floats = pl.splits > 1 ? (int64_t)pl.splits * Co * 9 * Ci : 0;
+    if (part_floats) *part_floats = pl.splits > 1 ? (int64_t)pl.splits * pl.tasks * W3_TILE_FLOATS : 0;
     return SVSR_OK;
+}
+
+/* workspace (floats) of svsr_conv3x3_wgrad_multi for n problems of this geometry */
+extern "C" int64_t svsr_conv3x3_wgrad_multi_floats(int n, int Nimg, int H, int W, int Ci, int Co) {
+    if (n < 1 || n > 4 || Ci % 64 || Co % 64 || Ci <= 0 || Co <= 0 || H < 1 || W < 1 || Nimg < 1) return 0;
+    const W3Plan pl = w3_plan(Nimg, H, W, Ci, Co, n);
+    return pl.splits > 1 ? (int64_t)n * pl.splits * pl.tasks * W3_TILE_FLOATS : 0;
 }
 
 extern "C" int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate,
                                 float scale, hipStream_t stream);
 
-extern "C" int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Ci, int Co, float* part,
-                                  int64_t part_floats, hipStream_t stream) {
+static int w3_fill_args(Wgrad3Args& a, int Nimg, int H, int W, int Ci, int Co) {
     if (Ci % 64 || Co % 64 || Ci <= 0 || Co <= 0 || W + 2 > (W3_MAXXR - W3_CH) / 2 - 1 || H < 1 || W < 1 || Nimg < 1) return SVSR_ERR_ARG;
-    Wgrad3Args a;
-    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw;
     a.Nimg = Nimg; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
     a.WP = W + 2; a.Q = (H + 2) * (W + 2);
     const long qtot = (long)Nimg * a.Q;
@@ -190,9 +246,12 @@ extern "C" int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int 
     a.Qtot = (int)qtot;
     a.XR = W3_CH + 2 * (a.WP + 1);
     a.inv_q = 1.0f / (float)a.Q; a.inv_wp = 1.0f / (float)a.WP;
-    const W3Plan pl = w3_plan(Nimg, H, W, Ci, Co);
-    const int64_t n = (int64_t)Co * 9 * Ci;
-    if (pl.splits > 1 && (part == nullptr || part_floats < (int64_t)pl.splits * n)) return SVSR_ERR_ARG;
+    return SVSR_OK;
+}
+
+static int w3_launch(const Wgrad3Args& a0, const Wgrad3Multi& m, int n, const W3Plan& pl, float* part, int64_t part_floats, hipStream_t stream) {
+    if (pl.splits > 1 && (part == nullptr || part_floats < (int64_t)n * pl.splits * pl.tasks * W3_TILE_FLOATS)) return SVSR_ERR_ARG;
+    Wgrad3Args a = a0;
     a.total_chunks = pl.total_chunks; a.chunks_per_block = pl.chunks_per_block; a.splits = pl.splits; a.part = part;
     const size_t lds = (size_t)(W3_CH + a.XR) * W3_PITCH * sizeof(bf16_t);
     static size_t lds_set = 0;
@@ -200,8 +259,38 @@ extern "C" int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3x3_halo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set = lds;
     }
-    hipLaunchKernelGGL(k_wgrad3x3_halo, dim3(pl.splits, pl.tasks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(k_wgrad3x3_halo, dim3(pl.splits, pl.tasks, n), dim3(256), lds, stream, a, m);
     int rc = svsr_check_launch();
     if (rc != SVSR_OK || pl.splits <= 1) return rc;
-    return svsr_colsum_rows(part, pl.splits, n, dw, n, nullptr, 0, 1, 1.0f, stream);
+    hipLaunchKernelGGL(k_wgrad3_reduce, dim3(W3_TILE_FLOATS / 4 / 64, pl.tasks, n), dim3(256), 0, stream, (const float*)part, m, pl.splits, a.Ci, a.Ci >> 6);
+    return svsr_check_launch();
+}
+
+extern "C" int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Ci, int Co, float* part,
+                                  int64_t part_floats, hipStream_t stream) {
+    Wgrad3Args a;
+    const int rc0 = w3_fill_args(a, Nimg, H, W, Ci, Co);
+    if (rc0 != SVSR_OK) return rc0;
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw;
+    Wgrad3Multi m{};
+    m.x[0] = a.x; m.dy[0] = a.dy; m.dw[0] = dw;
+    return w3_launch(a, m, 1, w3_plan(Nimg, H, W, Ci, Co), part, part_floats, stream);
+}
+
+/* svsr_conv3x3_wgrad_multi: n <= 4 weight gradients of the SAME geometry in one launch (the convolutions of a ResNet layer): the
+ * workgroups are divided among them, so every convolution writes 1/n of the slabs.  xs / dys / dws: HOST arrays of n device
+ * pointers.  part: svsr_conv3x3_wgrad_multi_floats(n, ...) floats. */
+extern "C" int svsr_conv3x3_wgrad_multi(const void* const* xs, const void* const* dys, float* const* dws, int n, int Nimg, int H, int W, int Ci, int Co,
+                                        float* part, int64_t part_floats, hipStream_t stream) {
+    if (xs == nullptr || dys == nullptr || dws == nullptr || n < 1 || n > 4) return SVSR_ERR_ARG;
+    Wgrad3Args a;
+    const int rc0 = w3_fill_args(a, Nimg, H, W, Ci, Co);
+    if (rc0 != SVSR_OK) return rc0;
+    Wgrad3Multi m{};
+    for (int i = 0; i < n; ++i) {
+        if (xs[i] == nullptr || dys[i] == nullptr || dws[i] == nullptr) return SVSR_ERR_ARG;
+        m.x[i] = (const bf16_t*)xs[i]; m.dy[i] = (const bf16_t*)dys[i]; m.dw[i] = dws[i];
+    }
+    a.x = m.x[0]; a.dy = m.dy[0]; a.dw = m.dw[0];
+    return w3_launch(a, m, n, w3_plan(Nimg, H, W, Ci, Co, n), part, part_floats, stream);
 }

@@ -654,6 +654,7 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
         else:
             dx, dx_stats = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw, addend=dres), None
         _ready(model, st, f"{prefix}.conv1.weight")
+    _flush_w3(model)
     ts = tape["stem"]
     if rec is not None:
         rec["stem"] = (dx.clone(), False)
@@ -671,10 +672,33 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
 _ABLATE: frozenset = frozenset()
 
 
+W3_GROUP = int(os.environ.get("SVSR_W3_GROUP", "0"))      # stride-1 3x3 weight gradients of one geometry per launch (0 / 1: a launch each; 2: per residual block; 4: per layer)
+
+
 def _conv_wgrad(model, st: "_ParamStore", conv: str, t: dict, dc: torch.Tensor, use_tr: bool) -> None:
     if "conv_wgrad" in _ABLATE:
         return
+    if W3_GROUP > 1 and use_tr and ops.halo_wgrad_ok(t["x"], dc, t["k"], t["stride"], t["pad"]):
+        # collected: weight gradients of the same geometry share a launch (fewer split-K slabs each); flushed when the group is full, the
+        # geometry changes or the trunk's backward ends
+        pend = model.__dict__.setdefault("_w3_pending", [])
+        if pend and (pend[0][0].shape != t["x"].shape or pend[0][1].shape != dc.shape):
+            _flush_w3(model)
+            pend = model._w3_pending
+        pend.append((t["x"], dc, st.g32(f"{conv}.weight")))
+        if len(pend) >= min(W3_GROUP, 4):
+            _flush_w3(model)
+        return
     model._side.run(lambda: ops.conv2d_wgrad(t["x"], dc, st.g32(f"{conv}.weight"), t["k"], t["stride"], t["pad"], use_tr), dc)
+
+
+def _flush_w3(model) -> None:
+    pend = model.__dict__.get("_w3_pending")
+    if not pend:
+        return
+    model._w3_pending = []
+    keep = [q for p in pend for q in p[:2]]
+    model._side.run(lambda: ops.conv3x3_wgrad_multi(pend), *keep)
 
 
 def _lin_wgrad(model, x, dy, gw, gb, rows: int, K: int, N: int, x_pitch: int, dy_pitch: int) -> None:
@@ -687,6 +711,9 @@ def _lin_wgrad(model, x, dy, gw, gb, rows: int, K: int, N: int, x_pitch: int, dy
         group.append(dict(x=x, dy=dy, dw=gw, db=gb, rows=rows, K=K, N=N, x_pitch=x_pitch, dy_pitch=dy_pitch))
         return
     model._side.run(lambda: ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=x_pitch, dy_pitch=dy_pitch, db=gb), x, dy, small=True)
+
+
+DEFER_REDUCTIONS = os.environ.get("SVSR_DEFER_REDUCTIONS", "1") != "0"     # encoder backward: parameter-gradient reductions on the side stream
 
 
 WG_GROUP_LAYERS = int(os.environ.get("SVSR_WG_GROUP_LAYERS", "1"))      # encoder layers per grouped weight-gradient launch (0: one launch for the whole encoder)
@@ -709,6 +736,7 @@ def _ready(model, st: "_ParamStore", name: Optional[str]) -> None:
     """Gradient-ready notification for bucketed all-reduce: everything at or above `name`'s offset in the decayed
     region is final (backward walks the flat buffer from its end to its start); None = all gradients final."""
     if model.grad_ready_hook is not None:     # (the reducer's comm stream waits for the side stream itself: engine.GradReducer._reduce)
+        _flush_w3(model)                      # collected weight gradients are not final until launched: bucket boundaries end a group
         model._side.flush()
         hook, lo = model.grad_ready_hook, (0 if name is None else st.offsets[name][0])
         ops.host_callback(lambda: hook(lo))   # a host-side step (collective): a segment boundary of a recorded step list
@@ -788,21 +816,31 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
     R = B * S
     use_tr = model.use_tr
     dx = dh
+    # parameter-gradient reductions of the row passes (LayerNorm gamma / beta, the intermediate bias): nothing downstream waits for them, so
+    # they leave the chain of dependent launches and run on the side stream, one hand-over per layer
+    defer = [] if (DEFER_REDUCTIONS and model._side.enabled) else None
+
+    def flush_deferred():
+        if defer:
+            fns, keep = [f for f, _ in defer], [k for _, k in defer]
+            defer.clear()
+            model._side.run(lambda: [f() for f in fns], *keep)
+
     for i in reversed(range(model.layers)):
         p = f"encoder.encoder.layer.{i}"
         t = tape[p]
         ds2 = ops.add_ln_bwd(dx, t["f"], t["x1"], st.p32(f"{p}.output.LayerNorm.weight"), t["m2"], t["r2"],
-                             st.g32(f"{p}.output.LayerNorm.weight"), st.g32(f"{p}.output.LayerNorm.bias"))
+                             st.g32(f"{p}.output.LayerNorm.weight"), st.g32(f"{p}.output.LayerNorm.bias"), defer=defer)
         # ds2 is the gradient of (dropout(f) + x1): the dense layer sees it through the regenerated mask, the skip path as it is
         df = ds2 if t["dfo"] is None else ops.scale_bf16(ds2, 1.0, drop=t["dfo"])
         _lin_wgrad(model, t["hg"], df, st.g32(f"{p}.output.dense.weight"), st.g32(f"{p}.output.dense.bias"), R, I, D, I, D)
         dhg = ops.linear_dgrad(df, st.t16(f"{p}.output.dense.weight"), rows=R, N=D, K=I, dy_pitch=D)
-        dz = ops.bias_act_bwd(dhg, t["z"], st.g32(f"{p}.intermediate.dense.bias"), R=R, N=I, n_valid=I, ld=I)
+        dz = ops.bias_act_bwd(dhg, t["z"], st.g32(f"{p}.intermediate.dense.bias"), R=R, N=I, n_valid=I, ld=I, defer=defer)
         _lin_wgrad(model, t["x1"], dz, st.g32(f"{p}.intermediate.dense.weight"), None, R, D, I, D, I)
         # (not in place: the side stream may still be reading ds2 / ds1 for the weight gradients)
         dx1 = ops.linear_dgrad(dz, st.t16(f"{p}.intermediate.dense.weight"), rows=R, N=I, K=D, dy_pitch=I, addend=ds2)
         ds1 = ops.add_ln_bwd(dx1, t["ao"], t["x"], st.p32(f"{p}.attention.output.LayerNorm.weight"), t["m1"], t["r1"],
-                             st.g32(f"{p}.attention.output.LayerNorm.weight"), st.g32(f"{p}.attention.output.LayerNorm.bias"))
+                             st.g32(f"{p}.attention.output.LayerNorm.weight"), st.g32(f"{p}.attention.output.LayerNorm.bias"), defer=defer)
         dao_ = ds1 if t["dao"] is None else ops.scale_bf16(ds1, 1.0, drop=t["dao"])
         _lin_wgrad(model, t["ctx"], dao_, st.g32(f"{p}.attention.output.dense.weight"), st.g32(f"{p}.attention.output.dense.bias"), R, D, D, D, D)
         dctx = ops.linear_dgrad(dao_, st.t16(f"{p}.attention.output.dense.weight"), rows=R, N=D, K=D, dy_pitch=D)
@@ -814,6 +852,7 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
         gqb = st.grad[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
         _lin_wgrad(model, t["x"], dqkv, gq, gqb, R, D, 3 * D, D, 3 * D)
         dx = ops.linear_dgrad(dqkv, st.t16(f"{p}.qkv"), rows=R, N=3 * D, K=D, dy_pitch=3 * D, addend=ds1)
+        flush_deferred()
         if getattr(model, "_wg_group", None) is None:
             _ready(model, st, f"{p}.attention.self.query.weight")
         elif WG_GROUP_LAYERS > 0 and (model.layers - i) % WG_GROUP_LAYERS == 0 and i > 0:
@@ -830,7 +869,8 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
     if te["d_out"] is not None:
         dx = ops.scale_bf16(dx, 1.0, drop=te["d_out"])
     ds0 = ops.add_ln_bwd(dx, te["sum"], None, st.p32("encoder.embeddings.LayerNorm.weight"), te["mean"], te["rstd"],
-                         st.g32("encoder.embeddings.LayerNorm.weight"), st.g32("encoder.embeddings.LayerNorm.bias"))
+                         st.g32("encoder.embeddings.LayerNorm.weight"), st.g32("encoder.embeddings.LayerNorm.bias"), defer=defer)
+    flush_deferred()
     dfeats = ops.embed_bwd_scatter(ds0, st.g32("cls_token"), st.g32("encoder.embeddings.position_embeddings.weight"),
                                    st.g32("encoder.embeddings.token_type_embeddings.weight"), B, S, D, drop_in=te["d_in"])
     _ready(model, st, "cls_token")

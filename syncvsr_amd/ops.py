@@ -96,7 +96,7 @@ def _query(name: str, *args) -> tuple:
     if hit is not None:
         return hit
     fn = getattr(_lib.load(), name)
-    if name.endswith("_rows") or name.endswith("_bytes"):
+    if name.endswith("_rows") or name.endswith("_bytes") or name.endswith("_floats"):
         out = (int(fn(*args)),)
     else:
         nout = {"svsr_conv3x3_wgrad_plan": (1, 1),
@@ -688,6 +688,26 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: int, st
                 out_pix=Ho * Wo, out_pitch=Co, wt_taps=k * k, flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
 
 
+def halo_wgrad_ok(x: torch.Tensor, dy: torch.Tensor, k: int, stride: int, pad: int) -> bool:
+    N, H, W, Ci = x.shape
+    Co = dy.shape[-1]
+    return HALO_WGRAD and k == 3 and stride == 1 and pad == 1 and W <= 29 and H * W >= 100 and Ci % 64 == 0 and Co % 64 == 0
+
+
+def conv3x3_wgrad_multi(problems: Sequence[tuple]) -> None:
+    """problems: up to four (x, dy, dw) of ONE geometry (halo_wgrad_ok): one launch whose workgroups are divided among them."""
+    x0, dy0, _ = problems[0]
+    N, H, W, Ci = x0.shape
+    Co = dy0.shape[-1]
+    n = len(problems)
+    nfl = _query("svsr_conv3x3_wgrad_multi_floats", n, N, H, W, Ci, Co)[0]
+    part = scratch(nfl) if nfl else None
+    PtrArr = ctypes.c_void_p * n
+    xs, dys, dws = PtrArr(*[p[0].data_ptr() for p in problems]), PtrArr(*[p[1].data_ptr() for p in problems]), PtrArr(*[p[2].data_ptr() for p in problems])
+    _call("svsr_conv3x3_wgrad_multi", xs, dys, dws, n, N, H, W, Ci, Co, _p(part), nfl, _stream(), label="k_wgrad3x3_halo",
+          flops=2.0 * n * N * H * W * Co * Ci * 9)
+
+
 def linear_fwd(x: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor], *, rows: int, K: int, N: int, x_pitch: int,
                out: Optional[torch.Tensor] = None, out_pitch: Optional[int] = None, gelu: bool = False,
                out_f32: bool = False, addend: Optional[torch.Tensor] = None,
@@ -879,9 +899,21 @@ def add_ln_fwd(a, r, gamma, beta, eps: float):
     return y, mean, rstd
 
 
-def add_ln_bwd(dy, a, r, gamma, mean, rstd, dgamma, dbeta, addend=None, out=None) -> torch.Tensor:
+def colsum_rows(part, rows: int, ld: int, out0, n0: int, out1=None, n1: int = 0) -> None:
+    _call("svsr_colsum_rows", _p(part), rows, ld, _p(out0), n0, _p(out1), n1, 1, 1.0, _stream())
+
+
+def add_ln_bwd(dy, a, r, gamma, mean, rstd, dgamma, dbeta, addend=None, out=None, defer: Optional[list] = None) -> torch.Tensor:
+    """defer = a list: the parameter-gradient reduction is not launched; a closure that launches it (on whatever stream is current when it
+    is called) is appended instead — the partial rows then live in a buffer of their own."""
     R, D = a.shape
     ds = torch.empty_like(a) if out is None else out
+    if defer is not None:
+        rows = _query("svsr_add_ln_bwd_rows", R)[0]
+        part = torch.empty(rows * 2 * D, dtype=torch.float32, device=a.device)
+        _call("svsr_add_ln_bwd_partials", _p(dy), _p(a), _p(r), _p(gamma), _p(mean), _p(rstd), _p(ds), R, D, _p(addend), _p(part), _stream())
+        defer.append((lambda: colsum_rows(part, rows, 2 * D, dgamma, D, dbeta, D), part))
+        return ds
     part = scratch(_query("svsr_add_ln_bwd_rows", R)[0] * 2 * D)
     _call("svsr_add_ln_bwd", _p(dy), _p(a), _p(r), _p(gamma), _p(mean), _p(rstd), _p(ds), _p(dgamma), _p(dbeta), R, D, _p(addend), _p(part),
           _stream())
@@ -1007,11 +1039,16 @@ def xt_embed_bwd(dx0, dcls, B: int, S: int, F: int, D: int, drop=None) -> torch.
     return dfeats
 
 
-def bias_act_bwd(dy, z, db, *, R: int, N: int, n_valid: int, ld: int, relu: bool = False, gscale: float = 1.0) -> torch.Tensor:
+def bias_act_bwd(dy, z, db, *, R: int, N: int, n_valid: int, ld: int, relu: bool = False, gscale: float = 1.0, defer: Optional[list] = None) -> torch.Tensor:
     """db[:n_valid] += column sums of dz, where dz = dy * act'(z) if z is given (returned) else dy; act = GELU from the
     pre-activation z, or (relu=True) ReLU from the saved output z."""
     dz = torch.empty_like(dy) if z is not None else None
     rows = _query("svsr_bias_act_bwd_rows", R, N)[0] if db is not None else 0
+    if defer is not None and rows:
+        part = torch.empty(rows * N, dtype=torch.float32, device=dy.device)
+        _call("svsr_bias_act_bwd_partials", _p(dy), _p(z), _p(dz), _p(db), R, N, n_valid, ld, 2 if relu else 1, float(gscale), _p(part), _stream())
+        defer.append((lambda: colsum_rows(part, rows, N, db, n_valid), part))
+        return dz if z is not None else dy
     part = scratch(rows * N) if rows else None
     _call("svsr_bias_act_bwd", _p(dy), _p(z), _p(dz), _p(db), R, N, n_valid, ld, 2 if relu else 1, float(gscale), _p(part), _stream())
     return dz if z is not None else dy
