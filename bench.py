@@ -203,6 +203,19 @@ def build_lrs(args, dev, world: int, rank: int):
     return model, cfg, batch, lrs_args, int(cpu_batch[1].sum()), cpu_batch[3].shape[-1]
 
 
+def host_idle_queue_ms(trainer, batch, reps: int = 3) -> float:
+    """Host time of one step's enqueue onto an EMPTY queue (median of `reps`): inside the timed loop the host runs ahead of the GPU until
+    the launch queue is full and then waits for slots, so the in-loop figure of a step with thousands of launches measures the GPU."""
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        trainer.step(*batch)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
+    return sorted(ts)[len(ts) // 2]
+
+
 def lrs_leg(args, dev) -> dict:
     """A short, bounded LRS measurement attached to the default (LRW) line, so that BASELINE configs[3] gets a driver-timed number:
     warm-up, `args.lrs_steps` timed steps (barrier + synchronize on both sides), then one eager step with per-launch HIP events."""
@@ -210,7 +223,8 @@ def lrs_leg(args, dev) -> dict:
     from syncvsr_amd.engine import TrainStep
 
     model, cfg, batch, lrs_args, n_frames, label_len = build_lrs(args, dev, 1, 0)
-    trainer = TrainStep(model, cfg)
+    native = args.enqueue == "native"
+    trainer = TrainStep(model, cfg, native=native)
     for _ in range(3):
         trainer.step(*batch)
     torch.cuda.synchronize()
@@ -222,11 +236,13 @@ def lrs_leg(args, dev) -> dict:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ms = elapsed / args.lrs_steps * 1e3
+    host_idle = host_idle_queue_ms(trainer, batch)
     flops = lrs_train_flops(args.lrs_batch, args.frames, label_len)
+    prof = TrainStep(model, cfg, data_parallel=False)          # eager in-line steps with per-launch HIP events
     model._side.enabled = model._side.enabled_small = False
-    trainer._step_impl(*batch)
+    prof._step_impl(*batch)
     ops.start_event_timing()
-    trainer._step_impl(*batch)
+    prof._step_impl(*batch)
     table = ops.stop_event_timing()
     rows = {}
     for k, v in table.items():          # "+bn" launches are counted with their kernel
@@ -240,12 +256,13 @@ def lrs_leg(args, dev) -> dict:
     return {
         "metric": f"lip-clips/sec training (LRS, <= {args.frames}x88x88)", "value": round(args.lrs_batch * 1e3 / ms, 2), "unit": "clips/s",
         "ms_per_step": round(ms, 3), "steps": args.lrs_steps, "padded_frames_per_s": round(args.lrs_batch * args.frames * 1e3 / ms, 1),
-        "host_enqueue_ms": round(host_ms[len(host_ms) // 2], 3) if host_ms else None,
+        "host_enqueue_ms": round(host_idle, 3), "host_enqueue_in_loop_ms": round(host_ms[len(host_ms) // 2], 3) if host_ms else None,
+        "launches_per_step": int(trainer._rec.size) if getattr(trainer, "_rec", None) is not None else None,
         "step_mfma_frac": round(flops / (ms * 1e-3) / MFMA_PEAK_BF16, 5), "final_loss": round(float(out[0].item()), 4),
         "config": {"workload": "LRS training step (fwd+bwd+clip+AdamW): Conv3d/ResNet18(Swish) front-end + 12-layer 768-d Conformer + CTC + 6-layer "
                                f"attention decoder + vq audio-token CE head (config/lrs3.yaml, 252 M parameters), random-init weights, N(0,1) clips, one "
                                f"length bucket padded to {args.frames} frames, dropout {args.dropout}",
-                   "per_gpu_batch": args.lrs_batch, "valid_frames": n_frames, "enqueue": "eager (python)"},
+                   "per_gpu_batch": args.lrs_batch, "valid_frames": n_frames, "enqueue": "native step list" if native else "eager (python)"},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                      "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 5), "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches"],
                      "per_kernel": {k: {"ms_per_step": round(v["ms"], 4), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "launches": v["launches"]}
@@ -335,7 +352,7 @@ def main() -> None:
         cfg.train.batch_size = args.batch
         model = Model(cfg, seed=0).to(dev).train()
         batch = [t.to(dev) for t in synthetic_batch(cfg, args.batch, seed=1234 + rank)]
-    native = args.enqueue == "native" and args.workload == "lrw" and not use_graph
+    native = args.enqueue == "native" and args.workload in ("lrw", "lrs") and not use_graph
     trainer = TrainStep(model, cfg, use_graph=use_graph, always_reduce=args.force_collective, bucket_mb=args.bucket_mb,
                         grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32, native=native)
 
@@ -356,6 +373,7 @@ def main() -> None:
     host_ms = sorted(trainer.host_ms)
     barrier()
     elapsed = time.perf_counter() - t0
+    host_idle = host_idle_queue_ms(trainer, batch) if not use_dist else None
     if use_dist and world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -385,6 +403,8 @@ def main() -> None:
                    "hip_graph": use_graph, "enqueue": "hip_graph" if use_graph else ("native step list" if native else "eager (python)")},
         # host time of one step's enqueue (median over the timed steps, this rank): below ms_per_step the GPU is the limit
         "host_enqueue_ms": round(host_ms[len(host_ms) // 2], 4) if host_ms else None,
+        "host_enqueue_idle_queue_ms": round(host_idle, 4) if host_idle is not None else None,
+        "launches_per_step": int(trainer._rec.size) if getattr(trainer, "_rec", None) is not None else None,
         "step_mfma_frac": round(clips_per_s / world * TRAIN_FLOP_PER_CLIP / MFMA_PEAK_BF16, 5),
         "final_loss": round(loss, 4),
     }

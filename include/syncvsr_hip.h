@@ -318,6 +318,9 @@ int svsr_enc_fwd(const void* x0, const svsr_enc_layer* layers, int n_layers, int
 
 int svsr_word_add(int* word, int delta, hipStream_t stream);
 int svsr_lincomb2(const float* a, const float* b, float wb, float* out, hipStream_t stream);
+/* out0 = (wa*a + wb*b) + wc*c with one rounding per product and per sum (what `mtlalpha * loss_ctc + (1 - mtlalpha) * loss_att + w * loss_audio` gives
+ * in torch, reference LRS e2e_asr_transformer.py:217-224), and out1 = num / den (the token accuracy) when out1 is not null: 0-d device values */
+int svsr_lincomb3_ratio(const float* a, float wa, const float* b, float wb, const float* c, float wc, float* out0, const float* num, const float* den, float* out1, hipStream_t stream);
 
 /* Device-side input pipeline (reference LRW/video/src/data.py:150,157-171: x/255 -> RandomHorizontalFlip ->
  * RandomResizedCrop | CenterCrop -> Normalize(0.421, 0.165)): stored uint8 clips [B][T][Hs][Ws] -> fp32 model input

@@ -329,6 +329,19 @@ __global__ void k_lincomb2(const float* a, const float* b, float wb, float* out)
     }
 }
 
+// out0 = (wa * a + wb * b) + wc * c with torch's roundings (three mul kernels, two add kernels); out1 = n / d (the sentence-level model's
+// loss and token accuracy: e2e_asr_transformer.py:217-224)
+__global__ void k_lincomb3_ratio(const float* a, float wa, const float* b, float wb, const float* c, float wc, float* out0, const float* n, const float* d, float* out1) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float t1 = wa * a[0], t2 = wb * b[0], t3 = wc * c[0];
+        asm volatile("" : "+v"(t1), "+v"(t2), "+v"(t3));
+        float s = t1 + t2;
+        asm volatile("" : "+v"(s));
+        out0[0] = s + t3;
+        if (out1 != nullptr) out1[0] = n[0] / d[0];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_video_cast(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = f2bf(src[i]);
 }
@@ -465,6 +478,13 @@ int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream) {
 int svsr_word_add(int* word, int delta, hipStream_t stream) {
     if (word == nullptr) return SVSR_ERR_ARG;
     hipLaunchKernelGGL(k_word_add, dim3(1), dim3(64), 0, stream, word, delta);
+    return svsr_check_launch();
+}
+
+int svsr_lincomb3_ratio(const float* a, float wa, const float* b, float wb, const float* c, float wc, float* out0, const float* num, const float* den,
+                        float* out1, hipStream_t stream) {
+    if (a == nullptr || b == nullptr || c == nullptr || out0 == nullptr || (out1 != nullptr && (num == nullptr || den == nullptr))) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_lincomb3_ratio, dim3(1), dim3(64), 0, stream, a, wa, b, wb, c, wc, out0, num, den, out1);
     return svsr_check_launch();
 }
 

@@ -108,8 +108,8 @@ class TrainStep:
         self.native = bool(native)
         if self.native and use_graph:
             raise ValueError("native=True and use_graph=True are two ways of replaying a step: pick one")
-        if self.native and not self.is_lrw:
-            raise NotImplementedError("native=True is implemented for the LRW model (the LRS forward prepares its targets with torch ops)")
+        if self.native and not self.is_lrw and getattr(model, "length_norm", False):
+            raise NotImplementedError("native=True: transformer_length_normalized_loss needs a torch kernel inside the step (use native=False)")
         if self.native and getattr(model, "layer_drop_p", 0.0) > 0.0:
             raise NotImplementedError("layer_dropout changes the launch sequence from step to step: it cannot be replayed from a recorded list")
         self._rec: Optional[ops.StepRecorder] = None
@@ -199,20 +199,22 @@ class TrainStep:
             if model._side.stream is None:
                 model._side.stream = torch.cuda.Stream()
             model.direct_constants(self._static[0].device)
-            if getattr(model, "_drop_word", None) is None and (model.drop_p > 0.0 or model.attn_drop_p > 0.0 or model.emb_drop_p > 0.0):
+            if getattr(model, "_drop_word", None) is None and (model.drop_p > 0.0 or model.attn_drop_p > 0.0 or getattr(model, "emb_drop_p", 0.0) > 0.0):
                 model._advance_dropout(self._static[0].device)      # creates the seed word outside the recorded region ...
                 ops.word_add(model._drop_word, -1)                   # ... and leaves its value where the first forward expects it
             rec = ops.StepRecorder()
             with ops.recording(rec):
                 out = self._direct_impl(*self._static)
             self._rec = rec
-            self._out = {k: v.detach() for k, v in out.items()}
+            self._out = {k: v.detach() for k, v in out.items()} if isinstance(out, dict) else tuple(v.detach() for v in out)
             self._main_stream = rec.main_stream
             return self._out
+        if not self.is_lrw:          # LRS: the conversions (and the decoder / CTC targets) are redone per batch, then copied into the static inputs
+            batch = model.prepare_batch(*batch)
         for dst, src in zip(self._static, batch):
             if not torch.is_tensor(dst):
                 continue
-            if dst.shape[0] != src.shape[0] or dst.shape[2:] != src.shape[2:]:
+            if dst.shape[0] != src.shape[0] or dst.shape[2:] != src.shape[2:] or (not self.is_lrw and dst.shape != src.shape):
                 raise ValueError("a recorded TrainStep needs fixed batch shapes (pad to the recorded size or use native=False)")
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src if src.dim() != 2 or src.shape[1] == dst.shape[1] else src[:, : dst.shape[1]], non_blocking=True)

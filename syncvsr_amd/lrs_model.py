@@ -30,7 +30,7 @@ def _sinusoid(positions: torch.Tensor, d_model: int) -> torch.Tensor:
     """transformer/embedding.py:54-76 / :180-199 — sin on even, cos on odd columns, computed in fp32 like the reference."""
     div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / d_model))
     ang = positions.float().unsqueeze(1) * div
-    pe = torch.zeros(positions.numel(), d_model)
+    pe = torch.empty(positions.numel(), d_model)
     pe[:, 0::2] = torch.sin(ang)
     pe[:, 1::2] = torch.cos(ang)
     return pe
@@ -273,7 +273,7 @@ class E2E(nn.Module):
     def _advance_dropout(self, dev: torch.device) -> None:
         if self._drop_word is None or self._drop_word.device != dev:
             self._drop_word = torch.tensor([self.dropout_seed], dtype=torch.int32, device=dev)
-        self._drop_word.add_(1)                   # a device op: graph replays keep drawing fresh masks
+        ops.word_add(self._drop_word, 1)          # a device op (a library launch: recorded by a native step list): replays keep drawing fresh masks
 
     def reseed_dropout(self, seed: int) -> None:
         self.dropout_seed = int(seed)
@@ -370,6 +370,47 @@ class E2E(nn.Module):
                                                                     torch.is_grad_enabled())
         loss = self.mtlalpha * loss_ctc + (1 - self.mtlalpha) * loss_att + self.audio_weight * loss_audio
         acc = counts[0] / counts[1]
+        return loss, loss_ctc, loss_att, loss_audio, acc
+
+
+    # ------------------------------------------------------------------------------------------------
+    # native step list (engine.TrainStep(native=True)): the same tape functions without autograd or torch kernels
+    def prepare_batch(self, x, lengths, audios, label):
+        """The input conversions of forward(), done ahead of it (outside any recorded region): what engine.TrainStep keeps as the static
+        inputs of a recorded step.  The decoder / CTC targets (add_sos_eos, e2e_asr_transformer.py:203-215) are derived here, once per batch."""
+        if x.dim() != 5 or x.size(2) != 1:
+            raise ValueError("x must be [B, T, 1, H, W]")
+        T, A = x.size(1), self.audio_alignment
+        if audios.dtype != torch.int64 or audios.dim() != 3 or audios.size(1) < T * A:
+            raise ValueError(f"pass pre-computed audio tokens int64 [B, >= {T * A}, G] in the `audios` slot (SURVEY §8b)")
+        tg = label if isinstance(label, LrsTargets) else self.prepare_targets(label.to(x.device))
+        self._pos_table("rel", T, x.device)                 # position tables of this shape exist before a step is recorded
+        self._pos_table("abs", tg.ys_in.size(1), x.device)
+        return (x.float().contiguous(), lengths.to(device=x.device, dtype=torch.int32).contiguous(), audios[:, : T * A].contiguous(),
+                tg.labels, tg.ys_in, tg.ys_out)
+
+    def direct_constants(self, dev) -> None:
+        """d loss / d {loss_ctc, loss_att, loss_audio} as device scalars (made once, outside any recorded region)."""
+        if getattr(self, "_g_consts", None) is None or self._g_consts[0].device != dev:
+            self._g_consts = tuple(torch.full((), w, dtype=torch.float32, device=dev) for w in (self.mtlalpha, 1.0 - self.mtlalpha, self.audio_weight))
+
+    def train_step_direct(self, x, ilen, tokens, labels, ys_in, ys_out):
+        """forward + backward of the loss WITHOUT autograd (inputs as prepare_batch returns them): every device operation is a library call,
+        so the step can be recorded into a native step list.  -> (loss, loss_ctc, loss_att, loss_audio, acc) as forward()."""
+        if self.length_norm:
+            raise NotImplementedError("transformer_length_normalized_loss divides by a device value with a torch kernel: use the autograd path")
+        st = self.store()
+        self.direct_constants(x.device)
+
+        class _Ctx:
+            def mark_non_differentiable(self, *a):
+                pass
+
+        ctx = _Ctx()
+        tg = LrsTargets(labels, ys_in, ys_out)
+        loss_ctc, loss_att, loss_audio, counts = _LrsFunction.forward(ctx, None, self, st, x, ilen, tokens, tg, True)
+        loss, acc = ops.lincomb3_ratio(loss_ctc, self.mtlalpha, loss_att, 1.0 - self.mtlalpha, loss_audio, self.audio_weight, counts[0:1], counts[1:2])
+        _LrsFunction.backward(ctx, *self._g_consts, None)
         return loss, loss_ctc, loss_att, loss_audio, acc
 
 
@@ -649,7 +690,7 @@ class _LrsFunction(torch.autograd.Function):
                 ctc_branch()
         else:                                      # `loss_ctc = 0` (e2e_asr_transformer.py:205-208)
             dctc = h_ctc = logits_c = ctc_state = None
-            loss_c = torch.zeros((), dtype=torch.float32, device=x.device)
+            loss_c = ops.zeros((), torch.float32, x.device)
         # attention decoder + label smoothing (decoder.py:122-151, label_smoothing_loss.py:41-63)
         # proj_decoder when the decoder is narrower/wider than the encoder (e2e_asr_transformer.py:93-95,209-210)
         memory = _lin(st, h, "proj_decoder", R, D, model.ddim) if model.adim != model.ddim else h
@@ -693,13 +734,13 @@ class _LrsFunction(torch.autograd.Function):
 
         g_ctc, g_att, g_audio = scalar(g_ctc), scalar(g_att), scalar(g_audio)
         h = th["h"]
-        dh = torch.zeros((R, D), dtype=BF16, device=dev)
+        dh = ops.zeros((R, D), BF16, dev)
         # decoder first: its parameters sit at the end of the flat gradient buffer
         if model.length_norm:
             g_att = (g_att / th["counts"][1]).contiguous()
         dpred = ops.ls_loss_bwd(th["pred"], Vp, th["tgt"], B * L, Vo, model.lsm_weight, th["inv_denom"], th["lse_p"], g_att, Vp)
         if model.adim != model.ddim:
-            dmem = torch.zeros((R, model.ddim), dtype=BF16, device=dev)
+            dmem = ops.zeros((R, model.ddim), BF16, dev)
             _decoder_bwd(model, st, tape, tg, dpred, th["memory"], dmem, B, T)
             _lin_bwd(model, st, "proj_decoder", h, dmem, R, D, model.ddim, addend=dh, out=dh)
         else:

@@ -339,6 +339,14 @@ def lincomb2(a: torch.Tensor, b: torch.Tensor, wb: float) -> torch.Tensor:
     return out
 
 
+def lincomb3_ratio(a, wa: float, b, wb: float, c, wc: float, num=None, den=None):
+    """0-d fp32 (wa*a + wb*b) + wc*c and, with num / den, their quotient: on the device, torch's roundings."""
+    out0 = torch.empty((), dtype=torch.float32, device=a.device)
+    out1 = torch.empty((), dtype=torch.float32, device=a.device) if num is not None else None
+    _call("svsr_lincomb3_ratio", _p(a), float(wa), _p(b), float(wb), _p(c), float(wc), _p(out0), _p(num), _p(den), _p(out1), _stream())
+    return out0, out1
+
+
 def _call(name: str, *args, label: Optional[str] = None, flops: float = 0.0, nbytes: float = 0.0) -> None:
     timing = _TIMING
     if timing is not None:

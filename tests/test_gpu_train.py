@@ -391,3 +391,47 @@ def test_checkpoint_resume_lrw_with_dropout():
     ts3.load_state_dict({k: v.to(dev) for k, v in ckpt_opt.items()})
     resumed = [ts3.step(*gb)["loss_total"].item() for _ in range(2)]
     assert first + resumed == ref, (first + resumed, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["lrs_tiny", "lrs_tiny_b3"])
+def test_lrs_native_step_list_equals_eager_steps(case):
+    """The sentence-level model under engine.TrainStep(native=True): decoder / CTC targets are prepared ahead of the recorded region
+    (E2E.prepare_batch; reference add_sos_eos.py:12-31 via e2e_asr_transformer.py:203-215), the loss combination and the token accuracy
+    are library launches — losses, parameters, running statistics and optimiser state equal the eager steps bit for bit, dropout on."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from golden_cases import build_lrs_case
+    from syncvsr_amd.engine import TrainStep, lrs_train_config
+    from syncvsr_amd.lrs_model import E2E
+
+    dev = torch.device("cuda:0")
+    args, odim, sd, batch, training, gold = build_lrs_case(case, load_golden=False)
+    args.dropout_rate = 0.1
+    args.transformer_attn_dropout_rate = 0.1
+    gb = [t.to(dev) for t in batch]
+    cfg = lrs_train_config(scheduler__num_warmup_steps=1)
+
+    def run(native):
+        model = E2E(odim, args, seed=3)
+        model.load_state_dict(sd)
+        model.to(dev).train()
+        ts = TrainStep(model, cfg, native=native)
+        outs = [[v.clone() for v in ts.step(*gb)] for _ in range(4)]
+        torch.cuda.synchronize()
+        st = model.store()
+        return outs, st.flat.clone(), st.bufflat.clone(), ts.opt_state.clone(), ts
+
+    eager, native = run(False), run(True)
+    assert native[4]._rec is not None and native[4]._rec.size > 100, "the step was not recorded"
+    for i, (a, b) in enumerate(zip(eager[0], native[0])):
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), f"step {i}: output {k} eager {x.item()} native {y.item()}"
+    for what, x, y in zip(("parameters", "running statistics", "optimiser state"), eager[1:4], native[1:4]):
+        assert torch.equal(x, y), f"{what}: {int((x != y).sum())} elements differ between eager and native steps"
+    losses = [o[0].item() for o in native[0]]
+    assert len(set(losses)) == 4, f"the replayed steps must keep training (and drawing fresh dropout masks): {losses}"
+    nb = [t.clone() for t in gb]
+    nb[0] = nb[0] * 0.5
+    out = native[4].step(*nb)
+    assert torch.isfinite(out[0]).item()
