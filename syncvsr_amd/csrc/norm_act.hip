@@ -15,7 +15,7 @@
 // running estimate).  Block = 16 channels x 64 row lanes (1024 threads): with ~1000 partial rows every lane walks ~16 rows, four
 // row pairs in flight — the launch is a few microseconds of pure latency, and there are 40 of them per step.
 // ---------------------------------------------------------------------------------------------------------
-#define BNF_CL 16
+#define BNF_CL 4      // 256-thread blocks: a 1,024-thread block needs a CU with 16 free wave slots, and under a side-stream weight gradient (two ~200-register workgroups per CU) no CU has them — the finaliser, 5 us of work on the critical path, then waited 25-35 us for a whole CU to drain
 #define BNF_RL 64
 __device__ __forceinline__ void bn_rows_sum(const float* __restrict__ part, int nrows, int C, int c, bool live, int rl, int cl,
                                             double (*sred)[2][BNF_CL], double& s, double& q) {
@@ -52,7 +52,7 @@ __device__ __forceinline__ void bn_rows_sum(const float* __restrict__ part, int 
     }
 }
 
-__global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ part, int nrows, int C, float count, float eps, float momentum,
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ part, int nrows, int C, float count, float eps, float momentum,
                                                       float* mean, float* rstd, float* running_mean, float* running_var,
                                                       long* num_batches_tracked) {
     __shared__ double sred[BNF_RL][2][BNF_CL];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd_reduce(const bf16_t* __restr
 
 // finalise the backward statistics (rows added in the same fixed order as k_bn_finalize):
 // dbeta += sum g, dgamma += sum g*xhat, coef = {gamma*rstd, sum g / n, sum g*xhat / n}
-__global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float* __restrict__ part, int nrows, int C, float count, const float* gamma,
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ part, int nrows, int C, float count, const float* gamma,
                                                           const float* rstd, float* dgamma, float* dbeta, float* coef) {
     __shared__ double sred[BNF_RL][2][BNF_CL];
     const int cl = threadIdx.x % BNF_CL, rl = threadIdx.x / BNF_CL;
@@ -807,7 +807,7 @@ extern "C" {
 int svsr_bn_finalize(const float* part, int nrows, int C, float count, float eps, float momentum, float* mean, float* rstd,
                      float* running_mean, float* running_var, int64_t* num_batches_tracked, hipStream_t stream) {
     if (nrows < 1 || C < 1) return SVSR_ERR_ARG;
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, part, nrows, C, count, eps, momentum, mean, rstd,
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(BNF_CL * BNF_RL), 0, stream, part, nrows, C, count, eps, momentum, mean, rstd,
                        running_mean, running_var, (long*)num_batches_tracked);
     return svsr_check_launch();
 }
@@ -844,7 +844,7 @@ int svsr_bn_act_bwd(const void* dy, const void* y, const void* x, const float* m
                        (const bf16_t*)x, mean, rstd, coef, (bf16_t*)dx, (bf16_t*)dres, nvec, C, gamma, beta, (const bf16_t*)res)
     if (act < 0 || act > 2) return SVSR_ERR_ARG;
     if (act == 2) SVSR_BN_BWD_REDUCE(2); else if (act == 1) SVSR_BN_BWD_REDUCE(1); else SVSR_BN_BWD_REDUCE(0);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, slots, grid, C, (float)npix, gamma, rstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(BNF_CL * BNF_RL), 0, stream, slots, grid, C, (float)npix, gamma, rstd, dgamma, dbeta, coef);
     if (act == 2) SVSR_BN_BWD_APPLY(2); else if (act == 1) SVSR_BN_BWD_APPLY(1); else SVSR_BN_BWD_APPLY(0);
     return svsr_check_launch();
 }
@@ -856,7 +856,7 @@ int svsr_bn_bwd_from_stats(const void* g, const void* x, const float* mean, cons
                            int nrows, float* coef, float* dgamma, float* dbeta, void* dx, int64_t npix, int C, hipStream_t stream) {
     if (!chan_ok_any(C) || nrows < 1 || npix < 1 || g == nullptr || x == nullptr || stats == nullptr || dx == nullptr) return SVSR_ERR_ARG;
     const long nvec = npix * (C / 8);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, stats, nrows, C, (float)npix, gamma, rstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(BNF_CL * BNF_RL), 0, stream, stats, nrows, C, (float)npix, gamma, rstd, dgamma, dbeta, coef);
     hipLaunchKernelGGL(k_bn_act_bwd_apply<0>, dim3(ew_grid_for(nvec, C)), dim3(256), 0, stream, (const bf16_t*)g, (const bf16_t*)nullptr,
                        (const bf16_t*)x, mean, rstd, coef, (bf16_t*)dx, (bf16_t*)nullptr, nvec, C, gamma, (const float*)nullptr, (const bf16_t*)nullptr);
     return svsr_check_launch();
@@ -934,7 +934,7 @@ int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x
             else
                 hipLaunchKernelGGL(k_stem_bwd_reduce_win<1>, gg, dim3(256), 0, stream, (const bf16_t*)dpool, (const bf16_t*)xwin, mean, rstd, gamma, beta,
                                    (bf16_t*)gpool, slots, Hp, Wp);
-            hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
+            hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(BNF_CL * BNF_RL), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
                                dgamma, dbeta, coef);
             if (act == SVSR_ACT_SWISH)
                 hipLaunchKernelGGL((k_stem_bwd_lds<2, true, true>), g2, dim3(256), lds_b, stream, (const bf16_t*)gpool, (const unsigned char*)amax, (const bf16_t*)x,
@@ -955,7 +955,7 @@ int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x
                 hipLaunchKernelGGL(k_stem_bwd_reduce_gather<1>, gg, dim3(256), lds_g, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
                                    (const bf16_t*)x, mean, rstd, gamma, beta, slots, Hc, Wc, Hp, Wp);
         } else if (act == SVSR_ACT_SWISH) SVSR_STEM_BWD(2, false); else SVSR_STEM_BWD(1, false);
-        hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
+        hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(BNF_CL * BNF_RL), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
                            dgamma, dbeta, coef);
         if (act == SVSR_ACT_SWISH) SVSR_STEM_BWD(2, true); else SVSR_STEM_BWD(1, true);
         return svsr_check_launch();
@@ -967,7 +967,7 @@ int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x
     else
         hipLaunchKernelGGL(k_stem_pool_bwd_reduce<1>, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,
                            (const bf16_t*)x, mean, rstd, gamma, beta, N, Hc, Wc, Hp, Wp, C, slots, it);
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(1024), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(BNF_CL * BNF_RL), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
                        dgamma, dbeta, coef);
     if (act == SVSR_ACT_SWISH)
         hipLaunchKernelGGL(k_stem_pool_bwd_apply<2>, grid, dim3(256), 0, stream, (const bf16_t*)dpool, (const unsigned char*)amax,

@@ -21,7 +21,7 @@ import torch.nn as nn
 from . import ops
 from .config import Config
 from .lrs_init import LRS_ODIM, lrs_audio_dims, lrs_buffer_specs, lrs_init_state_dict, lrs_param_specs
-from .model import BF16, _Holder, _SideStream, _ParamStore, _attach, _frontend_backward, _frontend_forward, _get, _bn_stats, _ready
+from .model import BF16, _Holder, _SideStream, _ParamStore, _attach, _defer_list, _frontend_backward, _frontend_forward, _get, _bn_stats, _ready
 
 LN_EPS = 1e-12          # transformer/layer_norm.py:19
 
@@ -443,8 +443,10 @@ def _ln(st: _ParamStore, x, name: str):
     return ops.add_ln_fwd(x, None, st.p32(f"{name}.weight"), st.p32(f"{name}.bias"), LN_EPS)
 
 
-def _ln_bwd(st: _ParamStore, dy, x, name: str, m, r, addend=None):
-    return ops.add_ln_bwd(dy, x, None, st.p32(f"{name}.weight"), m, r, st.g32(f"{name}.weight"), st.g32(f"{name}.bias"), addend=addend)
+def _ln_bwd(model, st: _ParamStore, dy, x, name: str, m, r, addend=None):
+    # (the gamma / beta reduction is postponed to the side stream: model._defer_list, flushed by _ready at the end of the layer)
+    return ops.add_ln_bwd(dy, x, None, st.p32(f"{name}.weight"), m, r, st.g32(f"{name}.weight"), st.g32(f"{name}.bias"), addend=addend,
+                          defer=_defer_list(model))
 
 
 def _branch_grad(dy, alpha: float, drop):
@@ -466,9 +468,9 @@ def _ffn_bwd(model, st, t: dict, dy, p: str, R: int, D: int, U: int, alpha: floa
     dys = _branch_grad(dy, alpha, t["do"])
     dh = _lin_bwd(model, st, f"{p}.w_2", t["h"], dys, R, U, D)
     gs = 1.0 / (1.0 - t["dh"][2]) if t["dh"] is not None else 1.0           # dropped hidden units are the zeros of the saved h
-    dz = ops.bias_act_bwd(dh, t["h"], st.g32(f"{p}.w_1.bias"), R=R, N=U, n_valid=U, ld=U, relu=True, gscale=gs)
+    dz = ops.bias_act_bwd(dh, t["h"], st.g32(f"{p}.w_1.bias"), R=R, N=U, n_valid=U, ld=U, relu=True, gscale=gs, defer=_defer_list(model))
     dtn = _lin_bwd(model, st, f"{p}.w_1", t["tn"], dz, R, D, U, bias=False)
-    return _ln_bwd(st, dtn, t["x"], norm, t["m"], t["r"], addend=dy)
+    return _ln_bwd(model, st, dtn, t["x"], norm, t["m"], t["r"], addend=dy)
 
 
 def _encoder_layer_fwd(model: E2E, st: _ParamStore, tape: dict, i: int, x, pos16, ilen, B: int, T: int, training: bool):
@@ -511,7 +513,7 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
     p = f"encoder.encoders.{i}"
     t = tape[p]
     tf = t["final"]
-    dx4 = _ln_bwd(st, dxo, tf["x"], f"{p}.norm_final", tf["m"], tf["r"])
+    dx4 = _ln_bwd(model, st, dxo, tf["x"], f"{p}.norm_final", tf["m"], tf["r"])
     dx3 = _ffn_bwd(model, st, t["ff"], dx4, f"{p}.feed_forward", R, D, U, 0.5, f"{p}.norm_ff")
     # convolution module
     tc = t["conv"]
@@ -533,7 +535,7 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
     du = ops.glu_dwconv_bwd(dc, tc["u"], st.p32(f"{cm}.depthwise_conv.weight"), st.g32(f"{cm}.depthwise_conv.weight"),
                             st.g32(f"{cm}.depthwise_conv.bias"), B, T, D, K)
     dt3 = _lin_bwd(model, st, f"{cm}.pointwise_cov1", tc["tn"], du, R, D, 2 * D)
-    dx2 = _ln_bwd(st, dt3, tc["x"], f"{p}.norm_conv", tc["m"], tc["r"], addend=dx3)
+    dx2 = _ln_bwd(model, st, dt3, tc["x"], f"{p}.norm_conv", tc["m"], tc["r"], addend=dx3)
     # attention
     tm = t["mha"]
     sa = f"{p}.self_attn"
@@ -543,11 +545,13 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
     dq_ac, dq_bd, dpe = ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, tm["probs"], B=B, H=H, Lq=T, Lk=T, dq=dqkv,
                                     dq_pitch=3 * D, dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, pe=tm["pe"],
                                     bias_u=st.p32(f"{sa}.pos_bias_u"), bias_v=st.p32(f"{sa}.pos_bias_v"), drop=tm["dpr"])
-    ops.bias_act_bwd(dq_ac, None, st.g32(f"{sa}.pos_bias_u"), R=R, N=D, n_valid=D, ld=D)
-    ops.bias_act_bwd(dq_bd, None, st.g32(f"{sa}.pos_bias_v"), R=R, N=D, n_valid=D, ld=D)
+    # pos_bias_u / pos_bias_v gradients: column sums nothing downstream reads — both launches on the side stream
+    gu, gv = st.g32(f"{sa}.pos_bias_u"), st.g32(f"{sa}.pos_bias_v")
+    model._side.run(lambda: (ops.bias_act_bwd(dq_ac, None, gu, R=R, N=D, n_valid=D, ld=D), ops.bias_act_bwd(dq_bd, None, gv, R=R, N=D, n_valid=D, ld=D)),
+                    dq_ac, dq_bd, small=True)
     _lin_bwd(model, st, f"{sa}.linear_pos", pos16, dpe, 2 * T - 1, D, D, bias=False, need_dx=False)
     dt2 = _lin_bwd(model, st, f"{sa}.linear_q", tm["tn"], dqkv, R, D, 3 * D, tkey=f"{sa}.qkv")
-    dx1 = _ln_bwd(st, dt2, tm["x"], f"{p}.norm_mha", tm["m"], tm["r"], addend=dx2)
+    dx1 = _ln_bwd(model, st, dt2, tm["x"], f"{p}.norm_mha", tm["m"], tm["r"], addend=dx2)
     dx = _ffn_bwd(model, st, t["ffm"], dx1, f"{p}.feed_forward_macaron", R, D, U, 0.5, f"{p}.norm_ff_macaron")
     _ready(model, st, f"{p}.self_attn.linear_q.weight")
     return dx
@@ -598,7 +602,7 @@ def _decoder_bwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, dpred,
     L, Vp, V = to["L"], to["Vp"], model.odim
     R = B * L
     dtn = _lin_bwd(model, st, "decoder.output_layer", to["tn"], dpred, R, D, V, dy_pitch=Vp)
-    dx = _ln_bwd(st, dtn, to["x"], "decoder.after_norm", to["m"], to["r"])
+    dx = _ln_bwd(model, st, dtn, to["x"], "decoder.after_norm", to["m"], to["r"])
     _ready(model, st, "decoder.output_layer.weight")
     for i in reversed(range(model.dlayers)):
         p = f"decoder.decoders.{i}"
@@ -612,7 +616,7 @@ def _decoder_bwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, dpred,
                     dv=dkv[:, D:], dkv_pitch=2 * D, drop=ts["dpr"])
         _lin_bwd(model, st, f"{p}.src_attn.linear_k", memory, dkv, B * T, D, 2 * D, tkey=f"{p}.src_attn.kv", addend=dmem, out=dmem)
         dt2 = _lin_bwd(model, st, f"{p}.src_attn.linear_q", ts["tn"], dq, R, D, D)
-        dx1 = _ln_bwd(st, dt2, ts["x"], f"{p}.norm2", ts["m"], ts["r"], addend=dx2)
+        dx1 = _ln_bwd(model, st, dt2, ts["x"], f"{p}.norm2", ts["m"], ts["r"], addend=dx2)
         tsf = t["self"]
         dctx = _lin_bwd(model, st, f"{p}.self_attn.linear_out", tsf["ctx"], _branch_grad(dx1, 1.0, tsf["dao"]), R, D, D)
         qkv = tsf["qkv"]
@@ -620,7 +624,7 @@ def _decoder_bwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, dpred,
         ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, tsf["probs"], B=B, H=H, Lq=L, Lk=L, dq=dqkv, dq_pitch=3 * D,
                     dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, drop=tsf["dpr"])
         dt1 = _lin_bwd(model, st, f"{p}.self_attn.linear_q", tsf["tn"], dqkv, R, D, 3 * D, tkey=f"{p}.self_attn.qkv")
-        dx = _ln_bwd(st, dt1, tsf["x"], f"{p}.norm1", tsf["m"], tsf["r"], addend=dx1)
+        dx = _ln_bwd(model, st, dt1, tsf["x"], f"{p}.norm1", tsf["m"], tsf["r"], addend=dx1)
         _ready(model, st, f"{p}.self_attn.linear_q.weight")
     ops.embed_pos_bwd(tg.ys_in, _branch_grad(dx, 1.0, tape["dec_embed_drop"]), st.g32("decoder.embed.0.weight"), D, math.sqrt(D))
     _ready(model, st, "decoder.embed.0.weight")
@@ -754,7 +758,7 @@ class _LrsFunction(torch.autograd.Function):
         ops.ce_bwd(th["logits_a"], V, th["tok"], None, R * A * G, V, 0.0, th["lse_a"], g_audio, dla, V)
         _lin_bwd(model, st, "audio_classifier", h, dla, R, D, NA, addend=dh, out=dh)
         _ready(model, st, "ctc.ctc_lo.weight" if th["logits_c"] is not None else "audio_classifier.weight")
-        dx = _ln_bwd(st, dh, th["hx"], "encoder.after_norm", th["mA"], th["rA"])
+        dx = _ln_bwd(model, st, dh, th["hx"], "encoder.after_norm", th["mA"], th["rA"])
         for i in reversed(range(model.elayers)):
             dx = _encoder_layer_bwd(model, st, tape, i, dx, th["pos16"], B, T)
         dfeats = _lin_bwd(model, st, "encoder.embed.0", th["feats"], _branch_grad(dx, math.sqrt(D), th["dex"]), R, 512, D)

@@ -663,6 +663,7 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
     dconv = ops.stem_bn_gelu_pool_bwd(dx, ts["amax"], ts["c"], ts["mean"], ts["rstd"], st.p32(f"{sb}.weight"), st.p32(f"{sb}.bias"),
                                       ws["coef"], st.g32(f"{sb}.weight"), st.g32(f"{sb}.bias"), model.stem_act, xwin=ts.get("xwin"))
     ops.stem_conv_wgrad(ts["videos"], dconv, st.g32(f"{sc}.weight"), use_tr)
+    _flush_deferred(model)
     model._side.join()
     _ready(model, st, None)
 
@@ -732,9 +733,28 @@ def _flush_lin_wgrads(model) -> None:
         ops.linear_wgrad_group(group)
 
 
+def _defer_list(model) -> Optional[list]:
+    """The list ops.add_ln_bwd / ops.bias_act_bwd append their postponed reductions to (None: reduce in line)."""
+    if not DEFER_REDUCTIONS or not (model._side.enabled or model._side.enabled_small):
+        return None
+    d = model.__dict__.get("_deferred")
+    if d is None:
+        d = model.__dict__["_deferred"] = []
+    return d
+
+
+def _flush_deferred(model) -> None:
+    d = model.__dict__.get("_deferred")
+    if d:
+        fns, keep = [f for f, _ in d], [k for _, k in d]
+        d.clear()
+        model._side.run(lambda: [f() for f in fns], *keep, small=True)
+
+
 def _ready(model, st: "_ParamStore", name: Optional[str]) -> None:
     """Gradient-ready notification for bucketed all-reduce: everything at or above `name`'s offset in the decayed
     region is final (backward walks the flat buffer from its end to its start); None = all gradients final."""
+    _flush_deferred(model)                    # postponed parameter-gradient reductions: to the side stream, once per layer
     if model.grad_ready_hook is not None:     # (the reducer's comm stream waits for the side stream itself: engine.GradReducer._reduce)
         _flush_w3(model)                      # collected weight gradients are not final until launched: bucket boundaries end a group
         model._side.flush()
@@ -817,14 +837,8 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
     use_tr = model.use_tr
     dx = dh
     # parameter-gradient reductions of the row passes (LayerNorm gamma / beta, the intermediate bias): nothing downstream waits for them, so
-    # they leave the chain of dependent launches and run on the side stream, one hand-over per layer
-    defer = [] if (DEFER_REDUCTIONS and model._side.enabled) else None
-
-    def flush_deferred():
-        if defer:
-            fns, keep = [f for f, _ in defer], [k for _, k in defer]
-            defer.clear()
-            model._side.run(lambda: [f() for f in fns], *keep)
+    # they leave the chain of dependent launches and run on the side stream, one hand-over per layer (_flush_deferred, from _ready)
+    defer = _defer_list(model)
 
     for i in reversed(range(model.layers)):
         p = f"encoder.encoder.layer.{i}"
@@ -852,7 +866,7 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
         gqb = st.grad[st.offsets[f"{p}.attention.self.query.bias"][0] :][: 3 * D]
         _lin_wgrad(model, t["x"], dqkv, gq, gqb, R, D, 3 * D, D, 3 * D)
         dx = ops.linear_dgrad(dqkv, st.t16(f"{p}.qkv"), rows=R, N=3 * D, K=D, dy_pitch=3 * D, addend=ds1)
-        flush_deferred()
+        _flush_deferred(model)
         if getattr(model, "_wg_group", None) is None:
             _ready(model, st, f"{p}.attention.self.query.weight")
         elif WG_GROUP_LAYERS > 0 and (model.layers - i) % WG_GROUP_LAYERS == 0 and i > 0:
@@ -870,7 +884,6 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
         dx = ops.scale_bf16(dx, 1.0, drop=te["d_out"])
     ds0 = ops.add_ln_bwd(dx, te["sum"], None, st.p32("encoder.embeddings.LayerNorm.weight"), te["mean"], te["rstd"],
                          st.g32("encoder.embeddings.LayerNorm.weight"), st.g32("encoder.embeddings.LayerNorm.bias"), defer=defer)
-    flush_deferred()
     dfeats = ops.embed_bwd_scatter(ds0, st.g32("cls_token"), st.g32("encoder.embeddings.position_embeddings.weight"),
                                    st.g32("encoder.embeddings.token_type_embeddings.weight"), B, S, D, drop_in=te["d_in"])
     _ready(model, st, "cls_token")
