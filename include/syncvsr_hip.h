@@ -291,6 +291,9 @@ int svsr_topk_acc(const float* logits, const int64_t* labels, const float* soft_
  * zero-initialised; svsr_grad_sumsq writes the 1024 partial sums of squares, svsr_adamw_step adds them in a fixed order. */
 int svsr_grad_sumsq(const float* g, int64_t n, void* opt_state, hipStream_t stream);
 int svsr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, int64_t decay_end, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, int warmup, int total_steps, void* opt_state, hipStream_t stream);
+/* the same over one RANGE of the flat buffers (pointers offset by the caller, decay_end relative to the range); the step counter advances only
+ * with advance != 0 — the last range of a step.  Lets a step update what the next forward needs first and the rest on another stream. */
+int svsr_adamw_range(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, int64_t decay_end, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, int warmup, int total_steps, void* opt_state, int advance, hipStream_t stream);
 
 /* bf16 shadows of fp32 parameters: plain cast, and a table-driven [A][T][B] -> [B][T][Apad] transpose-cast.
  * table: device array of {int64 src_off, dst_off; int32 A, T, Bd, Apad} (elements). */

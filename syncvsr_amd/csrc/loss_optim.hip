@@ -431,14 +431,25 @@ int svsr_grad_sumsq(const float* g, int64_t n, void* opt_state, hipStream_t stre
     return svsr_check_launch();
 }
 
+/* one RANGE of the flat buffers (pointers already offset; decay_end relative to the range) with the step counter advanced only when
+ * `advance` != 0: a step may update the range the next forward needs first on the main stream and the rest on another stream beside that
+ * forward (engine.TrainStep), the LAST range launched — behind every other range — advancing the counter. */
+int svsr_adamw_range(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, int64_t decay_end, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, float max_norm, int warmup, int total_steps,
+                     void* opt_state, int advance, hipStream_t stream) {
+    if (n > 0) {
+        AdamArgs a{p, g, m, v, (bf16_t*)shadow, (long)n, (long)decay_end, lr, beta1, beta2, eps, weight_decay, max_norm, warmup,
+                   total_steps, (OptState*)opt_state};
+        hipLaunchKernelGGL(k_adamw, dim3(grid_for(n)), dim3(256), 0, stream, a);
+    }
+    if (advance) hipLaunchKernelGGL(k_opt_advance, dim3(1), dim3(256), 0, stream, (OptState*)opt_state, lr, warmup, total_steps);
+    return svsr_check_launch();
+}
+
 int svsr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, int64_t decay_end, float lr,
                     float beta1, float beta2, float eps, float weight_decay, float max_norm, int warmup, int total_steps,
                     void* opt_state, hipStream_t stream) {
-    AdamArgs a{p, g, m, v, (bf16_t*)shadow, (long)n, (long)decay_end, lr, beta1, beta2, eps, weight_decay, max_norm, warmup,
-               total_steps, (OptState*)opt_state};
-    hipLaunchKernelGGL(k_adamw, dim3(grid_for(n)), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(k_opt_advance, dim3(1), dim3(256), 0, stream, (OptState*)opt_state, lr, warmup, total_steps);
-    return svsr_check_launch();
+    return svsr_adamw_range(p, g, m, v, shadow, n, decay_end, lr, beta1, beta2, eps, weight_decay, max_norm, warmup, total_steps, opt_state, 1, stream);
 }
 
 int svsr_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {

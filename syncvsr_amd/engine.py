@@ -27,6 +27,8 @@ from .model import TransformerLightningModule
 
 import os as _os
 
+SPLIT_OPTIMIZER = _os.environ.get("SVSR_SPLIT_OPTIMIZER", "1") != "0"      # AdamW of everything behind the front-end on the side stream, beside the next forward
+
 _ROCTX = _os.environ.get("SVSR_ROCTX", "0") == "1"
 
 
@@ -155,17 +157,41 @@ class TrainStep:
             torch.cuda.nvtx.range_push("svsr.allreduce_join+optimizer")
         if self.dp is not None:
             self.dp.finish()
-        ops.grad_sumsq(st.grad, self.opt_state)
-        ops.adamw_step(st.flat, st.grad, self.m, self.v, st.w16, st.decay_end, self.lr, self.betas, self.eps, self.weight_decay,
-                       self.max_norm, self.warmup, self.total_steps, self.opt_state)
-        ops.transpose_shadows(st.flat, st.w16, st.w16t, st.table, st.n_entries)
-        st.shadow_fresh = True
-        st.generation += 1
+        self._optimizer(st)
         if trace:
             torch.cuda.nvtx.range_pop()
         if self.is_lrw:
             return {k: v.detach() for k, v in out.items()}
         return tuple(v.detach() for v in out)
+
+    def _optimizer(self, st) -> None:
+        """Global-norm clip + AdamW + bf16 shadows.  With the model's side stream in use the update is SPLIT: the visual front-end's weights
+        (and every 1-D tensor: BatchNorm / LayerNorm parameters, biases), which the next forward needs first, on the main stream; everything
+        behind the front-end (two thirds of the word-level model, 95 % of the sentence-level one) on the side stream, where this
+        HBM-bound pass runs beside the next step's stem / trunk forward.  The model joins the side stream before its encoder runs and
+        before state_dict(); the step counter advances behind the last range."""
+        model = self.model
+        ops.grad_sumsq(st.grad, self.opt_state)
+        side = model._side
+        hp = (self.lr, self.betas, self.eps, self.weight_decay, self.max_norm, self.warmup, self.total_steps, self.opt_state)
+        if not (SPLIT_OPTIMIZER and side.enabled and st.front_end < st.decay_end):
+            ops.adamw_step(st.flat, st.grad, self.m, self.v, st.w16, st.decay_end, *hp)
+            ops.transpose_shadows(st.flat, st.w16, st.w16t, st.table, st.n_entries)
+        else:
+            bufs = (st.flat, st.grad, self.m, self.v, st.w16)
+            ops.adamw_range(*bufs, 0, st.front_end, st.decay_end, *hp, advance=False)
+            ops.adamw_range(*bufs, st.decay_end, st.numel, st.decay_end, *hp, advance=False)
+            nf = st.n_entries_front
+            side.run(lambda: (ops.adamw_range(*bufs, st.front_end, st.decay_end, st.decay_end, *hp, advance=True),
+                              ops.transpose_shadows_range(st.w16, st.w16t, st.table, nf, st.n_entries - nf)))
+            side.flush()
+            ops.transpose_shadows_range(st.w16, st.w16t, st.table, 0, nf)
+        st.shadow_fresh = True
+        st.generation += 1
+
+    def synchronize(self) -> None:
+        """Joins whatever the last step left on the model's side stream (the tail of its optimiser step)."""
+        self.model._side.join()
 
     # -- native step list ----------------------------------------------------------------------------
     def _direct_impl(self, *batch):
@@ -175,12 +201,7 @@ class TrainStep:
         out = model.train_step_direct(*batch)
         if self.dp is not None:
             ops.host_callback(self.dp.finish)
-        ops.grad_sumsq(st.grad, self.opt_state)
-        ops.adamw_step(st.flat, st.grad, self.m, self.v, st.w16, st.decay_end, self.lr, self.betas, self.eps, self.weight_decay,
-                       self.max_norm, self.warmup, self.total_steps, self.opt_state)
-        ops.transpose_shadows(st.flat, st.w16, st.w16t, st.table, st.n_entries)
-        st.shadow_fresh = True
-        st.generation += 1
+        self._optimizer(st)
         return out
 
     def _native_step(self, *batch):
@@ -289,6 +310,7 @@ class TrainStep:
     def state_dict(self) -> dict[str, torch.Tensor]:
         """Optimiser state for checkpointing (what Lightning stores next to the model's state_dict): AdamW moments as flat
         fp32 vectors in the parameter store's order, and the 16-byte device state {step, -, lr, grad-norm}."""
+        self.synchronize()
         sd = {"exp_avg": self.m.detach().clone(), "exp_avg_sq": self.v.detach().clone(), "opt_state": self.opt_state.detach().clone()}
         if hasattr(self.model, "rng_state"):        # dropout seed word + layer-drop generator: a resumed run draws the same masks / skips
             rs = self.model.rng_state()
@@ -298,6 +320,7 @@ class TrainStep:
         return sd
 
     def load_state_dict(self, sd: dict[str, torch.Tensor]) -> None:
+        self.synchronize()
         if sd["exp_avg"].numel() != self.m.numel():
             raise ValueError("optimiser state belongs to a different parameter layout")
         self.m.copy_(sd["exp_avg"])
@@ -311,6 +334,7 @@ class TrainStep:
 
     # -- introspection ------------------------------------------------------------------------------
     def state(self) -> dict[str, float]:
+        self.synchronize()
         raw = self.opt_state.cpu()
         f = raw.view(torch.float32)
         return {"step": int(raw[0]), "lr": float(f[2]), "grad_norm": float(f[3])}

@@ -144,6 +144,7 @@ class DecoderScorer:
             raise ValueError(f"memory is {memory.size(-1)} wide, the decoder expects ddim = {m.ddim} (the reference feeds the encoder "
                              "output to the decoder directly at inference, lightning.py:114-119, which needs adim == ddim)")
         st = m.store()
+        m._side.join()                # (a TrainStep may have left the tail of its optimiser step on the side stream)
         if not st.shadow_fresh:
             st.refresh_shadows()
             self._mem = None                         # projected with the old weights
@@ -236,6 +237,7 @@ class CTCPrefixScorer:
         """`CTC.log_softmax` (ctc.py:163-170): x [T, adim] -> fp32 [T, odim]."""
         m = self.model
         st = m.store()
+        m._side.join()                # (a TrainStep may have left the tail of its optimiser step on the side stream)
         if not st.shadow_fresh:
             st.refresh_shadows()
         T = x.size(0)

@@ -270,6 +270,10 @@ class E2E(nn.Module):
             self._store = _ParamStore(self, dev)
         return self._store
 
+    def state_dict(self, *args, **kwargs):
+        self._side.join()             # (a TrainStep may have left the tail of its optimiser step on the side stream)
+        return super().state_dict(*args, **kwargs)
+
     def _advance_dropout(self, dev: torch.device) -> None:
         if self._drop_word is None or self._drop_word.device != dev:
             self._drop_word = torch.tensor([self.dropout_seed], dtype=torch.int32, device=dev)
@@ -636,6 +640,7 @@ def _encoder_fwd(model: E2E, st: _ParamStore, tape: dict, x, ilen, training: boo
     D, R = model.adim, B * T
     videos = x.view(B, 1, T, x.size(3), x.size(4))             # [B,T,1,H,W] and [B,1,T,H,W] are the same memory (C = 1)
     feats = _frontend_forward(model, st, tape, videos, training)          # [R, 512] bf16
+    model._side.join()                # the previous step's optimiser may still be updating everything behind the front-end on the side stream (engine.TrainStep)
     if training and (model.drop_p > 0.0 or model.attn_drop_p > 0.0):
         model._advance_dropout(x.device)
     dex = model._d("enc.embed.x")

@@ -236,6 +236,10 @@ class TransformerLightningModule(nn.Module):
             return None
         return (self._drop_word, self._sites[site], p)
 
+    def state_dict(self, *args, **kwargs):
+        self._side.join()             # (a TrainStep may have left the tail of its optimiser step on the side stream)
+        return super().state_dict(*args, **kwargs)
+
     def mark_params_dirty(self) -> None:
         """Call after changing parameters outside engine.TrainStep (load_state_dict does it): the bf16 shadows are re-cast."""
         if self._store is not None:
@@ -403,6 +407,10 @@ class _ParamStore:
                 off = (off + 3) // 4 * 4
                 self.decay_end = off
         self.numel = (off + 3) // 4 * 4
+        # [0, front_end): the visual front-end's weights (forward ranks 0 and 1), what the next forward needs first (engine.TrainStep updates the
+        # rest on the side stream beside that forward)
+        later = [self.offsets[n][0] for n, s in decay if fwd_rank(n) >= 2]
+        self.front_end = min(later) if later else self.decay_end
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.w16 = torch.zeros(self.numel, dtype=BF16, device=device)
@@ -444,6 +452,8 @@ class _ParamStore:
         for n, s, kind in specs:
             if kind == "conv" and len(s) == 4:
                 add_t(n, self.offsets[n][0], s[0], s[2] * s[3], s[1])
+        self.n_entries_front = sum(1 for e in entries if e[0] < self.front_end)       # the front-end's entries come first
+        assert all(e[0] < self.front_end for e in entries[: self.n_entries_front]) and all(e[0] >= self.front_end for e in entries[self.n_entries_front:])
         for key, src_off, A, Bd in model._transposed_entries(self.offsets):
             add_t(key, src_off, A, 1, Bd)
         self.w16t = torch.zeros(max(toff, 1), dtype=BF16, device=device)
@@ -997,6 +1007,7 @@ class _LrwFunction(torch.autograd.Function):
             model._advance_dropout(videos.device)
         tape: dict[str, Any] = {}
         feats = _frontend_forward(model, st, tape, videos, training)
+        model._side.join()            # the previous step's optimiser may still be updating the encoder / heads on the side stream (engine.TrainStep)
         if model.encoder_type == "x-transformers":
             h = _xt_encoder_forward(model, st, tape, feats, word_mask, B, T)
         else:

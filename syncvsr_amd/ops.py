@@ -1098,6 +1098,21 @@ def adamw_step(p, g, m, v, shadow, decay_end: int, lr: float, betas, eps: float,
           max_norm, warmup, total_steps, _p(opt_state), _stream())
 
 
+def adamw_range(p, g, m, v, shadow, lo: int, hi: int, decay_end: int, lr: float, betas, eps: float, weight_decay: float, max_norm: float, warmup: int,
+                total_steps: int, opt_state, advance: bool) -> None:
+    """AdamW over elements [lo, hi) of the flat buffers (decay_end: absolute end of the weight-decayed region)."""
+    n = hi - lo
+    dec = min(max(decay_end - lo, 0), n)
+    _call("svsr_adamw_range", p.data_ptr() + 4 * lo, g.data_ptr() + 4 * lo, m.data_ptr() + 4 * lo, v.data_ptr() + 4 * lo, shadow.data_ptr() + 2 * lo, n, dec,
+          lr, betas[0], betas[1], eps, weight_decay, max_norm, warmup, total_steps, _p(opt_state), int(advance), _stream())
+
+
+def transpose_shadows_range(w16, dst, table: torch.Tensor, first: int, count: int) -> None:
+    """Entries [first, first + count) of the transposed-shadow table (from the bf16 shadow)."""
+    if count > 0:
+        _call("svsr_transpose_bf16_multi", _p(w16), _p(dst), table.data_ptr() + 32 * first, count, _stream())
+
+
 def clip_prep(frames_u8: torch.Tensor, params: torch.Tensor, H: int, W: int, mean: float = 0.421, std: float = 0.165) -> torch.Tensor:
     """uint8 clips [B, T, Hs, Ws] + int32 params [B, 5] = (top, left, h, w, flip) -> fp32 [B, 1, T, H, W] (svsr_clip_prep)."""
     B, T, Hs, Ws = frames_u8.shape
