@@ -150,20 +150,29 @@ def cpu_baseline_lrs(lrs_args, odim: int, frames: int, budget_s: float = 20.0) -
                       f"median step {med * 1e3:.0f} ms, {cores} torch threads"}
 
 
-def pmc_traffic(kernel_label: str):
-    """HBM bytes per launch of `kernel_label` from the committed rocprofv3 PMC passes (profiles/round3_pmc_per_kernel.json, made
-    by scripts/gpu_profiles_round3.sh + scripts/collect_profiles.py at the commit recorded in its __meta__: FETCH_SIZE and
-    WRITE_SIZE in KiB, separate --pmc runs).  gfx950 correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE reports half of the
-    bytes of wide coalesced reads, so it is doubled.  None when no PMC record exists for the kernel.  The bench label
-    k_igemm_p8<256,128,3> covers the profiler's instantiations k_igemm_p8<0|1, PH, false> (plain / BatchNorm-backward epilogue): their
-    launch-weighted mean."""
-    path = os.path.join(ROOT, "profiles", "round3_pmc_per_kernel.json")
+def pmc_traffic(kernel_label: str, lrs: bool = False):
+    """HBM bytes per launch of `kernel_label` from the committed rocprofv3 PMC passes of the newest round (profiles/roundN_pmc_per_kernel.json,
+    roundN_pmc_lrs_per_kernel.json for the sentence-level step; made by scripts/gpu_profiles_roundN.sh + scripts/collect_profiles.py at the
+    commit recorded in their __meta__: FETCH_SIZE and WRITE_SIZE in KiB, separate --pmc runs).  gfx950 correction per MI355X_MICROARCH.md
+    section HBM: FETCH_SIZE reports half of the bytes of wide coalesced reads, so it is doubled.  None when no PMC record exists for the
+    kernel.  The bench label k_igemm_p8<256,128,3> covers the profiler's instantiations k_igemm_p8<0|1, PH, false> (plain / BatchNorm-backward
+    epilogue): their launch-weighted mean; k_igemm_wgrad<BC,NS> covers k_igemm_wgrad and k_igemm_wgrad_units of that tile."""
+    import glob
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_lrs_per_kernel.json" if lrs else "round*_pmc_per_kernel.json")),
+                   key=lambda f: int(re.search(r"round(\d+)_", os.path.basename(f)).group(1)))
+    if not files:
+        return None
+    path = files[-1]
     try:
         rec = json.load(open(path))
     except OSError:
         return None
     key = kernel_label.replace(",", ", ")
     keys = {key, key[:-1] + ", 1>"}          # k_igemm_fwd_glds carries a defaulted fourth template argument (K groups) in the profiler's name
+    if kernel_label.startswith("k_igemm_wgrad<"):
+        keys.add(key.replace("k_igemm_wgrad<", "k_igemm_wgrad_units<"))
     tot_b = tot_n = 0.0
     for name, v in rec.items():
         if name == "__meta__" or "FETCH_SIZE_avg_per_dispatch" not in v or "WRITE_SIZE_avg_per_dispatch" not in v:
@@ -176,7 +185,7 @@ def pmc_traffic(kernel_label: str):
     if tot_n == 0:
         return None
     return {"bytes_per_launch": round(tot_b / tot_n),
-            "source": f"profiles/round3_pmc_per_kernel.json @ {rec.get('__meta__', {}).get('commit', '?')[:12]} (rocprofv3 --pmc, FETCH_SIZE doubled for gfx950)"}
+            "source": f"profiles/{os.path.basename(path)} @ {rec.get('__meta__', {}).get('commit', '?')[:12]} (rocprofv3 --pmc, FETCH_SIZE doubled for gfx950)"}
 
 
 def build_lrs(args, dev, world: int, rank: int):
@@ -216,7 +225,7 @@ def host_idle_queue_ms(trainer, batch, reps: int = 3) -> float:
     return sorted(ts)[len(ts) // 2]
 
 
-def lrs_leg(args, dev) -> dict:
+def lrs_leg(args, dev, with_cpu: bool = False) -> dict:
     """A short, bounded LRS measurement attached to the default (LRW) line, so that BASELINE configs[3] gets a driver-timed number:
     warm-up, `args.lrs_steps` timed steps (barrier + synchronize on both sides), then one eager step with per-launch HIP events."""
     from syncvsr_amd import ops
@@ -253,7 +262,13 @@ def lrs_leg(args, dev) -> dict:
     dom = max(rows, key=lambda k: rows[k]["ms"])
     d = rows[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    cpu = None
+    if with_cpu:
+        from syncvsr_amd.lrs_init import LRS_ODIM
+
+        cpu = cpu_baseline_lrs(lrs_args, LRS_ODIM, 32, budget_s=12.0)
     return {
+        **({"cpu_baseline": cpu} if cpu is not None else {}),
         "metric": f"lip-clips/sec training (LRS, <= {args.frames}x88x88)", "value": round(args.lrs_batch * 1e3 / ms, 2), "unit": "clips/s",
         "ms_per_step": round(ms, 3), "steps": args.lrs_steps, "padded_frames_per_s": round(args.lrs_batch * args.frames * 1e3 / ms, 1),
         "host_enqueue_ms": round(host_idle, 3), "host_enqueue_in_loop_ms": round(host_ms[len(host_ms) // 2], 3) if host_ms else None,
@@ -264,7 +279,10 @@ def lrs_leg(args, dev) -> dict:
                                f"length bucket padded to {args.frames} frames, dropout {args.dropout}",
                    "per_gpu_batch": args.lrs_batch, "valid_frames": n_frames, "enqueue": "native step list" if native else "eager (python)"},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                     "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 5), "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches"],
+                     "frac": round(ach * 1e12 / MFMA_PEAK_BF16, 5), "traffic": pmc_traffic(dom, lrs=True),
+                     "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches"],
+                     "timing": "HIP events around each library call; a weight-gradient call is the contraction AND its fixed-order reduce launch "
+                               "(rocprofv3 lists the two kernels separately: k_igemm_wgrad* + k_colsum / k_wgrad_unit_reduce)",
                      "per_kernel": {k: {"ms_per_step": round(v["ms"], 4), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "launches": v["launches"]}
                                     for k, v in sorted(rows.items())}},
     }
@@ -496,7 +514,7 @@ def main() -> None:
             del prof, trainer, model
             torch.cuda.empty_cache()
             try:
-                result["lrs"] = lrs_leg(args, dev)
+                result["lrs"] = lrs_leg(args, dev, with_cpu=not args.no_cpu_baseline)
             except Exception as e:          # the headline line must survive a failure of the extra leg
                 result["lrs"] = {"error": f"{type(e).__name__}: {e}"}
         try:        # RCCL prints its version banner through C stdio, which is flushed at exit: push it out first so the JSON line is last
