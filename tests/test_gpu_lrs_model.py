@@ -259,11 +259,14 @@ def test_lrs_longest_clip_full_width(dev):
         assert cos >= 0.97 and 0.93 <= float(g.norm() / r.norm()) <= 1.07, (n, cos, float(g.norm() / r.norm()))
 
 
-def test_lrs_bench_shape_matches_oracle(dev):
+@pytest.mark.parametrize("drop", [0.0, 0.1])
+def test_lrs_bench_shape_matches_oracle(dev, drop):
     """Whole-model LRS parity at the shape bench.py's LRS leg times (BASELINE configs[3]): the shipped 252 M-parameter config
     (LRS/video/config/lrs3.yaml:14-39), 16 clips of ONE length bucket padded to 160 frames, built by the benchmark's own batch builder
-    (syncvsr_amd.lrs_data.LengthBucketBatchSampler over the reference's length histogram), dropout off so the two sides see the same
-    function.  Losses to 1e-3, features / logits and every live gradient against the fp32 oracle with the bounds of the lrs_full cases."""
+    (syncvsr_amd.lrs_data.LengthBucketBatchSampler over the reference's length histogram).  drop = 0: the two sides see the same
+    function; drop = 0.1 (what the benchmark runs, lrs3.yaml:20-21): the oracle replays the library's counter-based masks
+    (oracle.lrs_oracle.DropPlan).  Losses to 1e-3, features / logits and every live gradient against the fp32 oracle with the bounds of
+    the lrs_full cases."""
     import numpy as np
 
     from oracle import lrs_oracle as O
@@ -271,7 +274,7 @@ def test_lrs_bench_shape_matches_oracle(dev):
     from syncvsr_amd.lrs_init import LRS_ODIM, default_lrs_args, lrs_init_state_dict, lrs_synthetic_batch
     from syncvsr_amd.lrs_model import E2E
 
-    args = default_lrs_args(dropout_rate=0.0, transformer_attn_dropout_rate=0.0)
+    args = default_lrs_args(dropout_rate=drop, transformer_attn_dropout_rate=drop)
     pool = reference_length_histogram(4096, seed=7) * 150 // 155
     sampler = LengthBucketBatchSampler(pool, 16, 1, 0, width=16, seed=11)
     idx = max(range(len(sampler)), key=lambda i: sampler.padded_frames()[i])
@@ -282,13 +285,20 @@ def test_lrs_bench_shape_matches_oracle(dev):
     model = E2E(LRS_ODIM, args)
     model.load_state_dict(sd, strict=True)
     model.to(dev).train()
+    model.reseed_dropout(41)
     out = model(x.to(dev), lengths.to(dev), tokens.to(dev), label.to(dev))
     out[0].backward()
     torch.cuda.synchronize()
     osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
     keep = {}
     torch.set_num_threads(min(32, os.cpu_count() or 8))
-    ref = O.forward(osd, args, x, lengths, tokens, label, training=True, keep=keep)
+    dp = None
+    if drop > 0:
+        from syncvsr_amd.dropout import lrs_sites
+
+        assert int(model._drop_word.item()) == 42
+        dp = O.DropPlan(42, drop, drop, lrs_sites(int(args.elayers), int(args.dlayers)))
+    ref = O.forward(osd, args, x, lengths, tokens, label, training=True, keep=keep, dp=dp)
     ref["loss"].backward()
     names = ("loss", "loss_ctc", "loss_att", "loss_audio")
     rows = {k: (out[i].item(), ref[k].item()) for i, k in enumerate(names)}
