@@ -56,6 +56,18 @@ class _RoundBf16(torch.autograd.Function):
         return g.bfloat16().float()
 
 
+class _RoundValueBf16(torch.autograd.Function):
+    """bf16 rounding of the VALUE only: a tensor the HIP forward stores in bf16 whose gradient the backward never materialises."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 class _RoundGradBf16(torch.autograd.Function):
     """Identity whose GRADIENT is rounded to bf16: a point where only the HIP path's backward stores a bf16 tensor."""
 
@@ -162,29 +174,40 @@ def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
 # --------------------------------------------------------------------------------------------
 # visual front-end  (lightning.py:49-55, 112-119)
 # --------------------------------------------------------------------------------------------
-def stem3d(videos: Tensor, sd: SD, training: bool, stats_out: dict | None = None, keep: dict | None = None, emu: bool = False) -> Tensor:
+def stem3d(videos: Tensor, sd: SD, training: bool, stats_out: dict | None = None, keep: dict | None = None, emu: bool = False,
+           prefix: str = "stem3d", act=None) -> Tensor:
     """Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) -> BatchNorm3d -> GELU -> MaxPool3d((1,3,3),(1,2,2),(0,1,1)).
-    emu: clip and weights enter the MFMA contraction as bf16; the conv output and the pooled output are stored in bf16."""
-    c32 = F.conv3d(videos.bfloat16().float() if emu else videos, _w16(sd["stem3d.0.weight"], emu), None, stride=(1, 2, 2), padding=(2, 3, 3))
+    emu: clip and weights enter the MFMA contraction as bf16; the conv output and the pooled output are stored in bf16.
+    prefix / act: the sentence-level model's stem has the same shape under another name and with Swish
+    (LRS/video/espnet/nets/pytorch_backend/backbones/conv3d_extractor.py:40-48)."""
+    c32 = F.conv3d(videos.bfloat16().float() if emu else videos, _w16(sd[f"{prefix}.0.weight"], emu), None, stride=(1, 2, 2), padding=(2, 3, 3))
     x = _st(c32, emu)
     if keep is not None:
         keep["stem_conv"] = x
-    x = batch_norm(x, sd, "stem3d.1", training, stats_out, x_stats=c32 if emu else None)
+    x = batch_norm(x, sd, f"{prefix}.1", training, stats_out, x_stats=c32 if emu else None)
     if emu:
         # the HIP backward keeps g = dpool * gelu'(z) per pooled output in bf16 between its reduce and apply passes (norm_act.hip
         # k_stem_bwd_reduce_win) — as the reference's own bf16 autocast does with the GELU's input gradient
         x = _RoundGradBf16.apply(x)
-    x = gelu_erf(x)
+    x = gelu_erf(x) if act is None else act(x)
     x = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
     return _st(x, emu)
 
 
 def basic_block(x: Tensor, sd: SD, prefix: str, stride: int, training: bool, stats_out: dict | None = None, emu: bool = False,
-                keep: dict | None = None) -> Tensor:
+                keep: dict | None = None, act=torch.relu) -> Tensor:
     """tcn/models/resnet.py:59-72 with relu_type='relu' (== timm BasicBlock).
-    emu: each convolution output (pre-BatchNorm, statistics from its fp32 accumulators) and each BatchNorm(+ReLU) output is a bf16 tensor."""
+    emu: each convolution output (pre-BatchNorm, statistics from its fp32 accumulators) and each BatchNorm(+ReLU) output is a bf16 tensor.
+    act: the sentence-level trunk is the same block with Swish (LRS/video/espnet/nets/pytorch_backend/backbones/modules/resnet.py:90-107)."""
     c32 = F.conv2d(x, _w16(sd[f"{prefix}.conv1.weight"], emu), None, stride=stride, padding=1)
-    out = _st(torch.relu(batch_norm(_st(c32, emu), sd, f"{prefix}.bn1", training, stats_out, x_stats=c32 if emu else None)), emu)
+    out = batch_norm(_st(c32, emu), sd, f"{prefix}.bn1", training, stats_out, x_stats=c32 if emu else None)
+    if emu:
+        # the HIP backward never stores the gradient of the activation's OUTPUT: the data-gradient launch of conv2 multiplies its fp32
+        # accumulators by act'(z) and stores that product in bf16 (igemm_p8.hip epilogue).  ReLU: the same numbers either way (a mask
+        # commutes with rounding); Swish: one rounding instead of two
+        out = _RoundValueBf16.apply(act(_RoundGradBf16.apply(out)))
+    else:
+        out = act(out)
     if keep is not None:
         keep[f"{prefix}.conv1.c"], keep[f"{prefix}.bn1.y"] = c32, out
     c32 = F.conv2d(out, _w16(sd[f"{prefix}.conv2.weight"], emu), None, stride=1, padding=1)
@@ -199,7 +222,7 @@ def basic_block(x: Tensor, sd: SD, prefix: str, stride: int, training: bool, sta
     z = out + res
     if keep is not None:
         keep[f"{prefix}.z"] = z           # pre-activation of the block's output
-    return _st(torch.relu(z), emu)
+    return _st(act(z), emu)
 
 
 def forward_videos(videos: Tensor, sd: SD, training: bool, stats_out: dict | None = None, keep: dict | None = None, emu: bool = False) -> Tensor:
