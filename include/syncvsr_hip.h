@@ -52,6 +52,20 @@ typedef struct svsr_enc_layer {
     unsigned site_probs; unsigned site_ao; unsigned site_fo; unsigned pad_;
 } svsr_enc_layer;
 
+/* one encoder layer of svsr_enc_bwd (the backward of svsr_enc_fwd: autograd of HF BertLayer, reference LRW/video/src/lightning.py:92,152-156):
+ * DEVICE pointers.  Weights: the TRANSPOSED bf16 shadows [in][out] the data-gradient launches read — output.dense [2048][512],
+ * intermediate.dense [512][2048], attention.output.dense [512][512], query|key|value [512][1536]; g1 / g2: LayerNorm weights.  Read: what
+ * the forward kept (f, x1, ao, the layer input xin, z, qkv, probs, LayerNorm statistics).  Written: see svsr_enc_bwd. */
+typedef struct svsr_enc_bwd_layer {
+    const void* w2t; const void* w1t; const void* wot; const void* wqkvt;
+    const float* g1; const float* g2;
+    const void* f; const void* x1; const void* ao; const void* xin; const void* z; const void* qkv; const void* probs;
+    const float* m1; const float* r1; const float* m2; const float* r2;
+    void* ds2; void* df; void* dz; void* dx1; void* ds1; void* dao; void* dqkv; void* dx;
+    float* part1; float* part2;
+    unsigned site_probs; unsigned site_ao; unsigned site_fo; unsigned pad_;
+} svsr_enc_bwd_layer;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -318,6 +332,15 @@ int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream);
 int64_t svsr_enc_fwd_ws_bytes(int B);
 int svsr_debug_enc_trace(int64_t* out, int n);     /* debug: out == null arms s_memtime stamps of workgroup 0 at the phase boundaries of the next launches; else copies n stamps out */
 int svsr_enc_fwd(const void* x0, const svsr_enc_layer* layers, int n_layers, int B, int S, float ln_eps, const unsigned* drop_seed, float p_hidden, float p_attn, void* ws, int64_t ws_bytes, hipStream_t stream);
+
+/* Backward of the same layers in one launch per 32 sequences (enc_fused.hip, k_enc_bwd): replaces, per layer, two svsr_add_ln_bwd, four
+ * svsr_igemm_fwd data-gradient launches, svsr_bias_act_bwd, svsr_mha_bwd and the dropout re-scalings between them.  dy bf16 [B*S][512] =
+ * gradient of the last layer's output; layers = HOST array in forward order.  Per layer it writes ds2 / df / dx1 / ds1 / dao / dx bf16
+ * [R][512], dz bf16 [R][2048], dqkv bf16 [R][1536] — (hg, df), (x1, dz), (ctx, dao), (xin, dqkv) are the operand pairs of the layer's four weight
+ * gradients; df may alias ds2 and dao ds1 without hidden dropout — and part1 / part2 fp32 [B][2][512], one row of {sum dy*xhat | sum dy} per
+ * sequence and LayerNorm (svsr_colsum_rows over B rows of 1024 gives gamma | beta gradients).  layers[0].dx = gradient of the first input. */
+int64_t svsr_enc_bwd_ws_bytes(int B);
+int svsr_enc_bwd(const void* dy, const svsr_enc_bwd_layer* layers, int n_layers, int B, int S, const unsigned* drop_seed, float p_hidden, float p_attn, void* ws, int64_t ws_bytes, hipStream_t stream);
 
 int svsr_word_add(int* word, int delta, hipStream_t stream);
 int svsr_lincomb2(const float* a, const float* b, float wb, float* out, hipStream_t stream);

@@ -83,11 +83,13 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const bf16_t* __restrict__ d
                 unpack8(reinterpret_cast<const u32x4*>(dy)[o], fd);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
+                    // (multiply-adds spelled out: csrc/enc_fused.hip's ln_bwd8 must round the same way, see common.h normal_cdf_exp)
                     xh[i][k] = (fa[k] + (r != nullptr ? fr[k] : 0.f) - mu) * rs;
                     gd[i][k] = fd[k] * gamma[c0 + k];
+                    asm volatile("" : "+v"(gd[i][k]));       // a rounded product: not to be fused into the sums below at the compiler's choice
                     m1 += gd[i][k];
-                    m2 += gd[i][k] * xh[i][k];
-                    ag[i][k] += fd[k] * xh[i][k];
+                    m2 = __builtin_fmaf(gd[i][k], xh[i][k], m2);
+                    ag[i][k] = __builtin_fmaf(fd[k], xh[i][k], ag[i][k]);
                     ab[i][k] += fd[k];
                 }
             }
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const bf16_t* __restrict__ d
             if ((i * 64 + lane) * 8 < D) {
                 float o[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = rs * (gd[i][k] - m1 - xh[i][k] * m2);
+                for (int k = 0; k < 8; ++k) o[k] = rs * __builtin_fmaf(-xh[i][k], m2, gd[i][k] - m1);
                 if (addend != nullptr) {       // pre-LN residual stream: grad(x) = grad through LN + grad of the skip path
                     float ad[8];
                     unpack8(reinterpret_cast<const u32x4*>(addend)[((long)row * D + (i * 64 + lane) * 8) >> 3], ad);

@@ -627,6 +627,550 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
     }
 }
 
+
+// =================================================================================================================================
+// Fused BACKWARD of the same layers (k_enc_bwd): gradient of the last layer's output -> gradient of the first layer's input, and every
+// tensor the weight-gradient launches read, in ONE launch.  Replaces 13 launches per layer (two add+LayerNorm backward passes, four
+// data-gradient GEMMs, the GELU backward pass, two attention-backward launches and their dropout re-scalings; reference: autograd of
+// HF BertLayer as reached from LRW/video/src/lightning.py:92,152-156), a dependent chain of 5-15 us launches at 960 rows.
+// The same cluster of 8 workgroups per sequence; workgroup h owns head h and the h-th eighth of every GEMM's output columns:
+//   B1  ds2 = LayerNorm2 backward of the incoming gradient (every workgroup, all rows), df = dropout-mask(ds2)      (redundant, no exchange)
+//   B2  dz[:, h] = (df W_2)[:, h-th 256] * gelu'(z)                                                                  -> cluster barrier 1
+//   B4  dx1[:, h] = dz W_1 + ds2                                   needs all of dz                                   -> cluster barrier 2
+//   B5  ds1 = LayerNorm1 backward of dx1, dao = dropout-mask(ds1)   (redundant)
+//   B6  dctx_h = (dao W_o)[:, head h]                               (head-local: stays in LDS)
+//   B7  attention backward of head h: dP = dctx V^T, dS = P o (dP' - rowsum(P o dP')) / 8, dq = dS K, dk = dS^T q, dv = P'^T dctx   -> cluster barrier 3
+//   B8  dx[:, h] = dqkv W_qkv + ds1                                 needs every head's dq | dk | dv                  -> cluster barrier 4
+// Rounding points are the launch chain's: every tensor that crosses a launch boundary there (ds2, df, dhg, dz, dx1, ds1, dao, dctx, dS,
+// dq | dk | dv, dx) is rounded to bf16 here as well, the GEMMs with K >= 1536 add two K halves, dropout masks are regenerated from the same
+// (site, element index) pairs.  Parameter gradients are NOT formed here: df, dz, dao, dqkv (with hg, x1, ctx, x of the forward) feed the
+// grouped weight-gradient launch, and the LayerNorm gamma / beta sums leave as one partial row per sequence (part1 / part2, reduced by
+// svsr_colsum_rows in a fixed order).
+// =================================================================================================================================
+namespace {
+
+struct EncBwdArgs {
+    const bf16_t* dy;                 // [R][512] gradient of the last layer's output
+    const svsr_enc_bwd_layer* Ls;     // DEVICE copy of the layer records, forward order
+    int layers, S, seq0, nseq;
+    const unsigned* seed; unsigned th_hidden, th_attn; float sc_hidden, sc_attn;
+    unsigned* cnt; unsigned* err;
+    unsigned long long* trace;
+};
+
+// LayerNorm backward of the 8 rows wave*8 .. +7 (lane owns columns lane*8 .. +7), k_add_ln_bwd's arithmetic:
+//   xhat = (a + r - mean) * rstd, gd = dy * gamma, ds = rstd * (gd - mean(gd) - xhat * mean(gd * xhat))
+// dy / a / r sit in three ring slots in the A layout.  ds (bf16) -> this workgroup's column slice of ds_out; dd = dropout-mask(ds) -> bufA
+// (A operand of the GEMM that follows) and, where it is a tensor of its own, its column slice of dd_out.  ag / ab: this lane's column sums
+// of dy * xhat and dy over the rows < S.
+__device__ __forceinline__ void ln_bwd8(const bf16_t* sDy, const bf16_t* sA, const bf16_t* sR, const float (&g8)[8], const float (&mu8)[8], const float (&rs8)[8],
+                                        long row0, int S, int wave, int lane, int h, bool drop_on, unsigned key, unsigned th, float sc,
+                                        bf16_t* bufA, bf16_t* ds_out, bf16_t* dd_out, float (&ag)[8], float (&ab)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float xh[4][8], gd[4][8], m1[4], m2[4], rs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 8 + half * 4 + i;
+            const float mu = mu8[half * 4 + i];
+            rs[i] = rs8[half * 4 + i];
+            const int o = (lane >> 3) * 2048 + EF_SWZ(row, lane & 7);
+            float fa[8], fr[8], fd[8];
+            unpack8(*reinterpret_cast<const u32x4*>(sA + o), fa);
+            unpack8(*reinterpret_cast<const u32x4*>(sR + o), fr);
+            unpack8(*reinterpret_cast<const u32x4*>(sDy + o), fd);
+            m1[i] = 0.f; m2[i] = 0.f;
+            const bool live = row < S;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                xh[i][k] = (fa[k] + fr[k] - mu) * rs[i];
+                gd[i][k] = fd[k] * g8[k];
+                asm volatile("" : "+v"(gd[i][k]));           // (as in k_add_ln_bwd: a rounded product)
+                m1[i] += gd[i][k];
+                m2[i] = __builtin_fmaf(gd[i][k], xh[i][k], m2[i]);
+                if (live) { ag[k] = __builtin_fmaf(fd[k], xh[i][k], ag[k]); ab[k] += fd[k]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { m1[i] = wave_sum(m1[i]) / (float)ED; m2[i] = wave_sum(m2[i]) / (float)ED; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 8 + half * 4 + i;
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = rs[i] * __builtin_fmaf(-xh[i][k], m2[i], gd[i][k] - m1[i]);
+            const u32x4 ds = pack8(o);
+            u32x4 dd = ds;
+            const long off = (row0 + row) * ED + lane * 8;
+            if (drop_on) {
+                float v[8];
+                unpack8(ds, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = drop_keep(key, th, (unsigned)(off + k)) ? v[k] * sc : 0.f;
+                dd = pack8(v);
+            }
+            *reinterpret_cast<u32x4*>(bufA + (lane >> 3) * 2048 + EF_SWZ(row, lane & 7)) = dd;
+            if (row < S && (lane >> 3) == h) {
+                st16_sc1(ds_out + off, ds);
+                if (dd_out != ds_out) st16_sc1(dd_out + off, dd);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* bufA = reinterpret_cast<bf16_t*>(smem + BUFA);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int c, h;
+    {
+        const int i = blockIdx.x;
+        if ((p.nseq & 7) == 0) { const int j = i >> 3; h = j & 7; c = (i & 7) + 8 * (j >> 3); }
+        else { c = i >> 3; h = i & 7; }
+    }
+    const int S = p.S;
+    const long row0 = (long)(p.seq0 + c) * S;
+    const int bh = (p.seq0 + c) * EH + h;
+    unsigned* cnt = p.cnt + c;
+    unsigned arrivals = 0;
+    int tix = 0;
+    auto stamp = [&]() {
+        if (p.trace != nullptr && blockIdx.x == 0 && tid == 0 && tix < 500) p.trace[tix] = __builtin_amdgcn_s_memtime();
+        ++tix;
+    };
+    stamp();
+    const int slot8 = tid & 7, r32 = tid >> 3;
+    const int csw = slot8 ^ ((r32 >> 1) & 7);
+    const int rsrc = r32 < S ? r32 : S - 1;
+    const bool drop_on = p.seed != nullptr;
+    const int ldp = (S + 7) & ~7;
+    auto ring = [&](int slot) { return reinterpret_cast<bf16_t*>(smem + RING + slot * SLOT); };
+    // a [rows][512] bf16 tensor's rows of this sequence -> one ring slot in the A layout (8 DMA pieces per thread)
+    auto rows512 = [&](const bf16_t* t, int slot, bool sc1) {
+        const bf16_t* src = t + (row0 + rsrc) * ED + csw * 8;
+        bf16_t* dst = ring(slot) + wave * 8 * 64;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            if (sc1) glds16_sc1(src + kb * 64, dst + kb * 2048); else glds16(src + kb * 64, dst + kb * 2048);
+        }
+    };
+    auto ln_consts = [&](const float* gamma, const float* mean, const float* rstd, float (&g8)[8], float (&mu8)[8], float (&rs8)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = wave * 8 + i;
+            const long gr = row0 + (row < S ? row : S - 1);
+            mu8[i] = mean[gr]; rs8[i] = rstd[gr];
+            g8[i] = gamma[lane * 8 + i];
+        }
+    };
+    // this sequence's partial row of a LayerNorm's gamma / beta gradient: the four waves' column sums meet in LDS (slot 3) in a fixed order;
+    // workgroup h writes columns h*64 .. +63 of both halves
+    auto ln_partials = [&](const float (&ag)[8], const float (&ab)[8], float* part) {
+        float* sc = reinterpret_cast<float*>(ring(3));           // [4 waves][2][512]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sc[(wave * 2 + 0) * ED + lane * 8 + k] = ag[k]; sc[(wave * 2 + 1) * ED + lane * 8 + k] = ab[k]; }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, col = h * 64 + (tid & 63);
+            part[(long)(p.seq0 + c) * 2 * ED + which * ED + col] =
+                ((sc[(0 + which) * ED + col] + sc[(2 + which) * ED + col]) + sc[(4 + which) * ED + col]) + sc[(6 + which) * ED + col];
+        }
+    };
+
+    for (int l = p.layers - 1; l >= 0; --l) {
+        const svsr_enc_bwd_layer L = p.Ls[l];
+        const bf16_t* dyin = l == p.layers - 1 ? p.dy : reinterpret_cast<const bf16_t*>(p.Ls[l + 1].dx);
+        const unsigned key_pr = drop_on ? svsr_mix(p.seed[0] * 0x9E3779B9u + L.site_probs * 0x7F4A7C15u + 0x165667B1u) : 0u;
+        const unsigned key_ao = drop_on ? svsr_mix(p.seed[0] * 0x9E3779B9u + L.site_ao * 0x7F4A7C15u + 0x165667B1u) : 0u;
+        const unsigned key_fo = drop_on ? svsr_mix(p.seed[0] * 0x9E3779B9u + L.site_fo * 0x7F4A7C15u + 0x165667B1u) : 0u;
+
+        // =========================== B1: ds2 = LN2 backward, df = mask(ds2) -> bufA ==========================================
+        {
+            if (l != p.layers - 1) {                        // the layer above has written every column of its dx
+                arrivals += EH;
+                cluster_wait(cnt, arrivals, p.err);
+            }
+            stamp();                                         // [b0] layer start
+            rows512(dyin, 0, true);
+            rows512(reinterpret_cast<const bf16_t*>(L.f), 1, false);
+            rows512(reinterpret_cast<const bf16_t*>(L.x1), 2, false);
+            float g8[8], mu8[8], rs8[8];                     // this wave's rows' statistics and this lane's gammas travel with the DMA
+            ln_consts(L.g2, L.m2, L.r2, g8, mu8, rs8);
+            EF_WAIT_VM(0);
+            EF_BARRIER();
+            float ag[8], ab[8];
+            ln_bwd8(ring(0), ring(1), ring(2), g8, mu8, rs8, row0, S, wave, lane, h, drop_on, key_fo, p.th_hidden, p.sc_hidden, bufA,
+                    reinterpret_cast<bf16_t*>(L.ds2), reinterpret_cast<bf16_t*>(L.df), ag, ab);
+            ln_partials(ag, ab, L.part2);
+            stamp();                                         // [b1] LN2 backward done
+        }
+
+        // =========================== B2: dz[:, h*256 ..] = (df W_2)[...] * gelu'(z) ==========================================
+        {
+            const bf16_t* W = reinterpret_cast<const bf16_t*>(L.w2t) + (long)(h * IH) * ED;          // rows = dhg columns, 512 long
+            auto stageW = [&](int s, int slot) {
+                bf16_t* dst = ring(slot);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) glds16(W + (long)(i * 32 + r32) * ED + s * 64 + csw * 8, dst + (i * 32 + wave * 8) * 64);
+            };
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            // z of this wave's epilogue rows: requested now, used after the K loop (plain loads: written by the forward launch)
+            u32x4 zr[4];
+            {
+                const int n = h * IH + wave * 64 + (lane & 7) * 8;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = (lane >> 3) + 8 * i;
+                    zr[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(L.z) + (row0 + (row < S ? row : S - 1)) * EI + n);
+                }
+            }
+            EF_WAIT_VM(0);                                   // this phase's own stores leave the queue before counted waits start
+            __syncthreads();                                 // slots 0..3 (LayerNorm inputs, partial sums) are consumed; df is in bufA
+            stageW(0, 0); stageW(1, 1); stageW(2, 2);
+            for (int s = 0; s < 8; ++s) {
+                if (s < 6) EF_WAIT_VM(16); else if (s == 6) EF_WAIT_VM(8); else EF_WAIT_VM(0);
+                EF_BARRIER();
+                if (s + 3 < 8) stageW(s + 3, (s + 3) & 3);
+                const bf16_t* B = ring(s & 3) + wave * 64 * 64;
+                const bf16_t* A = bufA + s * 2048;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ch = ks * 2 + (lane >> 5);
+                    const bf16x8 fa = lds_frag(A, lane & 31, ch);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, lds_frag(B, j * 32 + (lane & 31), ch), acc[j], 0, 0, 0);
+                }
+            }
+            __syncthreads();                                 // df in bufA and the ring are consumed
+            {
+                float* st = reinterpret_cast<float*>(bufA) + wave * 2048;               // fp32 [4][32][64]
+                acc_to_stage(acc[0], st, 64, 0, lane);
+                acc_to_stage(acc[1], st, 64, 32, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int c8 = lane & 7, n = h * IH + wave * 64 + c8 * 8;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = (lane >> 3) + 8 * i;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(st + row * 64 + c8 * 8), hi = *reinterpret_cast<const f32x4*>(st + row * 64 + c8 * 8 + 4);
+                    const float a8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    float g[8], z[8];
+                    unpack8(pack8(a8), g);                   // dhg is a bf16 tensor in the launch chain
+                    unpack8(zr[i], z);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) g[k] = g[k] * gelu_erf_grad(z[k]) * 1.0f;
+                    if (row < S) st16_sc1(reinterpret_cast<bf16_t*>(L.dz) + (row0 + row) * EI + n, pack8(g));
+                }
+            }
+            stamp();                                         // [b2] B2 done
+            cluster_signal(cnt);
+        }
+
+        // =========================== B4: dx1[:, h*64 ..] = dz W_1 + ds2 ======================================================
+        {
+            const bf16_t* W = reinterpret_cast<const bf16_t*>(L.w1t) + (long)(h * 64) * EI;            // rows = dx1 columns, 2048 long
+            const bf16_t* DZ = reinterpret_cast<const bf16_t*>(L.dz) + (row0 + rsrc) * EI + csw * 8;
+            auto stageW = [&](int s, int slot) {            // chunks s (K half 0) and 16 + s (K half 1): 64 rows x 64 k each
+                bf16_t* dst = ring(slot);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int g = i >> 1, row = (i & 1) * 32 + r32;
+                    glds16(W + (long)row * EI + (g * 16 + s) * 64 + csw * 8, dst + g * 4096 + ((i & 1) * 32 + wave * 8) * 64);
+                }
+            };
+            auto stageA = [&](int s, int slot) {
+                bf16_t* dst = ring(slot) + 8192;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) glds16_sc1(DZ + (g * 16 + s) * 64, dst + g * 2048 + wave * 8 * 64);
+            };
+            arrivals += EH;
+            cluster_wait(cnt, arrivals, p.err);
+            stamp();                                         // [b3] barrier 1 passed
+            const long eoff = (row0 + ((tid >> 3) < S ? (tid >> 3) : S - 1)) * ED + h * 64 + (tid & 7) * 8;      // this thread's epilogue piece
+            const u32x4 ad = ld16_sc1(reinterpret_cast<const bf16_t*>(L.ds2) + eoff);
+            EF_WAIT_VM(0);
+            for (int s = 0; s < 3; ++s) { stageW(s, s); stageA(s, s); }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int g = wave >> 1, jb = wave & 1;
+            for (int s = 0; s < 16; ++s) {
+                if (s < 14) EF_WAIT_VM(12); else if (s == 14) EF_WAIT_VM(6); else EF_WAIT_VM(0);
+                EF_BARRIER();
+                if (s + 3 < 16) { stageW(s + 3, (s + 3) & 3); stageA(s + 3, (s + 3) & 3); }
+                const bf16_t* T = ring(s & 3);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ch = ks * 2 + (lane >> 5);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(T + 8192 + g * 2048, lane & 31, ch), lds_frag(T + g * 4096, jb * 32 + (lane & 31), ch), acc, 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            float* stage = reinterpret_cast<float*>(bufA);   // fp32 [2 K halves][32][64]
+            acc_to_stage(acc, stage + g * 2048, 64, jb * 32, lane);
+            __syncthreads();
+            {
+                const int row = tid >> 3, c8 = tid & 7, n = h * 64 + c8 * 8;
+                const long off = eoff;
+                const f32x4 lo0 = *reinterpret_cast<const f32x4*>(stage + row * 64 + c8 * 8), hi0 = *reinterpret_cast<const f32x4*>(stage + row * 64 + c8 * 8 + 4);
+                const f32x4 lo1 = *reinterpret_cast<const f32x4*>(stage + 2048 + row * 64 + c8 * 8), hi1 = *reinterpret_cast<const f32x4*>(stage + 2048 + row * 64 + c8 * 8 + 4);
+                float v[8] = {lo0[0] + lo1[0], lo0[1] + lo1[1], lo0[2] + lo1[2], lo0[3] + lo1[3], hi0[0] + hi1[0], hi0[1] + hi1[1], hi0[2] + hi1[2], hi0[3] + hi1[3]};
+                float a8[8];
+                unpack8(ad, a8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += a8[k];
+                if (row < S) st16_sc1(reinterpret_cast<bf16_t*>(L.dx1) + off, pack8(v));
+            }
+            stamp();                                         // [b4] B4 done
+            cluster_signal(cnt);
+        }
+
+        // q | k | v of this head and the probabilities (written by the forward launch: plain loads), used in B7: requested ahead of the barrier
+        const int arow = tid >> 3, c8 = tid & 7;
+        const bf16_t* qsrc = reinterpret_cast<const bf16_t*>(L.qkv) + (row0 + (arow < S ? arow : S - 1)) * (3 * ED) + h * 64 + c8 * 8;
+        const u32x4 q8 = *reinterpret_cast<const u32x4*>(qsrc), k8 = *reinterpret_cast<const u32x4*>(qsrc + ED), v8 = *reinterpret_cast<const u32x4*>(qsrc + 2 * ED);
+        float prv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = 8 * wave + q + 4 * (lane >> 5), j = lane & 31;
+            prv[q] = (i < S && j < S) ? bf2f(reinterpret_cast<const bf16_t*>(L.probs)[((long)bh * S + i) * ldp + j]) : 0.f;
+        }
+
+        // =========================== B5: ds1 = LN1 backward of dx1, dao = mask(ds1) -> bufA ==================================
+        {
+            arrivals += EH;
+            cluster_wait(cnt, arrivals, p.err);
+            stamp();                                         // [b5] barrier 2 passed
+            rows512(reinterpret_cast<const bf16_t*>(L.dx1), 0, true);
+            rows512(reinterpret_cast<const bf16_t*>(L.ao), 1, false);
+            rows512(reinterpret_cast<const bf16_t*>(L.xin), 2, false);
+            float g8[8], mu8[8], rs8[8];
+            ln_consts(L.g1, L.m1, L.r1, g8, mu8, rs8);
+            EF_WAIT_VM(0);
+            EF_BARRIER();
+            float ag[8], ab[8];
+            ln_bwd8(ring(0), ring(1), ring(2), g8, mu8, rs8, row0, S, wave, lane, h, drop_on, key_ao, p.th_hidden, p.sc_hidden, bufA,
+                    reinterpret_cast<bf16_t*>(L.ds1), reinterpret_cast<bf16_t*>(L.dao), ag, ab);
+            ln_partials(ag, ab, L.part1);
+            stamp();                                         // [b6] LN1 backward done
+        }
+
+        // =========================== B6: dctx of head h = (dao W_o)[:, h*64 ..] -> LDS ========================================
+        // =========================== B7: attention backward of head h -> dq | dk | dv ========================================
+        {
+            const bf16_t* Wo = reinterpret_cast<const bf16_t*>(L.wot) + (long)(h * 64) * ED;           // rows = ctx columns of head h, 512 long
+            auto stageWo = [&](int s, int slot) {           // 64 rows x 256 k (4 chunks of 64): 8 pieces per thread
+                bf16_t* dst = ring(slot);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int sub = i >> 1, row = (i & 1) * 32 + r32;
+                    glds16(Wo + (long)row * ED + s * 256 + sub * 64 + csw * 8, dst + sub * 4096 + ((i & 1) * 32 + wave * 8) * 64);
+                }
+            };
+            EF_WAIT_VM(0);
+            __syncthreads();                                 // LayerNorm inputs / partial sums consumed, dao in bufA
+            stageWo(0, 1); stageWo(1, 2);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            EF_WAIT_VM(0);
+            EF_BARRIER();
+            if (wave < 2) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16_t* B = ring(1 + s);
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            const int ch = ks * 2 + (lane >> 5);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(bufA + (s * 4 + sub) * 2048, lane & 31, ch),
+                                                                           lds_frag(B + sub * 4096, wave * 32 + (lane & 31), ch), acc, 0, 0, 0);
+                        }
+                }
+            }
+            float* stage = reinterpret_cast<float*>(ring(0));     // fp32 [32][64]
+            if (wave < 2) acc_to_stage(acc, stage, 64, wave * 32, lane);
+            __syncthreads();                                 // dao in bufA is consumed: bufA becomes the attention operands
+            bf16_t* Da = bufA;                               // [32 i][64 d]   A layout of dctx
+            bf16_t* Vb = bufA + 2048;                        // [32 j][64 d]   B layout of v
+            bf16_t* Kt = bufA + 4096;                        // [64 d][64: j]  B layout of k^T
+            bf16_t* Qt = bufA + 8192;                        // [64 d][64: i]  B layout of q^T
+            bf16_t* Dt = bufA + 12288;                       // [64 d][64: i]  B layout of dctx^T
+            bf16_t* dSa = ring(0) + 4096;                    // [32 i][64: j]  A layout of dS         (behind the 8 KiB staging)
+            bf16_t* dSt = ring(0) + 6144;                    // [32 j][64: i]  A layout of dS^T
+            bf16_t* Pt = ring(0) + 8192;                     // [32 j][64: i]  A layout of dropout(P)^T
+            {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + arow * 64 + c8 * 8), hi = *reinterpret_cast<const f32x4*>(stage + arow * 64 + c8 * 8 + 4);
+                const float d8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const u32x4 dk = pack8(d8);
+                *reinterpret_cast<u32x4*>(Da + EF_SWZ(arow, c8)) = dk;
+                *reinterpret_cast<u32x4*>(Vb + EF_SWZ(arow, c8)) = v8;
+                const unsigned wd[4] = {dk.x, dk.y, dk.z, dk.w}, wk[4] = {k8.x, k8.y, k8.z, k8.w}, wq[4] = {q8.x, q8.y, q8.z, q8.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int o = EF_SWZ(c8 * 8 + e, arow >> 3) + (arow & 7);
+                    Dt[o] = (bf16_t)((wd[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                    Kt[o] = (bf16_t)((wk[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                    Qt[o] = (bf16_t)((wq[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                }
+            }
+            stamp();                                         // [b7] dctx done, attention operands staged
+            EF_BARRIER();
+            {   // dP of the whole 32 x 32 block on every wave; wave w finishes rows 8w .. 8w+7
+                f32x16 sc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ch = ks * 2 + (lane >> 5);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Da, lane & 31, ch), lds_frag(Vb, lane & 31, ch), sc, 0, 0, 0);
+                }
+                const int j = lane & 31;
+                float dp[4], part[4];
+                bool keep[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x = sc[0];
+                    if (wave == 0) x = sc[q]; else if (wave == 1) x = sc[4 + q]; else if (wave == 2) x = sc[8 + q]; else x = sc[12 + q];
+                    const int i = 8 * wave + q + 4 * (lane >> 5);
+                    keep[q] = !drop_on || drop_keep(key_pr, p.th_attn, (unsigned)(((long)bh * S + i) * ldp + j));
+                    dp[q] = (i < S && j < S) ? (drop_on ? (keep[q] ? x * p.sc_attn : 0.f) : x) : 0.f;
+                    part[q] = prv[q] * dp[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float a = part[q];
+                    a += dpp_xor1(a); a += dpp_xor2(a); a += dpp_half_mirror(a); a += dpp_mirror(a);
+                    part[q] = a + swz_xor16(a);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 8 * wave + q + 4 * (lane >> 5);
+                    const bf16_t ds = f2bf(prv[q] * (dp[q] - part[q]) * 0.125f);
+                    const bf16_t pd = drop_on ? (keep[q] ? f2bf(prv[q] * p.sc_attn) : (bf16_t)0) : f2bf(prv[q]);
+                    dSa[EF_SWZ(i, j >> 3) + (j & 7)] = ds;
+                    dSt[EF_SWZ(j, i >> 3) + (i & 7)] = ds;
+                    Pt[EF_SWZ(j, i >> 3) + (i & 7)] = pd;
+                }
+            }
+            EF_BARRIER();
+            float* ost = reinterpret_cast<float*>(ring(1));  // fp32 [3: dq, dk, dv][32][64]  (W_o's tiles are consumed)
+            {   // six (matrix, 32-column block) products of two MFMAs each: wave 0/1 dq then dv, wave 2/3 dk; two 16-deep k slices added at the end
+                const int nb = wave & 1;
+                const bf16_t* A0 = wave < 2 ? dSa : dSt;
+                const bf16_t* B0 = wave < 2 ? Kt : Qt;
+                f32x16 c0, c1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(A0, lane & 31, lane >> 5), lds_frag(B0, nb * 32 + (lane & 31), lane >> 5), c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(A0, lane & 31, 2 + (lane >> 5)), lds_frag(B0, nb * 32 + (lane & 31), 2 + (lane >> 5)), c1, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c0[r] += c1[r];
+                acc_to_stage(c0, ost + (wave < 2 ? 0 : 2048), 64, nb * 32, lane);
+                if (wave < 2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Pt, lane & 31, lane >> 5), lds_frag(Dt, nb * 32 + (lane & 31), lane >> 5), c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Pt, lane & 31, 2 + (lane >> 5)), lds_frag(Dt, nb * 32 + (lane & 31), 2 + (lane >> 5)), c1, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c0[r] += c1[r];
+                    acc_to_stage(c0, ost + 4096, 64, nb * 32, lane);
+                }
+            }
+            __syncthreads();
+            if (arow < S) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(ost + m * 2048 + arow * 64 + c8 * 8), hi = *reinterpret_cast<const f32x4*>(ost + m * 2048 + arow * 64 + c8 * 8 + 4);
+                    const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    st16_sc1(reinterpret_cast<bf16_t*>(L.dqkv) + (row0 + arow) * (3 * ED) + m * ED + h * 64 + c8 * 8, pack8(v));
+                }
+            }
+            stamp();                                         // [b8] attention backward done
+            cluster_signal(cnt);
+        }
+
+        // =========================== B8: dx[:, h*64 ..] = dqkv W_qkv + ds1 ===================================================
+        {
+            constexpr int KQ = 3 * ED, HC = KQ / 128;        // 1536 deep: two K halves of 12 chunks
+            const bf16_t* W = reinterpret_cast<const bf16_t*>(L.wqkvt) + (long)(h * 64) * KQ;
+            const bf16_t* DQ = reinterpret_cast<const bf16_t*>(L.dqkv) + (row0 + rsrc) * KQ + csw * 8;
+            auto stageW = [&](int s, int slot) {
+                bf16_t* dst = ring(slot);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int g = i >> 1, row = (i & 1) * 32 + r32;
+                    glds16(W + (long)row * KQ + (g * HC + s) * 64 + csw * 8, dst + g * 4096 + ((i & 1) * 32 + wave * 8) * 64);
+                }
+            };
+            auto stageA = [&](int s, int slot) {
+                bf16_t* dst = ring(slot) + 8192;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) glds16_sc1(DQ + (g * HC + s) * 64, dst + g * 2048 + wave * 8 * 64);
+            };
+            arrivals += EH;
+            cluster_wait(cnt, arrivals, p.err);
+            stamp();                                         // [b9] barrier 3 passed
+            const long eoff = (row0 + ((tid >> 3) < S ? (tid >> 3) : S - 1)) * ED + h * 64 + (tid & 7) * 8;
+            const u32x4 ad = ld16_sc1(reinterpret_cast<const bf16_t*>(L.ds1) + eoff);
+            EF_WAIT_VM(0);
+            for (int s = 0; s < 3; ++s) { stageW(s, s); stageA(s, s); }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int g = wave >> 1, jb = wave & 1;
+            for (int s = 0; s < HC; ++s) {
+                if (s < HC - 2) EF_WAIT_VM(12); else if (s == HC - 2) EF_WAIT_VM(6); else EF_WAIT_VM(0);
+                EF_BARRIER();
+                if (s + 3 < HC) { stageW(s + 3, (s + 3) & 3); stageA(s + 3, (s + 3) & 3); }
+                const bf16_t* T = ring(s & 3);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ch = ks * 2 + (lane >> 5);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(T + 8192 + g * 2048, lane & 31, ch), lds_frag(T + g * 4096, jb * 32 + (lane & 31), ch), acc, 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            float* stage = reinterpret_cast<float*>(bufA);
+            acc_to_stage(acc, stage + g * 2048, 64, jb * 32, lane);
+            __syncthreads();
+            {
+                const int row = tid >> 3, c8 = tid & 7, n = h * 64 + c8 * 8;
+                const long off = eoff;
+                const f32x4 lo0 = *reinterpret_cast<const f32x4*>(stage + row * 64 + c8 * 8), hi0 = *reinterpret_cast<const f32x4*>(stage + row * 64 + c8 * 8 + 4);
+                const f32x4 lo1 = *reinterpret_cast<const f32x4*>(stage + 2048 + row * 64 + c8 * 8), hi1 = *reinterpret_cast<const f32x4*>(stage + 2048 + row * 64 + c8 * 8 + 4);
+                float v[8] = {lo0[0] + lo1[0], lo0[1] + lo1[1], lo0[2] + lo1[2], lo0[3] + lo1[3], hi0[0] + hi1[0], hi0[1] + hi1[1], hi0[2] + hi1[2], hi0[3] + hi1[3]};
+                float a8[8];
+                unpack8(ad, a8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += a8[k];
+                if (row < S) st16_sc1(reinterpret_cast<bf16_t*>(L.dx) + off, pack8(v));
+            }
+            stamp();                                         // [b10] B8 done
+            if (l > 0) cluster_signal(cnt);
+            __syncthreads();                                 // the staging in bufA is consumed before the next layer's DMA lands in the ring / bufA
+        }
+    }
+}
+
+struct EncBwdTable { svsr_enc_bwd_layer L[8]; };
+static_assert(sizeof(EncBwdTable) <= 3584, "the layer records travel in the kernel-argument segment");
+
+__global__ __launch_bounds__(256) void k_enc_bwd_table(const EncBwdTable t, int words, long long* __restrict__ dst) {
+    const long long* src = reinterpret_cast<const long long*>(&t);
+    for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+}
+
 struct EncTable { svsr_enc_layer L[8]; };
 static_assert(sizeof(EncTable) <= 3584, "the layer records travel in the kernel-argument segment");
 
@@ -689,6 +1233,45 @@ int svsr_enc_fwd(const void* x0, const svsr_enc_layer* layers, int n_layers, int
     for (int s0 = 0; s0 < B; s0 += 32) {          // all workgroups of a launch must be resident together: 8 per sequence on 256 CUs
         a.seq0 = s0; a.nseq = B - s0 < 32 ? B - s0 : 32; a.cnt = cnt + s0;
         hipLaunchKernelGGL(k_enc_fwd, dim3(a.nseq * EH), dim3(256), LDS_TOTAL, stream, a);
+    }
+    return svsr_check_launch();
+}
+
+/* bytes of the device workspace svsr_enc_bwd needs for B sequences */
+int64_t svsr_enc_bwd_ws_bytes(int B) { return B < 1 ? 0 : (int64_t)(((B + 1) * 4 + 255) / 256 * 256) + (int64_t)sizeof(EncBwdTable); }
+
+/* svsr_enc_bwd: backward of the layers svsr_enc_fwd ran, in one launch per 32 sequences.  dy bf16 [B*S][512]: gradient of the last layer's
+ * output; layers: HOST array of n_layers records in FORWARD order.  Written per layer: ds2 / df / ds1 / dao / dx1 / dx bf16 [R][512], dz bf16
+ * [R][2048], dqkv bf16 [R][1536] (df, dz, dao, dqkv are the `dy` operands of the layer's four weight gradients; df may alias ds2 and dao ds1
+ * when there is no hidden dropout), part1 / part2 fp32 [B][2][512] (per-sequence sums of dy * xhat | dy of the two LayerNorms: svsr_colsum_rows
+ * over B rows of 1024 gives the gamma | beta gradients).  layers[0].dx is the gradient of the first layer's input.  Same workspace
+ * conventions as svsr_enc_fwd (word B of ws = error flag). */
+int svsr_enc_bwd(const void* dy, const svsr_enc_bwd_layer* layers, int n_layers, int B, int S, const unsigned* drop_seed, float p_hidden, float p_attn,
+                 void* ws, int64_t ws_bytes, hipStream_t stream) {
+    if (dy == nullptr || layers == nullptr || n_layers < 1 || n_layers > 8 || B < 1 || S < 1 || S > TR || ws == nullptr || ws_bytes < svsr_enc_bwd_ws_bytes(B))
+        return SVSR_ERR_ARG;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_enc_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); attr = true; }
+    unsigned* cnt = static_cast<unsigned*>(ws);
+    const size_t cnt_bytes = (size_t)(((B + 1) * 4 + 255) / 256 * 256);
+    hipError_t e = hipMemsetAsync(cnt, 0, cnt_bytes, stream);
+    if (e != hipSuccess) return (int)e;
+    EncBwdTable t;
+    memset(&t, 0, sizeof t);
+    for (int l = 0; l < n_layers; ++l) t.L[l] = layers[l];
+    svsr_enc_bwd_layer* tab_dev = reinterpret_cast<svsr_enc_bwd_layer*>(static_cast<char*>(ws) + cnt_bytes);
+    hipLaunchKernelGGL(k_enc_bwd_table, dim3(1), dim3(256), 0, stream, t, (int)(sizeof(EncBwdTable) / 8), reinterpret_cast<long long*>(tab_dev));
+    EncBwdArgs a;
+    a.dy = (const bf16_t*)dy; a.Ls = tab_dev;
+    a.layers = n_layers; a.S = S;
+    const DropArgs dh = svsr_make_drop(drop_seed, 0, p_hidden), da = svsr_make_drop(drop_seed, 0, p_attn);
+    a.seed = (dh.seed != nullptr || da.seed != nullptr) ? drop_seed : nullptr;
+    a.th_hidden = dh.thresh; a.sc_hidden = dh.scale; a.th_attn = da.thresh; a.sc_attn = da.scale;
+    a.err = cnt + B;
+    a.trace = g_enc_trace;
+    for (int s0 = 0; s0 < B; s0 += 32) {
+        a.seq0 = s0; a.nseq = B - s0 < 32 ? B - s0 : 32; a.cnt = cnt + s0;
+        hipLaunchKernelGGL(k_enc_bwd, dim3(a.nseq * EH), dim3(256), LDS_TOTAL, stream, a);
     }
     return svsr_check_launch();
 }

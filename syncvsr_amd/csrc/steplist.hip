@@ -14,6 +14,7 @@
 // Everything a CALL points to must stay alive and in place while the list exists: device buffers (the recorder on the Python side
 // keeps every tensor of the recorded step), host arrays (plan meta records, tap tables: cached for the life of the process).
 // Nothing here launches a kernel of its own; results are bit-identical to the eager step by construction.
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -68,7 +69,7 @@ const std::unordered_map<std::string, Entry>& registry() {
         SVSR_REG(svsr_transpose_bf16_multi), SVSR_REG(svsr_fill_f32), SVSR_REG(svsr_clip_prep), SVSR_REG(svsr_mha_fwd), SVSR_REG(svsr_mha_bwd),
         SVSR_REG(svsr_glu_dwconv_fwd), SVSR_REG(svsr_glu_dwconv_bwd), SVSR_REG(svsr_ctc_fwd), SVSR_REG(svsr_ctc_grad),
         SVSR_REG(svsr_ctc_prefix_score), SVSR_REG(svsr_embed_pos_fwd), SVSR_REG(svsr_embed_pos_bwd), SVSR_REG(svsr_ls_loss_fwd),
-        SVSR_REG(svsr_ls_loss_bwd), SVSR_REG(svsr_scale_bf16), SVSR_REG(svsr_word_add), SVSR_REG(svsr_lincomb2), SVSR_REG(svsr_igemm_wgrad_group), SVSR_REG(svsr_enc_fwd), SVSR_REG(svsr_conv3x3_wgrad_multi), SVSR_REG(svsr_lincomb3_ratio), SVSR_REG(svsr_add_ln_bwd_partials), SVSR_REG(svsr_bias_act_bwd_partials),
+        SVSR_REG(svsr_ls_loss_bwd), SVSR_REG(svsr_scale_bf16), SVSR_REG(svsr_word_add), SVSR_REG(svsr_lincomb2), SVSR_REG(svsr_igemm_wgrad_group), SVSR_REG(svsr_enc_fwd), SVSR_REG(svsr_enc_bwd), SVSR_REG(svsr_conv3x3_wgrad_multi), SVSR_REG(svsr_lincomb3_ratio), SVSR_REG(svsr_add_ln_bwd_partials), SVSR_REG(svsr_bias_act_bwd_partials),
     };
     return r;
 }
@@ -122,12 +123,26 @@ int svsr_steplist_push_call(void* list, const char* name, const int64_t* slots, 
     return SVSR_OK;
 }
 
+/* Flags of the events behind a cross-stream WAIT.  Both streams are on one device: the signaller's kernels release to agent scope when
+ * they end, which is all a kernel of the waiting stream needs; the system-scope fence an event performs by default when it is recorded
+ * (for the host and for peer devices) costs the SIGNALLING stream ~2.4 us per record (scripts/probes/handover_probe.hip: a dependent
+ * main-stream chain with a hand-over after every kernel, 52.9 -> 50.5 us per kernel) — 35 records per word-level step, ~250 per
+ * sentence-level step.  Nothing the host or RCCL reads is ordered by these events (the host synchronises the stream, the reducer's
+ * comm stream waits through torch's own events).  SVSR_EVENT_SYSTEM_FENCE=1 restores the default. */
+static unsigned wait_event_flags() {
+    static const unsigned flags = [] {
+        const char* v = getenv("SVSR_EVENT_SYSTEM_FENCE");
+        return (unsigned)hipEventDisableTiming | ((v != nullptr && v[0] == '1') ? 0u : (unsigned)hipEventDisableSystemFence);
+    }();
+    return flags;
+}
+
 int svsr_steplist_push_wait(void* list, hipStream_t waiter, hipStream_t signaller) {
     StepList* l = static_cast<StepList*>(list);
     if (l == nullptr) return SVSR_ERR_ARG;
     Op op{};
     op.kind = OP_WAIT; op.a = waiter; op.b = signaller;
-    hipError_t e = hipEventCreateWithFlags(&op.ev, hipEventDisableTiming);
+    hipError_t e = hipEventCreateWithFlags(&op.ev, wait_event_flags());
     if (e != hipSuccess) return (int)e;
     l->events.push_back(op.ev);
     l->ops.push_back(op);
@@ -196,7 +211,7 @@ int svsr_stream_wait(hipStream_t waiter, hipStream_t signaller) {
     static bool made = false;
     if (!made) {
         for (hipEvent_t& e : ring) {
-            hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            hipError_t rc = hipEventCreateWithFlags(&e, wait_event_flags());
             if (rc != hipSuccess) return (int)rc;
         }
         made = true;

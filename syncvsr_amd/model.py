@@ -841,6 +841,65 @@ def _encoder_forward_fused(model: TransformerLightningModule, st: _ParamStore, t
     return xin
 
 
+def _encoder_layers_backward_fused(model: TransformerLightningModule, st: _ParamStore, tape: dict, dh: torch.Tensor, B: int, S: int,
+                                   defer: Optional[list]) -> torch.Tensor:
+    """The backward of all encoder layers in one launch (ops.enc_bwd, csrc/enc_fused.hip k_enc_bwd), then the parameter gradients it leaves
+    to the weight-gradient launches — the same calls, in the same order, as the per-layer path below makes.  Returns the gradient of the
+    first layer's input."""
+    D, H, I, Lc = model.dim, model.heads, model.inter, model.layers
+    R = B * S
+    dev = dh.device
+    t0 = tape["encoder.encoder.layer.0"]
+    hidden_drop = t0["dfo"] is not None or t0["dao"] is not None
+    act = torch.empty((6 if hidden_drop else 4, Lc, R, D), dtype=BF16, device=dev)      # ds2, dx1, ds1, dx (, df, dao)
+    dz = torch.empty((Lc, R, I), dtype=BF16, device=dev)
+    dqkv = torch.empty((Lc, R, 3 * D), dtype=BF16, device=dev)
+    part = torch.empty((Lc, 2, B, 2 * D), dtype=torch.float32, device=dev)              # [layer][LayerNorm 1 | 2][sequence][dy*xhat | dy]
+    recs = []
+    for i in range(Lc):
+        p = f"encoder.encoder.layer.{i}"
+        t = tape[p]
+        recs.append(dict(
+            w2t=st.t16(f"{p}.output.dense.weight"), w1t=st.t16(f"{p}.intermediate.dense.weight"),
+            wot=st.t16(f"{p}.attention.output.dense.weight"), wqkvt=st.t16(f"{p}.qkv"),
+            g1=st.p32(f"{p}.attention.output.LayerNorm.weight"), g2=st.p32(f"{p}.output.LayerNorm.weight"),
+            f=t["f"], x1=t["x1"], ao=t["ao"], xin=t["x"], z=t["z"], qkv=t["qkv"], probs=t["probs"], m1=t["m1"], r1=t["r1"], m2=t["m2"], r2=t["r2"],
+            ds2=act[0, i], dx1=act[1, i], ds1=act[2, i], dx=act[3, i], df=act[4, i] if hidden_drop else act[0, i],
+            dao=act[5, i] if hidden_drop else act[2, i], dz=dz[i], dqkv=dqkv[i], part1=part[i, 0], part2=part[i, 1],
+            site_probs=model._sites[f"enc.{i}.attn.probs"], site_ao=model._sites[f"enc.{i}.attn.out"], site_fo=model._sites[f"enc.{i}.ff.out"]))
+    on = hidden_drop or t0["dpr"] is not None
+    ops.enc_bwd(dh, recs, B, S, model._drop_word if on else None, model.drop_p if hidden_drop else 0.0,
+                model.attn_drop_p if t0["dpr"] is not None else 0.0)
+
+    def ln_grads(rows, name):
+        gw, gb = st.g32(f"{name}.weight"), st.g32(f"{name}.bias")
+        if defer is None:
+            ops.colsum_rows(rows, B, 2 * D, gw, D, gb, D)
+        else:
+            defer.append((lambda: ops.colsum_rows(rows, B, 2 * D, gw, D, gb, D), rows))
+
+    for i in reversed(range(Lc)):
+        p = f"encoder.encoder.layer.{i}"
+        t, q = tape[p], recs[i]
+        ln_grads(q["part2"], f"{p}.output.LayerNorm")
+        _lin_wgrad(model, t["hg"], q["df"], st.g32(f"{p}.output.dense.weight"), st.g32(f"{p}.output.dense.bias"), R, I, D, I, D)
+        # (the intermediate bias's gradient: the column sums of dz, taken by the weight-gradient launch)
+        _lin_wgrad(model, t["x1"], q["dz"], st.g32(f"{p}.intermediate.dense.weight"), st.g32(f"{p}.intermediate.dense.bias"), R, D, I, D, I)
+        ln_grads(q["part1"], f"{p}.attention.output.LayerNorm")
+        _lin_wgrad(model, t["ctx"], q["dao"], st.g32(f"{p}.attention.output.dense.weight"), st.g32(f"{p}.attention.output.dense.bias"), R, D, D, D, D)
+        gq = st.grad[st.offsets[f"{p}.attention.self.query.weight"][0]:][: 3 * D * D]
+        gqb = st.grad[st.offsets[f"{p}.attention.self.query.bias"][0]:][: 3 * D]
+        _lin_wgrad(model, t["x"], q["dqkv"], gq, gqb, R, D, 3 * D, D, 3 * D)
+        _flush_deferred(model)
+        if getattr(model, "_wg_group", None) is None:
+            _ready(model, st, f"{p}.attention.self.query.weight")
+        elif WG_GROUP_LAYERS > 0 and (Lc - i) % WG_GROUP_LAYERS == 0 and i > 0:
+            _flush_lin_wgrads(model)
+            model._wg_group = []
+            _ready(model, st, f"{p}.attention.self.query.weight")
+    return recs[0]["dx"]
+
+
 def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: dict, dh: torch.Tensor, B: int, T: int) -> torch.Tensor:
     D, S, H, I = model.dim, T + 1, model.heads, model.inter
     R = B * S
@@ -850,7 +909,10 @@ def _encoder_backward(model: TransformerLightningModule, st: _ParamStore, tape: 
     # they leave the chain of dependent launches and run on the side stream, one hand-over per layer (_flush_deferred, from _ready)
     defer = _defer_list(model)
 
-    for i in reversed(range(model.layers)):
+    fused = ops.ENC_BWD_FUSED and ops.enc_fused_ok(D, H, I, S) and model.layers <= 8
+    if fused:
+        dx = _encoder_layers_backward_fused(model, st, tape, dh, B, S, defer)
+    for i in reversed(range(0 if fused else model.layers)):
         p = f"encoder.encoder.layer.{i}"
         t = tape[p]
         ds2 = ops.add_ln_bwd(dx, t["f"], t["x1"], st.p32(f"{p}.output.LayerNorm.weight"), t["m2"], t["r2"],

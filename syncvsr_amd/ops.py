@@ -990,6 +990,40 @@ def enc_fwd(x0: torch.Tensor, layers: Sequence[dict], B: int, S: int, eps: float
         x = chunk[-1]["xout"]
 
 
+class _EncBwdLayer(ctypes.Structure):
+    """svsr_enc_bwd_layer of include/syncvsr_hip.h"""
+    _PTRS = ("w2t", "w1t", "wot", "wqkvt", "g1", "g2", "f", "x1", "ao", "xin", "z", "qkv", "probs", "m1", "r1", "m2", "r2",
+             "ds2", "df", "dz", "dx1", "ds1", "dao", "dqkv", "dx", "part1", "part2")
+    _fields_ = [(n, ctypes.c_void_p) for n in _PTRS] + \
+               [("site_probs", ctypes.c_uint), ("site_ao", ctypes.c_uint), ("site_fo", ctypes.c_uint), ("pad_", ctypes.c_uint)]
+
+
+ENC_BWD_FUSED = os.environ.get("SVSR_ENC_BWD_FUSED", "1") != "0"     # the whole encoder backward as one launch (False: 13 launches per layer)
+_ENC_BWD_WS: dict = {}
+
+
+def enc_bwd(dy: torch.Tensor, layers: Sequence[dict], B: int, S: int, seed: Optional[torch.Tensor], p_hidden: float, p_attn: float) -> None:
+    """layers (forward order, at most 8): per layer a dict of tensors under the field names of svsr_enc_bwd_layer (+ the three site ints)."""
+    if len(layers) > 8:
+        raise ValueError("svsr_enc_bwd takes at most 8 layers per launch")
+    dev = dy.device
+    nbytes = int(_lib.load().svsr_enc_bwd_ws_bytes(B))
+    key = (str(dev), _stream())
+    ws = _ENC_BWD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _SCRATCH_KEEP.append(ws)
+        ws = _ENC_BWD_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    arr = (_EncBwdLayer * len(layers))()
+    for rec, q in zip(arr, layers):
+        for name in _EncBwdLayer._PTRS:
+            setattr(rec, name, q[name].data_ptr())
+        rec.site_probs, rec.site_ao, rec.site_fo, rec.pad_ = int(q["site_probs"]), int(q["site_ao"]), int(q["site_fo"]), 0
+    n = len(layers)
+    _call("svsr_enc_bwd", _p(dy), arr, n, B, S, _p(seed), float(p_hidden), float(p_attn), _p(ws), nbytes, _stream(),
+          label="k_enc_bwd", flops=float(n) * 2.0 * B * S * (4 * 512 * 512 + 2 * 512 * 2048) + float(n) * 8.0 * B * 8 * S * S * 64)
+
+
 # -- `type: x-transformers` encoder passes (csrc/xt.hip) ---------------------------------------------
 def rmsnorm_fwd(x, g, D: int, eps: float = 1e-8):
     """x bf16 [R][ld] (pad columns zero) -> (y, inv [R])."""

@@ -83,3 +83,64 @@ def test_fused_encoder_is_bit_reproducible(dev):
     assert torch.equal(o1[True][0], o2[True][0])
     for k in ("qkv", "probs", "ctx", "ao", "x1", "z", "hg", "f"):
         assert torch.equal(o1[True][1]["encoder.encoder.layer.5"][k], o2[True][1]["encoder.encoder.layer.5"][k]), k
+
+
+def _backward_pair(dev, B, T, layers, training, seed=3):
+    """The encoder's backward from the same tape and the same upstream gradient: the per-layer launch chain, then the fused launch."""
+    from syncvsr_amd import model as M
+    from syncvsr_amd import ops
+
+    model, out = _tapes(dev, B, T, layers, training, seed)
+    h, tape = out[True]
+    st = model.store()
+    dh = (torch.randn(h.shape, generator=torch.Generator().manual_seed(5 + B)) * 1e-2).to(torch.bfloat16).to(dev)
+    res = {}
+    for fused in (False, True):
+        ops.ENC_BWD_FUSED = fused
+        try:
+            st.zero_grad()
+            st.rebind_grads()
+            model._wg_group = None
+            dfeats = M._encoder_backward(model, st, tape, dh, B, T)
+            M._flush_deferred(model)
+            model._side.join()
+            torch.cuda.synchronize()
+            res[fused] = (dfeats.clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if n.startswith(("encoder.", "cls_token"))})
+        finally:
+            ops.ENC_BWD_FUSED = True
+    ws = ops._ENC_BWD_WS[next(iter(ops._ENC_BWD_WS))]
+    assert int(ws.view(torch.int32)[B].item()) == 0, "a bounded cluster wait gave up"
+    return res
+
+
+@pytest.mark.parametrize("B,T,layers,training", [(2, 7, 2, False), (3, 29, 2, True), (32, 29, 6, True), (5, 31, 1, True), (40, 11, 1, False)])
+def test_fused_encoder_backward_matches_launch_chain(dev, B, T, layers, training):
+    """The fused backward (svsr_enc_bwd) keeps the chain's rounding points, dropout masks and K-half split; what differs is the order of a few
+    fp32 additions (the LayerNorm parameter sums: one partial row per sequence instead of one per four rows; the attention backward's row
+    sums).  Input gradient and every parameter gradient of the encoder: relative L2 <= 2e-3 against the chain (measured: see the print)."""
+    res = _backward_pair(dev, B, T, layers, training)
+    (d0, g0), (d1, g1) = res[False], res[True]
+    worst = [(_rel(d1, d0), "dfeats")]
+    for n in g0:
+        if float(g0[n].float().norm()) == 0.0:
+            assert float(g1[n].float().norm()) == 0.0, n
+            continue
+        if n.endswith("attention.self.key.bias"):
+            # zero in exact arithmetic (a key bias shifts every score of a query alike): rounding noise on both sides, measured against the
+            # query bias's gradient instead of compared
+            qn = n.replace(".key.", ".query.")
+            noise = float((g1[n].float() - g0[n].float()).norm() / g0[qn].float().norm())
+            assert noise <= 2e-3, (n, noise)
+            continue
+        worst.append((_rel(g1[n], g0[n]), n))
+    worst.sort(reverse=True)
+    print("largest relative L2 differences:", "  ".join(f"{r:.2e} {n}" for r, n in worst[:8]))
+    assert worst[0][0] <= 2e-3, "  ".join(f"{r:.2e} {n}" for r, n in worst[:8])
+
+
+def test_fused_encoder_backward_is_bit_reproducible(dev):
+    a = _backward_pair(dev, 32, 29, 6, True)[True]
+    b = _backward_pair(dev, 32, 29, 6, True)[True]
+    assert torch.equal(a[0], b[0])
+    for n in a[1]:
+        assert torch.equal(a[1][n], b[1][n]), n
