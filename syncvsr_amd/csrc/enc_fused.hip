@@ -429,6 +429,12 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) glds16(W1 + (long)(i * 32 + r32) * ED + s * 64 + csw * 8, dst + (i * 32 + wave * 8) * 64);
             };
+            // the layer input X is complete since barrier 1 (every workgroup signalled it after its previous LN2): requested ahead of the wait
+            {
+                const bf16_t* sx = xin + (row0 + rsrc) * ED + csw * 8;
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) glds16_sc1(sx + kb * 64, ring(2) + kb * 2048 + wave * 8 * 64);
+            }
             arrivals += EH;
             cluster_wait(cnt, arrivals, p.err);
             stamp();                                         // [6] barrier 2 passed
@@ -436,12 +442,8 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
             // ao and X arrive by LDS-DMA (sc1) in slots 1 and 2 (free: W_o is consumed; W_1's first tiles sit in 3 and 0): one round trip
             {
                 const bf16_t* sa = reinterpret_cast<const bf16_t*>(L.ao) + (row0 + rsrc) * ED + csw * 8;
-                const bf16_t* sx = xin + (row0 + rsrc) * ED + csw * 8;
 #pragma unroll
-                for (int kb = 0; kb < 8; ++kb) {
-                    glds16_sc1(sa + kb * 64, ring(1) + kb * 2048 + wave * 8 * 64);
-                    glds16_sc1(sx + kb * 64, ring(2) + kb * 2048 + wave * 8 * 64);
-                }
+                for (int kb = 0; kb < 8; ++kb) glds16_sc1(sa + kb * 64, ring(1) + kb * 2048 + wave * 8 * 64);
                 fstamp(l);                                   // f5: LN1 DMA issued
                 EF_WAIT_VM(0);
                 EF_BARRIER();
@@ -588,17 +590,18 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
 
         // =========================== P5: X' = LN(f + x1) -> bufA, column slice -> xout =======================================
         {
+            {   // x1 is complete since barrier 3: requested ahead of the wait (the whole ring is idle here)
+                const bf16_t* sx = reinterpret_cast<const bf16_t*>(L.x1) + (row0 + rsrc) * ED + csw * 8;
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) glds16_sc1(sx + kb * 64, ring(1) + kb * 2048 + wave * 8 * 64);
+            }
             arrivals += EH;
             cluster_wait(cnt, arrivals, p.err);
             stamp();                                         // [11] barrier 4 passed
-            {   // f and x1 by LDS-DMA (sc1) into slots 0 and 1 (the whole ring is idle here)
+            {   // f by LDS-DMA (sc1) into slot 0
                 const bf16_t* sa = reinterpret_cast<const bf16_t*>(L.f) + (row0 + rsrc) * ED + csw * 8;
-                const bf16_t* sx = reinterpret_cast<const bf16_t*>(L.x1) + (row0 + rsrc) * ED + csw * 8;
 #pragma unroll
-                for (int kb = 0; kb < 8; ++kb) {
-                    glds16_sc1(sa + kb * 64, ring(0) + kb * 2048 + wave * 8 * 64);
-                    glds16_sc1(sx + kb * 64, ring(1) + kb * 2048 + wave * 8 * 64);
-                }
+                for (int kb = 0; kb < 8; ++kb) glds16_sc1(sa + kb * 64, ring(0) + kb * 2048 + wave * 8 * 64);
                 EF_WAIT_VM(0);
                 EF_BARRIER();
             }
@@ -791,16 +794,20 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
 
         // =========================== B1: ds2 = LN2 backward, df = mask(ds2) -> bufA ==========================================
         {
+            // what the forward kept (f, x1, statistics) does not depend on the other workgroups: requested AHEAD of the cluster wait
+            // (for every layer but the first one processed: at the end of the previous iteration, behind its arrival signal)
+            if (l == p.layers - 1) {
+                rows512(reinterpret_cast<const bf16_t*>(L.f), 1, false);
+                rows512(reinterpret_cast<const bf16_t*>(L.x1), 2, false);
+            }
+            float g8[8], mu8[8], rs8[8];                     // this wave's rows' statistics and this lane's gammas travel with the DMA
+            ln_consts(L.g2, L.m2, L.r2, g8, mu8, rs8);
             if (l != p.layers - 1) {                        // the layer above has written every column of its dx
                 arrivals += EH;
                 cluster_wait(cnt, arrivals, p.err);
             }
             stamp();                                         // [b0] layer start
             rows512(dyin, 0, true);
-            rows512(reinterpret_cast<const bf16_t*>(L.f), 1, false);
-            rows512(reinterpret_cast<const bf16_t*>(L.x1), 2, false);
-            float g8[8], mu8[8], rs8[8];                     // this wave's rows' statistics and this lane's gammas travel with the DMA
-            ln_consts(L.g2, L.m2, L.r2, g8, mu8, rs8);
             EF_WAIT_VM(0);
             EF_BARRIER();
             float ag[8], ab[8];
@@ -874,6 +881,9 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
             stamp();                                         // [b2] B2 done
             cluster_signal(cnt);
         }
+        // this thread's piece of ds2 (its own workgroup's store, drained by the signal above): the addend of B4's epilogue
+        const long eoff = (row0 + ((tid >> 3) < S ? (tid >> 3) : S - 1)) * ED + h * 64 + (tid & 7) * 8;
+        const u32x4 ad2 = ld16_sc1(reinterpret_cast<const bf16_t*>(L.ds2) + eoff);
 
         // =========================== B4: dx1[:, h*64 ..] = dz W_1 + ds2 ======================================================
         {
@@ -892,19 +902,20 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g) glds16_sc1(DZ + (g * 16 + s) * 64, dst + g * 2048 + wave * 8 * 64);
             };
+            // the weight halves of the first three tiles do not depend on the other workgroups: in flight across the cluster wait
+            stageW(0, 0); stageW(1, 1); stageW(2, 2);
             arrivals += EH;
             cluster_wait(cnt, arrivals, p.err);
             stamp();                                         // [b3] barrier 1 passed
-            const long eoff = (row0 + ((tid >> 3) < S ? (tid >> 3) : S - 1)) * ED + h * 64 + (tid & 7) * 8;      // this thread's epilogue piece
-            const u32x4 ad = ld16_sc1(reinterpret_cast<const bf16_t*>(L.ds2) + eoff);
-            EF_WAIT_VM(0);
-            for (int s = 0; s < 3; ++s) { stageW(s, s); stageA(s, s); }
+            const u32x4 ad = ad2;
+            stageA(0, 0); stageA(1, 1); stageA(2, 2);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const int g = wave >> 1, jb = wave & 1;
             for (int s = 0; s < 16; ++s) {
-                if (s < 14) EF_WAIT_VM(12); else if (s == 14) EF_WAIT_VM(6); else EF_WAIT_VM(0);
+                // outstanding behind tile s: s = 0: the dz pieces of tiles 1, 2 (4); s = 1: dz of tile 2 + tile 3 (8); then tiles s+1, s+2 (12); the tail drains
+                if (s == 0) EF_WAIT_VM(4); else if (s == 1) EF_WAIT_VM(8); else if (s < 14) EF_WAIT_VM(12); else if (s == 14) EF_WAIT_VM(6); else EF_WAIT_VM(0);
                 EF_BARRIER();
                 if (s + 3 < 16) { stageW(s + 3, (s + 3) & 3); stageA(s + 3, (s + 3) & 3); }
                 const bf16_t* T = ring(s & 3);
@@ -947,14 +958,14 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
 
         // =========================== B5: ds1 = LN1 backward of dx1, dao = mask(ds1) -> bufA ==================================
         {
+            rows512(reinterpret_cast<const bf16_t*>(L.ao), 1, false);          // (the ring is idle: B4's K loop is behind a workgroup barrier)
+            rows512(reinterpret_cast<const bf16_t*>(L.xin), 2, false);
+            float g8[8], mu8[8], rs8[8];
+            ln_consts(L.g1, L.m1, L.r1, g8, mu8, rs8);
             arrivals += EH;
             cluster_wait(cnt, arrivals, p.err);
             stamp();                                         // [b5] barrier 2 passed
             rows512(reinterpret_cast<const bf16_t*>(L.dx1), 0, true);
-            rows512(reinterpret_cast<const bf16_t*>(L.ao), 1, false);
-            rows512(reinterpret_cast<const bf16_t*>(L.xin), 2, false);
-            float g8[8], mu8[8], rs8[8];
-            ln_consts(L.g1, L.m1, L.r1, g8, mu8, rs8);
             EF_WAIT_VM(0);
             EF_BARRIER();
             float ag[8], ab[8];
@@ -1099,6 +1110,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
             stamp();                                         // [b8] attention backward done
             cluster_signal(cnt);
         }
+        const u32x4 ad1 = ld16_sc1(reinterpret_cast<const bf16_t*>(L.ds1) + eoff);
 
         // =========================== B8: dx[:, h*64 ..] = dqkv W_qkv + ds1 ===================================================
         {
@@ -1118,19 +1130,18 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g) glds16_sc1(DQ + (g * HC + s) * 64, dst + g * 2048 + wave * 8 * 64);
             };
+            stageW(0, 0); stageW(1, 1); stageW(2, 2);        // (the attention's LDS scratch in slots 0 and 1 is behind the signal's workgroup barrier)
             arrivals += EH;
             cluster_wait(cnt, arrivals, p.err);
             stamp();                                         // [b9] barrier 3 passed
-            const long eoff = (row0 + ((tid >> 3) < S ? (tid >> 3) : S - 1)) * ED + h * 64 + (tid & 7) * 8;
-            const u32x4 ad = ld16_sc1(reinterpret_cast<const bf16_t*>(L.ds1) + eoff);
-            EF_WAIT_VM(0);
-            for (int s = 0; s < 3; ++s) { stageW(s, s); stageA(s, s); }
+            const u32x4 ad = ad1;
+            stageA(0, 0); stageA(1, 1); stageA(2, 2);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const int g = wave >> 1, jb = wave & 1;
             for (int s = 0; s < HC; ++s) {
-                if (s < HC - 2) EF_WAIT_VM(12); else if (s == HC - 2) EF_WAIT_VM(6); else EF_WAIT_VM(0);
+                if (s == 0) EF_WAIT_VM(4); else if (s == 1) EF_WAIT_VM(8); else if (s < HC - 2) EF_WAIT_VM(12); else if (s == HC - 2) EF_WAIT_VM(6); else EF_WAIT_VM(0);
                 EF_BARRIER();
                 if (s + 3 < HC) { stageW(s + 3, (s + 3) & 3); stageA(s + 3, (s + 3) & 3); }
                 const bf16_t* T = ring(s & 3);
@@ -1157,8 +1168,12 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
                 if (row < S) st16_sc1(reinterpret_cast<bf16_t*>(L.dx) + off, pack8(v));
             }
             stamp();                                         // [b10] B8 done
-            if (l > 0) cluster_signal(cnt);
-            __syncthreads();                                 // the staging in bufA is consumed before the next layer's DMA lands in the ring / bufA
+            if (l > 0) {
+                cluster_signal(cnt);                         // (its workgroup barrier: the staging in bufA is consumed, the ring is idle)
+                const svsr_enc_bwd_layer& Ln = p.Ls[l - 1];
+                rows512(reinterpret_cast<const bf16_t*>(Ln.f), 1, false);
+                rows512(reinterpret_cast<const bf16_t*>(Ln.x1), 2, false);
+            }
         }
     }
 }
