@@ -181,6 +181,20 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
         P8_BARRIER();
     }
 
+    // Epilogue operands (stagger bit 2): the rows of x / y / addend this tile's epilogue reads are TOUCHED three K tiles before the K loop
+    // ends — one dword per 128-byte line and thread, the value is dropped — so that the epilogue's own requests, which every workgroup
+    // of a round issues at about the same time, find the lines in L2 instead of arriving at HBM as one burst while the matrix pipes wait.
+    // MEASURED WITHOUT EFFECT (round 4: the BatchNorm-backward-epilogue launches 612-623 TFLOP/s with, 622-643 without; step 5.03 ms either
+    // way) — the epilogue's extra 8-14 us are not HBM latency; off by default, kept as a knob.
+    // (Inline asm: the compiler must neither wait for these loads nor reuse their registers before the counted wait that covers them;
+    // they are older than the DMA pieces the next P8_WAIT_VM leaves outstanding.)
+    unsigned pf0 = 0, pf1 = 0, pf2 = 0;
+    auto touch = [&](const bf16_t* base, long el) -> unsigned {
+        unsigned v;
+        const bf16_t* q = base + el;
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(q) : "memory");
+        return v;
+    };
     f32x16 acc[2][NJ];
     for (;;) {
         // ---- the following item (its meta data is requested during K tile 0, its pointers are built at K tile 2) ----------
@@ -244,6 +258,15 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                     // K tile kt + 1 has landed once only K tile kt + 2's six pieces (and, at kt = 0, the two meta pieces) are outstanding
                     if (kt == 0) { if (has_next) meta_dma(m2, par ^ 1); }
                     else P8_WAIT_VM(NPIECE);
+                    if ((stagger & 4) && kt == KT - 3 && (EPI == 1 || p.addend != nullptr) && (NJ == 2 || (tid & 1) == 0)) {
+                        const int dstpix = sRowTab[par * 512 + (tid >> 1) * 2 + 1];
+                        if (dstpix >= 0) {
+                            const long el = (long)dstpix * p.out_pitch + cur.n0 + (tid & 1) * 64;
+                            if (EPI == 1) pf0 = touch(p.bnb_x, el);
+                            if (EPI == 1 && p.bnb_y != nullptr) pf1 = touch(p.bnb_y, el);
+                            if (p.addend != nullptr) pf2 = touch(p.addend, el);
+                        }
+                    }
                 }
                 P8_WAIT_LGKM0();
                 stamp(kt, h, 1);
@@ -268,6 +291,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
             stream_advance();
             stg = stg == 2 ? 0 : stg + 1;
         }
+        asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2));       // (the touched dwords: their registers stay reserved until here)
         if ((stagger & 1) && wn == 0) P8_BARRIER();             // the groups meet again
         if (TRACE && ablate == 9 && blockIdx.x == 0 && r == 0) {
             P8_SYNC_ALL();
@@ -508,7 +532,7 @@ int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) 
     int G = items < cus ? items : cus;
     const int forced = svsr_tune_get(SVSR_TUNE_P8_GRID);
     if (forced > 0) G = forced < items ? forced : items;          // (above the CU count: one tile per workgroup, handed out by the dispatcher)
-    const int ph = svsr_tune_get(SVSR_TUNE_P8_PH) == 2 ? 2 : 1, stagger = svsr_tune_get(SVSR_TUNE_P8_STAGGER) & 3;      // bit 0: wave groups one barrier apart, bit 1: odd workgroups walk their rounds backwards
+    const int ph = svsr_tune_get(SVSR_TUNE_P8_PH) == 2 ? 2 : 1, stagger = svsr_tune_get(SVSR_TUNE_P8_STAGGER) & 7;      // bit 0: wave groups one barrier apart, bit 1: odd workgroups walk their rounds backwards, bit 2: epilogue operands touched ahead
 #define P8_LAUNCH(...) do { static bool set_ = false; \
         if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_p8<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); set_ = true; } \
         hipLaunchKernelGGL((k_igemm_p8<__VA_ARGS__>), dim3(G), dim3(512), LDS_BYTES, stream, a, stagger, svsr_tune_get(SVSR_TUNE_P8_TRACE)); } while (0)

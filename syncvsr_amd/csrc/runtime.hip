@@ -37,7 +37,7 @@ static int g_tune[SVSR_TUNE_N] = {
     /* P8_MIN_ITEMS */ 200,    // ... from this many 256x128 tiles on (fewer leave CUs idle for the whole launch)
     /* P8_TRACE */ 0,          // debug: the instrumented instantiation (per-phase time stamps of workgroup 0, svsr_debug_p8_trace)
     /* P8_PH */ 1,             // phases per K tile of the persistent kernel: 1 (16 MFMAs between barriers) or 2 (8)
-    /* P8_STAGGER */ 3,        // bit 0: its two wave groups run their phases one barrier apart; bit 1: odd workgroups walk their rounds last to first (their first epilogue falls elsewhere than the even ones')
+    /* P8_STAGGER */ 3,        // bit 2 (off): the epilogue's operand rows are touched three K tiles ahead (igemm_p8.hip; measured: BatchNorm-epilogue launches 622 vs 642 TFLOP/s without); bit 0: its two wave groups run their phases one barrier apart; bit 1: odd workgroups walk their rounds last to first (their first epilogue falls elsewhere than the even ones')
     /* WG_IMGMAJOR */ 1,       // svsr_igemm_wgrad plans with >= 64 images enumerate rows by (position, block of 64 images): wave-uniform DMA bases (0: row-major)
     /* C64_DEPHASED */ 0,      // experiment: svsr_conv3x3_c64 (plain epilogue) with two wave groups half a period apart — one contracts a chunk while the other drains and fetches; at parity with the lock-step kernel (0)
     /* P8_BN64 */ 1,           // 3x3 plans with too few 256 x 128 items for one per CU use 256 x 64 tiles of the persistent kernel (layer4); 0: the 4-wave kernel
