@@ -13,7 +13,7 @@ GROUPS = [
     ("their fixed-order slab reductions (k_wgrad_unit_reduce, k_wgrad3_reduce)", r"k_wgrad_unit_reduce|k_wgrad3_reduce"),
     ("k_igemm_p8 (layer2/3/4 3x3 forward + data gradient, stride-2 forward)", r"k_igemm_p8"),
     ("BatchNorm apply / finalise passes", r"k_bn_"),
-    ("fused encoder forward (k_enc_fwd)", r"k_enc_fwd|k_enc_table"),
+    ("fused encoder forward + backward (k_enc_fwd, k_enc_bwd)", r"k_enc_fwd|k_enc_bwd|k_enc_table|k_enc_bwd_table"),
     ("4-wave contraction, 64x64 tiles (encoder data gradients, heads)", r"k_igemm_fwd_glds<64"),
     ("4-wave contraction, 128-row tiles (stride-2 data gradients, 1x1 convolutions, heads)", r"k_igemm_fwd_glds<128"),
     ("stem (conv fwd, wgrad, BN+GELU+pool fwd, bwd, prep)", r"k_stem_"),
