@@ -185,7 +185,8 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
     // ends — one dword per 128-byte line and thread, the value is dropped — so that the epilogue's own requests, which every workgroup
     // of a round issues at about the same time, find the lines in L2 instead of arriving at HBM as one burst while the matrix pipes wait.
     // MEASURED WITHOUT EFFECT (round 4: the BatchNorm-backward-epilogue launches 612-623 TFLOP/s with, 622-643 without; step 5.03 ms either
-    // way) — the epilogue's extra 8-14 us are not HBM latency; off by default, kept as a knob.
+    // way) — the epilogue's extra 8-14 us are not HBM latency; off by default, kept as a knob.  (Spread over the K loop instead — thread t at K
+    // tile 1 + t % 16 — it is worse, 593-595 TFLOP/s: every counted wait then sits out one HBM round trip.)
     // (Inline asm: the compiler must neither wait for these loads nor reuse their registers before the counted wait that covers them;
     // they are older than the DMA pieces the next P8_WAIT_VM leaves outstanding.)
     unsigned pf0 = 0, pf1 = 0, pf2 = 0;
