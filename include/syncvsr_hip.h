@@ -73,7 +73,7 @@ extern "C" {
 /* ---- plumbing (runtime.hip) ------------------------------------------------------------------------------------
  * svsr_tune: sets a result-preserving tuning knob ("igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd",
  * "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe",
- * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased", "p8_bn64": tile shapes, split counts, kernel-variant switches — documented at the table in runtime.hip;
+ * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased", "p8_bn64", "p8_lin_items": tile shapes, split counts, kernel-variant switches — documented at the table in runtime.hip;
  * never read from the environment); unknown key -> SVSR_ERR_ARG.
  * svsr_colsum_rows: out[c] (+)= scale * sum_{r<nrows} ws[r*ld + c], rows added in a fixed order; columns [0,n0) go to out0,
  * [n0,n0+n1) to out1 (may be null when n1 = 0); accumulate != 0 adds to the existing values. */
@@ -109,6 +109,9 @@ int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_
  *   per-channel BatchNorm partial sums stats[tiles][2][Co] (plain stores; reduced by svsr_bn_finalize). */
 int svsr_conv_plan(int mode, int Nimg, int H, int W, int Co_out, int k, int stride, int pad, int* words, int cap_words, int* meta);
 int svsr_rows_plan(int Nimg, int P, int src0, int dst0, int Co_out, int* words, int cap_words, int* meta);
+/* the same for a launch whose contraction depth Ci is known: large plain dense layers (P = 1, Ci >= 256, Co % 128 == 0, >= tune "p8_lin_items"
+ * 256 x 128 items) get the persistent 8-wave kernel's plan, whose launch supports bias, ReLU, dropout, alpha and addend (no GELU, no fp32 output) */
+int svsr_rows_plan_k(int Nimg, int P, int src0, int dst0, int Co_out, int Ci, int* words, int cap_words, int* meta);
 int svsr_igemm_fwd_kgroups(const int* meta, int Ci, int Co, int bn_epilogue);   /* host query: 2 when the launch splits K over two wave groups (k_igemm_fwd_glds<64,64,4,2>) */
 int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 

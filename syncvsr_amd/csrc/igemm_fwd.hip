@@ -904,6 +904,23 @@ extern "C" int svsr_rows_plan(int Nimg, int P, int src0, int dst0, int Co_out, i
     return n;
 }
 
+/* svsr_rows_plan_k (host): svsr_rows_plan for a launch whose contraction depth Ci is known.  A plain dense layer (P = 1, src0 = dst0 = 0) with
+ * Ci >= 256, Co a multiple of 128 and at least `p8_lin_items` (tune key; default 0 = never: measured slower, see runtime.hip) 256 x 128 work items gets the persistent
+ * 8-wave kernel's plan (svsr_igemm_fwd then runs k_igemm_p8 with the dense layers' epilogue: bias, ReLU, dropout, alpha, addend — no GELU,
+ * no fp32 output); everything else the plan svsr_rows_plan returns.  At 2,560 rows (the sentence-level model's 16 x 160 frames): the
+ * 3,072- and 2,304-wide layers (240 / 180 items). */
+extern "C" int svsr_rows_plan_k(int Nimg, int P, int src0, int dst0, int Co_out, int Ci, int* words, int cap_words, int* meta) {
+    const int min_items = svsr_tune_get(SVSR_TUNE_P8_LIN_ITEMS);
+    if (P == 1 && src0 == 0 && dst0 == 0 && Nimg >= 1 && Ci % 64 == 0 && Ci >= 256 && Co_out % P8_BN == 0 && min_items > 0 && svsr_tune_get(SVSR_TUNE_P8) &&
+        (long)((Nimg + P8_BM - 1) / P8_BM) * (Co_out / P8_BN) >= min_items) {
+        std::vector<PlanClass> cls(1);
+        cls[0].ntaps = 1; cls[0].delta[0] = 0; cls[0].tw[0] = 0;
+        cls[0].pos.push_back(0); cls[0].pos.push_back(0);
+        return plan_emit_p8(cls, Nimg, Co_out, 1, 1, words, cap_words, meta, (long)Nimg, 1, P8_BN);
+    }
+    return svsr_rows_plan(Nimg, P, src0, dst0, Co_out, words, cap_words, meta);
+}
+
 /* rows of [2][Co] BatchNorm partials svsr_conv3x3_res writes (one per 128-pixel tile) */
 extern "C" int svsr_conv3x3_res_stat_rows(int Nimg, int H, int W) { return (Nimg < 1 || H < 1 || W < 1) ? 0 : (int)(((long)Nimg * H * W + 127) / 128); }
 

@@ -81,6 +81,8 @@ __device__ __forceinline__ bool p8_next_item(int tiles_m, int gy, int items, int
 }  // namespace
 
 // EPI 0: out = acc (+ addend), optional BatchNorm partials of the fp32 accumulators;  EPI 1: BatchNorm-backward fusion (bnb_*)
+// EPI 2 / 3: the dense layers' epilogue  out = alpha * dropout(relu?(acc + bias)) + addend  (3: with dropout) — the arithmetic and its order are
+// k_igemm_fwd_glds's (igemm_fwd.hip), and so are the bits: one accumulator per output walks k upwards in both kernels
 // TRACE (debug builds of the probe only): waves 0 and 4 of workgroup 0 stamp s_memtime at four points of every phase of their first tile
 // into the (then idle) reduction scratch and dump it to g_p8_trace before the epilogue: [K tile][phase][wave group][4]
 __device__ unsigned long long g_p8_trace[1024];
@@ -342,6 +344,8 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                 }
             }
             const bool from_x = p.bnb_y == nullptr, swish_act = p.bnb_act == 2, has_add = p.addend != nullptr;
+            const bool lin_relu = p.act == 2;
+            const unsigned dkey = (EPI == 3) ? drop_key(p.drop) : 0u;
             float bs1[NJ][4], bs2[NJ][4];
             if (EPI == 1) {
 #pragma unroll
@@ -379,6 +383,11 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                             }
                         }
                 }
+                float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (EPI >= 2 && p.bias != nullptr) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) b4[k] = p.bias[n + k];
+                }
                 float mu[4], rs[4], sc[4], sh[4];
                 if (EPI == 1) {
 #pragma unroll
@@ -397,6 +406,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 #pragma unroll
                         for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(add_all[i][k].x), "+v"(add_all[i][k].y));
                 }
+                if (EPI >= 2) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
                 if (EPI == 1) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
@@ -427,6 +437,15 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                         // trip per row, 6 us per tile.  Padding rows compute on row 0's operands and are masked out of sums and stores.)
                         const bool live = offs[i][k] >= 0;
                         float v[4] = {rowv[k][0], rowv[k][1], rowv[k][2], rowv[k][3]};
+                        if (EPI >= 2) {     // (selects and multiplications by 1, no uniform branches: see the note on hipcc's waits above)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                v[c] += b4[c];
+                                v[c] = lin_relu ? fmaxf(v[c], 0.f) : v[c];
+                                if (EPI == 3) v[c] = drop_keep(dkey, p.drop.thresh, (unsigned)(offs[i][k] + n + c)) ? v[c] * p.drop.scale : 0.f;
+                                v[c] *= p.alpha;
+                            }
+                        }
                         {   // (selects, not a branch: a uniform branch in every row has the same effect on hipcc's waits as the early exit)
                             const unsigned ax = has_add ? add4[k].x : 0u, ay = has_add ? add4[k].y : 0u;
                             v[0] += __uint_as_float(ax << 16); v[1] += __uint_as_float(ax & 0xffff0000u);
@@ -521,7 +540,9 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 // ---------------------------------------------------------------------------------------------------------------------------------
 int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) {
     // meta: {256, 128, 3, M tiles, gy, classes, max taps, rows}; the epilogues this kernel has: (+addend | BatchNorm-backward), BatchNorm partials
-    if (a.bias != nullptr || a.act != 0 || a.out_f32 || a.out_pre != nullptr || a.alpha != 1.f || a.drop.seed != nullptr) return SVSR_ERR_ARG;
+    if (a.act == 1 || a.out_f32 || a.out_pre != nullptr) return SVSR_ERR_ARG;
+    const bool lin = a.bias != nullptr || a.act == 2 || a.alpha != 1.f || a.drop.seed != nullptr;      // the dense layers' epilogue (EPI 2 / 3)
+    if (lin && (a.bnb_x != nullptr || a.stats != nullptr)) return SVSR_ERR_ARG;
     const int bn = meta[1];                     // 128, or 64 (plans whose 128-wide items would not fill the chip)
     if ((bn != BN && bn != 64) || a.Co % bn != 0 || a.out_pitch % 8 != 0 || a.Ci % BK != 0) return SVSR_ERR_ARG;
     // per-lane addresses are 32-bit byte offsets from the tensor bases
@@ -537,7 +558,8 @@ int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) 
 #define P8_LAUNCH(...) do { static bool set_ = false; \
         if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_p8<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); set_ = true; } \
         hipLaunchKernelGGL((k_igemm_p8<__VA_ARGS__>), dim3(G), dim3(512), LDS_BYTES, stream, a, stagger, svsr_tune_get(SVSR_TUNE_P8_TRACE)); } while (0)
-    if (bn == 64) { if (a.bnb_x != nullptr) P8_LAUNCH(1, 1, false, 1); else P8_LAUNCH(0, 1, false, 1); }
+    if (lin) { if (bn != BN) return SVSR_ERR_ARG; if (a.drop.seed != nullptr) P8_LAUNCH(3, 1, false); else P8_LAUNCH(2, 1, false); }
+    else if (bn == 64) { if (a.bnb_x != nullptr) P8_LAUNCH(1, 1, false, 1); else P8_LAUNCH(0, 1, false, 1); }
     else if (svsr_tune_get(SVSR_TUNE_P8_TRACE) && a.bnb_x == nullptr) { if (ph == 2) P8_LAUNCH(0, 2, true); else P8_LAUNCH(0, 1, true); }
     else if (a.bnb_x != nullptr) { if (ph == 2) P8_LAUNCH(1, 2, false); else P8_LAUNCH(1, 1, false); }
     else { if (ph == 2) P8_LAUNCH(0, 2, false); else P8_LAUNCH(0, 1, false); }

@@ -45,8 +45,11 @@ static int g_tune[SVSR_TUNE_N] = {
     /* WG_UNITS */ 1,          // svsr_igemm_wgrad plans of long contractions as balanced unit lists (format 2); 0: (K split, task) grids
     /* WG_UNIT_MAX */ 48,      // ... longest unit in 64-row chunks before the list takes a further round of workgroups
     /* WG_UNIT_MIN */ 8,       // ... shortest unit worth a slab tile of its own
+    /* P8_LIN_ITEMS */ 0,      // dense layers with at least this many 256 x 128 items run k_igemm_p8 (svsr_rows_plan_k); 0: never.  OFF: at 2,560 rows x 3,072 columns x K = 768
+                               // (240 items, one per CU, 12 K tiles each) the persistent kernel takes 34.1 us against 23.8 of k_igemm_fwd_glds<128,128,2> (hipBLASLt: 19.4) — its
+                               // prologue and wave-private epilogue are amortised over 18-36 K tiles and several tiles per CU in the convolutions, not here; LRS step 25.3 vs 25.1 ms
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "p8_lin_items"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 

@@ -391,11 +391,16 @@ def conv_plan(mode: int, N: int, H: int, W: int, Co_out: int, k: int, stride: in
     return pl
 
 
-def rows_plan(Nimg: int, P: int, src0: int, dst0: int, Co_out: int) -> Plan:
-    key = ("rows", Nimg, P, src0, dst0, Co_out)
+def rows_plan(Nimg: int, P: int, src0: int, dst0: int, Co_out: int, Ci: Optional[int] = None) -> Plan:
+    """Ci (the contraction depth, when the launch has neither a GELU nor an fp32 output): lets large plain dense layers take the persistent
+    8-wave kernel (svsr_rows_plan_k)."""
+    key = ("rows", Nimg, P, src0, dst0, Co_out, Ci)
     pl = _PLAN_CACHE.get(key)
     if pl is None:
-        pl = _PLAN_CACHE[key] = Plan("svsr_rows_plan", Nimg, P, src0, dst0, Co_out)
+        if Ci is None:
+            pl = _PLAN_CACHE[key] = Plan("svsr_rows_plan", Nimg, P, src0, dst0, Co_out)
+        else:
+            pl = _PLAN_CACHE[key] = Plan("svsr_rows_plan_k", Nimg, P, src0, dst0, Co_out, Ci)
     return pl
 
 
@@ -728,7 +733,7 @@ def linear_fwd(x: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor],
         out = torch.empty((rows, out_pitch), dtype=torch.float32 if out_f32 else BF16, device=x.device)
     pre = torch.empty_like(out) if gelu else None
     if seq is None:
-        plan, geo = rows_plan(rows, 1, 0, 0, N), dict(Nimg=rows, in_pix=1, out_pix=1)
+        plan, geo = rows_plan(rows, 1, 0, 0, N, None if (gelu or out_f32 or out_pitch % 8) else K), dict(Nimg=rows, in_pix=1, out_pix=1)
     else:
         S, s0, n = seq
         plan, geo = rows_plan(rows // n, n, s0, 0, N), dict(Nimg=rows // n, in_pix=S, out_pix=n)
@@ -746,7 +751,7 @@ def linear_dgrad(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, K: 
     if seq is None:
         if out is None:
             out = torch.empty((rows, K), dtype=BF16, device=dy.device)
-        plan, geo = rows_plan(rows, 1, 0, 0, K), dict(Nimg=rows, in_pix=1, out_pix=1)
+        plan, geo = rows_plan(rows, 1, 0, 0, K, Np), dict(Nimg=rows, in_pix=1, out_pix=1)
     else:
         S, s0, n = seq
         assert out is not None
