@@ -535,6 +535,9 @@ class _ParamStore:
         ops.transpose_shadows(self.flat, self.w16, self.w16t, self.table, self.n_entries)
 
     def zero_grad(self) -> None:
+        if self.__dict__.get("grad_clean", False):       # engine.TrainStep zeroed the buffer on the side stream when the step began
+            self.grad_clean = False
+            return
         ops.memset(self.grad, 0)
 
     def rebind_grads(self) -> None:
