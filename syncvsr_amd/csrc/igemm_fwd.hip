@@ -45,7 +45,7 @@ __device__ unsigned g_zero_page[64];     // 256 zero bytes: DMA source for rows 
 // ---------------------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&acc)[TM][TN], unsigned char* smem_raw, const long* sRow,
-                                               int wm0, int wn0, int n0, int tid, bool active) {
+                                               int wm0, int wn0, int n0, int tid, bool active, int m_tile) {
     // tid: 0..255 inside the group of four waves that owns the tile; `active` is false for the waves of a second K group, which only
     // take part in the barriers
     constexpr int WN = BN / 2;
@@ -294,7 +294,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
             const int which = c / BN, cc = c - which * BN;
             float s = 0.f;
             for (int rb = 0; rb < RSTEP; ++rb) s += red[(rb * CV + (cc >> 3)) * 16 + which * 8 + (cc & 7)];
-            if (n0 + cc < p.Co) p.stats[((long)blockIdx.x * 2 + which) * p.Co + n0 + cc] = s;
+            if (n0 + cc < p.Co) p.stats[((long)m_tile * 2 + which) * p.Co + n0 + cc] = s;
         }
     } else if (p.stats != nullptr) {
         __syncthreads();
@@ -311,8 +311,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
             const float s = red[((0 * 2 + wcol) * WN + cc) * 2 + 0] + red[((1 * 2 + wcol) * WN + cc) * 2 + 0];
             const float q = red[((0 * 2 + wcol) * WN + cc) * 2 + 1] + red[((1 * 2 + wcol) * WN + cc) * 2 + 1];
             if (n0 + c < p.Co) {
-                p.stats[((long)blockIdx.x * 2 + 0) * p.Co + n0 + c] = s;
-                p.stats[((long)blockIdx.x * 2 + 1) * p.Co + n0 + c] = q;
+                p.stats[((long)m_tile * 2 + 0) * p.Co + n0 + c] = s;
+                p.stats[((long)m_tile * 2 + 1) * p.Co + n0 + c] = q;
             }
         }
     }
@@ -382,7 +382,20 @@ __global__ __launch_bounds__(256 * KG) void k_igemm_fwd_glds(const IgemmFwdArgs 
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    const int n0 = blockIdx.y * BN;
+    // Which tile this workgroup computes.  Workgroups are dispatched in the order of their linear index (x fastest) round-robin over the 8
+    // XCDs, each with its own 4 MiB L2: left alone, an XCD's share of a 20 x 24 tile grid touches every row tile and every column tile of
+    // the GEMM (8.6 MB of operands at 2,560 x 3,072 x 768) and its L2 thrashes — the staging then runs at the ~40-50 GB/s per CU of the
+    // Infinity Cache instead of the ~115 GB/s of an L2 hit (scripts/probes/fill_rate_probe.hip).  xcd_rx > 0: the grid is cut into
+    // xcd_rx x (8 / xcd_rx) rectangles, one per XCD, so that an XCD's workgroups share the fewest distinct operand tiles (10 x 6 tiles
+    // there: 3.1 MB).  A permutation of the tiles: results do not change.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_rx > 0) {
+        const int gx = gridDim.x, hw = blockIdx.x + gx * blockIdx.y, xcd = hw & 7, idx = hw >> 3;
+        const int RX = p.xcd_rx, sx = gx / RX, sy = (int)gridDim.y / (8 / RX);
+        bx = (xcd % RX) * sx + idx % sx;
+        by = (xcd / RX) * sy + idx / sx;
+    }
+    const int n0 = by * BN;
     const int slot = tid & 7, r0 = tid >> 3;                 // lane writes LDS chunk `slot` of row r0 + 32*i ...
     const int csw = slot ^ ((r0 >> 1) & 7);                  // ... which must hold global chunk csw (swizzle on the source)
     const int wrow = __builtin_amdgcn_readfirstlane(wave) * 8;   // first row of this wave's 8-row group
@@ -395,11 +408,11 @@ __global__ __launch_bounds__(256 * KG) void k_igemm_fwd_glds(const IgemmFwdArgs 
     const bool identity = (hdr0 >> 16) != 0;
     int cls = 0;
     for (int c = 1; c < ncls; ++c)
-        if ((int)blockIdx.x >= p.plan[PLAN_HDR_WORDS + c * PLAN_CLS_WORDS + 3]) cls = c;
+        if (bx >= p.plan[PLAN_HDR_WORDS + c * PLAN_CLS_WORDS + 3]) cls = c;
     const int* cw = p.plan + PLAN_HDR_WORDS + cls * PLAN_CLS_WORDS;
     const int ntaps = cw[0], P = cw[1];
     const int* pos = p.plan + p.plan[1] + 2 * cw[2];
-    const int m0 = ((int)blockIdx.x - cw[3]) * BM;
+    const int m0 = (bx - cw[3]) * BM;
     const int Mc = p.Nimg * P;
     const float inv_p = 1.0f / (float)P;
     if (tid < 18) sTap[tid] = cw[4 + tid];                 // (both K groups write the same values)
@@ -525,7 +538,7 @@ __global__ __launch_bounds__(256 * KG) void k_igemm_fwd_glds(const IgemmFwdArgs 
         }
         __syncthreads();
     }
-    igemm_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, sRow, wm0, wn0, n0, tid, grp == 0);
+    igemm_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, sRow, wm0, wn0, n0, tid, grp == 0, bx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -669,7 +682,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_res(const ResArgs q) {
         }
     }
     __syncthreads();
-    igemm_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, sRow, wm0, wn0, n0, tid, true);
+    igemm_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, sRow, wm0, wn0, n0, tid, true, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -681,7 +694,18 @@ static int launch_glds(const IgemmFwdArgs& a, int gx, int gy, hipStream_t stream
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_fwd_glds<BM, BN, NS, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = lds;
     }
-    hipLaunchKernelGGL((k_igemm_fwd_glds<BM, BN, NS, KG>), dim3(gx, gy), dim3(256 * KG), lds, stream, a);
+    IgemmFwdArgs b = a;
+    b.xcd_rx = 0;
+    if (svsr_tune_get(SVSR_TUNE_IGEMM_XCD) && (long)gx * gy % 8 == 0 && (long)gx * gy >= 64) {
+        long best = -1;
+        for (int rx = 1; rx <= 8; rx *= 2) {          // rectangles of (gx / rx) x (gy / (8 / rx)) tiles: fewest distinct operand rows per XCD
+            const int ry = 8 / rx;
+            if (gx % rx != 0 || gy % ry != 0) continue;
+            const long cost = (long)(gx / rx) * BM + (long)(gy / ry) * BN;
+            if (best < 0 || cost < best) { best = cost; b.xcd_rx = rx; }
+        }
+    }
+    hipLaunchKernelGGL((k_igemm_fwd_glds<BM, BN, NS, KG>), dim3(gx, gy), dim3(256 * KG), lds, stream, b);
     return svsr_check_launch();
 }
 
@@ -939,7 +963,7 @@ extern "C" int svsr_conv3x3_res(const void* in, const void* wt, void* out, const
     a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = out; a.out_pre = nullptr; a.bias = nullptr; a.addend = (const bf16_t*)addend;
     a.stats = stats; a.plan = nullptr; a.Nimg = Nimg; a.in_pix = H * W; a.Ci = Ci; a.in_pitch = Ci; a.Co = Co; a.out_pix = H * W; a.out_pitch = Co;
     a.wt_taps = 9; a.act = 0; a.out_f32 = 0; a.alpha = 1.f; a.drop = svsr_make_drop(nullptr, 0, 0.f);
-    a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED);
+    a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED); a.xcd_rx = 0;
     a.bnb_y = nullptr; a.bnb_x = nullptr; a.bnb_mean = nullptr; a.bnb_rstd = nullptr; a.bnb_gamma = nullptr; a.bnb_beta = nullptr; a.bnb_act = 0;
     q.H = H; q.W = W; q.M = (int)M;
     for (int t = 0; t < 9; ++t) {
@@ -994,7 +1018,7 @@ static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pr
     a.Nimg = Nimg; a.in_pix = in_pix; a.Ci = Ci; a.in_pitch = in_pitch; a.Co = Co; a.out_pix = out_pix; a.out_pitch = out_pitch;
     a.wt_taps = wt_taps; a.act = act; a.out_f32 = out_f32; a.alpha = alpha;
     a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
-    a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED);
+    a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED); a.xcd_rx = 0;
     a.bnb_y = (const bf16_t*)bnb_y; a.bnb_x = (const bf16_t*)bnb_x; a.bnb_mean = bnb_mean; a.bnb_rstd = bnb_rstd;
     a.bnb_gamma = bnb_gamma; a.bnb_beta = bnb_beta; a.bnb_act = bnb_act;
     const int bm = meta[0], bn = meta[1], ns = meta[2], gx = meta[3], gy = (Co + bn - 1) / bn;

@@ -48,8 +48,11 @@ static int g_tune[SVSR_TUNE_N] = {
     /* P8_LIN_ITEMS */ 0,      // dense layers with at least this many 256 x 128 items run k_igemm_p8 (svsr_rows_plan_k); 0: never.  OFF: at 2,560 rows x 3,072 columns x K = 768
                                // (240 items, one per CU, 12 K tiles each) the persistent kernel takes 34.1 us against 23.8 of k_igemm_fwd_glds<128,128,2> (hipBLASLt: 19.4) — its
                                // prologue and wave-private epilogue are amortised over 18-36 K tiles and several tiles per CU in the convolutions, not here; LRS step 25.3 vs 25.1 ms
+    /* IGEMM_XCD */ 0,         // k_igemm_fwd_glds: tile grid cut into one rectangle per XCD (operands of an XCD's workgroups fit its L2).  OFF: measured without effect
+                               // (2,560 x 3,072 x 768: 23.7 vs 25.4 us run to run, the other LRS shapes within 3 %): these launches are bound by the DMA round trip
+                               // per K step of their 2-deep ring (12 K steps), not by where the tiles come from
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "p8_lin_items"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "p8_lin_items", "igemm_xcd"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 
