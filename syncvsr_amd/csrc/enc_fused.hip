@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // cluster / head of this workgroup: with a multiple of 8 sequences the 8 workgroups of a cluster share blockIdx % 8 (observed to be
     // the XCD: the exchanged tensors stay in one L2's neighbourhood; with a HEAD per XCD instead — weights L2-resident — the weight
-    // stream was no faster, it is bound by the CU's LDS-DMA path at ~20 B/clk, and every exchange slower: 458 vs 319 us).  Speed only.
+    // stream was no faster and every exchange slower: 458 vs 319 us).  Speed only.
     int c, h;
     {
         const int i = blockIdx.x;
