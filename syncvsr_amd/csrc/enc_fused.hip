@@ -1056,6 +1056,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
                     const int i = 8 * wave + q + 4 * (lane >> 5);
                     keep[q] = !drop_on || drop_keep(key_pr, p.th_attn, (unsigned)(((long)bh * S + i) * ldp + j));
                     dp[q] = (i < S && j < S) ? (drop_on ? (keep[q] ? x * p.sc_attn : 0.f) : x) : 0.f;
+                    asm volatile("" : "+v"(dp[q]));          // a rounded product (k_mha_bwd_q4 keeps it in LDS): not to be fused into dp - rowsum below
                     part[q] = prv[q] * dp[q];
                 }
 #pragma unroll
