@@ -142,6 +142,8 @@ int svsr_igemm_wgrad_group(const svsr_wgrad_problem* problems, int n, void* tabl
  * weight tap tw[t] (HOST arrays of 9 ints); out = conv (+ addend); stats [rows][2][64] with rows =
  * svsr_conv3x3_c64_stat_rows(Nimg, H, W) (one per persistent workgroup).  Requires W <= 29. */
 int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W);
+/* the same for a launch on `stream` (a CU-masked stream runs fewer persistent workgroups: svsr_stream_create_cumask) */
+int svsr_conv3x3_c64_stat_rows_on(int Nimg, int H, int W, hipStream_t stream);
 /* pixtab (both launches below): device copy of svsr_conv3x3_c64_pixtab's table for (Nimg, H, W) — pixel index or -1 per padded
  * coordinate — or null.  With the table AND the tuning knob "c64_dephased" set, launches without the BatchNorm-backward epilogue take
  * the de-phased kernel (two wave groups half a period apart: one contracts a chunk while the other drains the previous one and
@@ -332,6 +334,11 @@ int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream);
  * layer writes has the contents the unfused launches (svsr_igemm_fwd, svsr_mha_fwd, svsr_add_ln_fwd) give it, dropout masks included.
  * ws: svsr_enc_fwd_ws_bytes(B) bytes of device workspace (arrival counters, zeroed here; word B = error flag, non-zero if a bounded
  * wait gave up; the layer records). */
+/* A bounded cluster wait that gives up is LOUD: the launch's error word (word B of ws) is set, the giving-up workgroup overwrites its slice
+ * of the launch's final output with NaN (the step's loss / gradient norm turn NaN without a host synchronisation), and a sticky
+ * process-wide flag is set that svsr_enc_gave_up(reset) returns (1 / 0; it synchronises: call it where the host waits anyway;
+ * engine.TrainStep.state() raises on it).  A launch holds at most svsr_stream_cu_count(stream) / 8 sequences. */
+int svsr_enc_gave_up(int reset);
 int64_t svsr_enc_fwd_ws_bytes(int B);
 int svsr_debug_enc_trace(int64_t* out, int n);     /* debug: out == null arms s_memtime stamps of workgroup 0 at the phase boundaries of the next launches; else copies n stamps out */
 int svsr_enc_fwd(const void* x0, const svsr_enc_layer* layers, int n_layers, int B, int S, float ln_eps, const unsigned* drop_seed, float p_hidden, float p_attn, void* ws, int64_t ws_bytes, hipStream_t stream);
@@ -439,6 +446,17 @@ int64_t svsr_steplist_size(void* list);
 int svsr_steplist_run(void* list, int segment, int* failed);
 int svsr_stream_wait(hipStream_t waiter, hipStream_t signaller);
 int svsr_memset_async(void* ptr, int value, int64_t bytes, hipStream_t stream);
+
+/* Streams restricted to a subset of the compute units (csrc/runtime.hip; hipExtStreamCreateWithCUMask).  The step being scheduled is the
+ * reference's training_step + optimizer step (LRW/video/src/lightning.py:194-202,216-223): its main stream (forward, data gradients) and
+ * its side stream (weight gradients, parameter-gradient reductions, most of AdamW) can be given DISJOINT compute units, and every
+ * persistent kernel sizes its grid / static tile list / cluster count by svsr_stream_cu_count of the stream it is launched on.
+ * mask: `words` 32-bit words, bit i = compute unit i in the driver's numbering (gfx950: XCD i % 8, then shader engine, then CU).
+ * svsr_stream_destroy only accepts streams made here.  svsr_device_cus: compute units of the current device. */
+int svsr_stream_create_cumask(const uint32_t* mask, int words, hipStream_t* out);
+int svsr_stream_destroy(hipStream_t stream);
+int svsr_stream_cu_count(hipStream_t stream);
+int svsr_device_cus(void);
 
 #ifdef __cplusplus
 }

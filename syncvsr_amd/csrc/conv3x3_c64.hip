@@ -582,16 +582,17 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64d(const Conv64Args p
     }
 }
 
-static int c64_grid(long total_chunks) {
-    static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+static int c64_grid(long total_chunks, hipStream_t stream) {
+    const int cus = svsr_stream_cus(stream);
     return (int)(total_chunks < cus ? total_chunks : cus);
 }
 
 /* rows of [2][64] BatchNorm partials svsr_conv3x3_c64 writes for this shape (= its persistent workgroups) */
-extern "C" int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W) {
+extern "C" int svsr_conv3x3_c64_stat_rows_on(int Nimg, int H, int W, hipStream_t stream) {
     if (Nimg < 1 || H < 1 || W < 1) return 0;
-    return c64_grid(((long)Nimg * (H + 2) * (W + 2) + C64_CH - 1) / C64_CH);
+    return c64_grid(((long)Nimg * (H + 2) * (W + 2) + C64_CH - 1) / C64_CH, stream);
 }
+extern "C" int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W) { return svsr_conv3x3_c64_stat_rows_on(Nimg, H, W, nullptr); }
 
 static int c64_run(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
                    const int* dy, const int* dx, const int* tw, const void* bnb_y, const void* bnb_x, const float* bnb_mean,
@@ -618,7 +619,7 @@ static int c64_run(const void* in, const void* wt, void* out, const void* addend
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64d<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64D_LDS_BYTES);
         attr = true;
     }
-    const int grid = c64_grid(a.total_chunks);
+    const int grid = c64_grid(a.total_chunks, stream);
     // de-phased kernel (tune key c64_dephased, off by default: 58.8 vs 57.4 us at the LRW shape): forward /
     // plain data-gradient launches only — its BatchNorm-backward epilogue does not fit the register file next to 64 accumulators
     if (svsr_tune_get(SVSR_TUNE_C64_DEPHASED) && pixtab != nullptr && bnb_x == nullptr && (long)Nimg * H * W * 128 < (1L << 32)) {

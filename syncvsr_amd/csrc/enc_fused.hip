@@ -86,15 +86,35 @@ __device__ __forceinline__ void cluster_signal(unsigned* cnt) {
 }
 // (the same when weight tiles of the next phase are already in flight: vmcnt(0) waits for them too — the price of one counter for loads and stores)
 __device__ __forceinline__ void cluster_signal_keep_dma(unsigned* cnt) { cluster_signal(cnt); }
-__device__ __forceinline__ void cluster_wait(unsigned* cnt, unsigned target, unsigned* err) {
+// A wait that gives up (the 8 workgroups of a sequence were not resident together: a CU-masked or partitioned device, a co-tenant holding
+// LDS) must not pass silently: the launch's error word is set (cleared by the next launch's memset: the tests read it), the STICKY word
+// g_enc_gave_up is set (never cleared by a launch: svsr_enc_gave_up / engine.TrainStep.state raise on it), and the workgroup poisons its
+// slice of the launch's final output with NaN (enc_poison below), so the loss of this step (forward) or the gradient norm and every
+// parameter after it (backward) turn NaN without a host synchronisation.
+__device__ unsigned g_enc_gave_up = 0;
+__device__ __forceinline__ void cluster_wait(unsigned* cnt, unsigned target, unsigned* err, bool& gave_up) {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 20)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++spins > (1u << 20)) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&g_enc_gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = true;
+                break;
+            }
         }
     }
     __syncthreads();
+}
+// end of a launch: thread 0 of a workgroup whose wait gave up overwrites the first 8 columns of its slice of row 0 of the final output with NaN
+__device__ __forceinline__ void enc_poison(bool gave_up, bf16_t* dst) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && gave_up) {
+        u32x4 nan; nan.x = nan.y = nan.z = nan.w = 0x7fc07fc0u;
+        st16_sc1(dst, nan);
+    }
 }
 
 __device__ __forceinline__ bf16x8 lds_frag(const bf16_t* blk, int row, int chunk) {
@@ -169,6 +189,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
     const int bh = (p.seq0 + c) * EH + h;
     unsigned* cnt = p.cnt + c;
     unsigned arrivals = 0;                                          // barrier target so far
+    bool gave_up = false;                                           // (thread 0's copy counts)
     int tix = 0;
     auto stamp = [&]() {
         if (p.trace != nullptr && blockIdx.x == 0 && tid == 0 && tix < 500) p.trace[tix] = __builtin_amdgcn_s_memtime();
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
         // =========================== P2: ao[:, h*64 ..] = dropout(ctx W_o^T + b) =============================================
         {
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err);
+            cluster_wait(cnt, arrivals, p.err, gave_up);
             stamp();                                         // [4] barrier 1 passed
             {   // every head's ctx -> bufA
                 const bf16_t* src = reinterpret_cast<const bf16_t*>(L.ctx) + (row0 + rsrc) * ED + csw * 8;
@@ -436,7 +457,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
                 for (int kb = 0; kb < 8; ++kb) glds16_sc1(sx + kb * 64, ring(2) + kb * 2048 + wave * 8 * 64);
             }
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err);
+            cluster_wait(cnt, arrivals, p.err, gave_up);
             stamp();                                         // [6] barrier 2 passed
             // LayerNorm of rows wave*8 .. +7 (lane owns 8 columns of each) -> bufA (A layout); this workgroup's column slice -> x1.
             // ao and X arrive by LDS-DMA (sc1) in slots 1 and 2 (free: W_o is consumed; W_1's first tiles sit in 3 and 0): one round trip
@@ -547,7 +568,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
                 for (int g = 0; g < 2; ++g) glds16_sc1(HG + (g * 16 + s) * 64, dst + g * 2048 + wave * 8 * 64);
             };
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err);
+            cluster_wait(cnt, arrivals, p.err, gave_up);
             stamp();                                         // [9] barrier 3 passed
             EF_WAIT_VM(0);                                   // the three prefetched weight half-tiles (and this wave's own stores)
             stageHG(0, 0); stageHG(1, 1); stageHG(2, 2);
@@ -596,7 +617,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
                 for (int kb = 0; kb < 8; ++kb) glds16_sc1(sx + kb * 64, ring(1) + kb * 2048 + wave * 8 * 64);
             }
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err);
+            cluster_wait(cnt, arrivals, p.err, gave_up);
             stamp();                                         // [11] barrier 4 passed
             {   // f by LDS-DMA (sc1) into slot 0
                 const bf16_t* sa = reinterpret_cast<const bf16_t*>(L.f) + (row0 + rsrc) * ED + csw * 8;
@@ -628,6 +649,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
             // every tensor of this layer that they may still be reading (f, x1) is never written again.
         }
     }
+    enc_poison(gave_up, reinterpret_cast<bf16_t*>(p.Ls[p.layers - 1].xout) + row0 * ED + h * 64);
 }
 
 
@@ -741,6 +763,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
     const int bh = (p.seq0 + c) * EH + h;
     unsigned* cnt = p.cnt + c;
     unsigned arrivals = 0;
+    bool gave_up = false;
     int tix = 0;
     auto stamp = [&]() {
         if (p.trace != nullptr && blockIdx.x == 0 && tid == 0 && tix < 500) p.trace[tix] = __builtin_amdgcn_s_memtime();
@@ -804,7 +827,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
             ln_consts(L.g2, L.m2, L.r2, g8, mu8, rs8);
             if (l != p.layers - 1) {                        // the layer above has written every column of its dx
                 arrivals += EH;
-                cluster_wait(cnt, arrivals, p.err);
+                cluster_wait(cnt, arrivals, p.err, gave_up);
             }
             stamp();                                         // [b0] layer start
             rows512(dyin, 0, true);
@@ -905,7 +928,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
             // the weight halves of the first three tiles do not depend on the other workgroups: in flight across the cluster wait
             stageW(0, 0); stageW(1, 1); stageW(2, 2);
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err);
+            cluster_wait(cnt, arrivals, p.err, gave_up);
             stamp();                                         // [b3] barrier 1 passed
             const u32x4 ad = ad2;
             stageA(0, 0); stageA(1, 1); stageA(2, 2);
@@ -963,7 +986,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
             float g8[8], mu8[8], rs8[8];
             ln_consts(L.g1, L.m1, L.r1, g8, mu8, rs8);
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err);
+            cluster_wait(cnt, arrivals, p.err, gave_up);
             stamp();                                         // [b5] barrier 2 passed
             rows512(reinterpret_cast<const bf16_t*>(L.dx1), 0, true);
             EF_WAIT_VM(0);
@@ -1133,7 +1156,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
             };
             stageW(0, 0); stageW(1, 1); stageW(2, 2);        // (the attention's LDS scratch in slots 0 and 1 is behind the signal's workgroup barrier)
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err);
+            cluster_wait(cnt, arrivals, p.err, gave_up);
             stamp();                                         // [b9] barrier 3 passed
             const u32x4 ad = ad1;
             stageA(0, 0); stageA(1, 1); stageA(2, 2);
@@ -1177,6 +1200,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
             }
         }
     }
+    enc_poison(gave_up, reinterpret_cast<bf16_t*>(p.Ls[0].dx) + row0 * ED + h * 64);
 }
 
 struct EncBwdTable { svsr_enc_bwd_layer L[8]; };
@@ -1197,6 +1221,13 @@ __global__ __launch_bounds__(256) void k_enc_table(const EncTable t, int words, 
 }
 
 static unsigned long long* g_enc_trace = nullptr;
+
+// sequences per launch: every workgroup takes a whole compute unit's LDS and spin-waits on its 7 siblings, so a launch may hold at most
+// (compute units of the stream) / 8 clusters (32 on the whole chip; fewer on a CU-masked stream)
+static int enc_clusters_per_launch(hipStream_t stream) {
+    const int n = svsr_stream_cus(stream) / EH;
+    return n < 1 ? 1 : n;
+}
 
 extern "C" {
 
@@ -1246,11 +1277,21 @@ int svsr_enc_fwd(const void* x0, const svsr_enc_layer* layers, int n_layers, int
     a.th_hidden = dh.thresh; a.sc_hidden = dh.scale; a.th_attn = da.thresh; a.sc_attn = da.scale;
     a.err = cnt + B;
     a.trace = g_enc_trace;
-    for (int s0 = 0; s0 < B; s0 += 32) {          // all workgroups of a launch must be resident together: 8 per sequence on 256 CUs
-        a.seq0 = s0; a.nseq = B - s0 < 32 ? B - s0 : 32; a.cnt = cnt + s0;
+    const int per = enc_clusters_per_launch(stream);      // all workgroups of a launch must be resident together: 8 per sequence, one per compute unit
+    for (int s0 = 0; s0 < B; s0 += per) {
+        a.seq0 = s0; a.nseq = B - s0 < per ? B - s0 : per; a.cnt = cnt + s0;
         hipLaunchKernelGGL(k_enc_fwd, dim3(a.nseq * EH), dim3(256), LDS_TOTAL, stream, a);
     }
     return svsr_check_launch();
+}
+
+/* 1 if ANY svsr_enc_fwd / svsr_enc_bwd launch of this process had a bounded cluster wait give up (its results were poisoned with NaN), else 0;
+ * reset != 0 clears the word afterwards.  Synchronises the device (call it where the host synchronises anyway). */
+int svsr_enc_gave_up(int reset) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_enc_gave_up), sizeof v) != hipSuccess) return -1;
+    if (reset && v != 0) { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_enc_gave_up), &z, sizeof z); }
+    return v != 0 ? 1 : 0;
 }
 
 /* bytes of the device workspace svsr_enc_bwd needs for B sequences */
@@ -1285,8 +1326,9 @@ int svsr_enc_bwd(const void* dy, const svsr_enc_bwd_layer* layers, int n_layers,
     a.th_hidden = dh.thresh; a.sc_hidden = dh.scale; a.th_attn = da.thresh; a.sc_attn = da.scale;
     a.err = cnt + B;
     a.trace = g_enc_trace;
-    for (int s0 = 0; s0 < B; s0 += 32) {
-        a.seq0 = s0; a.nseq = B - s0 < 32 ? B - s0 : 32; a.cnt = cnt + s0;
+    const int per = enc_clusters_per_launch(stream);
+    for (int s0 = 0; s0 < B; s0 += per) {
+        a.seq0 = s0; a.nseq = B - s0 < per ? B - s0 : per; a.cnt = cnt + s0;
         hipLaunchKernelGGL(k_enc_bwd, dim3(a.nseq * EH), dim3(256), LDS_TOTAL, stream, a);
     }
     return svsr_check_launch();

@@ -715,7 +715,7 @@ static int launch_glds(const IgemmFwdArgs& a, int gx, int gy, hipStream_t stream
 struct IgemmFwdPlan { int bm, bn, ns, gy; };
 
 static IgemmFwdPlan igemm_fwd_plan(long M, int Co, int max_taps) {
-    static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+    const int cus = svsr_stream_cus(nullptr);
     IgemmFwdPlan pl;
     const int forced = svsr_tune_get(SVSR_TUNE_IGEMM_TILE);            // 0 auto, 64 / 128 forced
     const int thr = svsr_tune_get(SVSR_TUNE_IGEMM_M128);

@@ -548,7 +548,7 @@ int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) 
     // per-lane addresses are 32-bit byte offsets from the tensor bases
     if ((long)a.Nimg * a.in_pix * a.in_pitch * 2 >= (1L << 32) || (long)a.Co * a.wt_taps * a.Ci * 2 >= (1L << 32)) return SVSR_ERR_ARG;
     if ((long)a.Nimg * a.out_pix * a.out_pitch >= (1L << 31)) return SVSR_ERR_ARG;          // the epilogue's row offsets are 32-bit element counts
-    static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+    const int cus = svsr_stream_cus(stream);          // (a CU-masked stream: one workgroup per compute unit it may use)
     const int tiles_m = meta[3], gy = a.Co / bn;
     const int items = (tiles_m + 7) / 8 * 8 * gy;
     int G = items < cus ? items : cus;

@@ -481,7 +481,7 @@ static WgradLaunch wgrad_launch(long total_chunks_l, int Co, int Ci, int ntaps, 
     pl.tasks = ((Co + BC - 1) / BC) * ((Ci + BC - 1) / BC) * ntaps;
     // one round of resident workgroups: 2 per CU for the 128-wide tile (64 KiB of LDS ring, ~200 VGPRs), 3 per CU for the 64-wide
     // one — a grid a little above that runs a second, almost empty round (layer4: 576 workgroups on 512 slots took 1.4x longer)
-    static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+    const int cus = svsr_stream_cus(nullptr);
     const int target_env = svsr_tune_get(SVSR_TUNE_WG_BLOCKS);
     const int target_blocks = target_env > 0 ? target_env : cus * (BC == 128 ? 2 : 3);
     int splits = target_blocks / pl.tasks;                    // every split costs a slab of Co*taps*Ci floats written and re-read
@@ -505,7 +505,7 @@ static WgradLaunch wgrad_launch(long total_chunks_l, int Co, int Ci, int ntaps, 
 struct WgradUnits { std::vector<int> units, tasktab; int slots = 0; };
 
 static WgradUnits wgrad_units(const std::vector<long>& tap_chunks, int co_tiles, int ci_tiles, int bc) {
-    static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+    const int cus = svsr_stream_cus(nullptr);
     const int target_env = svsr_tune_get(SVSR_TUNE_WG_BLOCKS);
     const long resident = target_env > 0 ? target_env : (long)cus * (bc == 128 ? 2 : 3);
     const int umax = svsr_tune_get(SVSR_TUNE_WG_UNIT_MAX) > 0 ? svsr_tune_get(SVSR_TUNE_WG_UNIT_MAX) : 48;

@@ -19,7 +19,7 @@ static int g_tune[SVSR_TUNE_N] = {
     /* IGEMM_TILE   */ 0,      // 0 auto, 64 / 128: force the M tile of svsr_igemm_fwd
     /* IGEMM_M128   */ 8192,   // rows from which 128-row tiles are used
     /* WG_BLOCKS    */ 0,      // target workgroups of svsr_igemm_wgrad (0: built-in per tile size)
-    /* W3_BLOCKS    */ 448,    // target workgroups of svsr_conv3x3_wgrad.  Alone the launch is fastest at one round of 2 per CU (512: 61 us, 448: 64, 288: 73), but it runs on the side stream under the backward chain and a smaller grid leaves the main stream's launches their share: step 5.62 -> 5.60 ms at 448, 5.55 at 288 (swept 224..512; 448 keeps the launch itself near its best)
+    /* W3_BLOCKS    */ 512,    // target workgroups of svsr_conv3x3_wgrad: one round of two per CU (alone 512: 61 us, 448: 64, 288: 73; inside the step, on the side stream: 5.006 / 5.005 / 5.021 ms at 512 / 448 / 288 in round 5)
     /* LN_RPB       */ 4,      // rows per workgroup of svsr_add_ln_bwd (one per wave: 16 -> 4 measured 6.00 -> 5.97 ms per LRW step)
     /* STEM_LDS_FWD */ 0,      // LDS-tiled stem BN+act+pool forward (measured slower)
     /* STEM_LDS_BWD */ 2,      // stem BN+act+pool backward: 0 plain, 1 LDS-tiled passes, 2 LDS-tiled apply pass + gather-form reduce pass (fastest)
@@ -60,6 +60,63 @@ extern "C" int svsr_tune(const char* key, int value) {
     if (key == nullptr) return SVSR_ERR_ARG;
     for (int i = 0; i < SVSR_TUNE_N; ++i)
         if (strcmp(key, g_tune_names[i]) == 0) { g_tune[i] = value; return SVSR_OK; }
+    return SVSR_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Streams restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): the training step can give its main stream and
+// its weight-gradient side stream DISJOINT compute units (engine.TrainStep(cu_split=...)), and every persistent kernel sizes its grid by
+// the compute units of the stream it is launched on.  The registry is a handful of entries, written at stream creation only.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct StreamCus { hipStream_t stream; int cus; };
+StreamCus g_stream_cus[32];
+int g_n_stream_cus = 0;
+int device_cus() {
+    static int per_dev[64];
+    int d = 0;
+    (void)hipGetDevice(&d);
+    if (d < 0 || d >= 64) d = 0;
+    if (per_dev[d] == 0) {
+        int n = 0;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d);
+        per_dev[d] = n > 0 ? n : 256;
+    }
+    return per_dev[d];
+}
+}  // namespace
+
+int svsr_stream_cus(hipStream_t stream) {
+    for (int i = 0; i < g_n_stream_cus; ++i)
+        if (g_stream_cus[i].stream == stream) return g_stream_cus[i].cus;
+    return device_cus();
+}
+
+extern "C" int svsr_device_cus(void) { return device_cus(); }
+extern "C" int svsr_stream_cu_count(hipStream_t stream) { return svsr_stream_cus(stream); }
+
+/* mask: `words` 32-bit words, bit i set = compute unit i of the driver's numbering may run the stream's kernels (on gfx942 / gfx950 bit i
+ * is XCD i % 8, then shader engine, then CU: scripts/probes/cumask_probe.hip prints the map) */
+extern "C" int svsr_stream_create_cumask(const uint32_t* mask, int words, hipStream_t* out) {
+    if (mask == nullptr || out == nullptr || words < 1 || words > 64 || g_n_stream_cus >= 32) return SVSR_ERR_ARG;
+    int n = 0;
+    for (int w = 0; w < words; ++w) n += __builtin_popcount(mask[w]);
+    const int dev = device_cus();
+    if (n < 1) return SVSR_ERR_ARG;
+    hipError_t e = hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask);
+    if (e != hipSuccess) return (int)e;
+    g_stream_cus[g_n_stream_cus].stream = *out;
+    g_stream_cus[g_n_stream_cus].cus = n < dev ? n : dev;
+    ++g_n_stream_cus;
+    return SVSR_OK;
+}
+
+extern "C" int svsr_stream_destroy(hipStream_t stream) {
+    for (int i = 0; i < g_n_stream_cus; ++i)
+        if (g_stream_cus[i].stream == stream) {
+            g_stream_cus[i] = g_stream_cus[--g_n_stream_cus];
+            return (int)hipStreamDestroy(stream);
+        }
     return SVSR_ERR_ARG;
 }
 

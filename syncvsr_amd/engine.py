@@ -69,16 +69,33 @@ def _rng_state_from_tensor(t: torch.Tensor):
 class TrainStep:
     """forward + backward + (all-reduce) + clip + AdamW for the LRW model (`TransformerLightningModule`; its step takes
     (videos, audio_tokens, labels, word_mask)) or the LRS model (`lrs_model.E2E`; (x, lengths, audio_tokens, label));
-    optionally one HIP graph per step."""
+    optionally one HIP graph per step.
+
+    After step() returns, the tail of the optimiser step (AdamW of everything behind the front-end, its shadow transposes) may still be
+    running on the model's side stream, beside whatever the main stream does next.  The model's own entry points join it where they need
+    the parameters (forward before the encoder, forward_videos, state_dict, load_state_dict, the LRS scorers, refresh_shadows); code that
+    touches parameters DIRECTLY (p.data, p.cpu(), an EMA update) calls synchronize() first."""
 
     def __init__(self, model, config: Optional[Config] = None, process_group=None,
                  use_graph: bool = False, bucket_mb: float = 32.0, always_reduce: bool = False, data_parallel: bool = True,
-                 grad_comm_dtype: torch.dtype = torch.float32, native: bool = False):
+                 grad_comm_dtype: torch.dtype = torch.float32, native: bool = False, cu_split: Optional[tuple] = None):
         """native=True: the launch sequence of the first step is recorded into a native step list (csrc/steplist.hip) and every
         later step re-issues it with one library call per segment — eager launches on the same streams (the weight-gradient side
         stream keeps overlapping, which a captured HIP graph loses) without the per-launch host cost of the Python loop.  Batch
-        shapes are fixed by the first call, as with use_graph."""
+        shapes are fixed by the first call, as with use_graph.
+        cu_split=(side_cus, layout): the step runs on two CU-masked HIP streams with DISJOINT compute units (ops.cu_split_masks): `side_cus`
+        of them for the side stream (weight gradients, parameter-gradient reductions, the larger part of AdamW), the rest for the main
+        stream; persistent kernels size their grids by their stream's share.  step() moves onto the main stream itself (and hands the
+        results back to the caller's stream); a caller that already runs on `self.main_stream` skips both hand-overs."""
         self.model = model
+        self.main_stream: Optional[torch.cuda.Stream] = None
+        if cu_split is not None:
+            if use_graph:
+                raise ValueError("cu_split places eager launches on two masked streams; a captured HIP graph replays on its own queues")
+            side_cus, layout = (cu_split if isinstance(cu_split, (tuple, list)) else (cu_split, "spread"))
+            main_bits, side_bits = ops.cu_split_masks(int(side_cus), str(layout))
+            self.main_stream = ops.create_masked_stream(main_bits)
+            model._side.stream = ops.create_masked_stream(side_bits)
         self.is_lrw = isinstance(model, TransformerLightningModule)
         if self.is_lrw:            # LRW/video/config/*.yaml: optim.optimizer / optim.scheduler / train.gradient_clip_val
             cfg = config or model.config
@@ -160,6 +177,8 @@ class TrainStep:
         if self.dp is not None:
             self.dp.finish()
         self._optimizer(st)
+        if self.use_graph:
+            model._side.join()       # (SVSR_GRAPH_SIDE=1: work forked onto the side stream must be joined before the capture ends)
         if trace:
             torch.cuda.nvtx.range_pop()
         if self.is_lrw:
@@ -277,6 +296,17 @@ class TrainStep:
     def step(self, *batch):
         """One optimisation step; returns the model's outputs (LRW: the dict of five scalars; LRS: the 5-tuple).
         With use_graph / native the batch shapes are fixed by the first call (later batches are copied into the static buffers)."""
+        if self.main_stream is not None:
+            cur = torch.cuda.current_stream()
+            if cur != self.main_stream:
+                self.main_stream.wait_stream(cur)
+                with torch.cuda.stream(self.main_stream):
+                    out = self._step(*batch)
+                cur.wait_stream(self.main_stream)
+                return out
+        return self._step(*batch)
+
+    def _step(self, *batch):
         if self.native:
             import time as _time
 
@@ -356,13 +386,20 @@ class TrainStep:
         if "dropout_word" in sd and hasattr(self.model, "load_rng_state"):
             rs = {"dropout_word": int(sd["dropout_word"].reshape(-1)[0])}
             if "layer_rng" in sd:
-                rs["layer_rng"] = _rng_state_from_tensor(sd["layer_rng"])
+                try:
+                    rs["layer_rng"] = _rng_state_from_tensor(sd["layer_rng"])
+                except ValueError as e:       # checkpoints written before the int64[628] format (pickled uint8 payload): nothing here unpickles
+                    warnings.warn(f"{e}; the layer-drop generator is NOT restored (it continues from this process's seed), everything else is")
             self.model.load_rng_state(rs)
 
     # -- introspection ------------------------------------------------------------------------------
     def state(self) -> dict[str, float]:
+        """{step, lr, grad_norm} of the last optimiser step (a host synchronisation).  Raises if a fused-encoder launch of this process had a
+        cluster wait give up (csrc/enc_fused.hip: its 8 workgroups per sequence were not resident together — the results of that step were
+        poisoned with NaN, the run must not continue on them)."""
         self.synchronize()
         raw = self.opt_state.cpu()
+        ops.check_enc_clusters()
         f = raw.view(torch.float32)
         return {"step": int(raw[0]), "lr": float(f[2]), "grad_norm": float(f[3])}
 

@@ -179,6 +179,7 @@ class E2E(nn.Module):
             _attach(self, name, sd[name], False)
         self._store: Optional[_ParamStore] = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_params_dirty())
+        self.register_load_state_dict_pre_hook(lambda module, *a, **k: module._side.join())       # (an AdamW range may still be writing the flat buffer on the side stream)
         from .lrs_init import lrs_frontend_names
 
         self.stem_name, self.trunk_name = lrs_frontend_names(args)

@@ -179,6 +179,8 @@ class TransformerLightningModule(nn.Module):
         self.cutmix = CutMix(self.word_labels).eval()          # lightning.py:85-88
         self._store: Optional[_ParamStore] = None
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_params_dirty())
+        # (PRE hook: the copies of load_state_dict into the flat buffer must not race with an AdamW range still running on the side stream)
+        self.register_load_state_dict_pre_hook(lambda module, *a, **k: module._side.join())
         self.stem_name, self.trunk_name = "stem3d", "resnet"
         self.stem_act, self.trunk_act = ops.ACT_GELU, ops.ACT_RELU          # lightning.py:52, timm BasicBlock
         self.use_tr = True          # ds_read_b64_tr_b16 fragments in the weight-gradient kernels
@@ -394,6 +396,7 @@ class _ParamStore:
         decay = sorted([(n, s) for n, s, k in specs if len(s) >= 2], key=lambda e: fwd_rank(e[0]))   # stable
         nodecay = [(n, s) for n, s, k in specs if len(s) < 2]
         self.offsets: dict[str, tuple[int, int, tuple[int, ...]]] = {}
+        self._side = getattr(model, "_side", None)      # a TrainStep may leave the tail of its optimiser step there: whoever reads or rewrites flat / w16 from the main stream joins it first
         self._vc: dict = {}        # cached views of the flat buffers (p32 / g32 / s16 / t16)
         off = 0
         phys = getattr(model, "_phys", {})
@@ -530,6 +533,8 @@ class _ParamStore:
         return o, o + (numel or n)
 
     def refresh_shadows(self) -> None:
+        if self._side is not None:
+            self._side.join()         # the side stream's AdamW range may still be writing flat / w16 (engine.TrainStep._optimizer)
         self.generation += 1
         ops.cast_bf16(self.flat, self.w16)
         ops.transpose_shadows(self.flat, self.w16, self.w16t, self.table, self.n_entries)

@@ -96,7 +96,7 @@ def _query(name: str, *args) -> tuple:
     if hit is not None:
         return hit
     fn = getattr(_lib.load(), name)
-    if name.endswith("_rows") or name.endswith("_bytes") or name.endswith("_floats"):
+    if name.endswith(("_rows", "_rows_on", "_bytes", "_floats")):
         out = (int(fn(*args)),)
     else:
         nout = {"svsr_conv3x3_wgrad_plan": (1, 1),
@@ -312,6 +312,47 @@ def stream_wait(waiter: torch.cuda.Stream, signaller: torch.cuda.Stream) -> None
     w, s = waiter.cuda_stream, signaller.cuda_stream
     _lib.check(_lib.load().svsr_stream_wait(w, s), "svsr_stream_wait")
     _REC.wait(w, s)
+
+
+def device_cus() -> int:
+    """Compute units of the current device."""
+    return int(_lib.load().svsr_device_cus())
+
+
+def stream_cus(stream: Optional[torch.cuda.Stream] = None) -> int:
+    """Compute units the launches of `stream` (default: the current one) may use."""
+    return int(_lib.load().svsr_stream_cu_count(_stream() if stream is None else stream.cuda_stream))
+
+
+def cu_split_masks(side_cus: int, layout: str = "spread", total: Optional[int] = None) -> tuple[list[int], list[int]]:
+    """Bit lists (compute-unit indices in the driver's numbering) of a main / side partition of the chip with `side_cus` compute units
+    on the side.  Measured with scripts/probes/cumask_probe.hip on MI355X / ROCm 7.2: bit i is XCD i % 8 (then shader engine, then CU),
+    and an XCD whose slice of the mask is ALL ZERO runs the stream's kernels on all of its compute units — a mask cannot exclude a whole
+    XCD, so the only partition that holds is "spread": the side stream gets the top side_cus / 8 compute units of EVERY XCD, the main
+    stream the rest (block b of a main-stream launch still lands on XCD b % 8)."""
+    total = device_cus() if total is None else total
+    if layout != "spread":
+        raise ValueError("only layout 'spread' exists (an all-zero XCD slice of a CU mask means 'unmasked': whole XCDs cannot be taken away)")
+    if side_cus % 8 != 0 or not 0 < side_cus < total:
+        raise ValueError("the same number of compute units is taken from each of the 8 XCDs: side_cus must be a multiple of 8")
+    side = list(range(total - side_cus, total))
+    return list(range(total - side_cus)), side
+
+
+_MASKED_STREAMS: list = []
+
+
+def create_masked_stream(bits: Sequence[int]) -> torch.cuda.Stream:
+    """A HIP stream whose kernels run only on the compute units `bits` (svsr_stream_create_cumask), as a torch stream object."""
+    words = (max(bits) + 32) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for b in bits:
+        mask[b // 32] |= 1 << (b % 32)
+    out = ctypes.c_void_p(0)
+    _lib.check(_lib.load().svsr_stream_create_cumask(mask, words, ctypes.byref(out)), "svsr_stream_create_cumask")
+    s = torch.cuda.ExternalStream(out.value)
+    _MASKED_STREAMS.append(s)
+    return s
 
 
 def memset(t: torch.Tensor, value: int = 0) -> None:
@@ -585,7 +626,7 @@ def conv3x3_c64(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, addend: Op
     dy, dx, tw = zip(*taps)
     stats = st = None
     if want_stats:
-        rows = _query("svsr_conv3x3_c64_stat_rows", N, H, W)[0]
+        rows = _query("svsr_conv3x3_c64_stat_rows_on", N, H, W, _stream())[0]
         stats = scratch(rows * 2 * 64)
         st = (stats, rows)
     _call("svsr_conv3x3_c64", _p(x), _p(wt), _p(out), _p(addend), _p(stats), N, H, W, _ints(dy), _ints(dx), _ints(tw), _p(c64_pixtab(N, H, W, x.device)), _stream(),
@@ -664,7 +705,7 @@ def conv2d_dgrad_bn(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, p
     if stride == 1 and _c64_ok(Ci, Co, k, stride, pad, W):
         taps = tuple((pad - kh, pad - kw, kh * k + kw) for kh in range(k) for kw in range(k))
         tdy, tdx, tw = zip(*taps)
-        rows = _query("svsr_conv3x3_c64_stat_rows", N, H, W)[0]
+        rows = _query("svsr_conv3x3_c64_stat_rows_on", N, H, W, _stream())[0]
         stats = scratch(rows * 2 * 64)
         _call("svsr_conv3x3_c64_dgrad_bn", _p(dy), _p(w16t), _p(g), _p(addend), _p(stats), N, H, W, _ints(tdy), _ints(tdx), _ints(tw),
               _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), act, _p(c64_pixtab(N, H, W, dy.device)), _stream(), label="k_conv3x3_c64+bn", flops=2.0 * N * H * W * 64 * 64 * 9)
@@ -965,6 +1006,15 @@ class _EncLayer(ctypes.Structure):
 
 ENC_FUSED = os.environ.get("SVSR_ENC_FUSED", "1") != "0"     # the whole encoder forward as one launch (False: seven launches per layer)
 _ENC_WS: dict = {}
+
+
+def check_enc_clusters(reset: bool = True) -> None:
+    """Raises if any svsr_enc_fwd / svsr_enc_bwd launch since the last check had a bounded cluster wait give up (synchronises the device)."""
+    rc = int(_lib.load().svsr_enc_gave_up(1 if reset else 0))
+    if rc != 0:
+        raise _lib.SvsrError("a fused-encoder launch (svsr_enc_fwd / svsr_enc_bwd) gave up waiting for the workgroups of a sequence: they were not "
+                             "resident together (CU-masked or partitioned device, a co-tenant kernel holding LDS).  Its outputs were poisoned with "
+                             "NaN.  Run with SVSR_ENC_FUSED=0 SVSR_ENC_BWD_FUSED=0 (the per-layer launch chain) on such a device.")
 
 
 def enc_fused_ok(D: int, H: int, inter: int, S: int) -> bool:

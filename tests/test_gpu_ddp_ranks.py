@@ -61,7 +61,8 @@ def _worker():
     if rank == 0:
         model.load_state_dict(sd)
     model.to(dev).train()
-    ts = TrainStep(model, cfg, bucket_mb=0.25)
+    comm = torch.bfloat16 if os.environ.get("SVSR_TEST_COMM", "fp32") == "bf16" else torch.float32
+    ts = TrainStep(model, cfg, bucket_mb=0.25, grad_comm_dtype=comm)
     st = model.store()
     out = {"rank": rank}
     # -- all-reduce self-test: gradient buffer = (rank + 1) * (1 + i mod 7): after the reducer it must hold the rank mean of that
@@ -125,9 +126,7 @@ def _definition(dev):
     return losses, st0.flat.detach().cpu(), st0.bufflat.detach().cpu()
 
 
-def test_two_ranks_reproduce_the_data_parallel_definition():
-    if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+def _run_two_ranks(comm: str):
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -137,7 +136,7 @@ def test_two_ranks_reproduce_the_data_parallel_definition():
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
-                   SVSR_TEST_BACKEND=backend, SVSR_TEST_OUT=base, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4",
+                   SVSR_TEST_BACKEND=backend, SVSR_TEST_OUT=base, SVSR_TEST_COMM=comm, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4",
                    PYTHONPATH=os.pathsep.join([ROOT, HERE, os.environ.get("PYTHONPATH", "")]))
         code = "import test_gpu_ddp_ranks as t; t._worker()"
         procs.append(subprocess.Popen([sys.executable, "-c", code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -148,11 +147,48 @@ def test_two_ranks_reproduce_the_data_parallel_definition():
     for r in res:
         assert r["selftest_ok"], "bucket all-reduce: rank-pattern self-test failed"
         assert r["buckets"] >= 3 and r["covered"], (r["buckets"], "the buckets must tile the gradient buffer")
+    got = [torch.load(base + f".rank{r}.pt") for r in range(2)]
+    return backend, res, got
+
+
+def test_two_ranks_reproduce_the_data_parallel_definition():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    backend, res, got = _run_two_ranks("fp32")
     want_losses, want_flat, want_buf = _definition(torch.device("cuda:0"))
     print(backend, "ranks' losses", [r["losses"] for r in res], "definition", want_losses)
     for r in range(2):
         assert res[r]["losses"] == want_losses[r], (backend, r, res[r]["losses"], want_losses[r])
-    got = [torch.load(base + f".rank{r}.pt") for r in range(2)]
     assert torch.equal(got[0]["flat"], got[1]["flat"]), "the ranks' parameters diverged"
     assert torch.equal(got[0]["flat"], want_flat), f"{int((got[0]['flat'] != want_flat).sum())} parameters differ from the definition"
     assert torch.equal(got[0]["bufflat"], want_buf) and torch.equal(got[1]["bufflat"], want_buf), "running statistics do not follow rank 0"
+
+
+def test_two_ranks_with_the_bf16_gradient_wire_format():
+    """GradReducer(comm_dtype=torch.bfloat16) (engine.py; bench.py --grad-comm bf16): the buckets cross the links as bf16 and come back into
+    the fp32 gradient buffer — an opt-in deviation from DDP's fp32 all-reduce.  The rank-pattern self-test uses
+    values bf16 represents exactly, so it must still be EXACT; the 3-step trajectory is held to the fp32 definition with a stated tolerance:
+    every gradient element is rounded to 8 mantissa bits once per step (relative 2^-9 = 2e-3 per element, uncorrelated), which AdamW's
+    normalisation passes on to the update — losses within 5e-3 relative (measured 1.0e-3 at the third step of this ill-conditioned 10-frame
+    batch, whose fp32-vs-bf16 trajectories the oracle tests hold to 1e-2), the accumulated parameter update within 5e-2 relative L2, and the
+    two ranks still bit-identical to each other (they apply the same reduced gradient)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    backend, res, got = _run_two_ranks("bf16")
+    want_losses, want_flat, want_buf = _definition(torch.device("cuda:0"))
+    cfg, sd, batch = _case()
+    from syncvsr_amd.model import Model
+
+    m0 = Model(cfg, seed=100)
+    m0.load_state_dict(sd)
+    flat0 = m0.to("cuda:0").store().flat.detach().cpu()
+    print(backend, "bf16 wire: ranks' losses", [r["losses"] for r in res], "fp32 definition", want_losses)
+    for r in range(2):
+        for a, b in zip(res[r]["losses"], want_losses[r]):
+            assert abs(a - b) <= 5e-3 * abs(b), (r, res[r]["losses"], want_losses[r])
+    assert torch.equal(got[0]["flat"], got[1]["flat"]), "the ranks' parameters diverged"
+    upd, want_upd = got[0]["flat"] - flat0, want_flat - flat0
+    err = float((upd - want_upd).norm() / want_upd.norm())
+    print("relative L2 error of the 3-step parameter update under the bf16 wire format:", err)
+    assert err <= 5e-2, err
+    assert torch.equal(got[0]["bufflat"], want_buf), "running statistics do not follow rank 0"
