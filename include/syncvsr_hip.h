@@ -72,15 +72,12 @@ extern "C" {
 
 /* ---- plumbing (runtime.hip) ------------------------------------------------------------------------------------
  * svsr_tune: sets a result-preserving tuning knob ("igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd",
- * "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe",
- * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased", "p8_bn64", "p8_lin_items": tile shapes, split counts, kernel-variant switches — documented at the table in runtime.hip;
+ * "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe",
+ * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min": tile shapes, split counts, kernel-variant switches — documented at the table in runtime.hip;
  * never read from the environment); unknown key -> SVSR_ERR_ARG.
  * svsr_colsum_rows: out[c] (+)= scale * sum_{r<nrows} ws[r*ld + c], rows added in a fixed order; columns [0,n0) go to out0,
  * [n0,n0+n1) to out1 (may be null when n1 = 0); accumulate != 0 adds to the existing values. */
 int svsr_tune(const char* key, int value);
-/* debug aid of scripts/probes: the per-phase time stamps (s_memtime) of the last launch made with the knob "p8_trace" set */
-int svsr_debug_p8_trace(int64_t* out1024);
-int svsr_debug_c64_trace(int64_t* out512);      /* the same for svsr_conv3x3_c64 (tune p8_trace = 9): [phase][wave group][8 stamps] of workgroup 0 */
 int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale, hipStream_t stream);
 
 /* ---- implicit-GEMM contractions (igemm_fwd.hip) -------------------------------------------------------------------
@@ -109,9 +106,6 @@ int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_
  *   per-channel BatchNorm partial sums stats[tiles][2][Co] (plain stores; reduced by svsr_bn_finalize). */
 int svsr_conv_plan(int mode, int Nimg, int H, int W, int Co_out, int k, int stride, int pad, int* words, int cap_words, int* meta);
 int svsr_rows_plan(int Nimg, int P, int src0, int dst0, int Co_out, int* words, int cap_words, int* meta);
-/* the same for a launch whose contraction depth Ci is known: large plain dense layers (P = 1, Ci >= 256, Co % 128 == 0, >= tune "p8_lin_items"
- * 256 x 128 items) get the persistent 8-wave kernel's plan, whose launch supports bias, ReLU, dropout, alpha and addend (no GELU, no fp32 output) */
-int svsr_rows_plan_k(int Nimg, int P, int src0, int dst0, int Co_out, int Ci, int* words, int cap_words, int* meta);
 int svsr_igemm_fwd_kgroups(const int* meta, int Ci, int Co, int bn_epilogue);   /* host query: 2 when the launch splits K over two wave groups (k_igemm_fwd_glds<64,64,4,2>) */
 int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* out_pre, const float* bias, const void* addend, float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, int act, int out_f32, float alpha, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 
@@ -145,10 +139,8 @@ int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W);
 /* the same for a launch on `stream` (a CU-masked stream runs fewer persistent workgroups: svsr_stream_create_cumask) */
 int svsr_conv3x3_c64_stat_rows_on(int Nimg, int H, int W, hipStream_t stream);
 /* pixtab (both launches below): device copy of svsr_conv3x3_c64_pixtab's table for (Nimg, H, W) — pixel index or -1 per padded
- * coordinate — or null.  With the table AND the tuning knob "c64_dephased" set, launches without the BatchNorm-backward epilogue take
- * the de-phased kernel (two wave groups half a period apart: one contracts a chunk while the other drains the previous one and
- * fetches the next; an experiment at parity with the default lock-step kernel).  Outputs are identical bit for bit, the BatchNorm
- * partial sums are added in a different (fixed) order.  svsr_conv3x3_c64_pixtab(..., out = null) returns the entry count. */
+ * coordinate — or null (the kernel then derives the source pixel of every staged row by arithmetic: ~500 instructions per chunk and thread).
+ * svsr_conv3x3_c64_pixtab(..., out = null) returns the entry count. */
 int64_t svsr_conv3x3_c64_pixtab(int Nimg, int H, int W, int* out, int64_t cap);
 int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, const int* dy, const int* dx, const int* tw, const int* pixtab, hipStream_t stream);
 
@@ -168,13 +160,6 @@ int svsr_igemm_dgrad_bn(const void* in, const void* wt, void* out, const void* a
 int svsr_conv3x3_c64_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, const int* dy, const int* dx, const int* tw, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, const int* pixtab, hipStream_t stream);
 int svsr_bn_bwd_from_stats(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma, const float* stats, int nrows, float* coef, float* dgamma, float* dbeta, void* dx, int64_t npix, int C, hipStream_t stream);
 
-/* svsr_conv3x3_res: conv3x3, stride 1, pad 1 for 128 / 256 input channels (layer2 / layer3 of the trunk, resnet.py:8-10,59-72) forward and,
- * with the transposed weights and mirrored taps, its input-gradient: the 128-pixel activation tile (+ a halo of W+1 pixels) stays in
- * LDS across the nine taps, only weight tiles stream (igemm_fwd.hip k_conv3x3_res).  in bf16 [Nimg][H][W][Ci]; wt bf16 [Co][9][Ci];
- * out bf16 [Nimg][H][W][Co] (+ addend, which may alias out); tap t reads pixel (y+dy[t], x+dx[t]) with weight tap tw[t] (HOST arrays
- * of 9 ints); stats [rows][2][Co] with rows = svsr_conv3x3_res_stat_rows(Nimg, H, W) or null. */
-int svsr_conv3x3_res_stat_rows(int Nimg, int H, int W);
-int svsr_conv3x3_res(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, int Ci, int Co, const int* dy, const int* dx, const int* tw, hipStream_t stream);
 
 /* svsr_conv3x3_wgrad: weight gradient of a 3x3 / stride-1 / pad-1 Conv2d (resnet.py:8-10) with all nine taps sharing one
  * pass over x [Nimg][H][W][Ci] and dy [Nimg][H][W][Co] (zero-padded coordinates, wgrad3x3.hip).  dw fp32 [Co][9][Ci] is
@@ -182,11 +167,6 @@ int svsr_conv3x3_res(const void* in, const void* wt, void* out, const void* adde
  * Requires Ci, Co multiples of 64 and W <= 29; other shapes go through svsr_igemm_wgrad. */
 int svsr_conv3x3_wgrad_plan(int Nimg, int H, int W, int Ci, int Co, int* splits, int64_t* part_floats);
 int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Ci, int Co, float* part, int64_t part_floats, hipStream_t stream);
-/* n <= 4 such weight gradients of one geometry in ONE launch (the stride-1 convolutions of a ResNet layer, once all their output
- * gradients exist): the launch's workgroups are divided among them, so each writes 1/n of the split-K
- * slabs of a launch of its own.  xs / dys / dws: HOST arrays of n device pointers; part: svsr_conv3x3_wgrad_multi_floats(...) floats. */
-int64_t svsr_conv3x3_wgrad_multi_floats(int n, int Nimg, int H, int W, int Ci, int Co);
-int svsr_conv3x3_wgrad_multi(const void* const* xs, const void* const* dys, float* const* dws, int n, int Nimg, int H, int W, int Ci, int Co, float* part, int64_t part_floats, hipStream_t stream);
 
 /* ---- 3-D stem (stem.hip) --------------------------------------------------------------------------------------
  * svsr_stem_conv_fwd replaces stem3d[0] = nn.Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3),bias=False) (lightning.py:50).

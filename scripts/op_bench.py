@@ -52,8 +52,6 @@ def main():
         if "=" in kv:
             k, v = kv.split("=")
             ops.tune(k, int(v))
-    if os.environ.get("OPB_RES"):          # e.g. OPB_RES=128,256: route stride-1 conv3x3 of those widths to the activation-resident kernel
-        ops.RES_CONV, ops.RES_CI = True, tuple(int(v) for v in os.environ["OPB_RES"].split(","))
     tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("SVSR_"))
     print(f"== op_bench {tag}")
     for name, hw, ci, co in LAYERS:

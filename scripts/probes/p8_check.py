@@ -77,60 +77,8 @@ def run(N, H, C, reps=30):
     return ok and rep
 
 
-def trace(N, H, C):
-    import ctypes
-    import numpy as np
-    from syncvsr_amd import _lib
-    x = (torch.randn(N, H, H, C, device=dev) * 0.5).to(BF16)
-    w = (torch.randn(C, 3, 3, C, device=dev) * 0.05).to(BF16)
-    ops.tune("p8", 1)
-    ops.tune("p8_trace", 9)
-    for _ in range(3):
-        ops.conv2d_fwd(x, w, 3, 1, 1, want_stats=True)
-    buf = np.zeros(1024, dtype=np.int64)
-    _lib.load().svsr_debug_p8_trace(buf.ctypes.data)
-    ops.tune("p8_trace", 0)
-    t = buf[:1008].reshape(-1, 2, 2, 4)            # [kt][h][group][stamp]
-    kts = min(t.shape[0], 9 * C // 64)
-    base = t[0, 0, 0, 0]
-    print(f"trace N={N} {H}x{H} C={C}: per K tile (cycles, 100 MHz ticks?): group 0 / group 1: L(issue+waits) bar M bar")
-    for kt in range(min(kts, 24)):
-        row = []
-        for g in range(2):
-            for h in range(2):
-                s0, s1, s2, s3 = t[kt, h, g]
-                nxt = t[kt, h + 1, g, 0] if h == 0 else (t[kt + 1, 0, g, 0] if kt + 1 < t.shape[0] else s3)
-                row.append(f"{s1 - s0:5d} {s2 - s1:5d} {s3 - s2:5d} {nxt - s3:5d}")
-        print(f"  kt {kt:2d} t={t[kt, 0, 0, 0] - base:7d} | g0 h0 {row[0]} | g0 h1 {row[1]} | g1 h0 {row[2]} | g1 h1 {row[3]}")
-    print("  K loop total", t[kts - 1, 1, 0, 3] - base, "end stamp", buf[1023] - base)
-    e = buf[1010:1018] - base
-    print("  epilogue stamps (cycles from K loop start): start", e[0], "acc staged", e[1], "passes", list(e[2:6]), "stats", e[6], "stores drained", e[7])
-
-
 if __name__ == "__main__":
     ops.tune("p8_min_items", 1)
-    if "--trace" in sys.argv:
-        for ph in (1,):
-            ops.tune("p8_ph", ph)
-            print("PH =", ph)
-            trace(928, 11, 128)
-            trace(928, 6, 256)
-        sys.exit(0)
-    if "--ablate" in sys.argv:
-        x2 = (torch.randn(928, 11, 11, 128, device=dev) * 0.5).to(BF16); w2 = (torch.randn(128, 3, 3, 128, device=dev) * 0.05).to(BF16)
-        x3 = (torch.randn(928, 6, 6, 256, device=dev) * 0.5).to(BF16); w3 = (torch.randn(256, 3, 3, 256, device=dev) * 0.05).to(BF16)
-        ops.tune("p8", 1)
-        names = {0: "product kernel", 5: "trace build, nothing ablated", 1: "no epilogue fragment work", 2: "no MFMA", 3: "no DMA in the loop", 4: "no ds_reads",
-                 6: "no epilogue global stores", 7: "no epilogue LDS writes"}
-        for ph in (1,):
-            ops.tune("p8_ph", ph)
-            for ab in (0, 5, 1, 6, 7, 2, 3, 4):
-                ops.tune("p8_trace", ab)
-                t2 = timeit(lambda: ops.conv2d_fwd(x2, w2, 3, 1, 1, want_stats=True), 30)
-                t3 = timeit(lambda: ops.conv2d_fwd(x3, w3, 3, 1, 1, want_stats=True), 30)
-                print(f"ph {ph} {names[ab]:32s}: layer2 {t2:.1f} us  layer3 {t3:.1f} us")
-        ops.tune("p8_trace", 0)
-        sys.exit(0)
     if "--order" in sys.argv:
         ops.tune("p8", 1)
         for (N, H, C) in ((928, 11, 128), (928, 6, 256), (928, 22, 128)):

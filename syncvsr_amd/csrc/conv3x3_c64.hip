@@ -38,12 +38,10 @@ struct Conv64Args {
     const float* bnb_gamma;     // bnb_y == nullptr: mask recomputed as bn(x) > 0 (forward's own expression), y not read
     const float* bnb_beta;
     int bnb_act;                // 1 ReLU, 2 Swish (bnb_y = the residual input or null; see svsr_igemm_dgrad_bn)
-    int dbg;                    // probes only (tune key p8_trace): parts of the de-phased kernel switched off
-    const int* pixtab;          // de-phased kernel: svsr_conv3x3_c64_pixtab's table, device copy
+    const int* pixtab;          // svsr_conv3x3_c64_pixtab's table (device copy): source pixel of every padded coordinate, or null
 };
 
 __device__ unsigned g_c64_zero_page[64];
-__device__ unsigned long long g_c64_trace[512];   // probes (dbg == 9): s_memtime stamps of workgroup 0, [phase][group][8]
 
 #define C64_SWZ(row, chunk) ((row) * 64 + ((((chunk) ^ (((row) >> 1) & 7))) << 3))
 
@@ -282,306 +280,6 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// DE-PHASED variant (k_conv3x3_c64d, the default): the eight waves are TWO groups of four that work on different chunks half a period
-// apart.  In every phase (one workgroup barrier) one group contracts its chunk — a wave owns 64 positions x 64 channels, so a weight
-// fragment serves two position blocks and an activation fragment two channel blocks: 1 KiB of LDS traffic per MFMA instead of 1.5 —
-// while the other group, whose waves share the SIMDs with the contracting ones, drains the accumulators of ITS previous chunk
-// (BatchNorm sums, optional BatchNorm-backward math, stores straight from the MFMA layout: 4 channels = 8 bytes per lane) and
-// fetches its next activation tile by LDS-DMA.  The matrix pipe of a SIMD therefore always has a contracting wave, and the epilogue
-// (25 of the lock-step kernel's 65 us) and the tile fetch cost nothing as long as they fit into a contraction phase (144 MFMAs per
-// wave, ~2.2 us).  One activation tile per group (no double buffer: the tile is free the moment the group's contraction ends), the
-// statistics live in 64 registers per lane (this lane's 32 channels x 2 sums, over all its chunks) and meet in LDS once, at the end.
-// Same MFMA instruction and accumulation order (tap-major, then 16-channel steps) as the lock-step kernel: outputs are bit-identical,
-// the statistics differ in the order their partial sums are added.
-// ---------------------------------------------------------------------------------------------------------------------------------
-#define C64D_SPIX_OFF ((C64_LDS_W + 2 * C64_LDS_A) * 2)                // int [2 groups][2 buffers][256]
-#define C64D_SC_OFF (C64D_SPIX_OFF + 2 * 2 * C64_CH * 4)               // float [4][64]
-#define C64D_LDS_BYTES (C64D_SC_OFF + 4 * 64 * 4)
-static_assert(C64D_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
-
-// Sum of v[0..31] over the 32 lanes that share lane >> 5, scattered: lane col returns the total of v[col].  Five butterfly steps
-// (partner = col ^ b, b = 16 .. 1): a lane keeps the indices whose bit b equals its own and adds the partner's copies — a fixed order.
-template <int B>
-__device__ __forceinline__ void c64d_rs_step(float (&u)[32], float (&v)[32], int col) {
-    const bool up = (col & B) != 0;
-#pragma unroll
-    for (int lo = 0; lo < B; ++lo) {          // live indices are 0 .. 2B-1; the result is packed into 0 .. B-1
-        const float ku = up ? u[lo + B] : u[lo], su = up ? u[lo] : u[lo + B];
-        const float kv = up ? v[lo + B] : v[lo], sv = up ? v[lo] : v[lo + B];
-        u[lo] = ku + __shfl_xor(su, B, 64);
-        v[lo] = kv + __shfl_xor(sv, B, 64);
-    }
-}
-// both statistics at once (two independent chains per exchange: the exchanges' latency is what this costs)
-__device__ __forceinline__ void c64d_reduce_scatter32x2(float (&u)[32], float (&v)[32], int col, float& tu, float& tv) {
-    c64d_rs_step<16>(u, v, col);
-    c64d_rs_step<8>(u, v, col);
-    c64d_rs_step<4>(u, v, col);
-    c64d_rs_step<2>(u, v, col);
-    c64d_rs_step<1>(u, v, col);
-    tu += u[0]; tv += v[0];
-}
-
-// BNB: the BatchNorm-backward epilogue (svsr_conv3x3_c64_dgrad_bn) — an instantiation of its own, like its Swish form
-template <bool BNB, bool SWISH>
-__global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64d(const Conv64Args p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);                // [9*64 rows][64]
-    bf16_t* sAall = sW + C64_LDS_W;                                   // [2 groups][C64_XR][64]
-    int* sPixAll = reinterpret_cast<int*>(smem_raw + C64D_SPIX_OFF);
-    float* sC = reinterpret_cast<float*>(smem_raw + C64D_SC_OFF);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wg = wave & 3;                         // wave w and w + 4 share a SIMD: one of each group
-    const int col = lane & 31, hi = lane >> 5;
-    const int slot = tid & 7;
-    const int halo = p.WP + 1;
-    const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_c64_zero_page) + slot * 8;
-    bf16_t* sA = sAall + grp * C64_LDS_A;
-    int* sPix = sPixAll + grp * 2 * C64_CH;
-
-    {   // weights: 576 rows [tap][co] x 8 pieces, 9 DMA instructions per thread (all eight waves)
-        const int r0w = tid >> 3, csww = slot ^ ((r0w >> 1) & 7), wrow = wave * 8;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int row = r0w + 64 * i;              // = t*64 + co with t == i
-            const bf16_t* src = p.wt + ((long)(row & 63) * 9 + p.tw[i]) * 64 + csww * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sW + (wrow + 64 * i) * 64), 16, 0, 0);
-        }
-    }
-    // activation tile of chunk c into this group's buffer: 320 rows x 8 pieces over the group's 256 threads (10 instructions each).
-    // The source pixel of a row comes from the table (svsr_conv3x3_c64_pixtab: pixel index or -1 per padded coordinate) — computing it
-    // costs ~100 instructions per row (two divisions by reciprocal with fix-ups), 1,000 per chunk and wave, which alone overran the
-    // contraction phase this work is supposed to hide in.  The ten entries of a tile are requested one epilogue phase before they are
-    // used (pixn), so the DMA goes out the moment its buffer is free.
-    const int r0 = wg * 8 + (lane >> 3);                              // row inside a 32-row instruction group
-    const int csw = slot ^ ((r0 >> 1) & 7);
-    const unsigned src_lane = (unsigned)(csw * 16);
-    int pixn[10];
-    auto table_rows = [&](int c) {
-        const int* t = p.pixtab + C64_TAB_PAD + c * C64_CH - halo + r0;
-#pragma unroll
-        for (int i = 0; i < 10; ++i) pixn[i] = t[32 * i];
-    };
-    auto stage = [&](int pb) {
-        bf16_t* dst = sA + wg * 8 * 64;
-        const char* inb = reinterpret_cast<const char*>(p.in);
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const int pix = pixn[i];
-            const void* src = pix >= 0 ? (const void*)(inb + ((unsigned)pix * 128u + src_lane)) : (const void*)zero_src;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + i * 32 * 64), 16, 0, 0);
-            const int pl = r0 + 32 * i - halo;
-            if (slot == 0 && pl >= 0 && pl < C64_CH) sPix[pb * C64_CH + pl] = pix;
-        }
-    };
-
-    constexpr bool bnb = BNB;
-    const bool from_x = p.bnb_y == nullptr, has_add = p.addend != nullptr;
-    if (bnb && tid < 64) {
-        const float m = p.bnb_mean[tid], r = p.bnb_rstd[tid];
-        sC[tid] = m; sC[64 + tid] = r;
-        const bool affine = from_x || SWISH;
-        const float c = affine ? p.bnb_gamma[tid] * r : 0.f;
-        sC[128 + tid] = c;
-        sC[192 + tid] = affine ? __builtin_fmaf(-m, c, p.bnb_beta[tid]) : 0.f;
-    }
-    // chunks of this workgroup: c(n) = blockIdx.x + n * gridDim.x, n < nb; group g contracts the chunks with n & 1 == g, in phase n
-    const int G = gridDim.x;
-    const int nb = ((int)p.total_chunks - (int)blockIdx.x + G - 1) / G;
-    if (grp < nb) { table_rows(blockIdx.x + grp * G); stage(0); }
-    if (grp + 2 < nb) table_rows(blockIdx.x + (grp + 2) * G);          // for this group's first epilogue phase
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-    // statistics: after a chunk's epilogue the 32 per-lane sums (this lane's 32 channels over its two positions) are reduce-scattered
-    // over the 32 position lanes (five butterfly steps, fixed order): lane (col, hi) then owns channel index col = j*16 + g4*4 + k of its
-    // half, i.e. channel (col >> 4) * 32 + 8 * ((col >> 2) & 3) + 4 * hi + (col & 3) — ONE register per statistic across the chunks
-    // instead of 64 (which, next to 64 accumulators, spilled)
-    float tot_s = 0.f, tot_q = 0.f;
-    f32x16 acc[2][2];                          // [i][j]: D[row = channel j*32 + ..][col = position wg*64 + i*32 + ..]
-
-    auto stamp = [&](int ph, int k) {
-        if (p.dbg == 9 && blockIdx.x == 0 && wg == 0 && lane == 0 && ph < 32) g_c64_trace[(ph * 2 + grp) * 8 + k] = __builtin_amdgcn_s_memtime();
-    };
-    for (int ph = 0; ph <= nb; ++ph) {
-        stamp(ph, 0);
-        if ((ph & 1) == grp) {
-            if (ph < nb && p.dbg != 1) {
-                // ---- contraction of chunk ph --------------------------------------------------------------------------------------
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-                __builtin_amdgcn_s_setprio(1);
-                // 36 steps (tap, 16-channel step), fragments of step s + 1 requested before the four MFMAs of step s: this SIMD's other
-                // wave is in its epilogue, so the read latency has to hide behind this wave's own matrix instructions
-                bf16x8 fa[2][2], fb[2][2];
-                auto frags = [&](int s, int b) {
-                    const int t = s >> 2, ch = (s & 3) * 2 + hi;
-                    const int row = wg * 64 + col + halo + p.dy[t] * p.WP + p.dx[t];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) fa[b][i] = *reinterpret_cast<const bf16x8*>(sA + C64_SWZ(row + 32 * i, ch));
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) fb[b][j] = *reinterpret_cast<const bf16x8*>(sW + C64_SWZ(t * 64 + j * 32 + col, ch));
-                };
-                frags(0, 0);
-#pragma unroll
-                for (int s2 = 0; s2 < 36; ++s2) {
-                    const int b = s2 & 1;
-                    if (s2 + 1 < 36) frags(s2 + 1, b ^ 1);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b][j], fa[b][i], acc[i][j], 0, 0, 0);
-                }
-                __builtin_amdgcn_s_setprio(0);
-                stamp(ph, 1);
-            }
-        } else if (ph >= 1) {
-            // ---- epilogue of chunk ph - 1 (its accumulators are still in registers), tile of chunk ph + 1 ------------------------------
-            const int pb = ((ph - 1) >> 1) & 1;
-            int pixv[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) pixv[i] = sPix[pb * C64_CH + wg * 64 + i * 32 + col];
-            // the operands of the first position block are requested BEFORE the tile's DMA: loads return in order, behind it they would
-            // arrive only after the whole tile.  Addresses: tensor base (scalar) + 32-bit byte offset of (pixel, this lane's 4 channels).
-            uint2 add_v[8], x_v[8], y_v[8];
-            unsigned boff[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) boff[i] = (unsigned)(pixv[i] >= 0 ? pixv[i] : 0) * 128u + (unsigned)(8 * hi);
-            auto request = [&](int i) {
-#pragma unroll
-                for (int jg = 0; jg < 8; ++jg) {
-                    if (has_add) add_v[jg] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.addend) + boff[i] + jg * 16);
-                    if (bnb) {
-                        x_v[jg] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.bnb_x) + boff[i] + jg * 16);
-                        if (!from_x) y_v[jg] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.bnb_y) + boff[i] + jg * 16);
-                    }
-                }
-            };
-            if (has_add || bnb) request(0);
-            stamp(ph, 2);
-            if (ph + 1 < nb && p.dbg != 3) stage(pb ^ 1);
-            if (ph + 3 < nb) table_rows(blockIdx.x + (ph + 3) * G);          // this group's tile after that one
-            stamp(ph, 3);
-            float st_s[32], st_q[32];             // index j*16 + g4*4 + k
-#pragma unroll
-            for (int v = 0; v < 32; ++v) { st_s[v] = 0.f; st_q[v] = 0.f; }
-            if (p.dbg != 2)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i == 1 && (has_add || bnb)) request(1);
-                // arrival point of the operands (see igemm_p8.hip: a first use inside divergent code makes hipcc re-wait in every row)
-                if (has_add) {
-#pragma unroll
-                    for (int jg = 0; jg < 8; ++jg) asm volatile("" : "+v"(add_v[jg].x), "+v"(add_v[jg].y));
-                }
-                if (bnb) {
-#pragma unroll
-                    for (int jg = 0; jg < 8; ++jg) {
-                        asm volatile("" : "+v"(x_v[jg].x), "+v"(x_v[jg].y));
-                        if (!from_x) asm volatile("" : "+v"(y_v[jg].x), "+v"(y_v[jg].y));
-                    }
-                }
-                const bool live = pixv[i] >= 0;
-                char* orow = reinterpret_cast<char*>(p.out) + boff[i];
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int jg = j * 4 + g4;
-                        __builtin_amdgcn_sched_barrier(0);      // (one channel group at a time: hoisting all eight groups' constants spills)
-                        // the convolution's result rounded to bf16 (what a separate pass would read back): packed bits, then its values
-                        uint2 o2;
-                        o2.x = pack2bf(acc[i][j][4 * g4 + 0], acc[i][j][4 * g4 + 1]);
-                        o2.y = pack2bf(acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]);
-                        float a[4] = {__uint_as_float(o2.x << 16), __uint_as_float(o2.x & 0xffff0000u), __uint_as_float(o2.y << 16), __uint_as_float(o2.y & 0xffff0000u)};
-                        if (bnb) {
-                            const int c0 = j * 32 + 8 * g4 + 4 * hi;
-                            const f32x4 mu = *reinterpret_cast<const f32x4*>(sC + c0), rs = *reinterpret_cast<const f32x4*>(sC + 64 + c0);
-                            const f32x4 sc = *reinterpret_cast<const f32x4*>(sC + 128 + c0), sh = *reinterpret_cast<const f32x4*>(sC + 192 + c0);
-                            const float xv[4] = {__uint_as_float(x_v[jg].x << 16), __uint_as_float(x_v[jg].x & 0xffff0000u),
-                                                 __uint_as_float(x_v[jg].y << 16), __uint_as_float(x_v[jg].y & 0xffff0000u)};
-                            float yv[4];
-                            if (from_x) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) yv[k] = __builtin_fmaf(xv[k], sc[k], sh[k]);
-                            } else {
-                                yv[0] = __uint_as_float(y_v[jg].x << 16); yv[1] = __uint_as_float(y_v[jg].x & 0xffff0000u);
-                                yv[2] = __uint_as_float(y_v[jg].y << 16); yv[3] = __uint_as_float(y_v[jg].y & 0xffff0000u);
-                            }
-                            if (has_add) {
-                                const float b[4] = {__uint_as_float(add_v[jg].x << 16), __uint_as_float(add_v[jg].x & 0xffff0000u),
-                                                    __uint_as_float(add_v[jg].y << 16), __uint_as_float(add_v[jg].y & 0xffff0000u)};
-                                const unsigned r0p = pack2bf(a[0] + b[0], a[1] + b[1]), r1p = pack2bf(a[2] + b[2], a[3] + b[3]);
-                                a[0] = __uint_as_float(r0p << 16); a[1] = __uint_as_float(r0p & 0xffff0000u);
-                                a[2] = __uint_as_float(r1p << 16); a[3] = __uint_as_float(r1p & 0xffff0000u);
-                            }
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                float v = a[k];
-                                if (SWISH) {
-                                    const float z = from_x ? yv[k] : __builtin_fmaf(xv[k], sc[k], sh[k]) + yv[k];
-                                    v = bf2f(f2bf(v * swish_grad(z)));
-                                } else {
-                                    v = yv[k] > 0.f ? v : 0.f;
-                                }
-                                v = live ? v : 0.f;
-                                a[k] = v;
-                                st_s[j * 16 + g4 * 4 + k] += v;
-                                st_q[j * 16 + g4 * 4 + k] += v * (xv[k] - mu[k]) * rs[k];
-                            }
-                            o2.x = pack2bf(a[0], a[1]); o2.y = pack2bf(a[2], a[3]);
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const float v = live ? a[k] : 0.f;         // (the statistics are those of the convolution's own output)
-                                st_s[j * 16 + g4 * 4 + k] += v;
-                                st_q[j * 16 + g4 * 4 + k] += v * v;
-                            }
-                            if (has_add) {
-                                const float b[4] = {__uint_as_float(add_v[jg].x << 16), __uint_as_float(add_v[jg].x & 0xffff0000u),
-                                                    __uint_as_float(add_v[jg].y << 16), __uint_as_float(add_v[jg].y & 0xffff0000u)};
-                                o2.x = pack2bf(a[0] + b[0], a[1] + b[1]); o2.y = pack2bf(a[2] + b[2], a[3] + b[3]);
-                            }
-                        }
-                        if (live) *reinterpret_cast<uint2*>(orow + jg * 16) = o2;
-                    }
-            }
-            stamp(ph, 4);
-            // (after the stores: the butterflies below give them the time to be acknowledged before the phase ends)
-            if (p.stats != nullptr && p.dbg != 4) c64d_reduce_scatter32x2(st_s, st_q, col, tot_s, tot_q);
-            stamp(ph, 5);
-        }
-        // The contracting group is done with its tile; the other group's tile (and its sPix) has landed and its stores are out (vmcnt
-        // counts stores on gfx950).
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        stamp(ph, 6);
-        asm volatile("s_barrier" ::: "memory");
-        stamp(ph, 7);
-    }
-    if (p.stats != nullptr) {
-        // lane (col, hi) of every wave owns one channel's sums: added over the eight waves in wave order
-        float* sred = reinterpret_cast<float*>(smem_raw);            // [2][8 waves][64 lanes]
-        __syncthreads();
-        sred[wave * 64 + lane] = tot_s;
-        sred[512 + wave * 64 + lane] = tot_q;
-        __syncthreads();
-        if (tid < 128) {
-            const int which = tid >> 6, l = tid & 63, c = l & 31, h2 = l >> 5;
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) sum += sred[which * 512 + w * 64 + l];
-            p.stats[((long)blockIdx.x * 2 + which) * 64 + (c >> 4) * 32 + 8 * ((c >> 2) & 3) + 4 * h2 + (c & 3)] = sum;
-        }
-    }
-}
-
 static int c64_grid(long total_chunks, hipStream_t stream) {
     const int cus = svsr_stream_cus(stream);
     return (int)(total_chunks < cus ? total_chunks : cus);
@@ -603,7 +301,6 @@ static int c64_run(const void* in, const void* wt, void* out, const void* addend
     a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = (bf16_t*)out; a.addend = (const bf16_t*)addend; a.stats = stats;
     a.bnb_y = (const bf16_t*)bnb_y; a.bnb_x = (const bf16_t*)bnb_x; a.bnb_mean = bnb_mean; a.bnb_rstd = bnb_rstd;
     a.bnb_gamma = bnb_gamma; a.bnb_beta = bnb_beta; a.bnb_act = bnb_act;
-    a.dbg = svsr_tune_get(SVSR_TUNE_P8_TRACE);
     a.Nimg = Nimg; a.H = H; a.W = W; a.WP = W + 2; a.Q = (H + 2) * (W + 2);
     const long qtot = (long)Nimg * a.Q;
     if (qtot >= (1L << 24) || (long)Nimg * H * W >= (1L << 25)) return SVSR_ERR_ARG;
@@ -616,27 +313,15 @@ static int c64_run(const void* in, const void* wt, void* out, const void* addend
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64d<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C64D_LDS_BYTES);
         attr = true;
     }
     const int grid = c64_grid(a.total_chunks, stream);
-    // de-phased kernel (tune key c64_dephased, off by default: 58.8 vs 57.4 us at the LRW shape): forward /
-    // plain data-gradient launches only — its BatchNorm-backward epilogue does not fit the register file next to 64 accumulators
-    if (svsr_tune_get(SVSR_TUNE_C64_DEPHASED) && pixtab != nullptr && bnb_x == nullptr && (long)Nimg * H * W * 128 < (1L << 32)) {
-        hipLaunchKernelGGL((k_conv3x3_c64d<false, false>), dim3(grid), dim3(C64_THREADS), (size_t)C64D_LDS_BYTES, stream, a);
-        return svsr_check_launch();
-    }
     if (bnb_x != nullptr && bnb_act == 2) hipLaunchKernelGGL(k_conv3x3_c64<true>, dim3(grid), dim3(C64_THREADS), lds, stream, a);
     else hipLaunchKernelGGL(k_conv3x3_c64<false>, dim3(grid), dim3(C64_THREADS), lds, stream, a);
     return svsr_check_launch();
 }
 
-extern "C" int svsr_debug_c64_trace(int64_t* out512) {
-    if (out512 == nullptr) return SVSR_ERR_ARG;
-    return (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_c64_trace), 512 * sizeof(unsigned long long));
-}
-
-/* svsr_conv3x3_c64_pixtab: the pixel table of the de-phased kernel for a shape — entry C64_TAB_PAD + q = pixel index of the padded
+/* svsr_conv3x3_c64_pixtab: the pixel table for a shape — entry C64_TAB_PAD + q = pixel index of the padded
  * coordinate q ((H+2) x (W+2) grid per image, flattened over the batch) or -1 (padding ring, outside the batch); covers every tile row
  * of every chunk.  Returns the number of entries; with out == nullptr only that (host memory; the caller keeps a device copy). */
 extern "C" int64_t svsr_conv3x3_c64_pixtab(int Nimg, int H, int W, int* out, int64_t cap) {

@@ -17,7 +17,6 @@ struct IgemmFwdArgs {
     int act, out_f32;          // act: 0 none, 1 GELU(erf) (pre-activation kept in out_pre), 2 ReLU
     float alpha;               // out = alpha * dropout(act(acc + bias)) + addend
     DropArgs drop;             // drop.seed == nullptr: no dropout
-    int xcd_rx;                // k_igemm_fwd_glds: > 0: the tile grid is cut into xcd_rx x (8 / xcd_rx) rectangles, one per XCD (set by the launcher)
     int epi_batched;           // epilogue: request all rows' operands before using the first (tuning knob "epi_batched", default on)
     // BatchNorm-backward fusion (data-gradient launches whose result is the gradient of a BatchNorm+ReLU output y = relu(bn(x) [+ res])):
     // out = g = (y > 0 ? result : 0) and stats rows = this tile's column sums of {g, g * (x - mean) * rstd}   (bnb_x == nullptr: off)

@@ -382,19 +382,7 @@ __global__ __launch_bounds__(256 * KG) void k_igemm_fwd_glds(const IgemmFwdArgs 
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    // Which tile this workgroup computes.  Workgroups are dispatched in the order of their linear index (x fastest) round-robin over the 8
-    // XCDs, each with its own 4 MiB L2: left alone, an XCD's share of a 20 x 24 tile grid touches every row tile and every column tile of
-    // the GEMM (8.6 MB of operands at 2,560 x 3,072 x 768) and its L2 thrashes — the staging then runs at the ~40-50 GB/s per CU of the
-    // Infinity Cache instead of the ~115 GB/s of an L2 hit (scripts/probes/fill_rate_probe.hip).  xcd_rx > 0: the grid is cut into
-    // xcd_rx x (8 / xcd_rx) rectangles, one per XCD, so that an XCD's workgroups share the fewest distinct operand tiles (10 x 6 tiles
-    // there: 3.1 MB).  A permutation of the tiles: results do not change.
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (p.xcd_rx > 0) {
-        const int gx = gridDim.x, hw = blockIdx.x + gx * blockIdx.y, xcd = hw & 7, idx = hw >> 3;
-        const int RX = p.xcd_rx, sx = gx / RX, sy = (int)gridDim.y / (8 / RX);
-        bx = (xcd % RX) * sx + idx % sx;
-        by = (xcd / RX) * sy + idx / sx;
-    }
+    const int bx = blockIdx.x, by = blockIdx.y;
     const int n0 = by * BN;
     const int slot = tid & 7, r0 = tid >> 3;                 // lane writes LDS chunk `slot` of row r0 + 32*i ...
     const int csw = slot ^ ((r0 >> 1) & 7);                  // ... which must hold global chunk csw (swizzle on the source)
@@ -542,150 +530,6 @@ __global__ __launch_bounds__(256 * KG) void k_igemm_fwd_glds(const IgemmFwdArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 3x3 / stride-1 / pad-1 convolution with the ACTIVATION TILE RESIDENT in LDS across the nine taps (layer2/3 of the trunk, forward
-// and data gradient).  The generic kernel above stages the 128-pixel activation tile once per tap: 18 of its 36 KiB-per-tap-pair
-// DMA instructions re-fetch pixels it already had, and the K loop is bound by exactly that staging.  Here a
-// workgroup owns 128 CONSECUTIVE pixels of the flattened [Nimg*H*W] index and loads them once, with a halo of W+1 pixels on both
-// sides, as rows of all CI channels; tap (dy,dx) is then the constant row shift dy*W+dx inside the tile, and only the 128x64
-// weight tile of the current (tap, 64-channel chunk) streams through the 2-deep ring.  Positions whose tap falls outside the image
-// (the flattened neighbour belongs to another row or another image) are masked per lane: 9 validity bits per accumulator row,
-// applied to the A fragment with four v_cndmask.  Staged bytes per tile: 38 KiB + 18 x 16 KiB instead of 18 x 32 KiB at CI = 128.
-// ---------------------------------------------------------------------------------------------------------------------
-struct ResArgs {
-    IgemmFwdArgs e;        // in, wt, out, addend, stats, Co, out_pitch, in_pitch; the epilogue reads this
-    int H, W, M;           // image size, total pixels Nimg*H*W
-    int shift[9], tw[9];   // row shift dy*W+dx of tap t and the weight tap it multiplies
-    int dy[9], dx[9];
-};
-
-template <int CI>
-__device__ __forceinline__ int res_a_off(int row, int chunk) { return row * CI + ((chunk ^ (row & 15)) << 3); }
-
-template <int CI, int BK, int NS>
-__global__ __launch_bounds__(256) void k_conv3x3_res(const ResArgs q) {
-    constexpr int BM = 128, BN = 128, KC = CI / BK;
-    constexpr int BCPR = BK / 8, BRPP = 256 / BCPR, BR = BN / BRPP;      // weight tile: chunks per row, rows per pass, DMA instructions per thread
-    constexpr int TM = 2, TN = 2, WM = 64, WN = 64;
-    constexpr int B_ELEMS = BN * BK;
-    constexpr int CPR = CI / 8, RPP = 256 / CPR;            // 16-byte chunks per activation row; rows per staging pass
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const IgemmFwdArgs& p = q.e;
-    const int halo = q.W + 1;
-    const int arows = (BM + 2 * halo + RPP - 1) / RPP * RPP;
-    bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);                       // [arows][CI], chunk-swizzled
-    bf16_t* sB = sA + (size_t)arows * CI;                                   // [NS][BN][64]
-    long* sRow = reinterpret_cast<long*>(sB + NS * B_ELEMS);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-
-    // ---- activation tile: rows m0-halo .. m0+BM+halo-1 (zero page outside [0, M)) ---------------------------------------
-    {
-        const int slot = tid % CPR, r0 = tid / CPR;
-        const int csw = slot ^ (r0 & 15);                    // RPP is a multiple of 16 (CI <= 128) or r0 < 16 (CI = 256: RPP = 8)
-        const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_page) + (slot & 7) * 8;
-        for (int r = r0; r < arows; r += RPP) {
-            const long g = (long)m0 - halo + r;
-            const int cs = CI == 256 ? (slot ^ (r & 15)) : csw;
-            const bf16_t* src = (g >= 0 && g < q.M) ? p.in + g * p.in_pitch + cs * 8 : zero_src;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(sA + (size_t)(r - r0) * CI + (size_t)__builtin_amdgcn_readfirstlane(wave) * (64 / CPR) * CI), 16, 0, 0);
-        }
-    }
-    for (int r = tid; r < BM; r += 256) sRow[r] = (m0 + r < q.M) ? (long)(m0 + r) * p.out_pitch : -1;
-
-    // validity of the nine taps for this lane's accumulator rows (TM = 2): bit t of vmask[i]
-    unsigned vmask[TM];
-    {
-        const int hw = q.H * q.W;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm0 + i * 32 + (lane & 31);
-            const int rem = m % hw, y = rem / q.W, x = rem - y * q.W;
-            unsigned v = 0;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int yy = y + q.dy[t], xx = x + q.dx[t];
-                if (m < q.M && yy >= 0 && yy < q.H && xx >= 0 && xx < q.W) v |= 1u << t;
-            }
-            vmask[i] = v;
-        }
-    }
-
-    // ---- weight tiles through the ring -----------------------------------------------------------------------------------
-    const int slotb = tid % BCPR, r0b = tid / BCPR;
-    const int cswb = slotb ^ (BK == 64 ? ((r0b >> 1) & 7) : ((r0b >> 2) & 3));
-    const int wrowb = __builtin_amdgcn_readfirstlane(wave) * (64 / BCPR);
-    const bf16_t* b_ptr[BR];
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-        const int n = n0 + r0b + BRPP * i;
-        b_ptr[i] = n < p.Co ? p.wt + (long)n * 9 * CI + cswb * 8 : nullptr;
-    }
-    const bf16_t* zero_b = reinterpret_cast<const bf16_t*>(g_zero_page) + slotb * 8;
-    constexpr int KT = 9 * KC;
-    // (taps are walked with COMPILE-TIME indices below: a kernel-argument array indexed with a run-time value lives in scratch memory,
-    // and one scratch load per K step costs more than the step's MFMAs)
-    auto stage = [&](int tw_t, int kc, int buf) {
-        const long off = (long)tw_t * CI + kc * BK;
-        bf16_t* dst = sB + buf * B_ELEMS + wrowb * BK;
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const bf16_t* src = b_ptr[i] != nullptr ? b_ptr[i] + off : zero_b;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + i * BRPP * BK), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-#pragma unroll
-    for (int s0 = 0; s0 < NS - 1; ++s0) stage(q.tw[s0 / KC], s0 % KC, s0);
-#pragma unroll
-    for (int it = 0; it < KT; ++it) {
-        // weight tile `it` (and, the first time, the activation tile in front of it) has landed once at most min(NS-2, tiles left) later
-        // tiles are still in flight; the barrier also frees the ring slot the next stage() overwrites
-        constexpr int dummy = 0; (void)dummy;
-        const int later = KT - 1 - it < NS - 2 ? KT - 1 - it : NS - 2;
-        wait_tiles_barrier<BR, NS - 2>(later);
-        if (it + NS - 1 < KT) stage(q.tw[(it + NS - 1) / KC], (it + NS - 1) % KC, (it + NS - 1) % NS);
-        const int t = it / KC, kc = it % KC;                      // compile-time after unrolling
-        const bf16_t* cB = sB + (it % NS) * B_ELEMS;
-        const int sh = halo + q.shift[t];
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const int ch = ks * 2 + (lane >> 5);
-            bf16x8 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm0 + i * 32 + (lane & 31) + sh;
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(sA + res_a_off<CI>(row, kc * (BK / 8) + ch));
-                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                fa[i] = ((vmask[i] >> t) & 1u) ? v : z;
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn0 + j * 32 + (lane & 31);
-                fb[j] = *reinterpret_cast<const bf16x8*>(cB + (BK == 64 ? LDS_SWZ(row, ch) : row * 32 + ((ch ^ ((row >> 2) & 3)) << 3)));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    igemm_epilogue<BM, BN, TM, TN>(p, acc, smem_raw, sRow, wm0, wn0, n0, tid, true, (int)blockIdx.x);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int NS, int KG = 1>
 static int launch_glds(const IgemmFwdArgs& a, int gx, int gy, hipStream_t stream) {
     const size_t lds = (size_t)KG * NS * (BM + BN) * 64 * sizeof(bf16_t) + (size_t)BM * sizeof(long) + 128 + (size_t)svsr_tune_get(SVSR_TUNE_IGEMM_LDS_PAD);
@@ -695,16 +539,6 @@ static int launch_glds(const IgemmFwdArgs& a, int gx, int gy, hipStream_t stream
         attr_set = lds;
     }
     IgemmFwdArgs b = a;
-    b.xcd_rx = 0;
-    if (svsr_tune_get(SVSR_TUNE_IGEMM_XCD) && (long)gx * gy % 8 == 0 && (long)gx * gy >= 64) {
-        long best = -1;
-        for (int rx = 1; rx <= 8; rx *= 2) {          // rectangles of (gx / rx) x (gy / (8 / rx)) tiles: fewest distinct operand rows per XCD
-            const int ry = 8 / rx;
-            if (gx % rx != 0 || gy % ry != 0) continue;
-            const long cost = (long)(gx / rx) * BM + (long)(gy / ry) * BN;
-            if (best < 0 || cost < best) { best = cost; b.xcd_rx = rx; }
-        }
-    }
     hipLaunchKernelGGL((k_igemm_fwd_glds<BM, BN, NS, KG>), dim3(gx, gy), dim3(256 * KG), lds, stream, b);
     return svsr_check_launch();
 }
@@ -928,71 +762,6 @@ extern "C" int svsr_rows_plan(int Nimg, int P, int src0, int dst0, int Co_out, i
     return n;
 }
 
-/* svsr_rows_plan_k (host): svsr_rows_plan for a launch whose contraction depth Ci is known.  A plain dense layer (P = 1, src0 = dst0 = 0) with
- * Ci >= 256, Co a multiple of 128 and at least `p8_lin_items` (tune key; default 0 = never: measured slower, see runtime.hip) 256 x 128 work items gets the persistent
- * 8-wave kernel's plan (svsr_igemm_fwd then runs k_igemm_p8 with the dense layers' epilogue: bias, ReLU, dropout, alpha, addend — no GELU,
- * no fp32 output); everything else the plan svsr_rows_plan returns.  At 2,560 rows (the sentence-level model's 16 x 160 frames): the
- * 3,072- and 2,304-wide layers (240 / 180 items). */
-extern "C" int svsr_rows_plan_k(int Nimg, int P, int src0, int dst0, int Co_out, int Ci, int* words, int cap_words, int* meta) {
-    const int min_items = svsr_tune_get(SVSR_TUNE_P8_LIN_ITEMS);
-    if (P == 1 && src0 == 0 && dst0 == 0 && Nimg >= 1 && Ci % 64 == 0 && Ci >= 256 && Co_out % P8_BN == 0 && min_items > 0 && svsr_tune_get(SVSR_TUNE_P8) &&
-        (long)((Nimg + P8_BM - 1) / P8_BM) * (Co_out / P8_BN) >= min_items) {
-        std::vector<PlanClass> cls(1);
-        cls[0].ntaps = 1; cls[0].delta[0] = 0; cls[0].tw[0] = 0;
-        cls[0].pos.push_back(0); cls[0].pos.push_back(0);
-        return plan_emit_p8(cls, Nimg, Co_out, 1, 1, words, cap_words, meta, (long)Nimg, 1, P8_BN);
-    }
-    return svsr_rows_plan(Nimg, P, src0, dst0, Co_out, words, cap_words, meta);
-}
-
-/* rows of [2][Co] BatchNorm partials svsr_conv3x3_res writes (one per 128-pixel tile) */
-extern "C" int svsr_conv3x3_res_stat_rows(int Nimg, int H, int W) { return (Nimg < 1 || H < 1 || W < 1) ? 0 : (int)(((long)Nimg * H * W + 127) / 128); }
-
-/* svsr_conv3x3_res: 3x3 / stride-1 / pad-1 convolution, activation tile resident in LDS (k_conv3x3_res).  in bf16 [Nimg][H][W][Ci],
- * wt bf16 [Co][9][Ci], out bf16 [Nimg][H][W][Co] (+ addend, may alias out), stats [rows][2][Co] or null; tap t reads pixel
- * (y+dy[t], x+dx[t]) with weight tap tw[t] (HOST arrays of 9 ints: the forward passes (kh-1, kw-1, kh*3+kw), the data gradient the
- * mirrored taps with the transposed weights).  Ci in {128, 256}, Co % 8 == 0, W <= 61. */
-extern "C" int svsr_conv3x3_res(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, int Ci, int Co,
-                                const int* dy, const int* dx, const int* tw, hipStream_t stream) {
-    if ((Ci != 128 && Ci != 256) || Co < 8 || Co % 8 != 0 || Nimg < 1 || H < 1 || W < 1 || W > 61 || dy == nullptr || dx == nullptr || tw == nullptr)
-        return SVSR_ERR_ARG;
-    const long M = (long)Nimg * H * W;
-    if (M >= (1L << 31) - 256) return SVSR_ERR_ARG;
-    ResArgs q;
-    IgemmFwdArgs& a = q.e;
-    a.in = (const bf16_t*)in; a.wt = (const bf16_t*)wt; a.out = out; a.out_pre = nullptr; a.bias = nullptr; a.addend = (const bf16_t*)addend;
-    a.stats = stats; a.plan = nullptr; a.Nimg = Nimg; a.in_pix = H * W; a.Ci = Ci; a.in_pitch = Ci; a.Co = Co; a.out_pix = H * W; a.out_pitch = Co;
-    a.wt_taps = 9; a.act = 0; a.out_f32 = 0; a.alpha = 1.f; a.drop = svsr_make_drop(nullptr, 0, 0.f);
-    a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED); a.xcd_rx = 0;
-    a.bnb_y = nullptr; a.bnb_x = nullptr; a.bnb_mean = nullptr; a.bnb_rstd = nullptr; a.bnb_gamma = nullptr; a.bnb_beta = nullptr; a.bnb_act = 0;
-    q.H = H; q.W = W; q.M = (int)M;
-    for (int t = 0; t < 9; ++t) {
-        if (dy[t] < -1 || dy[t] > 1 || dx[t] < -1 || dx[t] > 1 || tw[t] < 0 || tw[t] > 8) return SVSR_ERR_ARG;
-        q.dy[t] = dy[t]; q.dx[t] = dx[t]; q.tw[t] = tw[t]; q.shift[t] = dy[t] * W + dx[t];
-    }
-    const int halo = W + 1, rpp = 256 / (Ci / 8);
-    const int arows = (128 + 2 * halo + rpp - 1) / rpp * rpp;
-    const int deep = svsr_tune_get(SVSR_TUNE_RES_DEEP) && Ci == 128;       // 32-deep weight tiles, 4-deep ring (three in flight) in the same 32 KiB
-    size_t lds = (size_t)arows * Ci * sizeof(bf16_t) + 2 * 128 * 64 * sizeof(bf16_t) + 128 * sizeof(long) + 128;
-    if (lds < (size_t)128 * 128 * sizeof(float) + 128 * sizeof(long)) return SVSR_ERR_ARG;      // the fp32 epilogue staging re-uses the tiles
-    if (lds > 160 * 1024) return SVSR_ERR_ARG;
-    const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((Co + 127) / 128));
-    static size_t set128 = 0, set256 = 0;
-    if (Ci == 128) {
-        if (set128 < lds) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_res<128, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_res<128, 32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            set128 = lds;
-        }
-        if (deep) hipLaunchKernelGGL((k_conv3x3_res<128, 32, 4>), grid, dim3(256), lds, stream, q);
-        else hipLaunchKernelGGL((k_conv3x3_res<128, 64, 2>), grid, dim3(256), lds, stream, q);
-    } else {
-        if (set256 < lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_res<256, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set256 = lds; }
-        hipLaunchKernelGGL((k_conv3x3_res<256, 64, 2>), grid, dim3(256), lds, stream, q);
-    }
-    return svsr_check_launch();
-}
-
 /* K groups of the instantiation svsr_igemm_fwd / svsr_igemm_dgrad_bn will launch for this plan: 2 = k_igemm_fwd_glds<64,64,4,2> (the
  * contraction split over two wave groups of one workgroup: few 64x64 tiles, >= 12 K steps), else 1.  Host-side query (bench.py labels
  * its per-kernel table with it, so the table's names are the profiler's). */
@@ -1018,7 +787,7 @@ static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pr
     a.Nimg = Nimg; a.in_pix = in_pix; a.Ci = Ci; a.in_pitch = in_pitch; a.Co = Co; a.out_pix = out_pix; a.out_pitch = out_pitch;
     a.wt_taps = wt_taps; a.act = act; a.out_f32 = out_f32; a.alpha = alpha;
     a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
-    a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED); a.xcd_rx = 0;
+    a.epi_batched = svsr_tune_get(SVSR_TUNE_EPI_BATCHED);
     a.bnb_y = (const bf16_t*)bnb_y; a.bnb_x = (const bf16_t*)bnb_x; a.bnb_mean = bnb_mean; a.bnb_rstd = bnb_rstd;
     a.bnb_gamma = bnb_gamma; a.bnb_beta = bnb_beta; a.bnb_act = bnb_act;
     const int bm = meta[0], bn = meta[1], ns = meta[2], gx = meta[3], gy = (Co + bn - 1) / bn;

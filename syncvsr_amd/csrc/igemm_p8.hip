@@ -81,17 +81,11 @@ __device__ __forceinline__ bool p8_next_item(int tiles_m, int gy, int items, int
 }  // namespace
 
 // EPI 0: out = acc (+ addend), optional BatchNorm partials of the fp32 accumulators;  EPI 1: BatchNorm-backward fusion (bnb_*)
-// EPI 2 / 3: the dense layers' epilogue  out = alpha * dropout(relu?(acc + bias)) + addend  (3: with dropout) — the arithmetic and its order are
-// k_igemm_fwd_glds's (igemm_fwd.hip), and so are the bits: one accumulator per output walks k upwards in both kernels
-// TRACE (debug builds of the probe only): waves 0 and 4 of workgroup 0 stamp s_memtime at four points of every phase of their first tile
-// into the (then idle) reduction scratch and dump it to g_p8_trace before the epilogue: [K tile][phase][wave group][4]
-__device__ unsigned long long g_p8_trace[1024];
-
 // PH: phases per K tile (2: the 32-deep halves, 8 MFMAs between barriers; 1: the whole K tile, 16 MFMAs between barriers)
 // NJ: 32-column blocks of a wave's tile — 2: the 256 x 128 tile (wave tile 64 x 64); 1: a 256 x 64 tile (wave tile 64 x 32) for launches whose
 // 128-wide items would leave half the CUs idle (layer4: 33 row tiles x 512 channels = 132 items of 128 columns, 264 of 64)
-template <int EPI, int PH = 2, bool TRACE = false, int NJ = 2>
-__global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int stagger, int ablate) {
+template <int EPI, int PH = 2, int NJ = 2>
+__global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int stagger) {
     constexpr int BNT = 64 * NJ, NPIECE = 4 + NJ;          // tile columns; DMA pieces per thread and K tile
     static_assert(NJ == 2 || PH == 1, "the 64-column tile has five pieces per K tile: one phase");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -183,21 +177,6 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
         P8_BARRIER();
     }
 
-    // Epilogue operands (stagger bit 2): the rows of x / y / addend this tile's epilogue reads are TOUCHED three K tiles before the K loop
-    // ends — one dword per 128-byte line and thread, the value is dropped — so that the epilogue's own requests, which every workgroup
-    // of a round issues at about the same time, find the lines in L2 instead of arriving at HBM as one burst while the matrix pipes wait.
-    // MEASURED WITHOUT EFFECT (round 4: the BatchNorm-backward-epilogue launches 612-623 TFLOP/s with, 622-643 without; step 5.03 ms either
-    // way) — the epilogue's extra 8-14 us are not HBM latency; off by default, kept as a knob.  (Spread over the K loop instead — thread t at K
-    // tile 1 + t % 16 — it is worse, 593-595 TFLOP/s: every counted wait then sits out one HBM round trip.)
-    // (Inline asm: the compiler must neither wait for these loads nor reuse their registers before the counted wait that covers them;
-    // they are older than the DMA pieces the next P8_WAIT_VM leaves outstanding.)
-    unsigned pf0 = 0, pf1 = 0, pf2 = 0;
-    auto touch = [&](const bf16_t* base, long el) -> unsigned {
-        unsigned v;
-        const bf16_t* q = base + el;
-        asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(q) : "memory");
-        return v;
-    };
     f32x16 acc[2][NJ];
     for (;;) {
         // ---- the following item (its meta data is requested during K tile 0, its pointers are built at K tile 2) ----------
@@ -211,15 +190,6 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-        const bool tracing = TRACE && ablate == 9 && blockIdx.x == 0 && r == 0 && (wave & 3) == 0;
-        unsigned long long* sTrace = reinterpret_cast<unsigned long long*>(sRed);
-        auto stamp = [&](int kt, int h, int k) {
-            if (TRACE && tracing && kt < 32) {
-                const unsigned long long t = __builtin_amdgcn_s_memtime();
-                if (lane == 0) sTrace[((kt * 2 + h) * 2 + wn) * 4 + k] = t;
-                if (lane == 0 && PH == 1) sTrace[((kt * 2 + 1) * 2 + wn) * 4 + k] = t;
-            }
-        };
         if ((stagger & 1) && wn == 1) P8_BARRIER();             // stagger: group 1 runs one barrier behind group 0
         const int KT = cur.KT;
         for (int kt = 0; kt < KT; ++kt) {
@@ -233,22 +203,14 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
             bf16_t* dst = ring + tgt * S_ELEMS;
             constexpr int KF = 4 / PH, NP = NPIECE / PH;   // 16-deep fragments and DMA pieces per phase
             bf16x8 fa[KF][2], fb[KF][NJ];
-            if (TRACE) {
-#pragma unroll
-                for (int kf = 0; kf < KF; ++kf) { fa[kf][0] = fa[kf][1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; for (int j = 0; j < NJ; ++j) fb[kf][j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
-            }
 #pragma unroll
             for (int h = 0; h < PH; ++h) {
-                stamp(kt, h, 0);
                 // -- load section: NP DMA pieces of K tile kt + 2, then the fragments of this phase ---------------------------------
                 // (K tile 0 of a tile: the queue still holds the previous epilogue's stores and K tiles 0 / 1, requested two K tiles
                 // ago: drained here, before anything new is issued — from then on the queue holds DMA pieces only)
                 if (kt == 0 && h == 0) P8_WAIT_VM(0);
-                if (!TRACE || ablate != 3) {
-                    if (h == 0) stage_pieces(str, abase, bbase, dst, std::integral_constant<int, 0>{}, std::integral_constant<int, NP>{});
-                    else stage_pieces(str, abase, bbase, dst, std::integral_constant<int, NP>{}, std::integral_constant<int, NPIECE>{});
-                }
-                if (!TRACE || ablate != 4)
+                if (h == 0) stage_pieces(str, abase, bbase, dst, std::integral_constant<int, 0>{}, std::integral_constant<int, NP>{});
+                else stage_pieces(str, abase, bbase, dst, std::integral_constant<int, NP>{}, std::integral_constant<int, NPIECE>{});
 #pragma unroll
                 for (int kf = 0; kf < KF; ++kf) {
                     const int ch = (KF * h + kf) * 2 + (lane >> 5);
@@ -261,24 +223,12 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                     // K tile kt + 1 has landed once only K tile kt + 2's six pieces (and, at kt = 0, the two meta pieces) are outstanding
                     if (kt == 0) { if (has_next) meta_dma(m2, par ^ 1); }
                     else P8_WAIT_VM(NPIECE);
-                    if ((stagger & 4) && kt == KT - 3 && (EPI == 1 || p.addend != nullptr) && (NJ == 2 || (tid & 1) == 0)) {
-                        const int dstpix = sRowTab[par * 512 + (tid >> 1) * 2 + 1];
-                        if (dstpix >= 0) {
-                            const long el = (long)dstpix * p.out_pitch + cur.n0 + (tid & 1) * 64;
-                            if (EPI == 1) pf0 = touch(p.bnb_x, el);
-                            if (EPI == 1 && p.bnb_y != nullptr) pf1 = touch(p.bnb_y, el);
-                            if (p.addend != nullptr) pf2 = touch(p.addend, el);
-                        }
-                    }
                 }
                 P8_WAIT_LGKM0();
-                stamp(kt, h, 1);
                 P8_BARRIER();
-                stamp(kt, h, 2);
                 // -- matrix section ---------------------------------------------------------------------------------------------
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
-                if (!TRACE || ablate != 2)
 #pragma unroll
                 for (int kf = 0; kf < KF; ++kf)
 #pragma unroll
@@ -288,24 +238,12 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kf][i], fb[kf][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                stamp(kt, h, 3);
                 P8_BARRIER();
             }
             stream_advance();
             stg = stg == 2 ? 0 : stg + 1;
         }
-        asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2));       // (the touched dwords: their registers stay reserved until here)
         if ((stagger & 1) && wn == 0) P8_BARRIER();             // the groups meet again
-        if (TRACE && ablate == 9 && blockIdx.x == 0 && r == 0) {
-            P8_SYNC_ALL();
-            for (int i = tid; i < 1024; i += 512) g_p8_trace[i] = sTrace[i];
-            if (tid == 0) g_p8_trace[1023] = __builtin_amdgcn_s_memtime();
-            P8_SYNC_ALL();
-        }
-        auto estamp = [&](int k) {
-            if (TRACE && ablate == 9 && blockIdx.x == 0 && r == 0 && tid == 0) g_p8_trace[1010 + k] = __builtin_amdgcn_s_memtime();
-        };
-        estamp(0);
 
         // ---- epilogue of the tile: the ring slot read last is idle until K tile 2 of the next tile is staged ----------------------
         // WAVE-PRIVATE: every wave turns its own four 32x32 accumulator fragments round through a 4 KiB patch of that slot (fp32
@@ -344,8 +282,6 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                 }
             }
             const bool from_x = p.bnb_y == nullptr, swish_act = p.bnb_act == 2, has_add = p.addend != nullptr;
-            const bool lin_relu = p.act == 2;
-            const unsigned dkey = (EPI == 3) ? drop_key(p.drop) : 0u;
             float bs1[NJ][4], bs2[NJ][4];
             if (EPI == 1) {
 #pragma unroll
@@ -383,11 +319,6 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                             }
                         }
                 }
-                float b4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (EPI >= 2 && p.bias != nullptr) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) b4[k] = p.bias[n + k];
-                }
                 float mu[4], rs[4], sc[4], sh[4];
                 if (EPI == 1) {
 #pragma unroll
@@ -406,7 +337,6 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 #pragma unroll
                         for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(add_all[i][k].x), "+v"(add_all[i][k].y));
                 }
-                if (EPI >= 2) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
                 if (EPI == 1) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
@@ -418,11 +348,9 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    if (TRACE && ablate == 1) continue;
                     const uint2 (&add4)[4] = add_all[i];
                     const uint2 (&x4)[4] = x_all[i];
                     const uint2 (&y4)[4] = y_all[i];
-                    if (!TRACE || ablate != 7)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) sW[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][e];
                     P8_WAIT_LGKM0();
@@ -437,15 +365,6 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                         // trip per row, 6 us per tile.  Padding rows compute on row 0's operands and are masked out of sums and stores.)
                         const bool live = offs[i][k] >= 0;
                         float v[4] = {rowv[k][0], rowv[k][1], rowv[k][2], rowv[k][3]};
-                        if (EPI >= 2) {     // (selects and multiplications by 1, no uniform branches: see the note on hipcc's waits above)
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                v[c] += b4[c];
-                                v[c] = lin_relu ? fmaxf(v[c], 0.f) : v[c];
-                                if (EPI == 3) v[c] = drop_keep(dkey, p.drop.thresh, (unsigned)(offs[i][k] + n + c)) ? v[c] * p.drop.scale : 0.f;
-                                v[c] *= p.alpha;
-                            }
-                        }
                         {   // (selects, not a branch: a uniform branch in every row has the same effect on hipcc's waits as the early exit)
                             const unsigned ax = has_add ? add4[k].x : 0u, ay = has_add ? add4[k].y : 0u;
                             v[0] += __uint_as_float(ax << 16); v[1] += __uint_as_float(ax & 0xffff0000u);
@@ -482,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                         }
                         uint2 o2;
                         o2.x = pack2bf(v[0], v[1]); o2.y = pack2bf(v[2], v[3]);
-                        if (live && (!TRACE || ablate != 6)) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long)(offs[i][k] + n)) = o2;
+                        if (live) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long)(offs[i][k] + n)) = o2;
                     }
                 }
             }
@@ -526,8 +445,6 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
             // issues new DMA, so a counted wait only ever sees DMA pieces in the queue.  The LDS scratch (this ring slot, sRed) is free
             // again once everybody passed this barrier.
             P8_SYNC_LDS();
-            estamp(6);
-            if (TRACE && ablate == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); estamp(7); }
         }
         if (!has_next) return;
         cur = nxt;
@@ -541,8 +458,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) {
     // meta: {256, 128, 3, M tiles, gy, classes, max taps, rows}; the epilogues this kernel has: (+addend | BatchNorm-backward), BatchNorm partials
     if (a.act == 1 || a.out_f32 || a.out_pre != nullptr) return SVSR_ERR_ARG;
-    const bool lin = a.bias != nullptr || a.act == 2 || a.alpha != 1.f || a.drop.seed != nullptr;      // the dense layers' epilogue (EPI 2 / 3)
-    if (lin && (a.bnb_x != nullptr || a.stats != nullptr)) return SVSR_ERR_ARG;
+    if (a.bias != nullptr || a.act == 2 || a.alpha != 1.f || a.drop.seed != nullptr) return SVSR_ERR_ARG;      // (the dense layers' epilogue lives in k_igemm_fwd_glds)
     const int bn = meta[1];                     // 128, or 64 (plans whose 128-wide items would not fill the chip)
     if ((bn != BN && bn != 64) || a.Co % bn != 0 || a.out_pitch % 8 != 0 || a.Ci % BK != 0) return SVSR_ERR_ARG;
     // per-lane addresses are 32-bit byte offsets from the tensor bases
@@ -554,22 +470,13 @@ int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) 
     int G = items < cus ? items : cus;
     const int forced = svsr_tune_get(SVSR_TUNE_P8_GRID);
     if (forced > 0) G = forced < items ? forced : items;          // (above the CU count: one tile per workgroup, handed out by the dispatcher)
-    const int ph = svsr_tune_get(SVSR_TUNE_P8_PH) == 2 ? 2 : 1, stagger = svsr_tune_get(SVSR_TUNE_P8_STAGGER) & 7;      // bit 0: wave groups one barrier apart, bit 1: odd workgroups walk their rounds backwards, bit 2: epilogue operands touched ahead
+    const int ph = svsr_tune_get(SVSR_TUNE_P8_PH) == 2 ? 2 : 1, stagger = svsr_tune_get(SVSR_TUNE_P8_STAGGER) & 3;      // bit 0: wave groups one barrier apart, bit 1: odd workgroups walk their rounds backwards
 #define P8_LAUNCH(...) do { static bool set_ = false; \
         if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_p8<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); set_ = true; } \
-        hipLaunchKernelGGL((k_igemm_p8<__VA_ARGS__>), dim3(G), dim3(512), LDS_BYTES, stream, a, stagger, svsr_tune_get(SVSR_TUNE_P8_TRACE)); } while (0)
-    if (lin) { if (bn != BN) return SVSR_ERR_ARG; if (a.drop.seed != nullptr) P8_LAUNCH(3, 1, false); else P8_LAUNCH(2, 1, false); }
-    else if (bn == 64) { if (a.bnb_x != nullptr) P8_LAUNCH(1, 1, false, 1); else P8_LAUNCH(0, 1, false, 1); }
-    else if (svsr_tune_get(SVSR_TUNE_P8_TRACE) && a.bnb_x == nullptr) { if (ph == 2) P8_LAUNCH(0, 2, true); else P8_LAUNCH(0, 1, true); }
-    else if (a.bnb_x != nullptr) { if (ph == 2) P8_LAUNCH(1, 2, false); else P8_LAUNCH(1, 1, false); }
-    else { if (ph == 2) P8_LAUNCH(0, 2, false); else P8_LAUNCH(0, 1, false); }
+        hipLaunchKernelGGL((k_igemm_p8<__VA_ARGS__>), dim3(G), dim3(512), LDS_BYTES, stream, a, stagger); } while (0)
+    if (bn == 64) { if (a.bnb_x != nullptr) P8_LAUNCH(1, 1, 1); else P8_LAUNCH(0, 1, 1); }
+    else if (a.bnb_x != nullptr) { if (ph == 2) P8_LAUNCH(1, 2); else P8_LAUNCH(1, 1); }
+    else { if (ph == 2) P8_LAUNCH(0, 2); else P8_LAUNCH(0, 1); }
 #undef P8_LAUNCH
     return svsr_check_launch();
-}
-
-/* debug: copies the 1024 time stamps of the last traced launch (tuning knob "p8_trace") to the host */
-extern "C" int svsr_debug_p8_trace(int64_t* out1024) {
-    if (out1024 == nullptr) return SVSR_ERR_ARG;
-    (void)hipDeviceSynchronize();
-    return (int)hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_p8_trace), 1024 * sizeof(unsigned long long));
 }

@@ -382,27 +382,6 @@ __global__ __launch_bounds__(256) void k_igemm_wgrad_units(const WgradUnitArgs q
     wg_unit<BC, NS>(q.a, q.units + (long)blockIdx.x * WUNIT_WORDS, q.tile_stride, smem_raw);
 }
 
-// several unit-list problems (the convolutions of a ResNet layer) in ONE launch: entry i owns blocks [unit_begin_i, unit_begin_{i+1})
-struct WgradMultiEntry { WgradArgs a; const int* units; long tile_stride; int unit_begin; int pad_; };
-constexpr int WG_MULTI_CHUNK = 16;
-struct WgradMultiChunk { WgradMultiEntry e[WG_MULTI_CHUNK]; };
-static_assert(sizeof(WgradMultiEntry) % 8 == 0 && sizeof(WgradMultiChunk) <= 3584, "a chunk travels in the kernel-argument segment");
-
-__global__ __launch_bounds__(256) void k_wgrad_multi_table(const WgradMultiChunk c, int words, long long* __restrict__ dst) {
-    const long long* src = reinterpret_cast<const long long*>(&c);
-    for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
-}
-
-template <int BC, int NS>
-__global__ __launch_bounds__(256) void k_igemm_wgrad_multi(const WgradMultiEntry* __restrict__ table, int n) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    int idx = 0;
-    for (int i = 1; i < n; ++i)
-        if ((int)blockIdx.x >= table[i].unit_begin) idx = i;
-    const WgradArgs p = table[idx].a;
-    wg_unit<BC, NS>(p, table[idx].units + (long)((int)blockIdx.x - table[idx].unit_begin) * WUNIT_WORDS, table[idx].tile_stride, smem_raw);
-}
-
 // dW[co][tw][ci] += sum over a task's slots (in slot order) of its partial tiles; db likewise.  Task words: {slot_begin, slots}.
 // grid (BC*BC/4/64 (+1 for the bias row), tasks); a thread owns one float4 group of the fragment layout and one of four slot lanes.
 struct WgradReduceArgs {

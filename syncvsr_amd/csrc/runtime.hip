@@ -27,7 +27,6 @@ static int g_tune[SVSR_TUNE_N] = {
     /* IGEMM_BN64_BELOW */ 300, // multi-tap convolutions with fewer 128x128 tiles than this use 128x64 tiles (three workgroups per CU)
     /* WG_SHORT_K */ 16,       // svsr_igemm_wgrad: contractions of at most this many 64-row chunks use 64-wide tiles and no K split when that fills half the chip
     /* IGEMM_KSPLIT */ 160,    // svsr_igemm_fwd: launches of at most this many 64x64 tiles with >= 12 K steps split K over two wave groups per workgroup (0: never)
-    /* RES_DEEP */ 0,          // svsr_conv3x3_res at 128 channels: 32-deep weight tiles in a 4-deep ring (three in flight) instead of 64-deep / 2-deep
     /* EPI_BATCHED */ 1,       // svsr_igemm_fwd epilogue: all rows' staged accumulators / addend pieces requested before the first is used
     /* STEM_WG_PIPE */ 1,      // svsr_stem_conv_wgrad: next tile's operands prefetched into registers during the MFMA block
     /* STEM_FWD_DMA */ 1,      // svsr_stem_conv_fwd: bf16 prep pass + LDS-DMA tile fills (0: direct fp32 -> LDS path)
@@ -35,24 +34,16 @@ static int g_tune[SVSR_TUNE_N] = {
     /* P8 */ 1,                // stride-1 3x3 convolution plans with Co % 128 == 0 and enough tiles use the persistent 8-wave 256x128 kernel (igemm_p8.hip) — also the forward of the stride-2 3x3 convolutions (3: stride 1 only)
     /* P8_GRID */ 0,           // workgroups of that kernel (0: one per CU)
     /* P8_MIN_ITEMS */ 200,    // ... from this many 256x128 tiles on (fewer leave CUs idle for the whole launch)
-    /* P8_TRACE */ 0,          // debug: the instrumented instantiation (per-phase time stamps of workgroup 0, svsr_debug_p8_trace)
     /* P8_PH */ 1,             // phases per K tile of the persistent kernel: 1 (16 MFMAs between barriers) or 2 (8)
-    /* P8_STAGGER */ 3,        // bit 2 (off): the epilogue's operand rows are touched three K tiles ahead (igemm_p8.hip; measured: BatchNorm-epilogue launches 622 vs 642 TFLOP/s without); bit 0: its two wave groups run their phases one barrier apart; bit 1: odd workgroups walk their rounds last to first (their first epilogue falls elsewhere than the even ones')
+    /* P8_STAGGER */ 3,        // bit 0: its two wave groups run their phases one barrier apart; bit 1: odd workgroups walk their rounds last to first (their first epilogue falls elsewhere than the even ones')
     /* WG_IMGMAJOR */ 1,       // svsr_igemm_wgrad plans with >= 64 images enumerate rows by (position, block of 64 images): wave-uniform DMA bases (0: row-major)
-    /* C64_DEPHASED */ 0,      // experiment: svsr_conv3x3_c64 (plain epilogue) with two wave groups half a period apart — one contracts a chunk while the other drains and fetches; at parity with the lock-step kernel (0)
     /* P8_BN64 */ 1,           // 3x3 plans with too few 256 x 128 items for one per CU use 256 x 64 tiles of the persistent kernel (layer4); 0: the 4-wave kernel
     /* IGEMM_NS64 */ 0,        // ring depth of the 64x64 tiles of svsr_igemm_fwd: 0 auto (3 / 4), or 6 / 8
     /* WG_UNITS */ 1,          // svsr_igemm_wgrad plans of long contractions as balanced unit lists (format 2); 0: (K split, task) grids
     /* WG_UNIT_MAX */ 48,      // ... longest unit in 64-row chunks before the list takes a further round of workgroups
     /* WG_UNIT_MIN */ 8,       // ... shortest unit worth a slab tile of its own
-    /* P8_LIN_ITEMS */ 0,      // dense layers with at least this many 256 x 128 items run k_igemm_p8 (svsr_rows_plan_k); 0: never.  OFF: at 2,560 rows x 3,072 columns x K = 768
-                               // (240 items, one per CU, 12 K tiles each) the persistent kernel takes 34.1 us against 23.8 of k_igemm_fwd_glds<128,128,2> (hipBLASLt: 19.4) — its
-                               // prologue and wave-private epilogue are amortised over 18-36 K tiles and several tiles per CU in the convolutions, not here; LRS step 25.3 vs 25.1 ms
-    /* IGEMM_XCD */ 0,         // k_igemm_fwd_glds: tile grid cut into one rectangle per XCD (operands of an XCD's workgroups fit its L2).  OFF: measured without effect
-                               // (2,560 x 3,072 x 768: 23.7 vs 25.4 us run to run, the other LRS shapes within 3 %): these launches are bound by the DMA round trip
-                               // per K step of their 2-deep ring (12 K steps), not by where the tiles come from
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "res_deep", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_trace", "p8_ph", "p8_stagger", "wg_imgmajor", "c64_dephased", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "p8_lin_items", "igemm_xcd"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 

@@ -58,7 +58,7 @@ struct Bind<int (*)(A...), fn> {
 const std::unordered_map<std::string, Entry>& registry() {
     static const std::unordered_map<std::string, Entry> r = {
         SVSR_REG(svsr_colsum_rows), SVSR_REG(svsr_igemm_fwd), SVSR_REG(svsr_igemm_wgrad), SVSR_REG(svsr_conv3x3_c64),
-        SVSR_REG(svsr_igemm_dgrad_bn), SVSR_REG(svsr_conv3x3_c64_dgrad_bn), SVSR_REG(svsr_bn_bwd_from_stats), SVSR_REG(svsr_conv3x3_res),
+        SVSR_REG(svsr_igemm_dgrad_bn), SVSR_REG(svsr_conv3x3_c64_dgrad_bn), SVSR_REG(svsr_bn_bwd_from_stats),
         SVSR_REG(svsr_conv3x3_wgrad), SVSR_REG(svsr_stem_conv_fwd), SVSR_REG(svsr_stem_conv_wgrad), SVSR_REG(svsr_bn_finalize),
         SVSR_REG(svsr_bn_eval_prepare), SVSR_REG(svsr_bn_act_fwd), SVSR_REG(svsr_bn_act_bwd), SVSR_REG(svsr_stem_bn_act_pool_fwd),
         SVSR_REG(svsr_stem_bn_act_pool_bwd), SVSR_REG(svsr_avgpool_fwd), SVSR_REG(svsr_avgpool_bwd), SVSR_REG(svsr_add_ln_fwd),
@@ -69,7 +69,7 @@ const std::unordered_map<std::string, Entry>& registry() {
         SVSR_REG(svsr_transpose_bf16_multi), SVSR_REG(svsr_fill_f32), SVSR_REG(svsr_clip_prep), SVSR_REG(svsr_mha_fwd), SVSR_REG(svsr_mha_bwd),
         SVSR_REG(svsr_glu_dwconv_fwd), SVSR_REG(svsr_glu_dwconv_bwd), SVSR_REG(svsr_ctc_fwd), SVSR_REG(svsr_ctc_grad),
         SVSR_REG(svsr_ctc_prefix_score), SVSR_REG(svsr_embed_pos_fwd), SVSR_REG(svsr_embed_pos_bwd), SVSR_REG(svsr_ls_loss_fwd),
-        SVSR_REG(svsr_ls_loss_bwd), SVSR_REG(svsr_scale_bf16), SVSR_REG(svsr_word_add), SVSR_REG(svsr_lincomb2), SVSR_REG(svsr_igemm_wgrad_group), SVSR_REG(svsr_enc_fwd), SVSR_REG(svsr_enc_bwd), SVSR_REG(svsr_conv3x3_wgrad_multi), SVSR_REG(svsr_lincomb3_ratio), SVSR_REG(svsr_add_ln_bwd_partials), SVSR_REG(svsr_bias_act_bwd_partials),
+        SVSR_REG(svsr_ls_loss_bwd), SVSR_REG(svsr_scale_bf16), SVSR_REG(svsr_word_add), SVSR_REG(svsr_lincomb2), SVSR_REG(svsr_igemm_wgrad_group), SVSR_REG(svsr_enc_fwd), SVSR_REG(svsr_enc_bwd), SVSR_REG(svsr_lincomb3_ratio), SVSR_REG(svsr_add_ln_bwd_partials), SVSR_REG(svsr_bias_act_bwd_partials),
     };
     return r;
 }

@@ -37,7 +37,7 @@ struct Wgrad3Args {
 // accumulator registers rq*4 .. rq*4+3 — as 36 16-byte stores per lane (1 KiB per wave-instruction) instead of 144 dword stores of two
 // 128-byte rows each; k_wgrad3_reduce adds a task's slabs in split order (64 float4 groups x 4 slot lanes per block) and scatters the sum
 // into dW once.  Up to four convolutions of the same geometry can share a launch (blockIdx.z): the launch's workgroups are divided among
-// them, so each writes 1/n of the slabs of a launch of its own (svsr_conv3x3_wgrad_multi).
+// them, so each writes 1/n of the slabs of a launch of its own (grid.z = n; the shipped entry point launches n = 1).
 // (Measured and dropped: ONE 8-wave workgroup per CU whose two 4-wave groups take alternate chunks one barrier apart, accumulators merged
 // through LDS — half the slabs, but 94 vs 78 us per launch: a group's wait for its next chunk's rows, 2-3 us from HBM, stalls the shared
 // barrier for both groups, while two independent workgroups hide each other's waits.)
@@ -227,13 +227,6 @@ extern "C" int svsr_conv3x3_wgrad_plan(int Nimg, int H, int W, int Ci, int Co, i
     return SVSR_OK;
 }
 
-/* workspace (floats) of svsr_conv3x3_wgrad_multi for n problems of this geometry */
-extern "C" int64_t svsr_conv3x3_wgrad_multi_floats(int n, int Nimg, int H, int W, int Ci, int Co) {
-    if (n < 1 || n > 4 || Ci % 64 || Co % 64 || Ci <= 0 || Co <= 0 || H < 1 || W < 1 || Nimg < 1) return 0;
-    const W3Plan pl = w3_plan(Nimg, H, W, Ci, Co, n);
-    return pl.splits > 1 ? (int64_t)n * pl.splits * pl.tasks * W3_TILE_FLOATS : 0;
-}
-
 extern "C" int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate,
                                 float scale, hipStream_t stream);
 
@@ -275,22 +268,4 @@ extern "C" int svsr_conv3x3_wgrad(const void* x, const void* dy, float* dw, int 
     Wgrad3Multi m{};
     m.x[0] = a.x; m.dy[0] = a.dy; m.dw[0] = dw;
     return w3_launch(a, m, 1, w3_plan(Nimg, H, W, Ci, Co), part, part_floats, stream);
-}
-
-/* svsr_conv3x3_wgrad_multi: n <= 4 weight gradients of the SAME geometry in one launch (the convolutions of a ResNet layer): the
- * workgroups are divided among them, so every convolution writes 1/n of the slabs.  xs / dys / dws: HOST arrays of n device
- * pointers.  part: svsr_conv3x3_wgrad_multi_floats(n, ...) floats. */
-extern "C" int svsr_conv3x3_wgrad_multi(const void* const* xs, const void* const* dys, float* const* dws, int n, int Nimg, int H, int W, int Ci, int Co,
-                                        float* part, int64_t part_floats, hipStream_t stream) {
-    if (xs == nullptr || dys == nullptr || dws == nullptr || n < 1 || n > 4) return SVSR_ERR_ARG;
-    Wgrad3Args a;
-    const int rc0 = w3_fill_args(a, Nimg, H, W, Ci, Co);
-    if (rc0 != SVSR_OK) return rc0;
-    Wgrad3Multi m{};
-    for (int i = 0; i < n; ++i) {
-        if (xs[i] == nullptr || dys[i] == nullptr || dws[i] == nullptr) return SVSR_ERR_ARG;
-        m.x[i] = (const bf16_t*)xs[i]; m.dy[i] = (const bf16_t*)dys[i]; m.dw[i] = dws[i];
-    }
-    a.x = m.x[0]; a.dy = m.dy[0]; a.dw = m.dw[0];
-    return w3_launch(a, m, n, w3_plan(Nimg, H, W, Ci, Co, n), part, part_floats, stream);
 }

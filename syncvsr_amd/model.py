@@ -672,7 +672,6 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
         else:
             dx, dx_stats = ops.conv2d_dgrad(dc1, w1t, 3, stride, 1, in_hw, addend=dres), None
         _ready(model, st, f"{prefix}.conv1.weight")
-    _flush_w3(model)
     ts = tape["stem"]
     if rec is not None:
         rec["stem"] = (dx.clone(), False)
@@ -691,33 +690,10 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
 _ABLATE: frozenset = frozenset()
 
 
-W3_GROUP = int(os.environ.get("SVSR_W3_GROUP", "0"))      # stride-1 3x3 weight gradients of one geometry per launch (0 / 1: a launch each; 2: per residual block; 4: per layer)
-
-
 def _conv_wgrad(model, st: "_ParamStore", conv: str, t: dict, dc: torch.Tensor, use_tr: bool) -> None:
     if "conv_wgrad" in _ABLATE:
         return
-    if W3_GROUP > 1 and use_tr and ops.halo_wgrad_ok(t["x"], dc, t["k"], t["stride"], t["pad"]):
-        # collected: weight gradients of the same geometry share a launch (fewer split-K slabs each); flushed when the group is full, the
-        # geometry changes or the trunk's backward ends
-        pend = model.__dict__.setdefault("_w3_pending", [])
-        if pend and (pend[0][0].shape != t["x"].shape or pend[0][1].shape != dc.shape):
-            _flush_w3(model)
-            pend = model._w3_pending
-        pend.append((t["x"], dc, st.g32(f"{conv}.weight")))
-        if len(pend) >= min(W3_GROUP, 4):
-            _flush_w3(model)
-        return
     model._side.run(lambda: ops.conv2d_wgrad(t["x"], dc, st.g32(f"{conv}.weight"), t["k"], t["stride"], t["pad"], use_tr), dc)
-
-
-def _flush_w3(model) -> None:
-    pend = model.__dict__.get("_w3_pending")
-    if not pend:
-        return
-    model._w3_pending = []
-    keep = [q for p in pend for q in p[:2]]
-    model._side.run(lambda: ops.conv3x3_wgrad_multi(pend), *keep)
 
 
 def _lin_wgrad(model, x, dy, gw, gb, rows: int, K: int, N: int, x_pitch: int, dy_pitch: int) -> None:
@@ -774,7 +750,6 @@ def _ready(model, st: "_ParamStore", name: Optional[str]) -> None:
     region is final (backward walks the flat buffer from its end to its start); None = all gradients final."""
     _flush_deferred(model)                    # postponed parameter-gradient reductions: to the side stream, once per layer
     if model.grad_ready_hook is not None:     # (the reducer's comm stream waits for the side stream itself: engine.GradReducer._reduce)
-        _flush_w3(model)                      # collected weight gradients are not final until launched: bucket boundaries end a group
         model._side.flush()
         hook, lo = model.grad_ready_hook, (0 if name is None else st.offsets[name][0])
         ops.host_callback(lambda: hook(lo))   # a host-side step (collective): a segment boundary of a recorded step list

@@ -433,15 +433,11 @@ def conv_plan(mode: int, N: int, H: int, W: int, Co_out: int, k: int, stride: in
 
 
 def rows_plan(Nimg: int, P: int, src0: int, dst0: int, Co_out: int, Ci: Optional[int] = None) -> Plan:
-    """Ci (the contraction depth, when the launch has neither a GELU nor an fp32 output): lets large plain dense layers take the persistent
-    8-wave kernel (svsr_rows_plan_k)."""
-    key = ("rows", Nimg, P, src0, dst0, Co_out, Ci)
+    """Plan of a dense layer over rows grouped in Nimg sequences (svsr_rows_plan); Ci is accepted for the callers' convenience and unused."""
+    key = ("rows", Nimg, P, src0, dst0, Co_out)
     pl = _PLAN_CACHE.get(key)
     if pl is None:
-        if Ci is None:
-            pl = _PLAN_CACHE[key] = Plan("svsr_rows_plan", Nimg, P, src0, dst0, Co_out)
-        else:
-            pl = _PLAN_CACHE[key] = Plan("svsr_rows_plan_k", Nimg, P, src0, dst0, Co_out, Ci)
+        pl = _PLAN_CACHE[key] = Plan("svsr_rows_plan", Nimg, P, src0, dst0, Co_out)
     return pl
 
 
@@ -576,8 +572,6 @@ def conv2d_fwd(x: torch.Tensor, w16: torch.Tensor, k: int, stride: int, pad: int
     out = torch.empty((N, Ho, Wo, Co), dtype=BF16, device=x.device)
     if _c64_ok(Ci, Co, k, stride, pad, W):
         return out, conv3x3_c64(x, w16, out, None, want_stats, _conv_taps(k, pad))
-    if _res_ok(Ci, Co, k, stride, pad, W, N * H * W):
-        return out, conv3x3_res(x, w16, out, None, want_stats, _conv_taps(k, pad), Co)
     st = igemm_fwd(conv_plan(0, N, H, W, Co, k, stride, pad), x, w16, out, Nimg=N, in_pix=H * W, Ci=Ci, in_pitch=Ci, Co=Co,
                    out_pix=Ho * Wo, out_pitch=Co, wt_taps=k * k, want_stats=want_stats, flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
     return out, st
@@ -634,31 +628,6 @@ def conv3x3_c64(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, addend: Op
     return st
 
 
-# Activation-resident kernel for stride-1 conv3x3 with 128 / 256 input channels (svsr_conv3x3_res).  OFF by default: at layer2 its K loop
-# is 25 % faster than the generic kernel's (0.88 vs 1.18 us per step: half the bytes staged) but the tile load in front of it is exposed
-# (4.2 us per workgroup), which nets 57.8 vs 53.6 us per convolution.
-RES_CONV = False
-RES_CI = (128,)        # input widths routed to it
-
-
-def _res_ok(Ci: int, Co: int, k: int, stride: int, pad: int, W: int, M: int) -> bool:
-    return RES_CONV and Ci in RES_CI and Co % 8 == 0 and k == 3 and stride == 1 and pad == 1 and W <= 61 and M >= 16384
-
-
-def conv3x3_res(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, addend: Optional[torch.Tensor], want_stats: bool,
-                taps: Sequence[tuple[int, int, int]], Co: int):
-    N, H, W, Ci = x.shape
-    dy, dx, tw = zip(*taps)
-    stats = st = None
-    if want_stats:
-        rows = _query("svsr_conv3x3_res_stat_rows", N, H, W)[0]
-        stats = scratch(rows * 2 * Co)
-        st = (stats, rows)
-    _call("svsr_conv3x3_res", _p(x), _p(wt), _p(out), _p(addend), _p(stats), N, H, W, Ci, Co, _ints(dy), _ints(dx), _ints(tw), _stream(),
-          label=f"k_conv3x3_res<{Ci}>", flops=2.0 * N * H * W * Ci * Co * 9)
-    return st
-
-
 def conv2d_dgrad(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad: int, in_hw: tuple[int, int],
                  addend: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dy [N,Ho,Wo,Co], w16t bf16 [Ci][k][k][Co] (transposed shadow) -> dx [N,H,W,Ci] (+ addend, in place when given).
@@ -672,10 +641,6 @@ def conv2d_dgrad(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, pad:
     if stride == 1 and _c64_ok(Ci, Co, k, stride, pad, W):
         taps = tuple((pad - kh, pad - kw, kh * k + kw) for kh in range(k) for kw in range(k))
         conv3x3_c64(dy, w16t, dx, addend, False, taps)
-        return dx
-    if stride == 1 and _res_ok(Co, Ci, k, stride, pad, W, N * H * W):
-        taps = tuple((pad - kh, pad - kw, kh * k + kw) for kh in range(k) for kw in range(k))
-        conv3x3_res(dy, w16t, dx, addend, False, taps, Ci)
         return dx
     igemm_fwd(conv_plan(1 if addend is None else 2, N, H, W, Ci, k, stride, pad), dy, w16t, dx, Nimg=N, in_pix=Ho * Wo, Ci=Co, in_pitch=Co, Co=Ci, out_pix=H * W,
               out_pitch=Ci, wt_taps=k * k, addend=addend, flops=2.0 * N * Ho * Wo * Co * Ci * k * k)
@@ -746,20 +711,6 @@ def halo_wgrad_ok(x: torch.Tensor, dy: torch.Tensor, k: int, stride: int, pad: i
     N, H, W, Ci = x.shape
     Co = dy.shape[-1]
     return HALO_WGRAD and k == 3 and stride == 1 and pad == 1 and W <= 29 and H * W >= 100 and Ci % 64 == 0 and Co % 64 == 0
-
-
-def conv3x3_wgrad_multi(problems: Sequence[tuple]) -> None:
-    """problems: up to four (x, dy, dw) of ONE geometry (halo_wgrad_ok): one launch whose workgroups are divided among them."""
-    x0, dy0, _ = problems[0]
-    N, H, W, Ci = x0.shape
-    Co = dy0.shape[-1]
-    n = len(problems)
-    nfl = _query("svsr_conv3x3_wgrad_multi_floats", n, N, H, W, Ci, Co)[0]
-    part = scratch(nfl) if nfl else None
-    PtrArr = ctypes.c_void_p * n
-    xs, dys, dws = PtrArr(*[p[0].data_ptr() for p in problems]), PtrArr(*[p[1].data_ptr() for p in problems]), PtrArr(*[p[2].data_ptr() for p in problems])
-    _call("svsr_conv3x3_wgrad_multi", xs, dys, dws, n, N, H, W, Ci, Co, _p(part), nfl, _stream(), label="k_wgrad3x3_halo",
-          flops=2.0 * n * N * H * W * Co * Ci * 9)
 
 
 def linear_fwd(x: torch.Tensor, w16: torch.Tensor, bias: Optional[torch.Tensor], *, rows: int, K: int, N: int, x_pitch: int,

@@ -11,6 +11,25 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# SVSR_REDZONE=1: every device tensor of this pytest process gets poisoned 4 KiB red zones on both sides (tests/redzone/redzone_alloc.cpp,
+# installed as torch's device allocator BEFORE the first allocation) and every test ends with a sweep that fails it if a kernel wrote
+# into one (tests/test_gpu_redzone.py runs the kernel-level test files this way).
+_RZ = None
+if os.environ.get("SVSR_REDZONE") == "1":
+    import ctypes
+    import subprocess
+    import tempfile
+
+    import torch
+
+    _src = os.path.join(ROOT, "tests", "redzone", "redzone_alloc.cpp")
+    _so = os.path.join(tempfile.mkdtemp(prefix="svsr_rz_"), "libredzone.so")
+    subprocess.run(["hipcc", "-shared", "-fPIC", "-O2", "-o", _so, _src], check=True, capture_output=True)
+    torch.cuda.memory.change_current_allocator(torch.cuda.memory.CUDAPluggableAllocator(_so, "rz_malloc", "rz_free"))
+    _RZ = ctypes.CDLL(_so)
+    _RZ.rz_check_all.restype = ctypes.c_long
+    _RZ.rz_alloc_count.restype = ctypes.c_long
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -33,3 +52,15 @@ def _tuning_overrides():
             k, v = kv.split("=")
             ops.tune(k, int(v))
     yield
+
+
+@pytest.fixture(autouse=True)
+def _redzone_sweep():
+    """Under SVSR_REDZONE=1: fail the test that wrote outside a tensor it handed to the C ABI."""
+    if _RZ is None:
+        yield
+        return
+    before = _RZ.rz_check_all()
+    yield
+    after = _RZ.rz_check_all()
+    assert after == before, f"{after - before} byte(s) were written into the red zones around device tensors during this test (stderr names the tensor sizes)"

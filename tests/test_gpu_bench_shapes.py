@@ -297,55 +297,3 @@ def test_trunk_dgrad_with_bn_backward_epilogue_at_928_frames(dev, name, residual
     g2, stats2 = ops.conv2d_dgrad_bn(dy.to(dev), wt.to(dev), k, s, p, (H, W), None if add is None else add.to(dev).clone(),
                                      y_dev if residual else None, xb.to(dev), m, r, gamma.to(dev), beta.to(dev))
     assert torch.equal(g2, g) and torch.equal(stats2[0][: rows * 2 * Ci], buf[: rows * 2 * Ci]), f"{name}: not reproducible"
-
-
-# the sentence-level model's dense layers with >= 2,304 output columns at 16 x 160 frames: (K, N, relu, dropout, alpha, addend)
-P8_LINEARS = [(768, 3072, True, True, 1.0, False), (768, 2304, False, False, 1.0, False), (768, 3072, False, True, 0.5, True), (768, 3072, False, False, 1.0, True)]
-
-
-@pytest.mark.parametrize("K,N,relu,drop,alpha,addend", P8_LINEARS)
-def test_lrs_wide_linears_run_the_persistent_kernel(dev, K, N, relu, drop, alpha, addend):
-    """2,560 rows x {3,072, 2,304} columns are 240 / 180 items of 256 x 128: with the tune key p8_lin_items set (it is OFF by default: measured
-    slower at K = 768) svsr_rows_plan_k hands them to k_igemm_p8, whose dense-layer
-    epilogue (bias, ReLU, dropout, alpha, addend — reference positionwise_feed_forward.py:28-30, encoder_layer.py:93-137) must give the bits
-    of the 4-wave kernel it replaces (same MFMA, one accumulator walking k upwards in both), and agree with torch fp32."""
-    from syncvsr_amd import ops
-
-    rows = 2560
-    if relu and (addend or alpha != 1.0):
-        pytest.skip("the library applies an activation only without alpha / addend")
-    x = rnd((rows, K), 8).to(dev)
-    w = rnd((N, K), 9, 1 / math.sqrt(K)).to(dev)
-    b = torch.randn(N, generator=torch.Generator().manual_seed(10)).to(dev)
-    add = rnd((rows, N), 11).to(dev) if addend else None
-    seed = torch.tensor([12345], dtype=torch.int32, device=dev)
-    dr = (seed, 7, 0.1) if drop else None
-    outs = {}
-    for items in (160, 0):
-        ops.tune("p8_lin_items", items)
-        try:
-            plan = ops.rows_plan(rows, 1, 0, 0, N, K)
-            assert plan.label == ("k_igemm_p8<256,128,3>" if items else "k_igemm_fwd_glds<128,128,2>"), plan.label
-            outs[items], _ = ops.linear_fwd(x, w, b, rows=rows, K=K, N=N, x_pitch=K, relu=relu, alpha=alpha, addend=add, drop=dr)
-        finally:
-            ops.tune("p8_lin_items", 0)
-    torch.cuda.synchronize()
-    assert torch.equal(outs[160], outs[0]), float((outs[160].float() - outs[0].float()).abs().max())
-    if not drop:
-        ref = F.linear(x.float(), w.float(), b)
-        if relu:
-            ref = ref.relu()
-        ref = alpha * ref + (add.float() if addend else 0.0)
-        check(outs[160], ref.cpu(), "p8 linear")
-    # the data gradient of the 768-wide layers behind them (dy [2560, 768] -> dx [2560, 3072]): the same plan family through linear_dgrad
-    dy = rnd((rows, 768), 13).to(dev)
-    wt = rnd((N, 1, 768), 14, 1 / math.sqrt(768)).to(dev)          # transposed shadow [K_out][1][N_in]
-    dxs = {}
-    for items in (160, 0):
-        ops.tune("p8_lin_items", items)
-        try:
-            dxs[items] = ops.linear_dgrad(dy, wt, rows=rows, N=768, K=N, dy_pitch=768, addend=add, alpha=alpha, drop=dr)
-        finally:
-            ops.tune("p8_lin_items", 0)
-    torch.cuda.synchronize()
-    assert torch.equal(dxs[160], dxs[0])

@@ -104,36 +104,6 @@ def test_conv_dgrad(dev, case):
     check(dx2, nhwc(xs.grad) + add.float(), "conv_dgrad+addend")
 
 
-@pytest.mark.parametrize("case", [(157, 11, 11, 128, 128), (463, 6, 6, 256, 256), (35, 22, 22, 128, 64)])
-def test_conv3x3_activation_resident_kernel(dev, case, monkeypatch):
-    """svsr_conv3x3_res (activation tile resident in LDS across the nine taps; off by default, see ops.RES_CONV): forward with BatchNorm
-    partial rows and data gradient with the in-place addend, on pixel counts that are not multiples of the 128-pixel tile, against
-    torch fp32 and bit-identical to a second run."""
-    from syncvsr_amd import ops
-
-    N, H, W, Ci, Co = case
-    monkeypatch.setattr(ops, "RES_CONV", True)
-    monkeypatch.setattr(ops, "RES_CI", (128, 256))
-    assert ops._res_ok(Ci, Co, 3, 1, 1, W, N * H * W)
-    x = rnd((N, H, W, Ci), 1)
-    w = rnd((Co, 3, 3, Ci), 2, 1.0 / math.sqrt(9 * Ci))
-    out, stats = ops.conv2d_fwd(x.to(dev), w.to(dev), 3, 1, 1, want_stats=True)
-    out2, stats2 = ops.conv2d_fwd(x.to(dev), w.to(dev), 3, 1, 1, want_stats=True)
-    assert stats[1] == (N * H * W + 127) // 128 and torch.equal(out, out2)
-    ref = F.conv2d(nchw(x.float()), w.float().permute(0, 3, 1, 2), stride=1, padding=1)
-    check(out, nhwc(ref), "conv3x3_res fwd")
-    st = stat_sums(stats, Co)
-    check(st[1], (ref * ref).sum((0, 2, 3)), "stats.sumsq", 3e-3, 2e-3)
-    if Ci in (128, 256) and Co in (128, 256):          # data gradient: the roles of Ci and Co swap, so the OUTPUT-gradient width must be 128 / 256
-        dy = rnd((N, H, W, Co), 3)
-        wt = w.permute(3, 1, 2, 0).contiguous()
-        xs = torch.zeros(N, Ci, H, W, requires_grad=True)
-        F.conv2d(xs, w.float().permute(0, 3, 1, 2), stride=1, padding=1).backward(nchw(dy.float()))
-        add = rnd((N, H, W, Ci), 5)
-        dx = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), 3, 1, 1, (H, W), addend=add.to(dev).clone())
-        check(dx, nhwc(xs.grad) + add.float(), "conv3x3_res dgrad+addend")
-
-
 @pytest.mark.parametrize("use_tr", [False, True])
 @pytest.mark.parametrize("case", CONV_CASES[:6])
 def test_conv_wgrad(dev, case, use_tr):
@@ -747,33 +717,3 @@ def test_grouped_weight_gradients_replay_from_a_hip_graph(dev):
     for (dw, db), (wdw, wdb) in zip(zip(dws, dbs), want):
         assert torch.equal(dw, wdw) and torch.equal(db, wdb)
     assert float(dws[0].abs().max()) > 0
-
-
-@pytest.mark.parametrize("shape", [(3, 5, 7), (16, 22, 22), (70, 11, 29)])
-def test_conv3x3_c64_dephased_kernel_equals_lock_step(dev, shape):
-    """svsr_conv3x3_c64 with the pixel table and the knob c64_dephased (an experiment, off by default): two wave groups half a period
-    apart.  Same MFMA instruction and accumulation order as the lock-step kernel: forward and data-gradient(+addend) outputs are
-    EQUAL bit for bit; the BatchNorm partial sums agree to rounding (added in another fixed order) and are reproducible."""
-    from syncvsr_amd import ops
-
-    N, H, W = shape
-    x = rnd((N, H, W, 64), 31).to(dev)
-    w = rnd((64, 3, 3, 64), 32, 0.05).to(dev)
-    dy = rnd((N, H, W, 64), 33).to(dev)
-    add = rnd((N, H, W, 64), 34).to(dev)
-    got = {}
-    try:
-        for mode in (0, 1):
-            ops.tune("c64_dephased", mode)
-            out, st = ops.conv2d_fwd(x, w, 3, 1, 1, want_stats=True)
-            stats = st[0][: st[1] * 128].view(st[1], 2, 64).sum(0).clone()
-            out2, st2 = ops.conv2d_fwd(x, w, 3, 1, 1, want_stats=True)
-            assert torch.equal(out, out2) and torch.equal(st[0][: st[1] * 128], st2[0][: st2[1] * 128])
-            dx = ops.conv2d_dgrad(dy, w, 3, 1, 1, (H, W), addend=add.clone())
-            got[mode] = (out.clone(), stats, dx.clone())
-    finally:
-        ops.tune("c64_dephased", 0)
-    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][2], got[1][2])
-    assert float((got[0][1] - got[1][1]).abs().max() / got[0][1].abs().max()) <= 1e-5
-    ref = F.conv2d(nchw(x.float().cpu()), w.float().cpu().permute(0, 3, 1, 2), stride=1, padding=1)
-    check(got[1][0], nhwc(ref), "c64 de-phased fwd")

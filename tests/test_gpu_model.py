@@ -183,7 +183,9 @@ def test_benchmark_batch_matches_oracle_and_reference_golden(dev):
     trunk, other = _emu_grad_stats(cfg, sd2, batch2, model)
     print("bf16-emulation: trunk worst", trunk[:3], "median", trunk[len(trunk) // 2][0], "encoder/heads worst", other[:2])
     assert trunk[0][0] >= 0.93 and trunk[len(trunk) // 2][0] >= 0.96, (trunk[:3], trunk[len(trunk) // 2])
-    assert all(0.91 <= r <= 1.085 for _, r, _ in trunk), sorted(trunk, key=lambda t: -abs(t[1] - 1))[:3]
+    # EVERY tensor's gradient norm against the emulation: within 8 % inside the trunk (measured 0.930-1.063), within 0.6 % above it — a 10 %
+    # scale error in any single tensor cannot pass
+    assert all(0.92 <= r <= 1.08 for _, r, _ in trunk), sorted(trunk, key=lambda t: -abs(t[1] - 1))[:3]
     assert other[0][0] >= 0.9975 and all(0.995 <= r <= 1.006 for _, r, _ in other), (other[:3], sorted(other, key=lambda t: -abs(t[1] - 1))[:3])
 
 
