@@ -73,7 +73,7 @@ extern "C" {
 /* ---- plumbing (runtime.hip) ------------------------------------------------------------------------------------
  * svsr_tune: sets a result-preserving tuning knob ("igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd",
  * "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe",
- * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min": tile shapes, split counts, kernel-variant switches — documented at the table in runtime.hip;
+ * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128": tile shapes, split counts, kernel-variant switches — documented at the table in runtime.hip;
  * never read from the environment); unknown key -> SVSR_ERR_ARG.
  * svsr_colsum_rows: out[c] (+)= scale * sum_{r<nrows} ws[r*ld + c], rows added in a fixed order; columns [0,n0) go to out0,
  * [n0,n0+n1) to out1 (may be null when n1 = 0); accumulate != 0 adds to the existing values. */
@@ -358,6 +358,17 @@ int svsr_mha_fwd(const void* q, int q_pitch, const void* k, const void* v, int k
  * gradients) and dpe [2*Lq-1][dpe_pitch] (gradient of the projected position table, feeds linear_pos's weight gradient);
  * pe_part: fp32 workspace [B][2*Lq-1][dpe_pitch] (per-batch-item partials of dpe; dpe_pitch must equal H*64). */
 int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
+
+/* The same attention without the probability matrix on the way forward (mha_flash.h; attention.py:38-108,191-278 as above): keys streamed in
+ * blocks of 32 with an online softmax, one wave per 32-query tile, up to eight tiles of one (clip, head) per workgroup.  The forward keeps
+ * lse [B*H][Lq] fp32 (log-sum-exp of a query's scaled, masked scores; +inf when every key is masked) instead of probs; dropout decisions are
+ * the same hash(*drop_seed, drop_site, (bh * Lq + i) * ldp + j) as svsr_mha_fwd's.  The backward recomputes P from lse and takes
+ * rowsum(P o dP) as dctx_i . ctx_i (ctx: the forward's output); its query pass writes probs / ds [B*H][Lq][ldp] bf16 (ldp % 8 == 0) as
+ * WORKSPACE for the key and position-table passes, which are svsr_mha_bwd's.  ws: svsr_mha_flash_ws_bytes(H, Lq) bytes (the transposed
+ * position table; rel-pos only).  klen / causal must be the forward's. */
+int64_t svsr_mha_flash_ws_bytes(int H, int Lq);
+int svsr_mha_flash_fwd(const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* ctx, int ctx_pitch, float* lse, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
+int svsr_mha_flash_bwd(const void* dctx, int dctx_pitch, const void* ctx, int ctx_pitch, const float* lse, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal, void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, void* ws, int64_t ws_bytes, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 
 /* Conformer convolution module core (transformer/convolution.py:56-75): u [B*T][2D] = pointwise_cov1 output ->
  * GLU -> depthwise Conv1d(K odd <= 31, pad (K-1)/2, weight [D][K], bias) -> c [B*T][D] bf16 + BatchNorm1d partial sums

@@ -769,7 +769,13 @@ extern "C" int svsr_igemm_fwd_kgroups(const int* meta, int Ci, int Co, int bn_ep
     if (meta == nullptr || Ci < 64) return 1;
     const int bm = meta[0], bn = meta[1], gx = meta[3], gy = (Co + bn - 1) / bn;
     const int ks = svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT);
-    return (!bn_epilogue && bm == 64 && bn == 64 && ks && (long)gx * gy <= ks && (long)meta[6] * (Ci / 64) >= 12) ? 2 : 1;
+    if (!bn_epilogue && bm == 64 && bn == 64 && ks && (long)gx * gy <= ks && (long)meta[6] * (Ci / 64) >= 12) return 2;
+    // dense layers on 128 x 64 tiles that give about ONE four-wave workgroup per CU (2,560 rows x 768 columns = 240 tiles) and a long
+    // contraction: a single wave per SIMD cannot hide its own LDS-DMA round trips (K = 3,072: 29.2 us, 413 TFLOP/s against hipBLASLt's
+    // 20.2); two wave groups halve every workgroup's K loop and put two waves on every SIMD
+    const int ks128 = svsr_tune_get(SVSR_TUNE_IGEMM_KSPLIT128);
+    if (!bn_epilogue && bm == 128 && bn == 64 && meta[2] == 3 && meta[6] == 1 && ks128 > 0 && Ci / 64 >= ks128 && (long)gx * gy <= 288) return 2;
+    return 1;
 }
 
 /* svsr_igemm_fwd: runs a plan.  plan_dev = device copy of the words, meta = the host meta[8] svsr_*_plan returned with them. */
@@ -794,7 +800,10 @@ static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pr
     if (gx < 1) return SVSR_ERR_ARG;
     if (bm == P8_BM) return igemm_p8_launch(a, meta, stream);
     // few tiles, long contraction: split K inside the workgroup (see k_igemm_fwd_glds, KG = 2)
-    if (svsr_igemm_fwd_kgroups(meta, Ci, Co, bnb_x != nullptr) == 2) return launch_glds<64, 64, 4, 2>(a, gx, gy, stream);
+    if (svsr_igemm_fwd_kgroups(meta, Ci, Co, bnb_x != nullptr) == 2) {
+        if (bm == 128) return launch_glds<128, 64, 3, 2>(a, gx, gy, stream);
+        return launch_glds<64, 64, 4, 2>(a, gx, gy, stream);
+    }
 #define SVSR_IGEMM_CASE(BM_, BN_, NS_) if (bm == BM_ && bn == BN_ && ns == NS_) return launch_glds<BM_, BN_, NS_>(a, gx, gy, stream)
     SVSR_IGEMM_CASE(128, 128, 2);
     SVSR_IGEMM_CASE(128, 64, 2);

@@ -73,6 +73,7 @@ __device__ __forceinline__ bf16x8 f32row_frag(const float* p) {
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 #include "mha_coop.h"
+#include "mha_flash.h"
 
 __global__ __launch_bounds__(256) void k_mha_pe_reduce(const float* __restrict__ part, bf16_t* __restrict__ dpe, int B, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -142,6 +143,85 @@ int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, c
         hipLaunchKernelGGL(k_mha_pe_reduce, dim3((int)blocks), dim3(256), 0, stream, pe_part, (bf16_t*)dpe, B, n);
     } else {
         hipLaunchKernelGGL(k_mha_bwd_q4<false>, gq, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL(k_mha_bwd_kv4<false>, gk, dim3(256), 0, stream, a);
+    }
+    return svsr_check_launch();
+}
+
+/* waves per workgroup and workgroups per (clip, head) of the flash kernels: one query tile per wave, at most eight, balanced */
+static inline void mhaf_grid(int Lq, int& groups, int& waves, int max_waves = 8) {
+    const int nq = (Lq + 31) / 32;
+    groups = (nq + max_waves - 1) / max_waves;
+    waves = (nq + groups - 1) / groups;
+    if (waves < 4) waves = 4;          // (the staging of a key block is dealt out over 256 threads)
+}
+
+int64_t svsr_mha_flash_ws_bytes(int H, int Lq) {
+    if (H < 1 || Lq < 1) return 0;
+    const int LM = 64 + ((8 - Lq % 8) % 8), Rp = (2 * Lq + 32 + LM + 7) / 8 * 8;
+    return (int64_t)H * MHA_DH * Rp * 2;
+}
+
+int svsr_mha_flash_fwd(const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch,
+                       const float* bias_u, const float* bias_v, const int* klen, int causal, int B, int H, int dh, int Lq, int Lk, int ldp,
+                       float scale, void* ctx, int ctx_pitch, float* lse, const unsigned* drop_seed, unsigned drop_site, float drop_p,
+                       hipStream_t stream) {
+    if (dh != MHA_DH || Lq < 1 || Lk < 1 || ldp < Lk || (q_pitch | kv_pitch | pe_pitch | ctx_pitch) % 8 != 0 || lse == nullptr || ctx == nullptr) return SVSR_ERR_ARG;
+    if (pe != nullptr && (bias_u == nullptr || bias_v == nullptr || Lq != Lk)) return SVSR_ERR_ARG;
+    MhafArgs p{};
+    MhaArgs& a = p.m;
+    a.q = (const bf16_t*)q; a.q_pitch = q_pitch; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.kv_pitch = kv_pitch;
+    a.pe = (const bf16_t*)pe; a.pe_pitch = pe_pitch; a.bias_u = bias_u; a.bias_v = bias_v; a.klen = klen; a.causal = causal;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldp = ldp; a.scale = scale; a.ctx = (bf16_t*)ctx; a.ctx_pitch = ctx_pitch;
+    a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
+    p.lse = lse;
+    static bool attr = false;
+    if (!attr) { mha_allow_lds(k_mhaf_fwd<true>); mha_allow_lds(k_mhaf_fwd<false>); attr = true; }
+    int groups, waves;
+    mhaf_grid(Lq, groups, waves);
+    const dim3 grid(groups, B * H);
+    if (pe != nullptr) hipLaunchKernelGGL(k_mhaf_fwd<true>, grid, dim3(64 * waves), mhaf_fwd_lds(waves), stream, p);
+    else hipLaunchKernelGGL(k_mhaf_fwd<false>, grid, dim3(64 * waves), mhaf_fwd_lds(waves), stream, p);
+    return svsr_check_launch();
+}
+
+int svsr_mha_flash_bwd(const void* dctx, int dctx_pitch, const void* ctx, int ctx_pitch, const float* lse, const void* q, int q_pitch, const void* k,
+                       const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal,
+                       void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac,
+                       void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, void* ws,
+                       int64_t ws_bytes, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream) {
+    if (dh != MHA_DH || Lq < 1 || Lk < 1 || ldp < Lk || ldp % 8 != 0 || (q_pitch | kv_pitch | pe_pitch | dctx_pitch | ctx_pitch | dq_pitch | aux_pitch) % 8 != 0) return SVSR_ERR_ARG;
+    if (dctx == nullptr || ctx == nullptr || lse == nullptr || probs == nullptr || ds == nullptr || dq == nullptr || dk == nullptr || dv == nullptr) return SVSR_ERR_ARG;
+    const bool rel = pe != nullptr;
+    if (rel && (bias_u == nullptr || bias_v == nullptr || Lq != Lk || dq_ac == nullptr || dq_bd == nullptr || dpe == nullptr || pe_part == nullptr ||
+                ws == nullptr || ws_bytes < svsr_mha_flash_ws_bytes(H, Lq) || dpe_pitch != H * MHA_DH)) return SVSR_ERR_ARG;
+    MhafArgs p{};
+    MhaArgs& a = p.m;
+    a.q = (const bf16_t*)q; a.q_pitch = q_pitch; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.kv_pitch = kv_pitch;
+    a.pe = (const bf16_t*)pe; a.pe_pitch = pe_pitch; a.bias_u = bias_u; a.bias_v = bias_v; a.klen = klen; a.causal = causal;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.ldp = ldp; a.scale = scale; a.probs = (bf16_t*)probs;
+    a.dctx = (const bf16_t*)dctx; a.dctx_pitch = dctx_pitch; a.ds = (bf16_t*)ds; a.dq = (bf16_t*)dq; a.dq_pitch = dq_pitch;
+    a.dq_ac = (bf16_t*)dq_ac; a.dq_bd = (bf16_t*)dq_bd; a.aux_pitch = aux_pitch; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dkv_pitch = dkv_pitch;
+    a.dpe = (bf16_t*)dpe; a.dpe_pitch = dpe_pitch; a.pe_part = pe_part;
+    a.drop = svsr_make_drop(drop_seed, drop_site, drop_p);
+    p.lse = const_cast<float*>(lse); p.ctx = (const bf16_t*)ctx; p.ctx_in_pitch = ctx_pitch;
+    static bool attr = false;
+    if (!attr) { mha_allow_lds(k_mhaf_bwd_q<true>); mha_allow_lds(k_mhaf_bwd_q<false>); attr = true; }
+    int groups, waves;
+    mhaf_grid(Lq, groups, waves);
+    const dim3 gq(groups, B * H), gk((Lk + 31) / 32, B * H);
+    if (rel) {
+        const int LM = 64 + ((8 - Lq % 8) % 8), Rp = (2 * Lq + 32 + LM + 7) / 8 * 8;
+        p.pet = (const bf16_t*)ws; p.pet_pitch = Rp; p.pet_lm = LM;
+        hipLaunchKernelGGL(k_mhaf_pe_transpose, dim3((Rp + 31) / 32, H * MHA_DH / 32), dim3(256), 0, stream, a.pe, pe_pitch, 2 * Lq - 1, (bf16_t*)ws, Rp, LM);
+        hipLaunchKernelGGL(k_mhaf_bwd_q<true>, gq, dim3(64 * waves), mhaf_bwd_lds(waves), stream, p);
+        const long n = (long)(2 * Lq - 1) * dpe_pitch;
+        long blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_mha_bwd_kv4<true>, gk, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_mha_bwd_pe4, dim3((2 * Lq - 1 + 31) / 32, H, B), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_mha_pe_reduce, dim3((int)blocks), dim3(256), 0, stream, pe_part, (bf16_t*)dpe, B, n);
+    } else {
+        hipLaunchKernelGGL(k_mhaf_bwd_q<false>, gq, dim3(64 * waves), mhaf_bwd_lds(waves), stream, p);
         hipLaunchKernelGGL(k_mha_bwd_kv4<false>, gk, dim3(256), 0, stream, a);
     }
     return svsr_check_launch();

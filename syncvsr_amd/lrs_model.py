@@ -491,7 +491,7 @@ def _encoder_layer_fwd(model: E2E, st: _ParamStore, tape: dict, i: int, x, pos16
     bu, bv = st.p32(f"{p}.self_attn.pos_bias_u"), st.p32(f"{p}.self_attn.pos_bias_v")
     dpr, dao = model._d(f"enc.{i}.attn.probs", attn=True), model._d(f"enc.{i}.attn.out")
     ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=T, Lk=T, pe=pe, bias_u=bu, bias_v=bv, klen=ilen,
-                             drop=dpr)
+                             drop=dpr, flash=True)
     x2 = _lin(st, ctx, f"{p}.self_attn.linear_out", R, D, D, addend=x1, drop=dao)
     t["mha"] = dict(x=x1, tn=t2, m=m2, r=r2, qkv=qkv, pe=pe, ctx=ctx, probs=probs, dpr=dpr, dao=dao)
     # convolution module
@@ -578,14 +578,14 @@ def _decoder_fwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, memory
         t1, m1, r1 = _ln(st, x, f"{p}.norm1")
         qkv = _lin(st, t1, f"{p}.self_attn.linear_q", R, D, 3 * D)
         dsp, dso = model._d(f"dec.{i}.self.probs", attn=True), model._d(f"dec.{i}.self.out")
-        ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=L, Lk=L, causal=True, drop=dsp)
+        ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=L, Lk=L, causal=True, drop=dsp, flash=True)
         x1 = _lin(st, ctx, f"{p}.self_attn.linear_out", R, D, D, addend=x, drop=dso)
         t["self"] = dict(x=x, tn=t1, m=m1, r=r1, qkv=qkv, ctx=ctx, probs=probs, dpr=dsp, dao=dso)
         t2, m2, r2 = _ln(st, x1, f"{p}.norm2")
         q = _lin(st, t2, f"{p}.src_attn.linear_q", R, D, D)
         kv = _lin(st, memory, f"{p}.src_attn.linear_k", B * T, D, 2 * D)
         dcp, dco = model._d(f"dec.{i}.src.probs", attn=True), model._d(f"dec.{i}.src.out")
-        ctx2, probs2 = ops.mha_fwd(q, D, kv, kv[:, D:], 2 * D, B=B, H=H, Lq=L, Lk=T, klen=ilen, drop=dcp)
+        ctx2, probs2 = ops.mha_fwd(q, D, kv, kv[:, D:], 2 * D, B=B, H=H, Lq=L, Lk=T, klen=ilen, drop=dcp, flash=True)
         x2 = _lin(st, ctx2, f"{p}.src_attn.linear_out", R, D, D, addend=x1, drop=dco)
         t["src"] = dict(x=x1, tn=t2, m=m2, r=r2, q=q, kv=kv, ctx=ctx2, probs=probs2, dpr=dcp, dao=dco)
         x = _ffn_fwd(model, st, t, "ff", x2, f"{p}.feed_forward", R, D, U, 1.0, f"{p}.norm3", f"dec.{i}.ff")

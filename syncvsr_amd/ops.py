@@ -1188,32 +1188,64 @@ def probs_pitch(Lk: int) -> int:
     return (Lk + 7) // 8 * 8
 
 
+MHA_FLASH = os.environ.get("SVSR_MHA_FLASH", "1") != "0"     # sentence-level attention on the streamed-key kernels (mha_flash.h); False: the per-tile kernels
+
+
+class MhaLse:
+    """What the flash forward keeps for the backward instead of the probabilities: the rows' log-sum-exp, the output and the masks it ran with."""
+    __slots__ = ("lse", "ctx", "klen", "causal", "ldp")
+
+    def __init__(self, lse, ctx, klen, causal, ldp):
+        self.lse, self.ctx, self.klen, self.causal, self.ldp = lse, ctx, klen, causal, ldp
+
+
 def mha_fwd(q, q_pitch: int, k, v, kv_pitch: int, *, B: int, H: int, Lq: int, Lk: int, pe=None, bias_u=None, bias_v=None, klen=None,
-            causal: bool = False, drop=None):
-    """-> (ctx [B*Lq, H*64] bf16, probs [B*H, Lq, ldp] bf16).  q/k/v are views into (fused) projection outputs."""
+            causal: bool = False, drop=None, flash: bool = False):
+    """-> (ctx [B*Lq, H*64] bf16, probs [B*H, Lq, ldp] bf16).  q/k/v are views into (fused) projection outputs.
+    flash=True (and MHA_FLASH): svsr_mha_flash_fwd — the second result is an MhaLse record (no probabilities are stored); hand it to mha_bwd."""
     ldp = probs_pitch(Lk)
     ctx = torch.empty((B * Lq, H * 64), dtype=BF16, device=q.device)
+    flops = 2.0 * B * H * Lq * Lk * 64 * (3 if pe is not None else 2)
+    if flash and MHA_FLASH:
+        lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
+        _call("svsr_mha_flash_fwd", _p(q), q_pitch, _p(k), _p(v), kv_pitch, _p(pe), 0 if pe is None else pe.stride(0), _p(bias_u), _p(bias_v),
+              _p(klen), int(causal), B, H, 64, Lq, Lk, ldp, 0.125, _p(ctx), H * 64, _p(lse), *_drop(drop), _stream(), label="k_mhaf_fwd", flops=flops)
+        return ctx, MhaLse(lse, ctx, klen, bool(causal), ldp)
     probs = torch.empty((B * H, Lq, ldp), dtype=BF16, device=q.device)
     _call("svsr_mha_fwd", _p(q), q_pitch, _p(k), _p(v), kv_pitch, _p(pe), 0 if pe is None else pe.stride(0), _p(bias_u), _p(bias_v),
           _p(klen), int(causal), B, H, 64, Lq, Lk, ldp, 0.125, _p(ctx), H * 64, _p(probs), *_drop(drop), _stream(),
-          label="k_mha_fwd", flops=2.0 * B * H * Lq * Lk * 64 * (3 if pe is not None else 2))
+          label="k_mha_fwd", flops=flops)
     return ctx, probs
 
 
 def mha_bwd(dctx, q, q_pitch: int, k, v, kv_pitch: int, probs, *, B: int, H: int, Lq: int, Lk: int, dq, dq_pitch: int, dk, dv,
             dkv_pitch: int, pe=None, bias_u=None, bias_v=None, drop=None):
-    """Writes dq/dk/dv (views with the given pitches).  Relative-position form returns (dq_ac, dq_bd, dpe) as well."""
-    ldp = probs.shape[-1]
-    ds = torch.empty_like(probs)
+    """Writes dq/dk/dv (views with the given pitches).  Relative-position form returns (dq_ac, dq_bd, dpe) as well.
+    probs: the forward's second result (the probabilities, or the MhaLse record of a flash forward)."""
     rel = pe is not None
     D = H * 64
     dq_ac = torch.empty((B * Lq, D), dtype=BF16, device=q.device) if rel else None
     dq_bd = torch.empty((B * Lq, D), dtype=BF16, device=q.device) if rel else None
     dpe = torch.empty((2 * Lq - 1, D), dtype=BF16, device=q.device) if rel else None
     pe_part = torch.empty((B, 2 * Lq - 1, D), dtype=torch.float32, device=q.device) if rel else None
+    flops = 2.0 * B * H * Lq * Lk * 64 * (7 if rel else 4)
+    if isinstance(probs, MhaLse):
+        rec = probs
+        ldp = rec.ldp
+        pbuf = torch.empty((B * H, Lq, ldp), dtype=BF16, device=q.device)       # workspace: P and dS of the query pass for the key / table passes
+        ds = torch.empty_like(pbuf)
+        nws = int(_lib.load().svsr_mha_flash_ws_bytes(H, Lq)) if rel else 0
+        ws = torch.empty(nws, dtype=torch.uint8, device=q.device) if nws else None
+        _call("svsr_mha_flash_bwd", _p(dctx), dctx.stride(0), _p(rec.ctx), rec.ctx.stride(0), _p(rec.lse), _p(q), q_pitch, _p(k), _p(v), kv_pitch,
+              _p(pe), 0 if pe is None else pe.stride(0), _p(bias_u), _p(bias_v), _p(rec.klen), int(rec.causal), _p(pbuf), _p(ds), B, H, 64, Lq, Lk, ldp,
+              0.125, _p(dq), dq_pitch, _p(dq_ac), _p(dq_bd), D, _p(dk), _p(dv), dkv_pitch, _p(dpe), D, _p(pe_part), _p(ws), nws, *_drop(drop), _stream(),
+              label="k_mhaf_bwd", flops=flops)
+        return dq_ac, dq_bd, dpe
+    ldp = probs.shape[-1]
+    ds = torch.empty_like(probs)
     _call("svsr_mha_bwd", _p(dctx), dctx.stride(0), _p(q), q_pitch, _p(k), _p(v), kv_pitch, _p(pe), 0 if pe is None else pe.stride(0),
           _p(bias_u), _p(bias_v), _p(probs), _p(ds), B, H, 64, Lq, Lk, ldp, 0.125, _p(dq), dq_pitch, _p(dq_ac), _p(dq_bd), D,
-          _p(dk), _p(dv), dkv_pitch, _p(dpe), D, _p(pe_part), *_drop(drop), _stream(), label="k_mha_bwd", flops=2.0 * B * H * Lq * Lk * 64 * (7 if rel else 4))
+          _p(dk), _p(dv), dkv_pitch, _p(dpe), D, _p(pe_part), *_drop(drop), _stream(), label="k_mha_bwd", flops=flops)
     return dq_ac, dq_bd, dpe
 
 

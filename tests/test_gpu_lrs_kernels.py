@@ -24,9 +24,11 @@ def _rel_err(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
-@pytest.mark.parametrize("B,H,T,lens", [(2, 2, 9, [9, 6]), (3, 3, 50, [50, 33, 41]), (2, 12, 150, [150, 97])])
-def test_rel_mha_fwd_bwd(B, H, T, lens):
-    """Conformer rel-pos attention (attention.py:191-278) on bf16-rounded inputs vs the oracle's closed form in fp32."""
+@pytest.mark.parametrize("flash", [False, True])
+@pytest.mark.parametrize("B,H,T,lens", [(2, 2, 9, [9, 6]), (3, 3, 50, [50, 33, 41]), (2, 12, 150, [150, 97]), (2, 2, 300, [300, 77])])
+def test_rel_mha_fwd_bwd(B, H, T, lens, flash):
+    """Conformer rel-pos attention (attention.py:191-278) on bf16-rounded inputs vs the oracle's closed form in fp32; flash: the streamed-key
+    kernels (mha_flash.h: online softmax, no stored probabilities; 300 frames = two workgroups of five query tiles per (clip, head))."""
     from syncvsr_amd import ops
     dev = _dev()
     D = H * 64
@@ -56,9 +58,14 @@ def test_rel_mha_fwd_bwd(B, H, T, lens):
 
     qkv_d, pe_d = qkv.to(dev), pe.to(dev)
     ctx, probs = ops.mha_fwd(qkv_d, 3 * D, qkv_d[:, D:], qkv_d[:, 2 * D:], 3 * D, B=B, H=H, Lq=T, Lk=T, pe=pe_d, bias_u=u.to(dev).contiguous(),
-                             bias_v=v.to(dev).contiguous(), klen=klen.to(dev))
+                             bias_v=v.to(dev).contiguous(), klen=klen.to(dev), flash=flash)
     assert _rel_err(ctx.float().cpu(), ctx_ref.detach()) < 1.5e-2
-    assert _rel_err(probs[:, :, :T].float().cpu().view(B, H, T, T), attn.detach()) < 1.5e-2
+    if flash:
+        assert isinstance(probs, ops.MhaLse)
+        lse_ref = torch.logsumexp(scores.masked_fill(~mask, -float("inf")), -1).detach()
+        assert _rel_err(probs.lse.cpu().view(B, H, T), lse_ref) < 2e-3
+    else:
+        assert _rel_err(probs[:, :, :T].float().cpu().view(B, H, T, T), attn.detach()) < 1.5e-2
     dqkv = torch.empty_like(qkv_d)
     dq_ac, dq_bd, dpe = ops.mha_bwd(dctx.to(dev), qkv_d, 3 * D, qkv_d[:, D:], qkv_d[:, 2 * D:], 3 * D, probs, B=B, H=H, Lq=T, Lk=T,
                                     dq=dqkv, dq_pitch=3 * D, dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, pe=pe_d,
@@ -72,8 +79,9 @@ def test_rel_mha_fwd_bwd(B, H, T, lens):
     assert _rel_err(dq_bd.float().sum(0).cpu(), vf.grad.flatten()) < 3e-2
 
 
-@pytest.mark.parametrize("causal,Lq,Lk", [(True, 7, 7), (False, 11, 40), (True, 41, 41), (False, 41, 150)])
-def test_plain_mha_fwd_bwd(causal, Lq, Lk):
+@pytest.mark.parametrize("flash", [False, True])
+@pytest.mark.parametrize("causal,Lq,Lk", [(True, 7, 7), (False, 11, 40), (True, 41, 41), (False, 41, 150), (True, 290, 290), (False, 70, 333)])
+def test_plain_mha_fwd_bwd(causal, Lq, Lk, flash):
     """Decoder self- (causal) and source- (key padding) attention, attention.py:38-108."""
     from syncvsr_amd import ops
     dev = _dev()
@@ -94,7 +102,7 @@ def test_plain_mha_fwd_bwd(causal, Lq, Lk):
     ctx_ref = torch.matmul(attn, kvf[:, :, 1].transpose(1, 2)).transpose(1, 2).reshape(B * Lq, D)
     ctx_ref.backward(dctx.float())
     q_d, kv_d = q.to(dev), kv.to(dev)
-    ctx, probs = ops.mha_fwd(q_d, D, kv_d, kv_d[:, D:], 2 * D, B=B, H=H, Lq=Lq, Lk=Lk, klen=None if klen is None else klen.to(dev), causal=causal)
+    ctx, probs = ops.mha_fwd(q_d, D, kv_d, kv_d[:, D:], 2 * D, B=B, H=H, Lq=Lq, Lk=Lk, klen=None if klen is None else klen.to(dev), causal=causal, flash=flash)
     assert _rel_err(ctx.float().cpu(), ctx_ref.detach()) < 1.5e-2
     dq = torch.empty_like(q_d)
     dkv = torch.empty_like(kv_d)
@@ -102,6 +110,37 @@ def test_plain_mha_fwd_bwd(causal, Lq, Lk):
                 dkv_pitch=2 * D)
     assert _rel_err(dq.float().cpu(), qf.grad.reshape(B * Lq, D)) < 2.5e-2
     assert _rel_err(dkv.float().cpu(), kvf.grad.reshape(B * Lk, 2 * D)) < 2.5e-2
+
+
+@pytest.mark.parametrize("rel", [True, False])
+def test_flash_attention_draws_the_same_dropout_masks_as_the_per_tile_kernels(rel):
+    """Attention dropout (attention.py:80) is decided by hash(seed, site, index into the [B*H][Lq][ldp] probability tensor) in both
+    implementations (the oracles replay exactly these masks): with dropout 0.3 the streamed-key kernels must reproduce the per-tile kernels'
+    outputs and gradients to bf16 rounding — a different mask would change ctx by O(1)."""
+    from syncvsr_amd import ops
+    dev = _dev()
+    B, H, T = 2, 3, 75
+    D = H * 64
+    qkv = _r(B * T, 3 * D, seed=1).to(BF).to(dev)
+    pe = _r(2 * T - 1, D, seed=2).to(BF).to(dev) if rel else None
+    u = _r(H, 64, seed=3, scale=0.5).to(dev).contiguous() if rel else None
+    v = _r(H, 64, seed=4, scale=0.5).to(dev).contiguous() if rel else None
+    dctx = _r(B * T, D, seed=5).to(BF).to(dev)
+    klen = torch.tensor([T, 40], dtype=torch.int32, device=dev)
+    seed = torch.tensor([777], dtype=torch.int32, device=dev)
+    drop = (seed, 5, 0.3)
+    res = {}
+    for flash in (False, True):
+        ctx, keep = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=T, Lk=T, pe=pe, bias_u=u, bias_v=v, klen=klen,
+                                causal=not rel, drop=drop, flash=flash)
+        dqkv = torch.zeros_like(qkv)
+        aux = ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, keep, B=B, H=H, Lq=T, Lk=T, dq=dqkv, dq_pitch=3 * D, dk=dqkv[:, D:],
+                          dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, pe=pe, bias_u=u, bias_v=v, drop=drop)
+        res[flash] = (ctx.float().cpu(), dqkv.float().cpu(), None if not rel else aux[2].float().cpu())
+    assert _rel_err(res[True][0], res[False][0]) < 1e-2
+    assert _rel_err(res[True][1], res[False][1]) < 2e-2
+    if rel:
+        assert _rel_err(res[True][2], res[False][2]) < 2e-2
 
 
 @pytest.mark.parametrize("B,T,D,K", [(2, 9, 128, 31), (3, 70, 128, 7), (2, 150, 768, 31)])
