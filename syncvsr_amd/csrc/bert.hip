@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const bf16_t* __restrict__ d
     for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
         float xh[LN_MAXV][8], gd[LN_MAXV][8];
+        u32x4 adv[LN_MAXV];           // the skip-path gradient: requested with the other operands, not behind the two row reductions
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const bf16_t* __restrict__ d
                 const int c0 = (i * 64 + lane) * 8;
                 const long o = ((long)row * D + c0) >> 3;
                 float fa[8], fr[8], fd[8];
+                if (addend != nullptr) adv[i] = reinterpret_cast<const u32x4*>(addend)[o];
                 unpack8(reinterpret_cast<const u32x4*>(a)[o], fa);
                 if (r != nullptr) unpack8(reinterpret_cast<const u32x4*>(r)[o], fr);
                 unpack8(reinterpret_cast<const u32x4*>(dy)[o], fd);
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const bf16_t* __restrict__ d
                 for (int k = 0; k < 8; ++k) o[k] = rs * __builtin_fmaf(-xh[i][k], m2, gd[i][k] - m1);
                 if (addend != nullptr) {       // pre-LN residual stream: grad(x) = grad through LN + grad of the skip path
                     float ad[8];
-                    unpack8(reinterpret_cast<const u32x4*>(addend)[((long)row * D + (i * 64 + lane) * 8) >> 3], ad);
+                    unpack8(adv[i], ad);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) o[k] += ad[k];
                 }
