@@ -1,21 +1,22 @@
 #!/usr/bin/env python
-"""Copies the summaries scripts/gpu_profiles_round4.sh left under gpurun_out/round4/ into profiles/round4_*, stamped with the commit they
-were measured at (run right after the gpurun call, with a clean work tree):   python scripts/collect_profiles.py"""
+"""Copies the summaries scripts/gpu_profiles.sh left under gpurun_out/roundN/ into profiles/roundN_* (N = $ROUND, default 5), stamped with the
+commit they were measured at (run right after the gpurun call, with a clean work tree):   python scripts/collect_profiles.py"""
 import json
 import os
 import shutil
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC, DST = os.path.join(ROOT, "gpurun_out", "round4"), os.path.join(ROOT, "profiles")
+RN = "round" + os.environ.get("ROUND", "5")
+SRC, DST = os.path.join(ROOT, "gpurun_out", RN), os.path.join(ROOT, "profiles")
 head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "syncvsr_amd", "bench.py", "include"], cwd=ROOT, capture_output=True, text=True).stdout.strip())
 stamp = f"{head}{' + uncommitted changes' if dirty else ''}"
-note = (f"# measured at commit {stamp} on one MI355X (gfx950) by scripts/gpu_profiles_round4.sh: rocprofv3, every launch in line (SVSR_SIDE_*=0)\n")
-for src, dst in (("lrw_kernel_stats.csv", "round4_lrw_kernel_stats.csv"), ("lrs_kernel_stats.csv", "round4_lrs_kernel_stats.csv")):
+note = (f"# measured at commit {stamp} on one MI355X (gfx950) by scripts/gpu_profiles.sh: rocprofv3, every launch in line (SVSR_SIDE_*=0)\n")
+for src, dst in (("lrw_kernel_stats.csv", RN + "_lrw_kernel_stats.csv"), ("lrs_kernel_stats.csv", RN + "_lrs_kernel_stats.csv")):
     with open(os.path.join(SRC, src)) as f, open(os.path.join(DST, dst), "w") as g:
         g.write(note + f.read())
-with open(os.path.join(SRC, "sq_stall_breakdown.txt")) as f, open(os.path.join(DST, "round4_sq_stall_breakdown.txt"), "w") as g:
+with open(os.path.join(SRC, "sq_stall_breakdown.txt")) as f, open(os.path.join(DST, RN + "_sq_stall_breakdown.txt"), "w") as g:
     g.write(note + "# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES;\n"
             "# fractions of SQ_WAVE_CYCLES: wait_any = parked on s_waitcnt/barrier, wait_inst = issue stall, active = issuing; lds_conf = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE\n" + f.read())
 META = {"commit": stamp, "tool": "rocprofv3 --pmc (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES) --kernel-trace",
@@ -23,11 +24,11 @@ META = {"commit": stamp, "tool": "rocprofv3 --pmc (separate passes: FETCH_SIZE |
 if os.path.exists(os.path.join(SRC, "pmc_lrs_per_kernel.json")):
     lrs = json.load(open(os.path.join(SRC, "pmc_lrs_per_kernel.json")))
     lrs["__meta__"] = dict(META, workload="LRS step (B = 16, one 160-frame bucket)")
-    json.dump(lrs, open(os.path.join(DST, "round4_pmc_lrs_per_kernel.json"), "w"), indent=1, sort_keys=True)
+    json.dump(lrs, open(os.path.join(DST, RN + "_pmc_lrs_per_kernel.json"), "w"), indent=1, sort_keys=True)
 rec = json.load(open(os.path.join(SRC, "pmc_per_kernel.json")))
 rec["__meta__"] = {"commit": stamp, "tool": "rocprofv3 --pmc (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES) --kernel-trace",
                    "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch; on gfx950 FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md §HBM): double it"}
-json.dump(rec, open(os.path.join(DST, "round4_pmc_per_kernel.json"), "w"), indent=1, sort_keys=True)
+json.dump(rec, open(os.path.join(DST, RN + "_pmc_per_kernel.json"), "w"), indent=1, sort_keys=True)
 line = open(os.path.join(SRC, "bench_lrw.json")).read().strip().splitlines()[-1]
 bench_line = json.loads(line)
 # the bench run on the GPU box read the PMC file committed BEFORE this profiling call: point roofline.traffic at the passes of this one
@@ -38,6 +39,6 @@ if "roofline" in bench_line:
     bench_line["roofline"]["traffic"] = _bench.pmc_traffic(bench_line["roofline"]["kernel"])
 if "roofline" in bench_line.get("lrs", {}):
     bench_line["lrs"]["roofline"]["traffic"] = _bench.pmc_traffic(bench_line["lrs"]["roofline"]["kernel"], lrs=True)
-open(os.path.join(DST, "round4_bench_line.json"), "w").write(json.dumps(bench_line) + "\n")
-open(os.path.join(DST, "round4_COMMIT"), "w").write(stamp + "\n")
-print("profiles/round4_* written for", stamp)
+open(os.path.join(DST, RN + "_bench_line.json"), "w").write(json.dumps(bench_line) + "\n")
+open(os.path.join(DST, RN + "_COMMIT"), "w").write(stamp + "\n")
+print(f"profiles/{RN}_* written for", stamp)

@@ -80,7 +80,8 @@ def _worker():
     out["covered"] = covered[0][0] == 0 and covered[-1][1] == st.numel and all(a[1] <= b[0] for a, b in zip(covered, covered[1:]))
     if comm == torch.bfloat16:
         # random gradients through the bf16 wire format against the hand-averaged definition: each rank's values are rounded to bf16 once
-        # (relative 2^-9), their sum is rounded once more: |result - (g0 + g1) / 2| <= 2^-8 (|g0| + |g1|) / 2 element by element (stated bound)
+        # (bf16 keeps 8 significant bits: unit roundoff 2^-8), their sum is rounded once more: |result - (g0 + g1) / 2| <= 2^-7 (|g0| + |g1|) / 2
+        # element by element (stated bound; measured 0.98 of it)
         gs = [torch.randn(st.numel, generator=torch.Generator().manual_seed(4242 + r)).to(dev) for r in range(world)]
         st.grad.copy_(gs[rank])
         ts.dp.begin_step()
@@ -88,7 +89,7 @@ def _worker():
         ts.dp.finish()
         torch.cuda.synchronize()
         mean = sum(gs) / world
-        bound = sum(g.abs() for g in gs) / world * 2.0 ** -8 + 1e-30
+        bound = sum(g.abs() for g in gs) / world * 2.0 ** -7 + 1e-30
         out["bf16_wire_max_err_over_bound"] = float(((st.grad - mean).abs() / bound).max())
     # -- training on this rank's shard
     mine = [t.to(dev) for t in _shard(batch, rank, world)]
@@ -183,7 +184,7 @@ def test_two_ranks_with_the_bf16_gradient_wire_format():
     every gradient element is rounded to 8 mantissa bits once per step (relative 2^-9 = 2e-3 per element, uncorrelated), which AdamW's
     normalisation passes on to the update — losses within 5e-3 relative (measured 1.0e-3 at the third step of this ill-conditioned 10-frame
     batch, whose fp32-vs-bf16 trajectories the oracle tests hold to 1e-2); a random gradient through the reducer stays within the stated
-    element-wise bound 2^-8 (|g0| + |g1|) / 2 of the hand average, and the
+    element-wise bound 2^-7 (|g0| + |g1|) / 2 of the hand average, and the
     two ranks still bit-identical to each other (they apply the same reduced gradient)."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
