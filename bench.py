@@ -496,6 +496,7 @@ def main() -> None:
         torch.cuda.set_stream(torch.cuda.default_stream())
         result["config"]["cu_split"] = {"side_cus": cu_split[0], "layout": cu_split[1], "main_cus": ops.stream_cus(trainer.main_stream)}
         model._side.stream = None          # the profiling legs below run unmasked
+
     if rank == 0:
         # ---- roofline leg: eager steps with HIP events around every contraction launch -----------------------------
         prof = TrainStep(model, cfg, use_graph=False, data_parallel=False)      # rank 0 alone: must not issue a collective

@@ -282,6 +282,18 @@ int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R,
 int svsr_ce_fwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt, int R, int V, float smoothing, float* loss, float* lse, float* row_loss, hipStream_t stream);
 int svsr_ce_bwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt, int R, int V, float smoothing, const float* lse, const float* gout, void* dlogits, int ldo, hipStream_t stream);
 
+/* ---- the SyncVSR audio-token head (audio_head.hip) ----------------------------------------------------------------------
+ * svsr_linear_ce_fwd: loss = F.cross_entropy((h W^T + bias).reshape(-1, V), tok) of lightning.py:168-171 as ONE contraction whose
+ * accumulators never leave the registers: h bf16 rows of pitch K (row r = hidden row (r / seq_T) * seq_S + seq_s0 + r % seq_T, or row r
+ * when seq_T = 0), W bf16 [G*V][K] (nn.Linear layout), bias fp32 [G*V] or null, tok int64 [R*G] (row r, group g -> tok[r*G + g]: the
+ * reference's logits.reshape(-1, V) order).  Writes lse [R*G], row_loss [R*G] (workspace) and *loss = their mean (fixed order).  A target
+ * outside [0, V) yields NaN.  svsr_linear_ce_ok: 1 when the shape is taken (V a multiple of 320 — both codecs —, K a multiple of 64 up to 576).
+ * svsr_linear_ce_bwd: the contraction again, then dlogits [R][G*V] bf16 = gout[0] / (R*G) * (softmax - onehot) for the projection's
+ * data- and weight-gradient launches (svsr_igemm_fwd on the transposed weight, svsr_igemm_wgrad): no logits tensor is ever stored. */
+int svsr_linear_ce_ok(int R, int K, int G, int V);
+int svsr_linear_ce_fwd(const void* h, const void* w, const float* bias, const int64_t* tok, int R, int K, int G, int V, int seq_S, int seq_s0, int seq_T, float* loss, float* lse, float* row_loss, hipStream_t stream);
+int svsr_linear_ce_bwd(const void* h, const void* w, const float* bias, const int64_t* tok, int R, int K, int G, int V, int seq_S, int seq_s0, int seq_T, const float* lse, const float* gout, void* dlogits, hipStream_t stream);
+
 /* top-1 / top-5 accuracy (lightning.py:177-183); out2 = {top1, top5}; rows2: [B][2] float workspace. */
 int svsr_topk_acc(const float* logits, const int64_t* labels, const float* soft_labels, int B, int C, float* out2, float* rows2, hipStream_t stream);
 

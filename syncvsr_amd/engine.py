@@ -93,9 +93,20 @@ class TrainStep:
             if use_graph:
                 raise ValueError("cu_split places eager launches on two masked streams; a captured HIP graph replays on its own queues")
             side_cus, layout = (cu_split if isinstance(cu_split, (tuple, list)) else (cu_split, "spread"))
-            main_bits, side_bits = ops.cu_split_masks(int(side_cus), str(layout))
-            self.main_stream = ops.create_masked_stream(main_bits)
-            model._side.stream = ops.create_masked_stream(side_bits)
+            if str(layout) == "reserve":
+                # asymmetric: the side stream is confined to `side_cus` compute units (the first side_cus / 8 of every XCD), the main stream stays
+                # unmasked — the remaining compute units are never held by a weight-gradient workgroup, so the main stream's small launches
+                # (statistics finalisers, column sums) always find a free one
+                if int(side_cus) % 8 != 0 or not 0 < int(side_cus) < ops.device_cus():
+                    raise ValueError("cu_split=(side_cus, 'reserve'): side_cus must be a multiple of 8 below the device's compute-unit count")
+                model._side.stream = ops.create_masked_stream(list(range(int(side_cus))))
+                # a CU-masked stream is a BLOCKING stream (hipExtStreamCreateWithCUMask takes no flags): it synchronises implicitly with the null
+                # stream, i.e. with torch's default stream — the step has to live on a non-blocking stream of its own or every launch serialises
+                self.main_stream = torch.cuda.Stream()
+            else:
+                main_bits, side_bits = ops.cu_split_masks(int(side_cus), str(layout))
+                self.main_stream = ops.create_masked_stream(main_bits)
+                model._side.stream = ops.create_masked_stream(side_bits)
         self.is_lrw = isinstance(model, TransformerLightningModule)
         if self.is_lrw:            # LRW/video/config/*.yaml: optim.optimizer / optim.scheduler / train.gradient_clip_val
             cfg = config or model.config

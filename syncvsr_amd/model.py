@@ -118,6 +118,10 @@ class TransformerLightningModule(nn.Module):
         self.is_train = False
         self.word_labels = int(bert.num_labels)
         self.lambda_audio = float(config.optim.lambda_audio)
+        # audio head as one contraction with the cross-entropy in its epilogue (csrc/audio_head.hip) whenever the shape is taken; keep_audio_logits
+        # additionally materialises logits_audio in `_last` (one extra projection launch, for inspection and the parity tests)
+        self.fused_audio_head = True
+        self.keep_audio_logits = False
         self.label_smoothing = float(config.train.label_smoothing)
         self.codec, self.audio_alignment, self.vq_groups, self.audio_vocab_size = audio_codec_dims(config.model.wav2vec.path)
         self.dim = hidden_dim(config)
@@ -1067,15 +1071,22 @@ class _LrwFunction(torch.autograd.Function):
         loss_c, lse_c = ops.ce_fwd(logits_c, C, lab_idx, lab_prob, B, C, model.label_smoothing)
         # audio head: rows s = 1..T, logits [B*T, A*G*V] == [B*T*A*G, V]
         NA = A * G * V
-        logits_a, _ = ops.linear_fwd(h, st.s16("audio_projection.weight"), st.p32("audio_projection.bias"), rows=B * T, K=D, N=NA,
-                                     x_pitch=D, seq=(S, 1, T))
         tok = audio_tokens.reshape(-1)
-        loss_a, lse_a = ops.ce_fwd(logits_a, V, tok, None, B * T * A * G, V, 0.0)
+        fused_head = model.fused_audio_head and ops.linear_ce_ok(B * T, D, A * G, V)
+        logits_a = None
+        if not fused_head or model.keep_audio_logits:     # (keep_audio_logits: the logits tensor for inspection / the parity tests; the loss below does not read it)
+            logits_a, _ = ops.linear_fwd(h, st.s16("audio_projection.weight"), st.p32("audio_projection.bias"), rows=B * T, K=D, N=NA,
+                                         x_pitch=D, seq=(S, 1, T))
+        if fused_head:
+            # projection + per-frame cross-entropy in one contraction, logits never stored (csrc/audio_head.hip)
+            loss_a, lse_a = ops.linear_ce_fwd(h, st.s16("audio_projection.weight"), st.p32("audio_projection.bias"), tok, B * T, D, A * G, V, seq=(S, 1, T))
+        else:
+            loss_a, lse_a = ops.ce_fwd(logits_a, V, tok, None, B * T * A * G, V, 0.0)
         acc = ops.topk_acc(logits_c, lab_idx, lab_prob)
         model._last = dict(logits_category=logits_c, logits_audio=logits_a, feats=feats, hidden=h)
         if need_grad:
-            tape["head"] = dict(h=h, logits_c=logits_c, lse_c=lse_c, lab_idx=lab_idx, lab_prob=lab_prob, logits_a=logits_a, lse_a=lse_a,
-                                tok=tok, dims=(B, T, D, S, A, G, V, C))
+            tape["head"] = dict(h=h, logits_c=logits_c, lse_c=lse_c, lab_idx=lab_idx, lab_prob=lab_prob, logits_a=None if fused_head else logits_a,
+                                lse_a=lse_a, tok=tok, dims=(B, T, D, S, A, G, V, C))
             ctx.tape = tape
             ctx.model = model
             ctx.st = st
@@ -1097,7 +1108,11 @@ class _LrwFunction(torch.autograd.Function):
         NA = A * G * V
         Cp = (C + 63) // 64 * 64
         dla = torch.empty((B * T, NA), dtype=BF16, device=dev)
-        ops.ce_bwd(th["logits_a"], V, th["tok"], None, B * T * A * G, V, 0.0, th["lse_a"], g_audio, dla, V)
+        if th["logits_a"] is None:        # fused head: the logits are recomputed, dla = g / (B T A G) * (softmax - onehot)
+            ops.linear_ce_bwd(th["h"], st.s16("audio_projection.weight"), st.p32("audio_projection.bias"), th["tok"], B * T, D, A * G, V, th["lse_a"],
+                              g_audio, dla, seq=(S, 1, T))
+        else:
+            ops.ce_bwd(th["logits_a"], V, th["tok"], None, B * T * A * G, V, 0.0, th["lse_a"], g_audio, dla, V)
         dlc = ops.zeros((B, Cp), BF16, dev)
         ops.ce_bwd(th["logits_c"], C, th["lab_idx"], th["lab_prob"], B, C, model.label_smoothing, th["lse_c"], g_cat, dlc, Cp)
         h = th["h"]

@@ -1121,6 +1121,31 @@ def ce_bwd(logits, ld: int, target_idx, target_prob, R: int, V: int, smoothing: 
           float(smoothing), _p(lse), _p(gout), _p(dlogits), ldo, _stream())
 
 
+def linear_ce_ok(R: int, K: int, G: int, V: int) -> bool:
+    """True when the fused projection + cross-entropy kernels (csrc/audio_head.hip) take this shape."""
+    return bool(_lib.load().svsr_linear_ce_ok(R, K, G, V))
+
+
+def linear_ce_fwd(h: torch.Tensor, w16: torch.Tensor, bias, tok: torch.Tensor, R: int, K: int, G: int, V: int, seq=None):
+    """-> (loss, lse [R*G]): mean cross-entropy of (h W^T + bias).reshape(-1, V) against tok, logits never stored (svsr_linear_ce_fwd).
+    seq = (S, s0, T): row r reads hidden row (r // T) * S + s0 + r % T."""
+    dev = h.device
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    lse = torch.empty(R * G, dtype=torch.float32, device=dev)
+    S, s0, T = seq if seq is not None else (0, 0, 0)
+    _call("svsr_linear_ce_fwd", _p(h), _p(w16), _p(bias), _p(tok), R, K, G, V, S, s0, T, _p(loss), _p(lse), _p(scratch(R * G)), _stream(),
+          label="k_linear_ce", flops=2.0 * R * K * G * V)
+    return loss, lse
+
+
+def linear_ce_bwd(h: torch.Tensor, w16: torch.Tensor, bias, tok: torch.Tensor, R: int, K: int, G: int, V: int, lse: torch.Tensor, gout: torch.Tensor,
+                  dlogits: torch.Tensor, seq=None) -> None:
+    """dlogits [R][G*V] bf16 = gout / (R*G) * (softmax - onehot), the logits recomputed (svsr_linear_ce_bwd)."""
+    S, s0, T = seq if seq is not None else (0, 0, 0)
+    _call("svsr_linear_ce_bwd", _p(h), _p(w16), _p(bias), _p(tok), R, K, G, V, S, s0, T, _p(lse), _p(gout), _p(dlogits), _stream(),
+          label="k_linear_ce", flops=2.0 * R * K * G * V)
+
+
 def topk_acc(logits_f32, labels, soft_labels) -> torch.Tensor:
     B, C = logits_f32.shape
     out = torch.empty(2, dtype=torch.float32, device=logits_f32.device)

@@ -580,6 +580,38 @@ def test_cross_entropy_and_topk(dev):
         assert abs(acc[1].item() - corr.float().amax(1).mean().item()) < 1e-6
 
 
+@pytest.mark.parametrize("R,K,G,V,seq", [(58, 512, 8, 320, (30, 1, 29)), (301, 576, 4, 640, None), (928, 512, 8, 320, (30, 1, 29)), (128, 64, 1, 320, None)])
+def test_fused_audio_head(dev, R, K, G, V, seq):
+    """svsr_linear_ce_fwd / _bwd (projection + per-frame cross-entropy in one contraction, logits never stored) against
+    F.cross_entropy((h W^T + b).reshape(-1, V), tok) in fp32 on the same bf16 inputs: loss and log-sum-exp to fp32 accuracy, dlogits to one
+    bf16 rounding; rows gathered like the model's (S, s0, T) view of the encoder output; a target outside [0, V) poisons the loss."""
+    from syncvsr_amd import ops
+
+    g = torch.Generator().manual_seed(R + V)
+    rows_h = R if seq is None else (R // seq[2]) * seq[0]
+    h = (torch.randn(rows_h, K, generator=g) * 0.8).to(BF)
+    w = (torch.randn(G * V, K, generator=g) / math.sqrt(K) * 2.0).to(BF)
+    b = torch.randn(G * V, generator=g) * 0.5
+    tok = torch.randint(0, V, (R * G,), generator=g)
+    gout = torch.tensor(0.37)
+    assert ops.linear_ce_ok(R, K, G, V)
+    hs = h.float() if seq is None else h.float().view(-1, seq[0], K)[:, seq[1]:seq[1] + seq[2]].reshape(R, K)
+    z = (hs @ w.float().t() + b).reshape(R * G, V).requires_grad_(True)
+    ref = F.cross_entropy(z, tok)
+    (ref * gout).backward()
+    loss, lse = ops.linear_ce_fwd(h.to(dev), w.to(dev), b.to(dev), tok.to(dev), R, K, G, V, seq=seq)
+    assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item()), (loss.item(), ref.item())
+    check(lse, torch.logsumexp(z.detach(), dim=1), "lse", max_tol=2e-5, l2_tol=1e-5)
+    dl = torch.full((R, G * V), float("nan"), dtype=BF, device=dev)
+    ops.linear_ce_bwd(h.to(dev), w.to(dev), b.to(dev), tok.to(dev), R, K, G, V, lse, gout.to(dev), dl, seq=seq)
+    check(dl.view(R * G, V), z.grad, "dlogits", max_tol=6e-3, l2_tol=4e-3)
+    bad = tok.clone()
+    bad[3] = V
+    loss_bad, _ = ops.linear_ce_fwd(h.to(dev), w.to(dev), b.to(dev), bad.to(dev), R, K, G, V, seq=seq)
+    assert torch.isnan(loss_bad).item()
+    assert not ops.linear_ce_ok(R, K, G, 100) and not ops.linear_ce_ok(R, 72, G, V)
+
+
 def test_adamw_clip_schedule(dev):
     from oracle import lrw_oracle as O
     from syncvsr_amd import ops

@@ -35,6 +35,7 @@ def _run_pair(name, dev):
 
     cfg, sd, batch, training, gold = build_case(name)
     model = Model(cfg)
+    model.keep_audio_logits = True          # logits_audio for the comparisons below (the loss itself comes from the fused audio head)
     missing, unexpected = model.load_state_dict(sd, strict=True)
     model.to(dev).train(training)
     gbatch = [t.to(dev) for t in batch]

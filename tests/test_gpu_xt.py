@@ -164,6 +164,7 @@ def _pair(dev, wb, depth, B, frames, size, skip, ff_drop, seed=3):
     sd = init_state_dict(cfg, seed=seed, perturb_norm=True)
     batch = synthetic_batch(cfg, B, frames=frames, size=size, seed=seed + 100)
     model = Model(cfg, seed=77)
+    model.keep_audio_logits = True
     model.load_state_dict(sd, strict=True)
     model.to(dev).train()
     model.layer_skip_override = set(skip)
