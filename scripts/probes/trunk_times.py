@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from syncvsr_amd import ops
 
+for _a in sys.argv[1:]:          # tuning knobs: key=value
+    _k, _v = _a.split("=")
+    ops.tune(_k, int(_v))
 dev = torch.device("cuda:0")
 BF16 = torch.bfloat16
 N = 928

@@ -569,6 +569,34 @@ static WgradUnits wgrad_units(const std::vector<long>& tap_chunks, int co_tiles,
     std::vector<int> order(nu);
     for (int i = 0; i < nu; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return w.units[a * WUNIT_WORDS + 2] > w.units[b * WUNIT_WORDS + 2]; });
+    if (svsr_tune_get(SVSR_TUNE_WG_XCD) && ntaps > 1) {
+        // Multi-tap plans (the 3 x 3 / stride-2 convolutions): the units of all taps and channel tiles that cover the same stretch of the
+        // contraction read the same rows of x and dy.  Workgroup b runs on XCD b % 8 (observed, never relied on for correctness), each XCD has
+        // its own L2, and in plain index order every XCD ends up streaming ALL rows: 289 MB of fabric traffic per layer3 launch for <= 58 MB of
+        // operands, next to which the main stream's HBM-bound BatchNorm passes ran three times slower.  So the units are dealt to eight queues
+        // by the eighth of their task's contraction they sit in, long units first inside a queue, and the queues are interleaved: XCD x then
+        // touches about one eighth of the rows.  The order of a task's slots — the order its partial tiles are added in — is untouched.
+        // Measured (round 5): FETCH_SIZE per launch 261 -> 155 MB (layer3 / layer4 3 x 3), 160 -> 97 MB (stride-2 / 1 x 1 plans); standalone weight
+        // gradient + reduce of layer3's 3 x 3 69.7 -> 48.4 us (565 -> 814 TFLOP/s), layer3.0.conv1 53.4 -> 39.0, layer2.0.conv1 70.3 -> 44.7, layer4
+        // unchanged; LRW step 5.00-5.02 -> 4.92-4.93 ms same box, LRS -0.1 ms.  Walking a queue's stretch in order instead of long-first, and
+        // dealing single-tap plans (1 x 1 convolutions, dense layers) the same way, measured no further change.
+        std::vector<std::vector<int>> q(8);
+        for (int i = 0; i < nu; ++i) {
+            const int u = order[i];
+            const int task = w.units[u * WUNIT_WORDS], cb = w.units[u * WUNIT_WORDS + 1], cn = w.units[u * WUNIT_WORDS + 2];
+            const long L = tap_chunks[task / tiles];
+            int x = (int)((8 * (2L * cb + cn)) / (2 * (L > 0 ? L : 1)));
+            q[x < 0 ? 0 : (x > 7 ? 7 : x)].push_back(u);
+        }
+        std::vector<int> dealt;
+        std::vector<size_t> at(8, 0);
+        for (bool any = true; any;) {
+            any = false;
+            for (int x = 0; x < 8; ++x)
+                if (at[x] < q[x].size()) { dealt.push_back(q[x][at[x]++]); any = true; }
+        }
+        order.swap(dealt);
+    }
     std::vector<int> sorted((size_t)nu * WUNIT_WORDS);
     for (int i = 0; i < nu; ++i) std::copy(w.units.begin() + order[i] * WUNIT_WORDS, w.units.begin() + (order[i] + 1) * WUNIT_WORDS, sorted.begin() + i * WUNIT_WORDS);
     w.units.swap(sorted);

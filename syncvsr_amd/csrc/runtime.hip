@@ -43,8 +43,9 @@ static int g_tune[SVSR_TUNE_N] = {
     /* WG_UNIT_MAX */ 48,      // ... longest unit in 64-row chunks before the list takes a further round of workgroups
     /* WG_UNIT_MIN */ 8,       // ... shortest unit worth a slab tile of its own
     /* IGEMM_KSPLIT128 */ 12,  // svsr_igemm_fwd: dense layers on <= 288 tiles of 128 x 64 with at least this many 64-deep K steps split K over two wave groups per workgroup (0: never)
+    /* WG_XCD */ 1,            // svsr_igemm_wgrad unit lists of multi-tap plans: units dealt to the eight XCDs by the stretch of the contraction they cover (0: plain long-first order); same results
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128", "wg_xcd"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 
