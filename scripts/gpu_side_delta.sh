@@ -4,10 +4,10 @@
 W=${WORKLOAD:-lrw}
 cd /tmp; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 for side in 1 0; do
-  rm -rf /tmp/pp$side; SVSR_SIDE_TRUNK=$side SVSR_SIDE_ENCODER=$side timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/pp$side -o l -- python $GRAFT_REPO_ROOT/bench.py --workload $W --no-cpu-baseline --no-lrs-leg --profile-steps 0 --steps 6 --warmup 2 --enqueue eager > /tmp/run$side.log 2>&1
+  rm -rf /tmp/pp$side; SVSR_SIDE_TRUNK=$side SVSR_SIDE_ENCODER=$side timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/pp$side -o l -- python $GRAFT_REPO_ROOT/bench.py --workload $W --no-cpu-baseline --no-lrs-leg --profile-steps 0 --steps ${STEPS:-6} --warmup 2 --enqueue eager > /tmp/run$side.log 2>&1
 done
 python - <<'PY'
-import csv, glob, collections, re
+import csv, glob, collections, re, os
 def load(d):
     f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
@@ -18,7 +18,7 @@ def load(d):
         agg[k][0] += 1; agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     return agg
 on, off = load('/tmp/pp1'), load('/tmp/pp0')
-steps = 9.0
+steps = float(os.environ.get("STEPS", "6")) + 3.0
 rows = []
 for k in on:
     if k in off and on[k][0] == off[k][0]:
