@@ -19,7 +19,7 @@ GROUPS = [
     ("stem (conv fwd, wgrad, BN+GELU+pool fwd, bwd, prep)", r"k_stem_"),
     ("layer1 k_conv3x3_c64", r"k_conv3x3_c64"),
     ("grouped weight gradients (encoder + heads)", r"k_igemm_wgrad_group|k_wgrad_group_table"),
-    ("encoder row passes, attention backward, losses", r"k_add_ln|k_mha_|k_bias_act|k_embed|k_ce_|k_topk|k_avgpool|k_ls_|k_scale|k_lincomb"),
+    ("encoder row passes, attention backward, fused audio head (k_linear_ce), losses", r"k_add_ln|k_mha_|k_bias_act|k_embed|k_ce_|k_linear_ce|k_topk|k_avgpool|k_ls_|k_scale|k_lincomb"),
     ("fixed-order column sums (k_colsum)", r"k_colsum"),
     ("optimiser + shadows", r"k_adamw|k_grad_sumsq|k_transpose|k_opt_advance|k_cast_bf16"),
 ]
