@@ -230,6 +230,10 @@ int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* g
 /* svsr_add_ln_bwd / svsr_bias_act_bwd WITHOUT their fixed-order reduction: the partial rows stay in `part` (a buffer of the caller's that must live until
  * it has added them with svsr_colsum_rows on a stream of its choice — parameter-gradient sums the backward chain never waits for) */
 int svsr_add_ln_bwd_partials(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd, void* ds, int R, int D, const void* addend, float* part, hipStream_t stream);
+/* svsr_add_ln_bwd_partials with a second output for the residual branch that ends in this sum (x' = x + alpha * dropout(branch), the LRS
+ * encoder / decoder layers, encoder_layer.py:93-150): ds2 = alpha2 * mask / (1 - p) * ds, computed from the bf16-rounded ds with the element
+ * indices svsr_scale_bf16 uses, i.e. bit for bit what svsr_scale_bf16(ds) would write (ds2 null: exactly svsr_add_ln_bwd_partials) */
+int svsr_add_ln_bwd_branch(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd, void* ds, int R, int D, const void* addend, float* part, void* ds2, float alpha2, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 int svsr_bias_act_bwd_partials(const void* dy, const void* z, void* dz, float* db, int R, int N, int n_valid, int ld, int act, float gscale, float* part, hipStream_t stream);
 
 /* BertEmbeddings on inputs_embeds = emb_dropout(cat(cls_token, feats)) (lightning.py:149-156):

@@ -59,8 +59,13 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const bf16_t* __restrict__ d
                                                     const bf16_t* __restrict__ r, const float* __restrict__ gamma,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     bf16_t* __restrict__ ds, float* __restrict__ part,
-                                                    int R, int D, const bf16_t* __restrict__ addend) {
+                                                    int R, int D, const bf16_t* __restrict__ addend,
+                                                    bf16_t* __restrict__ ds2, float alpha2, DropArgs drop2) {
+    // ds2 (optional): the gradient handed to the residual BRANCH that ends in this sum — x' = x + alpha2 * dropout(branch(..)) has
+    // d branch = alpha2 * mask / (1 - p) * d x' — written from the bf16-rounded ds exactly as svsr_scale_bf16 would compute it from ds
+    // (same element indices for the mask): the separate pass over [R][D] that the sentence-level model ran 60 times per step
     extern __shared__ float sred_dyn[];          // [4 waves][2][D]
+    const unsigned key2 = (ds2 != nullptr && drop2.seed != nullptr) ? drop_key(drop2) : 0u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // lane owns columns (i*64 + lane)*8 .. +7 for i < LN_MAXV; any D % 8 == 0 up to 2048 (512 BERT, 768 Conformer)
     float ag[LN_MAXV][8], ab[LN_MAXV][8];
@@ -110,7 +115,19 @@ __global__ __launch_bounds__(256) void k_add_ln_bwd(const bf16_t* __restrict__ d
 #pragma unroll
                     for (int k = 0; k < 8; ++k) o[k] += ad[k];
                 }
-                reinterpret_cast<u32x4*>(ds)[((long)row * D + (i * 64 + lane) * 8) >> 3] = pack8(o);
+                const long vi = ((long)row * D + (i * 64 + lane) * 8) >> 3;
+                const u32x4 packed = pack8(o);
+                reinterpret_cast<u32x4*>(ds)[vi] = packed;
+                if (ds2 != nullptr) {
+                    float f[8];
+                    unpack8(packed, f);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (drop2.seed != nullptr) f[k] = drop_keep(key2, drop2.thresh, (unsigned)(vi * 8 + k)) ? f[k] * drop2.scale : 0.f;
+                        f[k] *= alpha2;
+                    }
+                    reinterpret_cast<u32x4*>(ds2)[vi] = pack8(f);
+                }
             }
         }
     }
@@ -330,13 +347,19 @@ int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_
 
 /* the launch without its reduction: part [svsr_add_ln_bwd_rows(R)][2 * D] is left for the caller to add with svsr_colsum_rows(part, rows, 2 * D,
  * dgamma, D, dbeta, D, 1, 1.0f, any stream) — a parameter-gradient sum nothing in the backward chain waits for */
-int svsr_add_ln_bwd_partials(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd,
-                             void* ds, int R, int D, const void* addend, float* part, hipStream_t stream) {
+int svsr_add_ln_bwd_branch(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd,
+                           void* ds, int R, int D, const void* addend, float* part, void* ds2, float alpha2, const unsigned* drop_seed,
+                           unsigned drop_site, float drop_p, hipStream_t stream) {
     if (D % 8 != 0 || D > 512 * LN_MAXV || part == nullptr) return SVSR_ERR_ARG;
     const int grid = ln_bwd_grid(R);
     hipLaunchKernelGGL(k_add_ln_bwd, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), stream, (const bf16_t*)dy, (const bf16_t*)a, (const bf16_t*)r, gamma,
-                       mean, rstd, (bf16_t*)ds, part, R, D, (const bf16_t*)addend);
+                       mean, rstd, (bf16_t*)ds, part, R, D, (const bf16_t*)addend, (bf16_t*)ds2, alpha2, svsr_make_drop(drop_seed, drop_site, drop_p));
     return svsr_check_launch();
+}
+
+int svsr_add_ln_bwd_partials(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd,
+                             void* ds, int R, int D, const void* addend, float* part, hipStream_t stream) {
+    return svsr_add_ln_bwd_branch(dy, a, r, gamma, mean, rstd, ds, R, D, addend, part, nullptr, 1.0f, nullptr, 0, 0.f, stream);
 }
 
 int svsr_add_ln_bwd(const void* dy, const void* a, const void* r, const float* gamma, const float* mean, const float* rstd,

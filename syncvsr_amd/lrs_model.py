@@ -448,14 +448,27 @@ def _ln(st: _ParamStore, x, name: str):
     return ops.add_ln_fwd(x, None, st.p32(f"{name}.weight"), st.p32(f"{name}.bias"), LN_EPS)
 
 
-def _ln_bwd(model, st: _ParamStore, dy, x, name: str, m, r, addend=None):
+def _ln_bwd(model, st: _ParamStore, dy, x, name: str, m, r, addend=None, branch=None):
+    """LayerNorm backward (+ skip-path gradient `addend`) -> dx.  branch = (alpha, drop) of the residual branch whose sum x is: the launch
+    also writes that branch's gradient alpha * mask / (1 - p) * dx (what _branch_grad(dx, alpha, drop) would launch svsr_scale_bf16 for); the
+    result is then a _WithBranch that _branch_grad recognises."""
     # (the gamma / beta reduction is postponed to the side stream: model._defer_list, flushed by _ready at the end of the layer)
-    return ops.add_ln_bwd(dy, x, None, st.p32(f"{name}.weight"), m, r, st.g32(f"{name}.weight"), st.g32(f"{name}.bias"), addend=addend,
-                          defer=_defer_list(model))
+    dl = _defer_list(model)
+    fuse = branch is not None and (branch[0] != 1.0 or branch[1] is not None) and ops.LN_BRANCH_FUSED and dl is not None
+    out = ops.add_ln_bwd(dy, x, None, st.p32(f"{name}.weight"), m, r, st.g32(f"{name}.weight"), st.g32(f"{name}.bias"), addend=addend,
+                         defer=dl, branch=branch if fuse else None)
+    if fuse:
+        dx, dbr = out
+        dx._svsr_branch = (float(branch[0]), branch[1], dbr)          # (alpha, drop, gradient of the branch)
+        return dx
+    return out
 
 
 def _branch_grad(dy, alpha: float, drop):
     """x' = x + alpha * dropout(y)  ->  dL/dy = alpha * mask/(1-p) * dL/dx'  (the mask is regenerated from its site id)."""
+    pre = getattr(dy, "_svsr_branch", None)
+    if pre is not None and pre[0] == float(alpha) and pre[1] is drop:       # already written by the launch that produced dy (_ln_bwd)
+        return pre[2]
     return ops.scale_bf16(dy, alpha, drop=drop) if (alpha != 1.0 or drop is not None) else dy
 
 
@@ -468,14 +481,14 @@ def _ffn_fwd(model, st, t: dict, key: str, x, p: str, R: int, D: int, U: int, al
     return y
 
 
-def _ffn_bwd(model, st, t: dict, dy, p: str, R: int, D: int, U: int, alpha: float, norm: str):
-    """x' = x + alpha * dropout(FFN(LN(x))); dy = grad of x' -> grad of x."""
+def _ffn_bwd(model, st, t: dict, dy, p: str, R: int, D: int, U: int, alpha: float, norm: str, branch=None):
+    """x' = x + alpha * dropout(FFN(LN(x))); dy = grad of x' -> grad of x.  branch: (alpha, drop) of the branch in front (see _ln_bwd)."""
     dys = _branch_grad(dy, alpha, t["do"])
     dh = _lin_bwd(model, st, f"{p}.w_2", t["h"], dys, R, U, D)
     gs = 1.0 / (1.0 - t["dh"][2]) if t["dh"] is not None else 1.0           # dropped hidden units are the zeros of the saved h
     dz = ops.bias_act_bwd(dh, t["h"], st.g32(f"{p}.w_1.bias"), R=R, N=U, n_valid=U, ld=U, relu=True, gscale=gs, defer=_defer_list(model))
     dtn = _lin_bwd(model, st, f"{p}.w_1", t["tn"], dz, R, D, U, bias=False)
-    return _ln_bwd(model, st, dtn, t["x"], norm, t["m"], t["r"], addend=dy)
+    return _ln_bwd(model, st, dtn, t["x"], norm, t["m"], t["r"], addend=dy, branch=branch)
 
 
 def _encoder_layer_fwd(model: E2E, st: _ParamStore, tape: dict, i: int, x, pos16, ilen, B: int, T: int, training: bool):
@@ -518,8 +531,8 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
     p = f"encoder.encoders.{i}"
     t = tape[p]
     tf = t["final"]
-    dx4 = _ln_bwd(model, st, dxo, tf["x"], f"{p}.norm_final", tf["m"], tf["r"])
-    dx3 = _ffn_bwd(model, st, t["ff"], dx4, f"{p}.feed_forward", R, D, U, 0.5, f"{p}.norm_ff")
+    dx4 = _ln_bwd(model, st, dxo, tf["x"], f"{p}.norm_final", tf["m"], tf["r"], branch=(0.5, t["ff"]["do"]))
+    dx3 = _ffn_bwd(model, st, t["ff"], dx4, f"{p}.feed_forward", R, D, U, 0.5, f"{p}.norm_ff", branch=(1.0, t["conv"]["dco"]))
     # convolution module
     tc = t["conv"]
     cm, bn = f"{p}.conv_module", f"{p}.conv_module.norm"
@@ -540,7 +553,7 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
     du = ops.glu_dwconv_bwd(dc, tc["u"], st.p32(f"{cm}.depthwise_conv.weight"), st.g32(f"{cm}.depthwise_conv.weight"),
                             st.g32(f"{cm}.depthwise_conv.bias"), B, T, D, K)
     dt3 = _lin_bwd(model, st, f"{cm}.pointwise_cov1", tc["tn"], du, R, D, 2 * D)
-    dx2 = _ln_bwd(model, st, dt3, tc["x"], f"{p}.norm_conv", tc["m"], tc["r"], addend=dx3)
+    dx2 = _ln_bwd(model, st, dt3, tc["x"], f"{p}.norm_conv", tc["m"], tc["r"], addend=dx3, branch=(1.0, t["mha"]["dao"]))
     # attention
     tm = t["mha"]
     sa = f"{p}.self_attn"
@@ -556,7 +569,7 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
                     dq_ac, dq_bd, small=True)
     _lin_bwd(model, st, f"{sa}.linear_pos", pos16, dpe, 2 * T - 1, D, D, bias=False, need_dx=False)
     dt2 = _lin_bwd(model, st, f"{sa}.linear_q", tm["tn"], dqkv, R, D, 3 * D, tkey=f"{sa}.qkv")
-    dx1 = _ln_bwd(model, st, dt2, tm["x"], f"{p}.norm_mha", tm["m"], tm["r"], addend=dx2)
+    dx1 = _ln_bwd(model, st, dt2, tm["x"], f"{p}.norm_mha", tm["m"], tm["r"], addend=dx2, branch=(0.5, t["ffm"]["do"]))
     dx = _ffn_bwd(model, st, t["ffm"], dx1, f"{p}.feed_forward_macaron", R, D, U, 0.5, f"{p}.norm_ff_macaron")
     _ready(model, st, f"{p}.self_attn.linear_q.weight")
     return dx
@@ -607,12 +620,14 @@ def _decoder_bwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, dpred,
     L, Vp, V = to["L"], to["Vp"], model.odim
     R = B * L
     dtn = _lin_bwd(model, st, "decoder.output_layer", to["tn"], dpred, R, D, V, dy_pitch=Vp)
-    dx = _ln_bwd(model, st, dtn, to["x"], "decoder.after_norm", to["m"], to["r"])
+    # (every LayerNorm backward below also writes the gradient of the residual branch that follows it: _ln_bwd's `branch`)
+    dx = _ln_bwd(model, st, dtn, to["x"], "decoder.after_norm", to["m"], to["r"],
+                 branch=(1.0, tape[f"decoder.decoders.{model.dlayers - 1}"]["ff"]["do"]) if model.dlayers > 0 else None)
     _ready(model, st, "decoder.output_layer.weight")
     for i in reversed(range(model.dlayers)):
         p = f"decoder.decoders.{i}"
         t = tape[p]
-        dx2 = _ffn_bwd(model, st, t["ff"], dx, f"{p}.feed_forward", R, D, U, 1.0, f"{p}.norm3")
+        dx2 = _ffn_bwd(model, st, t["ff"], dx, f"{p}.feed_forward", R, D, U, 1.0, f"{p}.norm3", branch=(1.0, t["src"]["dao"]))
         ts = t["src"]
         dctx2 = _lin_bwd(model, st, f"{p}.src_attn.linear_out", ts["ctx"], _branch_grad(dx2, 1.0, ts["dao"]), R, D, D)
         dq = torch.empty_like(ts["q"])
@@ -621,15 +636,16 @@ def _decoder_bwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, dpred,
                     dv=dkv[:, D:], dkv_pitch=2 * D, drop=ts["dpr"])
         _lin_bwd(model, st, f"{p}.src_attn.linear_k", memory, dkv, B * T, D, 2 * D, tkey=f"{p}.src_attn.kv", addend=dmem, out=dmem)
         dt2 = _lin_bwd(model, st, f"{p}.src_attn.linear_q", ts["tn"], dq, R, D, D)
-        dx1 = _ln_bwd(model, st, dt2, ts["x"], f"{p}.norm2", ts["m"], ts["r"], addend=dx2)
         tsf = t["self"]
+        dx1 = _ln_bwd(model, st, dt2, ts["x"], f"{p}.norm2", ts["m"], ts["r"], addend=dx2, branch=(1.0, tsf["dao"]))
         dctx = _lin_bwd(model, st, f"{p}.self_attn.linear_out", tsf["ctx"], _branch_grad(dx1, 1.0, tsf["dao"]), R, D, D)
         qkv = tsf["qkv"]
         dqkv = torch.empty_like(qkv)
         ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, tsf["probs"], B=B, H=H, Lq=L, Lk=L, dq=dqkv, dq_pitch=3 * D,
                     dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, drop=tsf["dpr"])
         dt1 = _lin_bwd(model, st, f"{p}.self_attn.linear_q", tsf["tn"], dqkv, R, D, 3 * D, tkey=f"{p}.self_attn.qkv")
-        dx = _ln_bwd(model, st, dt1, tsf["x"], f"{p}.norm1", tsf["m"], tsf["r"], addend=dx1)
+        nxt = tape[f"decoder.decoders.{i - 1}"]["ff"]["do"] if i > 0 else tape["dec_embed_drop"]
+        dx = _ln_bwd(model, st, dt1, tsf["x"], f"{p}.norm1", tsf["m"], tsf["r"], addend=dx1, branch=(1.0, nxt))
         _ready(model, st, f"{p}.self_attn.linear_q.weight")
     ops.embed_pos_bwd(tg.ys_in, _branch_grad(dx, 1.0, tape["dec_embed_drop"]), st.g32("decoder.embed.0.weight"), D, math.sqrt(D))
     _ready(model, st, "decoder.embed.0.weight")

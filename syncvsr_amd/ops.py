@@ -126,6 +126,10 @@ def tune(key: str, value: int) -> None:
         global STEM_KEEP_WINNERS
         STEM_KEEP_WINNERS = bool(value)
         return
+    if key == "ln_branch_fused":
+        global LN_BRANCH_FUSED
+        LN_BRANCH_FUSED = bool(value)
+        return
     if key == "ctc_side":
         global CTC_SIDE
         CTC_SIDE = bool(value)
@@ -908,14 +912,26 @@ def colsum_rows(part, rows: int, ld: int, out0, n0: int, out1=None, n1: int = 0)
     _call("svsr_colsum_rows", _p(part), rows, ld, _p(out0), n0, _p(out1), n1, 1, 1.0, _stream())
 
 
-def add_ln_bwd(dy, a, r, gamma, mean, rstd, dgamma, dbeta, addend=None, out=None, defer: Optional[list] = None) -> torch.Tensor:
+LN_BRANCH_FUSED = True      # host-side knob "ln_branch_fused": a residual branch's gradient alpha * mask * dx as a second output of the LayerNorm backward in front of it (LRS layers); False: svsr_scale_bf16
+
+
+def add_ln_bwd(dy, a, r, gamma, mean, rstd, dgamma, dbeta, addend=None, out=None, defer: Optional[list] = None, branch=None):
     """defer = a list: the parameter-gradient reduction is not launched; a closure that launches it (on whatever stream is current when it
-    is called) is appended instead — the partial rows then live in a buffer of their own."""
+    is called) is appended instead — the partial rows then live in a buffer of their own.
+    branch = (alpha, drop) (with defer): additionally returns alpha * dropout_mask(ds) — the gradient of the residual branch that ends in this
+    sum, bit for bit what scale_bf16(ds, alpha, drop) would compute — as a second tensor: -> (ds, ds_branch)."""
     R, D = a.shape
     ds = torch.empty_like(a) if out is None else out
     if defer is not None:
         rows = _query("svsr_add_ln_bwd_rows", R)[0]
         part = torch.empty(rows * 2 * D, dtype=torch.float32, device=a.device)
+        if branch is not None:
+            alpha, drop = branch
+            ds2 = torch.empty_like(a)
+            _call("svsr_add_ln_bwd_branch", _p(dy), _p(a), _p(r), _p(gamma), _p(mean), _p(rstd), _p(ds), R, D, _p(addend), _p(part), _p(ds2), float(alpha),
+                  *_drop(drop), _stream())
+            defer.append((lambda: colsum_rows(part, rows, 2 * D, dgamma, D, dbeta, D), part))
+            return ds, ds2
         _call("svsr_add_ln_bwd_partials", _p(dy), _p(a), _p(r), _p(gamma), _p(mean), _p(rstd), _p(ds), R, D, _p(addend), _p(part), _stream())
         defer.append((lambda: colsum_rows(part, rows, 2 * D, dgamma, D, dbeta, D), part))
         return ds

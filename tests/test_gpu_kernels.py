@@ -716,8 +716,15 @@ def test_grouped_weight_gradients_replay_from_a_hip_graph(dev):
     """svsr_igemm_wgrad_group inside a captured HIP graph: the problem table travels as kernel arguments (by value in the graph's
     nodes), so a replay long after the host-side problem list is gone still computes the same thing — 20 problems = two table
     chunks.  (A host-to-device copy node of the table kept a pointer into freed host memory: the replay aborted.)"""
+    import os
+
     from syncvsr_amd import ops
 
+    if os.environ.get("SVSR_REDZONE") == "1":
+        # the red-zone allocator (tests/conftest.py) is a plain hipMalloc per tensor: an allocation inside a stream capture invalidates the
+        # capture (torch's caching allocator serves captures from a private pool instead).  The launch itself is covered under red zones by
+        # test_grouped_linear_weight_gradients_equal_separate_launches.
+        pytest.skip("HIP graph capture needs torch's caching allocator")
     g = torch.Generator().manual_seed(11)
     R, K, N = 928, 512, 2048
     xs = [(torch.randn((R, K), generator=g)).to(torch.bfloat16).to(dev) for _ in range(20)]

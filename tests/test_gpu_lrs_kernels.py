@@ -276,6 +276,20 @@ def test_ln768_pre_norm_and_relu_alpha_epilogues():
     assert _rel_err(dbias.cpu(), refdz.sum(0)) < 4e-3
     s = ops.scale_bf16(dyn.to(dev), 0.5)
     assert _rel_err(s.float().cpu(), dyn.float() * 0.5) < 1e-6
+    # the residual branch's gradient as a second output of the LayerNorm backward (svsr_add_ln_bwd_branch) == svsr_scale_bf16 of its first output,
+    # bit for bit, with and without a dropout mask; the first output and the parameter-gradient partials are those of the plain launch
+    seed = torch.tensor([12345], dtype=torch.int32, device=dev)
+    for alpha, drop in ((0.5, (seed, 77, 0.1)), (1.0, (seed, 5, 0.25)), (0.5, None)):
+        dg1, db1, dg2, db2 = (torch.zeros(D, device=dev) for _ in range(4))
+        d1, d2 = [], []
+        ds1 = ops.add_ln_bwd(dy.to(dev), x.to(dev), None, gam.to(dev), mean, rstd, dg1, db1, addend=skip.to(dev), defer=d1)
+        ds2, br = ops.add_ln_bwd(dy.to(dev), x.to(dev), None, gam.to(dev), mean, rstd, dg2, db2, addend=skip.to(dev), defer=d2, branch=(alpha, drop))
+        for fn, _ in d1 + d2:
+            fn()
+        assert torch.equal(ds1, ds2) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+        assert torch.equal(br, ops.scale_bf16(ds1, alpha, drop=drop))
+        if drop is not None:
+            assert 0.02 < float((br == 0).float().mean()) < 0.4
 
 
 @pytest.mark.parametrize("C,res", [(64, True), (768, False), (128, False)])
