@@ -19,7 +19,7 @@ static int g_tune[SVSR_TUNE_N] = {
     /* IGEMM_TILE   */ 0,      // 0 auto, 64 / 128: force the M tile of svsr_igemm_fwd
     /* IGEMM_M128   */ 8192,   // rows from which 128-row tiles are used
     /* WG_BLOCKS    */ 0,      // target workgroups of svsr_igemm_wgrad (0: built-in per tile size)
-    /* W3_BLOCKS    */ 512,    // target workgroups of svsr_conv3x3_wgrad: one round of two per CU (alone 512: 61 us, 448: 64, 288: 73; inside the step, on the side stream: 5.006 / 5.005 / 5.021 ms at 512 / 448 / 288 in round 5)
+    /* W3_BLOCKS    */ 512,    // target workgroups of svsr_conv3x3_wgrad in its 4-wave form: one round of two per CU; the 8-wave form (W3_WAVES) launches half of it, one per CU (inside the step, 8 waves: 4.874-4.878 / 4.885-4.888 / 4.977-4.986 / 4.943-4.968 ms at 512 / 384 / 640 / 768 in round 5)
     /* LN_RPB       */ 4,      // rows per workgroup of svsr_add_ln_bwd (one per wave: 16 -> 4 measured 6.00 -> 5.97 ms per LRW step)
     /* STEM_LDS_FWD */ 0,      // LDS-tiled stem BN+act+pool forward (measured slower)
     /* STEM_LDS_BWD */ 2,      // stem BN+act+pool backward: 0 plain, 1 LDS-tiled passes, 2 LDS-tiled apply pass + gather-form reduce pass (fastest)
@@ -44,8 +44,9 @@ static int g_tune[SVSR_TUNE_N] = {
     /* WG_UNIT_MIN */ 8,       // ... shortest unit worth a slab tile of its own
     /* IGEMM_KSPLIT128 */ 12,  // svsr_igemm_fwd: dense layers on <= 288 tiles of 128 x 64 with at least this many 64-deep K steps split K over two wave groups per workgroup (0: never)
     /* WG_XCD */ 1,            // svsr_igemm_wgrad unit lists of multi-tap plans: units dealt to the eight XCDs by the stretch of the contraction they cover (0: plain long-first order); same results
+    /* W3_WAVES */ 8,          // waves per workgroup of svsr_conv3x3_wgrad: 8 (one workgroup per CU, the two wave groups split the nine taps: half the slabs, 138 instead of 247 registers per wave) or 4 (two workgroups per CU, nine taps per wave).  Round 5, same box: layer1 launch + reduce 80.1 -> 71.6 us at 928 frames, LRW step 5.03-5.05 -> 4.97-4.99 ms, LRS 23.69 -> 23.58-23.61
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128", "wg_xcd"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128", "wg_xcd", "w3_waves"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 

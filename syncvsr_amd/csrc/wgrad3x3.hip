@@ -38,9 +38,9 @@ struct Wgrad3Args {
 // 128-byte rows each; k_wgrad3_reduce adds a task's slabs in split order (64 float4 groups x 4 slot lanes per block) and scatters the sum
 // into dW once.  Up to four convolutions of the same geometry can share a launch (blockIdx.z): the launch's workgroups are divided among
 // them, so each writes 1/n of the slabs of a launch of its own (grid.z = n; the shipped entry point launches n = 1).
-// (Measured and dropped: ONE 8-wave workgroup per CU whose two 4-wave groups take alternate chunks one barrier apart, accumulators merged
-// through LDS — half the slabs, but 94 vs 78 us per launch: a group's wait for its next chunk's rows, 2-3 us from HBM, stalls the shared
-// barrier for both groups, while two independent workgroups hide each other's waits.)
+// (Measured and dropped in round 4: ONE 8-wave workgroup per CU whose two 4-wave groups take alternate CHUNKS one barrier apart, accumulators
+// merged through LDS — half the slabs, but 94 vs 78 us per launch: a group's wait for its next chunk's rows, 2-3 us from HBM, stalls the shared
+// barrier for both groups.  The 8-wave form that is the default since round 5 splits the TAPS instead: both groups work on the same chunk.)
 struct Wgrad3Multi { const bf16_t* x[4]; const bf16_t* dy[4]; float* dw[4]; };
 #define W3_TILE_FLOATS (9 * 64 * 64)
 
@@ -69,44 +69,57 @@ __device__ __forceinline__ long w3_pixel(const Wgrad3Args& p, int q) {
     return ((long)n * p.H + (yp - 1)) * p.W + (xp - 1);
 }
 
-__global__ __launch_bounds__(256, 2) void k_wgrad3x3_halo(const Wgrad3Args p, const Wgrad3Multi m) {
+// NW = 4: four waves = the four 32 x 32 quadrants of the 64 x 64 tile, nine taps each (144 accumulator registers; two workgroups per CU).
+// NW = 8 (round 5): eight waves, one workgroup per CU — waves 0-3 take taps 0-4 of their quadrant, waves 4-7 taps 5-8: all eight waves work on
+// the SAME chunk (no merge of accumulators: different taps are different outputs), a workgroup covers twice the positions, so a launch writes
+// HALF the slabs, and a wave needs ~130 registers instead of 247 (two 4-wave workgroups held 496 of a SIMD's 512 registers).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_wgrad3x3_halo(const Wgrad3Args p, const Wgrad3Multi m) {
+    constexpr int NT = NW * 64, RPP = NT / 8;                    // threads; tile rows staged per pass of all threads
+    constexpr int YR = W3_CH / RPP, XRN = W3_MAXXR / RPP;        // dY / X rows per thread and chunk (4 / 6 or 2 / 3)
+    constexpr int TPW = NW == 4 ? 9 : 5;                         // taps per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sY = reinterpret_cast<bf16_t*>(smem_raw);            // [128][PITCH]
     bf16_t* sX = sY + W3_CH * W3_PITCH;                          // [XR][PITCH]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci_tiles = p.Ci >> 6;
     const int cot = blockIdx.y / ci_tiles, cit = blockIdx.y - cot * ci_tiles;
     const int co0 = cot * 64, ci0 = cit * 64;
-    const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+    const int wq = wave & 3, tap0 = NW == 4 ? 0 : (wave >> 2) * 5;
+    const int wco = (wq >> 1) * 32, wci = (wq & 1) * 32;
     const int chunk = tid & 7, r0 = tid >> 3;
     const bf16_t* gx = m.x[blockIdx.z];
     const bf16_t* gy = m.dy[blockIdx.z];
 
-    f32x16 acc[9];
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int shift[TPW];                                              // row shift of this wave's taps (kh * WP + kw); wave-uniform
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) { const int tt = tap0 + t < 9 ? tap0 + t : 8; shift[t] = (tt / 3) * p.WP + tt % 3; }
 
     const int c_begin = blockIdx.x * p.chunks_per_block;
     int c_end = c_begin + p.chunks_per_block;
     if (c_end > p.total_chunks) c_end = p.total_chunks;
 
-    u32x4 vy[4], vx[6];
+    u32x4 vy[YR], vx[XRN];
     unsigned ld_ok = 0;
     auto load_chunk = [&](int c) {
         const int q0 = c * W3_CH;
         ld_ok = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long pix = w3_pixel(p, q0 + r0 + 32 * i);
+        for (int i = 0; i < YR; ++i) {
+            const long pix = w3_pixel(p, q0 + r0 + RPP * i);
             const bool ok = pix >= 0;
             vy[i] = *reinterpret_cast<const u32x4*>(gy + (ok ? pix * p.Co + co0 + chunk * 8 : 0));
             ld_ok |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int rr = r0 + 32 * i;
+        for (int i = 0; i < XRN; ++i) {
+            const int rr = r0 + RPP * i;
             const long pix = rr < p.XR ? w3_pixel(p, q0 - (p.WP + 1) + rr) : -1;
             const bool ok = pix >= 0;
             vx[i] = *reinterpret_cast<const u32x4*>(gx + (ok ? pix * p.Ci + ci0 + chunk * 8 : 0));
@@ -115,15 +128,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_halo(const Wgrad3Args p, co
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < YR; ++i) {
             const bool ok = (ld_ok >> i) & 1u;
             u32x4 v = vy[i];
             v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-            *reinterpret_cast<u32x4*>(sY + (r0 + 32 * i) * W3_PITCH + chunk * 8) = v;
+            *reinterpret_cast<u32x4*>(sY + (r0 + RPP * i) * W3_PITCH + chunk * 8) = v;
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int rr = r0 + 32 * i;
+        for (int i = 0; i < XRN; ++i) {
+            const int rr = r0 + RPP * i;
             const bool ok = (ld_ok >> (8 + i)) & 1u;
             u32x4 v = vx[i];
             v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
@@ -141,34 +154,37 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3_halo(const Wgrad3Args p, co
         for (int ks = 0; ks < W3_CH / 16; ++ks) {
             const bf16x8 fa = w3_frag_T(sY, wco, ks * 16, lane);
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const bf16x8 fb = w3_frag_T(sX, wci, ks * 16 + kh * p.WP + kw, lane);
-                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[kh * 3 + kw], 0, 0, 0);
-                }
+            for (int t = 0; t < TPW; ++t) {
+                if (NW == 8 && t == TPW - 1 && tap0 + t >= 9) break;           // the second wave group has four taps (wave-uniform)
+                const bf16x8 fb = w3_frag_T(sX, wci, ks * 16 + shift[t], lane);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+            }
         }
     }
     if (p.splits > 1) {
         f32x4* dst = reinterpret_cast<f32x4*>(p.part + (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * W3_TILE_FLOATS);
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < TPW; ++t) {
+            if (tap0 + t >= 9) break;
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq)
-                dst[((t * 4 + wave) * 4 + rq) * 64 + lane] = f32x4{acc[t][rq * 4], acc[t][rq * 4 + 1], acc[t][rq * 4 + 2], acc[t][rq * 4 + 3]};
+                dst[(((tap0 + t) * 4 + wq) * 4 + rq) * 64 + lane] = f32x4{acc[t][rq * 4], acc[t][rq * 4 + 1], acc[t][rq * 4 + 2], acc[t][rq * 4 + 3]};
+        }
         return;
     }
     // single split: D[row = co][col = ci] added to dW directly (one writer per element)
     const int ci = ci0 + wci + (lane & 31);
     float* dwp = m.dw[blockIdx.z];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < TPW; ++t) {
+        if (tap0 + t >= 9) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float* d = dwp + ((long)co * 9 + t) * p.Ci + ci;
+            float* d = dwp + ((long)co * 9 + tap0 + t) * p.Ci + ci;
             *d += acc[t][r];
         }
+    }
 }
 
 // dW[co][t][ci] += sum over the splits (in split order) of a task's tiles.  grid (9 * 16 blocks of 64 float4 groups, tasks, problems)
@@ -208,8 +224,9 @@ static W3Plan w3_plan(int Nimg, int H, int W, int Ci, int Co, int nprob = 1) {
     const long qtot = (long)Nimg * (H + 2) * (W + 2);
     pl.total_chunks = (int)((qtot + W3_CH - 1) / W3_CH);
     pl.tasks = (Co / 64) * (Ci / 64);
-    int target_blocks = svsr_tune_get(SVSR_TUNE_W3_BLOCKS);      // one round of 2 workgroups per CU, shared by the problems of the launch
+    int target_blocks = svsr_tune_get(SVSR_TUNE_W3_BLOCKS);      // one round of 2 workgroups per CU (4-wave form) / 1 per CU (8-wave form), shared by the problems of the launch
     target_blocks = (target_blocks > 0 ? target_blocks : 512) / (nprob > 0 ? nprob : 1);
+    if (svsr_tune_get(SVSR_TUNE_W3_WAVES) == 8) target_blocks /= 2;
     int splits = (target_blocks + pl.tasks - 1) / pl.tasks;       // every split costs a slab written and re-read
     if (splits > pl.total_chunks) splits = pl.total_chunks;
     if (splits < 1) splits = 1;
@@ -249,10 +266,12 @@ static int w3_launch(const Wgrad3Args& a0, const Wgrad3Multi& m, int n, const W3
     const size_t lds = (size_t)(W3_CH + a.XR) * W3_PITCH * sizeof(bf16_t);
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3x3_halo), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3x3_halo<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3x3_halo<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set = lds;
     }
-    hipLaunchKernelGGL(k_wgrad3x3_halo, dim3(pl.splits, pl.tasks, n), dim3(256), lds, stream, a, m);
+    if (svsr_tune_get(SVSR_TUNE_W3_WAVES) == 8) hipLaunchKernelGGL(k_wgrad3x3_halo<8>, dim3(pl.splits, pl.tasks, n), dim3(512), lds, stream, a, m);
+    else hipLaunchKernelGGL(k_wgrad3x3_halo<4>, dim3(pl.splits, pl.tasks, n), dim3(256), lds, stream, a, m);
     int rc = svsr_check_launch();
     if (rc != SVSR_OK || pl.splits <= 1) return rc;
     hipLaunchKernelGGL(k_wgrad3_reduce, dim3(W3_TILE_FLOATS / 4 / 64, pl.tasks, n), dim3(256), 0, stream, (const float*)part, m, pl.splits, a.Ci, a.Ci >> 6);
