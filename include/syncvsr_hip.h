@@ -181,6 +181,14 @@ int svsr_stem_conv_fwd(const float* vid, const float* w, void* out, float* stats
 int svsr_stem_conv_wgrad_plan(int B, int T, int H, int W, int* splits, int64_t* part_floats);
 int svsr_stem_conv_wgrad(const float* vid, const void* dy, float* dw, int B, int T, int H, int W, int use_tr, float* part, int64_t part_floats, hipStream_t stream);
 
+/* The apply pass of svsr_stem_bn_act_pool_bwd and svsr_stem_conv_wgrad as ONE pass (autograd of lightning.py:49-54's stem3d[1..3] into
+ * stem3d[0].weight): the gradient of the convolution output is made tile by tile in LDS and contracted at once, never written.  Call
+ * svsr_stem_bn_act_pool_bwd first with dx = NULL and xwin / gpool given (it then runs its reduce pass and the finalisation only and
+ * leaves gpool and coef); x = the convolution output, amax / mean / rstd as there.  dw bit-identical to the two-launch form.
+ * svsr_stem_bwd_wgrad_ok: 1 when the shape is covered (else use the two launches). */
+int svsr_stem_bwd_wgrad_ok(int B, int T, int H, int W);
+int svsr_stem_bwd_wgrad(const float* vid, const void* gpool, const void* amax, const void* x, const float* mean, const float* rstd, const float* coef, float* dw, int B, int T, int H, int W, float* part, int64_t part_floats, hipStream_t stream);
+
 /* ---- BatchNorm / activation / pooling passes (norm_act.hip) ---------------------------------------------------
  * svsr_bn_finalize: train-mode statistics of nn.BatchNorm2d/3d (lightning.py:51; resnet.py:37,54,14): adds the nrows
  * partial rows part[nrows][2][C] written by the producing convolution in a fixed order (double accumulation), writes

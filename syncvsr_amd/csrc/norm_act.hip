@@ -920,6 +920,7 @@ int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x
     if (!stem_iter(it, C, Wc, Hc)) return SVSR_ERR_ARG;
     const size_t lds_b = (size_t)(STEM_BR / 2 + 1) * Wp * C * 3;
     const int nrows = svsr_stem_bn_act_pool_bwd_rows(N, Hc, Wc, C);
+    if (dx == nullptr && !(stem_bwd_uses_lds(Wp, C) && stem_bwd_gathers(Wc, Wp, C) && xwin != nullptr && gpool != nullptr)) return SVSR_ERR_ARG;
     if (stem_bwd_uses_lds(Wp, C)) {
         const dim3 g2((Hc + STEM_BR - 1) / STEM_BR, N);
 #define SVSR_STEM_BWD(A, AP) hipLaunchKernelGGL((k_stem_bwd_lds<A, AP>), g2, dim3(256), lds_b, stream, (const bf16_t*)dpool, (const unsigned char*)amax, \
@@ -936,6 +937,7 @@ int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x
                                    (bf16_t*)gpool, slots, Hp, Wp);
             hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(BNF_CL * BNF_RL), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
                                dgamma, dbeta, coef);
+            if (dx == nullptr) return svsr_check_launch();      // the apply pass runs inside svsr_stem_bwd_wgrad (stem.hip): gpool and coef are its inputs
             if (act == SVSR_ACT_SWISH)
                 hipLaunchKernelGGL((k_stem_bwd_lds<2, true, true>), g2, dim3(256), lds_b, stream, (const bf16_t*)gpool, (const unsigned char*)amax, (const bf16_t*)x,
                                    mean, rstd, gamma, beta, coef, (bf16_t*)dx, slots, Hc, Wc, Hp, Wp, C);

@@ -11,6 +11,7 @@
 #define STEM_WPITCH 296        // 288 + 8 pad: 592-byte rows -> conflict-free ds_read_b128 of B fragments
 
 typedef __attribute__((ext_vector_type(4))) unsigned v4u;
+typedef __attribute__((ext_vector_type(2))) unsigned v2u;
 
 struct StemFwdArgs {
     const float* vid;   // [B][T][H][W] fp32 (C = 1)
@@ -597,6 +598,261 @@ __global__ __launch_bounds__(256) void k_stem_conv_wgrad_pipe(const StemWgradArg
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// The stem's BatchNorm + activation + max-pool backward APPLY pass and the weight gradient as ONE pass (round 5): the gradient of the
+// convolution output was written (230 MB at 928 frames) by svsr_stem_bn_act_pool_bwd's apply launch and read back by k_stem_conv_wgrad_pipe
+// with nothing else on either stream — the step's last ~265 us.  Here a tile's four gradient rows are made where the contraction wants
+// them: the convolution output x takes the place of dY in the prefetch registers, the three pooled rows over the tile (g = dpool * act'
+// at the window winners, written by k_stem_bwd_reduce_win, and the arg-max bytes) go through LDS, and every thread turns its eight
+// 16-byte pieces of x into dY = coef0 * (sum of the windows this element won - coef1 - xhat * coef2) — norm_act.hip k_stem_bwd_lds<.,true,true>'s
+// arithmetic, operation for operation (same window order, same bf16 rounding) — straight into the dY tile.  Tile walk, MFMA order and
+// slabs are k_stem_conv_wgrad_pipe's, so dW is bit-identical to the two-launch form (tests/test_gpu_kernels.py).
+// ------------------------------------------------------------------------------------------------------------
+#define SBW_PR (SW_RB / 2 + 1)      // pooled rows whose windows reach a tile's SW_RB convolution rows (tiles start at even rows)
+#define SBW_NG 3                    // 16-byte (g) + 8-byte (arg-max) pieces of the pooled rows per thread: SBW_PR * Wp * 8 <= SBW_NG * 256
+
+struct StemBwdWgradArgs {
+    const float* vid;
+    const bf16_t* x;              // [B*T][Ho][Wo][64] convolution output (before BatchNorm)
+    const bf16_t* gpool;          // [B*T][Hp][Wp][64] dpool * act'(winner)
+    const unsigned char* amax;    // [B*T][Hp][Wp][64] window position of the winner, i * 3 + j
+    const float* mean;
+    const float* rstd;
+    const float* coef;            // [3][64]: gamma * rstd, mean(g), mean(g * xhat)
+    float* part;                  // slabs [gridDim.x][64*245]
+    int B, T, H, W, Ho, Wo, Hp, Wp;
+    int WoP, PW, groups_per_frame, total_tiles;
+};
+
+// NDY: 16-byte pieces of the x tile per thread, SW_RB * WoP * 8 <= NDY * 256; NIN: float4 pieces of the 65 input rows per thread,
+// 65 * (W / 4) <= NIN * 256 (6 and 6 for 88-wide clips: prefetch registers that are never used still count against the 256)
+template <int NDY, int NIN>
+__global__ __launch_bounds__(256, 2) void k_stem_bwd_wgrad(const StemBwdWgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int nrows = 2 * SW_RB + 5;
+    bf16_t* sDY = reinterpret_cast<bf16_t*>(smem_raw);                 // [SW_RB*WoP][SW_DPITCH]
+    bf16_t* sIn = sDY + SW_RB * p.WoP * SW_DPITCH;                     // [5][2*SW_RB+5][2][PW]
+    bf16_t* sG = sIn + 5 * nrows * 2 * p.PW;                           // [SBW_PR][Wp][64]
+    unsigned char* sM = reinterpret_cast<unsigned char*>(sG + SBW_PR * p.Wp * STEM_C);      // [SBW_PR][Wp][64]
+    float* sC = reinterpret_cast<float*>(sM + SBW_PR * p.Wp * STEM_C);                       // [5][64]: mean, rstd, coef[0..2]
+    const int tid_k = threadIdx.x, lane = tid_k & 63, wave = tid_k >> 6;
+    const int kg = lane >> 5;
+
+    int kbase[2];
+    bool kvalid[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = (wave * 2 + q) * 32 + (lane & 31);
+        kvalid[q] = k < 245;
+        const int kk = kvalid[q] ? k : 0;
+        const int kt = kk / 49, kh = (kk % 49) / 7, kw = kk % 7;
+        const int plane = (kw + 1) & 1, off = (kw + 1) >> 1;
+        kbase[q] = ((kt * nrows + kh) * 2 + plane) * p.PW + off + kg * 8;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    v4u xv[NDY], gv[SBW_NG];
+    v2u mv[SBW_NG];
+    f32x4 inv[NIN];
+    const int dy_total = SW_RB * p.WoP * 8, g_total = SBW_PR * p.Wp * 8;
+    const int nq = p.W >> 2, in_total = 5 * nrows * nq;      // input rows as float4 pieces, flat over (row, piece)
+    const float inv_nq = 1.f / (float)nq;
+    // the zero borders of the de-interleaved rows (plane dword 0 and dwords past W / 4) are written once; tiles only rewrite the pixels
+    for (int d = tid_k; d < 5 * nrows * p.PW; d += 256) reinterpret_cast<unsigned*>(sIn)[d] = 0u;
+    // a thread keeps its channel group (256 % 8 == 0); the BatchNorm constants of its eight channels are re-read from LDS for every tile's
+    // gradient pieces (held in registers across the contraction they cost 40 of a 256-register budget that two workgroups per CU allow)
+    if (tid_k < STEM_C) {
+        sC[0 * STEM_C + tid_k] = p.mean[tid_k]; sC[1 * STEM_C + tid_k] = p.rstd[tid_k];
+        sC[2 * STEM_C + tid_k] = p.coef[tid_k]; sC[3 * STEM_C + tid_k] = p.coef[STEM_C + tid_k]; sC[4 * STEM_C + tid_k] = p.coef[2 * STEM_C + tid_k];
+    }
+    const float inv_wop = 1.f / (float)p.WoP;       // tile row of a position: (pos + 0.5) / WoP is never within 0.007 of an integer
+
+    for (int tile = (int)blockIdx.x - (int)gridDim.x;; tile += gridDim.x) {
+        const int nxt = tile + (int)gridDim.x;
+        int rb = 0;
+        // (opaque per tile: the compiler otherwise keeps ~100 registers of tile-invariant piece offsets and predicates across the loop,
+        // in scratch memory at the 256 registers two workgroups per CU leave)
+        int tid = tid_k;
+        asm volatile("" : "+v"(tid));
+        const int c0 = (tid & 7) * 8;
+        if (tile >= 0) {
+            const int gi = tile % p.groups_per_frame, y0 = gi * SW_RB, p_lo = y0 >> 1;
+            rb = p.Ho - y0;
+            if (rb > SW_RB) rb = SW_RB;
+            __syncthreads();                 // everybody is done reading the previous tile
+#pragma unroll
+            for (int i = 0; i < NDY; ++i) {      // x for now (pad positions zero): every thread turns its own pieces into dY in place below
+                const int e = tid + 256 * i;
+                if (e < dy_total) *reinterpret_cast<v4u*>(sDY + (e >> 3) * SW_DPITCH + c0) = xv[i];
+            }
+#pragma unroll
+            for (int i = 0; i < SBW_NG; ++i) {
+                const int e = tid + 256 * i;
+                if (e < g_total) {
+                    *reinterpret_cast<v4u*>(sG + (e >> 3) * STEM_C + c0) = gv[i];
+                    *reinterpret_cast<v2u*>(sM + (e >> 3) * STEM_C + c0) = mv[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                const int it = tid + 256 * i, rr = (int)(((float)it + 0.5f) * inv_nq), l = it - rr * nq;
+                if (it < in_total) {         // pixels 4l..4l+3 -> even plane dword l + 1 = (x0, x2), odd plane dword l + 1 = (x1, x3)
+                    bf16_t* dst = sIn + (long)rr * 2 * p.PW;
+                    reinterpret_cast<unsigned*>(dst)[l + 1] = pack2bf(inv[i][0], inv[i][2]);
+                    reinterpret_cast<unsigned*>(dst + p.PW)[l + 1] = pack2bf(inv[i][1], inv[i][3]);
+                }
+            }
+            __syncthreads();                 // the pooled rows are in LDS
+            float mu[8], rs[8], k0[8], k1[8], k2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                mu[k] = sC[0 * STEM_C + c0 + k]; rs[k] = sC[1 * STEM_C + c0 + k];
+                k0[k] = sC[2 * STEM_C + c0 + k]; k1[k] = sC[3 * STEM_C + c0 + k]; k2[k] = sC[4 * STEM_C + c0 + k];
+            }
+            // A thread turns 2 x 2 blocks of positions (even row and column first) of its channel group into dY in place: the four pooled
+            // pixels whose windows reach the block are read and unpacked once (per element that was up to four reads each), and which window
+            // position an element holds in each is a compile-time constant: i * 3 + j with i = h - (2 ph - 1), j = w - (2 pw - 1).  Windows are
+            // added in k_stem_bwd_lds's order (ph_lo, pw_lo), (ph_lo, pw_hi), (ph_hi, pw_lo), (ph_hi, pw_hi); one that lies past the frame never
+            // matches (code 0xff, clamped address); a non-winner adds +0, which changes nothing (a sum here is never -0).
+            const int nbw = (p.Wo + 1) >> 1;
+#pragma unroll 1
+            for (int e = tid; e < (SW_RB / 2) * nbw * 8; e += 256) {
+                const int blk = e >> 3, rp = blk >= nbw ? 1 : 0, cp = blk - rp * nbw;        // (SW_RB / 2 == 2 row pairs)
+                if (2 * rp >= rb) continue;
+                const bool row1 = 2 * rp + 1 < rb, col1 = 2 * cp + 1 < p.Wo;
+                const bool ph1 = p_lo + rp + 1 < p.Hp, pw1 = cp + 1 < p.Wp;
+                const int soA = (rp * p.Wp + cp) * STEM_C + c0, soB = soA + (pw1 ? STEM_C : 0);
+                const int soC = soA + (ph1 ? p.Wp * STEM_C : 0), soD = soC + (pw1 ? STEM_C : 0);
+                const uint2 mA = *reinterpret_cast<const uint2*>(sM + soA), mB = *reinterpret_cast<const uint2*>(sM + soB);
+                const uint2 mC = *reinterpret_cast<const uint2*>(sM + soC), mD = *reinterpret_cast<const uint2*>(sM + soD);
+                float gA[8], gB[8], gC[8], gD[8];
+                unpack8(*reinterpret_cast<const u32x4*>(sG + soA), gA);
+                unpack8(*reinterpret_cast<const u32x4*>(sG + soB), gB);
+                unpack8(*reinterpret_cast<const u32x4*>(sG + soC), gC);
+                unpack8(*reinterpret_cast<const u32x4*>(sG + soD), gD);
+                const unsigned offB = pw1 ? 0u : 0xffu, offC = ph1 ? 0u : 0xffu, offD = (ph1 && pw1) ? 0u : 0xffu;      // | 0xff: never a stored code
+#define SBW_WIN(acc, m, g, code)                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                             \
+        acc[k] += (((m.x >> (8 * k)) & 0xffu) == (code)) ? g[k] : 0.f;                                          \
+        acc[k + 4] += (((m.y >> (8 * k)) & 0xffu) == (code)) ? g[k + 4] : 0.f;                                  \
+    }
+#define SBW_ELEM(dy_, dx_, BODY)                                                                                   \
+    {                                                                                                              \
+        bf16_t* cell = sDY + ((2 * rp + dy_) * p.WoP + 2 * cp + dx_) * SW_DPITCH + c0;                            \
+        float xf[8], a[8], ov[8];                                                                                  \
+        unpack8(*reinterpret_cast<const u32x4*>(cell), xf);                                                        \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) a[k] = 0.f;                                               \
+        BODY                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                         \
+            const float xh = (xf[k] - mu[k]) * rs[k];                                                              \
+            ov[k] = k0[k] * (a[k] - k1[k] - xh * k2[k]);                                                           \
+        }                                                                                                          \
+        *reinterpret_cast<u32x4*>(cell) = pack8(ov);                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }
+                SBW_ELEM(0, 0, SBW_WIN(a, mA, gA, 4u))
+                if (col1) SBW_ELEM(0, 1, SBW_WIN(a, mA, gA, 5u) SBW_WIN(a, mB, gB, 3u | offB))
+                if (row1) {
+                    SBW_ELEM(1, 0, SBW_WIN(a, mA, gA, 7u) SBW_WIN(a, mC, gC, 1u | offC))
+                    if (col1) SBW_ELEM(1, 1, SBW_WIN(a, mA, gA, 8u) SBW_WIN(a, mB, gB, 6u | offB) SBW_WIN(a, mC, gC, 2u | offC) SBW_WIN(a, mD, gD, 0u | offD))
+                }
+#undef SBW_ELEM
+#undef SBW_WIN
+            }
+            __syncthreads();
+        }
+        {
+        if (nxt < p.total_tiles) {
+            const int f = nxt / p.groups_per_frame, gi = nxt - f * p.groups_per_frame;
+            const int b = f / p.T, t = f - b * p.T;
+            const int y0 = gi * SW_RB, p_lo = y0 >> 1;
+            int rbn = p.Ho - y0;
+            if (rbn > SW_RB) rbn = SW_RB;
+            const int row_base = 2 * y0 - 3;
+#pragma unroll
+            for (int i = 0; i < NDY; ++i) {
+                const int e = tid + 256 * i, pos = e >> 3, yl = (int)(((float)pos + 0.5f) * inv_wop), w = pos - yl * p.WoP;
+                const bool ok = e < dy_total && yl < rbn && w < p.Wo;       // (no branch: the register arrays must not end up in scratch)
+                xv[i] = *reinterpret_cast<const v4u*>(ok ? p.x + (((long)f * p.Ho + y0 + yl) * p.Wo + w) * STEM_C + c0
+                                                           : reinterpret_cast<const bf16_t*>(g_stem_zero));
+            }
+            // the SBW_PR pooled rows from p_lo on are consecutive in memory; rows past the frame read as "no winner here"
+            const int g_live = (p.Hp - p_lo) * p.Wp * 8;
+#pragma unroll
+            for (int i = 0; i < SBW_NG; ++i) {
+                const int e = tid + 256 * i;
+                const bool ok = e < g_total && e < g_live;
+                const long o = (((long)f * p.Hp + p_lo) * p.Wp + (e >> 3)) * STEM_C + c0;
+                gv[i] = *reinterpret_cast<const v4u*>(ok ? p.gpool + o : reinterpret_cast<const bf16_t*>(g_stem_zero));
+                mv[i] = *reinterpret_cast<const v2u*>(ok ? p.amax + o : reinterpret_cast<const unsigned char*>(g_stem_zero));      // (never read: ph >= Hp is skipped)
+            }
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                const int it = tid + 256 * i, rr = (int)(((float)it + 0.5f) * inv_nq), l = it - rr * nq;
+                const int kt = rr / nrows, r = rr - kt * nrows;
+                const int tt = t + kt - 2, iy = row_base + r;
+                const bool ok = it < in_total && tt >= 0 && tt < p.T && iy >= 0 && iy < p.H;
+                inv[i] = *reinterpret_cast<const f32x4*>(ok ? p.vid + (((long)b * p.T + tt) * p.H + iy) * p.W + 4 * l
+                                                             : reinterpret_cast<const float*>(g_stem_zero));
+            }
+        }
+        }
+        if (tile < 0) {
+            if (nxt >= p.total_tiles) break;
+            continue;
+        }
+
+        for (int yl = 0; yl < rb; ++yl) {
+            for (int xs = 0; xs < p.WoP; xs += 16) {
+                const int pos0 = yl * p.WoP + xs;
+                bf16x8 fa[2], fb[2];
+                fa[0] = stem_frag_T<true>(sDY, 0, pos0, lane);
+                fa[1] = stem_frag_T<true>(sDY, 32, pos0, lane);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int a = kbase[q] + (2 * yl) * 2 * p.PW + xs;
+                    const unsigned* src = reinterpret_cast<const unsigned*>(sIn + (a & ~1));
+                    const unsigned sh = (a & 1) * 16;
+                    const unsigned d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3], d4 = src[4];
+                    u32x4 fr;
+                    fr.x = kvalid[q] ? __builtin_amdgcn_alignbit(d1, d0, sh) : 0u;
+                    fr.y = kvalid[q] ? __builtin_amdgcn_alignbit(d2, d1, sh) : 0u;
+                    fr.z = kvalid[q] ? __builtin_amdgcn_alignbit(d3, d2, sh) : 0u;
+                    fr.w = kvalid[q] ? __builtin_amdgcn_alignbit(d4, d3, sh) : 0u;
+                    fb[q] = __builtin_bit_cast(bf16x8, fr);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[q], acc[i][q], 0, 0, 0);
+            }
+        }
+        if (nxt >= p.total_tiles) break;
+    }
+    float* dst = p.part + (long)blockIdx.x * (STEM_C * 245);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = (wave * 2 + q) * 32 + (lane & 31);
+        if (k >= 245) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                dst[c * 245 + k] = acc[i][q][r];
+            }
+    }
+}
+
 extern "C" {
 
 static int stem_fwd_grid(int B, int T, int H, int W) {
@@ -703,6 +959,52 @@ int svsr_stem_conv_wgrad(const float* vid, const void* dy, float* dw, int B, int
         hipLaunchKernelGGL(k_stem_conv_wgrad_pipe<true>, dim3(grid), dim3(256), lds, stream, a);
     } else if (use_tr) hipLaunchKernelGGL(k_stem_conv_wgrad<true>, dim3(grid), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL(k_stem_conv_wgrad<false>, dim3(grid), dim3(256), lds, stream, a);
+    const int rc = svsr_check_launch();
+    if (rc != SVSR_OK) return rc;
+    return svsr_colsum_rows(part, grid, STEM_C * 245, dw, STEM_C * 245, nullptr, 0, 1, 1.0f, stream);
+}
+
+
+/* shapes the fused stem backward (BatchNorm/activation/pool apply + weight gradient in one pass) takes: 0 = call the two launches */
+static bool stem_bwd_wgrad_shape(int B, int T, int H, int W, StemBwdWgradArgs& a, size_t& lds) {
+    if ((H & 1) || (W & 3) || H < 8 || W < 8 || B < 1 || T < 1) return false;
+    a.B = B; a.T = T; a.H = H; a.W = W; a.Ho = H / 2; a.Wo = W / 2;
+    a.Hp = (a.Ho - 1) / 2 + 1; a.Wp = (a.Wo - 1) / 2 + 1;
+    a.WoP = (a.Wo + 15) / 16 * 16;
+    a.PW = a.WoP + 8;
+    a.groups_per_frame = (a.Ho + SW_RB - 1) / SW_RB;
+    a.total_tiles = a.groups_per_frame * B * T;
+    lds = (size_t)SW_RB * a.WoP * SW_DPITCH * 2 + (size_t)5 * (2 * SW_RB + 5) * 2 * a.PW * 2 + (size_t)SBW_PR * a.Wp * STEM_C * 3 + 5 * STEM_C * sizeof(float);
+    return a.PW / 2 <= 32 && SW_RB * a.WoP * 8 <= 8 * 256 && 5 * (2 * SW_RB + 5) * (W / 4) <= 8 * 256 && SBW_PR * a.Wp * 8 <= SBW_NG * 256 && lds <= 160 * 1024;
+}
+
+int svsr_stem_bwd_wgrad_ok(int B, int T, int H, int W) {
+    StemBwdWgradArgs a;
+    size_t lds;
+    return stem_bwd_wgrad_shape(B, T, H, W, a, lds) ? 1 : 0;
+}
+
+int svsr_stem_bwd_wgrad(const float* vid, const void* gpool, const void* amax, const void* x, const float* mean, const float* rstd,
+                        const float* coef, float* dw, int B, int T, int H, int W, float* part, int64_t part_floats, hipStream_t stream) {
+    StemBwdWgradArgs a;
+    size_t lds;
+    if (!stem_bwd_wgrad_shape(B, T, H, W, a, lds)) return SVSR_ERR_ARG;
+    const int grid = stem_wgrad_grid(B, T, H);
+    if (part == nullptr || part_floats < (int64_t)grid * STEM_C * 245) return SVSR_ERR_ARG;
+    a.vid = vid; a.x = (const bf16_t*)x; a.gpool = (const bf16_t*)gpool; a.amax = (const unsigned char*)amax;
+    a.mean = mean; a.rstd = rstd; a.coef = coef; a.part = part;
+    // prefetch-register variants: 88-wide clips need 6 + 6 pieces per thread, the general form holds 8 + 8
+    const int v = (SW_RB * a.WoP * 8 <= 6 * 256) ? ((5 * (2 * SW_RB + 5) * (W / 4) <= 6 * 256) ? 0 : 1) : 2;
+    const void* fn = v == 0 ? reinterpret_cast<const void*>(k_stem_bwd_wgrad<6, 6>)
+                   : v == 1 ? reinterpret_cast<const void*>(k_stem_bwd_wgrad<6, 8>) : reinterpret_cast<const void*>(k_stem_bwd_wgrad<8, 8>);
+    static size_t lds_set[3] = {0, 0, 0};
+    if (lds > lds_set[v]) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set[v] = lds;
+    }
+    if (v == 0) hipLaunchKernelGGL((k_stem_bwd_wgrad<6, 6>), dim3(grid), dim3(256), lds, stream, a);
+    else if (v == 1) hipLaunchKernelGGL((k_stem_bwd_wgrad<6, 8>), dim3(grid), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((k_stem_bwd_wgrad<8, 8>), dim3(grid), dim3(256), lds, stream, a);
     const int rc = svsr_check_launch();
     if (rc != SVSR_OK) return rc;
     return svsr_colsum_rows(part, grid, STEM_C * 245, dw, STEM_C * 245, nullptr, 0, 1, 1.0f, stream);

@@ -681,9 +681,20 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
         rec["stem"] = (dx.clone(), False)
     sc, sb = model.stem_name + ".0", model.stem_name + ".1"
     ws = st.bn[sb]
+    fused = ts.get("xwin") is not None and use_tr and ops.stem_bwd_wgrad_ok(ts["videos"])
     dconv = ops.stem_bn_gelu_pool_bwd(dx, ts["amax"], ts["c"], ts["mean"], ts["rstd"], st.p32(f"{sb}.weight"), st.p32(f"{sb}.bias"),
-                                      ws["coef"], st.g32(f"{sb}.weight"), st.g32(f"{sb}.bias"), model.stem_act, xwin=ts.get("xwin"))
-    ops.stem_conv_wgrad(ts["videos"], dconv, st.g32(f"{sc}.weight"), use_tr)
+                                      ws["coef"], st.g32(f"{sb}.weight"), st.g32(f"{sb}.bias"), model.stem_act, xwin=ts.get("xwin"),
+                                      want_dx=not fused)
+    if fused:
+        # The gradient of the convolution output is made tile by tile inside the weight-gradient pass, never written.  The side stream is
+        # joined FIRST: the pass is a persistent grid of two 248-register workgroups per CU, and beside the last trunk weight gradients
+        # (8-wave workgroups that leave no CU room for them) half its workgroups started late and the step LOST 0.02 / 0.4 ms (LRW / LRS);
+        # alone it is 223 us against 105 + 134 (928 frames) and the sentence-level step gains 0.2 ms.
+        _flush_deferred(model)
+        model._side.join()
+        ops.stem_bwd_wgrad(ts["videos"], dconv, ts["amax"], ts["c"], ts["mean"], ts["rstd"], ws["coef"], st.g32(f"{sc}.weight"))
+    else:
+        ops.stem_conv_wgrad(ts["videos"], dconv, st.g32(f"{sc}.weight"), use_tr)
     _flush_deferred(model)
     model._side.join()
     _ready(model, st, None)

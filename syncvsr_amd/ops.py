@@ -130,6 +130,10 @@ def tune(key: str, value: int) -> None:
         global LN_BRANCH_FUSED
         LN_BRANCH_FUSED = bool(value)
         return
+    if key == "stem_bwd_fused":
+        global STEM_BWD_FUSED
+        STEM_BWD_FUSED = bool(value)
+        return
     if key == "ctc_side":
         global CTC_SIDE
         CTC_SIDE = bool(value)
@@ -840,15 +844,35 @@ def stem_bn_gelu_pool_fwd(x: torch.Tensor, mean, rstd, gamma, beta, act: int = A
     return (y, amax, xwin) if want_win else (y, amax)
 
 
-def stem_bn_gelu_pool_bwd(dpool, amax, x, mean, rstd, gamma, beta, coef, dgamma, dbeta, act: int = ACT_GELU, xwin=None) -> torch.Tensor:
+def stem_bn_gelu_pool_bwd(dpool, amax, x, mean, rstd, gamma, beta, coef, dgamma, dbeta, act: int = ACT_GELU, xwin=None, want_dx: bool = True):
+    """-> dx (gradient of the stem convolution's output); with want_dx=False (needs xwin) -> gpool, and `coef` is left filled: the inputs of
+    stem_bwd_wgrad, which makes dx tile by tile inside the weight-gradient pass instead of writing it."""
     N, Hc, Wc, C = x.shape
     _, Hp, Wp, _ = dpool.shape
-    dx = torch.empty_like(x)
+    assert want_dx or xwin is not None
+    dx = torch.empty_like(x) if want_dx else None
     slots = scratch(_query("svsr_stem_bn_act_pool_bwd_rows", N, Hc, Wc, C)[0] * 2 * C)
     gpool = torch.empty_like(dpool) if xwin is not None else None
     _call("svsr_stem_bn_act_pool_bwd", _p(dpool), _p(amax), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slots), _p(coef),
           _p(dgamma), _p(dbeta), _p(dx), N, Hc, Wc, Hp, Wp, C, act, _p(xwin), _p(gpool), _stream())
-    return dx
+    return dx if want_dx else gpool
+
+
+STEM_BWD_FUSED = True        # the stem's backward apply pass inside its weight-gradient pass (svsr_stem_bwd_wgrad) where the shape allows
+
+
+def stem_bwd_wgrad_ok(videos: torch.Tensor) -> bool:
+    B, _, T, H, W = videos.shape
+    return bool(STEM_BWD_FUSED and _lib.load().svsr_stem_bwd_wgrad_ok(B, T, H, W))
+
+
+def stem_bwd_wgrad(videos: torch.Tensor, gpool, amax, x, mean, rstd, coef, dw: torch.Tensor) -> None:
+    """dw += the stem convolution's weight gradient, from the pooled-size gradient `gpool` (stem_bn_gelu_pool_bwd(want_dx=False)),
+    the window winners `amax`, the convolution output `x` and the finalised BatchNorm-backward coefficients `coef`."""
+    B, _, T, H, W = videos.shape
+    _, nfl = _query("svsr_stem_conv_wgrad_plan", B, T, H, W)
+    _call("svsr_stem_bwd_wgrad", _p(videos), _p(gpool), _p(amax), _p(x), _p(mean), _p(rstd), _p(coef), _p(dw), B, T, H, W, _p(scratch(nfl)), nfl,
+          _stream(), label="k_stem_bwd_wgrad", flops=2.0 * B * T * (H // 2) * (W // 2) * 64 * 245)
 
 
 # --------------------------------------------------------------------------------------------------

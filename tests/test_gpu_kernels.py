@@ -471,6 +471,36 @@ def test_stem_bn_gelu_pool(dev, Hc, Wc):
     check(db2, bt.grad, "stem.dbeta (winners)", 1e-2, 6e-3)
 
 
+@pytest.mark.parametrize("B,T,H,W,act", [(2, 5, 88, 88, 1), (1, 3, 44, 72, 2), (1, 2, 42, 40, 1), (3, 7, 96, 96, 2)])
+def test_stem_backward_apply_inside_the_weight_gradient(dev, B, T, H, W, act):
+    """svsr_stem_bwd_wgrad (BatchNorm / activation / max-pool backward apply pass fused into the stem convolution's weight gradient):
+    dW bit-identical to svsr_stem_bn_act_pool_bwd -> svsr_stem_conv_wgrad, dgamma / dbeta likewise; frame heights that leave a short
+    last tile (H/2 = 22, 21) and pooled rows past the frame, both activations."""
+    from syncvsr_amd import ops
+
+    C, Ho, Wo = 64, H // 2, W // 2
+    g = torch.Generator().manual_seed(1234 + H + W)
+    vid = torch.randn((B, 1, T, H, W), generator=g).to(dev)
+    x = (1.5 * torch.randn((B * T, Ho, Wo, C), generator=g)).to(torch.bfloat16).to(dev)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(dev); beta = (0.2 * torch.randn(C, generator=g)).to(dev)
+    xf = x.float()
+    m = xf.mean((0, 1, 2)); r = torch.rsqrt(xf.var((0, 1, 2), unbiased=False) + 1e-5)
+    y, amax, xwin = ops.stem_bn_gelu_pool_fwd(x, m, r, gamma, beta, act=act, want_win=True)
+    dpool = torch.randn(tuple(y.shape), generator=g).to(torch.bfloat16).to(dev)
+    assert ops.stem_bwd_wgrad_ok(vid)
+    coef = torch.empty(3 * C, device=dev); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+    dx = ops.stem_bn_gelu_pool_bwd(dpool, amax, x, m, r, gamma, beta, coef, dg, db, act=act, xwin=xwin)
+    dw = torch.zeros(64 * 245, device=dev)
+    ops.stem_conv_wgrad(vid, dx, dw, use_tr=True)
+    coef2 = torch.empty(3 * C, device=dev); dg2 = torch.zeros(C, device=dev); db2 = torch.zeros(C, device=dev)
+    gpool = ops.stem_bn_gelu_pool_bwd(dpool, amax, x, m, r, gamma, beta, coef2, dg2, db2, act=act, xwin=xwin, want_dx=False)
+    dw2 = torch.zeros(64 * 245, device=dev)
+    ops.stem_bwd_wgrad(vid, gpool, amax, x, m, r, coef2, dw2)
+    assert torch.equal(coef, coef2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    assert dw.abs().max().item() > 0
+    assert torch.equal(dw, dw2), f"fused stem backward: max |diff| {(dw - dw2).abs().max().item():.3e} of {dw.abs().max().item():.3e}"
+
+
 def test_avgpool(dev):
     from syncvsr_amd import ops
 
