@@ -313,6 +313,9 @@ int svsr_topk_acc(const float* logits, const int64_t* labels, const float* soft_
  * opt_state: device struct {int step; float sumsq; float lr_last; float gnorm_last; float part[1024]} (4112 bytes),
  * zero-initialised; svsr_grad_sumsq writes the 1024 partial sums of squares, svsr_adamw_step adds them in a fixed order. */
 int svsr_grad_sumsq(const float* g, int64_t n, void* opt_state, hipStream_t stream);
+/* one range of the gradient into partial sums [part0, part0 + nparts): a step's ranges cover the buffer and the 1024 partials once each
+ * (the clip of lightning's `gradient_clip_val` needs the whole norm; most of it can be summed before the last weight gradient is done) */
+int svsr_grad_sumsq_parts(const float* g, int64_t n, void* opt_state, int part0, int nparts, hipStream_t stream);
 int svsr_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, int64_t decay_end, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, int warmup, int total_steps, void* opt_state, hipStream_t stream);
 /* the same over one RANGE of the flat buffers (pointers offset by the caller, decay_end relative to the range); the step counter advances only
  * with advance != 0 — the last range of a step.  Lets a step update what the next forward needs first and the rest on another stream. */

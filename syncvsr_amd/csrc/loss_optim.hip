@@ -139,7 +139,7 @@ __device__ __forceinline__ float opt_sumsq(const OptState* st, float* s4) {
     return ((s4[0] + s4[1]) + s4[2]) + s4[3];
 }
 
-__global__ __launch_bounds__(256) void k_grad_sumsq(const float* __restrict__ g, long n, OptState* st) {
+__global__ __launch_bounds__(256) void k_grad_sumsq(const float* __restrict__ g, long n, OptState* st, int part0) {
     __shared__ float spart[4];
     float acc = 0.f;
     const long nv = n >> 2;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_grad_sumsq(const float* __restrict__ g,
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) spart[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) st->part[blockIdx.x] = ((spart[0] + spart[1]) + spart[2]) + spart[3];
+    if (threadIdx.x == 0) st->part[part0 + blockIdx.x] = ((spart[0] + spart[1]) + spart[2]) + spart[3];
 }
 
 struct AdamArgs {
@@ -427,7 +427,17 @@ int svsr_topk_acc(const float* logits, const int64_t* labels, const float* soft_
 
 int svsr_grad_sumsq(const float* g, int64_t n, void* opt_state, hipStream_t stream) {
     if (((uintptr_t)g & 15) != 0) return SVSR_ERR_ARG;
-    hipLaunchKernelGGL(k_grad_sumsq, dim3(OPT_PARTS), dim3(256), 0, stream, g, (long)n, (OptState*)opt_state);
+    hipLaunchKernelGGL(k_grad_sumsq, dim3(OPT_PARTS), dim3(256), 0, stream, g, (long)n, (OptState*)opt_state, 0);
+    return svsr_check_launch();
+}
+
+/* the sum of squares of one RANGE of the gradient into partial sums [part0, part0 + nparts) of the 1024: the ranges of a step together
+ * must cover the buffer once and the partial sums once.  engine.TrainStep sums everything behind the stem convolution's weight into
+ * partials 0..1022 on the side stream while the stem's weight gradient — the last one of the backward — is still being computed, and
+ * that weight into partial 1023 afterwards (the whole-buffer pass sat alone between the backward and AdamW: 23 us LRW, 164 us LRS). */
+int svsr_grad_sumsq_parts(const float* g, int64_t n, void* opt_state, int part0, int nparts, hipStream_t stream) {
+    if (((uintptr_t)g & 15) != 0 || part0 < 0 || nparts < 1 || part0 + nparts > OPT_PARTS || n < 0) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_grad_sumsq, dim3(nparts), dim3(256), 0, stream, g, (long)n, (OptState*)opt_state, part0);
     return svsr_check_launch();
 }
 

@@ -202,6 +202,9 @@ class TrainStep:
         runs, long before the backward's main-stream writers): the 128 MB (LRW) / 1 GB (LRS) fill leaves the main stream, where it sat in front
         of the backward (17 / 140 us).  The backward's own zero_grad() then finds `grad_clean` set and does nothing."""
         model = self.model
+        # no collective between the backward and the clip: the model may sum the squares of every gradient but the last while that one is
+        # computed (set per step: two TrainSteps may drive one model, each with its own optimiser state)
+        model._early_sumsq = self.opt_state if (self.dp is None and ops.EARLY_SUMSQ) else None
         if getattr(model, "accumulate_grads", False) or not ZERO_GRADS_EARLY:
             return
         model._side.run(lambda: ops.memset(st.grad, 0))
@@ -215,7 +218,15 @@ class TrainStep:
         HBM-bound pass runs beside the next step's stem / trunk forward.  The model joins the side stream before its encoder runs and
         before state_dict(); the step counter advances behind the last range."""
         model = self.model
-        ops.grad_sumsq(st.grad, self.opt_state)
+        model._early_sumsq = None        # (a backward outside a step must not write this optimiser's state)
+        if st.sumsq_head:
+            # two ranges, always the same two (one association whatever ran early): [head, n) -> partial sums 0..1022 — already summed on the
+            # side stream beside the stem's weight gradient when the model could (model._early_sumsq) — and the stem weight -> partial 1023
+            if not st.__dict__.pop("sumsq_tail_done", False):
+                ops.grad_sumsq_parts(st.grad, st.sumsq_head, st.numel - st.sumsq_head, self.opt_state, 0, ops.SUMSQ_PARTS - 1)
+            ops.grad_sumsq_parts(st.grad, 0, st.sumsq_head, self.opt_state, ops.SUMSQ_PARTS - 1, 1)
+        else:
+            ops.grad_sumsq(st.grad, self.opt_state)
         side = model._side
         hp = (self.lr, self.betas, self.eps, self.weight_decay, self.max_norm, self.warmup, self.total_steps, self.opt_state)
         if not (SPLIT_OPTIMIZER and side.enabled and st.front_end < st.decay_end):

@@ -414,6 +414,10 @@ class _ParamStore:
                 off = (off + 3) // 4 * 4
                 self.decay_end = off
         self.numel = (off + 3) // 4 * 4
+        # [0, sumsq_head): the stem convolution's weight, the LAST gradient of a backward pass: the global norm's sum of squares over everything
+        # behind it can run while that gradient is still being computed (engine.TrainStep._optimizer; 0: the buffer does not start with it)
+        first = (decay + nodecay)[0][0]
+        self.sumsq_head = self.offsets[first][1] if first == getattr(model, "stem_name", "?") + ".0.weight" and self.offsets[first][1] % 4 == 0 else 0
         # [0, front_end): the visual front-end's weights (forward ranks 0 and 1), what the next forward needs first (engine.TrainStep updates the
         # rest on the side stream beside that forward)
         later = [self.offsets[n][0] for n, s in decay if fwd_rank(n) >= 2]
@@ -692,6 +696,12 @@ def _frontend_backward(model, st: "_ParamStore", tape: dict, dfeats: torch.Tenso
         # alone it is 223 us against 105 + 134 (928 frames) and the sentence-level step gains 0.2 ms.
         _flush_deferred(model)
         model._side.join()
+        early = getattr(model, "_early_sumsq", None)      # the optimiser's device state, set by engine.TrainStep when no collective follows
+        if early is not None and st.sumsq_head:
+            # every gradient but the stem convolution's is final: their sum of squares (the global-norm clip's) runs beside that last pass
+            model._side.run(lambda: ops.grad_sumsq_parts(st.grad, st.sumsq_head, st.numel - st.sumsq_head, early, 0, ops.SUMSQ_PARTS - 1))
+            model._side.flush()
+            st.sumsq_tail_done = True
         ops.stem_bwd_wgrad(ts["videos"], dconv, ts["amax"], ts["c"], ts["mean"], ts["rstd"], ws["coef"], st.g32(f"{sc}.weight"))
     else:
         ops.stem_conv_wgrad(ts["videos"], dconv, st.g32(f"{sc}.weight"), use_tr)

@@ -130,6 +130,10 @@ def tune(key: str, value: int) -> None:
         global LN_BRANCH_FUSED
         LN_BRANCH_FUSED = bool(value)
         return
+    if key == "early_sumsq":
+        global EARLY_SUMSQ
+        EARLY_SUMSQ = bool(value)
+        return
     if key == "stem_bwd_fused":
         global STEM_BWD_FUSED
         STEM_BWD_FUSED = bool(value)
@@ -1195,6 +1199,16 @@ def topk_acc(logits_f32, labels, soft_labels) -> torch.Tensor:
 
 def grad_sumsq(g: torch.Tensor, opt_state: torch.Tensor) -> None:
     _call("svsr_grad_sumsq", _p(g), g.numel(), _p(opt_state), _stream())
+
+
+EARLY_SUMSQ = True      # host-side knob "early_sumsq": the clip's sum of squares over everything but the stem weight on the side stream beside the stem's weight gradient
+SUMSQ_PARTS = 1024      # partial sums of squares in the optimiser's device state (loss_optim.hip OPT_PARTS)
+
+
+def grad_sumsq_parts(g: torch.Tensor, start: int, n: int, opt_state: torch.Tensor, part0: int, nparts: int) -> None:
+    """sum of squares of g[start : start + n] into the partial sums [part0, part0 + nparts) (start a multiple of 4 floats)"""
+    assert start % 4 == 0
+    _call("svsr_grad_sumsq_parts", g.data_ptr() + 4 * start, n, _p(opt_state), part0, nparts, _stream())
 
 
 def adamw_step(p, g, m, v, shadow, decay_end: int, lr: float, betas, eps: float, weight_decay: float, max_norm: float, warmup: int,
