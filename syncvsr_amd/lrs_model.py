@@ -56,7 +56,9 @@ class _EncoderFacade(_Holder):
 
     def forward_one_step(self, xs: torch.Tensor, masks: Optional[torch.Tensor] = None, cache=None):
         """encoder.py:291-318 for cache=None: (xs, masks, per-layer outputs).  Incremental re-use of a cache is not implemented —
-        the reference's own inference path never passes one (lightning.py:100-101,114-118)."""
+        the reference's own inference path never passes one (lightning.py:100-101,114-118), and with the shipped rel_pos Conformer layers
+        the reference's method itself raises on its first call (it hands the layers' (x, pos_emb) tuple to after_norm, encoder.py:311-317;
+        checked against the imported reference): there is no reference behaviour for a cache to reproduce."""
         if cache is not None:
             raise NotImplementedError("Encoder.forward_one_step with a cache (streaming) is not implemented")
         owner = self._owner()
