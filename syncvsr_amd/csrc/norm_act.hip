@@ -629,6 +629,8 @@ __device__ unsigned g_stem_zero_page[64];
 // arg-max): per pooled output one activation derivative, g = dpool * act'(z), written out (bf16) for the apply pass, and the sums of g
 // and g * xhat over the values the apply pass will read back.  Streams 3 x 57 MB at B = 32 instead of re-reading the 230 MB
 // convolution output through LDS tiles (k_stem_bwd_reduce_gather).  Same grid and partial rows as the gather form.
+#define STEM_GPW 24      // pooled rows per workgroup of k_stem_bwd_reduce_win: a whole 22-row frame.  With STEM_GP (4) rows the pass wrote 5,568 (LRW) /
+                         // 15,360 (LRS) partial rows and the finaliser behind it — 16 workgroups on the step's critical path — took 26 / ~70 us to add them
 template <int ACT>
 __global__ __launch_bounds__(256) void k_stem_bwd_reduce_win(const bf16_t* __restrict__ dpool, const bf16_t* __restrict__ xwin,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -636,14 +638,14 @@ __global__ __launch_bounds__(256) void k_stem_bwd_reduce_win(const bf16_t* __res
                                                               bf16_t* __restrict__ gpool, float* __restrict__ slots, int Hp, int Wp) {
     constexpr int C = 64;
     __shared__ float sred[256 * 16];
-    const int tid = threadIdx.x, n = blockIdx.y, p0 = blockIdx.x * STEM_GP;
+    const int tid = threadIdx.x, n = blockIdx.y, p0 = blockIdx.x * STEM_GPW;
     const int c0 = (tid & 7) * 8;
     float mu[8], rs[8], ga[8], be[8], s1[8], s2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         mu[k] = mean[c0 + k]; rs[k] = rstd[c0 + k]; ga[k] = gamma[c0 + k]; be[k] = beta[c0 + k]; s1[k] = 0.f; s2[k] = 0.f;
     }
-    int rows = Hp - p0; if (rows > STEM_GP) rows = STEM_GP;
+    int rows = Hp - p0; if (rows > STEM_GPW) rows = STEM_GPW;
     const int pcv = Wp * 8;
     for (int v = tid; v < rows * pcv; v += 256) {               // 256 % 8 == 0: a thread keeps its channel group
         const int pr = v / pcv, pw = (v - pr * pcv) >> 3;
@@ -928,14 +930,15 @@ int svsr_stem_bn_act_pool_bwd(const void* dpool, const void* amax, const void* x
         if (stem_bwd_gathers(Wc, Wp, C) && xwin != nullptr && gpool != nullptr) {
             // winners kept by the forward: reduce pass over pooled outputs only, apply pass without activation derivatives
             if (Hp != (Hc - 1) / 2 + 1) return SVSR_ERR_ARG;
-            const dim3 gg((Hp + STEM_GP - 1) / STEM_GP, N);
+            const dim3 gg((Hp + STEM_GPW - 1) / STEM_GPW, N);
+            const int nrows_w = (int)(gg.x * gg.y);            // (<= nrows, the gather form's count the workspace is sized for)
             if (act == SVSR_ACT_SWISH)
                 hipLaunchKernelGGL(k_stem_bwd_reduce_win<2>, gg, dim3(256), 0, stream, (const bf16_t*)dpool, (const bf16_t*)xwin, mean, rstd, gamma, beta,
                                    (bf16_t*)gpool, slots, Hp, Wp);
             else
                 hipLaunchKernelGGL(k_stem_bwd_reduce_win<1>, gg, dim3(256), 0, stream, (const bf16_t*)dpool, (const bf16_t*)xwin, mean, rstd, gamma, beta,
                                    (bf16_t*)gpool, slots, Hp, Wp);
-            hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(BNF_CL * BNF_RL), 0, stream, slots, nrows, C, (float)((long)N * Hc * Wc), gamma, rstd,
+            hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + BNF_CL - 1) / BNF_CL), dim3(BNF_CL * BNF_RL), 0, stream, slots, nrows_w, C, (float)((long)N * Hc * Wc), gamma, rstd,
                                dgamma, dbeta, coef);
             if (dx == nullptr) return svsr_check_launch();      // the apply pass runs inside svsr_stem_bwd_wgrad (stem.hip): gpool and coef are its inputs
             if (act == SVSR_ACT_SWISH)
