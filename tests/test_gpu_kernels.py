@@ -671,6 +671,41 @@ def test_adamw_clip_schedule(dev):
     assert int(st[0]) == 3
 
 
+def test_grad_sumsq_in_ranges(dev):
+    """svsr_grad_sumsq_parts: the clip's sum of squares (Lightning's gradient_clip_val, lightning.py:216-223 via the Trainer) over two
+    ranges into disjoint partial sums — what engine.TrainStep runs (everything behind the stem weight early, the stem weight last).  The
+    norm AdamW then reads equals the fp64 norm of the whole buffer; a range with a ragged tail, partial sums of an earlier step overwritten."""
+    from syncvsr_amd import ops
+
+    g = torch.Generator().manual_seed(91)
+    n, head = 1_000_003, 15680
+    grad = (torch.randn(n, generator=g) * 0.3).to(dev)
+    state = torch.zeros(4 + 1024, dtype=torch.int32, device=dev)
+    state[4:] = torch.randn(1024, device=dev).view(torch.int32)           # stale partial sums
+    ops.grad_sumsq_parts(grad, head, n - head, state, 0, ops.SUMSQ_PARTS - 1)
+    ops.grad_sumsq_parts(grad, 0, head, state, ops.SUMSQ_PARTS - 1, 1)
+    parts = state[4:].view(torch.float32).double().cpu()
+    ref_tail = float((grad[head:].double() ** 2).sum()); ref_head = float((grad[:head].double() ** 2).sum())
+    assert abs(float(parts[:-1].sum()) - ref_tail) <= 2e-6 * ref_tail
+    assert abs(float(parts[-1]) - ref_head) <= 2e-6 * ref_head
+    # through AdamW: one step with a clip that bites; the update equals the single-launch form's up to the norm's last bits
+    p0 = torch.randn(n, generator=g).to(dev)
+    outs = []
+    for split in (True, False):
+        pd = p0.clone(); md = torch.zeros(n, device=dev); vd = torch.zeros(n, device=dev); sh = torch.zeros(n, dtype=BF, device=dev)
+        st = torch.zeros(4 + 1024, dtype=torch.int32, device=dev)
+        if split:
+            ops.grad_sumsq_parts(grad, head, n - head, st, 0, ops.SUMSQ_PARTS - 1)
+            ops.grad_sumsq_parts(grad, 0, head, st, ops.SUMSQ_PARTS - 1, 1)
+        else:
+            ops.grad_sumsq(grad, st)
+        ops.adamw_step(pd, grad, md, vd, sh, n, 1e-2, (0.9, 0.98), 1e-6, 0.03, 1.0, 0, 0, st)
+        outs.append(pd)
+    assert ((outs[0] - outs[1]).abs().max() / outs[1].abs().max()).item() <= 1e-6
+    with pytest.raises(Exception):
+        ops.grad_sumsq_parts(grad, 0, n, state, 1000, 100)                  # partial sums past the 1,024
+
+
 def test_grouped_linear_weight_gradients_equal_separate_launches(dev):
     """svsr_igemm_wgrad_group: the encoder's / heads' nn.Linear weight gradients of a backward pass as ONE launch (reference
     lightning.py:82,92,107 via autograd).  Same workgroup code, one writer per element: the results must EQUAL those of separate
