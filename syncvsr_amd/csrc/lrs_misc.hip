@@ -36,6 +36,9 @@ __device__ __forceinline__ void dw_stage_glu(float* sG, const bf16_t* __restrict
     }
 }
 
+// KT = 31 (the shipped cnn_module_kernel): a thread's DW_FPT frames need DW_FPT + 30 rows of its channel — read from LDS ONCE into registers
+// (38 reads instead of 248 / 496 one-word reads, the time of these kernels), then the same multiply-adds in the same order; KT = 0: any odd K <= 31
+template <int KT>
 __global__ __launch_bounds__(256) void k_glu_dwconv_fwd(const bf16_t* __restrict__ u, const float* __restrict__ w, const float* __restrict__ bias,
                                                         bf16_t* __restrict__ c, float* __restrict__ stats, int B, int T, int D, int K) {
     __shared__ float sG[(DW_TT + DW_MAXK - 1) * 64];
@@ -51,15 +54,32 @@ __global__ __launch_bounds__(256) void k_glu_dwconv_fwd(const bf16_t* __restrict
     for (int k = 0; k < DW_MAXK; ++k) wk[k] = k < K ? w[(long)(c0 + ch) * K + k] : 0.f;
     const float bs = bias[c0 + ch];
     float s1 = 0.f, s2 = 0.f;
-    for (int tl = tq * DW_FPT; tl < tq * DW_FPT + DW_FPT; ++tl) {
-        const int t = t0 + tl;
-        if (t >= T) break;
-        float acc = bs;
+    if (KT == DW_MAXK) {
+        float gr[DW_FPT + DW_MAXK - 1];
 #pragma unroll
-        for (int k = 0; k < DW_MAXK; ++k)
-            if (k < K) acc += wk[k] * sG[(tl + k) * 64 + ch];
-        c[((long)b * T + t) * D + c0 + ch] = f2bf(acc);
-        s1 += acc; s2 += acc * acc;
+        for (int j = 0; j < DW_FPT + DW_MAXK - 1; ++j) gr[j] = sG[(tq * DW_FPT + j) * 64 + ch];
+#pragma unroll
+        for (int i = 0; i < DW_FPT; ++i) {
+            const int t = t0 + tq * DW_FPT + i;
+            if (t < T) {
+                float acc = bs;
+#pragma unroll
+                for (int k = 0; k < DW_MAXK; ++k) acc += wk[k] * gr[i + k];
+                c[((long)b * T + t) * D + c0 + ch] = f2bf(acc);
+                s1 += acc; s2 += acc * acc;
+            }
+        }
+    } else {
+        for (int tl = tq * DW_FPT; tl < tq * DW_FPT + DW_FPT; ++tl) {
+            const int t = t0 + tl;
+            if (t >= T) break;
+            float acc = bs;
+#pragma unroll
+            for (int k = 0; k < DW_MAXK; ++k)
+                if (k < K) acc += wk[k] * sG[(tl + k) * 64 + ch];
+            c[((long)b * T + t) * D + c0 + ch] = f2bf(acc);
+            s1 += acc; s2 += acc * acc;
+        }
     }
     if (stats != nullptr) {
         sRed[tq][0][ch] = s1; sRed[tq][1][ch] = s2;
@@ -74,6 +94,7 @@ __global__ __launch_bounds__(256) void k_glu_dwconv_fwd(const bf16_t* __restrict
 }
 
 // backward: dc [B*T][D] -> du [B*T][2D]; per-block partial dw/dbias into part[split][D*(K+1)] (reduced by k_dw_reduce)
+template <int KT>
 __global__ __launch_bounds__(256) void k_glu_dwconv_bwd(const bf16_t* __restrict__ dc, const bf16_t* __restrict__ u, const float* __restrict__ w,
                                                         bf16_t* __restrict__ du, float* __restrict__ part, int B, int T, int D, int K, int ntt) {
     constexpr int STAGE_F = 2 * (DW_TT + DW_MAXK - 1) * 64, RED_F = 4 * (DW_MAXK + 1) * 64;       // staging (g, dc) / final reduction
@@ -112,20 +133,37 @@ __global__ __launch_bounds__(256) void k_glu_dwconv_bwd(const bf16_t* __restrict
             ua[i] = u[o];
             ug[i] = u[o + D];
         }
+        float gr[DW_FPT + DW_MAXK - 1], dcr[DW_FPT + DW_MAXK - 1];
+        if (KT == DW_MAXK) {
+#pragma unroll
+            for (int j = 0; j < DW_FPT + DW_MAXK - 1; ++j) {
+                gr[j] = sG[(tq * DW_FPT + j) * 64 + ch];
+                dcr[j] = sDC[(tq * DW_FPT + j) * 64 + ch];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < DW_FPT; ++i) {
             const int tl = tq * DW_FPT + i;
             const int t = t0 + tl;
             if (t >= T) continue;
             // c[t] = sum_k g[t+k-pad] w[k]  =>  dg[t] = sum_k dc[t-k+pad] w[k];  dw[k] += dc[t] g[t+k-pad]
-            const float dct = sDC[(tl + pad) * 64 + ch];
-            float dg = 0.f;
+            float dct, dg = 0.f;
+            if (KT == DW_MAXK) {
+                dct = dcr[i + (DW_MAXK - 1) / 2];
 #pragma unroll
-            for (int k = 0; k < DW_MAXK; ++k)
-                if (k < K) {
-                    dg += wk[k] * sDC[(tl + 2 * pad - k) * 64 + ch];
-                    dwk[k] += dct * sG[(tl + k) * 64 + ch];
+                for (int k = 0; k < DW_MAXK; ++k) {
+                    dg += wk[k] * dcr[i + (DW_MAXK - 1) - k];
+                    dwk[k] += dct * gr[i + k];
                 }
+            } else {
+                dct = sDC[(tl + pad) * 64 + ch];
+#pragma unroll
+                for (int k = 0; k < DW_MAXK; ++k)
+                    if (k < K) {
+                        dg += wk[k] * sDC[(tl + 2 * pad - k) * 64 + ch];
+                        dwk[k] += dct * sG[(tl + k) * 64 + ch];
+                    }
+            }
             dbs += dct;
             const long o = ((long)b * T + t) * (2 * D) + c0 + ch;
             const float av = bf2f(ua[i]), sg = sigmoid_fast(bf2f(ug[i]));
@@ -532,8 +570,12 @@ int svsr_glu_dwconv_fwd_stat_rows(int B, int T) { return (B < 1 || T < 1) ? 0 : 
 
 int svsr_glu_dwconv_fwd(const void* u, const float* w, const float* bias, void* c, float* stats, int B, int T, int D, int K, hipStream_t stream) {
     if (D % 64 != 0 || K < 1 || K > DW_MAXK || (K & 1) == 0) return SVSR_ERR_ARG;
-    hipLaunchKernelGGL(k_glu_dwconv_fwd, dim3((T + DW_TT - 1) / DW_TT, D / 64, B), dim3(256), 0, stream, (const bf16_t*)u, w, bias, (bf16_t*)c,
-                       stats, B, T, D, K);
+    if (K == DW_MAXK)
+        hipLaunchKernelGGL(k_glu_dwconv_fwd<DW_MAXK>, dim3((T + DW_TT - 1) / DW_TT, D / 64, B), dim3(256), 0, stream, (const bf16_t*)u, w, bias, (bf16_t*)c,
+                           stats, B, T, D, K);
+    else
+        hipLaunchKernelGGL(k_glu_dwconv_fwd<0>, dim3((T + DW_TT - 1) / DW_TT, D / 64, B), dim3(256), 0, stream, (const bf16_t*)u, w, bias, (bf16_t*)c,
+                           stats, B, T, D, K);
     return svsr_check_launch();
 }
 
@@ -543,8 +585,12 @@ int svsr_glu_dwconv_bwd(const void* dc, const void* u, const float* w, void* du,
     if (D % 64 != 0 || K < 1 || K > DW_MAXK || (K & 1) == 0 || nsplit < 1) return SVSR_ERR_ARG;
     const int ntt = (T + DW_TT - 1) / DW_TT;
     if (nsplit > B * ntt) nsplit = B * ntt;
-    hipLaunchKernelGGL(k_glu_dwconv_bwd, dim3(D / 64, nsplit), dim3(256), 0, stream, (const bf16_t*)dc, (const bf16_t*)u, w, (bf16_t*)du, part,
-                       B, T, D, K, ntt);
+    if (K == DW_MAXK)
+        hipLaunchKernelGGL(k_glu_dwconv_bwd<DW_MAXK>, dim3(D / 64, nsplit), dim3(256), 0, stream, (const bf16_t*)dc, (const bf16_t*)u, w, (bf16_t*)du, part,
+                           B, T, D, K, ntt);
+    else
+        hipLaunchKernelGGL(k_glu_dwconv_bwd<0>, dim3(D / 64, nsplit), dim3(256), 0, stream, (const bf16_t*)dc, (const bf16_t*)u, w, (bf16_t*)du, part,
+                           B, T, D, K, ntt);
     hipLaunchKernelGGL(k_dw_reduce, dim3(grid1d((long)D * (K + 1), 256)), dim3(256), 0, stream, part, nsplit, D, K, dw, dbias);
     return svsr_check_launch();
 }
