@@ -425,6 +425,10 @@ int svsr_ctc_prefix_score(const float* logp, int ldp, const float* r_prev, const
 
 /* Decoder input: x[r] = emb[tok[r]] * scale + pe[r % L]  (torch.nn.Embedding + PositionalEncoding, decoder.py:80-84,
  * embedding.py:78-89); backward scatter-adds scale * dx into demb. */
+/* add_sos_eos (reference add_sos_eos.py:10-31, e2e_asr_transformer.py:203-215) + the CTC label form, one launch: label [B][L] int64 padded with
+ * ignore_id at the tail -> labels [B][L] (-1 padded), ys_in / ys_out [B][L+1] (sos = eos; ys_out padded with ignore_id).  A token outside
+ * [1, odim) or padding that is not a tail traps the device, like torch's device-side assert in Embedding / CTCLoss. */
+int svsr_lrs_targets(const int64_t* label, int B, int L, int odim, int64_t ignore_id, int64_t eos, int64_t* labels, int64_t* ys_in, int64_t* ys_out, hipStream_t stream);
 int svsr_embed_pos_fwd(const int64_t* tok, const float* emb, const float* pe, void* x, int R, int L, int D, float scale, hipStream_t stream);
 int svsr_embed_pos_bwd(const int64_t* tok, const void* dx, float* demb, int R, int D, float scale, hipStream_t stream);
 

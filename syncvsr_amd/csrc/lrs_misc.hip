@@ -357,6 +357,40 @@ __global__ __launch_bounds__(256) void k_ctc_grad(const float* __restrict__ z, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Decoder / CTC targets of a batch from its padded labels — add_sos_eos (reference espnet/nets/pytorch_backend/transformer/add_sos_eos.py:10-31
+// as called by e2e_asr_transformer.py:203-215) in ONE launch; as torch index operations it was ~20 small launches per step on the step's
+// stream (0.12-0.15 ms of the sentence-level step).  label [B][L] int64, ignore_id at the tail:
+//   labels[b][l] = label or -1 (CTC);  ys_in[b] = [eos, label.., eos pad];  ys_out[b] = [label.., eos, ignore_id pad]
+// A token outside [1, odim) or padding that is not a tail is what torch's Embedding / CTCLoss would trap on with a device assert: same here.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lrs_targets(const long* __restrict__ label, int L, int odim, long ignore_id, long eos,
+                                                     long* __restrict__ labels, long* __restrict__ ys_in, long* __restrict__ ys_out) {
+    __shared__ int s_n, s_bad;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) { s_n = 0; s_bad = 0; }
+    __syncthreads();
+    int cnt = 0;
+    for (int l = threadIdx.x; l < L; l += 256) cnt += label[(long)b * L + l] != ignore_id ? 1 : 0;
+    if (cnt) atomicAdd(&s_n, cnt);              // (an integer count: the order of the additions does not matter)
+    __syncthreads();
+    const int n = s_n;
+    for (int l = threadIdx.x; l < L; l += 256) {
+        const long v = label[(long)b * L + l];
+        const bool live = v != ignore_id;
+        if (live != (l < n) || (live && (v < 1 || v >= odim))) s_bad = 1;
+        labels[(long)b * L + l] = live ? v : -1;
+        ys_in[(long)b * (L + 1) + l + 1] = live ? v : eos;
+        ys_out[(long)b * (L + 1) + l] = l == n ? eos : v;
+    }
+    if (threadIdx.x == 0) {
+        ys_in[(long)b * (L + 1)] = eos;          // sos == eos (e2e_asr_transformer.py:111-112)
+        ys_out[(long)b * (L + 1) + L] = n == L ? eos : ignore_id;
+    }
+    __syncthreads();
+    if (s_bad) __builtin_trap();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // decoder input embedding: x[b,l,:] = emb[tok[b,l]] * scale + pe[l]      (bf16 out);  backward scatter-adds into demb
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_embed_pos_fwd(const long* __restrict__ tok, const float* __restrict__ emb, const float* __restrict__ pe,
@@ -615,6 +649,14 @@ int svsr_ctc_grad(const float* logits, int ld, const int64_t* labels, int Lmax, 
     if (Lmax < 1 || lds > 60 * 1024) return SVSR_ERR_ARG;
     hipLaunchKernelGGL(k_ctc_grad, dim3(B * T), dim3(256), lds, stream, logits, ld, lse, (const long*)labels, Lmax, ilen, ab,
                        nll, B, T, V, 2 * Lmax + 1, gout, (bf16_t*)dlogits, ldo);
+    return svsr_check_launch();
+}
+
+int svsr_lrs_targets(const int64_t* label, int B, int L, int odim, int64_t ignore_id, int64_t eos, int64_t* labels, int64_t* ys_in,
+                     int64_t* ys_out, hipStream_t stream) {
+    if (B < 1 || L < 1 || odim < 2 || label == nullptr || labels == nullptr || ys_in == nullptr || ys_out == nullptr) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_lrs_targets, dim3(B), dim3(256), 0, stream, (const long*)label, L, odim, (long)ignore_id, (long)eos, (long*)labels,
+                       (long*)ys_in, (long*)ys_out);
     return svsr_check_launch();
 }
 

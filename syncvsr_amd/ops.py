@@ -1350,6 +1350,17 @@ def glu_dwconv_bwd(dc, u, w, dw, dbias, B: int, T: int, D: int, K: int) -> torch
     return du
 
 
+def lrs_targets(label: torch.Tensor, odim: int, ignore_id: int, eos: int):
+    """label int64 [B, L] on the device, ignore_id at the tail -> (labels [B, L] with -1, ys_in [B, L+1], ys_out [B, L+1]): add_sos_eos in one launch"""
+    B, L = label.shape
+    label = label.contiguous()
+    labels = torch.empty_like(label)
+    ys_in = torch.empty((B, L + 1), dtype=torch.int64, device=label.device)
+    ys_out = torch.empty_like(ys_in)
+    _call("svsr_lrs_targets", _p(label), B, L, odim, ignore_id, eos, _p(labels), _p(ys_in), _p(ys_out), _stream())
+    return labels, ys_in, ys_out
+
+
 def ctc_fwd(logits, ld: int, labels, ilen, B: int, T: int, V: int):
     """logits fp32 [B*T, ld]; labels int64 [B, Lmax] (-1 padded); ilen int32 [B] -> (loss 0-d, state for ctc_grad)."""
     Lmax = labels.shape[1]

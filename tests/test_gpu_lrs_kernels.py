@@ -169,6 +169,25 @@ def test_glu_dwconv(B, T, D, K):
     assert _rel_err(db.cpu(), bf_.grad) < 5e-3
 
 
+def test_lrs_targets_equal_add_sos_eos():
+    """svsr_lrs_targets (one launch) against the oracle's add_sos_eos (reference add_sos_eos.py:10-31) and the CTC label form: rows of every
+    length from 1 to L (a full row has no padding), 300-token rows (more than one pass of the workgroup)."""
+    from oracle import lrs_oracle as O
+    from syncvsr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    odim, ignore = 5049, -1
+    for B, L in ((7, 7), (16, 41), (3, 300)):
+        lens = [L, 1] + [int(x) for x in torch.randint(1, L + 1, (B - 2,), generator=g)]
+        label = torch.full((B, L), ignore, dtype=torch.int64)
+        for b, n in enumerate(lens):
+            label[b, :n] = torch.randint(1, odim, (n,), generator=g)
+        labels, ys_in, ys_out = ops.lrs_targets(label.to(dev), odim, ignore, odim - 1)
+        ref_in, ref_out = O.add_sos_eos([y[y != ignore] for y in label], odim - 1, odim - 1)
+        assert torch.equal(ys_in.cpu(), ref_in) and torch.equal(ys_out.cpu(), ref_out)
+        assert torch.equal(labels.cpu(), label)
+
+
 @pytest.mark.parametrize("B,T,V,lens,ylens", [(2, 7, 11, [7, 5], [3, 2]), (3, 40, 41, [40, 25, 31], [10, 4, 12]), (4, 150, 5049, [150, 90, 120, 6], [40, 12, 25, 8])])
 def test_ctc(B, T, V, lens, ylens):
     """Matches torch.nn.CTCLoss(reduction='sum', zero_infinity=True)/B on log_softmax, ctc.py:65-74; last case has an infeasible item."""
