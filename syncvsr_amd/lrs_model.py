@@ -21,6 +21,7 @@ import torch.nn as nn
 from . import ops
 from .config import Config
 from .lrs_init import LRS_ODIM, lrs_audio_dims, lrs_buffer_specs, lrs_init_state_dict, lrs_param_specs
+from . import model as _model_mod
 from .model import BF16, _Holder, _SideStream, _ParamStore, _attach, _defer_list, _frontend_backward, _frontend_forward, _get, _bn_stats, _ready
 
 LN_EPS = 1e-12          # transformer/layer_norm.py:19
@@ -437,8 +438,9 @@ def _lin_bwd(model, st: _ParamStore, name: str, x, dy, rows: int, K: int, N: int
     gw = st.grad[st.offsets[f"{name}.weight"][0] :][: N * K]
     gb = st.grad[st.offsets[f"{name}.bias"][0] :][:N] if bias else None          # column sums of dy, fused into the wgrad launch
     # weight gradients only feed the flat gradient buffer: optionally on the side stream, next to the data-gradient GEMM
-    model._side.run(lambda: ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=dy_pitch, use_tr=model.use_tr, db=gb),
-                    x, dy, small=True)
+    if "lin_wgrad" not in _model_mod._ABLATE:       # (timing experiments only, see model._ABLATE)
+        model._side.run(lambda: ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=dy_pitch, use_tr=model.use_tr, db=gb),
+                        x, dy, small=True)
     if not need_dx:
         return None
     return ops.linear_dgrad(dy, st.t16(tkey or f"{name}.weight"), rows=rows, N=N, K=K, dy_pitch=dy_pitch, addend=addend, out=out, drop=drop)
