@@ -417,6 +417,13 @@ __global__ __launch_bounds__(256) void k_wgrad_unit_reduce(const WgradReduceArgs
     const int g = blk * 64 + gl;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     int s = sl;
+    for (; s + 28 < ns; s += 32) {          // eight loads in flight, added in the lane's slot order
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = reinterpret_cast<const f32x4*>(src + (long)(s + 4 * k) * q.tile_stride)[g];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a = a + v[k];
+    }
     for (; s + 4 < ns; s += 8) {
         const f32x4 v0 = reinterpret_cast<const f32x4*>(src + (long)s * q.tile_stride)[g];
         const f32x4 v1 = reinterpret_cast<const f32x4*>(src + (long)(s + 4) * q.tile_stride)[g];

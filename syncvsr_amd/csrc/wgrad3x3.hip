@@ -195,6 +195,15 @@ __global__ __launch_bounds__(256) void k_wgrad3_reduce(const float* __restrict__
     const float* src = part + ((long)blockIdx.z * gridDim.y + blockIdx.y) * splits * W3_TILE_FLOATS;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     int s = sl;
+    // eight loads in flight per thread, added in the lane's split order (two in flight made a lane's 64 slabs a chain of 32 dependent round
+    // trips: 18 us alone, 30-130 us beside the main stream's HBM-bound passes)
+    for (; s + 28 < splits; s += 32) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = reinterpret_cast<const f32x4*>(src + (long)(s + 4 * k) * W3_TILE_FLOATS)[g];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a = a + v[k];
+    }
     for (; s + 4 < splits; s += 8) {
         const f32x4 v0 = reinterpret_cast<const f32x4*>(src + (long)s * W3_TILE_FLOATS)[g];
         const f32x4 v1 = reinterpret_cast<const f32x4*>(src + (long)(s + 4) * W3_TILE_FLOATS)[g];
