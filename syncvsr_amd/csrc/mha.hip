@@ -78,7 +78,15 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 __global__ __launch_bounds__(256) void k_mha_pe_reduce(const float* __restrict__ part, bf16_t* __restrict__ dpe, int B, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += part[(long)b * n + i];
+        int b = 0;
+        for (; b + 7 < B; b += 8) {          // eight loads in flight, added in clip order
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = part[(long)(b + k) * n + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += t[k];
+        }
+        for (; b < B; ++b) s += part[(long)b * n + i];
         dpe[i] = f2bf(s);
     }
 }
