@@ -13,6 +13,7 @@ written tape, and a single autograd node for the whole model; every computation 
 from __future__ import annotations
 
 import math
+import os
 from typing import Any, Optional
 
 import torch
@@ -439,11 +440,31 @@ def _lin_bwd(model, st: _ParamStore, name: str, x, dy, rows: int, K: int, N: int
     gb = st.grad[st.offsets[f"{name}.bias"][0] :][:N] if bias else None          # column sums of dy, fused into the wgrad launch
     # weight gradients only feed the flat gradient buffer: optionally on the side stream, next to the data-gradient GEMM
     if "lin_wgrad" not in _model_mod._ABLATE:       # (timing experiments only, see model._ABLATE)
-        model._side.run(lambda: ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=dy_pitch, use_tr=model.use_tr, db=gb),
-                        x, dy, small=True)
+        group = model.__dict__.get("_wg_group")
+        if group is not None and model.use_tr:      # a decoder layer's weight gradients: collected, one grouped launch per layer (_flush_wg_group)
+            group.append(dict(x=x, dy=dy, dw=gw, db=gb, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=dy_pitch))
+        else:
+            model._side.run(lambda: ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=K, dy_pitch=dy_pitch, use_tr=model.use_tr, db=gb),
+                            x, dy, small=True)
     if not need_dx:
         return None
     return ops.linear_dgrad(dy, st.t16(tkey or f"{name}.weight"), rows=rows, N=N, K=K, dy_pitch=dy_pitch, addend=addend, out=out, drop=drop)
+
+
+WG_GROUP_DECODER = os.environ.get("SVSR_WG_GROUP_DECODER", "1") != "0"
+
+
+def _flush_wg_group(model) -> None:
+    """The weight gradients a decoder layer's backward collected, as ONE launch over a device table of problems (ops.linear_wgrad_group, the
+    launch the word-level encoder uses): at ~800 target rows each of the layer's eight contractions is a 13-chunk K loop — 22 us of latency
+    apiece as a launch of its own, 48 of them per step on the weight-gradient stream.  (Problems the grouped kernel does not take — the
+    source-attention key / value projection over the 2,560 encoder rows — go out on their own inside that call.)"""
+    group = model.__dict__.get("_wg_group")
+    model._wg_group = None
+    if not group:
+        return
+    keep = [t for q in group for t in (q["x"], q["dy"])]
+    model._side.run(lambda: ops.linear_wgrad_group(group), *keep, small=True)
 
 
 def _ln(st: _ParamStore, x, name: str):
@@ -629,6 +650,7 @@ def _decoder_bwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, dpred,
     for i in reversed(range(model.dlayers)):
         p = f"decoder.decoders.{i}"
         t = tape[p]
+        model._wg_group = [] if WG_GROUP_DECODER else None
         dx2 = _ffn_bwd(model, st, t["ff"], dx, f"{p}.feed_forward", R, D, U, 1.0, f"{p}.norm3", branch=(1.0, t["src"]["dao"]))
         ts = t["src"]
         dctx2 = _lin_bwd(model, st, f"{p}.src_attn.linear_out", ts["ctx"], _branch_grad(dx2, 1.0, ts["dao"]), R, D, D)
@@ -648,6 +670,7 @@ def _decoder_bwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, dpred,
         dt1 = _lin_bwd(model, st, f"{p}.self_attn.linear_q", tsf["tn"], dqkv, R, D, 3 * D, tkey=f"{p}.self_attn.qkv")
         nxt = tape[f"decoder.decoders.{i - 1}"]["ff"]["do"] if i > 0 else tape["dec_embed_drop"]
         dx = _ln_bwd(model, st, dt1, tsf["x"], f"{p}.norm1", tsf["m"], tsf["r"], addend=dx1, branch=(1.0, nxt))
+        _flush_wg_group(model)
         _ready(model, st, f"{p}.self_attn.linear_q.weight")
     ops.embed_pos_bwd(tg.ys_in, _branch_grad(dx, 1.0, tape["dec_embed_drop"]), st.g32("decoder.embed.0.weight"), D, math.sqrt(D))
     _ready(model, st, "decoder.embed.0.weight")
