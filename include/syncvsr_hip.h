@@ -79,6 +79,11 @@ extern "C" {
  * [n0,n0+n1) to out1 (may be null when n1 = 0); accumulate != 0 adds to the existing values. */
 int svsr_tune(const char* key, int value);
 int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale, hipStream_t stream);
+/* up to any number of svsr_colsum_rows problems, 16 per launch (the postponed parameter-gradient reductions of a layer's backward: LayerNorm
+ * weight / bias, linear biases — autograd's accumulation into .grad of lightning.py's modules).  entries: n records of 64 bytes in HOST memory,
+ * {const float* ws; float* out0; float* out1; int64_t ld, n0, n1; int32_t nrows, accumulate; float scale; int32_t reserved}; the outputs of
+ * different records must not overlap.  Same additions in the same order as n separate calls. */
+int svsr_colsum_rows_multi(const void* entries, int n, hipStream_t stream);
 
 /* ---- implicit-GEMM contractions (igemm_fwd.hip) -------------------------------------------------------------------
  * svsr_igemm_fwd replaces: nn.Conv2d forward of resnet.layer{1..4} (reference LRW/video/src/tcn/models/resnet.py:8-16,

@@ -158,6 +158,82 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ ws, in
     *dst = accumulate ? *dst + v : v;
 }
 
+// Up to COLSUM_MULTI_MAX column-sum problems as ONE launch (blockIdx.y = problem): the postponed parameter-gradient reductions of a layer's
+// backward (LayerNorm weight / bias, linear biases) are 5-us launches of their own, 128 of them per sentence-level step on the weight-gradient
+// stream.  Every problem keeps the column / row-lane shape svsr_colsum_rows would choose for it: the same additions in the same order.
+#define COLSUM_MULTI_MAX 16
+struct SvsrColsumEntry { const float* ws; float* out0; float* out1; int64_t ld, n0, n1; int nrows, accumulate; float scale; int cl; };      // 64 bytes
+struct ColsumBatch { SvsrColsumEntry e[COLSUM_MULTI_MAX]; };
+static_assert(sizeof(SvsrColsumEntry) == 64, "entry layout is part of the C ABI (include/syncvsr_hip.h)");
+
+__global__ __launch_bounds__(256) void k_colsum_multi(const ColsumBatch b) {
+    __shared__ float sred[256];
+    const SvsrColsumEntry& e = b.e[blockIdx.y];
+    const int CL = e.cl, RL = 256 / CL;                 // CL a power of two
+    const long n = e.n0 + e.n1;
+    if ((long)blockIdx.x * CL >= n) return;             // (the grid is as wide as the widest problem)
+    const int cl = threadIdx.x & (CL - 1), rl = threadIdx.x / CL;
+    const long c = (long)blockIdx.x * CL + cl;
+    const bool live = c < n;
+    const int nrows = e.nrows;
+    const long ld = e.ld;
+    float acc = 0.f;
+    if (live) {
+        const float* src = e.ws + c;
+        int r = rl;
+        for (; r + 7 * RL < nrows; r += 8 * RL) {
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = src[(long)(r + k * RL) * ld];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += t[k];
+        }
+        for (; r + 3 * RL < nrows; r += 4 * RL) {
+            const float a = src[(long)r * ld], b2 = src[(long)(r + RL) * ld], d = src[(long)(r + 2 * RL) * ld], f = src[(long)(r + 3 * RL) * ld];
+            acc = (((acc + a) + b2) + d) + f;
+        }
+        for (; r < nrows; r += RL) acc += src[(long)r * ld];
+    }
+    if (RL > 1) {
+        sred[threadIdx.x] = acc;
+        __syncthreads();
+        if (rl != 0) return;
+        acc = 0.f;
+        for (int k = 0; k < RL; ++k) acc += sred[k * CL + cl];
+    }
+    if (!live) return;
+    float* dst = c < e.n0 ? e.out0 + c : e.out1 + (c - e.n0);
+    const float v = acc * e.scale;
+    *dst = e.accumulate ? *dst + v : v;
+}
+
+static inline int colsum_cl(int nrows, long n) { return (nrows <= 8 || n >= 65536) ? 256 : (nrows <= 64 || n >= 8192) ? 32 : n >= 8 ? 8 : 1; }
+
+/* entries: n records of 64 bytes {const float* ws; float* out0; float* out1; int64 ld, n0, n1; int32 nrows, accumulate; float scale; int32 reserved}
+ * in HOST memory, each with svsr_colsum_rows's meaning; outputs of different records must not overlap.  One launch per 16 records. */
+extern "C" int svsr_colsum_rows_multi(const void* entries, int n, hipStream_t stream) {
+    if (entries == nullptr || n < 1) return SVSR_ERR_ARG;
+    const SvsrColsumEntry* src = static_cast<const SvsrColsumEntry*>(entries);
+    for (int i0 = 0; i0 < n; i0 += COLSUM_MULTI_MAX) {
+        ColsumBatch b;
+        const int m = n - i0 < COLSUM_MULTI_MAX ? n - i0 : COLSUM_MULTI_MAX;
+        long gx = 1;
+        for (int i = 0; i < m; ++i) {
+            b.e[i] = src[i0 + i];
+            const long cols = (long)b.e[i].n0 + (long)b.e[i].n1;
+            if (b.e[i].nrows < 0 || cols <= 0 || b.e[i].ld < cols || (b.e[i].n1 > 0 && b.e[i].out1 == nullptr) || b.e[i].out0 == nullptr || b.e[i].ws == nullptr) return SVSR_ERR_ARG;
+            b.e[i].cl = colsum_cl(b.e[i].nrows, cols);
+            const long blocks = (cols + b.e[i].cl - 1) / b.e[i].cl;
+            if (blocks > gx) gx = blocks;
+        }
+        for (int i = m; i < COLSUM_MULTI_MAX; ++i) b.e[i] = b.e[0];
+        hipLaunchKernelGGL(k_colsum_multi, dim3((unsigned)gx, (unsigned)m), dim3(256), 0, stream, b);
+        const int rc = svsr_check_launch();
+        if (rc != SVSR_OK) return rc;
+    }
+    return SVSR_OK;
+}
+
 extern "C" int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate,
                                 float scale, hipStream_t stream) {
     const long n = (long)n0 + (long)n1;

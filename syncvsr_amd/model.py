@@ -767,7 +767,7 @@ def _flush_deferred(model) -> None:
     if d:
         fns, keep = [f for f, _ in d], [k for _, k in d]
         d.clear()
-        model._side.run(lambda: [f() for f in fns], *keep, small=True)
+        model._side.run(lambda: ops.run_deferred(fns), *keep, small=True)
 
 
 def _ready(model, st: "_ParamStore", name: Optional[str]) -> None:

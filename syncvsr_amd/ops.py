@@ -130,6 +130,10 @@ def tune(key: str, value: int) -> None:
         global LN_BRANCH_FUSED
         LN_BRANCH_FUSED = bool(value)
         return
+    if key == "colsum_multi":
+        global COLSUM_MULTI
+        COLSUM_MULTI = bool(value)
+        return
     if key == "early_sumsq":
         global EARLY_SUMSQ
         EARLY_SUMSQ = bool(value)
@@ -940,6 +944,49 @@ def colsum_rows(part, rows: int, ld: int, out0, n0: int, out1=None, n1: int = 0)
     _call("svsr_colsum_rows", _p(part), rows, ld, _p(out0), n0, _p(out1), n1, 1, 1.0, _stream())
 
 
+class _ColsumEntry(ctypes.Structure):       # include/syncvsr_hip.h svsr_colsum_rows_multi: 64 bytes
+    _fields_ = [("ws", ctypes.c_void_p), ("out0", ctypes.c_void_p), ("out1", ctypes.c_void_p), ("ld", ctypes.c_int64), ("n0", ctypes.c_int64),
+                ("n1", ctypes.c_int64), ("nrows", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("scale", ctypes.c_float), ("reserved", ctypes.c_int32)]
+
+
+COLSUM_MULTI = True       # host-side knob "colsum_multi": a layer's postponed parameter-gradient reductions as one launch per 16
+
+
+def _deferred_colsum(part, rows: int, ld: int, out0, n0: int, out1=None, n1: int = 0):
+    """A postponed colsum_rows(...) (accumulating) as a closure for a model's deferred list; run_deferred() merges neighbours into one launch."""
+    f = lambda: colsum_rows(part, rows, ld, out0, n0, out1, n1)
+    f.colsum = (part, rows, ld, out0, n0, out1, n1)
+    return f
+
+
+def run_deferred(fns) -> None:
+    """Runs a model's postponed reductions on the current stream: those made by _deferred_colsum as svsr_colsum_rows_multi launches (results
+    identical to the separate launches: every problem keeps its own order of additions), the others one by one."""
+    batch: list = []
+
+    def flush():
+        if len(batch) == 1:
+            colsum_rows(*batch[0])
+        elif batch:
+            arr = (_ColsumEntry * len(batch))()
+            for e, (part, rows, ld, out0, n0, out1, n1) in zip(arr, batch):
+                e.ws, e.out0, e.out1, e.ld, e.n0, e.n1, e.nrows, e.accumulate, e.scale = _p(part), _p(out0), _p(out1), ld, n0, n1, rows, 1, 1.0
+            _call("svsr_colsum_rows_multi", arr, len(batch), _stream())
+        batch.clear()
+
+    for f in fns:
+        a = getattr(f, "colsum", None)
+        if a is None or not COLSUM_MULTI:
+            flush()
+            f()
+            continue
+        outs = {_p(a[3]), _p(a[5])} - {None}
+        if any(({_p(b[3]), _p(b[5])} - {None}) & outs for b in batch):       # (two contributions to one gradient: separate launches, in order)
+            flush()
+        batch.append(a)
+    flush()
+
+
 LN_BRANCH_FUSED = True      # host-side knob "ln_branch_fused": a residual branch's gradient alpha * mask * dx as a second output of the LayerNorm backward in front of it (LRS layers); False: svsr_scale_bf16
 
 
@@ -958,10 +1005,10 @@ def add_ln_bwd(dy, a, r, gamma, mean, rstd, dgamma, dbeta, addend=None, out=None
             ds2 = torch.empty_like(a)
             _call("svsr_add_ln_bwd_branch", _p(dy), _p(a), _p(r), _p(gamma), _p(mean), _p(rstd), _p(ds), R, D, _p(addend), _p(part), _p(ds2), float(alpha),
                   *_drop(drop), _stream())
-            defer.append((lambda: colsum_rows(part, rows, 2 * D, dgamma, D, dbeta, D), part))
+            defer.append((_deferred_colsum(part, rows, 2 * D, dgamma, D, dbeta, D), part))
             return ds, ds2
         _call("svsr_add_ln_bwd_partials", _p(dy), _p(a), _p(r), _p(gamma), _p(mean), _p(rstd), _p(ds), R, D, _p(addend), _p(part), _stream())
-        defer.append((lambda: colsum_rows(part, rows, 2 * D, dgamma, D, dbeta, D), part))
+        defer.append((_deferred_colsum(part, rows, 2 * D, dgamma, D, dbeta, D), part))
         return ds
     part = scratch(_query("svsr_add_ln_bwd_rows", R)[0] * 2 * D)
     _call("svsr_add_ln_bwd", _p(dy), _p(a), _p(r), _p(gamma), _p(mean), _p(rstd), _p(ds), _p(dgamma), _p(dbeta), R, D, _p(addend), _p(part),
@@ -1139,7 +1186,7 @@ def bias_act_bwd(dy, z, db, *, R: int, N: int, n_valid: int, ld: int, relu: bool
     if defer is not None and rows:
         part = torch.empty(rows * N, dtype=torch.float32, device=dy.device)
         _call("svsr_bias_act_bwd_partials", _p(dy), _p(z), _p(dz), _p(db), R, N, n_valid, ld, 2 if relu else 1, float(gscale), _p(part), _stream())
-        defer.append((lambda: colsum_rows(part, rows, N, db, n_valid), part))
+        defer.append((_deferred_colsum(part, rows, N, db, n_valid), part))
         return dz if z is not None else dy
     part = scratch(rows * N) if rows else None
     _call("svsr_bias_act_bwd", _p(dy), _p(z), _p(dz), _p(db), R, N, n_valid, ld, 2 if relu else 1, float(gscale), _p(part), _stream())

@@ -671,6 +671,35 @@ def test_adamw_clip_schedule(dev):
     assert int(st[0]) == 3
 
 
+def test_colsum_rows_multi_equals_separate_launches(dev):
+    """svsr_colsum_rows_multi: a layer's postponed parameter-gradient reductions (LayerNorm weight / bias, linear biases: autograd's accumulation
+    into .grad) as one launch — every shape class of svsr_colsum_rows in one batch, 19 problems (two launches), accumulating into non-zero
+    outputs: bit-identical to separate launches.  Two contributions to the same output stay separate launches, in order."""
+    from syncvsr_amd import ops
+
+    g = torch.Generator().manual_seed(17)
+    shapes = [(512, 1536, 768, 768), (5, 70000, 70000, 0), (40, 3072, 3000, 0), (300, 9000, 9000, 0), (700, 6, 3, 3), (64, 768, 768, 0), (9, 40, 40, 0)]
+    shapes = shapes + shapes + shapes[:5]
+    fns_a, fns_b, outs_a, outs_b = [], [], [], []
+    for rows, ld, n0, n1 in shapes:
+        part = torch.randn(rows * ld, generator=g).to(dev)
+        base0, base1 = torch.randn(n0, generator=g), (torch.randn(n1, generator=g) if n1 else None)
+        for fns, outs in ((fns_a, outs_a), (fns_b, outs_b)):
+            o0, o1 = base0.clone().to(dev), (base1.clone().to(dev) if n1 else None)
+            fns.append(ops._deferred_colsum(part, rows, ld, o0, n0, o1, n1))
+            outs.append((o0, o1))
+    # a second contribution to the first problem's outputs
+    extra = torch.randn(512 * 1536, generator=g).to(dev)
+    fns_a.append(ops._deferred_colsum(extra, 512, 1536, outs_a[0][0], 768, outs_a[0][1], 768))
+    fns_b.append(ops._deferred_colsum(extra, 512, 1536, outs_b[0][0], 768, outs_b[0][1], 768))
+    ops.run_deferred(fns_a)
+    for f in fns_b:
+        f()
+    torch.cuda.synchronize()
+    for (a0, a1), (b0, b1) in zip(outs_a, outs_b):
+        assert torch.equal(a0, b0) and (a1 is None or torch.equal(a1, b1))
+
+
 def test_grad_sumsq_in_ranges(dev):
     """svsr_grad_sumsq_parts: the clip's sum of squares (Lightning's gradient_clip_val, lightning.py:216-223 via the Trainer) over two
     ranges into disjoint partial sums — what engine.TrainStep runs (everything behind the stem weight early, the stem weight last).  The
