@@ -377,3 +377,39 @@ def test_c64_pixel_table_matches_the_padded_grid():
         if want >= 0:
             seen.append(want)
     assert seen == list(range(N * H * W)) and all(v == -1 for v in tab[pad + N * Q:])
+
+
+def test_deferred_reductions_are_batched_without_merging_contributions_to_one_gradient(monkeypatch):
+    """ops.run_deferred (host logic, no device): neighbouring postponed column sums go out as svsr_colsum_rows_multi records — but two
+    contributions to the same gradient never share a launch (a launch's records must not overlap), a closure that is not a column sum runs
+    in its place, and a single leftover falls back to svsr_colsum_rows."""
+    from syncvsr_amd import ops
+
+    calls = []
+    monkeypatch.setattr(ops, "_call", lambda name, *a, **k: calls.append((name, a)))
+    monkeypatch.setattr(ops, "_stream", lambda: 0)
+    mk = lambda n: torch.zeros(n)
+    outs = [mk(8) for _ in range(6)]
+    parts = [mk(64) for _ in range(8)]
+    other = []
+    fns = [ops._deferred_colsum(parts[0], 8, 8, outs[0], 8),
+           ops._deferred_colsum(parts[1], 8, 8, outs[1], 4, outs[2], 4),
+           ops._deferred_colsum(parts[2], 8, 8, outs[0], 8),                 # second contribution to outs[0]: a new launch
+           ops._deferred_colsum(parts[3], 8, 8, outs[3], 8),
+           (lambda: other.append("ran")),                                    # not a column sum: flushes, then runs
+           ops._deferred_colsum(parts[4], 8, 8, outs[4], 8)]
+    ops.run_deferred(fns)
+    names = [c[0] for c in calls]
+    assert names == ["svsr_colsum_rows_multi", "svsr_colsum_rows_multi", "svsr_colsum_rows"], names
+    assert calls[0][1][1] == 2 and calls[1][1][1] == 2 and other == ["ran"]
+    rec = calls[0][1][0]
+    assert ctypes.sizeof(rec[0]) == 64 and rec[1].n0 == 4 and rec[1].n1 == 4 and rec[1].out1 == outs[2].data_ptr() and rec[0].accumulate == 1
+    # more than 16 records still go out in one call (the library cuts it into launches of 16)
+    calls.clear()
+    ops.run_deferred([ops._deferred_colsum(mk(64), 8, 8, mk(8), 8) for _ in range(19)])
+    assert [c[0] for c in calls] == ["svsr_colsum_rows_multi"] and calls[0][1][1] == 19
+    # the knob off: every closure by itself
+    calls.clear()
+    monkeypatch.setattr(ops, "COLSUM_MULTI", False)
+    ops.run_deferred(fns[:2])
+    assert [c[0] for c in calls] == ["svsr_colsum_rows", "svsr_colsum_rows"]
