@@ -331,8 +331,6 @@ def main() -> None:
     ap.add_argument("--no-lrs-leg", action="store_true", help="skip the LRS leg of the default (LRW, one GPU) run")
     ap.add_argument("--ablate", default="", help="TIMING EXPERIMENTS ONLY (gradients wrong, the line is marked invalid): comma list of conv_wgrad, lin_wgrad — "
                     "those launches are skipped (how much of the step do they cost?)")
-    ap.add_argument("--cu-split", default="", help="SIDE[:layout]: main and side stream on disjoint compute units (engine.TrainStep(cu_split=...)): "
-                    "SIDE compute units (SIDE/8 from every XCD) for the weight-gradient side stream.  Measured SLOWER than sharing the chip (DESIGN.md section 7)")
     ap.add_argument("--dropout", type=float, default=0.1, help="LRS: dropout_rate = transformer_attn_dropout_rate (config/lrs3.yaml:20-21)")
     args = ap.parse_args()
     if args.workload == "lrs" and args.batch == 32 and "--batch" not in sys.argv:
@@ -391,15 +389,8 @@ def main() -> None:
         model = Model(cfg, seed=0).to(dev).train()
         batch = [t.to(dev) for t in synthetic_batch(cfg, args.batch, seed=1234 + rank)]
     native = args.enqueue == "native" and args.workload in ("lrw", "lrs") and not use_graph
-    cu_split = None
-    if args.cu_split:
-        side, _, layout = args.cu_split.partition(":")
-        cu_split = (int(side), layout or "spread")
     trainer = TrainStep(model, cfg, use_graph=use_graph, always_reduce=args.force_collective, bucket_mb=args.bucket_mb,
-                        grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32, native=native, cu_split=cu_split)
-    if trainer.main_stream is not None:          # the whole loop lives on the masked main stream (no per-step hand-over with the default stream)
-        torch.cuda.synchronize()
-        torch.cuda.set_stream(trainer.main_stream)
+                        grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32, native=native)
 
     def barrier():
         if use_dist:
@@ -491,11 +482,6 @@ def main() -> None:
             allr = [mine]
         result["collective"]["exposed_join_ms_per_rank"] = [round(float(t[0]), 4) for t in allr]
         result["collective"]["host_enqueue_ms_per_rank"] = [round(float(t[1]), 4) for t in allr]
-    if trainer.main_stream is not None:
-        torch.cuda.synchronize()
-        torch.cuda.set_stream(torch.cuda.default_stream())
-        result["config"]["cu_split"] = {"side_cus": cu_split[0], "layout": cu_split[1], "main_cus": ops.stream_cus(trainer.main_stream)}
-        model._side.stream = None          # the profiling legs below run unmasked
 
     if rank == 0:
         # ---- roofline leg: eager steps with HIP events around every contraction launch -----------------------------

@@ -141,8 +141,6 @@ int svsr_igemm_wgrad_group(const svsr_wgrad_problem* problems, int n, void* tabl
  * weight tap tw[t] (HOST arrays of 9 ints); out = conv (+ addend); stats [rows][2][64] with rows =
  * svsr_conv3x3_c64_stat_rows(Nimg, H, W) (one per persistent workgroup).  Requires W <= 29. */
 int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W);
-/* the same for a launch on `stream` (a CU-masked stream runs fewer persistent workgroups: svsr_stream_create_cumask) */
-int svsr_conv3x3_c64_stat_rows_on(int Nimg, int H, int W, hipStream_t stream);
 /* pixtab (both launches below): device copy of svsr_conv3x3_c64_pixtab's table for (Nimg, H, W) — pixel index or -1 per padded
  * coordinate — or null (the kernel then derives the source pixel of every staged row by arithmetic: ~500 instructions per chunk and thread).
  * svsr_conv3x3_c64_pixtab(..., out = null) returns the entry count. */
@@ -315,8 +313,11 @@ int svsr_linear_ce_bwd(const void* h, const void* w, const float* bias, const in
 int svsr_topk_acc(const float* logits, const int64_t* labels, const float* soft_labels, int B, int C, float* out2, float* rows2, hipStream_t stream);
 
 /* clip_grad_norm_ + AdamW + HF cosine-with-warm-up (lightning.py:216-223; Lightning gradient_clip_val).
- * opt_state: device struct {int step; float sumsq; float lr_last; float gnorm_last; float part[1024]} (4112 bytes),
- * zero-initialised; svsr_grad_sumsq writes the 1024 partial sums of squares, svsr_adamw_step adds them in a fixed order. */
+ * opt_state: device struct {int step; int skipped; float lr_last; float gnorm_last; float part[1024]} (4112 bytes),
+ * zero-initialised; svsr_grad_sumsq writes the 1024 partial sums of squares, svsr_adamw_step adds them in a fixed order.
+ * A step whose gradient norm is NOT FINITE is skipped: parameters, moments and `step` stay as they are, `skipped` counts it and
+ * gnorm_last shows the value (the reference would train on with NaN parameters; a poisoned fused-encoder launch — svsr_enc_gave_up —
+ * is the case this exists for). */
 int svsr_grad_sumsq(const float* g, int64_t n, void* opt_state, hipStream_t stream);
 /* one range of the gradient into partial sums [part0, part0 + nparts): a step's ranges cover the buffer and the 1024 partials once each
  * (the clip of lightning's `gradient_clip_val` needs the whole norm; most of it can be summed before the last weight gradient is done) */
@@ -349,8 +350,13 @@ int svsr_fill_f32(float* p, int64_t n, float v, hipStream_t stream);
 /* A bounded cluster wait that gives up is LOUD: the launch's error word (word B of ws) is set, the giving-up workgroup overwrites its slice
  * of the launch's final output with NaN (the step's loss / gradient norm turn NaN without a host synchronisation), and a sticky
  * process-wide flag is set that svsr_enc_gave_up(reset) returns (1 / 0; it synchronises: call it where the host waits anyway;
- * engine.TrainStep.state() raises on it).  A launch holds at most svsr_stream_cu_count(stream) / 8 sequences. */
+ * -1 if the flag cannot be read).  svsr_enc_gave_up_peek() reads a copy of the flag that the giving-up workgroup stores into pinned host
+ * memory: no synchronisation, so engine.TrainStep looks at it before every step and, when set, re-routes the encoder to the per-layer launch
+ * chain for the rest of the run (the poisoned step itself is skipped by svsr_adamw_step's non-finite guard).  A launch holds at most
+ * svsr_device_cus() / 8 sequences. */
 int svsr_enc_gave_up(int reset);
+int svsr_enc_gave_up_peek(void);
+int svsr_debug_enc_spin_limit(unsigned limit);     /* test aid: polls before a cluster wait gives up (0 = default 2^20; 1 provokes the give-up path) */
 int64_t svsr_enc_fwd_ws_bytes(int B);
 int svsr_debug_enc_trace(int64_t* out, int n);     /* debug: out == null arms s_memtime stamps of workgroup 0 at the phase boundaries of the next launches; else copies n stamps out */
 int svsr_enc_fwd(const void* x0, const svsr_enc_layer* layers, int n_layers, int B, int S, float ln_eps, const unsigned* drop_seed, float p_hidden, float p_attn, void* ws, int64_t ws_bytes, hipStream_t stream);
@@ -430,10 +436,15 @@ int svsr_ctc_prefix_score(const float* logp, int ldp, const float* r_prev, const
 
 /* Decoder input: x[r] = emb[tok[r]] * scale + pe[r % L]  (torch.nn.Embedding + PositionalEncoding, decoder.py:80-84,
  * embedding.py:78-89); backward scatter-adds scale * dx into demb. */
-/* add_sos_eos (reference add_sos_eos.py:10-31, e2e_asr_transformer.py:203-215) + the CTC label form, one launch: label [B][L] int64 padded with
- * ignore_id at the tail -> labels [B][L] (-1 padded), ys_in / ys_out [B][L+1] (sos = eos; ys_out padded with ignore_id).  A token outside
- * [1, odim) or padding that is not a tail traps the device, like torch's device-side assert in Embedding / CTCLoss. */
+/* add_sos_eos (reference add_sos_eos.py:10-31, e2e_asr_transformer.py:203-215) + the CTC label form, one launch: label [B][L] int64 with
+ * ignore_id padding (dropped wherever it sits in a row, as the reference's `y[y != ignore_id]`) -> labels [B][L] (live tokens, -1 padded),
+ * ys_in / ys_out [B][L+1] (sos = eos; ys_out padded with ignore_id).  A live token outside [1, odim) — torch's Embedding / CTCLoss stop on it
+ * with a device-side assert — is replaced by eos and reported through svsr_lrs_target_errors (nothing traps). */
 int svsr_lrs_targets(const int64_t* label, int B, int L, int odim, int64_t ignore_id, int64_t eos, int64_t* labels, int64_t* ys_in, int64_t* ys_out, hipStream_t stream);
+/* sticky error word of svsr_lrs_targets: 1 if a label outside [1, odim) was met since the last reset (it was replaced by eos so that no
+ * later kernel leaves its tables; ignore_id entries anywhere in a row are dropped as the reference's add_sos_eos drops them), else 0; -1 if
+ * the word cannot be read.  Synchronises. */
+int svsr_lrs_target_errors(int reset);
 int svsr_embed_pos_fwd(const int64_t* tok, const float* emb, const float* pe, void* x, int R, int L, int D, float scale, hipStream_t stream);
 int svsr_embed_pos_bwd(const int64_t* tok, const void* dx, float* demb, int R, int D, float scale, hipStream_t stream);
 
@@ -474,16 +485,14 @@ int svsr_steplist_run(void* list, int segment, int* failed);
 int svsr_stream_wait(hipStream_t waiter, hipStream_t signaller);
 int svsr_memset_async(void* ptr, int value, int64_t bytes, hipStream_t stream);
 
-/* Streams restricted to a subset of the compute units (csrc/runtime.hip; hipExtStreamCreateWithCUMask).  The step being scheduled is the
- * reference's training_step + optimizer step (LRW/video/src/lightning.py:194-202,216-223): its main stream (forward, data gradients) and
- * its side stream (weight gradients, parameter-gradient reductions, most of AdamW) can be given DISJOINT compute units, and every
- * persistent kernel sizes its grid / static tile list / cluster count by svsr_stream_cu_count of the stream it is launched on.
- * mask: `words` 32-bit words, bit i = compute unit i in the driver's numbering (gfx950: XCD i % 8, then shader engine, then CU).
- * svsr_stream_destroy only accepts streams made here.  svsr_device_cus: compute units of the current device. */
-int svsr_stream_create_cumask(const uint32_t* mask, int words, hipStream_t* out);
-int svsr_stream_destroy(hipStream_t stream);
-int svsr_stream_cu_count(hipStream_t stream);
+/* Compute units of the current device (persistent kernels size their grids, static tile lists and cluster counts by it). */
 int svsr_device_cus(void);
+
+/* Test aid (csrc/runtime.hip): a foreign resident kernel — `workgroups` workgroups x 256 threads, each holding lds_bytes of LDS, that sleep
+ * until svsr_debug_occupy_stop() (or ~4 s).  Stands in for a peer-waiting collective kernel beside a training step of the reference's
+ * strategy="ddp" loop (LRW/video/src/train.py:28): tests/test_gpu_cotenant.py runs steps beside it. */
+int svsr_debug_occupy_start(int workgroups, int lds_bytes, hipStream_t stream);
+int svsr_debug_occupy_stop(void);
 
 #ifdef __cplusplus
 }

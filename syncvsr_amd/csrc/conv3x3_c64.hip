@@ -280,17 +280,16 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
     }
 }
 
-static int c64_grid(long total_chunks, hipStream_t stream) {
-    const int cus = svsr_stream_cus(stream);
+static int c64_grid(long total_chunks) {
+    const int cus = svsr_stream_cus(nullptr);
     return (int)(total_chunks < cus ? total_chunks : cus);
 }
 
 /* rows of [2][64] BatchNorm partials svsr_conv3x3_c64 writes for this shape (= its persistent workgroups) */
-extern "C" int svsr_conv3x3_c64_stat_rows_on(int Nimg, int H, int W, hipStream_t stream) {
+extern "C" int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W) {
     if (Nimg < 1 || H < 1 || W < 1) return 0;
-    return c64_grid(((long)Nimg * (H + 2) * (W + 2) + C64_CH - 1) / C64_CH, stream);
+    return c64_grid(((long)Nimg * (H + 2) * (W + 2) + C64_CH - 1) / C64_CH);
 }
-extern "C" int svsr_conv3x3_c64_stat_rows(int Nimg, int H, int W) { return svsr_conv3x3_c64_stat_rows_on(Nimg, H, W, nullptr); }
 
 static int c64_run(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W,
                    const int* dy, const int* dx, const int* tw, const void* bnb_y, const void* bnb_x, const float* bnb_mean,
@@ -315,7 +314,7 @@ static int c64_run(const void* in, const void* wt, void* out, const void* addend
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_c64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    const int grid = c64_grid(a.total_chunks, stream);
+    const int grid = c64_grid(a.total_chunks);
     if (bnb_x != nullptr && bnb_act == 2) hipLaunchKernelGGL(k_conv3x3_c64<true>, dim3(grid), dim3(C64_THREADS), lds, stream, a);
     else hipLaunchKernelGGL(k_conv3x3_c64<false>, dim3(grid), dim3(C64_THREADS), lds, stream, a);
     return svsr_check_launch();

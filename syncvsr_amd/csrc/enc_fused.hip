@@ -52,6 +52,8 @@ struct EncArgs {
     const unsigned* seed; unsigned th_hidden, th_attn; float sc_hidden, sc_attn;
     unsigned* cnt;               // [nseq] arrival counters (zero at launch)
     unsigned* err;               // set to 1 when a bounded spin gave up
+    unsigned* host_flag;         // the same word in pinned HOST memory (svsr_enc_gave_up_peek reads it without a synchronisation), or null
+    unsigned spin_limit;         // polls of a cluster wait before it gives up (2^20 ~ 1 s; svsr_debug_enc_spin_limit lowers it for the fall-back test)
     unsigned long long* trace;   // debug (svsr_debug_enc_trace): s_memtime stamps of workgroup 0 at the phase boundaries, or null
 };
 
@@ -88,18 +90,20 @@ __device__ __forceinline__ void cluster_signal(unsigned* cnt) {
 __device__ __forceinline__ void cluster_signal_keep_dma(unsigned* cnt) { cluster_signal(cnt); }
 // A wait that gives up (the 8 workgroups of a sequence were not resident together: a CU-masked or partitioned device, a co-tenant holding
 // LDS) must not pass silently: the launch's error word is set (cleared by the next launch's memset: the tests read it), the STICKY word
-// g_enc_gave_up is set (never cleared by a launch: svsr_enc_gave_up / engine.TrainStep.state raise on it), and the workgroup poisons its
+// g_enc_gave_up is set (never cleared by a launch: svsr_enc_gave_up reads it; the same word in pinned host memory lets engine.TrainStep see it
+// WITHOUT a synchronisation and fall back to the per-layer launch chain: svsr_enc_gave_up_peek), and the workgroup poisons its
 // slice of the launch's final output with NaN (enc_poison below), so the loss of this step (forward) or the gradient norm and every
 // parameter after it (backward) turn NaN without a host synchronisation.
 __device__ unsigned g_enc_gave_up = 0;
-__device__ __forceinline__ void cluster_wait(unsigned* cnt, unsigned target, unsigned* err, bool& gave_up) {
-    if (threadIdx.x == 0) {
+__device__ __forceinline__ void cluster_wait(unsigned* cnt, unsigned target, unsigned* err, unsigned* host_flag, unsigned spin_limit, bool& gave_up) {
+    if (threadIdx.x == 0 && !gave_up) {          // (a workgroup that gave up once does not wait again: its launch is lost anyway, it only has to end)
         unsigned spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 20)) {
+            if (++spins > spin_limit) {
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&g_enc_gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (host_flag != nullptr) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 gave_up = true;
                 break;
             }
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
         // =========================== P2: ao[:, h*64 ..] = dropout(ctx W_o^T + b) =============================================
         {
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err, gave_up);
+            cluster_wait(cnt, arrivals, p.err, p.host_flag, p.spin_limit, gave_up);
             stamp();                                         // [4] barrier 1 passed
             {   // every head's ctx -> bufA
                 const bf16_t* src = reinterpret_cast<const bf16_t*>(L.ctx) + (row0 + rsrc) * ED + csw * 8;
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
                 for (int kb = 0; kb < 8; ++kb) glds16_sc1(sx + kb * 64, ring(2) + kb * 2048 + wave * 8 * 64);
             }
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err, gave_up);
+            cluster_wait(cnt, arrivals, p.err, p.host_flag, p.spin_limit, gave_up);
             stamp();                                         // [6] barrier 2 passed
             // LayerNorm of rows wave*8 .. +7 (lane owns 8 columns of each) -> bufA (A layout); this workgroup's column slice -> x1.
             // ao and X arrive by LDS-DMA (sc1) in slots 1 and 2 (free: W_o is consumed; W_1's first tiles sit in 3 and 0): one round trip
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
                 for (int g = 0; g < 2; ++g) glds16_sc1(HG + (g * 16 + s) * 64, dst + g * 2048 + wave * 8 * 64);
             };
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err, gave_up);
+            cluster_wait(cnt, arrivals, p.err, p.host_flag, p.spin_limit, gave_up);
             stamp();                                         // [9] barrier 3 passed
             EF_WAIT_VM(0);                                   // the three prefetched weight half-tiles (and this wave's own stores)
             stageHG(0, 0); stageHG(1, 1); stageHG(2, 2);
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_fwd(const EncArgs p) {
                 for (int kb = 0; kb < 8; ++kb) glds16_sc1(sx + kb * 64, ring(1) + kb * 2048 + wave * 8 * 64);
             }
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err, gave_up);
+            cluster_wait(cnt, arrivals, p.err, p.host_flag, p.spin_limit, gave_up);
             stamp();                                         // [11] barrier 4 passed
             {   // f by LDS-DMA (sc1) into slot 0
                 const bf16_t* sa = reinterpret_cast<const bf16_t*>(L.f) + (row0 + rsrc) * ED + csw * 8;
@@ -679,7 +683,7 @@ struct EncBwdArgs {
     const svsr_enc_bwd_layer* Ls;     // DEVICE copy of the layer records, forward order
     int layers, S, seq0, nseq;
     const unsigned* seed; unsigned th_hidden, th_attn; float sc_hidden, sc_attn;
-    unsigned* cnt; unsigned* err;
+    unsigned* cnt; unsigned* err; unsigned* host_flag; unsigned spin_limit;
     unsigned long long* trace;
 };
 
@@ -827,7 +831,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
             ln_consts(L.g2, L.m2, L.r2, g8, mu8, rs8);
             if (l != p.layers - 1) {                        // the layer above has written every column of its dx
                 arrivals += EH;
-                cluster_wait(cnt, arrivals, p.err, gave_up);
+                cluster_wait(cnt, arrivals, p.err, p.host_flag, p.spin_limit, gave_up);
             }
             stamp();                                         // [b0] layer start
             rows512(dyin, 0, true);
@@ -928,7 +932,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
             // the weight halves of the first three tiles do not depend on the other workgroups: in flight across the cluster wait
             stageW(0, 0); stageW(1, 1); stageW(2, 2);
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err, gave_up);
+            cluster_wait(cnt, arrivals, p.err, p.host_flag, p.spin_limit, gave_up);
             stamp();                                         // [b3] barrier 1 passed
             const u32x4 ad = ad2;
             stageA(0, 0); stageA(1, 1); stageA(2, 2);
@@ -986,7 +990,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
             float g8[8], mu8[8], rs8[8];
             ln_consts(L.g1, L.m1, L.r1, g8, mu8, rs8);
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err, gave_up);
+            cluster_wait(cnt, arrivals, p.err, p.host_flag, p.spin_limit, gave_up);
             stamp();                                         // [b5] barrier 2 passed
             rows512(reinterpret_cast<const bf16_t*>(L.dx1), 0, true);
             EF_WAIT_VM(0);
@@ -1156,7 +1160,7 @@ __global__ __launch_bounds__(256, 1) void k_enc_bwd(const EncBwdArgs p) {
             };
             stageW(0, 0); stageW(1, 1); stageW(2, 2);        // (the attention's LDS scratch in slots 0 and 1 is behind the signal's workgroup barrier)
             arrivals += EH;
-            cluster_wait(cnt, arrivals, p.err, gave_up);
+            cluster_wait(cnt, arrivals, p.err, p.host_flag, p.spin_limit, gave_up);
             stamp();                                         // [b9] barrier 3 passed
             const u32x4 ad = ad1;
             stageA(0, 0); stageA(1, 1); stageA(2, 2);
@@ -1222,6 +1226,22 @@ __global__ __launch_bounds__(256) void k_enc_table(const EncTable t, int words, 
 
 static unsigned long long* g_enc_trace = nullptr;
 
+// One word of pinned, device-mapped host memory: a giving-up workgroup stores 1 into it (system scope), the host polls it for free.
+// Allocated by the first workspace-size query (every launch is preceded by one; never inside a stream capture).
+static unsigned g_enc_spin_limit = 1u << 20;       // polls (s_sleep 4 + one L2 read each: ~1 s in all) before a cluster wait gives up
+static unsigned* g_enc_host_flag = nullptr;        // host address
+static unsigned* g_enc_host_flag_dev = nullptr;    // the device's address of the same word
+static void enc_host_flag_init() {
+    if (g_enc_host_flag != nullptr) return;
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return; }
+    *static_cast<volatile unsigned*>(h) = 0;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+    g_enc_host_flag = static_cast<unsigned*>(h);
+    g_enc_host_flag_dev = static_cast<unsigned*>(d);
+}
+
 // sequences per launch: every workgroup takes a whole compute unit's LDS and spin-waits on its 7 siblings, so a launch may hold at most
 // (compute units of the stream) / 8 clusters (32 on the whole chip; fewer on a CU-masked stream)
 static int enc_clusters_per_launch(hipStream_t stream) {
@@ -1246,7 +1266,7 @@ int svsr_debug_enc_trace(int64_t* out, int n) {
 }
 
 /* bytes of the device workspace svsr_enc_fwd needs for B sequences: arrival counters, error word, layer records */
-int64_t svsr_enc_fwd_ws_bytes(int B) { return B < 1 ? 0 : (int64_t)(((B + 1) * 4 + 255) / 256 * 256) + (int64_t)sizeof(EncTable); }
+int64_t svsr_enc_fwd_ws_bytes(int B) { enc_host_flag_init(); return B < 1 ? 0 : (int64_t)(((B + 1) * 4 + 255) / 256 * 256) + (int64_t)sizeof(EncTable); }
 
 /* svsr_enc_fwd: forward of `n_layers` consecutive HF-BERT encoder layers (width 512, 8 heads of 64, FFN 2048, sequences of S <= 32
  * rows) in one launch per 32 sequences.  x0 bf16 [B*S][512]: the first layer's input; layers: HOST array of n_layers records (device
@@ -1276,6 +1296,8 @@ int svsr_enc_fwd(const void* x0, const svsr_enc_layer* layers, int n_layers, int
     a.seed = (dh.seed != nullptr || da.seed != nullptr) ? drop_seed : nullptr;
     a.th_hidden = dh.thresh; a.sc_hidden = dh.scale; a.th_attn = da.thresh; a.sc_attn = da.scale;
     a.err = cnt + B;
+    a.host_flag = g_enc_host_flag_dev;
+    a.spin_limit = g_enc_spin_limit;
     a.trace = g_enc_trace;
     const int per = enc_clusters_per_launch(stream);      // all workgroups of a launch must be resident together: 8 per sequence, one per compute unit
     for (int s0 = 0; s0 < B; s0 += per) {
@@ -1291,11 +1313,26 @@ int svsr_enc_gave_up(int reset) {
     unsigned v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_enc_gave_up), sizeof v) != hipSuccess) return -1;
     if (reset && v != 0) { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_enc_gave_up), &z, sizeof z); }
+    if (reset && g_enc_host_flag != nullptr) *static_cast<volatile unsigned*>(g_enc_host_flag) = 0;
     return v != 0 ? 1 : 0;
 }
 
+/* test aid: polls a cluster wait makes before it gives up (0 restores the default, 2^20).  tests/test_gpu_cotenant.py sets 1 to provoke the
+ * give-up path on purpose: a wait that does not find its siblings arrived at the second look poisons the launch. */
+int svsr_debug_enc_spin_limit(unsigned limit) {
+    g_enc_spin_limit = limit == 0 ? (1u << 20) : limit;
+    return SVSR_OK;
+}
+
+/* The same flag WITHOUT a synchronisation: the giving-up workgroup also stores it into a word of pinned host memory, which this reads
+ * (it may trail the device by the flight time of that store).  engine.TrainStep looks at it before every step and, when it is set,
+ * switches the encoder to the per-layer launch chain (svsr_igemm_fwd / svsr_mha_fwd / svsr_add_ln_fwd ...) for the rest of the run. */
+int svsr_enc_gave_up_peek(void) {
+    return g_enc_host_flag != nullptr && *static_cast<volatile unsigned*>(g_enc_host_flag) != 0 ? 1 : 0;
+}
+
 /* bytes of the device workspace svsr_enc_bwd needs for B sequences */
-int64_t svsr_enc_bwd_ws_bytes(int B) { return B < 1 ? 0 : (int64_t)(((B + 1) * 4 + 255) / 256 * 256) + (int64_t)sizeof(EncBwdTable); }
+int64_t svsr_enc_bwd_ws_bytes(int B) { enc_host_flag_init(); return B < 1 ? 0 : (int64_t)(((B + 1) * 4 + 255) / 256 * 256) + (int64_t)sizeof(EncBwdTable); }
 
 /* svsr_enc_bwd: backward of the layers svsr_enc_fwd ran, in one launch per 32 sequences.  dy bf16 [B*S][512]: gradient of the last layer's
  * output; layers: HOST array of n_layers records in FORWARD order.  Written per layer: ds2 / df / ds1 / dao / dx1 / dx bf16 [R][512], dz bf16
@@ -1325,6 +1362,8 @@ int svsr_enc_bwd(const void* dy, const svsr_enc_bwd_layer* layers, int n_layers,
     a.seed = (dh.seed != nullptr || da.seed != nullptr) ? drop_seed : nullptr;
     a.th_hidden = dh.thresh; a.sc_hidden = dh.scale; a.th_attn = da.thresh; a.sc_attn = da.scale;
     a.err = cnt + B;
+    a.host_flag = g_enc_host_flag_dev;
+    a.spin_limit = g_enc_spin_limit;
     a.trace = g_enc_trace;
     const int per = enc_clusters_per_launch(stream);
     for (int s0 = 0; s0 < B; s0 += per) {

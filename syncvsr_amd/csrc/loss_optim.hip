@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_topk_acc(const float* __restrict__ logi
 // optimiser
 // ---------------------------------------------------------------------------------------------------------
 #define OPT_PARTS 1024      // workgroups of k_grad_sumsq = partial sums of squares kept in the device state
-struct OptState { int step; float sumsq; float lr_last; float gnorm_last; float part[OPT_PARTS]; };   // device-resident
+struct OptState { int step; int skipped; float lr_last; float gnorm_last; float part[OPT_PARTS]; };   // device-resident; skipped: steps whose gradient norm was not finite (no update, step not advanced)
 
 // sum of the OPT_PARTS partials in a fixed order (every thread of a 256-thread block gets the same value)
 __device__ __forceinline__ float opt_sumsq(const OptState* st, float* s4) {
@@ -174,6 +174,11 @@ __global__ __launch_bounds__(256) void k_adamw(const AdamArgs a) {
     __shared__ float s4[4];
     const int step = a.st->step;             // steps already taken
     const float gnorm = sqrtf(opt_sumsq(a.st, s4));
+    // A gradient norm that is not finite (a fused-encoder launch whose cluster wait gave up poisons its outputs with NaN: csrc/enc_fused.hip;
+    // an overflow) would turn every parameter and both moments into NaN for good.  Such a step is SKIPPED: nothing is written, the step counter
+    // does not advance (k_opt_advance counts it in `skipped`, TrainStep.state() reports it).  The reference (AdamW behind
+    // clip_grad_norm_, lightning.py:216-223) would keep training on NaN parameters; there is nothing to be identical to.
+    if (!(gnorm <= 3.0e38f)) return;
     const float clip = a.max_norm > 0.f ? fminf(1.f, a.max_norm / (gnorm + 1e-6f)) : 1.f;
     const float lr = sched_lr(a, step);
     const float t = (float)(step + 1);
@@ -197,9 +202,9 @@ __global__ __launch_bounds__(256) void k_opt_advance(OptState* st, float lr_base
     if (threadIdx.x != 0) return;
     AdamArgs a; a.lr = lr_base; a.warmup = warmup; a.total_steps = total_steps;
     st->lr_last = sched_lr(a, st->step);
-    st->sumsq = sumsq;
     st->gnorm_last = sqrtf(sumsq);
-    st->step += 1;
+    if (st->gnorm_last <= 3.0e38f) st->step += 1;
+    else st->skipped += 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -359,35 +359,51 @@ __global__ __launch_bounds__(256) void k_ctc_grad(const float* __restrict__ z, i
 // ---------------------------------------------------------------------------------------------------------------------
 // Decoder / CTC targets of a batch from its padded labels — add_sos_eos (reference espnet/nets/pytorch_backend/transformer/add_sos_eos.py:10-31
 // as called by e2e_asr_transformer.py:203-215) in ONE launch; as torch index operations it was ~20 small launches per step on the step's
-// stream (0.12-0.15 ms of the sentence-level step).  label [B][L] int64, ignore_id at the tail:
-//   labels[b][l] = label or -1 (CTC);  ys_in[b] = [eos, label.., eos pad];  ys_out[b] = [label.., eos, ignore_id pad]
-// A token outside [1, odim) or padding that is not a tail is what torch's Embedding / CTCLoss would trap on with a device assert: same here.
+// stream (0.12-0.15 ms of the sentence-level step).  label [B][L] int64; ignore_id entries are DROPPED wherever they sit in a row, as the
+// reference's `y[y != ignore_id]` does (a tail is the usual case); with n live tokens in a row:
+//   labels[b] = [live.., -1 pad] (CTC);  ys_in[b] = [eos, live.., eos pad];  ys_out[b] = [live.., eos, ignore_id pad]
+// A live token outside [1, odim) is what torch's Embedding / CTCLoss would stop on with a device assert; here nothing traps (a trap kills
+// the HIP context with an opaque launch failure, on every replay of a recorded step): the token is replaced by eos — every later kernel
+// stays inside its tables — and a STICKY error word is set that svsr_lrs_target_errors returns (E2E.check_targets / TrainStep.state raise
+// a descriptive error from it).
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ unsigned g_lrs_target_err = 0;
 __global__ __launch_bounds__(256) void k_lrs_targets(const long* __restrict__ label, int L, int odim, long ignore_id, long eos,
                                                      long* __restrict__ labels, long* __restrict__ ys_in, long* __restrict__ ys_out) {
-    __shared__ int s_n, s_bad;
-    const int b = blockIdx.x;
-    if (threadIdx.x == 0) { s_n = 0; s_bad = 0; }
+    __shared__ int s_w[4], s_run, s_bad;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_run = 0; s_bad = 0; }
     __syncthreads();
-    int cnt = 0;
-    for (int l = threadIdx.x; l < L; l += 256) cnt += label[(long)b * L + l] != ignore_id ? 1 : 0;
-    if (cnt) atomicAdd(&s_n, cnt);              // (an integer count: the order of the additions does not matter)
-    __syncthreads();
-    const int n = s_n;
-    for (int l = threadIdx.x; l < L; l += 256) {
-        const long v = label[(long)b * L + l];
-        const bool live = v != ignore_id;
-        if (live != (l < n) || (live && (v < 1 || v >= odim))) s_bad = 1;
-        labels[(long)b * L + l] = live ? v : -1;
-        ys_in[(long)b * (L + 1) + l + 1] = live ? v : eos;
-        ys_out[(long)b * (L + 1) + l] = l == n ? eos : v;
+    for (int base = 0; base < L; base += 256) {           // stable compaction: position of a live token = live tokens in front of it
+        const int l = base + tid;
+        long v = l < L ? label[(long)b * L + l] : ignore_id;
+        const bool live = l < L && v != ignore_id;
+        if (live && (v < 1 || v >= odim)) { s_bad = 1; v = eos; }
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) s_w[wave] = __popcll(m);
+        __syncthreads();
+        int pos = s_run + __popcll(m & ((1ull << lane) - 1ull));
+        for (int k = 0; k < wave; ++k) pos += s_w[k];
+        if (live) {
+            labels[(long)b * L + pos] = v;
+            ys_in[(long)b * (L + 1) + pos + 1] = v;
+            ys_out[(long)b * (L + 1) + pos] = v;
+        }
+        __syncthreads();
+        if (tid == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    const int n = s_run;
+    for (int l = n + tid; l < L; l += 256) {
+        labels[(long)b * L + l] = -1;
+        ys_in[(long)b * (L + 1) + l + 1] = eos;
+        ys_out[(long)b * (L + 1) + l + 1] = ignore_id;
+    }
+    if (tid == 0) {
         ys_in[(long)b * (L + 1)] = eos;          // sos == eos (e2e_asr_transformer.py:111-112)
-        ys_out[(long)b * (L + 1) + L] = n == L ? eos : ignore_id;
+        ys_out[(long)b * (L + 1) + n] = eos;
+        if (s_bad) __hip_atomic_store(&g_lrs_target_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    if (s_bad) __builtin_trap();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -658,6 +674,15 @@ int svsr_lrs_targets(const int64_t* label, int B, int L, int odim, int64_t ignor
     hipLaunchKernelGGL(k_lrs_targets, dim3(B), dim3(256), 0, stream, (const long*)label, L, odim, (long)ignore_id, (long)eos, (long*)labels,
                        (long*)ys_in, (long*)ys_out);
     return svsr_check_launch();
+}
+
+/* 1 if a svsr_lrs_targets launch since the last reset met a label outside [1, odim) (it was replaced by eos), else 0; -1 if the word cannot be
+ * read.  Synchronises the device. */
+int svsr_lrs_target_errors(int reset) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_lrs_target_err), sizeof v) != hipSuccess) return -1;
+    if (reset && v != 0) { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lrs_target_err), &z, sizeof z); }
+    return v != 0 ? 1 : 0;
 }
 
 int svsr_embed_pos_fwd(const int64_t* tok, const float* emb, const float* pe, void* x, int R, int L, int D, float scale, hipStream_t stream) {

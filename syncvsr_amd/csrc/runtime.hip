@@ -58,14 +58,10 @@ extern "C" int svsr_tune(const char* key, int value) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Streams restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): the training step can give its main stream and
-// its weight-gradient side stream DISJOINT compute units (engine.TrainStep(cu_split=...)), and every persistent kernel sizes its grid by
-// the compute units of the stream it is launched on.  The registry is a handful of entries, written at stream creation only.
+// Compute units of the device: every persistent kernel sizes its grid / static tile list / cluster count by it.  (Round 5 also had
+// CU-masked streams here — main and side stream on disjoint compute units; slower at every split, DESIGN.md appendix — removed in round 6.)
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-struct StreamCus { hipStream_t stream; int cus; };
-StreamCus g_stream_cus[32];
-int g_n_stream_cus = 0;
 int device_cus() {
     static int per_dev[64];
     int d = 0;
@@ -80,38 +76,58 @@ int device_cus() {
 }
 }  // namespace
 
-int svsr_stream_cus(hipStream_t stream) {
-    for (int i = 0; i < g_n_stream_cus; ++i)
-        if (g_stream_cus[i].stream == stream) return g_stream_cus[i].cus;
-    return device_cus();
-}
+int svsr_stream_cus(hipStream_t) { return device_cus(); }
 
 extern "C" int svsr_device_cus(void) { return device_cus(); }
-extern "C" int svsr_stream_cu_count(hipStream_t stream) { return svsr_stream_cus(stream); }
 
-/* mask: `words` 32-bit words, bit i set = compute unit i of the driver's numbering may run the stream's kernels (on gfx942 / gfx950 bit i
- * is XCD i % 8, then shader engine, then CU: scripts/probes/cumask_probe.hip prints the map) */
-extern "C" int svsr_stream_create_cumask(const uint32_t* mask, int words, hipStream_t* out) {
-    if (mask == nullptr || out == nullptr || words < 1 || words > 64 || g_n_stream_cus >= 32) return SVSR_ERR_ARG;
-    int n = 0;
-    for (int w = 0; w < words; ++w) n += __builtin_popcount(mask[w]);
-    const int dev = device_cus();
-    if (n < 1) return SVSR_ERR_ARG;
-    hipError_t e = hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask);
-    if (e != hipSuccess) return (int)e;
-    g_stream_cus[g_n_stream_cus].stream = *out;
-    g_stream_cus[g_n_stream_cus].cus = n < dev ? n : dev;
-    ++g_n_stream_cus;
-    return SVSR_OK;
+// ---------------------------------------------------------------------------------------------------------------------
+// Test aid: a FOREIGN RESIDENT KERNEL — `workgroups` workgroups of 256 threads that each hold `lds_bytes` of LDS and sleep-poll a word of
+// pinned host memory until svsr_debug_occupy_stop() sets it (or ~4 s pass: the kernel can never hang the device).  It stands in for a
+// peer-waiting collective kernel of another process / stream that sits on some compute units while a training step runs
+// (tests/test_gpu_cotenant.py: the fused encoder must fall back instead of dying, everything else must only get slower).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+unsigned* g_occupy_flag = nullptr;        // pinned host word
+unsigned* g_occupy_flag_dev = nullptr;
+
+__global__ __launch_bounds__(256) void k_debug_occupy(const unsigned* stop, unsigned* sink) {
+    extern __shared__ unsigned occ_lds[];
+    occ_lds[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+            __builtin_amdgcn_s_sleep(127);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) break;
+        }
+    }
+    __syncthreads();
+    if (occ_lds[(threadIdx.x + 1) & 255] == 0xffffffffu) sink[0] = 1;          // (keeps the LDS allocation alive)
+}
+}  // namespace
+
+extern "C" int svsr_debug_occupy_start(int workgroups, int lds_bytes, hipStream_t stream) {
+    if (workgroups < 1 || workgroups > 1024 || lds_bytes < 1024 || lds_bytes > 160 * 1024) return SVSR_ERR_ARG;
+    if (g_occupy_flag == nullptr) {
+        void* h = nullptr;
+        hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped);
+        if (e != hipSuccess) return (int)e;
+        void* d = nullptr;
+        e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) { (void)hipHostFree(h); return (int)e; }
+        g_occupy_flag = static_cast<unsigned*>(h);
+        g_occupy_flag_dev = static_cast<unsigned*>(d);
+    }
+    *static_cast<volatile unsigned*>(g_occupy_flag) = 0;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(k_debug_occupy, dim3(workgroups), dim3(256), lds_bytes, stream, g_occupy_flag_dev, g_occupy_flag_dev + 8);
+    return svsr_check_launch();
 }
 
-extern "C" int svsr_stream_destroy(hipStream_t stream) {
-    for (int i = 0; i < g_n_stream_cus; ++i)
-        if (g_stream_cus[i].stream == stream) {
-            g_stream_cus[i] = g_stream_cus[--g_n_stream_cus];
-            return (int)hipStreamDestroy(stream);
-        }
-    return SVSR_ERR_ARG;
+extern "C" int svsr_debug_occupy_stop(void) {
+    if (g_occupy_flag == nullptr) return SVSR_ERR_ARG;
+    *static_cast<volatile unsigned*>(g_occupy_flag) = 1;
+    return SVSR_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -78,35 +78,12 @@ class TrainStep:
 
     def __init__(self, model, config: Optional[Config] = None, process_group=None,
                  use_graph: bool = False, bucket_mb: float = 32.0, always_reduce: bool = False, data_parallel: bool = True,
-                 grad_comm_dtype: torch.dtype = torch.float32, native: bool = False, cu_split: Optional[tuple] = None):
+                 grad_comm_dtype: torch.dtype = torch.float32, native: bool = False):
         """native=True: the launch sequence of the first step is recorded into a native step list (csrc/steplist.hip) and every
         later step re-issues it with one library call per segment — eager launches on the same streams (the weight-gradient side
         stream keeps overlapping, which a captured HIP graph loses) without the per-launch host cost of the Python loop.  Batch
-        shapes are fixed by the first call, as with use_graph.
-        cu_split=(side_cus, layout): the step runs on two CU-masked HIP streams with DISJOINT compute units (ops.cu_split_masks): `side_cus`
-        of them for the side stream (weight gradients, parameter-gradient reductions, the larger part of AdamW), the rest for the main
-        stream; persistent kernels size their grids by their stream's share.  step() moves onto the main stream itself (and hands the
-        results back to the caller's stream); a caller that already runs on `self.main_stream` skips both hand-overs."""
+        shapes are fixed by the first call, as with use_graph."""
         self.model = model
-        self.main_stream: Optional[torch.cuda.Stream] = None
-        if cu_split is not None:
-            if use_graph:
-                raise ValueError("cu_split places eager launches on two masked streams; a captured HIP graph replays on its own queues")
-            side_cus, layout = (cu_split if isinstance(cu_split, (tuple, list)) else (cu_split, "spread"))
-            if str(layout) == "reserve":
-                # asymmetric: the side stream is confined to `side_cus` compute units (the first side_cus / 8 of every XCD), the main stream stays
-                # unmasked — the remaining compute units are never held by a weight-gradient workgroup, so the main stream's small launches
-                # (statistics finalisers, column sums) always find a free one
-                if int(side_cus) % 8 != 0 or not 0 < int(side_cus) < ops.device_cus():
-                    raise ValueError("cu_split=(side_cus, 'reserve'): side_cus must be a multiple of 8 below the device's compute-unit count")
-                model._side.stream = ops.create_masked_stream(list(range(int(side_cus))))
-                # a CU-masked stream is a BLOCKING stream (hipExtStreamCreateWithCUMask takes no flags): it synchronises implicitly with the null
-                # stream, i.e. with torch's default stream — the step has to live on a non-blocking stream of its own or every launch serialises
-                self.main_stream = torch.cuda.Stream()
-            else:
-                main_bits, side_bits = ops.cu_split_masks(int(side_cus), str(layout))
-                self.main_stream = ops.create_masked_stream(main_bits)
-                model._side.stream = ops.create_masked_stream(side_bits)
         self.is_lrw = isinstance(model, TransformerLightningModule)
         if self.is_lrw:            # LRW/video/config/*.yaml: optim.optimizer / optim.scheduler / train.gradient_clip_val
             cfg = config or model.config
@@ -144,6 +121,7 @@ class TrainStep:
         if self.native and getattr(model, "layer_drop_p", 0.0) > 0.0:
             raise NotImplementedError("layer_dropout changes the launch sequence from step to step: it cannot be replayed from a recorded list")
         self._rec: Optional[ops.StepRecorder] = None
+        self.fused_encoder_fallbacks = 0        # times _watch_fused_encoder switched the encoder to the launch chain
         self.host_ms: list[float] = []          # host time of the last steps' enqueue (bench.py reports the median)
         if use_graph and getattr(model, "layer_drop_p", 0.0) > 0.0:
             raise NotImplementedError("layer_dropout skips whole encoder blocks at random: the launch sequence differs from step to "
@@ -202,6 +180,9 @@ class TrainStep:
         runs, long before the backward's main-stream writers): the 128 MB (LRW) / 1 GB (LRS) fill leaves the main stream, where it sat in front
         of the backward (17 / 140 us).  The backward's own zero_grad() then finds `grad_clean` set and does nothing."""
         model = self.model
+        # (a step that aborted between its backward and its optimiser — an exception in the training loop — must not leave its handshake
+        # behind: the flag is only valid for the step that set it)
+        st.__dict__.pop("sumsq_tail_done", None)
         # no collective between the backward and the clip: the model may sum the squares of every gradient but the last while that one is
         # computed (set per step: two TrainSteps may drive one model, each with its own optimiser state)
         model._early_sumsq = self.opt_state if (self.dp is None and ops.EARLY_SUMSQ) else None
@@ -266,7 +247,12 @@ class TrainStep:
             if not model.training:
                 raise RuntimeError("TrainStep(native=True) records a TRAINING step: call model.train() first")
             prepped = model.prepare_batch(*batch)
-            self._static = [t.clone() if torch.is_tensor(t) else t for t in prepped]
+            if self._static is None:
+                self._static = [t.clone() if torch.is_tensor(t) else t for t in prepped]
+            else:                        # recorded again (_watch_fused_encoder): the input buffers a loader may be writing into stay the same
+                for dst, src in zip(self._static, prepped):
+                    if torch.is_tensor(dst) and dst.data_ptr() != src.data_ptr():
+                        dst.copy_(src)
             st = model.store()
             if not st.shadow_fresh:
                 st.refresh_shadows()
@@ -318,15 +304,31 @@ class TrainStep:
     def step(self, *batch):
         """One optimisation step; returns the model's outputs (LRW: the dict of five scalars; LRS: the 5-tuple).
         With use_graph / native the batch shapes are fixed by the first call (later batches are copied into the static buffers)."""
-        if self.main_stream is not None:
-            cur = torch.cuda.current_stream()
-            if cur != self.main_stream:
-                self.main_stream.wait_stream(cur)
-                with torch.cuda.stream(self.main_stream):
-                    out = self._step(*batch)
-                cur.wait_stream(self.main_stream)
-                return out
-        return self._step(*batch)
+        self._watch_fused_encoder()
+        try:
+            return self._step(*batch)
+        except BaseException:
+            # an aborted step must not leave its early-sum-of-squares handshake pointing at this optimiser's state (a later stand-alone
+            # backward would write partial sums into it and the next optimiser step would trust them)
+            self.model._early_sumsq = None
+            self.model.store().__dict__.pop("sumsq_tail_done", None)
+            raise
+
+    def _watch_fused_encoder(self) -> None:
+        """Automatic fall-back of the fused encoder (csrc/enc_fused.hip).  Its launches need the 8 workgroups of a sequence resident together;
+        when a bounded cluster wait gives up (a co-tenant kernel holding LDS or compute units — e.g. a peer-waiting collective kernel), the
+        launch poisons its output with NaN and sets a flag that is also stored into pinned host memory.  The poisoned step updates nothing
+        (svsr_adamw_step skips a step whose gradient norm is not finite); here, before the next step is enqueued, the flag is read WITHOUT a
+        synchronisation and the encoder is re-routed to the per-layer launch chain for the rest of the run: the recorded list / captured
+        graph is dropped and re-made on that path.  At most the steps already enqueued when the wait gave up are lost (skipped)."""
+        if not self.is_lrw or not ops.enc_gave_up_peek():
+            return
+        torch.cuda.synchronize()
+        ops.check_enc_clusters(reset=True)
+        ops.disable_enc_fused("a cluster wait of svsr_enc_fwd / svsr_enc_bwd gave up (its workgroups were not resident together)")
+        self.fused_encoder_fallbacks += 1
+        self._rec = None                 # native: record the step again (now on the chain)
+        self._graph = None               # graph: capture again
 
     def _step(self, *batch):
         if self.native:
@@ -361,7 +363,12 @@ class TrainStep:
 
     def _capture(self, *batch) -> None:
         ops.PLAN_CACHE_PINNED = True       # the captured launches reference the plans' device words
-        self._static = [t.clone() for t in batch]
+        if self._static is None:
+            self._static = [t.clone() for t in batch]
+        else:                            # captured again (_watch_fused_encoder): same input buffers
+            for dst, src in zip(self._static, batch):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
         # warm-up on a side stream (allocator pools, hipFuncSetAttribute, lazy module loads), state restored afterwards
         st = self.model.store()
         snap = (st.flat.clone(), self.m.clone(), self.v.clone(), self.opt_state.clone(),
@@ -405,6 +412,7 @@ class TrainStep:
         self.m.copy_(sd["exp_avg"])
         self.v.copy_(sd["exp_avg_sq"])
         self.opt_state[:4].copy_(sd["opt_state"][:4])
+        self.opt_state[1] = 0                    # (word 1 counts the skipped steps of THIS run; older checkpoints kept a float there)
         if "dropout_word" in sd and hasattr(self.model, "load_rng_state"):
             rs = {"dropout_word": int(sd["dropout_word"].reshape(-1)[0])}
             if "layer_rng" in sd:
@@ -416,14 +424,18 @@ class TrainStep:
 
     # -- introspection ------------------------------------------------------------------------------
     def state(self) -> dict[str, float]:
-        """{step, lr, grad_norm} of the last optimiser step (a host synchronisation).  Raises if a fused-encoder launch of this process had a
-        cluster wait give up (csrc/enc_fused.hip: its 8 workgroups per sequence were not resident together — the results of that step were
-        poisoned with NaN, the run must not continue on them)."""
+        """{step, lr, grad_norm, skipped_steps} of the last optimiser step (a host synchronisation).  skipped_steps counts steps whose gradient
+        norm was not finite: they updated nothing and did not advance `step` (svsr_adamw_step).  A fused-encoder launch whose cluster wait
+        gave up (csrc/enc_fused.hip) produces such a step; it is picked up here as well as before every step (_watch_fused_encoder): the
+        encoder continues on the per-layer launch chain, with a warning."""
         self.synchronize()
         raw = self.opt_state.cpu()
-        ops.check_enc_clusters()
+        if self.is_lrw and ops.check_enc_clusters(reset=False):
+            self._watch_fused_encoder()
+        if not self.is_lrw and hasattr(self.model, "check_targets"):
+            self.model.check_targets()          # a label outside [1, odim) reached svsr_lrs_targets: raises with the cause
         f = raw.view(torch.float32)
-        return {"step": int(raw[0]), "lr": float(f[2]), "grad_norm": float(f[3])}
+        return {"step": int(raw[0]), "lr": float(f[2]), "grad_norm": float(f[3]), "skipped_steps": int(raw[1])}
 
 
 def reduce_metrics(metrics, process_group=None):

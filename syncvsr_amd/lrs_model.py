@@ -308,21 +308,32 @@ class E2E(nn.Module):
         return self._pos_cache[key]
 
     def prepare_targets(self, label: torch.Tensor) -> LrsTargets:
-        """label int64 [B,1,L] or [B,L], padded with ignore_id at the tail -> device tensors (no host sync)."""
+        """label int64 [B,1,L] or [B,L], padded with ignore_id (dropped wherever it sits in a row, as the reference's add_sos_eos does; a tail
+        is the usual case) -> device tensors (no host sync).  Token ids must lie in [1, odim) — 0 is the CTC blank: torch's Embedding /
+        CTCLoss stop on anything else with a device assert; the device kernel replaces such a token by eos and sets a sticky error word
+        that check_targets() / TrainStep.state() turn into an exception."""
         B = label.size(0)
         lab = label.reshape(B, -1).long()
         if lab.is_cuda:         # one launch (svsr_lrs_targets) instead of the ~20 index operations below, which stay the host-side form
             return LrsTargets(*ops.lrs_targets(lab, self.odim, self.ignore_id, self.eos))
         live = lab != self.ignore_id
+        if bool(((lab < 1) | (lab >= self.odim))[live].any()):
+            raise ValueError(f"labels must lie in [1, {self.odim}) (0 is the CTC blank)")
+        order = torch.argsort((~live).to(torch.int8), dim=1, stable=True)           # live tokens first, in their order
+        lab, live = lab.gather(1, order), live.gather(1, order)
         n = live.sum(1, keepdim=True)
-        # (token ids must lie in [1, odim) — 0 is the CTC blank — and the ignore_id padding must be a tail: the device kernel traps otherwise,
-        # as torch's Embedding / CTCLoss would; the host form is only used for checks)
         eos = torch.full_like(lab[:, :1], self.eos)
         ys_in = torch.cat([eos, torch.where(live, lab, eos)], dim=1).contiguous()                  # sos == eos (e2e:111-112)
         ys_out = torch.cat([lab, torch.full_like(lab[:, :1], self.ignore_id)], dim=1)
         ys_out = torch.where(live.new_zeros(ys_out.shape).scatter_(1, n, True), torch.full_like(ys_out, self.eos), ys_out)
         labels = torch.where(live, lab, torch.full_like(lab, -1)).contiguous()
         return LrsTargets(labels, ys_in, ys_out.contiguous())
+
+    def check_targets(self) -> None:
+        """Raises if a batch handed to prepare_targets since the last check held a label outside [1, odim) (synchronises the device)."""
+        if ops.lrs_target_errors(reset=True):
+            raise ValueError(f"a label outside [1, {self.odim}) reached svsr_lrs_targets (0 is the CTC blank, ignore_id = {self.ignore_id} marks "
+                             f"padding): it was replaced by eos, the losses of that batch are meaningless")
 
     # ------------------------------------------------------------------------------------------------
     # inference surface (syncvsr_amd/lrs_infer.py): model.encoder(xs, masks), model.decoder.batch_score(...), model.ctc.log_softmax(...)
@@ -642,6 +653,7 @@ def _decoder_bwd(model: E2E, st: _ParamStore, tape: dict, tg: LrsTargets, dpred,
     to = tape["dec_out"]
     L, Vp, V = to["L"], to["Vp"], model.odim
     R = B * L
+    model._wg_group = None      # (a backward that aborted inside a layer must not leave its half-filled group: the launches below would join it and be dropped)
     dtn = _lin_bwd(model, st, "decoder.output_layer", to["tn"], dpred, R, D, V, dy_pitch=Vp)
     # (every LayerNorm backward below also writes the gradient of the residual branch that follows it: _ln_bwd's `branch`)
     dx = _ln_bwd(model, st, dtn, to["x"], "decoder.after_norm", to["m"], to["r"],

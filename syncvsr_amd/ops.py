@@ -96,7 +96,7 @@ def _query(name: str, *args) -> tuple:
     if hit is not None:
         return hit
     fn = getattr(_lib.load(), name)
-    if name.endswith(("_rows", "_rows_on", "_bytes", "_floats")):
+    if name.endswith(("_rows", "_bytes", "_floats")):
         out = (int(fn(*args)),)
     else:
         nout = {"svsr_conv3x3_wgrad_plan": (1, 1),
@@ -333,42 +333,6 @@ def stream_wait(waiter: torch.cuda.Stream, signaller: torch.cuda.Stream) -> None
 def device_cus() -> int:
     """Compute units of the current device."""
     return int(_lib.load().svsr_device_cus())
-
-
-def stream_cus(stream: Optional[torch.cuda.Stream] = None) -> int:
-    """Compute units the launches of `stream` (default: the current one) may use."""
-    return int(_lib.load().svsr_stream_cu_count(_stream() if stream is None else stream.cuda_stream))
-
-
-def cu_split_masks(side_cus: int, layout: str = "spread", total: Optional[int] = None) -> tuple[list[int], list[int]]:
-    """Bit lists (compute-unit indices in the driver's numbering) of a main / side partition of the chip with `side_cus` compute units
-    on the side.  Measured with scripts/probes/cumask_probe.hip on MI355X / ROCm 7.2: bit i is XCD i % 8 (then shader engine, then CU),
-    and an XCD whose slice of the mask is ALL ZERO runs the stream's kernels on all of its compute units — a mask cannot exclude a whole
-    XCD, so the only partition that holds is "spread": the side stream gets the top side_cus / 8 compute units of EVERY XCD, the main
-    stream the rest (block b of a main-stream launch still lands on XCD b % 8)."""
-    total = device_cus() if total is None else total
-    if layout != "spread":
-        raise ValueError("only layout 'spread' exists (an all-zero XCD slice of a CU mask means 'unmasked': whole XCDs cannot be taken away)")
-    if side_cus % 8 != 0 or not 0 < side_cus < total:
-        raise ValueError("the same number of compute units is taken from each of the 8 XCDs: side_cus must be a multiple of 8")
-    side = list(range(total - side_cus, total))
-    return list(range(total - side_cus)), side
-
-
-_MASKED_STREAMS: list = []
-
-
-def create_masked_stream(bits: Sequence[int]) -> torch.cuda.Stream:
-    """A HIP stream whose kernels run only on the compute units `bits` (svsr_stream_create_cumask), as a torch stream object."""
-    words = (max(bits) + 32) // 32
-    mask = (ctypes.c_uint32 * words)()
-    for b in bits:
-        mask[b // 32] |= 1 << (b % 32)
-    out = ctypes.c_void_p(0)
-    _lib.check(_lib.load().svsr_stream_create_cumask(mask, words, ctypes.byref(out)), "svsr_stream_create_cumask")
-    s = torch.cuda.ExternalStream(out.value)
-    _MASKED_STREAMS.append(s)
-    return s
 
 
 def memset(t: torch.Tensor, value: int = 0) -> None:
@@ -636,7 +600,7 @@ def conv3x3_c64(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, addend: Op
     dy, dx, tw = zip(*taps)
     stats = st = None
     if want_stats:
-        rows = _query("svsr_conv3x3_c64_stat_rows_on", N, H, W, _stream())[0]
+        rows = _query("svsr_conv3x3_c64_stat_rows", N, H, W)[0]
         stats = scratch(rows * 2 * 64)
         st = (stats, rows)
     _call("svsr_conv3x3_c64", _p(x), _p(wt), _p(out), _p(addend), _p(stats), N, H, W, _ints(dy), _ints(dx), _ints(tw), _p(c64_pixtab(N, H, W, x.device)), _stream(),
@@ -686,7 +650,7 @@ def conv2d_dgrad_bn(dy: torch.Tensor, w16t: torch.Tensor, k: int, stride: int, p
     if stride == 1 and _c64_ok(Ci, Co, k, stride, pad, W):
         taps = tuple((pad - kh, pad - kw, kh * k + kw) for kh in range(k) for kw in range(k))
         tdy, tdx, tw = zip(*taps)
-        rows = _query("svsr_conv3x3_c64_stat_rows_on", N, H, W, _stream())[0]
+        rows = _query("svsr_conv3x3_c64_stat_rows", N, H, W)[0]
         stats = scratch(rows * 2 * 64)
         _call("svsr_conv3x3_c64_dgrad_bn", _p(dy), _p(w16t), _p(g), _p(addend), _p(stats), N, H, W, _ints(tdy), _ints(tdx), _ints(tw),
               _p(y), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), act, _p(c64_pixtab(N, H, W, dy.device)), _stream(), label="k_conv3x3_c64+bn", flops=2.0 * N * H * W * 64 * 64 * 9)
@@ -1050,13 +1014,37 @@ ENC_FUSED = os.environ.get("SVSR_ENC_FUSED", "1") != "0"     # the whole encoder
 _ENC_WS: dict = {}
 
 
-def check_enc_clusters(reset: bool = True) -> None:
-    """Raises if any svsr_enc_fwd / svsr_enc_bwd launch since the last check had a bounded cluster wait give up (synchronises the device)."""
+_ENC_FUSED_USED = False      # a fused-encoder launch has been issued by this process (svsr_enc_fwd / svsr_enc_bwd)
+
+
+def enc_gave_up_peek() -> bool:
+    """True once a fused-encoder launch had a bounded cluster wait give up — read from pinned host memory, NO synchronisation (the value may
+    trail the device by the flight time of one store): engine.TrainStep looks at it before every step."""
+    return _ENC_FUSED_USED and bool(_lib.load().svsr_enc_gave_up_peek())
+
+
+def check_enc_clusters(reset: bool = True) -> bool:
+    """True if any svsr_enc_fwd / svsr_enc_bwd launch since the last reset had a bounded cluster wait give up (synchronises the device; not
+    called at all while no fused launch has been issued).  Raises when the flag itself cannot be read (a sticky HIP error, the wrong device)."""
+    if not _ENC_FUSED_USED:
+        return False
     rc = int(_lib.load().svsr_enc_gave_up(1 if reset else 0))
-    if rc != 0:
-        raise _lib.SvsrError("a fused-encoder launch (svsr_enc_fwd / svsr_enc_bwd) gave up waiting for the workgroups of a sequence: they were not "
-                             "resident together (CU-masked or partitioned device, a co-tenant kernel holding LDS).  Its outputs were poisoned with "
-                             "NaN.  Run with SVSR_ENC_FUSED=0 SVSR_ENC_BWD_FUSED=0 (the per-layer launch chain) on such a device.")
+    if rc < 0:
+        raise _lib.SvsrError("svsr_enc_gave_up could not read the fused encoder's error word (hipMemcpyFromSymbol failed: an earlier HIP error is "
+                             "pending on this device, or the library was loaded for another one)")
+    return rc == 1
+
+
+def disable_enc_fused(why: str) -> None:
+    """Routes the word-level encoder to the per-layer launch chain for the rest of the process (a cluster wait gave up: the 8 workgroups of a
+    sequence were not resident together — a co-tenant kernel holding LDS or compute units, a partitioned device)."""
+    global ENC_FUSED, ENC_BWD_FUSED
+    import warnings
+
+    if ENC_FUSED or ENC_BWD_FUSED:
+        warnings.warn(f"fused encoder disabled: {why}; the encoder runs on the per-layer launch chain (svsr_igemm_fwd / svsr_mha_fwd / "
+                      f"svsr_add_ln_fwd ...) from here on", RuntimeWarning, stacklevel=2)
+    ENC_FUSED = ENC_BWD_FUSED = False
 
 
 def enc_fused_ok(D: int, H: int, inter: int, S: int) -> bool:
@@ -1082,6 +1070,8 @@ def enc_fwd(x0: torch.Tensor, layers: Sequence[dict], B: int, S: int, eps: float
             for name, _ in _EncLayer._fields_[:25]:
                 setattr(rec, name, q[name].data_ptr())
             rec.site_probs, rec.site_ao, rec.site_fo, rec.pad_ = int(q["site_probs"]), int(q["site_ao"]), int(q["site_fo"]), 0
+        global _ENC_FUSED_USED
+        _ENC_FUSED_USED = True
         _call("svsr_enc_fwd", _p(x), arr, len(chunk), B, S, float(eps), _p(seed), float(p_hidden), float(p_attn), _p(ws), nbytes, _stream(),
               label="k_enc_fwd", flops=float(len(chunk)) * 2.0 * B * S * (4 * 512 * 512 + 2 * 512 * 2048) + float(len(chunk)) * 4.0 * B * 8 * S * S * 64)
         x = chunk[-1]["xout"]
@@ -1117,6 +1107,8 @@ def enc_bwd(dy: torch.Tensor, layers: Sequence[dict], B: int, S: int, seed: Opti
             setattr(rec, name, q[name].data_ptr())
         rec.site_probs, rec.site_ao, rec.site_fo, rec.pad_ = int(q["site_probs"]), int(q["site_ao"]), int(q["site_fo"]), 0
     n = len(layers)
+    global _ENC_FUSED_USED
+    _ENC_FUSED_USED = True
     _call("svsr_enc_bwd", _p(dy), arr, n, B, S, _p(seed), float(p_hidden), float(p_attn), _p(ws), nbytes, _stream(),
           label="k_enc_bwd", flops=float(n) * 2.0 * B * S * (4 * 512 * 512 + 2 * 512 * 2048) + float(n) * 8.0 * B * 8 * S * S * 64)
 
@@ -1398,7 +1390,8 @@ def glu_dwconv_bwd(dc, u, w, dw, dbias, B: int, T: int, D: int, K: int) -> torch
 
 
 def lrs_targets(label: torch.Tensor, odim: int, ignore_id: int, eos: int):
-    """label int64 [B, L] on the device, ignore_id at the tail -> (labels [B, L] with -1, ys_in [B, L+1], ys_out [B, L+1]): add_sos_eos in one launch"""
+    """label int64 [B, L] on the device, ignore_id padding (anywhere in a row: dropped) -> (labels [B, L] with -1, ys_in [B, L+1], ys_out [B, L+1]):
+    add_sos_eos in one launch.  A label outside [1, odim) becomes eos and sets the sticky word lrs_target_errors() reads."""
     B, L = label.shape
     label = label.contiguous()
     labels = torch.empty_like(label)
@@ -1406,6 +1399,14 @@ def lrs_targets(label: torch.Tensor, odim: int, ignore_id: int, eos: int):
     ys_out = torch.empty_like(ys_in)
     _call("svsr_lrs_targets", _p(label), B, L, odim, ignore_id, eos, _p(labels), _p(ys_in), _p(ys_out), _stream())
     return labels, ys_in, ys_out
+
+
+def lrs_target_errors(reset: bool = True) -> bool:
+    """True if a svsr_lrs_targets launch since the last reset met a label outside [1, odim) (synchronises the device)."""
+    rc = int(_lib.load().svsr_lrs_target_errors(1 if reset else 0))
+    if rc < 0:
+        raise _lib.SvsrError("svsr_lrs_target_errors could not read the error word (an earlier HIP error is pending on this device)")
+    return rc == 1
 
 
 def ctc_fwd(logits, ld: int, labels, ilen, B: int, T: int, V: int):

@@ -186,6 +186,28 @@ def test_lrs_targets_equal_add_sos_eos():
         ref_in, ref_out = O.add_sos_eos([y[y != ignore] for y in label], odim - 1, odim - 1)
         assert torch.equal(ys_in.cpu(), ref_in) and torch.equal(ys_out.cpu(), ref_out)
         assert torch.equal(labels.cpu(), label)
+        # ignore_id INSIDE a row is dropped, as the reference's `y[y != ignore_id]` drops it (add_sos_eos.py:26-27, ctc.py's own filter)
+        holes = label.clone()
+        holes[torch.rand(B, L, generator=g) < 0.3] = ignore
+        holes[0, 0] = 7                     # (at least one live token per row keeps the reference's pad_list happy)
+        holes[:, -1] = torch.where(holes[:, -1] == ignore, torch.ones_like(holes[:, -1]), holes[:, -1])
+        labels, ys_in, ys_out = ops.lrs_targets(holes.to(dev), odim, ignore, odim - 1)
+        live = [y[y != ignore] for y in holes]
+        ref_in, ref_out = O.add_sos_eos(live, odim - 1, odim - 1)
+        pad = L + 1 - ref_in.shape[1]       # (the reference pads to the longest LIVE row; the kernel to L + 1)
+        ref_in = torch.nn.functional.pad(ref_in, (0, pad), value=odim - 1)
+        ref_out = torch.nn.functional.pad(ref_out, (0, pad), value=ignore)
+        assert torch.equal(ys_in.cpu(), ref_in) and torch.equal(ys_out.cpu(), ref_out)
+        want = torch.full((B, L), -1, dtype=torch.int64)
+        for b, y in enumerate(live):
+            want[b, : len(y)] = y
+        assert torch.equal(labels.cpu(), want)
+    # a label outside [1, odim) does not trap: it becomes eos and a sticky error word is set
+    assert not ops.lrs_target_errors(reset=True)
+    bad = torch.tensor([[3, odim + 5, 4, ignore], [0, 2, ignore, ignore]], dtype=torch.int64)
+    labels, ys_in, ys_out = ops.lrs_targets(bad.to(dev), odim, ignore, odim - 1)
+    assert labels.cpu().tolist() == [[3, odim - 1, 4, -1], [odim - 1, 2, -1, -1]]
+    assert ops.lrs_target_errors(reset=True) and not ops.lrs_target_errors(reset=True)
 
 
 @pytest.mark.parametrize("B,T,V,lens,ylens", [(2, 7, 11, [7, 5], [3, 2]), (3, 40, 41, [40, 25, 31], [10, 4, 12]), (4, 150, 5049, [150, 90, 120, 6], [40, 12, 25, 8])])

@@ -321,7 +321,7 @@ def test_step_list_registry_covers_every_stream_entry_point():
 
     lib = _lib.load()
     hdr = _lib.parse_header()
-    plumbing = {"svsr_stream_wait", "svsr_memset_async", "svsr_stream_destroy", "svsr_stream_cu_count", "svsr_conv3x3_c64_stat_rows_on"}      # (stream management / host-side queries, not launches)
+    plumbing = {"svsr_stream_wait", "svsr_memset_async", "svsr_debug_occupy_start"}      # (stream management / test aids, not launches of a step)
     launches = [n for n, a in hdr.items() if a and a[-1][0] == "hipStream_t" and not n.startswith("svsr_steplist") and n not in plumbing]
     assert len(launches) >= 50
     missing = [n for n in launches if not lib.svsr_steplist_knows(n.encode())]
