@@ -73,11 +73,15 @@ extern "C" {
 /* ---- plumbing (runtime.hip) ------------------------------------------------------------------------------------
  * svsr_tune: sets a result-preserving tuning knob ("igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd",
  * "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe",
- * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128": tile shapes, split counts, kernel-variant switches — documented at the table in runtime.hip;
- * never read from the environment); unknown key -> SVSR_ERR_ARG.
+ * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128", "wg_xcd", "w3_waves", "reduce_cus": tile shapes, split counts, kernel-variant switches — documented at the table in
+ * runtime.hip; never read from the environment); unknown key -> SVSR_ERR_ARG.  svsr_tune_value reads a knob back.  The knobs that decide
+ * the ORDER in which a weight gradient's or a BatchNorm statistic's partial sums are added (reduce_cus — the compute-unit count the splits
+ * are planned for: a fixed 256, not the device's —, wg_blocks, wg_units, wg_unit_max, wg_unit_min, wg_short_k, w3_blocks, w3_waves) are what a
+ * bit-identical resume depends on: engine.TrainStep.state_dict() records them, load_state_dict() warns when they differ.
  * svsr_colsum_rows: out[c] (+)= scale * sum_{r<nrows} ws[r*ld + c], rows added in a fixed order; columns [0,n0) go to out0,
  * [n0,n0+n1) to out1 (may be null when n1 = 0); accumulate != 0 adds to the existing values. */
 int svsr_tune(const char* key, int value);
+int svsr_tune_value(const char* key, int* value);
 int svsr_colsum_rows(const float* ws, int nrows, int64_t ld, float* out0, int64_t n0, float* out1, int64_t n1, int accumulate, float scale, hipStream_t stream);
 /* up to any number of svsr_colsum_rows problems, 16 per launch (the postponed parameter-gradient reductions of a layer's backward: LayerNorm
  * weight / bias, linear biases — autograd's accumulation into .grad of lightning.py's modules).  entries: n records of 64 bytes in HOST memory,
@@ -487,6 +491,11 @@ int svsr_memset_async(void* ptr, int value, int64_t bytes, hipStream_t stream);
 
 /* Compute units of the current device (persistent kernels size their grids, static tile lists and cluster counts by it). */
 int svsr_device_cus(void);
+
+/* Measurement aid: the effective shader clock.  `blocks` workgroups run iters x 4 MFMAs per wave and write {shader cycles (s_memtime),
+ * 100 MHz ticks (s_memrealtime)} of that block to out[b][2] (device int64, blocks * 2 + 1 words): MHz = 100 * sum(cycles) / sum(ticks).
+ * bench.py reads it before and after its sustained leg (the `sustained` object of its line). */
+int svsr_clock_probe(int64_t* out, int blocks, int iters, hipStream_t stream);
 
 /* Test aid (csrc/runtime.hip): a foreign resident kernel — `workgroups` workgroups x 256 threads, each holding lds_bytes of LDS, that sleep
  * until svsr_debug_occupy_stop() (or ~4 s).  Stands in for a peer-waiting collective kernel beside a training step of the reference's

@@ -9,7 +9,10 @@ from functools import lru_cache
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(PKG), "include", "syncvsr_hip.h")
-LIB_PATH = os.path.join(PKG, "libsyncvsr_hip.so")
+# SVSR_LIB_VARIANT=syncdbg: the test-only build whose counted LDS-DMA waits are all vmcnt(0) (csrc/common.h SVSR_SYNC_DEBUG; built by
+# `python -m syncvsr_amd.build --variant syncdbg`, loaded by the child process of tests/test_gpu_syncdbg.py).  Anything else: the product library.
+_VARIANT = os.environ.get("SVSR_LIB_VARIANT", "")
+LIB_PATH = os.path.join(PKG, f"libsyncvsr_hip_{_VARIANT}.so" if _VARIANT else "libsyncvsr_hip.so")
 
 _CTYPES = {
     "int": ctypes.c_int,

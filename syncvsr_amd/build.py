@@ -38,16 +38,28 @@ def headers() -> list[str]:
     return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(pub, "*.h"))
 
 
-def stale() -> bool:
-    if not os.path.exists(LIB):
+# build variants: "" = the product library; "syncdbg" = -DSVSR_SYNC_DEBUG (every counted s_waitcnt vmcnt(n) of the LDS-DMA pipelines is
+# vmcnt(0): csrc/common.h), a TEST library that tests/test_gpu_syncdbg.py compares the product's outputs with, bit for bit
+VARIANTS = {"": [], "syncdbg": ["-DSVSR_SYNC_DEBUG"]}
+
+
+def lib_path(variant: str = "") -> str:
+    return os.path.join(PKG, f"libsyncvsr_hip_{variant}.so") if variant else LIB
+
+
+def stale(variant: str = "") -> bool:
+    lib = lib_path(variant)
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = sources() + headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not stale():
+def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
+    LIB = lib_path(variant)
+    OBJ = os.path.join(PKG, "csrc", "_obj" + ("_" + variant if variant else ""))
+    if not force and not stale(variant):
         return LIB
     cc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
@@ -57,7 +69,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
-            cmd = [cc, *FLAGS, "-c", src, "-o", obj]
+            cmd = [cc, *FLAGS, *VARIANTS[variant], "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -77,4 +89,5 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    print(build(force="--force" in sys.argv, variant=_variant))

@@ -43,11 +43,16 @@ __device__ unsigned g_ah_zero_page[64];
 
 // s_waitcnt vmcnt(10 * later) + s_barrier with a compile-time immediate (10 LDS-DMA pieces per thread and stage)
 __device__ __forceinline__ void ah_wait_barrier(int later) {
+#ifdef SVSR_SYNC_DEBUG
+    (void)later;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
     if (later >= 4) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else if (later == 3) asm volatile("s_waitcnt vmcnt(30) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else if (later == 2) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else if (later == 1) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // The launch is latency-bound (2.4 GFLOP on 232 workgroups at the benchmark batch): the 32 hidden rows of a workgroup stay in LDS for the

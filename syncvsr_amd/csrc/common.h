@@ -16,10 +16,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // Result-preserving tuning knobs (runtime.hip): a process-wide table set through svsr_tune(); the library never reads the
 // environment.
 enum { SVSR_TUNE_IGEMM_TILE = 0, SVSR_TUNE_IGEMM_M128, SVSR_TUNE_WG_BLOCKS, SVSR_TUNE_W3_BLOCKS, SVSR_TUNE_LN_RPB,
-       SVSR_TUNE_STEM_LDS_FWD, SVSR_TUNE_STEM_LDS_BWD, SVSR_TUNE_IGEMM_LDS_PAD, SVSR_TUNE_IGEMM_BN64_BELOW, SVSR_TUNE_WG_SHORT_K, SVSR_TUNE_IGEMM_KSPLIT, SVSR_TUNE_EPI_BATCHED, SVSR_TUNE_STEM_WG_PIPE, SVSR_TUNE_STEM_FWD_DMA, SVSR_TUNE_IGEMM_LIN_BN64, SVSR_TUNE_P8, SVSR_TUNE_P8_GRID, SVSR_TUNE_P8_MIN_ITEMS, SVSR_TUNE_P8_PH, SVSR_TUNE_P8_STAGGER, SVSR_TUNE_WG_IMGMAJOR, SVSR_TUNE_P8_BN64, SVSR_TUNE_IGEMM_NS64, SVSR_TUNE_WG_UNITS, SVSR_TUNE_WG_UNIT_MAX, SVSR_TUNE_WG_UNIT_MIN, SVSR_TUNE_IGEMM_KSPLIT128, SVSR_TUNE_WG_XCD, SVSR_TUNE_W3_WAVES, SVSR_TUNE_N };
+       SVSR_TUNE_STEM_LDS_FWD, SVSR_TUNE_STEM_LDS_BWD, SVSR_TUNE_IGEMM_LDS_PAD, SVSR_TUNE_IGEMM_BN64_BELOW, SVSR_TUNE_WG_SHORT_K, SVSR_TUNE_IGEMM_KSPLIT, SVSR_TUNE_EPI_BATCHED, SVSR_TUNE_STEM_WG_PIPE, SVSR_TUNE_STEM_FWD_DMA, SVSR_TUNE_IGEMM_LIN_BN64, SVSR_TUNE_P8, SVSR_TUNE_P8_GRID, SVSR_TUNE_P8_MIN_ITEMS, SVSR_TUNE_P8_PH, SVSR_TUNE_P8_STAGGER, SVSR_TUNE_WG_IMGMAJOR, SVSR_TUNE_P8_BN64, SVSR_TUNE_IGEMM_NS64, SVSR_TUNE_WG_UNITS, SVSR_TUNE_WG_UNIT_MAX, SVSR_TUNE_WG_UNIT_MIN, SVSR_TUNE_IGEMM_KSPLIT128, SVSR_TUNE_WG_XCD, SVSR_TUNE_W3_WAVES, SVSR_TUNE_REDUCE_CUS, SVSR_TUNE_N };
 int svsr_tune_get(int id);
 // compute units of the device (runtime.hip).  Persistent kernels size their grids and static tile lists with it.
 int svsr_stream_cus(hipStream_t stream);
+// compute units ASSUMED where the split of a reduction is planned (weight-gradient unit lists, the layer1 kernel's BatchNorm partial rows): the
+// tuning knob reduce_cus (256), not the device's count — the association of every sum, and with it every bit of a training run, then is the
+// same on a partition of another size (a checkpoint resumed there continues bit for bit); 0 = follow the device (runtime.hip)
+int svsr_reduction_cus();
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((unsigned)u) << 16); }
 
@@ -147,6 +151,20 @@ static inline DropArgs svsr_make_drop(const unsigned* seed, unsigned site, float
     d.scale = on ? 1.0f / (1.0f - p) : 1.0f;
     return d;
 }
+
+// Counted waits of the LDS-DMA pipelines (s_waitcnt vmcnt(n), n > 0: tiles stay in flight across barriers).  A wait that counts one piece too
+// few, or a ring slot re-staged one phase too early, reads LDS bytes a DMA has not written yet — and passes every test whenever the DMA happens
+// to land first (guide: "place reads by the vmcnt / barrier count, never by clean runs").  The build variant -DSVSR_SYNC_DEBUG
+// (python -m syncvsr_amd.build --variant syncdbg -> libsyncvsr_hip_syncdbg.so) turns EVERY counted wait into vmcnt(0): no tile is in flight
+// when anything is read.  tests/test_gpu_syncdbg.py runs the benchmark shapes on both libraries and asserts bit-identical outputs — a
+// difference is a latent race.
+#ifdef SVSR_SYNC_DEBUG
+#define SVSR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define SVSR_WAIT_VM_BARRIER(n) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define SVSR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define SVSR_WAIT_VM_BARRIER(n) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(n) : "memory")
+#endif
 
 static inline int svsr_check_launch() {
     hipError_t e = hipGetLastError();

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(C64_THREADS) void k_conv3x3_c64(const Conv64Args p)
 }
 
 static int c64_grid(long total_chunks) {
-    const int cus = svsr_stream_cus(nullptr);
+    const int cus = svsr_reduction_cus();      // (a fixed number, not the device's: one BatchNorm partial row per persistent workgroup)
     return (int)(total_chunks < cus ? total_chunks : cus);
 }
 

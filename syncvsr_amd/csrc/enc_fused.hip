@@ -77,7 +77,7 @@ __device__ __forceinline__ u32x4 ld16_sc1(const bf16_t* p) {
     return v;
 }
 
-#define EF_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define EF_WAIT_VM(n) SVSR_WAIT_VM(n)      /* (vmcnt(0) in the SVSR_SYNC_DEBUG build: common.h) */
 #define EF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // arrival: every wave's payload stores have left (write-through), then one lane counts the workgroup in

@@ -349,7 +349,7 @@ __device__ __forceinline__ void igemm_mma_tile(const bf16_t* cA, const bf16_t* c
 template <int LPT, int MAXL>
 __device__ __forceinline__ void wait_tiles_barrier(int later) {
     if constexpr (MAXL > 0) {
-        if (later == MAXL) { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPT * MAXL) : "memory"); return; }
+        if (later == MAXL) { SVSR_WAIT_VM_BARRIER(LPT * MAXL); return; }
         wait_tiles_barrier<LPT, MAXL - 1>(later);
     } else {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");

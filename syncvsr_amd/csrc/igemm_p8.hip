@@ -44,7 +44,7 @@ __device__ __forceinline__ void glds4(const void* src, void* dst) {
 
 #define P8_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define P8_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define P8_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define P8_WAIT_VM(n) SVSR_WAIT_VM(n)      /* (vmcnt(0) in the SVSR_SYNC_DEBUG build: common.h) */
 #define P8_SYNC_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define P8_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")       /* LDS traffic only: global stores stay in flight */
 

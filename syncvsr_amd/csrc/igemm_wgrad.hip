@@ -72,7 +72,7 @@ __device__ __forceinline__ bf16x8 wg_frag_T(const bf16_t* tile, int ch0, int pos
 template <int LPT, int MAXL>
 __device__ __forceinline__ void wg_wait_tiles_barrier(int later) {
     if constexpr (MAXL > 0) {
-        if (later == MAXL) { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPT * MAXL) : "memory"); return; }
+        if (later == MAXL) { SVSR_WAIT_VM_BARRIER(LPT * MAXL); return; }
         wg_wait_tiles_barrier<LPT, MAXL - 1>(later);
     } else {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -513,7 +513,7 @@ static WgradLaunch wgrad_launch(long total_chunks_l, int Co, int Ci, int ntaps, 
     pl.tasks = ((Co + BC - 1) / BC) * ((Ci + BC - 1) / BC) * ntaps;
     // one round of resident workgroups: 2 per CU for the 128-wide tile (64 KiB of LDS ring, ~200 VGPRs), 3 per CU for the 64-wide
     // one — a grid a little above that runs a second, almost empty round (layer4: 576 workgroups on 512 slots took 1.4x longer)
-    const int cus = svsr_stream_cus(nullptr);
+    const int cus = svsr_reduction_cus();      // (a fixed number, not the device's: the split decides the order of the additions)
     const int target_env = svsr_tune_get(SVSR_TUNE_WG_BLOCKS);
     const int target_blocks = target_env > 0 ? target_env : cus * (BC == 128 ? 2 : 3);
     int splits = target_blocks / pl.tasks;                    // every split costs a slab of Co*taps*Ci floats written and re-read
@@ -537,7 +537,7 @@ static WgradLaunch wgrad_launch(long total_chunks_l, int Co, int Ci, int ntaps, 
 struct WgradUnits { std::vector<int> units, tasktab; int slots = 0; };
 
 static WgradUnits wgrad_units(const std::vector<long>& tap_chunks, int co_tiles, int ci_tiles, int bc) {
-    const int cus = svsr_stream_cus(nullptr);
+    const int cus = svsr_reduction_cus();      // (a fixed number, not the device's: the split decides the order of the additions)
     const int target_env = svsr_tune_get(SVSR_TUNE_WG_BLOCKS);
     const long resident = target_env > 0 ? target_env : (long)cus * (bc == 128 ? 2 : 3);
     const int umax = svsr_tune_get(SVSR_TUNE_WG_UNIT_MAX) > 0 ? svsr_tune_get(SVSR_TUNE_WG_UNIT_MAX) : 48;

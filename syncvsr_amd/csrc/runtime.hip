@@ -45,8 +45,9 @@ static int g_tune[SVSR_TUNE_N] = {
     /* IGEMM_KSPLIT128 */ 12,  // svsr_igemm_fwd: dense layers on <= 288 tiles of 128 x 64 with at least this many 64-deep K steps split K over two wave groups per workgroup (0: never)
     /* WG_XCD */ 1,            // svsr_igemm_wgrad unit lists of multi-tap plans: units dealt to the eight XCDs by the stretch of the contraction they cover (0: plain long-first order); same results
     /* W3_WAVES */ 8,          // waves per workgroup of svsr_conv3x3_wgrad: 8 (one workgroup per CU, the two wave groups split the nine taps: half the slabs, 138 instead of 247 registers per wave) or 4 (two workgroups per CU, nine taps per wave).  Round 5, same box: layer1 launch + reduce 80.1 -> 71.6 us at 928 frames, LRW step 5.03-5.05 -> 4.97-4.99 ms, LRS 23.69 -> 23.58-23.61
+    /* REDUCE_CUS */ 256,      // compute units assumed when the split of a reduction is planned (svsr_reduction_cus, common.h): fixed, so the bits of a run do not depend on the partition it runs on; 0: the device's count
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128", "wg_xcd", "w3_waves"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128", "wg_xcd", "w3_waves", "reduce_cus"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 
@@ -54,6 +55,13 @@ extern "C" int svsr_tune(const char* key, int value) {
     if (key == nullptr) return SVSR_ERR_ARG;
     for (int i = 0; i < SVSR_TUNE_N; ++i)
         if (strcmp(key, g_tune_names[i]) == 0) { g_tune[i] = value; return SVSR_OK; }
+    return SVSR_ERR_ARG;
+}
+
+extern "C" int svsr_tune_value(const char* key, int* value) {
+    if (key == nullptr || value == nullptr) return SVSR_ERR_ARG;
+    for (int i = 0; i < SVSR_TUNE_N; ++i)
+        if (strcmp(key, g_tune_names[i]) == 0) { *value = g_tune[i]; return SVSR_OK; }
     return SVSR_ERR_ARG;
 }
 
@@ -77,6 +85,7 @@ int device_cus() {
 }  // namespace
 
 int svsr_stream_cus(hipStream_t) { return device_cus(); }
+int svsr_reduction_cus() { const int v = svsr_tune_get(SVSR_TUNE_REDUCE_CUS); return v > 0 ? v : device_cus(); }
 
 extern "C" int svsr_device_cus(void) { return device_cus(); }
 
@@ -121,6 +130,37 @@ extern "C" int svsr_debug_occupy_start(int workgroups, int lds_bytes, hipStream_
     *static_cast<volatile unsigned*>(g_occupy_flag) = 0;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL(k_debug_occupy, dim3(workgroups), dim3(256), lds_bytes, stream, g_occupy_flag_dev, g_occupy_flag_dev + 8);
+    return svsr_check_launch();
+}
+
+// Effective shader clock: s_memtime counts shader cycles, s_memrealtime the constant 100 MHz reference; their ratio over a fixed block of
+// MFMA work (one wave per SIMD) is the clock the compute units ran at while it executed.  bench.py reads it before and after its sustained leg.
+namespace {
+typedef __attribute__((ext_vector_type(8))) short cp_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float cp_f32x16;
+__global__ __launch_bounds__(256) void k_clock_probe(long long* out, float* sink, int iters) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+    cp_f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+    cp_bf16x8 a, b;
+    for (int k = 0; k < 8; ++k) { a[k] = (short)(threadIdx.x * 5 + k * 321); b[k] = (short)(threadIdx.x * 3 + k * 77); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 16; ++k) s += acc[i][k];
+    if (s == 123.456f) sink[0] = s;
+    if (threadIdx.x == 0) { out[blockIdx.x * 2] = (long long)(c1 - c0); out[blockIdx.x * 2 + 1] = (long long)(w1 - w0); }
+}
+}  // namespace
+
+/* out: device int64 [blocks][2] = {shader cycles, 100 MHz ticks} of each workgroup's MFMA block (blocks x 256 threads, iters x 4 MFMAs per wave);
+ * the effective clock in MHz is 100 * sum(cycles) / sum(ticks).  out needs 8 more bytes behind it (a sink word). */
+extern "C" int svsr_clock_probe(int64_t* out, int blocks, int iters, hipStream_t stream) {
+    if (out == nullptr || blocks < 1 || iters < 1) return SVSR_ERR_ARG;
+    hipLaunchKernelGGL(k_clock_probe, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<long long*>(out), reinterpret_cast<float*>(out + 2 * (size_t)blocks), iters);
     return svsr_check_launch();
 }
 

@@ -397,7 +397,11 @@ class TrainStep:
         """Optimiser state for checkpointing (what Lightning stores next to the model's state_dict): AdamW moments as flat
         fp32 vectors in the parameter store's order, and the 16-byte device state {step, -, lr, grad-norm}."""
         self.synchronize()
-        sd = {"exp_avg": self.m.detach().clone(), "exp_avg_sq": self.v.detach().clone(), "opt_state": self.opt_state.detach().clone()}
+        sd = {"exp_avg": self.m.detach().clone(), "exp_avg_sq": self.v.detach().clone(), "opt_state": self.opt_state.detach().clone(),
+              # what the order of the additions inside a weight gradient / a BatchNorm statistic depends on (ops.REDUCTION_KNOBS; the
+              # compute-unit count the splits are planned for is one of them and is a fixed 256, not the device's): a resumed run is
+              # bit-identical when these agree
+              "reduction_plan": torch.tensor(ops.reduction_plan_params(), dtype=torch.int64)}
         if hasattr(self.model, "rng_state"):        # dropout seed word + layer-drop generator: a resumed run draws the same masks / skips
             rs = self.model.rng_state()
             sd["dropout_word"] = torch.tensor([rs["dropout_word"]], dtype=torch.int64)
@@ -412,6 +416,12 @@ class TrainStep:
         self.m.copy_(sd["exp_avg"])
         self.v.copy_(sd["exp_avg_sq"])
         self.opt_state[:4].copy_(sd["opt_state"][:4])
+        if "reduction_plan" in sd:
+            then, now = [int(x) for x in sd["reduction_plan"].tolist()], ops.reduction_plan_params()
+            if then != now:
+                diff = {k: (a, b) for k, a, b in zip(ops.REDUCTION_KNOBS, then, now) if a != b}
+                warnings.warn(f"this checkpoint was written with other reduction-split knobs {diff} (then, now): the resumed run is numerically "
+                              f"equivalent but not bit-identical to the original (ops.tune(key, value) restores them)")
         self.opt_state[1] = 0                    # (word 1 counts the skipped steps of THIS run; older checkpoints kept a float there)
         if "dropout_word" in sd and hasattr(self.model, "load_rng_state"):
             rs = {"dropout_word": int(sd["dropout_word"].reshape(-1)[0])}
@@ -482,6 +492,7 @@ class GradReducer:
         self._st = None
         self.measure = False                  # bench.py: time the join in finish() with HIP events (the collective time the step is exposed to)
         self._join_events: list = []
+        self._bucket_events: list = []        # measure=True: per step a list of (elements, ready event, done event), one per bucket in launch order
         self._backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self.top = 0
@@ -516,6 +527,22 @@ class GradReducer:
         self._join_events.clear()
         return t[len(t) // 2]
 
+    def bucket_times(self) -> list:
+        """measure=True: per bucket of a step (launch order) {mb, ready_ms: start of its all-reduce after the first bucket's start, ms: ready -> done
+        on the comm stream}, medians over the measured steps.  Synchronises the device."""
+        steps = [s for s in self._bucket_events if s]
+        if not steps:
+            return []
+        torch.cuda.synchronize()
+        n = min(len(s) for s in steps)
+        out = []
+        for i in range(n):
+            ready = sorted(s[0][1].elapsed_time(s[i][1]) for s in steps)
+            dur = sorted(s[i][1].elapsed_time(s[i][2]) for s in steps)
+            out.append({"mb": round(steps[0][i][0] * 4 / 2 ** 20, 2), "ready_ms": round(ready[len(ready) // 2], 4), "ms": round(dur[len(dur) // 2], 4)})
+        self._bucket_events.clear()
+        return out
+
     def _broadcast_buffers(self, st) -> None:
         """broadcast_buffers=True of DDP: the BatchNorm running statistics of every rank follow rank 0's — one collective over
         the flat buffer vector (model._ParamStore.bufflat).  num_batches_tracked advances identically on every rank."""
@@ -527,6 +554,10 @@ class GradReducer:
         st = self._st = self.model.store()         # (store() re-validates ~300 tensors: once per step, not once per hook call)
         self.top = st.decay_end
         self.launched = []
+        if self.measure:
+            self._bucket_events.append([])
+            if len(self._bucket_events) > 64:
+                del self._bucket_events[:32]
         if self.comm_stream is None and st.flat.is_cuda:
             self.comm_stream = torch.cuda.Stream(device=st.flat.device)
 
@@ -547,6 +578,9 @@ class GradReducer:
                 if side is not None and side.stream is not None and (side.enabled or side.enabled_small):
                     self.comm_stream.wait_stream(side.stream)                 # ... and, for weight gradients, on the model's side stream
             with torch.cuda.stream(self.comm_stream):
+                if self.measure and self._bucket_events:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()              # on the comm stream, behind its waits: the bucket's producers are done
                 if self.comm_dtype == torch.bfloat16:
                     if self._comm_buf is None or self._comm_buf.numel() < seg.numel():      # on the comm stream, used only there
                         self._comm_buf = torch.empty(max(seg.numel(), self.bucket_elems), dtype=torch.bfloat16, device=seg.device)
@@ -561,6 +595,9 @@ class GradReducer:
                     wire.div_(self.world)
                 if wire is not seg:
                     seg.copy_(wire)
+                if self.measure and self._bucket_events:
+                    ev1.record()
+                    self._bucket_events[-1].append((hi - lo, ev0, ev1))
         else:
             dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
             seg.div_(self.world)

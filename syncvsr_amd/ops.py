@@ -111,6 +111,22 @@ def _query(name: str, *args) -> tuple:
     return out
 
 
+REDUCTION_KNOBS = ("reduce_cus", "wg_blocks", "wg_units", "wg_unit_max", "wg_unit_min", "wg_short_k", "w3_blocks", "w3_waves")
+
+
+def tune_value(key: str) -> int:
+    """Current value of a library tuning knob (svsr_tune_value)."""
+    out = ctypes.c_int(0)
+    _lib.check(_lib.load().svsr_tune_value(key.encode(), ctypes.byref(out)), f"svsr_tune_value({key})")
+    return int(out.value)
+
+
+def reduction_plan_params() -> list[int]:
+    """The knobs that decide the ORDER in which partial sums of a weight gradient / a BatchNorm statistic are added (REDUCTION_KNOBS): with the
+    same values — whatever the device's compute-unit count — two runs produce the same bits.  Stored in TrainStep.state_dict()."""
+    return [tune_value(k) for k in REDUCTION_KNOBS]
+
+
 def tune(key: str, value: int) -> None:
     """Result-preserving tuning knob of the library (svsr_tune); invalidates cached plans.  `bn_bwd_fused` is a host-side choice
     (which launches the trunk backward issues), kept in this module."""
@@ -333,6 +349,16 @@ def stream_wait(waiter: torch.cuda.Stream, signaller: torch.cuda.Stream) -> None
 def device_cus() -> int:
     """Compute units of the current device."""
     return int(_lib.load().svsr_device_cus())
+
+
+def shader_clock_mhz(blocks: int = 256, iters: int = 20000) -> float:
+    """Effective shader clock (MHz) over a ~1 ms block of MFMA work on every compute unit, right now, on the current stream: the ratio of
+    s_memtime (shader cycles) to s_memrealtime (100 MHz) inside svsr_clock_probe.  Synchronises the stream."""
+    out = torch.zeros(blocks * 2 + 1, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.load().svsr_clock_probe(_p(out), blocks, iters, _stream()), "svsr_clock_probe")
+    torch.cuda.current_stream().synchronize()
+    h = out[: blocks * 2].view(blocks, 2).sum(0).tolist()
+    return 100.0 * h[0] / max(1, h[1])
 
 
 def memset(t: torch.Tensor, value: int = 0) -> None:

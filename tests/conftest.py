@@ -14,8 +14,25 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # SVSR_REDZONE=1: every device tensor of this pytest process gets poisoned 4 KiB red zones on both sides (tests/redzone/redzone_alloc.cpp,
 # installed as torch's device allocator BEFORE the first allocation) and every test ends with a sweep that fails it if a kernel wrote
 # into one (tests/test_gpu_redzone.py runs the kernel-level test files this way).
+# SVSR_TAILFLUSH=1: out-of-bounds READS — every device tensor is its own virtual-memory reservation that ends flush (to 16 bytes) against an
+# UNMAPPED page (same source file, tf_malloc): the first 16-byte access behind a tensor is a GPU memory-access fault that aborts the process.
 _RZ = None
-if os.environ.get("SVSR_REDZONE") == "1":
+_TF = None
+if os.environ.get("SVSR_TAILFLUSH") == "1":
+    import ctypes
+    import subprocess
+    import tempfile
+
+    import torch
+
+    _src = os.path.join(ROOT, "tests", "redzone", "redzone_alloc.cpp")
+    _so = os.path.join(tempfile.mkdtemp(prefix="svsr_tf_"), "libredzone.so")
+    subprocess.run(["hipcc", "-shared", "-fPIC", "-O2", "-w", "-o", _so, _src], check=True, capture_output=True)
+    torch.cuda.memory.change_current_allocator(torch.cuda.memory.CUDAPluggableAllocator(_so, "tf_malloc", "tf_free"))
+    _TF = ctypes.CDLL(_so)
+    _TF.tf_sweep.restype = ctypes.c_long
+    _TF.tf_alloc_count.restype = ctypes.c_long
+elif os.environ.get("SVSR_REDZONE") == "1":
     import ctypes
     import subprocess
     import tempfile
@@ -57,6 +74,11 @@ def _tuning_overrides():
 @pytest.fixture(autouse=True)
 def _redzone_sweep():
     """Under SVSR_REDZONE=1: fail the test that wrote outside a tensor it handed to the C ABI."""
+    if _TF is not None:          # tail-flush mode: an out-of-bounds read does not reach this line (the process is gone); release what the test freed
+        yield
+        assert _TF.tf_sweep() == 0, "tf_malloc failed: the virtual-memory API is not available, this run proves nothing"
+        assert _TF.tf_alloc_count() > 0
+        return
     if _RZ is None:
         yield
         return

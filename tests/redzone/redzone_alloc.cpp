@@ -87,3 +87,87 @@ long rz_check_all(void) {
 long rz_alloc_count(void) { return g_allocs; }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Second mode (SVSR_TAILFLUSH=1): out-of-bounds READS.  Red zones only see stores; a per-lane offset that reads 16 bytes past a tensor, or a
+// padding row fetched from behind the last image, changes no byte anywhere.  Here every tensor is its own virtual-memory reservation whose
+// LAST mapped byte is the tensor's last byte (rounded up to 16: the kernels' vector width) and whose next page is NOT mapped: the first
+// 16-byte access behind a tensor raises a GPU memory-access fault, which aborts the process — the child pytest run dies in the test that
+// did it (tests/test_gpu_redzone.py reports the test named last).  hipMemAddressReserve / hipMemCreate / hipMemMap, one allocation
+// granule of slack in front of the tensor at most.  Frees are deferred to tf_sweep() like the red-zone blocks.
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct TfBlock { char* va; size_t reserved, mapped; hipMemGenericAllocationHandle_t handle; };
+std::unordered_map<void*, TfBlock> g_tf_live;
+std::vector<TfBlock> g_tf_freed;
+size_t g_tf_gran = 0;
+long g_tf_allocs = 0, g_tf_fail = 0;
+
+void tf_release(const TfBlock& b) {
+    (void)hipMemUnmap(b.va, b.mapped);
+    (void)hipMemRelease(b.handle);
+    (void)hipMemAddressFree(b.va, b.reserved);
+}
+}  // namespace
+
+extern "C" {
+
+void* tf_malloc(ssize_t size, int device, hipStream_t stream) {
+    (void)stream;
+    if (size < 0) return nullptr;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (g_tf_gran == 0) {
+        if (hipMemGetAllocationGranularity(&g_tf_gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || g_tf_gran == 0) {
+            fprintf(stderr, "[tailflush] hipMemGetAllocationGranularity failed: the virtual-memory API is not available\n");
+            ++g_tf_fail;
+            return nullptr;
+        }
+    }
+    const size_t used = ((size_t)size + 15) & ~(size_t)15;
+    const size_t mapped = used == 0 ? g_tf_gran : (used + g_tf_gran - 1) / g_tf_gran * g_tf_gran;
+    TfBlock b{};
+    b.mapped = mapped;
+    b.reserved = mapped + g_tf_gran;                 // the granule behind the tensor stays unmapped
+    void* va = nullptr;
+    if (hipMemAddressReserve(&va, b.reserved, 0, nullptr, 0) != hipSuccess) { ++g_tf_fail; return nullptr; }
+    b.va = static_cast<char*>(va);
+    if (hipMemCreate(&b.handle, mapped, &prop, 0) != hipSuccess) { (void)hipMemAddressFree(va, b.reserved); ++g_tf_fail; return nullptr; }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemMap(va, mapped, 0, b.handle, 0) != hipSuccess || hipMemSetAccess(va, mapped, &acc, 1) != hipSuccess) {
+        (void)hipMemRelease(b.handle); (void)hipMemAddressFree(va, b.reserved); ++g_tf_fail; return nullptr;
+    }
+    char* user = b.va + (mapped - used);
+    g_tf_live[user] = b;
+    ++g_tf_allocs;
+    return user;
+}
+
+void tf_free(void* ptr, ssize_t size, int device, hipStream_t stream) {
+    (void)size; (void)device; (void)stream;
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_tf_live.find(ptr);
+    if (it == g_tf_live.end()) return;
+    g_tf_freed.push_back(it->second);
+    g_tf_live.erase(it);
+}
+
+/* synchronises the device (a kernel in flight may still read a freed tensor) and releases the blocks freed since the last sweep;
+ * returns the number of allocations that FAILED so far (the virtual-memory API missing: the run proves nothing then) */
+long tf_sweep(void) {
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (const TfBlock& b : g_tf_freed) tf_release(b);
+    g_tf_freed.clear();
+    return g_tf_fail;
+}
+
+long tf_alloc_count(void) { return g_tf_allocs; }
+size_t tf_granule(void) { return g_tf_gran; }
+
+}  // extern "C"

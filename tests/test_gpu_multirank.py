@@ -32,4 +32,11 @@ def test_two_rank_bench_completes(extra):
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["steps"] == 3
     assert d["collective"]["ranks"] == 2 and d["collective"]["all_reduce_launches_per_step"] >= 2
     assert d["value"] > 0 and d["final_loss"] == d["final_loss"]          # finite
+    # what a first real 8-GPU run diagnoses itself with: the join every rank sat in, and every bucket's size / start / duration on rank 0
+    c = d["collective"]
+    assert len(c["exposed_join_ms_per_rank"]) == 2 and len(c["host_enqueue_ms_per_rank"]) == 2
+    b = c["buckets_rank0"]
+    assert len(b) == c["all_reduce_launches_per_step"] and all(x["mb"] > 0 and x["ms"] >= 0 and x["ready_ms"] >= 0 for x in b), b
+    assert abs(sum(x["mb"] for x in b) - c["gradient_mb_per_step"]) < 0.1 * len(b) + 0.5, (b, c["gradient_mb_per_step"])
+    assert b[0]["ready_ms"] == 0.0 and all(y["ready_ms"] >= x["ready_ms"] for x, y in zip(b, b[1:])), b
     assert "roofline" in d and d["roofline"]["per_kernel"]

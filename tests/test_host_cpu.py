@@ -321,7 +321,7 @@ def test_step_list_registry_covers_every_stream_entry_point():
 
     lib = _lib.load()
     hdr = _lib.parse_header()
-    plumbing = {"svsr_stream_wait", "svsr_memset_async", "svsr_debug_occupy_start"}      # (stream management / test aids, not launches of a step)
+    plumbing = {"svsr_stream_wait", "svsr_memset_async", "svsr_debug_occupy_start", "svsr_clock_probe"}      # (stream management / test aids, not launches of a step)
     launches = [n for n, a in hdr.items() if a and a[-1][0] == "hipStream_t" and not n.startswith("svsr_steplist") and n not in plumbing]
     assert len(launches) >= 50
     missing = [n for n in launches if not lib.svsr_steplist_knows(n.encode())]
@@ -413,3 +413,23 @@ def test_deferred_reductions_are_batched_without_merging_contributions_to_one_gr
     monkeypatch.setattr(ops, "COLSUM_MULTI", False)
     ops.run_deferred(fns[:2])
     assert [c[0] for c in calls] == ["svsr_colsum_rows", "svsr_colsum_rows"]
+
+
+def test_reduction_splits_are_planned_for_a_fixed_compute_unit_count():
+    """The order in which the partial sums of a weight gradient (unit lists of svsr_igemm_wgrad) and of the layer1 kernel's BatchNorm statistics are
+    added must not depend on the device the run happens to sit on (a checkpoint resumed on a partition of another size continues bit for bit):
+    the splits are planned for the knob `reduce_cus` = 256, not for the device's compute-unit count, and the knobs that decide the order are
+    readable (TrainStep.state_dict() records them)."""
+    from syncvsr_amd import ops
+
+    assert ops.REDUCTION_KNOBS[0] == "reduce_cus" and ops.tune_value("reduce_cus") == 256
+    before = ops.reduction_plan_params()
+    assert len(before) == len(ops.REDUCTION_KNOBS) and before[0] == 256
+    try:
+        ops.tune("reduce_cus", 128)
+        assert ops.tune_value("reduce_cus") == 128 and ops.reduction_plan_params() != before
+    finally:
+        ops.tune("reduce_cus", 256)
+    assert ops.reduction_plan_params() == before
+    with pytest.raises(Exception):
+        ops.tune_value("no_such_knob")
