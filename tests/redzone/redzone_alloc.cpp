@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <sys/types.h>
 
 #include <mutex>
@@ -94,20 +95,18 @@ long rz_alloc_count(void) { return g_allocs; }
 // LAST mapped byte is the tensor's last byte (rounded up to 16: the kernels' vector width) and whose next page is NOT mapped: the first
 // 16-byte access behind a tensor raises a GPU memory-access fault, which aborts the process — the child pytest run dies in the test that
 // did it (tests/test_gpu_redzone.py reports the test named last).  hipMemAddressReserve / hipMemCreate / hipMemMap, one allocation
-// granule of slack in front of the tensor at most.  Frees are deferred to tf_sweep() like the red-zone blocks.
+// granule of slack in front of the tensor at most.  Freed tensors are NEVER unmapped: physical pages released with hipMemRelease and handed
+// out again by the next hipMemCreate came back with stale cache lines on this stack (measured: a convolution right after a sweep that unmapped
+// the previous test's tensors read garbage or zeros; scripts/probes/tf_dbg.py) — so the pass keeps everything it ever allocated (a cap of
+// 160 GiB makes tf_malloc fail, i.e. torch raise, long before the 288 GB device is full).
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
 struct TfBlock { char* va; size_t reserved, mapped; hipMemGenericAllocationHandle_t handle; };
 std::unordered_map<void*, TfBlock> g_tf_live;
-std::vector<TfBlock> g_tf_freed;
-size_t g_tf_gran = 0;
+size_t g_tf_gran = 0, g_tf_bytes = 0;
+constexpr size_t TF_CAP = (size_t)160 << 30;
 long g_tf_allocs = 0, g_tf_fail = 0;
 
-void tf_release(const TfBlock& b) {
-    (void)hipMemUnmap(b.va, b.mapped);
-    (void)hipMemRelease(b.handle);
-    (void)hipMemAddressFree(b.va, b.reserved);
-}
 }  // namespace
 
 extern "C" {
@@ -127,8 +126,14 @@ void* tf_malloc(ssize_t size, int device, hipStream_t stream) {
             return nullptr;
         }
     }
-    const size_t used = ((size_t)size + 15) & ~(size_t)15;
+    static size_t align = 0;
+    if (align == 0) {        // SVSR_TF_ALIGN: alignment of the tensor's start = granularity of what is caught (default 16: the kernels' vector width)
+        const char* e = getenv("SVSR_TF_ALIGN");
+        align = e != nullptr && atol(e) >= 16 ? (size_t)atol(e) : 16;
+    }
+    const size_t used = ((size_t)size + align - 1) / align * align;
     const size_t mapped = used == 0 ? g_tf_gran : (used + g_tf_gran - 1) / g_tf_gran * g_tf_gran;
+    if (g_tf_bytes + mapped > TF_CAP) { fprintf(stderr, "[tailflush] more than 160 GiB allocated by this pass (nothing is ever unmapped): refusing\n"); ++g_tf_fail; return nullptr; }
     TfBlock b{};
     b.mapped = mapped;
     b.reserved = mapped + g_tf_gran;                 // the granule behind the tensor stays unmapped
@@ -144,6 +149,7 @@ void* tf_malloc(ssize_t size, int device, hipStream_t stream) {
     }
     char* user = b.va + (mapped - used);
     g_tf_live[user] = b;
+    g_tf_bytes += mapped;
     ++g_tf_allocs;
     return user;
 }
@@ -151,21 +157,17 @@ void* tf_malloc(ssize_t size, int device, hipStream_t stream) {
 void tf_free(void* ptr, ssize_t size, int device, hipStream_t stream) {
     (void)size; (void)device; (void)stream;
     std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_tf_live.find(ptr);
-    if (it == g_tf_live.end()) return;
-    g_tf_freed.push_back(it->second);
-    g_tf_live.erase(it);
+    g_tf_live.erase(ptr);        // (stays mapped: see the header of this section)
 }
 
-/* synchronises the device (a kernel in flight may still read a freed tensor) and releases the blocks freed since the last sweep;
- * returns the number of allocations that FAILED so far (the virtual-memory API missing: the run proves nothing then) */
+/* number of allocations that FAILED so far (the virtual-memory API missing, or the cap reached: the run proves nothing then) */
 long tf_sweep(void) {
     (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> lock(g_mu);
-    for (const TfBlock& b : g_tf_freed) tf_release(b);
-    g_tf_freed.clear();
     return g_tf_fail;
 }
+
+size_t tf_bytes(void) { return g_tf_bytes; }
 
 long tf_alloc_count(void) { return g_tf_allocs; }
 size_t tf_granule(void) { return g_tf_gran; }
