@@ -20,6 +20,7 @@
                            // start at banks 0/48/32/16 and their 16-bank windows are disjoint (pitch 80 = 40 banks made row 3 wrap
                            // onto row 0: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.45)
 #define W3_MAXXR 192       // max X-tile rows: 128 + 2*(WP+1), i.e. W <= 29
+#define W3D_MAXXR 256      // dense form (below): 128 REAL positions span up to this many padded rows (+ halo); checked per shape on the host
 
 struct Wgrad3Args {
     const bf16_t* x;       // [Nimg][H][W][Ci]
@@ -31,6 +32,7 @@ struct Wgrad3Args {
     int WP, Q, Qtot, XR;   // padded row length, padded pixels per image, total, X-tile rows
     float inv_q, inv_wp;
     int chunks_per_block, total_chunks;
+    int P, Ptot;           // dense form: real pixels per image, in all
 };
 
 // Slab format: a workgroup's nine 64 x 64 tiles leave in MFMA FRAGMENT layout — float4 group ((tap * 4 + wave) * 4 + rq) * 64 + lane holds
@@ -56,6 +58,17 @@ __device__ __forceinline__ bf16x8 w3_frag_T(const bf16_t* tile, int ch0, int pos
     return f;
 }
 
+// the same fragment with the two row groups of a lane given as rows (gathered positions: the dense form)
+__device__ __forceinline__ bf16x8 w3_frag_T2(const bf16_t* tile, int ch0, int rowa, int rowb, int lane) {
+    const int col = ch0 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile + rowa * W3_PITCH + col));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tile + rowb * W3_PITCH + col));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
 // padded index q -> pixel index n*H*W + (y'-1)*W + (x'-1), or -1 for pad pixels / outside the batch
 __device__ __forceinline__ long w3_pixel(const Wgrad3Args& p, int q) {
     if (q < 0 || q >= p.Qtot) return -1;
@@ -73,14 +86,20 @@ __device__ __forceinline__ long w3_pixel(const Wgrad3Args& p, int q) {
 // NW = 8 (round 5): eight waves, one workgroup per CU — waves 0-3 take taps 0-4 of their quadrant, waves 4-7 taps 5-8: all eight waves work on
 // the SAME chunk (no merge of accumulators: different taps are different outputs), a workgroup covers twice the positions, so a launch writes
 // HALF the slabs, and a wave needs ~130 registers instead of 247 (two 4-wave workgroups held 496 of a SIMD's 512 registers).
-template <int NW>
+// DENSE (round 6): the contraction runs over the REAL pixels only.  In the padded walk above every pad pixel is a zero row of dY that is
+// multiplied all the same: 13 x 13 / 11 x 11 = 1.40x the MFMAs and fragment reads at layer2, 24 x 24 / 22 x 22 = 1.19x at layer1 (the profile
+// showed it: matrix pipe 32 % busy for 19 % of the peak delivered).  Here a chunk is 128 consecutive real pixels: the dY tile is dense, the X tile
+// is still the padded stretch those pixels span (+ halo; pad rows are zeros), and a small LDS table maps position k of the chunk to its padded row
+// — ds_read_b64_tr_b16 takes a row address per lane, so the nine shifted fragments are gathered through that table instead of walked.
+template <int NW, bool DENSE>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_wgrad3x3_halo(const Wgrad3Args p, const Wgrad3Multi m) {
     constexpr int NT = NW * 64, RPP = NT / 8;                    // threads; tile rows staged per pass of all threads
-    constexpr int YR = W3_CH / RPP, XRN = W3_MAXXR / RPP;        // dY / X rows per thread and chunk (4 / 6 or 2 / 3)
+    constexpr int YR = W3_CH / RPP, XRN = (DENSE ? W3D_MAXXR : W3_MAXXR) / RPP;        // dY / X rows per thread and chunk
     constexpr int TPW = NW == 4 ? 9 : 5;                         // taps per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* sY = reinterpret_cast<bf16_t*>(smem_raw);            // [128][PITCH]
     bf16_t* sX = sY + W3_CH * W3_PITCH;                          // [XR][PITCH]
+    int* sMap = reinterpret_cast<int*>(sX + (DENSE ? W3D_MAXXR : 0) * W3_PITCH);      // dense form: padded row (relative to the chunk's first pixel) of position k
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci_tiles = p.Ci >> 6;
@@ -105,60 +124,94 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_wgrad3x3_halo(cons
     int c_end = c_begin + p.chunks_per_block;
     if (c_end > p.total_chunks) c_end = p.total_chunks;
 
-    u32x4 vy[YR], vx[XRN];
-    unsigned ld_ok = 0;
-    auto load_chunk = [&](int c) {
+    // padded index of real pixel g (n * Q + (y + 1) * WP + x + 1); exact for the sizes the launcher admits (< 2^24 pixels)
+    auto padq = [&](int g) {
+        const int n = g / p.P, rem = g - n * p.P;
+        const int y = rem / p.W, x = rem - y * p.W;
+        return n * p.Q + (y + 1) * p.WP + x + 1;
+    };
+    // one chunk's rows on their way from global memory to LDS: dY / X pieces of this thread, which of them are real, and (dense form) the padded
+    // index of the chunk's first pixel and the rows of its X tile
+    struct Staged { u32x4 vy[YR], vx[XRN]; unsigned ok; int q0, xr; };
+    auto load_chunk = [&](Staged& g, int c) {
         const int q0 = c * W3_CH;
-        ld_ok = 0;
+        g.ok = 0; g.q0 = q0; g.xr = p.XR;
+        if (DENSE) {
+            int plast = q0 + W3_CH - 1;
+            if (plast > p.Ptot - 1) plast = p.Ptot - 1;
+            g.q0 = padq(q0);
+            g.xr = padq(plast) - g.q0 + 1 + 2 * (p.WP + 1);
+        }
 #pragma unroll
         for (int i = 0; i < YR; ++i) {
-            const long pix = w3_pixel(p, q0 + r0 + RPP * i);
+            long pix;
+            if (DENSE) { const int px = q0 + r0 + RPP * i; pix = px < p.Ptot ? px : -1; }
+            else pix = w3_pixel(p, q0 + r0 + RPP * i);
             const bool ok = pix >= 0;
-            vy[i] = *reinterpret_cast<const u32x4*>(gy + (ok ? pix * p.Co + co0 + chunk * 8 : 0));
-            ld_ok |= (ok ? 1u : 0u) << i;
+            g.vy[i] = *reinterpret_cast<const u32x4*>(gy + (ok ? pix * p.Co + co0 + chunk * 8 : 0));
+            g.ok |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < XRN; ++i) {
             const int rr = r0 + RPP * i;
-            const long pix = rr < p.XR ? w3_pixel(p, q0 - (p.WP + 1) + rr) : -1;
+            const long pix = rr < g.xr ? w3_pixel(p, g.q0 - (p.WP + 1) + rr) : -1;
             const bool ok = pix >= 0;
-            vx[i] = *reinterpret_cast<const u32x4*>(gx + (ok ? pix * p.Ci + ci0 + chunk * 8 : 0));
-            ld_ok |= (ok ? 1u : 0u) << (8 + i);
+            g.vx[i] = *reinterpret_cast<const u32x4*>(gx + (ok ? pix * p.Ci + ci0 + chunk * 8 : 0));
+            g.ok |= (ok ? 1u : 0u) << (8 + i);
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](const Staged& g, int c, bf16_t* bY, bf16_t* bX, int* bMap) {
 #pragma unroll
         for (int i = 0; i < YR; ++i) {
-            const bool ok = (ld_ok >> i) & 1u;
-            u32x4 v = vy[i];
+            const bool ok = (g.ok >> i) & 1u;
+            u32x4 v = g.vy[i];
             v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-            *reinterpret_cast<u32x4*>(sY + (r0 + RPP * i) * W3_PITCH + chunk * 8) = v;
+            *reinterpret_cast<u32x4*>(bY + (r0 + RPP * i) * W3_PITCH + chunk * 8) = v;
+        }
+        if (DENSE && tid < W3_CH) {         // position k of the chunk -> its padded row inside the X tile (without the tap shift)
+            int px = c * W3_CH + tid;
+            if (px > p.Ptot - 1) px = p.Ptot - 1;            // (rows past the last pixel: dY is zero there, any readable row will do)
+            bMap[tid] = padq(px) - g.q0;
         }
 #pragma unroll
         for (int i = 0; i < XRN; ++i) {
             const int rr = r0 + RPP * i;
-            const bool ok = (ld_ok >> (8 + i)) & 1u;
-            u32x4 v = vx[i];
+            const bool ok = (g.ok >> (8 + i)) & 1u;
+            u32x4 v = g.vx[i];
             v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-            if (rr < p.XR) *reinterpret_cast<u32x4*>(sX + rr * W3_PITCH + chunk * 8) = v;
+            if (rr < g.xr) *reinterpret_cast<u32x4*>(bX + rr * W3_PITCH + chunk * 8) = v;
         }
     };
-
-    if (c_begin < c_end) load_chunk(c_begin);
-    for (int c = c_begin; c < c_end; ++c) {
-        __syncthreads();                           // previous chunk's fragment reads are done
-        store_chunk();
-        __syncthreads();
-        if (c + 1 < c_end) load_chunk(c + 1);      // in flight while this chunk is contracted
+    auto contract = [&](const bf16_t* bY, const bf16_t* bX, const int* bMap) {
 #pragma unroll 2
         for (int ks = 0; ks < W3_CH / 16; ++ks) {
-            const bf16x8 fa = w3_frag_T(sY, wco, ks * 16, lane);
+            const bf16x8 fa = w3_frag_T(bY, wco, ks * 16, lane);
+            int rowa = 0, rowb = 0;
+            if (DENSE) {                           // this lane's two positions of the step (w3_frag_T's row pattern), as padded rows
+                const int k0 = ks * 16 + ((lane >> 4) >> 1) * 8 + ((lane & 15) >> 2);
+                rowa = bMap[k0]; rowb = bMap[k0 + 4];
+            }
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 if (NW == 8 && t == TPW - 1 && tap0 + t >= 9) break;           // the second wave group has four taps (wave-uniform)
-                const bf16x8 fb = w3_frag_T(sX, wci, ks * 16 + shift[t], lane);
+                const bf16x8 fb = DENSE ? w3_frag_T2(bX, wci, rowa + shift[t], rowb + shift[t], lane) : w3_frag_T(bX, wci, ks * 16 + shift[t], lane);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
             }
+        }
+    };
+
+    {
+        // (Measured in round 6 and dropped: two LDS tiles + two chunks in flight for the 8-wave form — one barrier per chunk, the store pass of chunk
+        // c + 1 beside the contraction of chunk c: 73 -> 78 us at layer1, 72 -> 76 at layer2.  A chunk's ~4 us are not a load round trip: they are its
+        // 384 KiB of fragment reads (1.2 KiB per MFMA: every X fragment feeds ONE MFMA) next to 1.2 us of MFMA time.)
+        Staged g;
+        if (c_begin < c_end) load_chunk(g, c_begin);
+        for (int c = c_begin; c < c_end; ++c) {
+            __syncthreads();                           // previous chunk's fragment reads are done
+            store_chunk(g, c, sY, sX, sMap);
+            __syncthreads();
+            if (c + 1 < c_end) load_chunk(g, c + 1);   // in flight while this chunk is contracted
+            contract(sY, sX, sMap);
         }
     }
     if (p.splits > 1) {
@@ -226,11 +279,22 @@ __global__ __launch_bounds__(256) void k_wgrad3_reduce(const float* __restrict__
     }
 }
 
-struct W3Plan { int splits, chunks_per_block, total_chunks, tasks; };
+struct W3Plan { int splits, chunks_per_block, total_chunks, tasks, dense; };
+
+// dense form (k_wgrad3x3_halo<NW, true>): do 128 consecutive real pixels, wherever they start, span at most W3D_MAXXR padded rows with the halo?
+static bool w3_dense_ok(int H, int W) {
+    if (svsr_tune_get(SVSR_TUNE_W3_DENSE) == 0) return false;
+    const int WP = W + 2, Q = (H + 2) * WP, P = H * W;
+    auto padq = [&](int g) { const int n = g / P, rem = g - n * P; return n * Q + (rem / W + 1) * WP + rem % W + 1; };
+    int worst = 0;
+    for (int s0 = 0; s0 < P; ++s0) { const int d = padq(s0 + W3_CH - 1) - padq(s0); if (d > worst) worst = d; }
+    return worst + 1 + 2 * (WP + 1) <= W3D_MAXXR;
+}
 
 static W3Plan w3_plan(int Nimg, int H, int W, int Ci, int Co, int nprob = 1) {
     W3Plan pl;
-    const long qtot = (long)Nimg * (H + 2) * (W + 2);
+    pl.dense = w3_dense_ok(H, W) ? 1 : 0;
+    const long qtot = pl.dense ? (long)Nimg * H * W : (long)Nimg * (H + 2) * (W + 2);
     pl.total_chunks = (int)((qtot + W3_CH - 1) / W3_CH);
     pl.tasks = (Co / 64) * (Ci / 64);
     int target_blocks = svsr_tune_get(SVSR_TUNE_W3_BLOCKS);      // one round of 2 workgroups per CU (4-wave form) / 1 per CU (8-wave form), shared by the problems of the launch
@@ -265,6 +329,7 @@ static int w3_fill_args(Wgrad3Args& a, int Nimg, int H, int W, int Ci, int Co) {
     a.Qtot = (int)qtot;
     a.XR = W3_CH + 2 * (a.WP + 1);
     a.inv_q = 1.0f / (float)a.Q; a.inv_wp = 1.0f / (float)a.WP;
+    a.P = H * W; a.Ptot = Nimg * H * W;
     return SVSR_OK;
 }
 
@@ -272,15 +337,21 @@ static int w3_launch(const Wgrad3Args& a0, const Wgrad3Multi& m, int n, const W3
     if (pl.splits > 1 && (part == nullptr || part_floats < (int64_t)n * pl.splits * pl.tasks * W3_TILE_FLOATS)) return SVSR_ERR_ARG;
     Wgrad3Args a = a0;
     a.total_chunks = pl.total_chunks; a.chunks_per_block = pl.chunks_per_block; a.splits = pl.splits; a.part = part;
-    const size_t lds = (size_t)(W3_CH + a.XR) * W3_PITCH * sizeof(bf16_t);
+    const bool w8 = svsr_tune_get(SVSR_TUNE_W3_WAVES) == 8;
+    const size_t lds = pl.dense ? (size_t)(W3_CH + W3D_MAXXR) * W3_PITCH * sizeof(bf16_t) + W3_CH * sizeof(int)
+                                : (size_t)(W3_CH + a.XR) * W3_PITCH * sizeof(bf16_t);
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3x3_halo<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3x3_halo<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3x3_halo<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3x3_halo<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3x3_halo<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad3x3_halo<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set = lds;
     }
-    if (svsr_tune_get(SVSR_TUNE_W3_WAVES) == 8) hipLaunchKernelGGL(k_wgrad3x3_halo<8>, dim3(pl.splits, pl.tasks, n), dim3(512), lds, stream, a, m);
-    else hipLaunchKernelGGL(k_wgrad3x3_halo<4>, dim3(pl.splits, pl.tasks, n), dim3(256), lds, stream, a, m);
+    if (w8 && pl.dense) hipLaunchKernelGGL((k_wgrad3x3_halo<8, true>), dim3(pl.splits, pl.tasks, n), dim3(512), lds, stream, a, m);
+    else if (w8) hipLaunchKernelGGL((k_wgrad3x3_halo<8, false>), dim3(pl.splits, pl.tasks, n), dim3(512), lds, stream, a, m);
+    else if (pl.dense) hipLaunchKernelGGL((k_wgrad3x3_halo<4, true>), dim3(pl.splits, pl.tasks, n), dim3(256), lds, stream, a, m);
+    else hipLaunchKernelGGL((k_wgrad3x3_halo<4, false>), dim3(pl.splits, pl.tasks, n), dim3(256), lds, stream, a, m);
     int rc = svsr_check_launch();
     if (rc != SVSR_OK || pl.splits <= 1) return rc;
     hipLaunchKernelGGL(k_wgrad3_reduce, dim3(W3_TILE_FLOATS / 4 / 64, pl.tasks, n), dim3(256), 0, stream, (const float*)part, m, pl.splits, a.Ci, a.Ci >> 6);

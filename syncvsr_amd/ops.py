@@ -111,7 +111,7 @@ def _query(name: str, *args) -> tuple:
     return out
 
 
-REDUCTION_KNOBS = ("reduce_cus", "wg_blocks", "wg_units", "wg_unit_max", "wg_unit_min", "wg_short_k", "w3_blocks", "w3_waves")
+REDUCTION_KNOBS = ("reduce_cus", "wg_blocks", "wg_units", "wg_unit_max", "wg_unit_min", "wg_short_k", "w3_blocks", "w3_waves", "w3_dense")
 
 
 def tune_value(key: str) -> int:
