@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""In-loop cycles per 64-deep K tile of k_igemm_p8 at the benchmark shapes (build variant p8stamp: SVSR_LIB_VARIANT=p8stamp): the number the
+producer / consumer probe (scripts/probes/pc_probe.hip) is compared with."""
+import ctypes, os, sys, math
+os.environ["SVSR_LIB_VARIANT"] = "p8stamp"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from syncvsr_amd import _lib, ops
+lib = ctypes.CDLL(_lib.LIB_PATH)
+dev = torch.device("cuda:0")
+BF16 = torch.bfloat16
+out2 = (ctypes.c_longlong * 4)()
+for name, (N, H, C) in {"layer2.conv": (928, 11, 128), "layer3.conv": (928, 6, 256), "layer4.conv": (928, 3, 512), "lrs layer2": (2560, 11, 128), "lrs layer3": (2560, 6, 256)}.items():
+    x = (torch.randn(N, H, H, C, device=dev) * 0.5).to(BF16)
+    w = (torch.randn(C, 3, 3, C, device=dev) / math.sqrt(9 * C)).to(BF16)
+    dy = (torch.randn(N, H, H, C, device=dev) * 0.5).to(BF16)
+    xb = torch.randn(N, H, H, C, device=dev).to(BF16)
+    yb = torch.relu(torch.randn(N, H, H, C, device=dev)).to(BF16)
+    add = (torch.randn(N, H, H, C, device=dev) * 0.5).to(BF16)
+    mean, rstd, gamma, beta = torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
+    runs = {"fwd+stats": lambda: ops.conv2d_fwd(x, w, 3, 1, 1, want_stats=True),
+            "dgrad+add": lambda: ops.conv2d_dgrad(dy, w, 3, 1, 1, (H, H), addend=add),
+            "dgrad+bn(res)": lambda: ops.conv2d_dgrad_bn(dy, w, 3, 1, 1, (H, H), add, yb, xb, mean, rstd, gamma, beta, 1)}
+    for what, fn in runs.items():
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        lib.svsr_debug_p8_stamps(out2)
+        reps = 10
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        lib.svsr_debug_p8_stamps(out2)
+        print(f"{name:12s} {what:20s} {s.elapsed_time(e) / reps * 1e3:7.1f} us per launch; in-loop {out2[0] / max(1, out2[1]):6.0f} cycles per K tile ({out2[1] // reps} K tiles), "
+              f"epilogue {out2[2] / max(1, out2[3]):7.0f} cycles per tile ({out2[3] // reps} tiles); per workgroup: loops {out2[0] / reps / 256 / 2.1e3:6.1f} us + epilogues {out2[2] / reps / 256 / 2.1e3:6.1f} us @2.1 GHz")

@@ -40,7 +40,7 @@ def headers() -> list[str]:
 
 # build variants: "" = the product library; "syncdbg" = -DSVSR_SYNC_DEBUG (every counted s_waitcnt vmcnt(n) of the LDS-DMA pipelines is
 # vmcnt(0): csrc/common.h), a TEST library that tests/test_gpu_syncdbg.py compares the product's outputs with, bit for bit
-VARIANTS = {"": [], "syncdbg": ["-DSVSR_SYNC_DEBUG"]}
+VARIANTS = {"": [], "syncdbg": ["-DSVSR_SYNC_DEBUG"], "p8stamp": ["-DSVSR_P8_STAMP"]}      # p8stamp: s_memtime stamps around k_igemm_p8's K loops (scripts/probes/p8_stamps.py)
 
 
 def lib_path(variant: str = "") -> str:

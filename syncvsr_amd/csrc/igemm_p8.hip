@@ -20,6 +20,7 @@
 //   WAR  a ring slot is re-staged from the phase AFTER its last read; reads are retired (lgkmcnt(0)) before the mid-phase barrier.
 // Epilogue: accumulators -> fp32 LDS (the ring slot that just went idle) in four 64-row passes -> (+addend | BatchNorm-backward
 // masks) -> 16-byte bf16 stores; BatchNorm partial rows (one per M tile) in a fixed order.  No atomics: results are reproducible.
+#include <string.h>
 #include <type_traits>
 
 #include "igemm_fwd.h"
@@ -77,6 +78,10 @@ __device__ __forceinline__ bool p8_next_item(int tiles_m, int gy, int items, int
         if (m_tile < tiles_m) return true;
     }
 }
+
+#ifdef SVSR_P8_STAMP
+__device__ long long g_p8_stamp[2048];          // [workgroup][4]: cycles inside K loops (wave 0), K tiles walked, cycles inside epilogues, tiles — build variant "p8stamp" only
+#endif
 
 }  // namespace
 
@@ -192,6 +197,9 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 
         if ((stagger & 1) && wn == 1) P8_BARRIER();             // stagger: group 1 runs one barrier behind group 0
         const int KT = cur.KT;
+#ifdef SVSR_P8_STAMP
+        const long long t_k0 = __builtin_amdgcn_s_memtime();
+#endif
         for (int kt = 0; kt < KT; ++kt) {
             if (kt == 2 && has_next) make_ctx(nxt, m2, n2, par ^ 1);
             if (!st_next && st_kt == KT) { st_next = true; st_kt = 0; st_t = 0; st_c = 0; str = nxt; }
@@ -243,6 +251,10 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
             stream_advance();
             stg = stg == 2 ? 0 : stg + 1;
         }
+#ifdef SVSR_P8_STAMP
+        const long long t_e0 = __builtin_amdgcn_s_memtime();
+        if (tid == 0) { g_p8_stamp[4 * w] += t_e0 - t_k0; g_p8_stamp[4 * w + 1] += KT; }
+#endif
         if ((stagger & 1) && wn == 0) P8_BARRIER();             // the groups meet again
 
         // ---- epilogue of the tile: the ring slot read last is idle until K tile 2 of the next tile is staged ----------------------
@@ -446,6 +458,9 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
             // again once everybody passed this barrier.
             P8_SYNC_LDS();
         }
+#ifdef SVSR_P8_STAMP
+        if (tid == 0) { g_p8_stamp[4 * w + 2] += __builtin_amdgcn_s_memtime() - t_e0; g_p8_stamp[4 * w + 3] += 1; }
+#endif
         if (!has_next) return;
         cur = nxt;
         str = nxt;
@@ -453,6 +468,19 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
         st_next = false;            // the stream is at K tile 2 of what is now the current tile
     }
 }
+
+#ifdef SVSR_P8_STAMP
+/* build variant p8stamp (python -m syncvsr_amd.build --variant p8stamp; scripts/probes/p8_stamps.py): sums over the workgroups of {cycles inside
+ * the K loops, K tiles, cycles inside the epilogues, tiles} since the last call; resets the counters */
+extern "C" int svsr_debug_p8_stamps(long long* out4) {
+    static long long h[2048];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_p8_stamp), sizeof h) != hipSuccess) return SVSR_ERR_LAUNCH;
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    for (int i = 0; i < 512; ++i) for (int k = 0; k < 4; ++k) out4[k] += h[4 * i + k];
+    memset(h, 0, sizeof h);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_p8_stamp), h, sizeof h);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) {
