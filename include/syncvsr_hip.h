@@ -73,7 +73,7 @@ extern "C" {
 /* ---- plumbing (runtime.hip) ------------------------------------------------------------------------------------
  * svsr_tune: sets a result-preserving tuning knob ("igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd",
  * "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe",
- * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128", "wg_xcd", "w3_waves", "reduce_cus", "w3_dense": tile shapes, split counts, kernel-variant switches — documented at the table in
+ * "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128", "wg_xcd", "w3_waves", "reduce_cus", "w3_dense", "p8_wide": tile shapes, split counts, kernel-variant switches — documented at the table in
  * runtime.hip; never read from the environment); unknown key -> SVSR_ERR_ARG.  svsr_tune_value reads a knob back.  The knobs that decide
  * the ORDER in which a weight gradient's or a BatchNorm statistic's partial sums are added (reduce_cus — the compute-unit count the splits
  * are planned for: a fixed 256, not the device's —, wg_blocks, wg_units, wg_unit_max, wg_unit_min, wg_short_k, w3_blocks, w3_waves, w3_dense) are what a

@@ -21,7 +21,17 @@ for name, (N, H, C) in {"layer2.conv": (928, 11, 128), "layer3.conv": (928, 6, 2
     runs = {"fwd+stats": lambda: ops.conv2d_fwd(x, w, 3, 1, 1, want_stats=True),
             "dgrad+add": lambda: ops.conv2d_dgrad(dy, w, 3, 1, 1, (H, H), addend=add),
             "dgrad+bn(res)": lambda: ops.conv2d_dgrad_bn(dy, w, 3, 1, 1, (H, H), add, yb, xb, mean, rstd, gamma, beta, 1)}
-    for what, fn in runs.items():
+    keep = {}
+    for what, fn in [(f"{k} wide={d}", (d, k, f)) for k, f in runs.items() for d in (0, 1)]:
+        ops.tune("p8_wide", fn[0])
+        res = fn[2]()                     # bit-identity of the two epilogues: outputs and raw partial rows
+        flat = [t.clone() for t in (res if isinstance(res, tuple) else (res,)) if torch.is_tensor(t)] + \
+               [res[1][0][: res[1][1] * 2 * C].clone()] if isinstance(res, tuple) and isinstance(res[1], tuple) else [res.clone()]
+        if fn[1] in keep:
+            same = all(torch.equal(a, b) for a, b in zip(keep[fn[1]], flat))
+            print(f"    {fn[1]}: wide == narrow bit for bit: {same}")
+        keep[fn[1]] = flat
+        fn = fn[2]
         for _ in range(3):
             fn()
         torch.cuda.synchronize()

@@ -16,7 +16,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // Result-preserving tuning knobs (runtime.hip): a process-wide table set through svsr_tune(); the library never reads the
 // environment.
 enum { SVSR_TUNE_IGEMM_TILE = 0, SVSR_TUNE_IGEMM_M128, SVSR_TUNE_WG_BLOCKS, SVSR_TUNE_W3_BLOCKS, SVSR_TUNE_LN_RPB,
-       SVSR_TUNE_STEM_LDS_FWD, SVSR_TUNE_STEM_LDS_BWD, SVSR_TUNE_IGEMM_LDS_PAD, SVSR_TUNE_IGEMM_BN64_BELOW, SVSR_TUNE_WG_SHORT_K, SVSR_TUNE_IGEMM_KSPLIT, SVSR_TUNE_EPI_BATCHED, SVSR_TUNE_STEM_WG_PIPE, SVSR_TUNE_STEM_FWD_DMA, SVSR_TUNE_IGEMM_LIN_BN64, SVSR_TUNE_P8, SVSR_TUNE_P8_GRID, SVSR_TUNE_P8_MIN_ITEMS, SVSR_TUNE_P8_PH, SVSR_TUNE_P8_STAGGER, SVSR_TUNE_WG_IMGMAJOR, SVSR_TUNE_P8_BN64, SVSR_TUNE_IGEMM_NS64, SVSR_TUNE_WG_UNITS, SVSR_TUNE_WG_UNIT_MAX, SVSR_TUNE_WG_UNIT_MIN, SVSR_TUNE_IGEMM_KSPLIT128, SVSR_TUNE_WG_XCD, SVSR_TUNE_W3_WAVES, SVSR_TUNE_REDUCE_CUS, SVSR_TUNE_W3_DENSE, SVSR_TUNE_N };
+       SVSR_TUNE_STEM_LDS_FWD, SVSR_TUNE_STEM_LDS_BWD, SVSR_TUNE_IGEMM_LDS_PAD, SVSR_TUNE_IGEMM_BN64_BELOW, SVSR_TUNE_WG_SHORT_K, SVSR_TUNE_IGEMM_KSPLIT, SVSR_TUNE_EPI_BATCHED, SVSR_TUNE_STEM_WG_PIPE, SVSR_TUNE_STEM_FWD_DMA, SVSR_TUNE_IGEMM_LIN_BN64, SVSR_TUNE_P8, SVSR_TUNE_P8_GRID, SVSR_TUNE_P8_MIN_ITEMS, SVSR_TUNE_P8_PH, SVSR_TUNE_P8_STAGGER, SVSR_TUNE_WG_IMGMAJOR, SVSR_TUNE_P8_BN64, SVSR_TUNE_IGEMM_NS64, SVSR_TUNE_WG_UNITS, SVSR_TUNE_WG_UNIT_MAX, SVSR_TUNE_WG_UNIT_MIN, SVSR_TUNE_IGEMM_KSPLIT128, SVSR_TUNE_WG_XCD, SVSR_TUNE_W3_WAVES, SVSR_TUNE_REDUCE_CUS, SVSR_TUNE_W3_DENSE, SVSR_TUNE_P8_WIDE, SVSR_TUNE_N };
 int svsr_tune_get(int id);
 // compute units of the device (runtime.hip).  Persistent kernels size their grids and static tile lists with it.
 int svsr_stream_cus(hipStream_t stream);

@@ -89,7 +89,10 @@ __device__ long long g_p8_stamp[2048];          // [workgroup][4]: cycles inside
 // PH: phases per K tile (2: the 32-deep halves, 8 MFMAs between barriers; 1: the whole K tile, 16 MFMAs between barriers)
 // NJ: 32-column blocks of a wave's tile — 2: the 256 x 128 tile (wave tile 64 x 64); 1: a 256 x 64 tile (wave tile 64 x 32) for launches whose
 // 128-wide items would leave half the CUs idle (layer4: 33 row tiles x 512 channels = 132 items of 128 columns, 264 of 64)
-template <int EPI, int PH = 2, int NJ = 2>
+// WIDE (round 6, NJ = 2): the epilogue's global accesses as FULL 128-byte lines.  The patch holds 16 rows of BOTH 32-column fragments of a wave
+// (fp32 [16][64], the same 4 KiB), a lane reads 8 consecutive channels of a row and stores 16 bytes: a wave instruction covers 8 rows x 128 bytes
+// (its addend / x / y loads likewise) instead of 8 rows x 64 bytes.  Same arithmetic per element, same order of every sum: bit-identical results.
+template <int EPI, int PH = 2, int NJ = 2, bool WIDE = false>
 __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int stagger) {
     constexpr int BNT = 64 * NJ, NPIECE = 4 + NJ;          // tile columns; DMA pieces per thread and K tile
     static_assert(NJ == 2 || PH == 1, "the 64-column tile has five pieces per K tile: one phase");
@@ -294,13 +297,124 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                 }
             }
             const bool from_x = p.bnb_y == nullptr, swish_act = p.bnb_act == 2, has_add = p.addend != nullptr;
-            float bs1[NJ][4], bs2[NJ][4];
+            float bs1[NJ][4], bs2[NJ][4];          // (WIDE: the same 8 accumulators, [c >> 2][c & 3] over the lane's 8 channels c)
             if (EPI == 1) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { bs1[j][k] = 0.f; bs2[j][k] = 0.f; }
             }
+            if constexpr (WIDE) {
+                static_assert(NJ == 2, "the full-line epilogue covers the two 32-column fragments of a wave together");
+                const int c8 = lane & 7;                   // this lane's 8 channels: columns c8 * 8 .. + 7 of the wave's 64
+                const int n = n0t + wn * 64 + c8 * 8;
+                // target offsets of this lane's rows: row block i, 16-row half h, read kk -> row wm*64 + i*32 + 16 h + rq + 8 kk
+                int offs[2][2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            const int dstpix = rowtab[(wm * 64 + i * 32 + 16 * h + rq + 8 * kk) * 2 + 1];
+                            offs[i][h][kk] = dstpix >= 0 ? dstpix * p.out_pitch : -1;
+                        }
+                float mu[8], rs[8], sc[8], sh[8];
+                if (EPI == 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { mu[k] = p.bnb_mean[n + k]; rs[k] = p.bnb_rstd[n + k]; sc[k] = 0.f; sh[k] = 0.f; }
+                    if (from_x || swish_act) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { sc[k] = p.bnb_gamma[n + k] * rs[k]; sh[k] = __builtin_fmaf(-mu[k], sc[k], p.bnb_beta[n + k]); }
+                    }
+                }
+                P8_WAIT_LGKM0();
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    // the global operands of this row block (4 rows x 16 bytes per tensor) are requested HERE, before the first is used (see the 8-byte form below)
+                    u32x4 add_all[2][2], x_all[2][2], y_all[2][2];
+                    if (has_add || EPI == 1) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int kk = 0; kk < 2; ++kk) {
+                                const long o = (long)((offs[i][h][kk] >= 0 ? offs[i][h][kk] : 0) + n);
+                                if (has_add) add_all[h][kk] = *reinterpret_cast<const u32x4*>(p.addend + o);
+                                if (EPI == 1) {
+                                    x_all[h][kk] = *reinterpret_cast<const u32x4*>(p.bnb_x + o);
+                                    if (!from_x) y_all[h][kk] = *reinterpret_cast<const u32x4*>(p.bnb_y + o);
+                                }
+                            }
+                    }
+                    if (has_add) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int kk = 0; kk < 2; ++kk) asm volatile("" : "+v"(add_all[h][kk].x), "+v"(add_all[h][kk].y), "+v"(add_all[h][kk].z), "+v"(add_all[h][kk].w));
+                    }
+                    if (EPI == 1) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int kk = 0; kk < 2; ++kk) {
+                                asm volatile("" : "+v"(x_all[h][kk].x), "+v"(x_all[h][kk].y), "+v"(x_all[h][kk].z), "+v"(x_all[h][kk].w));
+                                if (!from_x) asm volatile("" : "+v"(y_all[h][kk].x), "+v"(y_all[h][kk].y), "+v"(y_all[h][kk].z), "+v"(y_all[h][kk].w));
+                            }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        // rows 16 h .. 16 h + 15 of this row block: accumulator registers 8 h .. 8 h + 7 of both fragments -> patch [16][64]
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) sW[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 64 + j * 32 + (lane & 31)] = acc[i][j][8 * h + e];
+                        P8_WAIT_LGKM0();
+                        f32x4 rowv[2][2];
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            rowv[kk][0] = *reinterpret_cast<const f32x4*>(sW + (rq + 8 * kk) * 64 + c8 * 8);
+                            rowv[kk][1] = *reinterpret_cast<const f32x4*>(sW + (rq + 8 * kk) * 64 + c8 * 8 + 4);
+                        }
+                        P8_WAIT_LGKM0();
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            const bool live = offs[i][h][kk] >= 0;
+                            float v[8] = {rowv[kk][0][0], rowv[kk][0][1], rowv[kk][0][2], rowv[kk][0][3], rowv[kk][1][0], rowv[kk][1][1], rowv[kk][1][2], rowv[kk][1][3]};
+                            if (has_add) {
+                                float a8[8];
+                                unpack8(add_all[h][kk], a8);
+#pragma unroll
+                                for (int c = 0; c < 8; ++c) v[c] += a8[c];
+                            }
+                            if (EPI == 1) {
+                                float xv[8], yv[8];
+                                unpack8(x_all[h][kk], xv);
+                                if (from_x) {
+#pragma unroll
+                                    for (int c = 0; c < 8; ++c) yv[c] = __builtin_fmaf(xv[c], sc[c], sh[c]);
+                                } else unpack8(y_all[h][kk], yv);
+                                if (swish_act) {
+#pragma unroll
+                                    for (int c = 0; c < 8; ++c) {
+                                        const float z = __builtin_fmaf(xv[c], sc[c], sh[c]) + (from_x ? 0.f : yv[c]);
+                                        v[c] = live ? bf2f(f2bf(bf2f(f2bf(v[c])) * swish_grad(z))) : 0.f;
+                                        bs1[c >> 2][c & 3] += v[c];
+                                        bs2[c >> 2][c & 3] += v[c] * (xv[c] - mu[c]) * rs[c];
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int c = 0; c < 8; ++c) {
+                                        v[c] = (live && yv[c] > 0.f) ? bf2f(f2bf(v[c])) : 0.f;
+                                        bs1[c >> 2][c & 3] += v[c];
+                                        bs2[c >> 2][c & 3] += v[c] * (xv[c] - mu[c]) * rs[c];
+                                    }
+                                }
+                            }
+                            if (live) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)(offs[i][h][kk] + n)) = pack8(v);
+                        }
+                    }
+                }
+            } else {
             // target offsets of this lane's rows: fragment i, read k -> row wm*64 + i*32 + rq + 8k
             int offs[2][4];          // elements (the launcher bounds rows * out_pitch below 2^31)
 #pragma unroll
@@ -417,6 +531,7 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                     }
                 }
             }
+            }
             if (EPI == 1) {
                 // lanes with the same c4 (8 row lanes rq) in the waves wm = 0..3 of a column group share their channels: partial sums
                 // through LDS, added in the fixed order (wm, rq).  red: [8 waves][64 lanes][16] floats = 32 KiB of the idle slot.
@@ -428,8 +543,9 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                     for (int k = 0; k < 4; ++k) { red[(wave * 64 + lane) * 16 + j * 4 + k] = bs1[j][k]; red[(wave * 64 + lane) * 16 + 8 + j * 4 + k] = bs2[j][k]; }
                 P8_SYNC_LDS();
                 if (tid < 2 * BNT) {
-                    const int which = tid / BNT, cc = tid - which * BNT;     // cc = wn*32*NJ + j*32 + c4*4 + k
-                    const int g = cc / (32 * NJ), j = (cc >> 5) % NJ, c4r = (cc >> 2) & 7, k = cc & 3;
+                    const int which = tid / BNT, cc = tid - which * BNT;     // cc = wn*32*NJ + j*32 + c4*4 + k   (WIDE: wn*64 + c8*8 + 4 j + k, the lane's channel c = 4 j + k)
+                    const int g = cc / (32 * NJ);
+                    const int j = WIDE ? (cc >> 2) & 1 : (cc >> 5) % NJ, c4r = WIDE ? (cc >> 3) & 7 : (cc >> 2) & 7, k = cc & 3;
                     float s = 0.f;
                     for (int m = 0; m < 4; ++m)
                         for (int q = 0; q < 8; ++q) s += red[((g * 4 + m) * 64 + q * 8 + c4r) * 16 + which * 8 + j * 4 + k];
@@ -499,10 +615,17 @@ int igemm_p8_launch(const IgemmFwdArgs& a, const int* meta, hipStream_t stream) 
     const int forced = svsr_tune_get(SVSR_TUNE_P8_GRID);
     if (forced > 0) G = forced < items ? forced : items;          // (above the CU count: one tile per workgroup, handed out by the dispatcher)
     const int ph = svsr_tune_get(SVSR_TUNE_P8_PH) == 2 ? 2 : 1, stagger = svsr_tune_get(SVSR_TUNE_P8_STAGGER) & 3;      // bit 0: wave groups one barrier apart, bit 1: odd workgroups walk their rounds backwards
+    const bool wide = svsr_tune_get(SVSR_TUNE_P8_WIDE) != 0;
 #define P8_LAUNCH(...) do { static bool set_ = false; \
         if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_igemm_p8<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); set_ = true; } \
         hipLaunchKernelGGL((k_igemm_p8<__VA_ARGS__>), dim3(G), dim3(512), LDS_BYTES, stream, a, stagger); } while (0)
     if (bn == 64) { if (a.bnb_x != nullptr) P8_LAUNCH(1, 1, 1); else P8_LAUNCH(0, 1, 1); }
+    // (the BatchNorm-backward epilogue in this form — p8_wide = 2 — shortens its epilogue by 19 % and lengthens its K loop by 7-12 %: 32 more
+    // live registers of per-channel constants; layer2 62.3 -> 60.4 us, layer3 52.6 -> 53.9: the plain epilogue only by default)
+    else if (wide && (a.bnb_x == nullptr || svsr_tune_get(SVSR_TUNE_P8_WIDE) == 2)) {
+        if (a.bnb_x != nullptr) { if (ph == 2) P8_LAUNCH(1, 2, 2, true); else P8_LAUNCH(1, 1, 2, true); }
+        else { if (ph == 2) P8_LAUNCH(0, 2, 2, true); else P8_LAUNCH(0, 1, 2, true); }
+    }
     else if (a.bnb_x != nullptr) { if (ph == 2) P8_LAUNCH(1, 2); else P8_LAUNCH(1, 1); }
     else { if (ph == 2) P8_LAUNCH(0, 2); else P8_LAUNCH(0, 1); }
 #undef P8_LAUNCH

@@ -47,8 +47,9 @@ static int g_tune[SVSR_TUNE_N] = {
     /* W3_WAVES */ 8,          // waves per workgroup of svsr_conv3x3_wgrad: 8 (one workgroup per CU, the two wave groups split the nine taps: half the slabs, 138 instead of 247 registers per wave) or 4 (two workgroups per CU, nine taps per wave).  Round 5, same box: layer1 launch + reduce 80.1 -> 71.6 us at 928 frames, LRW step 5.03-5.05 -> 4.97-4.99 ms, LRS 23.69 -> 23.58-23.61
     /* REDUCE_CUS */ 256,      // compute units assumed when the split of a reduction is planned (svsr_reduction_cus, common.h): fixed, so the bits of a run do not depend on the partition it runs on; 0: the device's count
     /* W3_DENSE */ 1,          // svsr_conv3x3_wgrad contracts over the REAL pixels (dense dY tile, X rows gathered through a position table) instead of walking the zero-padded grid: 1.40x / 1.19x fewer MFMAs at 11 x 11 / 22 x 22 maps; 0: the padded walk of rounds 2-5
+    /* P8_WIDE */ 2,           // epilogue of the persistent 8-wave kernel (256 x 128 tiles): full 128-byte lines per row (16-byte accesses, 8 lanes per row: both fragments of a wave through one [16][64] patch) — 1: the plain epilogue, 2: the BatchNorm-backward epilogue too; 0 = 64 bytes per row (rounds 3-5).  Same outputs bit for bit; stamped epilogue 8,785 -> 7,018 cycles per tile (plain), 28,473 -> 23,176 (BatchNorm backward, whose K loop pays 7 % for 32 more live registers); same-box steps: LRW 4.991 / 4.959 / 4.960 ms, LRS 23.14 / 23.20 / 23.03 at 0 / 1 / 2
 };
-static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128", "wg_xcd", "w3_waves", "reduce_cus", "w3_dense"};
+static const char* const g_tune_names[SVSR_TUNE_N] = {"igemm_tile", "igemm_m128", "wg_blocks", "w3_blocks", "ln_rpb", "stem_lds_fwd", "stem_lds_bwd", "igemm_lds_pad", "igemm_bn64_below", "wg_short_k", "igemm_ksplit", "epi_batched", "stem_wg_pipe", "stem_fwd_dma", "igemm_lin_bn64", "p8", "p8_grid", "p8_min_items", "p8_ph", "p8_stagger", "wg_imgmajor", "p8_bn64", "igemm_ns64", "wg_units", "wg_unit_max", "wg_unit_min", "igemm_ksplit128", "wg_xcd", "w3_waves", "reduce_cus", "w3_dense", "p8_wide"};
 
 int svsr_tune_get(int id) { return (id >= 0 && id < SVSR_TUNE_N) ? g_tune[id] : 0; }
 
