@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Copies the summaries scripts/gpu_profiles.sh left under gpurun_out/roundN/ into profiles/roundN_* (N = $ROUND, default 5), stamped with the
+"""Copies the summaries scripts/gpu_profiles.sh left under gpurun_out/roundN/ into profiles/roundN_* (N = $ROUND, default 6), stamped with the
 commit they were measured at (run right after the gpurun call, with a clean work tree):   python scripts/collect_profiles.py"""
 import json
 import os
@@ -7,7 +7,7 @@ import shutil
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RN = "round" + os.environ.get("ROUND", "5")
+RN = "round" + os.environ.get("ROUND", "6")
 SRC, DST = os.path.join(ROOT, "gpurun_out", RN), os.path.join(ROOT, "profiles")
 head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "syncvsr_amd", "bench.py", "include"], cwd=ROOT, capture_output=True, text=True).stdout.strip())

@@ -1,13 +1,13 @@
 #!/bin/bash
-# Everything profiles/roundN_* is made from (N = $ROUND, default 5), in one gpurun call (every pass is its own rocprofv3 run; PMC passes carry --kernel-trace only).
+# Everything profiles/roundN_* is made from (N = $ROUND, default 6), in one gpurun call (every pass is its own rocprofv3 run; PMC passes carry --kernel-trace only).
 # All launches in line (no side-stream overlap), like bench.py's roofline leg.  Output: gpurun_out/round$ROUND/;
 # scripts/collect_profiles.py copies the summaries into profiles/ and stamps the commit.
-ROUND=${ROUND:-5}
+ROUND=${ROUND:-6}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/round$ROUND
 rm -rf $OUT; mkdir -p $OUT
 export ROUND PYTHONUNBUFFERED=1 SVSR_SIDE_TRUNK=0 SVSR_SIDE_ENCODER=0
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-lrs-leg --enqueue eager --profile-steps 1"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-lrs-leg --sustained-steps 0 --enqueue eager --profile-steps 1"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o lrw -- $B --steps 5 --warmup 2 > $OUT/lrw_run.log 2>&1; echo "lrw stats $?"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o lrs -- $B --workload lrs --steps 3 --warmup 2 > $OUT/lrs_run.log 2>&1; echo "lrs stats $?"
 for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
@@ -26,7 +26,7 @@ python bench.py --steps 50 --warmup 5 > $OUT/bench_lrw.json 2> $OUT/bench_lrw.er
 # reduce the PMC csvs to per-kernel averages here (the raw files are large)
 python - <<'PY'
 import csv, glob, collections, json, os, re
-out = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "round" + os.environ.get("ROUND", "5"))
+out = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "round" + os.environ.get("ROUND", "6"))
 rec = collections.defaultdict(dict)
 for f in sorted(glob.glob(os.path.join(out, "pmc_*counter_collection.csv"))):
     agg = collections.defaultdict(float); cnt = collections.Counter()

@@ -97,7 +97,7 @@ long rz_alloc_count(void) { return g_allocs; }
 // did it (tests/test_gpu_redzone.py reports the test named last).  hipMemAddressReserve / hipMemCreate / hipMemMap, one allocation
 // granule of slack in front of the tensor at most.  Freed tensors are NEVER unmapped: physical pages released with hipMemRelease and handed
 // out again by the next hipMemCreate came back with stale cache lines on this stack (measured: a convolution right after a sweep that unmapped
-// the previous test's tensors read garbage or zeros; scripts/probes/tf_dbg.py) — so the pass keeps everything it ever allocated (a cap of
+// the previous test's tensors read garbage or zeros) — so the pass keeps everything it ever allocated (a cap of
 // 160 GiB makes tf_malloc fail, i.e. torch raise, long before the 288 GB device is full).
 // ---------------------------------------------------------------------------------------------------------------------------------
 namespace {
