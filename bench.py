@@ -193,7 +193,7 @@ def rocprof_avg_us(kernel_label: str, lrs: bool = False):
     """Average launch duration (us) of `kernel_label` in the committed rocprofv3 --kernel-trace --stats summary of the newest round
     (profiles/roundN_lrw_kernel_stats.csv / roundN_lrs_kernel_stats.csv, every launch in line), launch-weighted over the profiler's
     instantiations of the label (the label's <BM,BN,NS> are the tile, the profiler's template arguments are <EPI,PH,NJ>: k_igemm_p8<256,128,3> =
-    k_igemm_p8<*, *, 2>, k_igemm_p8<256,64,3> = k_igemm_p8<*, *, 1>; k_igemm_wgrad<BC,NS> = k_igemm_wgrad + k_igemm_wgrad_units of that tile).
+    k_igemm_p8<*, *, 2, *>, k_igemm_p8<256,64,3> = k_igemm_p8<*, *, 1, *>; k_igemm_wgrad<BC,NS> = k_igemm_wgrad + k_igemm_wgrad_units of that tile).
     None when the summary has no such kernel.  -> (us, source)"""
     import csv
     import glob
@@ -219,7 +219,7 @@ def rocprof_avg_us(kernel_label: str, lrs: bool = False):
         b = plain.split("<")[0]
         a = [x.strip() for x in plain[len(b) + 1:-1].split(",")] if "<" in plain else []
         if base == "k_igemm_p8":
-            return b == base and len(a) == 3 and a[2] == ("2" if targs[1] == "128" else "1")
+            return b == base and len(a) >= 3 and a[2] == ("2" if targs[1] == "128" else "1")
         if base == "k_igemm_wgrad":
             return b in ("k_igemm_wgrad", "k_igemm_wgrad_units") and a[: len(targs)] == targs
         if b != base:

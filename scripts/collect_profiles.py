@@ -35,10 +35,21 @@ bench_line = json.loads(line)
 import sys
 sys.path.insert(0, ROOT)
 import bench as _bench
+def _refresh(roof, lrs):
+    """traffic and frac_rocprof of a roofline object from the passes of THIS call (the run on the GPU box read the previous round's files)"""
+    roof["traffic"] = _bench.pmc_traffic(roof["kernel"], lrs=lrs)
+    rp = _bench.rocprof_avg_us(roof["kernel"], lrs=lrs)
+    if rp is not None:
+        flops_per_launch = roof["achieved"] * 1e12 * roof["avg_launch_us"] * 1e-6
+        roof["frac_rocprof"] = round(flops_per_launch / (rp[0] * 1e-6) / _bench.MFMA_PEAK_BF16, 5)
+        roof["rocprof_avg_launch_us"] = round(rp[0], 2)
+        roof["rocprof_source"] = rp[1]
+
+
 if "roofline" in bench_line:
-    bench_line["roofline"]["traffic"] = _bench.pmc_traffic(bench_line["roofline"]["kernel"])
+    _refresh(bench_line["roofline"], False)
 if "roofline" in bench_line.get("lrs", {}):
-    bench_line["lrs"]["roofline"]["traffic"] = _bench.pmc_traffic(bench_line["lrs"]["roofline"]["kernel"], lrs=True)
+    _refresh(bench_line["lrs"]["roofline"], True)
 open(os.path.join(DST, RN + "_bench_line.json"), "w").write(json.dumps(bench_line) + "\n")
 open(os.path.join(DST, RN + "_COMMIT"), "w").write(stamp + "\n")
 print(f"profiles/{RN}_* written for", stamp)

@@ -369,11 +369,17 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 #pragma unroll
                             for (int e = 0; e < 8; ++e) sW[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 64 + j * 32 + (lane & 31)] = acc[i][j][8 * h + e];
                         P8_WAIT_LGKM0();
+                        // a lane's 8 channels are two 16-byte reads; 16 lanes of a ds_read_b128 group cover 4 rows x 4 lanes, and with every lane
+                        // reading its LOW half first two of those rows share their banks (2-way).  Rows with bit 1 set read their HIGH half first:
+                        // the 16 accesses of a group then fall on 16 different 16-byte slots in both instructions.
+                        const int hb = (rq >> 1) & 1;
                         f32x4 rowv[2][2];
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk) {
-                            rowv[kk][0] = *reinterpret_cast<const f32x4*>(sW + (rq + 8 * kk) * 64 + c8 * 8);
-                            rowv[kk][1] = *reinterpret_cast<const f32x4*>(sW + (rq + 8 * kk) * 64 + c8 * 8 + 4);
+                            const f32x4 r0 = *reinterpret_cast<const f32x4*>(sW + (rq + 8 * kk) * 64 + c8 * 8 + 4 * hb);
+                            const f32x4 r1 = *reinterpret_cast<const f32x4*>(sW + (rq + 8 * kk) * 64 + c8 * 8 + 4 * (1 - hb));
+                            rowv[kk][0] = hb ? r1 : r0;
+                            rowv[kk][1] = hb ? r0 : r1;
                         }
                         P8_WAIT_LGKM0();
 #pragma unroll
