@@ -13,7 +13,7 @@ lo, hi = marks[-3], marks[-2]          # one whole step, from its first launch t
 seg = ev[lo:hi]
 t0 = seg[0][0]
 qs = sorted({e[3] for e in seg})
-out = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "timeline.txt")
+out = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", f"timeline_{os.environ.get('WORKLOAD', 'lrw')}.txt")
 with open(out, "w") as fo:
     for s, e, n, q, g in seg:
         fo.write(f"{(s - t0) / 1e3:9.1f} {(e - t0) / 1e3:9.1f} {(e - s) / 1e3:7.1f} q{qs.index(q)} g{g:<5d} {n}\n")

@@ -80,6 +80,7 @@ __device__ __forceinline__ bool p8_next_item(int tiles_m, int gy, int items, int
 }
 
 #ifdef SVSR_P8_STAMP
+__device__ long long g_p8_phase[8];             // wave 0 of every workgroup adds: [0] epilogue head (statistics of the accumulators, offsets, constants), [1] row block 0, [2] row block 1
 __device__ long long g_p8_stamp[2048];          // [workgroup][4]: cycles inside K loops (wave 0), K tiles walked, cycles inside epilogues, tiles — build variant "p8stamp" only
 #endif
 
@@ -329,6 +330,10 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                     }
                 }
                 P8_WAIT_LGKM0();
+#ifdef SVSR_P8_STAMP
+                if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g_p8_phase[0]), (unsigned long long)(__builtin_amdgcn_s_memtime() - t_e0));
+                long long t_ph = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     // the global operands of this row block (4 rows x 16 bytes per tensor) are requested HERE, before the first is used (see the 8-byte form below)
@@ -419,6 +424,9 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
                             if (live) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.out) + (long)(offs[i][h][kk] + n)) = pack8(v);
                         }
                     }
+#ifdef SVSR_P8_STAMP
+                    { const long long t_n = __builtin_amdgcn_s_memtime(); if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&g_p8_phase[1 + i]), (unsigned long long)(t_n - t_ph)); t_ph = t_n; }
+#endif
                 }
             } else {
             // target offsets of this lane's rows: fragment i, read k -> row wm*64 + i*32 + rq + 8k
@@ -594,11 +602,16 @@ __global__ __launch_bounds__(512, 2) void k_igemm_p8(const IgemmFwdArgs p, int s
 #ifdef SVSR_P8_STAMP
 /* build variant p8stamp (python -m syncvsr_amd.build --variant p8stamp; scripts/probes/p8_stamps.py): sums over the workgroups of {cycles inside
  * the K loops, K tiles, cycles inside the epilogues, tiles} since the last call; resets the counters */
-extern "C" int svsr_debug_p8_stamps(long long* out4) {
+extern "C" int svsr_debug_p8_stamps(long long* out4) {        /* out4: 8 words */
     static long long h[2048];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_p8_stamp), sizeof h) != hipSuccess) return SVSR_ERR_LAUNCH;
     out4[0] = out4[1] = out4[2] = out4[3] = 0;
     for (int i = 0; i < 512; ++i) for (int k = 0; k < 4; ++k) out4[k] += h[4 * i + k];
+    long long ph[8];
+    if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_p8_phase), sizeof ph) != hipSuccess) return SVSR_ERR_LAUNCH;
+    for (int k = 0; k < 4; ++k) out4[4 + k] = ph[k];
+    memset(ph, 0, sizeof ph);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_p8_phase), ph, sizeof ph);
     memset(h, 0, sizeof h);
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_p8_stamp), h, sizeof h);
 }
