@@ -411,6 +411,9 @@ int svsr_mha_bwd(const void* dctx, int dctx_pitch, const void* q, int q_pitch, c
 int64_t svsr_mha_flash_ws_bytes(int H, int Lq);
 int svsr_mha_flash_fwd(const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* ctx, int ctx_pitch, float* lse, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 int svsr_mha_flash_bwd(const void* dctx, int dctx_pitch, const void* ctx, int ctx_pitch, const float* lse, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal, void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, void* ws, int64_t ws_bytes, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
+/* the same in two parts (parts bit 0: query + key passes — dq, dq_ac, dq_bd, dk, dv; bit 1: the position-table pass — dpe, which only the weight
+ * gradient of linear_pos reads, so it may be issued on another stream behind bit 0's launches; 3 = svsr_mha_flash_bwd) */
+int svsr_mha_flash_bwd_parts(const void* dctx, int dctx_pitch, const void* ctx, int ctx_pitch, const float* lse, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal, void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, void* ws, int64_t ws_bytes, const unsigned* drop_seed, unsigned drop_site, float drop_p, int parts, hipStream_t stream);
 
 /* Conformer convolution module core (transformer/convolution.py:56-75): u [B*T][2D] = pointwise_cov1 output ->
  * GLU -> depthwise Conv1d(K odd <= 31, pad (K-1)/2, weight [D][K], bias) -> c [B*T][D] bf16 + BatchNorm1d partial sums
@@ -421,6 +424,9 @@ int svsr_glu_dwconv_fwd(const void* u, const float* w, const float* bias, void* 
 /* backward: dc = gradient of c -> du [B*T][2D]; dw [D][K] and dbias [D] accumulated.  part: fp32 workspace of
  * nsplit * D * (K+1) floats. */
 int svsr_glu_dwconv_bwd(const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias, float* part, int nsplit, int B, int T, int D, int K, hipStream_t stream);
+/* the same in two parts (bit 0: du and the partial rows; bit 1: the fixed-order sum of the rows into dw / dbias, which nothing in the backward
+ * chain waits for — another stream may take it; part must then be a buffer of its own until that launch is done) */
+int svsr_glu_dwconv_bwd_parts(const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias, float* part, int nsplit, int B, int T, int D, int K, int parts, hipStream_t stream);
 
 /* CTC loss as the reference calls it (ctc.py:44-74,83-151): log_softmax over V, torch.nn.CTCLoss(reduction="sum",
  * zero_infinity=True), blank 0, divided by the batch size.  logits fp32 [B*T][ld]; labels int64 [B][Lmax] padded with -1

@@ -630,19 +630,28 @@ int svsr_glu_dwconv_fwd(const void* u, const float* w, const float* bias, void* 
 }
 
 /* part: fp32 workspace of nsplit * D * (K+1) floats (any contents) */
-int svsr_glu_dwconv_bwd(const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias, float* part, int nsplit,
-                        int B, int T, int D, int K, hipStream_t stream) {
-    if (D % 64 != 0 || K < 1 || K > DW_MAXK || (K & 1) == 0 || nsplit < 1) return SVSR_ERR_ARG;
+/* parts: bit 0 = the pass over the activations (du, partial rows of dw / dbias into part), bit 1 = the fixed-order sum of the partial rows into
+ * dw / dbias — parameter gradients nothing in the backward chain waits for: the caller may issue bit 1 on another stream behind bit 0 */
+int svsr_glu_dwconv_bwd_parts(const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias, float* part, int nsplit,
+                              int B, int T, int D, int K, int parts, hipStream_t stream) {
+    if (D % 64 != 0 || K < 1 || K > DW_MAXK || (K & 1) == 0 || nsplit < 1 || (parts & 3) == 0 || (parts & ~3) != 0) return SVSR_ERR_ARG;
     const int ntt = (T + DW_TT - 1) / DW_TT;
     if (nsplit > B * ntt) nsplit = B * ntt;
-    if (K == DW_MAXK)
-        hipLaunchKernelGGL(k_glu_dwconv_bwd<DW_MAXK>, dim3(D / 64, nsplit), dim3(256), 0, stream, (const bf16_t*)dc, (const bf16_t*)u, w, (bf16_t*)du, part,
-                           B, T, D, K, ntt);
-    else
-        hipLaunchKernelGGL(k_glu_dwconv_bwd<0>, dim3(D / 64, nsplit), dim3(256), 0, stream, (const bf16_t*)dc, (const bf16_t*)u, w, (bf16_t*)du, part,
-                           B, T, D, K, ntt);
-    hipLaunchKernelGGL(k_dw_reduce, dim3(grid1d((long)D * (K + 1), 256)), dim3(256), 0, stream, part, nsplit, D, K, dw, dbias);
+    if (parts & 1) {
+        if (K == DW_MAXK)
+            hipLaunchKernelGGL(k_glu_dwconv_bwd<DW_MAXK>, dim3(D / 64, nsplit), dim3(256), 0, stream, (const bf16_t*)dc, (const bf16_t*)u, w, (bf16_t*)du, part,
+                               B, T, D, K, ntt);
+        else
+            hipLaunchKernelGGL(k_glu_dwconv_bwd<0>, dim3(D / 64, nsplit), dim3(256), 0, stream, (const bf16_t*)dc, (const bf16_t*)u, w, (bf16_t*)du, part,
+                               B, T, D, K, ntt);
+    }
+    if (parts & 2) hipLaunchKernelGGL(k_dw_reduce, dim3(grid1d((long)D * (K + 1), 256)), dim3(256), 0, stream, part, nsplit, D, K, dw, dbias);
     return svsr_check_launch();
+}
+
+int svsr_glu_dwconv_bwd(const void* dc, const void* u, const float* w, void* du, float* dw, float* dbias, float* part, int nsplit,
+                        int B, int T, int D, int K, hipStream_t stream) {
+    return svsr_glu_dwconv_bwd_parts(dc, u, w, du, dw, dbias, part, nsplit, B, T, D, K, 3, stream);
 }
 
 /* logits fp32 [B*T][ld]; labels int64 [B][Lmax] padded with -1; ilen int32 [B]; ab workspace fp32 [B][T][2*Lmax+1];

@@ -193,11 +193,14 @@ int svsr_mha_flash_fwd(const void* q, int q_pitch, const void* k, const void* v,
     return svsr_check_launch();
 }
 
-int svsr_mha_flash_bwd(const void* dctx, int dctx_pitch, const void* ctx, int ctx_pitch, const float* lse, const void* q, int q_pitch, const void* k,
-                       const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal,
-                       void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac,
-                       void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, void* ws,
-                       int64_t ws_bytes, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream) {
+/* parts: bit 0 = the query and key passes (dq, dq_ac, dq_bd, dk, dv; probs / ds workspace), bit 1 = the position-table pass (dpe from ds and q:
+ * nothing but the weight gradient of linear_pos reads it, so the caller may issue it on another stream once bit 0's launches are done there) */
+int svsr_mha_flash_bwd_parts(const void* dctx, int dctx_pitch, const void* ctx, int ctx_pitch, const float* lse, const void* q, int q_pitch, const void* k,
+                             const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal,
+                             void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac,
+                             void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, void* ws,
+                             int64_t ws_bytes, const unsigned* drop_seed, unsigned drop_site, float drop_p, int parts, hipStream_t stream) {
+    if ((parts & 3) == 0 || (parts & ~3) != 0) return SVSR_ERR_ARG;
     if (dh != MHA_DH || Lq < 1 || Lk < 1 || ldp < Lk || ldp % 8 != 0 || (q_pitch | kv_pitch | pe_pitch | dctx_pitch | ctx_pitch | dq_pitch | aux_pitch) % 8 != 0) return SVSR_ERR_ARG;
     if (dctx == nullptr || ctx == nullptr || lse == nullptr || probs == nullptr || ds == nullptr || dq == nullptr || dk == nullptr || dv == nullptr) return SVSR_ERR_ARG;
     const bool rel = pe != nullptr;
@@ -221,18 +224,32 @@ int svsr_mha_flash_bwd(const void* dctx, int dctx_pitch, const void* ctx, int ct
     if (rel) {
         const int LM = 64 + ((8 - Lq % 8) % 8), Rp = (2 * Lq + 32 + LM + 7) / 8 * 8;
         p.pet = (const bf16_t*)ws; p.pet_pitch = Rp; p.pet_lm = LM;
-        hipLaunchKernelGGL(k_mhaf_pe_transpose, dim3((Rp + 31) / 32, H * MHA_DH / 32), dim3(256), 0, stream, a.pe, pe_pitch, 2 * Lq - 1, (bf16_t*)ws, Rp, LM);
-        hipLaunchKernelGGL(k_mhaf_bwd_q<true>, gq, dim3(64 * waves), mhaf_bwd_lds(waves), stream, p);
-        const long n = (long)(2 * Lq - 1) * dpe_pitch;
-        long blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(k_mha_bwd_kv4<true>, gk, dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(k_mha_bwd_pe4, dim3((2 * Lq - 1 + 31) / 32, H, B), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(k_mha_pe_reduce, dim3((int)blocks), dim3(256), 0, stream, pe_part, (bf16_t*)dpe, B, n);
-    } else {
+        if (parts & 1) {
+            hipLaunchKernelGGL(k_mhaf_pe_transpose, dim3((Rp + 31) / 32, H * MHA_DH / 32), dim3(256), 0, stream, a.pe, pe_pitch, 2 * Lq - 1, (bf16_t*)ws, Rp, LM);
+            hipLaunchKernelGGL(k_mhaf_bwd_q<true>, gq, dim3(64 * waves), mhaf_bwd_lds(waves), stream, p);
+            hipLaunchKernelGGL(k_mha_bwd_kv4<true>, gk, dim3(256), 0, stream, a);
+        }
+        if (parts & 2) {
+            const long n = (long)(2 * Lq - 1) * dpe_pitch;
+            long blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+            hipLaunchKernelGGL(k_mha_bwd_pe4, dim3((2 * Lq - 1 + 31) / 32, H, B), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(k_mha_pe_reduce, dim3((int)blocks), dim3(256), 0, stream, pe_part, (bf16_t*)dpe, B, n);
+        }
+    } else if (parts & 1) {
         hipLaunchKernelGGL(k_mhaf_bwd_q<false>, gq, dim3(64 * waves), mhaf_bwd_lds(waves), stream, p);
         hipLaunchKernelGGL(k_mha_bwd_kv4<false>, gk, dim3(256), 0, stream, a);
     }
     return svsr_check_launch();
+}
+
+int svsr_mha_flash_bwd(const void* dctx, int dctx_pitch, const void* ctx, int ctx_pitch, const float* lse, const void* q, int q_pitch, const void* k,
+                       const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal,
+                       void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac,
+                       void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, void* ws,
+                       int64_t ws_bytes, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream) {
+    return svsr_mha_flash_bwd_parts(dctx, dctx_pitch, ctx, ctx_pitch, lse, q, q_pitch, k, v, kv_pitch, pe, pe_pitch, bias_u, bias_v, klen, causal, probs, ds, B, H, dh,
+                                    Lq, Lk, ldp, scale, dq, dq_pitch, dq_ac, dq_bd, aux_pitch, dk, dv, dkv_pitch, dpe, dpe_pitch, pe_part, ws, ws_bytes, drop_seed,
+                                    drop_site, drop_p, 3, stream);
 }
 
 }  // extern "C"

@@ -463,6 +463,7 @@ def _lin_bwd(model, st: _ParamStore, name: str, x, dy, rows: int, K: int, N: int
 
 
 WG_GROUP_DECODER = os.environ.get("SVSR_WG_GROUP_DECODER", "1") != "0"
+TAILS_ON_SIDE = os.environ.get("SVSR_LRS_TAILS_SIDE", "1") != "0"      # _encoder_layer_bwd: parameter-gradient tails of the layer on the side stream
 
 
 def _flush_wg_group(model) -> None:
@@ -584,8 +585,15 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
         dy = _lin_bwd(model, st, f"{cm}.pointwise_cov2", tc["y"], _branch_grad(dx3, 1.0, tc["dco"]), R, D, D)
         dc, _ = ops.bn_act_bwd(dy, tc["y"], tc["c"], tc["mean"], tc["rstd"], st.p32(f"{bn}.weight"), ws["coef"], st.g32(f"{bn}.weight"),
                                st.g32(f"{bn}.bias"), ops.ACT_SWISH, False, beta=st.p32(f"{bn}.bias"))
+    # (round 6) the two parameter-gradient tails of this layer — the depthwise convolution's partial-row sum and the position-table pass of
+    # the attention backward — feed nothing but gradients of parameters: with the weight gradients on the side stream they go there too
+    # (24 launches fewer in the main stream's chain per layer pair; same launches, same bits)
+    later = model._side.enabled and TAILS_ON_SIDE
     du = ops.glu_dwconv_bwd(dc, tc["u"], st.p32(f"{cm}.depthwise_conv.weight"), st.g32(f"{cm}.depthwise_conv.weight"),
-                            st.g32(f"{cm}.depthwise_conv.bias"), B, T, D, K)
+                            st.g32(f"{cm}.depthwise_conv.bias"), B, T, D, K, reduce_later=later)
+    if later:
+        du, (fn_dw, keep_dw) = du
+        model._side.run(fn_dw, *keep_dw)
     dt3 = _lin_bwd(model, st, f"{cm}.pointwise_cov1", tc["tn"], du, R, D, 2 * D)
     dx2 = _ln_bwd(model, st, dt3, tc["x"], f"{p}.norm_conv", tc["m"], tc["r"], addend=dx3, branch=(1.0, t["mha"]["dao"]))
     # attention
@@ -594,9 +602,12 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
     dctx = _lin_bwd(model, st, f"{sa}.linear_out", tm["ctx"], _branch_grad(dx2, 1.0, tm["dao"]), R, D, D)
     qkv = tm["qkv"]
     dqkv = torch.empty_like(qkv)
-    dq_ac, dq_bd, dpe = ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, tm["probs"], B=B, H=H, Lq=T, Lk=T, dq=dqkv,
-                                    dq_pitch=3 * D, dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, pe=tm["pe"],
-                                    bias_u=st.p32(f"{sa}.pos_bias_u"), bias_v=st.p32(f"{sa}.pos_bias_v"), drop=tm["dpr"])
+    res = ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, tm["probs"], B=B, H=H, Lq=T, Lk=T, dq=dqkv,
+                      dq_pitch=3 * D, dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, pe=tm["pe"],
+                      bias_u=st.p32(f"{sa}.pos_bias_u"), bias_v=st.p32(f"{sa}.pos_bias_v"), drop=tm["dpr"], pe_later=later)
+    dq_ac, dq_bd, dpe = res[:3]
+    if len(res) == 4:          # dpe is filled on the side stream, in front of the weight gradient of linear_pos (same stream, later)
+        model._side.run(res[3][0], *res[3][1])
     # pos_bias_u / pos_bias_v gradients: column sums nothing downstream reads — both launches on the side stream
     gu, gv = st.g32(f"{sa}.pos_bias_u"), st.g32(f"{sa}.pos_bias_v")
     model._side.run(lambda: (ops.bias_act_bwd(dq_ac, None, gu, R=R, N=D, n_valid=D, ld=D), ops.bias_act_bwd(dq_bd, None, gv, R=R, N=D, n_valid=D, ld=D)),

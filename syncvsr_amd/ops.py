@@ -1363,9 +1363,12 @@ def mha_fwd(q, q_pitch: int, k, v, kv_pitch: int, *, B: int, H: int, Lq: int, Lk
 
 
 def mha_bwd(dctx, q, q_pitch: int, k, v, kv_pitch: int, probs, *, B: int, H: int, Lq: int, Lk: int, dq, dq_pitch: int, dk, dv,
-            dkv_pitch: int, pe=None, bias_u=None, bias_v=None, drop=None):
+            dkv_pitch: int, pe=None, bias_u=None, bias_v=None, drop=None, pe_later: bool = False):
     """Writes dq/dk/dv (views with the given pitches).  Relative-position form returns (dq_ac, dq_bd, dpe) as well.
-    probs: the forward's second result (the probabilities, or the MhaLse record of a flash forward)."""
+    probs: the forward's second result (the probabilities, or the MhaLse record of a flash forward).
+    pe_later (flash + relative positions): a fourth result — (fn, keep): fn() issues the position-table pass that fills dpe on the stream
+    current WHEN IT IS CALLED (only the weight gradient of linear_pos reads dpe: the model hands fn to its side stream); keep = the tensors
+    that pass reads."""
     rel = pe is not None
     D = H * 64
     dq_ac = torch.empty((B * Lq, D), dtype=BF16, device=q.device) if rel else None
@@ -1380,10 +1383,16 @@ def mha_bwd(dctx, q, q_pitch: int, k, v, kv_pitch: int, probs, *, B: int, H: int
         ds = torch.empty_like(pbuf)
         nws = int(_lib.load().svsr_mha_flash_ws_bytes(H, Lq)) if rel else 0
         ws = torch.empty(nws, dtype=torch.uint8, device=q.device) if nws else None
-        _call("svsr_mha_flash_bwd", _p(dctx), dctx.stride(0), _p(rec.ctx), rec.ctx.stride(0), _p(rec.lse), _p(q), q_pitch, _p(k), _p(v), kv_pitch,
-              _p(pe), 0 if pe is None else pe.stride(0), _p(bias_u), _p(bias_v), _p(rec.klen), int(rec.causal), _p(pbuf), _p(ds), B, H, 64, Lq, Lk, ldp,
-              0.125, _p(dq), dq_pitch, _p(dq_ac), _p(dq_bd), D, _p(dk), _p(dv), dkv_pitch, _p(dpe), D, _p(pe_part), _p(ws), nws, *_drop(drop), _stream(),
-              label="k_mhaf_bwd", flops=flops)
+        def launch(parts: int, fl: float) -> None:
+            _call("svsr_mha_flash_bwd_parts", _p(dctx), dctx.stride(0), _p(rec.ctx), rec.ctx.stride(0), _p(rec.lse), _p(q), q_pitch, _p(k), _p(v), kv_pitch,
+                  _p(pe), 0 if pe is None else pe.stride(0), _p(bias_u), _p(bias_v), _p(rec.klen), int(rec.causal), _p(pbuf), _p(ds), B, H, 64, Lq, Lk, ldp,
+                  0.125, _p(dq), dq_pitch, _p(dq_ac), _p(dq_bd), D, _p(dk), _p(dv), dkv_pitch, _p(dpe), D, _p(pe_part), _p(ws), nws, *_drop(drop), parts,
+                  _stream(), label="k_mhaf_bwd" if parts & 1 else "k_mha_bwd_pe", flops=fl)
+
+        if rel and pe_later:
+            launch(1, flops * 6.0 / 7.0)
+            return dq_ac, dq_bd, dpe, (lambda: launch(2, flops / 7.0), (ds, q, dpe, pe_part))
+        launch(3, flops)
         return dq_ac, dq_bd, dpe
     ldp = probs.shape[-1]
     ds = torch.empty_like(probs)
@@ -1408,10 +1417,19 @@ def glu_dwconv_fwd(u, w, bias, want_stats: bool, B: int, T: int, D: int, K: int)
 DW_SPLITS = 96        # workgroups per 64-channel block of svsr_glu_dwconv_bwd: one (clip, 32-frame tile) each at B = 16, T <= 192 (16 splits left a quarter of the CUs idle with several tiles in a row each)
 
 
-def glu_dwconv_bwd(dc, u, w, dw, dbias, B: int, T: int, D: int, K: int) -> torch.Tensor:
+def glu_dwconv_bwd(dc, u, w, dw, dbias, B: int, T: int, D: int, K: int, reduce_later: bool = False):
+    """-> du; reduce_later: -> (du, (fn, keep)) — fn() issues the fixed-order sum of the partial rows into dw / dbias on the stream current when
+    it is called (parameter gradients: the model hands fn to its side stream), keep = the partial rows."""
     du = torch.empty_like(u)
     part = torch.empty(DW_SPLITS * D * (K + 1), dtype=torch.float32, device=u.device)
-    _call("svsr_glu_dwconv_bwd", _p(dc), _p(u), _p(w), _p(du), _p(dw), _p(dbias), _p(part), DW_SPLITS, B, T, D, K, _stream())
+
+    def launch(parts: int) -> None:
+        _call("svsr_glu_dwconv_bwd_parts", _p(dc), _p(u), _p(w), _p(du), _p(dw), _p(dbias), _p(part), DW_SPLITS, B, T, D, K, parts, _stream())
+
+    if reduce_later:
+        launch(1)
+        return du, (lambda: launch(2), (part,))
+    launch(3)
     return du
 
 
