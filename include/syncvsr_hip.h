@@ -412,7 +412,9 @@ int64_t svsr_mha_flash_ws_bytes(int H, int Lq);
 int svsr_mha_flash_fwd(const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* ctx, int ctx_pitch, float* lse, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 int svsr_mha_flash_bwd(const void* dctx, int dctx_pitch, const void* ctx, int ctx_pitch, const float* lse, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal, void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, void* ws, int64_t ws_bytes, const unsigned* drop_seed, unsigned drop_site, float drop_p, hipStream_t stream);
 /* the same in two parts (parts bit 0: query + key passes — dq, dq_ac, dq_bd, dk, dv; bit 1: the position-table pass — dpe, which only the weight
- * gradient of linear_pos reads, so it may be issued on another stream behind bit 0's launches; 3 = svsr_mha_flash_bwd) */
+ * gradient of linear_pos reads, so it may be issued on another stream behind bit 0's launches; 3 = svsr_mha_flash_bwd; bit 2, with bit 0: ws already
+ * holds the transposed position table, made by svsr_mha_pe_transpose — it depends on pe alone, so the forward or another stream can make it) */
+int svsr_mha_pe_transpose(const void* pe, int pe_pitch, int H, int Lq, void* ws, int64_t ws_bytes, hipStream_t stream);
 int svsr_mha_flash_bwd_parts(const void* dctx, int dctx_pitch, const void* ctx, int ctx_pitch, const float* lse, const void* q, int q_pitch, const void* k, const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal, void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac, void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, void* ws, int64_t ws_bytes, const unsigned* drop_seed, unsigned drop_site, float drop_p, int parts, hipStream_t stream);
 
 /* Conformer convolution module core (transformer/convolution.py:56-75): u [B*T][2D] = pointwise_cov1 output ->

@@ -193,14 +193,23 @@ int svsr_mha_flash_fwd(const void* q, int q_pitch, const void* k, const void* v,
     return svsr_check_launch();
 }
 
-/* parts: bit 0 = the query and key passes (dq, dq_ac, dq_bd, dk, dv; probs / ds workspace), bit 1 = the position-table pass (dpe from ds and q:
+/* the transposed position table the query pass of svsr_mha_flash_bwd reads, made ahead of time (it depends on pe alone: the forward, or another
+ * stream, can make it): ws of svsr_mha_flash_ws_bytes(H, Lq) bytes; hand the same ws to svsr_mha_flash_bwd_parts with bit 2 set */
+int svsr_mha_pe_transpose(const void* pe, int pe_pitch, int H, int Lq, void* ws, int64_t ws_bytes, hipStream_t stream) {
+    if (pe == nullptr || ws == nullptr || H < 1 || Lq < 1 || pe_pitch % 8 != 0 || ws_bytes < svsr_mha_flash_ws_bytes(H, Lq)) return SVSR_ERR_ARG;
+    const int LM = 64 + ((8 - Lq % 8) % 8), Rp = (2 * Lq + 32 + LM + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_mhaf_pe_transpose, dim3((Rp + 31) / 32, H * MHA_DH / 32), dim3(256), 0, stream, (const bf16_t*)pe, pe_pitch, 2 * Lq - 1, (bf16_t*)ws, Rp, LM);
+    return svsr_check_launch();
+}
+
+/* parts: bit 2 = ws already holds the transposed table (svsr_mha_pe_transpose); bit 0 = the query and key passes (dq, dq_ac, dq_bd, dk, dv; probs / ds workspace), bit 1 = the position-table pass (dpe from ds and q:
  * nothing but the weight gradient of linear_pos reads it, so the caller may issue it on another stream once bit 0's launches are done there) */
 int svsr_mha_flash_bwd_parts(const void* dctx, int dctx_pitch, const void* ctx, int ctx_pitch, const float* lse, const void* q, int q_pitch, const void* k,
                              const void* v, int kv_pitch, const void* pe, int pe_pitch, const float* bias_u, const float* bias_v, const int* klen, int causal,
                              void* probs, void* ds, int B, int H, int dh, int Lq, int Lk, int ldp, float scale, void* dq, int dq_pitch, void* dq_ac,
                              void* dq_bd, int aux_pitch, void* dk, void* dv, int dkv_pitch, void* dpe, int dpe_pitch, float* pe_part, void* ws,
                              int64_t ws_bytes, const unsigned* drop_seed, unsigned drop_site, float drop_p, int parts, hipStream_t stream) {
-    if ((parts & 3) == 0 || (parts & ~3) != 0) return SVSR_ERR_ARG;
+    if ((parts & 3) == 0 || (parts & ~7) != 0 || ((parts & 4) && !(parts & 1))) return SVSR_ERR_ARG;
     if (dh != MHA_DH || Lq < 1 || Lk < 1 || ldp < Lk || ldp % 8 != 0 || (q_pitch | kv_pitch | pe_pitch | dctx_pitch | ctx_pitch | dq_pitch | aux_pitch) % 8 != 0) return SVSR_ERR_ARG;
     if (dctx == nullptr || ctx == nullptr || lse == nullptr || probs == nullptr || ds == nullptr || dq == nullptr || dk == nullptr || dv == nullptr) return SVSR_ERR_ARG;
     const bool rel = pe != nullptr;
@@ -225,7 +234,8 @@ int svsr_mha_flash_bwd_parts(const void* dctx, int dctx_pitch, const void* ctx, 
         const int LM = 64 + ((8 - Lq % 8) % 8), Rp = (2 * Lq + 32 + LM + 7) / 8 * 8;
         p.pet = (const bf16_t*)ws; p.pet_pitch = Rp; p.pet_lm = LM;
         if (parts & 1) {
-            hipLaunchKernelGGL(k_mhaf_pe_transpose, dim3((Rp + 31) / 32, H * MHA_DH / 32), dim3(256), 0, stream, a.pe, pe_pitch, 2 * Lq - 1, (bf16_t*)ws, Rp, LM);
+            if (!(parts & 4))
+                hipLaunchKernelGGL(k_mhaf_pe_transpose, dim3((Rp + 31) / 32, H * MHA_DH / 32), dim3(256), 0, stream, a.pe, pe_pitch, 2 * Lq - 1, (bf16_t*)ws, Rp, LM);
             hipLaunchKernelGGL(k_mhaf_bwd_q<true>, gq, dim3(64 * waves), mhaf_bwd_lds(waves), stream, p);
             hipLaunchKernelGGL(k_mha_bwd_kv4<true>, gk, dim3(256), 0, stream, a);
         }

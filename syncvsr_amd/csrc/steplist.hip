@@ -66,7 +66,7 @@ const std::unordered_map<std::string, Entry>& registry() {
         SVSR_REG(svsr_rmsnorm_bwd), SVSR_REG(svsr_rotary), SVSR_REG(svsr_geglu_fwd), SVSR_REG(svsr_geglu_bwd), SVSR_REG(svsr_xt_embed_fwd),
         SVSR_REG(svsr_xt_embed_bwd), SVSR_REG(svsr_bias_act_bwd), SVSR_REG(svsr_ce_fwd), SVSR_REG(svsr_ce_bwd), SVSR_REG(svsr_linear_ce_fwd), SVSR_REG(svsr_linear_ce_bwd), SVSR_REG(svsr_topk_acc),
         SVSR_REG(svsr_grad_sumsq), SVSR_REG(svsr_grad_sumsq_parts), SVSR_REG(svsr_adamw_step), SVSR_REG(svsr_adamw_range), SVSR_REG(svsr_cast_bf16), SVSR_REG(svsr_transpose_cast_multi),
-        SVSR_REG(svsr_transpose_bf16_multi), SVSR_REG(svsr_fill_f32), SVSR_REG(svsr_clip_prep), SVSR_REG(svsr_mha_fwd), SVSR_REG(svsr_mha_bwd), SVSR_REG(svsr_mha_flash_fwd), SVSR_REG(svsr_mha_flash_bwd), SVSR_REG(svsr_mha_flash_bwd_parts),
+        SVSR_REG(svsr_transpose_bf16_multi), SVSR_REG(svsr_fill_f32), SVSR_REG(svsr_clip_prep), SVSR_REG(svsr_mha_fwd), SVSR_REG(svsr_mha_bwd), SVSR_REG(svsr_mha_flash_fwd), SVSR_REG(svsr_mha_flash_bwd), SVSR_REG(svsr_mha_flash_bwd_parts), SVSR_REG(svsr_mha_pe_transpose),
         SVSR_REG(svsr_glu_dwconv_fwd), SVSR_REG(svsr_glu_dwconv_bwd), SVSR_REG(svsr_glu_dwconv_bwd_parts), SVSR_REG(svsr_ctc_fwd), SVSR_REG(svsr_ctc_grad),
         SVSR_REG(svsr_ctc_prefix_score), SVSR_REG(svsr_lrs_targets), SVSR_REG(svsr_embed_pos_fwd), SVSR_REG(svsr_embed_pos_bwd), SVSR_REG(svsr_ls_loss_fwd),
         SVSR_REG(svsr_ls_loss_bwd), SVSR_REG(svsr_scale_bf16), SVSR_REG(svsr_word_add), SVSR_REG(svsr_lincomb2), SVSR_REG(svsr_igemm_wgrad_group), SVSR_REG(svsr_enc_fwd), SVSR_REG(svsr_enc_bwd), SVSR_REG(svsr_lincomb3_ratio), SVSR_REG(svsr_add_ln_bwd_partials), SVSR_REG(svsr_add_ln_bwd_branch), SVSR_REG(svsr_bias_act_bwd_partials),

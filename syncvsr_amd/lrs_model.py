@@ -463,6 +463,7 @@ def _lin_bwd(model, st: _ParamStore, name: str, x, dy, rows: int, K: int, N: int
 
 
 WG_GROUP_DECODER = os.environ.get("SVSR_WG_GROUP_DECODER", "1") != "0"
+PE_AHEAD = os.environ.get("SVSR_LRS_PE_AHEAD", "1") != "0"             # _encoder_fwd: every layer's linear_pos(pos_emb) + its transposed copy on the side stream, under the front-end
 TAILS_ON_SIDE = os.environ.get("SVSR_LRS_TAILS_SIDE", "1") != "0"      # _encoder_layer_bwd: parameter-gradient tails of the layer on the side stream
 
 
@@ -535,13 +536,14 @@ def _encoder_layer_fwd(model: E2E, st: _ParamStore, tape: dict, i: int, x, pos16
     # relative-position self-attention
     t2, m2, r2 = _ln(st, x1, f"{p}.norm_mha")
     qkv = _lin(st, t2, f"{p}.self_attn.linear_q", R, D, 3 * D)
-    pe = _lin(st, pos16, f"{p}.self_attn.linear_pos", 2 * T - 1, D, D, bias=False)
+    ahead = tape.get("_pe_ahead")
+    pe, pet = ahead[i] if ahead is not None else (_lin(st, pos16, f"{p}.self_attn.linear_pos", 2 * T - 1, D, D, bias=False), None)
     bu, bv = st.p32(f"{p}.self_attn.pos_bias_u"), st.p32(f"{p}.self_attn.pos_bias_v")
     dpr, dao = model._d(f"enc.{i}.attn.probs", attn=True), model._d(f"enc.{i}.attn.out")
     ctx, probs = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=T, Lk=T, pe=pe, bias_u=bu, bias_v=bv, klen=ilen,
                              drop=dpr, flash=True)
     x2 = _lin(st, ctx, f"{p}.self_attn.linear_out", R, D, D, addend=x1, drop=dao)
-    t["mha"] = dict(x=x1, tn=t2, m=m2, r=r2, qkv=qkv, pe=pe, ctx=ctx, probs=probs, dpr=dpr, dao=dao)
+    t["mha"] = dict(x=x1, tn=t2, m=m2, r=r2, qkv=qkv, pe=pe, pet=pet, ctx=ctx, probs=probs, dpr=dpr, dao=dao)
     # convolution module
     t3, m3, r3 = _ln(st, x2, f"{p}.norm_conv")
     cm = f"{p}.conv_module"
@@ -604,7 +606,7 @@ def _encoder_layer_bwd(model: E2E, st: _ParamStore, tape: dict, i: int, dxo, pos
     dqkv = torch.empty_like(qkv)
     res = ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, tm["probs"], B=B, H=H, Lq=T, Lk=T, dq=dqkv,
                       dq_pitch=3 * D, dk=dqkv[:, D:], dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, pe=tm["pe"],
-                      bias_u=st.p32(f"{sa}.pos_bias_u"), bias_v=st.p32(f"{sa}.pos_bias_v"), drop=tm["dpr"], pe_later=later)
+                      bias_u=st.p32(f"{sa}.pos_bias_u"), bias_v=st.p32(f"{sa}.pos_bias_v"), drop=tm["dpr"], pe_later=later, pet=tm.get("pet"))
     dq_ac, dq_bd, dpe = res[:3]
     if len(res) == 4:          # dpe is filled on the side stream, in front of the weight gradient of linear_pos (same stream, later)
         model._side.run(res[3][0], *res[3][1])
@@ -704,16 +706,30 @@ def _encoder_fwd(model: E2E, st: _ParamStore, tape: dict, x, ilen, training: boo
     B, T = x.shape[:2]
     D, R = model.adim, B * T
     videos = x.view(B, 1, T, x.size(3), x.size(4))             # [B,T,1,H,W] and [B,1,T,H,W] are the same memory (C = 1)
-    feats = _frontend_forward(model, st, tape, videos, training)          # [R, 512] bf16
-    model._side.join()                # the previous step's optimiser may still be updating everything behind the front-end on the side stream (engine.TrainStep)
     if training and (model.drop_p > 0.0 or model.attn_drop_p > 0.0):
         model._advance_dropout(x.device)
-    dex = model._d("enc.embed.x")
-    h = _lin(st, feats, "encoder.embed.0", R, 512, D, alpha=math.sqrt(D), drop=dex)        # dropout(x * xscale), embedding.py:208,217
     pos16 = model._pos_table("rel", T, x.device)
     dpos = model._d("enc.embed.pos")
     if dpos is not None:
         pos16 = ops.scale_bf16(pos16, 1.0, drop=dpos)                                      # dropout(pos_emb), embedding.py:217
+    if training and model._side.enabled and PE_AHEAD:
+        # (round 6) every layer's projection of the position table — linear_pos(pos_emb), attention.py:238-250 — and its transposed copy for the
+        # attention backward depend on the step's weights and on pos_emb alone: all of them are made on the side stream while the front-end
+        # runs (behind the previous step's optimiser there; the join below is the one that existed), 24 launches off the main chain
+        pre: dict = {}
+        tape["_pe_ahead"] = pre
+
+        def ahead(pos16=pos16) -> None:
+            for i in range(model.elayers):
+                pe = _lin(st, pos16, f"encoder.encoders.{i}.self_attn.linear_pos", 2 * T - 1, D, D, bias=False)
+                pre[i] = (pe, ops.mha_pe_transpose(pe, model.aheads, T))
+
+        model._side.run(ahead, pos16)
+        model._side.flush()
+    feats = _frontend_forward(model, st, tape, videos, training)          # [R, 512] bf16
+    model._side.join()                # the previous step's optimiser may still be updating everything behind the front-end on the side stream (engine.TrainStep)
+    dex = model._d("enc.embed.x")
+    h = _lin(st, feats, "encoder.embed.0", R, 512, D, alpha=math.sqrt(D), drop=dex)        # dropout(x * xscale), embedding.py:208,217
     for i in range(model.elayers):
         h = _encoder_layer_fwd(model, st, tape, i, h, pos16, ilen, B, T, training)
         if "layer_outs" in tape:

@@ -1362,8 +1362,16 @@ def mha_fwd(q, q_pitch: int, k, v, kv_pitch: int, *, B: int, H: int, Lq: int, Lk
     return ctx, probs
 
 
+def mha_pe_transpose(pe: torch.Tensor, H: int, Lq: int) -> torch.Tensor:
+    """The transposed position table the query pass of the flash backward reads (mha_bwd(..., pet=...)): it depends on pe alone."""
+    nws = int(_lib.load().svsr_mha_flash_ws_bytes(H, Lq))
+    ws = torch.empty(nws, dtype=torch.uint8, device=pe.device)
+    _call("svsr_mha_pe_transpose", _p(pe), pe.stride(0), H, Lq, _p(ws), nws, _stream())
+    return ws
+
+
 def mha_bwd(dctx, q, q_pitch: int, k, v, kv_pitch: int, probs, *, B: int, H: int, Lq: int, Lk: int, dq, dq_pitch: int, dk, dv,
-            dkv_pitch: int, pe=None, bias_u=None, bias_v=None, drop=None, pe_later: bool = False):
+            dkv_pitch: int, pe=None, bias_u=None, bias_v=None, drop=None, pe_later: bool = False, pet: Optional[torch.Tensor] = None):
     """Writes dq/dk/dv (views with the given pitches).  Relative-position form returns (dq_ac, dq_bd, dpe) as well.
     probs: the forward's second result (the probabilities, or the MhaLse record of a flash forward).
     pe_later (flash + relative positions): a fourth result — (fn, keep): fn() issues the position-table pass that fills dpe on the stream
@@ -1382,7 +1390,8 @@ def mha_bwd(dctx, q, q_pitch: int, k, v, kv_pitch: int, probs, *, B: int, H: int
         pbuf = torch.empty((B * H, Lq, ldp), dtype=BF16, device=q.device)       # workspace: P and dS of the query pass for the key / table passes
         ds = torch.empty_like(pbuf)
         nws = int(_lib.load().svsr_mha_flash_ws_bytes(H, Lq)) if rel else 0
-        ws = torch.empty(nws, dtype=torch.uint8, device=q.device) if nws else None
+        have_pet = 4 if (rel and pet is not None) else 0          # (mha_pe_transpose made the table ahead of time)
+        ws = pet if have_pet else (torch.empty(nws, dtype=torch.uint8, device=q.device) if nws else None)
         def launch(parts: int, fl: float) -> None:
             _call("svsr_mha_flash_bwd_parts", _p(dctx), dctx.stride(0), _p(rec.ctx), rec.ctx.stride(0), _p(rec.lse), _p(q), q_pitch, _p(k), _p(v), kv_pitch,
                   _p(pe), 0 if pe is None else pe.stride(0), _p(bias_u), _p(bias_v), _p(rec.klen), int(rec.causal), _p(pbuf), _p(ds), B, H, 64, Lq, Lk, ldp,
@@ -1390,9 +1399,9 @@ def mha_bwd(dctx, q, q_pitch: int, k, v, kv_pitch: int, probs, *, B: int, H: int
                   _stream(), label="k_mhaf_bwd" if parts & 1 else "k_mha_bwd_pe", flops=fl)
 
         if rel and pe_later:
-            launch(1, flops * 6.0 / 7.0)
+            launch(1 | have_pet, flops * 6.0 / 7.0)
             return dq_ac, dq_bd, dpe, (lambda: launch(2, flops / 7.0), (ds, q, dpe, pe_part))
-        launch(3, flops)
+        launch(3 | have_pet, flops)
         return dq_ac, dq_bd, dpe
     ldp = probs.shape[-1]
     ds = torch.empty_like(probs)
