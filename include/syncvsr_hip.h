@@ -299,6 +299,7 @@ int svsr_bias_act_bwd(const void* dy, const void* z, void* dz, float* db, int R,
  * target_idx (int64 [R]) / target_prob (fp32 [R][V], pitch ldt) is non-null.  *loss = mean loss (row losses land in
  * row_loss [R] and are added in a fixed order).  A target index outside [0, V) yields NaN (torch raises a device assert). */
 int svsr_ce_fwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt, int R, int V, float smoothing, float* loss, float* lse, float* row_loss, hipStream_t stream);
+/* svsr_ce_bwd: dlogits bf16 [R][ldo] = gout / R * d loss / d logits; columns V .. ldo - 1 of every row are written as zeros. */
 int svsr_ce_bwd(const void* logits, int logits_f32, int ld, const int64_t* target_idx, const float* target_prob, int ldt, int R, int V, float smoothing, const float* lse, const float* gout, void* dlogits, int ldo, hipStream_t stream);
 
 /* ---- the SyncVSR audio-token head (audio_head.hip) ----------------------------------------------------------------------

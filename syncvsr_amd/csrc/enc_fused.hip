@@ -25,6 +25,7 @@
 // finishes with garbage instead of hanging).  Weights are read-only and stream through a 3-deep LDS ring by LDS-DMA.
 // Grid: 8 workgroups per sequence, all of which must be resident together: at most 32 sequences per launch (256 CUs); the host
 // splits larger batches into several launches (sequences are independent).
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -1226,6 +1227,42 @@ __global__ __launch_bounds__(256) void k_enc_table(const EncTable t, int words, 
 
 static unsigned long long* g_enc_trace = nullptr;
 
+// Layer-record tables that are already on the device (round 6): a training step calls svsr_enc_fwd / svsr_enc_bwd with the same records every
+// time (the recorded step list re-issues the call with frozen arguments), and the writer kernel was a 5-us launch in the main stream's chain
+// each time.  A table is uploaded ONCE into a slot of a small pool and found again by its bytes; slots are never recycled (a captured graph
+// or an enqueued launch may still read them): when the pool is full, or the stream is being captured, the table goes into the caller's
+// workspace as before.  The pool is allocated by the workspace-size queries (never inside a capture).
+constexpr int TAB_SLOTS = 64, TAB_BYTES = 3584;
+struct TabEntry { unsigned char bytes[TAB_BYTES]; size_t n; hipStream_t stream; };
+static char* g_tab_pool = nullptr;
+static TabEntry* g_tab_entries = nullptr;
+static int g_tab_used = 0;
+static void enc_tab_pool_init() {
+    if (g_tab_pool != nullptr) return;
+    void* d = nullptr;
+    if (hipMalloc(&d, (size_t)TAB_SLOTS * TAB_BYTES) != hipSuccess) { (void)hipGetLastError(); return; }
+    g_tab_entries = static_cast<TabEntry*>(malloc(sizeof(TabEntry) * TAB_SLOTS));
+    if (g_tab_entries == nullptr) { (void)hipFree(d); return; }
+    g_tab_pool = static_cast<char*>(d);
+}
+// -> device address of an uploaded table with these bytes (hit), or of a fresh slot the caller must fill on `stream` (*fill = true), or null
+static void* enc_tab_find(const void* t, size_t n, hipStream_t stream, bool* fill) {
+    *fill = false;
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("SVSR_ENC_TAB_CACHE"); off = (e != nullptr && e[0] == '0') ? 1 : 0; }      // SVSR_ENC_TAB_CACHE=0: a writer launch per call, as before
+    if (off || g_tab_pool == nullptr || n > (size_t)TAB_BYTES) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
+    for (int i = 0; i < g_tab_used; ++i)
+        if (g_tab_entries[i].n == n && g_tab_entries[i].stream == stream && memcmp(g_tab_entries[i].bytes, t, n) == 0) return g_tab_pool + (size_t)i * TAB_BYTES;
+    if (g_tab_used >= TAB_SLOTS) return nullptr;
+    TabEntry& e = g_tab_entries[g_tab_used];
+    memcpy(e.bytes, t, n); e.n = n; e.stream = stream;
+    *fill = true;
+    return g_tab_pool + (size_t)(g_tab_used++) * TAB_BYTES;
+}
+
 // One word of pinned, device-mapped host memory: a giving-up workgroup stores 1 into it (system scope), the host polls it for free.
 // Allocated by the first workspace-size query (every launch is preceded by one; never inside a stream capture).
 static unsigned g_enc_spin_limit = 1u << 20;       // polls (s_sleep 4 + one L2 read each: ~1 s in all) before a cluster wait gives up
@@ -1266,7 +1303,7 @@ int svsr_debug_enc_trace(int64_t* out, int n) {
 }
 
 /* bytes of the device workspace svsr_enc_fwd needs for B sequences: arrival counters, error word, layer records */
-int64_t svsr_enc_fwd_ws_bytes(int B) { enc_host_flag_init(); return B < 1 ? 0 : (int64_t)(((B + 1) * 4 + 255) / 256 * 256) + (int64_t)sizeof(EncTable); }
+int64_t svsr_enc_fwd_ws_bytes(int B) { enc_host_flag_init(); enc_tab_pool_init(); return B < 1 ? 0 : (int64_t)(((B + 1) * 4 + 255) / 256 * 256) + (int64_t)sizeof(EncTable); }
 
 /* svsr_enc_fwd: forward of `n_layers` consecutive HF-BERT encoder layers (width 512, 8 heads of 64, FFN 2048, sequences of S <= 32
  * rows) in one launch per 32 sequences.  x0 bf16 [B*S][512]: the first layer's input; layers: HOST array of n_layers records (device
@@ -1287,8 +1324,10 @@ int svsr_enc_fwd(const void* x0, const svsr_enc_layer* layers, int n_layers, int
     EncTable t;
     memset(&t, 0, sizeof t);
     for (int l = 0; l < n_layers; ++l) t.L[l] = layers[l];
-    svsr_enc_layer* tab_dev = reinterpret_cast<svsr_enc_layer*>(static_cast<char*>(ws) + cnt_bytes);
-    hipLaunchKernelGGL(k_enc_table, dim3(1), dim3(256), 0, stream, t, (int)(sizeof(EncTable) / 8), reinterpret_cast<long long*>(tab_dev));
+    bool fill = true;
+    svsr_enc_layer* tab_dev = static_cast<svsr_enc_layer*>(enc_tab_find(&t, sizeof t, stream, &fill));
+    if (tab_dev == nullptr) { tab_dev = reinterpret_cast<svsr_enc_layer*>(static_cast<char*>(ws) + cnt_bytes); fill = true; }
+    if (fill) hipLaunchKernelGGL(k_enc_table, dim3(1), dim3(256), 0, stream, t, (int)(sizeof(EncTable) / 8), reinterpret_cast<long long*>(tab_dev));
     EncArgs a;
     a.x0 = (const bf16_t*)x0; a.Ls = tab_dev;
     a.layers = n_layers; a.S = S; a.eps = ln_eps;
@@ -1332,7 +1371,7 @@ int svsr_enc_gave_up_peek(void) {
 }
 
 /* bytes of the device workspace svsr_enc_bwd needs for B sequences */
-int64_t svsr_enc_bwd_ws_bytes(int B) { enc_host_flag_init(); return B < 1 ? 0 : (int64_t)(((B + 1) * 4 + 255) / 256 * 256) + (int64_t)sizeof(EncBwdTable); }
+int64_t svsr_enc_bwd_ws_bytes(int B) { enc_host_flag_init(); enc_tab_pool_init(); return B < 1 ? 0 : (int64_t)(((B + 1) * 4 + 255) / 256 * 256) + (int64_t)sizeof(EncBwdTable); }
 
 /* svsr_enc_bwd: backward of the layers svsr_enc_fwd ran, in one launch per 32 sequences.  dy bf16 [B*S][512]: gradient of the last layer's
  * output; layers: HOST array of n_layers records in FORWARD order.  Written per layer: ds2 / df / ds1 / dao / dx1 / dx bf16 [R][512], dz bf16
@@ -1353,8 +1392,10 @@ int svsr_enc_bwd(const void* dy, const svsr_enc_bwd_layer* layers, int n_layers,
     EncBwdTable t;
     memset(&t, 0, sizeof t);
     for (int l = 0; l < n_layers; ++l) t.L[l] = layers[l];
-    svsr_enc_bwd_layer* tab_dev = reinterpret_cast<svsr_enc_bwd_layer*>(static_cast<char*>(ws) + cnt_bytes);
-    hipLaunchKernelGGL(k_enc_bwd_table, dim3(1), dim3(256), 0, stream, t, (int)(sizeof(EncBwdTable) / 8), reinterpret_cast<long long*>(tab_dev));
+    bool fill = true;
+    svsr_enc_bwd_layer* tab_dev = static_cast<svsr_enc_bwd_layer*>(enc_tab_find(&t, sizeof t, stream, &fill));
+    if (tab_dev == nullptr) { tab_dev = reinterpret_cast<svsr_enc_bwd_layer*>(static_cast<char*>(ws) + cnt_bytes); fill = true; }
+    if (fill) hipLaunchKernelGGL(k_enc_bwd_table, dim3(1), dim3(256), 0, stream, t, (int)(sizeof(EncBwdTable) / 8), reinterpret_cast<long long*>(tab_dev));
     EncBwdArgs a;
     a.dy = (const bf16_t*)dy; a.Ls = tab_dev;
     a.layers = n_layers; a.S = S;

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void k_ce_bwd(const CeArgs a, const float* gou
                 dlogits[(long)row * ldo + v] = f2bf(g * (p * st - tt));
             }
         }
+        for (int v = a.V + lane; v < ldo; v += 64) dlogits[(long)row * ldo + v] = (bf16_t)0;      // pad columns of the row (ldo > V): zeros, no memset in front of the launch
     }
 }
 

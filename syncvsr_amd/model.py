@@ -371,9 +371,19 @@ class TransformerLightningModule(nn.Module):
                 pass
 
         ctx = _Ctx()
-        loss_category, loss_audio, acc = _LrwFunction.forward(ctx, self.cls_token, self, st, videos, audio_tokens, labels, True,
-                                                              word_mask if self.use_wb else None)
-        loss_total = ops.lincomb2(loss_category, loss_audio, self.lambda_audio)
+        self._metrics_on_side = True          # what only the caller reads (accuracy, loss_total) is computed on the side stream: joined when the backward ends
+        try:
+            loss_category, loss_audio, acc = _LrwFunction.forward(ctx, self.cls_token, self, st, videos, audio_tokens, labels, True,
+                                                                  word_mask if self.use_wb else None)
+        finally:
+            self._metrics_on_side = False
+        if self._side.enabled and METRICS_ON_SIDE:
+            box: dict = {}
+            self._side.run(lambda: box.__setitem__("t", ops.lincomb2(loss_category, loss_audio, self.lambda_audio)), loss_category, loss_audio)
+            self._side.flush()
+            loss_total = box["t"]
+        else:
+            loss_total = ops.lincomb2(loss_category, loss_audio, self.lambda_audio)
         _LrwFunction.backward(ctx, self._g_one, self._g_lam, None)
         return {"loss_total": loss_total, "loss_category": loss_category, "loss_audio": loss_audio, "accuracy_top1": acc[0],
                 "accuracy_top5": acc[1]}
@@ -733,6 +743,7 @@ def _lin_wgrad(model, x, dy, gw, gb, rows: int, K: int, N: int, x_pitch: int, dy
     model._side.run(lambda: ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=x_pitch, dy_pitch=dy_pitch, db=gb), x, dy, small=True)
 
 
+METRICS_ON_SIDE = os.environ.get("SVSR_METRICS_ON_SIDE", "1") != "0"      # train_step_direct: accuracy and loss_total (read by the caller only) on the side stream
 DEFER_REDUCTIONS = os.environ.get("SVSR_DEFER_REDUCTIONS", "1") != "0"     # encoder backward: parameter-gradient reductions on the side stream
 
 
@@ -1103,7 +1114,15 @@ class _LrwFunction(torch.autograd.Function):
             loss_a, lse_a = ops.linear_ce_fwd(h, st.s16("audio_projection.weight"), st.p32("audio_projection.bias"), tok, B * T, D, A * G, V, seq=(S, 1, T))
         else:
             loss_a, lse_a = ops.ce_fwd(logits_a, V, tok, None, B * T * A * G, V, 0.0)
-        acc = ops.topk_acc(logits_c, lab_idx, lab_prob)
+        if getattr(model, "_metrics_on_side", False) and model._side.enabled and METRICS_ON_SIDE:
+            # (round 6) inside TrainStep the metric is read when the step is over: its two launches leave the main stream's chain (the
+            # side stream is joined at the end of the backward)
+            box: dict = {}
+            model._side.run(lambda: box.__setitem__("acc", ops.topk_acc(logits_c, lab_idx, lab_prob)), logits_c)
+            model._side.flush()
+            acc = box["acc"]
+        else:
+            acc = ops.topk_acc(logits_c, lab_idx, lab_prob)
         model._last = dict(logits_category=logits_c, logits_audio=logits_a, feats=feats, hidden=h)
         if need_grad:
             tape["head"] = dict(h=h, logits_c=logits_c, lse_c=lse_c, lab_idx=lab_idx, lab_prob=lab_prob, logits_a=None if fused_head else logits_a,
@@ -1134,7 +1153,7 @@ class _LrwFunction(torch.autograd.Function):
                               g_audio, dla, seq=(S, 1, T))
         else:
             ops.ce_bwd(th["logits_a"], V, th["tok"], None, B * T * A * G, V, 0.0, th["lse_a"], g_audio, dla, V)
-        dlc = ops.zeros((B, Cp), BF16, dev)
+        dlc = torch.empty((B, Cp), dtype=BF16, device=dev)          # (svsr_ce_bwd writes the pad columns C .. Cp - 1 as zeros)
         ops.ce_bwd(th["logits_c"], C, th["lab_idx"], th["lab_prob"], B, C, model.label_smoothing, th["lse_c"], g_cat, dlc, Cp)
         h = th["h"]
         grouped = ops.WGRAD_GROUP and model.encoder_type == "huggingface"
