@@ -164,6 +164,11 @@ int svsr_conv3x3_c64(const void* in, const void* wt, void* out, const void* adde
  * svsr_bn_bwd_from_stats then adds the rows in a fixed order (dgamma +=, dbeta +=, coef[3][C] scratch) and writes
  * dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)). */
 int svsr_igemm_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, hipStream_t stream);
+/* The same epilogue for a linear layer / convolution whose INPUT was y = dropout(relu(z)) (positionwise_feed_forward.py:28-30): stores
+ * dz = (y > 0 ? gscale * dL/dy : 0) (gscale = 1 / (1 - p): y is zero where ReLU or the dropout mask cut) and writes the column sums of dz per row tile
+ * into the first half of stats[meta[3]][2][Co] — the partial rows of the bias gradient of the layer in front (svsr_colsum_rows adds them).
+ * zeros / ones: device vectors of Co floats holding 0 / 1.  4-wave plans only (not the persistent 3x3 kernel). */
+int svsr_igemm_dgrad_relu(const void* in, const void* wt, void* out, float* stats, const int* plan_dev, const int* meta, int Nimg, int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, const void* y, const float* zeros, const float* ones, float gscale, hipStream_t stream);
 int svsr_conv3x3_c64_dgrad_bn(const void* in, const void* wt, void* out, const void* addend, float* stats, int Nimg, int H, int W, const int* dy, const int* dx, const int* tw, const void* y, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act, const int* pixtab, hipStream_t stream);
 int svsr_bn_bwd_from_stats(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma, const float* stats, int nrows, float* coef, float* dgamma, float* dbeta, void* dx, int64_t npix, int C, hipStream_t stream);
 

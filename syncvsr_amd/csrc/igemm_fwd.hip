@@ -158,6 +158,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmFwdArgs& p, f32x16 (&a
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         v[k] = yv[k] > 0.f ? bf2f(f2bf(v[k])) : 0.f;
+                        if (p.alpha != 1.f) v[k] = bf2f(f2bf(v[k] * p.alpha));       // svsr_igemm_dgrad_relu: the dropout scale of the masked units (uniform branch)
                         bs1[k] += v[k];
                         bs2[k] += v[k] * (xv[k] - mu[k]) * rs[k];
                     }
@@ -800,7 +801,7 @@ static int igemm_fwd_run(const void* in, const void* wt, void* out, void* out_pr
     a.bnb_gamma = bnb_gamma; a.bnb_beta = bnb_beta; a.bnb_act = bnb_act;
     const int bm = meta[0], bn = meta[1], ns = meta[2], gx = meta[3], gy = (Co + bn - 1) / bn;
     if (gx < 1) return SVSR_ERR_ARG;
-    if (bm == P8_BM) return igemm_p8_launch(a, meta, stream);
+    if (bm == P8_BM) return (bnb_x != nullptr && alpha != 1.f) ? SVSR_ERR_ARG : igemm_p8_launch(a, meta, stream);      // (the persistent kernel's BatchNorm-backward epilogue has no scale)
     // few tiles, long contraction: split K inside the workgroup (see k_igemm_fwd_glds, KG = 2)
     if (svsr_igemm_fwd_kgroups(meta, Ci, Co, bnb_x != nullptr) == 2) {
         if (bm == 128) return launch_glds<128, 64, 3, 2>(a, gx, gy, stream);
@@ -824,6 +825,20 @@ extern "C" int svsr_igemm_fwd(const void* in, const void* wt, void* out, void* o
                               unsigned drop_site, float drop_p, hipStream_t stream) {
     return igemm_fwd_run(in, wt, out, out_pre, bias, addend, stats, plan_dev, meta, Nimg, in_pix, Ci, in_pitch, Co, out_pix, out_pitch,
                          wt_taps, act, out_f32, alpha, drop_seed, drop_site, drop_p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+
+/* svsr_igemm_dgrad_relu: the data gradient of a linear layer / convolution whose INPUT was y = dropout(relu(z)) — the feed-forward blocks of the
+ * Conformer and of the decoder (positionwise_feed_forward.py:28-30: w_2(dropout(relu(w_1 x)))).  The launch stores
+ * dz = (y > 0 ? gscale * dL/dy : 0) instead of dL/dy (y: the saved activation, zero where ReLU or the dropout mask cut; gscale = 1 / (1 - p)) and
+ * writes, per row tile, the column sums of dz into stats[meta[3]][2][Co] (first half of every row: the partial rows of the bias gradient of
+ * w_1; the second half is scratch) — what svsr_bias_act_bwd did in a launch of its own behind the data gradient.  It is the BatchNorm-backward
+ * epilogue of svsr_igemm_dgrad_bn run with mean 0, rstd 1, gamma 1, beta 0: zeros / ones are device vectors of Co floats holding those values. */
+extern "C" int svsr_igemm_dgrad_relu(const void* in, const void* wt, void* out, float* stats, const int* plan_dev, const int* meta, int Nimg,
+                                     int in_pix, int Ci, int in_pitch, int Co, int out_pix, int out_pitch, int wt_taps, const void* y,
+                                     const float* zeros, const float* ones, float gscale, hipStream_t stream) {
+    if (y == nullptr || zeros == nullptr || ones == nullptr || stats == nullptr || Co % 8 != 0 || out_pitch % 8 != 0 || !(gscale > 0.f)) return SVSR_ERR_ARG;
+    return igemm_fwd_run(in, wt, out, nullptr, nullptr, nullptr, stats, plan_dev, meta, Nimg, in_pix, Ci, in_pitch, Co, out_pix, out_pitch,
+                         wt_taps, 0, 0, gscale, nullptr, 0, 0.f, nullptr, y, zeros, ones, ones, zeros, 1, stream);
 }
 
 /* svsr_igemm_dgrad_bn: a data-gradient plan (every target pixel visited exactly once: svsr_conv_plan mode 1) whose result dL/dy is the

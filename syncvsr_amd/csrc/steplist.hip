@@ -58,7 +58,7 @@ struct Bind<int (*)(A...), fn> {
 const std::unordered_map<std::string, Entry>& registry() {
     static const std::unordered_map<std::string, Entry> r = {
         SVSR_REG(svsr_colsum_rows), SVSR_REG(svsr_colsum_rows_multi), SVSR_REG(svsr_igemm_fwd), SVSR_REG(svsr_igemm_wgrad), SVSR_REG(svsr_conv3x3_c64),
-        SVSR_REG(svsr_igemm_dgrad_bn), SVSR_REG(svsr_conv3x3_c64_dgrad_bn), SVSR_REG(svsr_bn_bwd_from_stats),
+        SVSR_REG(svsr_igemm_dgrad_bn), SVSR_REG(svsr_igemm_dgrad_relu), SVSR_REG(svsr_conv3x3_c64_dgrad_bn), SVSR_REG(svsr_bn_bwd_from_stats),
         SVSR_REG(svsr_conv3x3_wgrad), SVSR_REG(svsr_stem_conv_fwd), SVSR_REG(svsr_stem_conv_wgrad), SVSR_REG(svsr_stem_bwd_wgrad), SVSR_REG(svsr_bn_finalize),
         SVSR_REG(svsr_bn_eval_prepare), SVSR_REG(svsr_bn_act_fwd), SVSR_REG(svsr_bn_act_bwd), SVSR_REG(svsr_stem_bn_act_pool_fwd),
         SVSR_REG(svsr_stem_bn_act_pool_bwd), SVSR_REG(svsr_avgpool_fwd), SVSR_REG(svsr_avgpool_bwd), SVSR_REG(svsr_add_ln_fwd),

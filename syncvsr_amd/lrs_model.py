@@ -463,6 +463,7 @@ def _lin_bwd(model, st: _ParamStore, name: str, x, dy, rows: int, K: int, N: int
 
 
 WG_GROUP_DECODER = os.environ.get("SVSR_WG_GROUP_DECODER", "1") != "0"
+FFN_DGRAD_FUSED = os.environ.get("SVSR_LRS_FFN_DGRAD_FUSED", "1") != "0"      # _ffn_bwd: relu' + bias-gradient partials in the epilogue of w_2's data gradient
 PE_AHEAD = os.environ.get("SVSR_LRS_PE_AHEAD", "1") != "0"             # _encoder_fwd: every layer's linear_pos(pos_emb) + its transposed copy on the side stream, under the front-end
 TAILS_ON_SIDE = os.environ.get("SVSR_LRS_TAILS_SIDE", "1") != "0"      # _encoder_layer_bwd: parameter-gradient tails of the layer on the side stream
 
@@ -520,9 +521,20 @@ def _ffn_fwd(model, st, t: dict, key: str, x, p: str, R: int, D: int, U: int, al
 def _ffn_bwd(model, st, t: dict, dy, p: str, R: int, D: int, U: int, alpha: float, norm: str, branch=None):
     """x' = x + alpha * dropout(FFN(LN(x))); dy = grad of x' -> grad of x.  branch: (alpha, drop) of the branch in front (see _ln_bwd)."""
     dys = _branch_grad(dy, alpha, t["do"])
-    dh = _lin_bwd(model, st, f"{p}.w_2", t["h"], dys, R, U, D)
     gs = 1.0 / (1.0 - t["dh"][2]) if t["dh"] is not None else 1.0           # dropped hidden units are the zeros of the saved h
-    dz = ops.bias_act_bwd(dh, t["h"], st.g32(f"{p}.w_1.bias"), R=R, N=U, n_valid=U, ld=U, relu=True, gscale=gs, defer=_defer_list(model))
+    if FFN_DGRAD_FUSED and U % 64 == 0 and model.use_tr:
+        # (round 6) relu' / the dropout mask and the bias gradient's partial rows in the epilogue of w_2's data gradient: one launch fewer
+        # per feed-forward block in the main stream's chain, two passes over [R, U] fewer
+        _lin_bwd(model, st, f"{p}.w_2", t["h"], dys, R, U, D, need_dx=False)
+        dz, (part, tiles) = ops.linear_dgrad_relu(dys, st.t16(f"{p}.w_2.weight"), rows=R, N=D, K=U, dy_pitch=D, y=t["h"], gscale=gs)
+        dl, gb = _defer_list(model), st.g32(f"{p}.w_1.bias")
+        if dl is not None:
+            dl.append((ops._deferred_colsum(part, tiles, 2 * U, gb, U), part))
+        else:
+            ops.colsum_rows(part, tiles, 2 * U, gb, U)
+    else:
+        dh = _lin_bwd(model, st, f"{p}.w_2", t["h"], dys, R, U, D)
+        dz = ops.bias_act_bwd(dh, t["h"], st.g32(f"{p}.w_1.bias"), R=R, N=U, n_valid=U, ld=U, relu=True, gscale=gs, defer=_defer_list(model))
     dtn = _lin_bwd(model, st, f"{p}.w_1", t["tn"], dz, R, D, U, bias=False)
     return _ln_bwd(model, st, dtn, t["x"], norm, t["m"], t["r"], addend=dy, branch=branch)
 

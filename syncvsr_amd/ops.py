@@ -775,6 +775,30 @@ def linear_dgrad_bn(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, 
     return g, (stats, plan.tiles)
 
 
+_CONST_VECS: dict = {}
+
+
+def linear_dgrad_relu(dy: torch.Tensor, w16t: torch.Tensor, *, rows: int, N: int, K: int, dy_pitch: int, y: torch.Tensor, gscale: float = 1.0):
+    """linear_dgrad for a layer whose input was y = dropout(relu(z)) [rows, K]: the launch stores dz = (y > 0 ? gscale * dgrad : 0) and the column
+    sums of dz per row tile (svsr_igemm_dgrad_relu) -> (dz, (stats, tiles)): colsum_rows(stats, tiles, 2 * K, db, K) is the bias gradient of
+    the layer that produced z."""
+    Np = w16t.shape[-1]
+    if y.shape != (rows, K) or not y.is_contiguous():
+        raise ValueError("linear_dgrad_relu: y must be a contiguous [rows, K] tensor")
+    key = (str(dy.device), K)
+    cv = _CONST_VECS.get(key)
+    if cv is None:
+        import numpy as np          # (host arrays + copies: made once, also inside a recorded step — no fill kernel for the recorder to miss)
+
+        cv = _CONST_VECS[key] = tuple(torch.from_numpy(np.full(K, v, dtype=np.float32)).to(dy.device) for v in (0.0, 1.0))
+    dz = torch.empty((rows, K), dtype=BF16, device=dy.device)
+    plan = rows_plan(rows, 1, 0, 0, K)
+    stats = torch.empty(plan.tiles * 2 * K, dtype=torch.float32, device=dy.device)      # (a buffer of its own: its sum may run later, on another stream)
+    _call("svsr_igemm_dgrad_relu", _p(dy), _p(w16t), _p(dz), _p(stats), plan.words.data_ptr(), plan.meta, rows, 1, Np, dy_pitch, K, 1, K, 1,
+          _p(y), _p(cv[0]), _p(cv[1]), float(gscale), _stream(), label=plan.label + "+relu", flops=2.0 * rows * N * K)
+    return dz, (stats, plan.tiles)
+
+
 def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, rows: int, K: int, N: int, x_pitch: int, dy_pitch: int,
                  seq: Optional[tuple[int, int, int]] = None, use_tr: bool = True, db: Optional[torch.Tensor] = None) -> None:
     """dw fp32 [N][K] += dy[rows, N]^T @ x[rows, K];  db fp32 [N] += column sums of dy (bias gradient), if given.

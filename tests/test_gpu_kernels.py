@@ -421,6 +421,34 @@ def test_linear_dgrad_with_swish_bn_backward_epilogue(dev):
     check(db, s1, "linear_dgrad_bn.dbeta", 1e-2, 6e-3)
 
 
+@pytest.mark.parametrize("R,D,U,pdrop", [(2400, 768, 2048, 0.1), (704, 768, 2048, 0.0), (130, 256, 512, 0.25)])
+def test_linear_dgrad_with_relu_dropout_epilogue(dev, R, D, U, pdrop):
+    """ops.linear_dgrad_relu (feed-forward block: w_2's data gradient through dropout(relu(z)), positionwise_feed_forward.py:28-30) against
+    autograd in fp32 and against the two launches it replaces (linear_dgrad + bias_act_bwd)."""
+    from syncvsr_amd import ops
+
+    dy = rnd((R, D), 3)
+    w2 = rnd((D, U), 4, 1.0 / math.sqrt(U))           # [N out = D][K in = U]
+    wt = w2.t().contiguous().view(U, 1, D)            # transposed shadow [K][1][N]
+    g_ = torch.Generator().manual_seed(11)
+    z = torch.randn(R, U, generator=g_)
+    keep = (torch.rand(R, U, generator=g_) >= pdrop).float()
+    gs = 1.0 / (1.0 - pdrop)
+    h = (torch.relu(z) * keep * gs).to(BF)            # the saved activation: zero where ReLU or the mask cut
+    dref = (dy.float() @ w2.float()) * (h.float() > 0).float() * gs
+    dz, (part, tiles) = ops.linear_dgrad_relu(dy.to(dev), wt.to(dev), rows=R, N=D, K=U, dy_pitch=D, y=h.to(dev), gscale=gs)
+    check(dz, dref, "linear_dgrad_relu.dz", 2e-2, 8e-3)
+    db = torch.zeros(U, device=dev)
+    ops.colsum_rows(part, tiles, 2 * U, db, U)
+    check(db, dref.sum(0), "linear_dgrad_relu.dbias", 1e-2, 2e-2)
+    # the pair of launches it replaces: same dz bit for bit (both round the data gradient to bf16, then the product)
+    dh = ops.linear_dgrad(dy.to(dev), wt.to(dev), rows=R, N=D, K=U, dy_pitch=D)
+    db2 = torch.zeros(U, device=dev)
+    dz2 = ops.bias_act_bwd(dh, h.to(dev), db2, R=R, N=U, n_valid=U, ld=U, relu=True, gscale=gs)
+    assert torch.equal(dz, dz2)
+    check(db, db2.float().cpu(), "linear_dgrad_relu.dbias vs bias_act_bwd", 4e-3, 4e-3)      # (sums of the rounded values here, of the unrounded products there)
+
+
 @pytest.mark.parametrize("Hc,Wc", [(12, 12), (11, 9), (44, 44)])
 def test_stem_bn_gelu_pool(dev, Hc, Wc):
     from syncvsr_amd import ops
