@@ -616,11 +616,20 @@ def _frontend_forward(model, st: "_ParamStore", tape: dict, videos: torch.Tensor
     tape["stem"] = dict(videos=videos, c=c, amax=amax, xwin=xwin, mean=mean, rstd=rstd, pooled_shape=tuple(x.shape))
     for prefix, inp, planes, stride, down in _trunk_blocks(model):
         xin = x
-        o1 = _conv_bn(st, tape, xin, f"{prefix}.conv1", f"{prefix}.bn1", 3, stride, 1, training, None, act)
-        if down:
-            idt = _conv_bn(st, tape, xin, f"{prefix}.downsample.0", f"{prefix}.downsample.1", 1, stride, 0, training, None, 0)
+        if down and training and model._side.enabled and DOWN_ON_SIDE:
+            # (round 6) the downsample branch (1x1 convolution, its statistics and apply pass) meets the main branch only at the residual sum: on the
+            # side stream beside conv1 / bn1 (3 blocks x 3 launches off the main chain: -0.035 ms LRW same box, LRS unchanged; the backward
+            # twin measured SLOWER — its join waits for the weight gradients queued on that stream — and is not here)
+            box: dict = {}
+            model._side.run(lambda xin=xin, prefix=prefix, stride=stride: box.__setitem__(
+                "idt", _conv_bn(st, tape, xin, f"{prefix}.downsample.0", f"{prefix}.downsample.1", 1, stride, 0, training, None, 0)), xin)
+            model._side.flush()
+            o1 = _conv_bn(st, tape, xin, f"{prefix}.conv1", f"{prefix}.bn1", 3, stride, 1, training, None, act)
+            model._side.join()
+            idt = box["idt"]
         else:
-            idt = xin
+            o1 = _conv_bn(st, tape, xin, f"{prefix}.conv1", f"{prefix}.bn1", 3, stride, 1, training, None, act)
+            idt = _conv_bn(st, tape, xin, f"{prefix}.downsample.0", f"{prefix}.downsample.1", 1, stride, 0, training, None, 0) if down else xin
         x = _conv_bn(st, tape, o1, f"{prefix}.conv2", f"{prefix}.bn2", 3, 1, 1, training, idt, act)
     tape["trunk_out_shape"] = tuple(x.shape)
     return ops.avgpool_fwd(x)            # [N, 512] bf16
@@ -743,6 +752,7 @@ def _lin_wgrad(model, x, dy, gw, gb, rows: int, K: int, N: int, x_pitch: int, dy
     model._side.run(lambda: ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=x_pitch, dy_pitch=dy_pitch, db=gb), x, dy, small=True)
 
 
+DOWN_ON_SIDE = os.environ.get("SVSR_DOWN_ON_SIDE", "1") != "0"      # _frontend_forward: a block's downsample branch (1x1 convolution + its BatchNorm) on the side stream beside conv1 / bn1
 METRICS_ON_SIDE = os.environ.get("SVSR_METRICS_ON_SIDE", "1") != "0"      # train_step_direct: accuracy and loss_total (read by the caller only) on the side stream
 DEFER_REDUCTIONS = os.environ.get("SVSR_DEFER_REDUCTIONS", "1") != "0"     # encoder backward: parameter-gradient reductions on the side stream
 
