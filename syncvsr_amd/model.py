@@ -752,6 +752,7 @@ def _lin_wgrad(model, x, dy, gw, gb, rows: int, K: int, N: int, x_pitch: int, dy
     model._side.run(lambda: ops.linear_wgrad(x, dy, gw, rows=rows, K=K, N=N, x_pitch=x_pitch, dy_pitch=dy_pitch, db=gb), x, dy, small=True)
 
 
+HEADS_CONCURRENT = os.environ.get("SVSR_HEADS_CONCURRENT", "1") != "0"      # train_step_direct: the word head (forward and backward) on the side stream beside the audio head
 DOWN_ON_SIDE = os.environ.get("SVSR_DOWN_ON_SIDE", "1") != "0"      # _frontend_forward: a block's downsample branch (1x1 convolution + its BatchNorm) on the side stream beside conv1 / bn1
 METRICS_ON_SIDE = os.environ.get("SVSR_METRICS_ON_SIDE", "1") != "0"      # train_step_direct: accuracy and loss_total (read by the caller only) on the side stream
 DEFER_REDUCTIONS = os.environ.get("SVSR_DEFER_REDUCTIONS", "1") != "0"     # encoder backward: parameter-gradient reductions on the side stream
@@ -1105,12 +1106,28 @@ class _LrwFunction(torch.autograd.Function):
             h = _encoder_forward(model, st, tape, feats, B, T)          # [B*S, D] bf16
         # word head: rows s = 0
         C = model.word_labels
-        logits_c, _ = ops.linear_fwd(h, st.s16("category_classifier.weight"), st.p32("category_classifier.bias"), rows=B, K=D, N=C,
-                                     x_pitch=D, out_f32=True, seq=(S, 0, 1))
         hard = labels.dtype in (torch.int64, torch.int32)
         lab_idx = labels.long() if hard else None
         lab_prob = None if hard else labels.float().contiguous()
-        loss_c, lse_c = ops.ce_fwd(logits_c, C, lab_idx, lab_prob, B, C, model.label_smoothing)
+        # (round 6) inside TrainStep the word head (classifier, its loss, the metric — and in the backward its loss gradient and data gradient) is a
+        # branch of its own between the two encoder launches, of 1-8 workgroups per launch: it runs on the side stream beside the audio head
+        side_heads = bool(getattr(model, "_metrics_on_side", False) and model._side.enabled and HEADS_CONCURRENT and need_grad
+                          and ops.WGRAD_GROUP and model.encoder_type == "huggingface")       # (the heads' weight gradients then follow on the side stream too)
+        hb: dict = {}
+
+        def word_head():
+            hb["logits_c"], _ = ops.linear_fwd(h, st.s16("category_classifier.weight"), st.p32("category_classifier.bias"), rows=B, K=D, N=C,
+                                               x_pitch=D, out_f32=True, seq=(S, 0, 1))
+            hb["loss_c"], hb["lse_c"] = ops.ce_fwd(hb["logits_c"], C, lab_idx, lab_prob, B, C, model.label_smoothing)
+            if side_heads:
+                hb["acc"] = ops.topk_acc(hb["logits_c"], lab_idx, lab_prob)
+
+        if side_heads:
+            model._side.run(word_head, h)
+            model._side.flush()
+        else:
+            word_head()
+        logits_c, loss_c, lse_c = hb["logits_c"], hb["loss_c"], hb["lse_c"]
         # audio head: rows s = 1..T, logits [B*T, A*G*V] == [B*T*A*G, V]
         NA = A * G * V
         tok = audio_tokens.reshape(-1)
@@ -1124,7 +1141,9 @@ class _LrwFunction(torch.autograd.Function):
             loss_a, lse_a = ops.linear_ce_fwd(h, st.s16("audio_projection.weight"), st.p32("audio_projection.bias"), tok, B * T, D, A * G, V, seq=(S, 1, T))
         else:
             loss_a, lse_a = ops.ce_fwd(logits_a, V, tok, None, B * T * A * G, V, 0.0)
-        if getattr(model, "_metrics_on_side", False) and model._side.enabled and METRICS_ON_SIDE:
+        if side_heads:
+            acc = hb["acc"]
+        elif getattr(model, "_metrics_on_side", False) and model._side.enabled and METRICS_ON_SIDE:
             # (round 6) inside TrainStep the metric is read when the step is over: its two launches leave the main stream's chain (the
             # side stream is joined at the end of the backward)
             box: dict = {}
@@ -1136,7 +1155,7 @@ class _LrwFunction(torch.autograd.Function):
         model._last = dict(logits_category=logits_c, logits_audio=logits_a, feats=feats, hidden=h)
         if need_grad:
             tape["head"] = dict(h=h, logits_c=logits_c, lse_c=lse_c, lab_idx=lab_idx, lab_prob=lab_prob, logits_a=None if fused_head else logits_a,
-                                lse_a=lse_a, tok=tok, dims=(B, T, D, S, A, G, V, C))
+                                lse_a=lse_a, tok=tok, dims=(B, T, D, S, A, G, V, C), side_heads=side_heads)
             ctx.tape = tape
             ctx.model = model
             ctx.st = st
@@ -1157,14 +1176,28 @@ class _LrwFunction(torch.autograd.Function):
         g_audio = (g_audio if g_audio is not None else torch.zeros((), device=dev)).float().contiguous()
         NA = A * G * V
         Cp = (C + 63) // 64 * 64
+        dlc = torch.empty((B, Cp), dtype=BF16, device=dev)          # (svsr_ce_bwd writes the pad columns C .. Cp - 1 as zeros)
+        dh = torch.empty((B * S, D), dtype=BF16, device=dev)
+        side_heads = bool(th.get("side_heads")) and model._side.enabled
+        if th.get("side_heads") and not side_heads:
+            model._side.join()          # (the forward's half of the branch ran there)
+
+        def word_head_bwd():
+            ops.ce_bwd(th["logits_c"], C, th["lab_idx"], th["lab_prob"], B, C, model.label_smoothing, th["lse_c"], g_cat, dlc, Cp)
+            if side_heads:      # (rows s = 0 of dh; the audio head's data gradient below writes rows 1..T)
+                ops.linear_dgrad(dlc, st.t16("category_classifier.weight"), rows=B, N=C, K=D, dy_pitch=Cp, out=dh, seq=(S, 0, 1))
+
+        if side_heads:
+            model._side.run(word_head_bwd, dlc, dh, g_cat)
+            model._side.flush()
+        else:
+            word_head_bwd()
         dla = torch.empty((B * T, NA), dtype=BF16, device=dev)
         if th["logits_a"] is None:        # fused head: the logits are recomputed, dla = g / (B T A G) * (softmax - onehot)
             ops.linear_ce_bwd(th["h"], st.s16("audio_projection.weight"), st.p32("audio_projection.bias"), th["tok"], B * T, D, A * G, V, th["lse_a"],
                               g_audio, dla, seq=(S, 1, T))
         else:
             ops.ce_bwd(th["logits_a"], V, th["tok"], None, B * T * A * G, V, 0.0, th["lse_a"], g_audio, dla, V)
-        dlc = torch.empty((B, Cp), dtype=BF16, device=dev)          # (svsr_ce_bwd writes the pad columns C .. Cp - 1 as zeros)
-        ops.ce_bwd(th["logits_c"], C, th["lab_idx"], th["lab_prob"], B, C, model.label_smoothing, th["lse_c"], g_cat, dlc, Cp)
         h = th["h"]
         grouped = ops.WGRAD_GROUP and model.encoder_type == "huggingface"
         model._wg_group = [] if grouped else None
@@ -1176,9 +1209,11 @@ class _LrwFunction(torch.autograd.Function):
             else:
                 ops.linear_wgrad(q["x"], q["dy"], q["dw"], rows=q["rows"], K=q["K"], N=q["N"], x_pitch=q["x_pitch"], dy_pitch=q["dy_pitch"], seq=q["seq"],
                                  use_tr=use_tr, db=q["db"])
-        dh = torch.empty((B * S, D), dtype=BF16, device=dev)
         ops.linear_dgrad(dla, st.t16("audio_projection.weight"), rows=B * T, N=NA, K=D, dy_pitch=NA, out=dh, seq=(S, 1, T))
-        ops.linear_dgrad(dlc, st.t16("category_classifier.weight"), rows=B, N=C, K=D, dy_pitch=Cp, out=dh, seq=(S, 0, 1))
+        if side_heads:
+            model._side.join()
+        else:
+            ops.linear_dgrad(dlc, st.t16("category_classifier.weight"), rows=B, N=C, K=D, dy_pitch=Cp, out=dh, seq=(S, 0, 1))
         if not grouped:
             _ready(model, st, "audio_projection.weight")
         if model.encoder_type == "x-transformers":
