@@ -33,6 +33,7 @@ class _SideStream:
         self.stream: Optional[torch.cuda.Stream] = None
         self.keep: list = []
         self.pending: list = []
+        self._flushing = False
         self.enabled = False     # set by engine.TrainStep
         # linear-layer weight gradients: neutral for the LRW encoder, a gain for the LRS linears (engine.TrainStep turns it on there)
         self.enabled_small = False
@@ -46,13 +47,17 @@ class _SideStream:
         if not (self.enabled or (small and self.enabled_small)):
             fn()
             return
+        if self._flushing:       # called from inside a function that is being issued on the side stream: issue it there, now, in order
+            self.keep.extend(keep)
+            fn()
+            return
         self.pending.append(fn)
         self.keep.extend(keep)
         if len(self.pending) >= self.group:
             self.flush()
 
     def flush(self) -> None:
-        if not self.pending:
+        if not self.pending or self._flushing:
             return
         if self.stream is None:
             self.stream = torch.cuda.Stream()
@@ -60,10 +65,12 @@ class _SideStream:
         # launches go to the side stream through ops.STREAM_OVERRIDE (they allocate nothing on the device), which is
         # much cheaper on the host than entering a torch.cuda.stream() context per weight-gradient launch
         ops.STREAM_OVERRIDE = self.stream.cuda_stream
+        self._flushing = True
         try:
             for fn in self.pending:
                 fn()
         finally:
+            self._flushing = False
             ops.STREAM_OVERRIDE = None
             self.pending.clear()
 
