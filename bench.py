@@ -421,7 +421,7 @@ def main() -> None:
     ap.add_argument("--lrs-steps", type=int, default=8, help="timed steps of the LRS leg attached to the default line")
     ap.add_argument("--no-lrs-leg", action="store_true", help="skip the LRS leg of the default (LRW, one GPU) run")
     ap.add_argument("--no-lrs400", action="store_true", help="skip the <= 400-frame timing inside the LRS leg")
-    ap.add_argument("--sustained-steps", type=int, default=400, help="back-to-back LRW steps of the `sustained` leg behind the headline region (0: skip)")
+    ap.add_argument("--sustained-steps", type=int, default=1600, help="back-to-back LRW steps of the `sustained` leg behind the headline region (0: skip); the default is ~8 s of GPU time, long enough for a 5-s utilisation sampler around the run to see it")
     ap.add_argument("--ablate", default="", help="TIMING EXPERIMENTS ONLY (gradients wrong, the line is marked invalid): comma list of conv_wgrad, lin_wgrad — "
                     "those launches are skipped (how much of the step do they cost?)")
     ap.add_argument("--dropout", type=float, default=0.1, help="LRS: dropout_rate = transformer_attn_dropout_rate (config/lrs3.yaml:20-21)")
