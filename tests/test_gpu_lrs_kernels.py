@@ -143,6 +143,72 @@ def test_flash_attention_draws_the_same_dropout_masks_as_the_per_tile_kernels(re
         assert _rel_err(res[True][2], res[False][2]) < 2e-2
 
 
+@pytest.mark.parametrize("T", [75, 160])
+def test_flash_attention_backward_in_parts_and_with_the_table_made_ahead_equals_the_single_call(T):
+    """svsr_mha_flash_bwd_parts (query + key passes, then the position-table pass as a call of its own — on ANOTHER stream behind an event, as the
+    sentence-level model issues it) and svsr_mha_pe_transpose (the transposed position table made ahead of time) against svsr_mha_flash_bwd:
+    dq / dk / dv, dq_ac, dq_bd and dpe bit for bit."""
+    from syncvsr_amd import ops
+    dev = _dev()
+    B, H = 2, 3
+    D = H * 64
+    qkv = _r(B * T, 3 * D, seed=1).to(BF).to(dev)
+    pe = _r(2 * T - 1, D, seed=2).to(BF).to(dev)
+    u = _r(H, 64, seed=3, scale=0.5).to(dev).contiguous()
+    v = _r(H, 64, seed=4, scale=0.5).to(dev).contiguous()
+    dctx = _r(B * T, D, seed=5).to(BF).to(dev)
+    klen = torch.tensor([T, T - 35], dtype=torch.int32, device=dev)
+    seed = torch.tensor([777], dtype=torch.int32, device=dev)
+    drop = (seed, 5, 0.2)
+    ctx, rec = ops.mha_fwd(qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, B=B, H=H, Lq=T, Lk=T, pe=pe, bias_u=u, bias_v=v, klen=klen, drop=drop, flash=True)
+
+    def bwd(**kw):
+        dqkv = torch.zeros_like(qkv)
+        out = ops.mha_bwd(dctx, qkv, 3 * D, qkv[:, D:], qkv[:, 2 * D:], 3 * D, rec, B=B, H=H, Lq=T, Lk=T, dq=dqkv, dq_pitch=3 * D, dk=dqkv[:, D:],
+                          dv=dqkv[:, 2 * D:], dkv_pitch=3 * D, pe=pe, bias_u=u, bias_v=v, drop=drop, **kw)
+        return dqkv, out
+
+    dq0, (ac0, bd0, dpe0) = bwd()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    pet = ops.mha_pe_transpose(pe, H, T)
+    dq1, out1 = bwd(pe_later=True, pet=pet)
+    assert len(out1) == 4
+    ops.stream_wait(side, torch.cuda.current_stream())
+    ops.STREAM_OVERRIDE = side.cuda_stream
+    try:
+        out1[3][0]()                         # the position-table pass, on the other stream
+    finally:
+        ops.STREAM_OVERRIDE = None
+    torch.cuda.synchronize()
+    for a, b, name in ((dq1, dq0, "dqkv"), (out1[0], ac0, "dq_ac"), (out1[1], bd0, "dq_bd"), (out1[2], dpe0, "dpe")):
+        assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("B,T,D,K", [(2, 9, 128, 31), (2, 150, 768, 31)])
+def test_glu_dwconv_backward_in_parts_equals_the_single_call(B, T, D, K):
+    """svsr_glu_dwconv_bwd_parts: the pass over the activations, then the sum of the weight gradient's partial rows as a call of its own."""
+    from syncvsr_amd import ops
+    dev = _dev()
+    u = _r(B * T, 2 * D, seed=1).to(BF).to(dev)
+    w = _r(D, K, seed=2, scale=1 / math.sqrt(K)).to(dev)
+    dc = _r(B * T, D, seed=4).to(BF).to(dev)
+    res = []
+    for later in (False, True):
+        dw, db = torch.zeros(D, K, device=dev), torch.zeros(D, device=dev)
+        out = ops.glu_dwconv_bwd(dc, u, w, dw, db, B, T, D, K, reduce_later=later)
+        if later:
+            du, (fn, keep) = out
+            assert float(dw.abs().sum()) == 0.0          # nothing summed yet
+            fn()
+        else:
+            du = out
+        torch.cuda.synchronize()
+        res.append((du, dw, db))
+    for a, b, name in zip(res[1], res[0], ("du", "dw", "dbias")):
+        assert torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("B,T,D,K", [(2, 9, 128, 31), (3, 70, 128, 7), (2, 150, 768, 31)])
 def test_glu_dwconv(B, T, D, K):
     from syncvsr_amd import ops
